@@ -1,0 +1,265 @@
+/*
+ * fcp_hip.h — C ABI of libfcp_hip.so: the MI355X-native fused feature-column
+ * (embedding-column) inference path.
+ *
+ * This is the drop-in boundary for the three custom ops of the reference
+ * (AlibabaResearch/recom, paths relative to the reference root):
+ *
+ *   Addons>ConcatInputs                      custom_ops/concat_inputs/concat_inputs_ops.cc:42-88
+ *   Addons>FeatureColumnProcess[WithSymbols] custom_ops/feature_column_process/feature_column_process_op_gpu.cu.cc:65-175
+ *   Addons>ConcatOutputs[NoHost]             custom_ops/concat_outputs/concat_outputs_op_gpu.cu.cc:180-288
+ *
+ * and for the `extern "C"` entry points those ops dlsym from the JIT-compiled
+ * artifact today:
+ *
+ *   CreateConstBuffers      graph_optimizers/cuda_emitter.cc:2260-2301
+ *   ProcessFeatureColumns   graph_optimizers/cuda_emitter.cc:2303-2494 (decl feature_column_process_ops.h:37-43)
+ *   ConcatOutputs           custom_ops/concat_outputs/concat_outputs_op_gpu.cu.cc:133-140 (decl concat_outputs_ops.h:34)
+ *
+ * The reference entry points are C-named but C++-typed (std::vector,
+ * std::function, references).  Here everything is plain C: pointers, sizes,
+ * int status codes, function-pointer allocators.  No torch / TF / HIP types
+ * appear in any signature (a HIP stream is passed as an opaque pointer).
+ *
+ * What the reference generates as CUDA text per model (one `struct FCi` per
+ * feature column, cuda_emitter.cc:1976-2055) is described here by a static
+ * *column plan* (fcp_column_desc_t[]) that pre-compiled gfx950 kernels
+ * interpret.  No code generation and no runtime compiler are involved.
+ *
+ * Threading: a plan is immutable after creation; fcp_process_feature_columns
+ * and fcp_concat_outputs are re-entrant on a shared plan (the reference ops
+ * keep no per-call state in members either, SURVEY.md §8b "Threading").
+ * No entry point synchronises the stream: work is enqueued and the call
+ * returns (the reference blocks three times per request).
+ */
+#ifndef FCP_HIP_H_
+#define FCP_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FCP_ABI_VERSION 1
+
+/* ---- status codes (reference: void returns + CubDebugExit/exit(1)) ------ */
+enum {
+  FCP_OK = 0,
+  FCP_ERR_INVALID_ARGUMENT = 1, /* bad descriptor / null pointer / bad enum  */
+  FCP_ERR_SHAPE_MISMATCH = 2,   /* run-time shapes inconsistent with the plan */
+  FCP_ERR_ALLOC = 3,            /* an allocator callback returned NULL        */
+  FCP_ERR_HIP = 4,              /* a HIP runtime call failed                  */
+  FCP_ERR_UNSUPPORTED = 5,      /* valid but not implemented for this plan    */
+  FCP_ERR_NO_DEVICE = 6         /* no gfx950 device / code object not loadable*/
+};
+
+/* ---- column forms: the canonical per-column rewrites of the reference ---- */
+/* (lookup_optimizer.cc:157-440; emitter dispatch cuda_emitter.cc:1096-1152)  */
+enum {
+  /* GatherV2(table, ids): out[i,:] = W[ids[i],:]
+   * cuda_emitter.cc:250-293 (GatherRowsToGlbMem), driver :1246-1330 */
+  FCP_FORM_GATHER = 1,
+  /* SparseSegment{Sum,Mean}[WithNumSegments](table, ids, seg_ids, B)
+   * cuda_emitter.cc:402-501, :564-661 (dim<=20) and :768-962 (dim>20) */
+  FCP_FORM_SEGMENT_REDUCE = 2,
+  /* ScatterNd(rows, GatherV2(table, ids), [B,dim]): zero-fill, then
+   * out[rows[i],:] = W[ids[i],:]   cuda_emitter.cc:296-345, :1332-1442 */
+  FCP_FORM_GATHER_SCATTER = 3,
+  /* A tensor of the ConcatInputs blob copied straight into its concat slot
+   * (ConcatOutputs `host_inputs`, concat_outputs_op_gpu.cu.cc:186-216) */
+  FCP_FORM_PASSTHROUGH = 4,
+  /* Sum(x, axis=1) on a rank-3 [B,R,C] tensor of the blob
+   * cuda_emitter.cc:1180-1244 (BatchColReduction) */
+  FCP_FORM_BATCH_COL_REDUCTION = 5
+};
+
+enum { FCP_COMBINER_NONE = 0, FCP_COMBINER_SUM = 1, FCP_COMBINER_MEAN = 2 };
+
+/* How the id stream of a column is stored in the blob (what EmitInputInline
+ * folds into the index expression, cuda_emitter.cc:1769-1949). */
+enum {
+  FCP_IDS_I32 = 0,           /* int32 ids                                    */
+  FCP_IDS_I64 = 1,           /* int64 ids (reference truncates to int, :270) */
+  FCP_IDS_F32_BUCKETIZE = 2  /* float32 values -> Bucketize(boundaries), :233-247, :1798-1835 */
+};
+
+/* How segment membership of the id stream is given. */
+enum {
+  FCP_SEG_NONE = 0,     /* forms 1,4,5                                        */
+  FCP_SEG_IDS_I32 = 1,  /* sorted segment / row ids, element stride seg_stride */
+  FCP_SEG_IDS_I64 = 2,  /* e.g. SparseTensor indices[nnz,2] int64 with stride 2
+                           (inlined StridedSlice [:,0], cuda_emitter.cc:1836-1873) */
+  FCP_SEG_CSR_I32 = 3   /* CSR offsets int32[B+1] (what ComputeSegmentOffsets,
+                           cuda_emitter.cc:768-818, produces on the fly)      */
+};
+
+/* Where the number of output rows ("prefix size") of a column comes from. */
+enum {
+  FCP_ROWS_FROM_IDS = 0,    /* rows = number of elements of the ids tensor (form 1) */
+  FCP_ROWS_FROM_SYMBOL = 1, /* rows = symbols[rows_arg] (Addons>ShapeConstruct
+                               result, cuda_emitter.cc:2438-2455)             */
+  FCP_ROWS_FROM_INPUT_DIM0 = 2 /* rows = shape[0] of host input rows_arg       */
+};
+
+/* Output arena layouts. */
+enum {
+  /* One [rows, sum(dim)] row-major matrix per concat group; every column is
+   * written directly at its concat offset: ConcatOutputsKnl
+   * (concat_outputs_op_gpu.cu.cc:85-131) is fused away. */
+  FCP_LAYOUT_CONCAT = 0,
+  /* The reference arena: one contiguous [rows, dim] buffer per column, each
+   * 128-byte aligned (alignmem, cuda_emitter.cc:967-969, :2151-2179);
+   * fcp_concat_outputs then performs the reference's second pass. */
+  FCP_LAYOUT_PER_COLUMN = 1
+};
+
+enum {
+  FCP_FLAG_NONE = 0,
+  /* Count ids outside [0, vocab) into the plan's device error counter.  Such
+   * rows always read as zeros (TF-GPU GatherV2 semantics); the reference
+   * reads out of bounds. */
+  FCP_FLAG_COUNT_BAD_IDS = 1u << 0
+};
+
+typedef struct fcp_column_desc {
+  int32_t form;         /* FCP_FORM_*                                         */
+  int32_t combiner;     /* FCP_COMBINER_* (form 2)                            */
+  int32_t dim;          /* embedding width (table.shape[1]); form 4/5: width  */
+  int32_t id_source;    /* FCP_IDS_*                                          */
+  int64_t vocab;        /* table.shape[0]                                     */
+  int32_t table_input;  /* index into fcp_process_args_t.input_ptrs           */
+  int32_t ids_input;    /* host-input (blob tensor) index of ids / values /
+                           passthrough payload                                */
+  int32_t seg_input;    /* host-input index of seg ids / CSR offsets, or -1   */
+  int32_t seg_kind;     /* FCP_SEG_*                                          */
+  int32_t seg_stride;   /* element stride between consecutive seg ids (>=1)   */
+  int32_t rows_source;  /* FCP_ROWS_*                                         */
+  int32_t rows_arg;     /* symbol index / host-input index                    */
+  int32_t n_boundaries; /* FCP_IDS_F32_BUCKETIZE: number of boundaries        */
+  const float *boundaries; /* host pointer, copied at plan creation           */
+  int32_t concat_group; /* which ConcatV2 this column feeds, 0..n_groups-1    */
+  int32_t concat_slot;  /* position inside the group (ConcatOutputs
+                           device_concat_indices / host_concat_indices)       */
+} fcp_column_desc_t;
+
+typedef struct fcp_plan_desc {
+  int32_t abi_version;            /* FCP_ABI_VERSION                          */
+  int32_t n_columns;
+  const fcp_column_desc_t *columns;
+  int32_t n_host_inputs;          /* ConcatInputs attr T / ranks sizes        */
+  const int32_t *host_input_ranks;      /* attr "ranks"                       */
+  const int32_t *host_input_elem_sizes; /* DataTypeSize of attr "T" entries   */
+  int32_t n_device_inputs;        /* FeatureColumnProcess `inputs` (tables)   */
+  int32_t n_groups;               /* number of concat groups                  */
+  int32_t n_symbols;              /* length of the `symbols` host tensor      */
+  int32_t layout;                 /* FCP_LAYOUT_*                             */
+  int32_t device;                 /* HIP device ordinal                       */
+  int32_t shard_rank;             /* row sharding: this GPU owns ids with     */
+  int32_t shard_world;            /*   id % shard_world == shard_rank, local
+                                       row id / shard_world. 1 = unsharded.   */
+  uint32_t flags;                 /* FCP_FLAG_*                               */
+} fcp_plan_desc_t;
+
+typedef struct fcp_plan fcp_plan_t; /* opaque; owns const buffers on device  */
+
+/* Allocator callback: return device memory of `bytes` bytes (or NULL).
+ * Reference: std::function<void(void**,int)> malloc_temp / malloc_buff
+ * (feature_column_process_op_gpu.cu.cc:99-111).  The library never frees
+ * caller memory.  malloc_buff is called at most once per process call
+ * (it maps to allocate_output(2)). */
+typedef void *(*fcp_alloc_fn)(void *ctx, size_t bytes);
+
+typedef struct fcp_process_args {
+  const void *concated_inputs;     /* device: ConcatInputs blob (input 0)     */
+  int64_t concated_bytes;
+  const int32_t *concated_offsets; /* host int32[n_host_inputs]   (input 1)   */
+  const int32_t *concated_shapes;  /* host int32[sum ranks]       (input 2)   */
+  const void *const *input_ptrs;   /* host array of device table pointers     */
+  const int32_t *input_shapes;     /* host int32[2*n_device_inputs] or NULL   */
+  const int32_t *symbols;          /* host int32[n_symbols] or NULL           */
+  void *stream;                    /* hipStream_t                             */
+  fcp_alloc_fn malloc_temp;        /* may be NULL: plan-owned scratch is used */
+  void *malloc_temp_ctx;
+  fcp_alloc_fn malloc_buff;        /* required: allocates the output arena    */
+  void *malloc_buff_ctx;
+} fcp_process_args_t;
+
+typedef struct fcp_process_result {
+  void **output_ptrs;          /* host void*[n_columns]: device address of
+                                  element (0,0) of each column's output       */
+  int32_t *output_shapes;      /* host int32[2*n_columns]: rows, dim          */
+  int64_t *output_row_strides; /* host int64[n_columns]: row stride, elements */
+  void **group_ptrs;           /* host void*[n_groups]: concat matrices
+                                  (FCP_LAYOUT_CONCAT) or NULLs                */
+  int32_t *group_shapes;       /* host int32[2*n_groups]: rows, sum(dim)      */
+  void *buffer;                /* the arena returned by malloc_buff           */
+  int64_t buffer_bytes;
+} fcp_process_result_t;
+
+/* Plain view of a host tensor for fcp_concat_inputs. */
+typedef struct fcp_host_tensor {
+  const void *data;
+  int32_t elem_size;
+  int32_t rank;
+  const int64_t *dims;
+} fcp_host_tensor_t;
+
+/* ---- library ------------------------------------------------------------- */
+int fcp_abi_version(void);
+const char *fcp_status_string(int status);
+/* Last HIP error string seen by this thread ("" if none). */
+const char *fcp_last_error(void);
+
+/* ---- Addons>ConcatInputs (concat_inputs_ops.cc:42-77), host only --------- */
+/* Sizes of the three outputs for these inputs. */
+int fcp_concat_inputs_sizes(const fcp_host_tensor_t *inputs, int32_t n_inputs,
+                            int64_t *blob_bytes, int32_t *rank_sum);
+/* Pack: blob = byte concatenation, offsets[i] = byte offset of input i
+ * (int32, as the reference), shapes = all dims in order. */
+int fcp_concat_inputs(const fcp_host_tensor_t *inputs, int32_t n_inputs,
+                      void *blob, int64_t blob_capacity, int32_t *offsets,
+                      int32_t *shapes);
+
+/* ---- plan: replaces code generation + CreateConstBuffers ------------------ */
+int fcp_plan_create(const fcp_plan_desc_t *desc, fcp_plan_t **plan);
+int fcp_plan_destroy(fcp_plan_t *plan);
+/* Static facts: total concat width of a group (sum of dims in slot order)
+ * and the element offset of a column inside its group. */
+int fcp_plan_group_width(const fcp_plan_t *plan, int32_t group, int32_t *width);
+int fcp_plan_column_offset(const fcp_plan_t *plan, int32_t column,
+                           int32_t *offset);
+/* Arena bytes ProcessFeatureColumns will request for these run-time shapes
+ * (buffer_size_sum, cuda_emitter.cc:2151-2158). */
+int fcp_plan_arena_bytes(fcp_plan_t *plan, const int32_t *concated_shapes,
+                         const int32_t *symbols, int64_t *bytes);
+/* Device error counter (FCP_FLAG_COUNT_BAD_IDS); synchronises `stream`. */
+int fcp_plan_read_bad_ids(fcp_plan_t *plan, void *stream, int64_t *count);
+
+/* ---- ProcessFeatureColumns (cuda_emitter.cc:2303-2494) ------------------- */
+int fcp_process_feature_columns(fcp_plan_t *plan,
+                                const fcp_process_args_t *args,
+                                fcp_process_result_t *result);
+
+/* ---- ConcatOutputs (concat_outputs_op_gpu.cu.cc:85-140) ------------------ */
+/* out[p, off_k : off_k + dims[k]] = inputs[k][p*dims[k] ...] for k < n.
+ * `inputs` is a HOST array of device pointers; the pointer table is passed to
+ * the kernel without a separate H2D copy when n is small.  elem_size 4 only
+ * (reference registers float and int, :250-251). */
+int fcp_concat_outputs(const void *const *inputs, const int32_t *dims,
+                       int32_t n, int64_t prefix_size, void *out, void *stream);
+
+/* ---- multi-GPU finalize (no reference counterpart) --------- */
+/* After the all-to-all of per-rank partial sums: out = sum over `world`
+ * slices in rank order; for MEAN columns divide by the segment length read
+ * from the same blob.  partial_slices: device [world, rows, width]. */
+int fcp_shard_finalize(fcp_plan_t *plan, const fcp_process_args_t *args,
+                       int32_t group, const void *partial_slices,
+                       int32_t world, int64_t row_begin, int64_t row_count,
+                       void *out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FCP_HIP_H_ */

@@ -1,0 +1,504 @@
+/*
+ * fcp_oracle.c — plain-C CPU restatement of the reference's fused
+ * feature-column path (AlibabaResearch/recom).  TEST INFRASTRUCTURE ONLY — see
+ * fcp_oracle.h for who may use it and for the parity-pinning statement.
+ *
+ * Every function cites the reference file:line it restates (paths relative to
+ * the reference root, tensorflow_addons/ prefix dropped where unambiguous).
+ * Integer / index / copy work is restated exactly; floating-point pooling uses
+ * sequential fp32 accumulation in id order (the order of the reference-owned
+ * plain-C++ segment mean, custom_ops/extended_sparse_segment_reduce/
+ * extended_sparse_segment_reduce_ops.cc:53-107, and of TF-CPU's
+ * SparseSegmentReduction functor), NOT the CUB block-scan tree order of the
+ * generated CUDA (graph_optimizers/cuda_emitter.cc:452-455), which cannot be
+ * pinned without CUB 1.8 and is only tolerance-comparable anyway.
+ *
+ * Build: gcc -O2 -fPIC -shared [-fopenmp] fcp_oracle.c -o libfcp_oracle.so
+ * (no -ffast-math, no FMA contraction: additions and one division only).
+ */
+#include "fcp_oracle.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* --------------------------------------------------------------------------
+ * a5 — Bucketize.  graph_optimizers/cuda_emitter.cc:233-247: binary search,
+ * returns r+1 = number of boundaries <= value (upper bound; TF Bucketize).
+ * NaN compares false with `<`, so it walks right and lands in bucket n, as the
+ * generated code does.
+ * ------------------------------------------------------------------------ */
+int32_t orc_bucketize(const float *boundaries, int32_t n, float value) {
+  int32_t l = 0, r = n - 1;
+  while (l <= r) {
+    int32_t mid = (l + r) >> 1;
+    if (value < boundaries[mid]) {
+      r = mid - 1;
+    } else {
+      l = mid + 1;
+    }
+  }
+  return r + 1;
+}
+
+void orc_bucketize_array(const float *boundaries, int32_t n, const float *values,
+                         int64_t count, int32_t *out) {
+  for (int64_t i = 0; i < count; ++i) out[i] = orc_bucketize(boundaries, n, values[i]);
+}
+
+/* --------------------------------------------------------------------------
+ * a1 — ConcatInputs.  custom_ops/concat_inputs/concat_inputs_ops.cc:42-77:
+ * offsets[i] = running byte size (int32), shapes = all dims in order, blob =
+ * byte concatenation (mempcpy per input, :74).  Returns total bytes.
+ * ------------------------------------------------------------------------ */
+int64_t orc_concat_inputs(const void *const *datas, const int64_t *nbytes,
+                          const int32_t *ranks, const int64_t *const *dims,
+                          int32_t n, int8_t *blob, int32_t *offsets,
+                          int32_t *shapes) {
+  int64_t size = 0;
+  int32_t *shape_itr = shapes;
+  for (int32_t i = 0; i < n; ++i) {
+    offsets[i] = (int32_t)size;
+    size += nbytes[i];
+    for (int32_t j = 0; j < ranks[i]; ++j) *(shape_itr++) = (int32_t)dims[i][j];
+  }
+  if (blob) {
+    int8_t *itr = blob;
+    for (int32_t i = 0; i < n; ++i) {
+      if (nbytes[i]) memcpy(itr, datas[i], (size_t)nbytes[i]);
+      itr += nbytes[i];
+    }
+  }
+  return size;
+}
+
+/* --------------------------------------------------------------------------
+ * a6 — GatherRows.  cuda_emitter.cc:250-293 (+ driver loop :1305-1327):
+ * out[i, :] = table[ids[i], :].  An id outside [0, vocab) is undefined in the
+ * reference (out-of-bounds read); here, as in the product, the row reads as
+ * zeros and is counted.
+ * ------------------------------------------------------------------------ */
+int64_t orc_gather_rows(const float *table, int64_t vocab, int32_t dim,
+                        const int64_t *ids, int64_t n, float *out,
+                        int64_t out_stride) {
+  int64_t bad = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    float *o = out + i * out_stride;
+    int64_t id = ids[i];
+    if (id < 0 || id >= vocab) {
+      memset(o, 0, sizeof(float) * (size_t)dim);
+      ++bad;
+    } else {
+      memcpy(o, table + id * dim, sizeof(float) * (size_t)dim);
+    }
+  }
+  return bad;
+}
+
+/* --------------------------------------------------------------------------
+ * a9 — GatherScatterRows.  cuda_emitter.cc:296-345; output pre-zeroed
+ * (:1351-1359); out[rows[i], :] = table[ids[i], :].  The matcher guarantees at
+ * most one id per row (lookup_optimizer.cc:150-155); if a row repeats, the
+ * reference races — here (and in the product) the highest i wins.
+ * ------------------------------------------------------------------------ */
+int64_t orc_gather_scatter_rows(const float *table, int64_t vocab, int32_t dim,
+                                const int64_t *ids, const int64_t *rows,
+                                int64_t n, int64_t num_rows, float *out,
+                                int64_t out_stride) {
+  int64_t bad = 0;
+  for (int64_t r = 0; r < num_rows; ++r)
+    memset(out + r * out_stride, 0, sizeof(float) * (size_t)dim);
+  for (int64_t i = 0; i < n; ++i) {
+    int64_t r = rows[i];
+    if (r < 0 || r >= num_rows) continue; /* TF ScatterNd-GPU drops bad rows */
+    float *o = out + r * out_stride;
+    int64_t id = ids[i];
+    if (id < 0 || id >= vocab) {
+      memset(o, 0, sizeof(float) * (size_t)dim);
+      ++bad;
+    } else {
+      memcpy(o, table + id * dim, sizeof(float) * (size_t)dim);
+    }
+  }
+  return bad;
+}
+
+/* --------------------------------------------------------------------------
+ * a8 — ComputeSegmentOffsets.  cuda_emitter.cc:768-818.  For sorted segment
+ * ids it writes offsets[id] = first position whose segment id >= id, for
+ * id in (seg[idx-1], seg[idx]] (inner loop :792-795), with seg[-1] = -1
+ * (:785) and seg[n] = num_segments (:786).  Result: CSR offsets[0..S].
+ * Ids >= num_segments are clamped into the tail (positions past the last
+ * valid segment belong to no output row), ids < 0 behave like segment 0's
+ * predecessor exactly as the reference's loop bounds do.
+ * ------------------------------------------------------------------------ */
+void orc_segment_offsets(const int64_t *seg_ids, int64_t n,
+                         int64_t num_segments, int32_t *offsets) {
+  int64_t prev = -1;
+  for (int64_t idx = 0; idx <= n; ++idx) {
+    int64_t cur = idx < n ? seg_ids[idx] : num_segments;
+    if (cur > num_segments) cur = num_segments;
+    for (int64_t id = prev + 1; id <= cur; ++id) {
+      if (id >= 0 && id <= num_segments) offsets[id] = (int32_t)idx;
+    }
+    if (cur > prev) prev = cur;
+  }
+}
+
+/* --------------------------------------------------------------------------
+ * a7 / a8 — SparseSegment{Sum,Mean}WithNumSegments.
+ *   dim <= 20: cuda_emitter.cc:402-501 (sum), :564-661 (mean; sum / counter,
+ *              :625), driver :1542-1618, arena pre-zeroed :1460-1475;
+ *   dim  > 20: cuda_emitter.cc:831-909 (mean: / float(end-begin), :903).
+ * Semantics restated: out[s,:] = sum_{i in [off[s], off[s+1])} W[ids[i],:],
+ * divided by the count for mean; a segment with no ids is all zeros (TF-CPU
+ * SparseSegment*WithNumSegments; the dim>20 template would produce 0/0 there,
+ * the dim<=20 one and TF produce 0 — the TF behaviour is the contract).
+ * ------------------------------------------------------------------------ */
+int64_t orc_sparse_segment_reduce(const float *table, int64_t vocab, int32_t dim,
+                                  const int64_t *ids, const int32_t *offsets,
+                                  int64_t num_segments, int32_t mean, float *out,
+                                  int64_t out_stride) {
+  int64_t bad = 0;
+  for (int64_t s = 0; s < num_segments; ++s) {
+    float *o = out + s * out_stride;
+    int32_t lo = offsets[s], hi = offsets[s + 1];
+    for (int32_t e = 0; e < dim; ++e) o[e] = 0.0f;
+    for (int32_t i = lo; i < hi; ++i) {
+      int64_t id = ids[i];
+      if (id < 0 || id >= vocab) {
+        ++bad;
+        continue;
+      }
+      const float *w = table + id * dim;
+      for (int32_t e = 0; e < dim; ++e) o[e] = o[e] + w[e];
+    }
+    if (mean && hi > lo) {
+      const float cnt = (float)(hi - lo);
+      for (int32_t e = 0; e < dim; ++e) o[e] = o[e] / cnt;
+    }
+  }
+  return bad;
+}
+
+/* a8 in the reference's own order: VBLOCK_DIM_Y = 8 `ty` lanes take rows
+ * begin+ty, begin+ty+8, ... (cuda_emitter.cc:868-883), then partial sums are
+ * combined by the stride loop :885-899 — (8+1)/2 = 4, 2, 1 — i.e.
+ * t[y] += t[y+stride] for y+stride < last_stride. */
+void orc_sparse_segment_reduce_ref8x8(const float *table, int32_t dim,
+                                      const int64_t *ids, const int32_t *offsets,
+                                      int64_t num_segments, int32_t mean,
+                                      float *out, int64_t out_stride) {
+  enum { Y = 8 };
+  float *part = (float *)malloc(sizeof(float) * Y * (size_t)dim);
+  for (int64_t s = 0; s < num_segments; ++s) {
+    int32_t lo = offsets[s], hi = offsets[s + 1];
+    for (int32_t k = 0; k < Y * dim; ++k) part[k] = 0.0f;
+    for (int32_t ty = 0; ty < Y; ++ty)
+      for (int32_t i = lo + ty; i < hi; i += Y) {
+        const float *w = table + ids[i] * dim;
+        for (int32_t e = 0; e < dim; ++e) part[ty * dim + e] += w[e];
+      }
+    for (int32_t stride = (Y + 1) / 2, last = Y; last != stride;
+         last = stride, stride = (stride + 1) / 2) {
+      for (int32_t ty = 0; ty + stride < last; ++ty)
+        for (int32_t e = 0; e < dim; ++e) part[ty * dim + e] += part[(ty + stride) * dim + e];
+    }
+    float *o = out + s * out_stride;
+    for (int32_t e = 0; e < dim; ++e)
+      o[e] = (mean && hi > lo) ? part[e] / (float)(hi - lo) : part[e];
+  }
+  free(part);
+}
+
+/* --------------------------------------------------------------------------
+ * a11 — BatchColReduction.  cuda_emitter.cc:1216-1241 (Sum(x, axis=1) on a
+ * rank-3 input): out[b,c] = sum_r x[b,r,c], r ascending (:1231-1236).
+ * ------------------------------------------------------------------------ */
+void orc_batch_col_reduction(const float *x, int64_t batch, int64_t rows,
+                             int64_t cols, float *out, int64_t out_stride) {
+  for (int64_t b = 0; b < batch; ++b)
+    for (int64_t c = 0; c < cols; ++c) {
+      float acc = 0.0f;
+      for (int64_t r = 0; r < rows; ++r) acc += x[(b * rows + r) * cols + c];
+      out[b * out_stride + c] = acc;
+    }
+}
+
+/* --------------------------------------------------------------------------
+ * a10 — ConcatOutputs.  custom_ops/concat_outputs/concat_outputs_op_gpu.cu.cc
+ * :85-99 (ScatterBlock): out[p*sum + off_k + e] = in_k[p*dim_k + e], off_k =
+ * prefix sum of dims (:74-79).
+ * ------------------------------------------------------------------------ */
+void orc_concat_outputs(const float *const *inputs, const int32_t *dims,
+                        int32_t n, int64_t prefix, float *out) {
+  int64_t sum = 0;
+  for (int32_t k = 0; k < n; ++k) sum += dims[k];
+  int64_t off = 0;
+  for (int32_t k = 0; k < n; ++k) {
+    for (int64_t p = 0; p < prefix; ++p)
+      memcpy(out + p * sum + off, inputs[k] + p * dims[k], sizeof(float) * (size_t)dims[k]);
+    off += dims[k];
+  }
+}
+
+/* ------------------------------ whole path ------------------------------- */
+
+static int64_t shape_offset(const orc_plan_t *p, int32_t input) {
+  int64_t o = 0;
+  for (int32_t i = 0; i < input; ++i) o += p->host_input_ranks[i];
+  return o;
+}
+
+static int64_t input_numel(const orc_plan_t *p, int32_t input, const int32_t *shapes) {
+  int64_t o = shape_offset(p, input), n = 1;
+  for (int32_t j = 0; j < p->host_input_ranks[input]; ++j) n *= shapes[o + j];
+  return n;
+}
+
+static int64_t column_rows(const orc_plan_t *p, const orc_column_t *c,
+                           const int32_t *shapes, const int32_t *symbols) {
+  switch (c->rows_source) {
+  case ORC_ROWS_FROM_IDS:
+    return input_numel(p, c->ids_input, shapes);
+  case ORC_ROWS_FROM_SYMBOL:
+    return symbols ? symbols[c->rows_arg] : -1;
+  case ORC_ROWS_FROM_INPUT_DIM0:
+    return shapes[shape_offset(p, c->rows_arg)];
+  default:
+    return -1;
+  }
+}
+
+int64_t orc_group_rows(const orc_plan_t *p, int32_t group, const int32_t *shapes,
+                       const int32_t *symbols) {
+  int64_t rows = -1;
+  for (int32_t k = 0; k < p->n_columns; ++k) {
+    if (p->columns[k].concat_group != group) continue;
+    int64_t r = column_rows(p, &p->columns[k], shapes, symbols);
+    if (r < 0 || (rows >= 0 && r != rows)) return -1;
+    rows = r;
+  }
+  return rows;
+}
+
+int32_t orc_group_width(const orc_plan_t *p, int32_t group) {
+  int32_t w = 0;
+  for (int32_t k = 0; k < p->n_columns; ++k)
+    if (p->columns[k].concat_group == group) w += p->columns[k].dim;
+  return w;
+}
+
+int32_t orc_column_offset(const orc_plan_t *p, int32_t column) {
+  const orc_column_t *c = &p->columns[column];
+  int32_t off = 0;
+  for (int32_t k = 0; k < p->n_columns; ++k)
+    if (p->columns[k].concat_group == c->concat_group &&
+        p->columns[k].concat_slot < c->concat_slot)
+      off += p->columns[k].dim;
+  return off;
+}
+
+/* Materialise the id stream of a column as int64 (the index expression the
+ * reference inlines: Cast :1788-1797, Bucketize :1798-1835). */
+static void load_ids(const orc_column_t *c, const int8_t *src, int64_t n, int64_t *ids) {
+  for (int64_t i = 0; i < n; ++i) {
+    if (c->id_source == ORC_IDS_I32) {
+      int32_t v;
+      memcpy(&v, src + 4 * i, 4);
+      ids[i] = v;
+    } else if (c->id_source == ORC_IDS_I64) {
+      int64_t v;
+      memcpy(&v, src + 8 * i, 8);
+      ids[i] = v;
+    } else {
+      float v;
+      memcpy(&v, src + 4 * i, 4);
+      ids[i] = orc_bucketize(c->boundaries, c->n_boundaries, v);
+    }
+  }
+}
+
+static void load_seg(const orc_column_t *c, const int8_t *src, int64_t n, int64_t *seg) {
+  for (int64_t i = 0; i < n; ++i) {
+    if (c->seg_kind == ORC_SEG_IDS_I32) {
+      int32_t v;
+      memcpy(&v, src + 4 * i * c->seg_stride, 4);
+      seg[i] = v;
+    } else {
+      int64_t v;
+      memcpy(&v, src + 8 * i * c->seg_stride, 8);
+      seg[i] = v;
+    }
+  }
+}
+
+/* Row sharding (no reference counterpart): this rank owns ids
+ * with id % world == rank, stored at local row id / world.  Non-owned ids
+ * contribute nothing; pooled columns emit partial SUMS (the mean division
+ * happens after the cross-rank reduction). */
+static void shard_ids(const orc_plan_t *p, int64_t *ids, int64_t n, int64_t vocab_global) {
+  if (p->shard_world <= 1) return;
+  for (int64_t i = 0; i < n; ++i) {
+    int64_t id = ids[i];
+    if (id < 0 || id >= vocab_global) continue; /* stays bad */
+    ids[i] = (id % p->shard_world == p->shard_rank) ? id / p->shard_world : INT64_MIN;
+  }
+}
+
+static int64_t process_column(const orc_plan_t *p, int32_t k, const int8_t *blob,
+                              const int32_t *offsets, const int32_t *shapes,
+                              const float *const *tables, const int32_t *symbols,
+                              float *const *group_out, const int32_t *widths,
+                              const int32_t *col_offs) {
+  const orc_column_t *c = &p->columns[k];
+  const int32_t width = widths[c->concat_group];
+  const int32_t off = col_offs[k];
+  const int64_t rows = column_rows(p, c, shapes, symbols);
+  float *out = group_out[c->concat_group] + off;
+  int64_t bad = 0;
+  const int sharded = p->shard_world > 1;
+  /* local vocab of the shard */
+  const int64_t vocab_local =
+      sharded ? (c->vocab - p->shard_rank + p->shard_world - 1) / p->shard_world : c->vocab;
+
+  if (sharded && p->shard_rank != 0 &&
+      (c->form == ORC_FORM_PASSTHROUGH || c->form == ORC_FORM_BATCH_COL_REDUCTION)) {
+    /* table-free columns are owned by rank 0; the others contribute zeros */
+    for (int64_t r = 0; r < rows; ++r) memset(out + r * width, 0, 4 * (size_t)c->dim);
+    return 0;
+  }
+  if (c->form == ORC_FORM_PASSTHROUGH) {
+    const int8_t *src = blob + offsets[c->ids_input];
+    for (int64_t r = 0; r < rows; ++r)
+      memcpy(out + r * width, src + 4 * r * c->dim, 4 * (size_t)c->dim);
+    return 0;
+  }
+  if (c->form == ORC_FORM_BATCH_COL_REDUCTION) {
+    const int64_t so = shape_offset(p, c->ids_input);
+    const int64_t R = shapes[so + 1];
+    float *x = (float *)malloc(sizeof(float) * (size_t)(rows * R * c->dim) + 4);
+    memcpy(x, blob + offsets[c->ids_input], sizeof(float) * (size_t)(rows * R * c->dim));
+    orc_batch_col_reduction(x, rows, R, c->dim, out, width);
+    free(x);
+    return 0;
+  }
+
+  const int64_t nnz = input_numel(p, c->ids_input, shapes);
+  int64_t *ids = (int64_t *)malloc(sizeof(int64_t) * (size_t)(nnz + 1));
+  load_ids(c, blob + offsets[c->ids_input], nnz, ids);
+  /* count globally-bad ids once, then map to the local shard */
+  if (sharded) {
+    for (int64_t i = 0; i < nnz; ++i)
+      if (ids[i] < 0 || ids[i] >= c->vocab) ++bad;
+    shard_ids(p, ids, nnz, c->vocab);
+  }
+  const float *table = tables[c->table_input];
+
+  if (c->form == ORC_FORM_GATHER) {
+    int64_t b = orc_gather_rows(table, vocab_local, c->dim, ids, nnz, out, width);
+    if (!sharded) bad += b;
+  } else {
+    int64_t *seg = NULL;
+    int32_t *offs = (int32_t *)malloc(sizeof(int32_t) * (size_t)(rows + 1));
+    if (c->seg_kind == ORC_SEG_CSR_I32) {
+      memcpy(offs, blob + offsets[c->seg_input], sizeof(int32_t) * (size_t)(rows + 1));
+    } else {
+      seg = (int64_t *)malloc(sizeof(int64_t) * (size_t)(nnz + 1));
+      load_seg(c, blob + offsets[c->seg_input], nnz, seg);
+      orc_segment_offsets(seg, nnz, rows, offs);
+    }
+    if (c->form == ORC_FORM_SEGMENT_REDUCE) {
+      const int32_t mean = (c->combiner == ORC_COMBINER_MEAN) && !sharded;
+      int64_t b = orc_sparse_segment_reduce(table, vocab_local, c->dim, ids, offs, rows, mean,
+                                            out, width);
+      if (!sharded) bad += b;
+    } else { /* ORC_FORM_GATHER_SCATTER */
+      if (seg) {
+        int64_t b = orc_gather_scatter_rows(table, vocab_local, c->dim, ids, seg, nnz, rows, out,
+                                            width);
+        if (!sharded) bad += b;
+      } else {
+        /* CSR form of "at most one id per row": last id of the row wins */
+        for (int64_t r = 0; r < rows; ++r) {
+          float *o = out + r * width;
+          memset(o, 0, 4 * (size_t)c->dim);
+          if (offs[r + 1] > offs[r]) {
+            int64_t id = ids[offs[r + 1] - 1];
+            if (id >= 0 && id < vocab_local)
+              memcpy(o, table + id * c->dim, 4 * (size_t)c->dim);
+            else if (!sharded)
+              ++bad;
+          }
+        }
+      }
+    }
+    free(seg);
+    free(offs);
+  }
+  free(ids);
+  return bad;
+}
+
+/* (group, slot)-ordered prefix sums of dims: O(n log n) once per call. */
+static const orc_plan_t *g_sort_plan; /* qsort has no context argument */
+static int cmp_group_slot(const void *a, const void *b) {
+  const orc_column_t *x = &g_sort_plan->columns[*(const int32_t *)a];
+  const orc_column_t *y = &g_sort_plan->columns[*(const int32_t *)b];
+  if (x->concat_group != y->concat_group) return x->concat_group < y->concat_group ? -1 : 1;
+  if (x->concat_slot != y->concat_slot) return x->concat_slot < y->concat_slot ? -1 : 1;
+  return 0;
+}
+
+static void layout_columns(const orc_plan_t *p, int32_t *widths, int32_t *col_offs) {
+  int32_t *order = (int32_t *)malloc(sizeof(int32_t) * (size_t)(p->n_columns + 1));
+  for (int32_t k = 0; k < p->n_columns; ++k) order[k] = k;
+#ifdef _OPENMP
+#pragma omp critical(orc_sort)
+#endif
+  {
+    g_sort_plan = p;
+    qsort(order, (size_t)p->n_columns, sizeof(int32_t), cmp_group_slot);
+  }
+  for (int32_t g = 0; g < p->n_groups; ++g) widths[g] = 0;
+  for (int32_t j = 0; j < p->n_columns; ++j) {
+    const orc_column_t *c = &p->columns[order[j]];
+    col_offs[order[j]] = widths[c->concat_group];
+    widths[c->concat_group] += c->dim;
+  }
+  free(order);
+}
+
+int64_t orc_process_feature_columns(const orc_plan_t *p, const int8_t *blob,
+                                    const int32_t *offsets, const int32_t *shapes,
+                                    const float *const *tables,
+                                    const int32_t *symbols, float *const *group_out,
+                                    int32_t n_threads) {
+  for (int32_t g = 0; g < p->n_groups; ++g)
+    if (orc_group_rows(p, g, shapes, symbols) < 0) return -1;
+  int32_t *widths = (int32_t *)malloc(sizeof(int32_t) * (size_t)(p->n_groups + 1));
+  int32_t *col_offs = (int32_t *)malloc(sizeof(int32_t) * (size_t)(p->n_columns + 1));
+  layout_columns(p, widths, col_offs);
+  int64_t bad = 0;
+#ifdef _OPENMP
+  if (n_threads > 1) {
+#pragma omp parallel for schedule(dynamic, 4) num_threads(n_threads) reduction(+ : bad)
+    for (int32_t k = 0; k < p->n_columns; ++k)
+      bad += process_column(p, k, blob, offsets, shapes, tables, symbols, group_out, widths,
+                            col_offs);
+    free(widths);
+    free(col_offs);
+    return bad;
+  }
+#endif
+  (void)n_threads;
+  for (int32_t k = 0; k < p->n_columns; ++k)
+    bad += process_column(p, k, blob, offsets, shapes, tables, symbols, group_out, widths,
+                          col_offs);
+  free(widths);
+  free(col_offs);
+  return bad;
+}

@@ -1,0 +1,124 @@
+/*
+ * fcp_oracle.h — CPU oracle for the fused feature-column path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under recom_amd/ may include, link, load
+ * or call this.  Allowed users: tests/, __graft_entry__.smoke(), and the
+ * cpu_baseline leg of bench.py.
+ *
+ * PARITY PINNING: the reference (AlibabaResearch/recom) ships no tests, golden
+ * vectors or fixtures for this path and its implementation
+ * cannot be built here (device code exists only as C++ string fragments that
+ * need TensorFlow 2.6.2 + SymEngine + nvcc + CUB 1.8 to assemble).  The oracle
+ * is therefore pinned against independent implementations of the same TF op
+ * semantics that ARE importable in the build container — PyTorch-CPU
+ * `embedding_bag` / `bucketize(right=True)` / `index_select` and a NumPy
+ * float64 restatement — through tests/test_oracle.py and the committed
+ * fixtures in tests/golden/.  Relative to the reference itself parity is
+ * "unpinned by reference-owned vectors" and DESIGN.md says so.
+ */
+#ifndef FCP_ORACLE_H_
+#define FCP_ORACLE_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Same numeric values as include/fcp_hip.h (kept separate on purpose). */
+enum { ORC_FORM_GATHER = 1, ORC_FORM_SEGMENT_REDUCE = 2, ORC_FORM_GATHER_SCATTER = 3,
+       ORC_FORM_PASSTHROUGH = 4, ORC_FORM_BATCH_COL_REDUCTION = 5 };
+enum { ORC_COMBINER_NONE = 0, ORC_COMBINER_SUM = 1, ORC_COMBINER_MEAN = 2 };
+enum { ORC_IDS_I32 = 0, ORC_IDS_I64 = 1, ORC_IDS_F32_BUCKETIZE = 2 };
+enum { ORC_SEG_NONE = 0, ORC_SEG_IDS_I32 = 1, ORC_SEG_IDS_I64 = 2, ORC_SEG_CSR_I32 = 3 };
+enum { ORC_ROWS_FROM_IDS = 0, ORC_ROWS_FROM_SYMBOL = 1, ORC_ROWS_FROM_INPUT_DIM0 = 2 };
+
+typedef struct orc_column {
+  int32_t form, combiner, dim, id_source;
+  int64_t vocab;
+  int32_t table_input, ids_input, seg_input, seg_kind, seg_stride;
+  int32_t rows_source, rows_arg;
+  int32_t n_boundaries;
+  const float *boundaries;
+  int32_t concat_group, concat_slot;
+} orc_column_t;
+
+typedef struct orc_plan {
+  int32_t n_columns;
+  const orc_column_t *columns;
+  int32_t n_host_inputs;
+  const int32_t *host_input_ranks;
+  const int32_t *host_input_elem_sizes;
+  int32_t n_groups;
+  int32_t shard_rank, shard_world;
+} orc_plan_t;
+
+/* a5  cuda_emitter.cc:233-247 */
+int32_t orc_bucketize(const float *boundaries, int32_t n, float value);
+void orc_bucketize_array(const float *boundaries, int32_t n, const float *values,
+                         int64_t count, int32_t *out);
+
+/* a1  custom_ops/concat_inputs/concat_inputs_ops.cc:42-77 */
+int64_t orc_concat_inputs(const void *const *datas, const int64_t *nbytes,
+                          const int32_t *ranks, const int64_t *const *dims,
+                          int32_t n, int8_t *blob, int32_t *offsets,
+                          int32_t *shapes);
+
+/* a6  cuda_emitter.cc:250-293, driver :1305-1327 */
+int64_t orc_gather_rows(const float *table, int64_t vocab, int32_t dim,
+                        const int64_t *ids, int64_t n, float *out,
+                        int64_t out_stride);
+
+/* a9  cuda_emitter.cc:296-345, zero-fill :1351-1359 */
+int64_t orc_gather_scatter_rows(const float *table, int64_t vocab, int32_t dim,
+                                const int64_t *ids, const int64_t *rows,
+                                int64_t n, int64_t num_rows, float *out,
+                                int64_t out_stride);
+
+/* a8  cuda_emitter.cc:768-818 (ComputeSegmentOffsets) */
+void orc_segment_offsets(const int64_t *seg_ids, int64_t n,
+                         int64_t num_segments, int32_t *offsets);
+
+/* a7/a8  cuda_emitter.cc:402-501, :564-661, :831-909.  Sequential fp32
+ * accumulation in id order; mean = sum / count (:625, :903); empty = 0. */
+int64_t orc_sparse_segment_reduce(const float *table, int64_t vocab, int32_t dim,
+                                  const int64_t *ids, const int32_t *offsets,
+                                  int64_t num_segments, int32_t mean, float *out,
+                                  int64_t out_stride);
+
+/* a8 in the reference's own summation order (8 `ty` lanes stride the rows of a
+ * segment, then an LDS pairwise tree, cuda_emitter.cc:868-906).  Used only to
+ * bound the fp32 reordering error against the sequential order. */
+void orc_sparse_segment_reduce_ref8x8(const float *table, int32_t dim,
+                                      const int64_t *ids, const int32_t *offsets,
+                                      int64_t num_segments, int32_t mean,
+                                      float *out, int64_t out_stride);
+
+/* a11 cuda_emitter.cc:1216-1241 */
+void orc_batch_col_reduction(const float *x, int64_t batch, int64_t rows,
+                             int64_t cols, float *out, int64_t out_stride);
+
+/* a10 concat_outputs_op_gpu.cu.cc:85-99 */
+void orc_concat_outputs(const float *const *inputs, const int32_t *dims,
+                        int32_t n, int64_t prefix, float *out);
+
+/* Whole path a2..a10: blob + tables -> one [rows_g, width_g] matrix per group.
+ * group_out[g] must hold rows_g*width_g floats.  Returns the number of ids
+ * outside [0,vocab) (their rows read as zeros), or -1 on a malformed plan.
+ * n_threads > 1 parallelises over columns with OpenMP (CPU baseline). */
+int64_t orc_process_feature_columns(const orc_plan_t *plan, const int8_t *blob,
+                                    const int32_t *offsets, const int32_t *shapes,
+                                    const float *const *tables,
+                                    const int32_t *symbols, float *const *group_out,
+                                    int32_t n_threads);
+
+/* Rows / width of a group for these run-time shapes (-1 on error). */
+int64_t orc_group_rows(const orc_plan_t *plan, int32_t group,
+                       const int32_t *shapes, const int32_t *symbols);
+int32_t orc_group_width(const orc_plan_t *plan, int32_t group);
+int32_t orc_column_offset(const orc_plan_t *plan, int32_t column);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,340 @@
+"""Python face of the CPU oracle.  TEST INFRASTRUCTURE ONLY.
+
+Allowed importers: ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py``.  Nothing under ``recom_amd/`` imports this.
+
+Two independent restatements live here:
+
+* :class:`COracle` — ctypes binding of ``libfcp_oracle.so`` (``fcp_oracle.c``,
+  plain C, every function cites the reference file:line it follows);
+* the ``np_*`` functions — a NumPy restatement of the same TF op semantics with
+  float64 accumulation ("truth") used to pin the C oracle, together with
+  PyTorch-CPU ``embedding_bag`` / ``bucketize`` in ``tests/test_oracle.py``.
+
+Parity pinning: see ``fcp_oracle.h`` — the reference owns no golden vectors for
+this path, so the pin is against these independent implementations and the
+committed fixtures in ``tests/golden/``.
+
+Plans are consumed as plain dicts (``PlanSpec.to_dict()``) so this module has no
+dependency on the product package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libfcp_oracle.so")
+
+
+def build(force: bool = False) -> str:
+    """Compile the C oracle with gcc (idempotent)."""
+    src = os.path.join(_HERE, "fcp_oracle.c")
+    hdr = os.path.join(_HERE, "fcp_oracle.h")
+    if (not force and os.path.exists(_LIB)
+            and os.path.getmtime(_LIB) >= max(os.path.getmtime(src), os.path.getmtime(hdr))):
+        return _LIB
+    subprocess.check_call(["make", "-C", _HERE, "-B", "libfcp_oracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB
+
+
+class _Column(C.Structure):
+    _fields_ = [
+        ("form", C.c_int32), ("combiner", C.c_int32), ("dim", C.c_int32), ("id_source", C.c_int32),
+        ("vocab", C.c_int64),
+        ("table_input", C.c_int32), ("ids_input", C.c_int32), ("seg_input", C.c_int32),
+        ("seg_kind", C.c_int32), ("seg_stride", C.c_int32),
+        ("rows_source", C.c_int32), ("rows_arg", C.c_int32),
+        ("n_boundaries", C.c_int32),
+        ("boundaries", C.POINTER(C.c_float)),
+        ("concat_group", C.c_int32), ("concat_slot", C.c_int32),
+    ]
+
+
+class _Plan(C.Structure):
+    _fields_ = [
+        ("n_columns", C.c_int32), ("columns", C.POINTER(_Column)),
+        ("n_host_inputs", C.c_int32),
+        ("host_input_ranks", C.POINTER(C.c_int32)),
+        ("host_input_elem_sizes", C.POINTER(C.c_int32)),
+        ("n_groups", C.c_int32),
+        ("shard_rank", C.c_int32), ("shard_world", C.c_int32),
+    ]
+
+
+def _i32(a) -> np.ndarray:
+    return np.ascontiguousarray(np.asarray(a, dtype=np.int32))
+
+
+class COracle:
+    """ctypes binding of libfcp_oracle.so."""
+
+    def __init__(self) -> None:
+        self.lib = C.CDLL(build())
+        L = self.lib
+        L.orc_bucketize.restype = C.c_int32
+        L.orc_bucketize.argtypes = [C.c_void_p, C.c_int32, C.c_float]
+        L.orc_bucketize_array.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]
+        L.orc_gather_rows.restype = C.c_int64
+        L.orc_gather_rows.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64,
+                                      C.c_void_p, C.c_int64]
+        L.orc_gather_scatter_rows.restype = C.c_int64
+        L.orc_gather_scatter_rows.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
+                                              C.c_int64, C.c_int64, C.c_void_p, C.c_int64]
+        L.orc_segment_offsets.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
+        L.orc_sparse_segment_reduce.restype = C.c_int64
+        L.orc_sparse_segment_reduce.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
+                                                C.c_int64, C.c_int32, C.c_void_p, C.c_int64]
+        L.orc_sparse_segment_reduce_ref8x8.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                                       C.c_int64, C.c_int32, C.c_void_p, C.c_int64]
+        L.orc_batch_col_reduction.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p,
+                                              C.c_int64]
+        L.orc_concat_outputs.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p]
+        L.orc_concat_inputs.restype = C.c_int64
+        L.orc_concat_inputs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                        C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_process_feature_columns.restype = C.c_int64
+        L.orc_process_feature_columns.argtypes = [C.POINTER(_Plan), C.c_void_p, C.c_void_p, C.c_void_p,
+                                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
+        L.orc_group_rows.restype = C.c_int64
+        L.orc_group_rows.argtypes = [C.POINTER(_Plan), C.c_int32, C.c_void_p, C.c_void_p]
+        L.orc_group_width.restype = C.c_int32
+        L.orc_group_width.argtypes = [C.POINTER(_Plan), C.c_int32]
+        L.orc_column_offset.restype = C.c_int32
+        L.orc_column_offset.argtypes = [C.POINTER(_Plan), C.c_int32]
+
+    # ---- single functions -----------------------------------------------------
+    def bucketize(self, boundaries, values) -> np.ndarray:
+        b = np.ascontiguousarray(boundaries, np.float32)
+        v = np.ascontiguousarray(values, np.float32)
+        out = np.empty(v.shape, np.int32)
+        self.lib.orc_bucketize_array(b.ctypes.data, len(b), v.ctypes.data, v.size, out.ctypes.data)
+        return out
+
+    def gather_rows(self, table, ids):
+        t = np.ascontiguousarray(table, np.float32)
+        i = np.ascontiguousarray(ids, np.int64).ravel()
+        out = np.empty((i.size, t.shape[1]), np.float32)
+        bad = self.lib.orc_gather_rows(t.ctypes.data, t.shape[0], t.shape[1], i.ctypes.data, i.size,
+                                       out.ctypes.data, t.shape[1])
+        return out, bad
+
+    def gather_scatter_rows(self, table, ids, rows, num_rows):
+        t = np.ascontiguousarray(table, np.float32)
+        i = np.ascontiguousarray(ids, np.int64).ravel()
+        r = np.ascontiguousarray(rows, np.int64).ravel()
+        out = np.empty((num_rows, t.shape[1]), np.float32)
+        bad = self.lib.orc_gather_scatter_rows(t.ctypes.data, t.shape[0], t.shape[1], i.ctypes.data,
+                                               r.ctypes.data, i.size, num_rows, out.ctypes.data,
+                                               t.shape[1])
+        return out, bad
+
+    def segment_offsets(self, seg_ids, num_segments) -> np.ndarray:
+        s = np.ascontiguousarray(seg_ids, np.int64).ravel()
+        out = np.full(num_segments + 1, -12345, np.int32)
+        self.lib.orc_segment_offsets(s.ctypes.data, s.size, num_segments, out.ctypes.data)
+        return out
+
+    def sparse_segment_reduce(self, table, ids, offsets, mean: bool, ref_order: bool = False):
+        t = np.ascontiguousarray(table, np.float32)
+        i = np.ascontiguousarray(ids, np.int64).ravel()
+        o = np.ascontiguousarray(offsets, np.int32)
+        S = o.size - 1
+        out = np.empty((S, t.shape[1]), np.float32)
+        if ref_order:
+            self.lib.orc_sparse_segment_reduce_ref8x8(t.ctypes.data, t.shape[1], i.ctypes.data,
+                                                      o.ctypes.data, S, int(mean), out.ctypes.data,
+                                                      t.shape[1])
+            return out, 0
+        bad = self.lib.orc_sparse_segment_reduce(t.ctypes.data, t.shape[0], t.shape[1], i.ctypes.data,
+                                                 o.ctypes.data, S, int(mean), out.ctypes.data,
+                                                 t.shape[1])
+        return out, bad
+
+    def batch_col_reduction(self, x) -> np.ndarray:
+        x = np.ascontiguousarray(x, np.float32)
+        B, R, Cc = x.shape
+        out = np.empty((B, Cc), np.float32)
+        self.lib.orc_batch_col_reduction(x.ctypes.data, B, R, Cc, out.ctypes.data, Cc)
+        return out
+
+    def concat_outputs(self, inputs: Sequence[np.ndarray]) -> np.ndarray:
+        arrs = [np.ascontiguousarray(a, np.float32) for a in inputs]
+        prefix = arrs[0].shape[0]
+        dims = _i32([a.shape[1] for a in arrs])
+        ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+        out = np.empty((prefix, int(dims.sum())), np.float32)
+        self.lib.orc_concat_outputs(ptrs, dims.ctypes.data, len(arrs), prefix, out.ctypes.data)
+        return out
+
+    def concat_inputs(self, tensors: Sequence[np.ndarray]):
+        arrs = [np.require(np.asarray(a), requirements="C") for a in tensors]  # keeps rank-0
+        n = len(arrs)
+        datas = (C.c_void_p * n)(*[a.ctypes.data for a in arrs])
+        nbytes = np.asarray([a.nbytes for a in arrs], np.int64)
+        ranks = _i32([a.ndim for a in arrs])
+        dim_arrs = [np.asarray(a.shape, np.int64) for a in arrs]
+        dims = (C.c_void_p * n)(*[d.ctypes.data for d in dim_arrs])
+        offsets = np.empty(n, np.int32)
+        shapes = np.empty(int(ranks.sum()), np.int32)
+        blob = np.empty(int(nbytes.sum()), np.int8)
+        total = self.lib.orc_concat_inputs(datas, nbytes.ctypes.data, ranks.ctypes.data, dims, n,
+                                           blob.ctypes.data, offsets.ctypes.data, shapes.ctypes.data)
+        assert total == blob.size
+        return blob, offsets, shapes
+
+    # ---- whole path -------------------------------------------------------------
+    def _make_plan(self, plan: dict):
+        cols = plan["columns"]
+        keep: List[np.ndarray] = []
+        arr = (_Column * len(cols))()
+        for k, c in enumerate(cols):
+            b = c.get("boundaries")
+            if b is not None:
+                b = np.ascontiguousarray(b, np.float32)
+                keep.append(b)
+            arr[k] = _Column(
+                c["form"], c["combiner"], c["dim"], c["id_source"], c["vocab"], c["table_input"],
+                c["ids_input"], c["seg_input"], c["seg_kind"], max(1, c["seg_stride"]),
+                c["rows_source"], c["rows_arg"], 0 if b is None else len(b),
+                None if b is None else b.ctypes.data_as(C.POINTER(C.c_float)),
+                c["concat_group"], c["concat_slot"])
+        ranks = _i32(plan["host_input_ranks"])
+        esz = _i32(plan["host_input_elem_sizes"])
+        keep += [ranks, esz]
+        p = _Plan(len(cols), arr, len(ranks), ranks.ctypes.data_as(C.POINTER(C.c_int32)),
+                  esz.ctypes.data_as(C.POINTER(C.c_int32)), plan["n_groups"],
+                  plan.get("shard_rank", 0), plan.get("shard_world", 1))
+        return p, (arr, keep)
+
+    def process_feature_columns(self, plan: dict, blob: np.ndarray, offsets, shapes,
+                                tables: Sequence[np.ndarray], symbols=None, n_threads: int = 1,
+                                out: Optional[List[np.ndarray]] = None):
+        """Returns (list of [rows_g, width_g] float32 matrices, n_bad_ids)."""
+        p, _keep = self._make_plan(plan)
+        blob = np.ascontiguousarray(blob).view(np.int8)
+        offsets = _i32(offsets)
+        shapes = _i32(shapes)
+        sym = None if symbols is None else _i32(symbols)
+        symp = None if sym is None else sym.ctypes.data
+        tabs = [np.ascontiguousarray(t, np.float32) for t in tables]
+        tptrs = (C.c_void_p * max(1, len(tabs)))(*[t.ctypes.data for t in tabs])
+        if out is None:
+            out = []
+            for g in range(plan["n_groups"]):
+                rows = self.lib.orc_group_rows(C.byref(p), g, shapes.ctypes.data, symp)
+                if rows < 0:
+                    raise ValueError(f"oracle: inconsistent rows in group {g}")
+                out.append(np.zeros((rows, self.lib.orc_group_width(C.byref(p), g)), np.float32))
+        optrs = (C.c_void_p * len(out))(*[o.ctypes.data for o in out])
+        bad = self.lib.orc_process_feature_columns(C.byref(p), blob.ctypes.data, offsets.ctypes.data,
+                                                   shapes.ctypes.data, tptrs, symp, optrs, n_threads)
+        if bad < 0:
+            raise ValueError("oracle: malformed plan / shapes")
+        return out, int(bad)
+
+
+# =============================================================================
+# NumPy restatement (float64 accumulation) — the independent pin for the C oracle
+# =============================================================================
+
+def np_bucketize(boundaries, values) -> np.ndarray:
+    """TF Bucketize == number of boundaries <= value (cuda_emitter.cc:233-247)."""
+    return np.searchsorted(np.asarray(boundaries, np.float32), np.asarray(values, np.float32),
+                           side="right").astype(np.int32)
+
+
+def np_segment_offsets(seg_ids, num_segments) -> np.ndarray:
+    """CSR offsets of sorted segment ids (cuda_emitter.cc:768-818)."""
+    seg = np.asarray(seg_ids, np.int64)
+    return np.searchsorted(seg, np.arange(num_segments + 1), side="left").astype(np.int32)
+
+
+def np_sparse_segment_reduce(table, ids, offsets, mean: bool) -> np.ndarray:
+    """float64-accumulated truth for SparseSegment{Sum,Mean}WithNumSegments."""
+    t = np.asarray(table, np.float64)
+    ids = np.asarray(ids, np.int64)
+    S = len(offsets) - 1
+    out = np.zeros((S, t.shape[1]), np.float64)
+    for s in range(S):
+        lo, hi = int(offsets[s]), int(offsets[s + 1])
+        if hi > lo:
+            acc = t[ids[lo:hi]].sum(axis=0)
+            out[s] = acc / (hi - lo) if mean else acc
+    return out
+
+
+def np_process_feature_columns(plan: dict, blob: np.ndarray, offsets, shapes, tables, symbols=None
+                               ) -> List[np.ndarray]:
+    """Whole path in NumPy, float64 pooling (unsharded plans only)."""
+    blob = np.ascontiguousarray(blob).view(np.uint8)
+    ranks = plan["host_input_ranks"]
+    so = np.concatenate([[0], np.cumsum(ranks)]).astype(int)
+
+    def tensor(i, dtype):
+        shape = tuple(int(x) for x in shapes[so[i]:so[i + 1]])
+        n = int(np.prod(shape)) if shape else 1
+        nb = n * np.dtype(dtype).itemsize
+        return np.frombuffer(blob[int(offsets[i]):int(offsets[i]) + nb].tobytes(), dtype).reshape(shape)
+
+    cols = plan["columns"]
+    widths = [sum(c["dim"] for c in cols if c["concat_group"] == g) for g in range(plan["n_groups"])]
+    col_off: Dict[int, int] = {}
+    for g in range(plan["n_groups"]):
+        acc = 0
+        for _, k in sorted((c["concat_slot"], k) for k, c in enumerate(cols) if c["concat_group"] == g):
+            col_off[k] = acc
+            acc += cols[k]["dim"]
+
+    def rows_of(c):
+        if c["rows_source"] == 0:
+            return int(np.prod(shapes[so[c["ids_input"]]:so[c["ids_input"] + 1]]))
+        if c["rows_source"] == 1:
+            return int(symbols[c["rows_arg"]])
+        return int(shapes[so[c["rows_arg"]]])
+
+    outs = [None] * plan["n_groups"]
+    for k, c in enumerate(cols):
+        g = c["concat_group"]
+        rows = rows_of(c)
+        if outs[g] is None:
+            outs[g] = np.zeros((rows, widths[g]), np.float64)
+        dst = outs[g][:, col_off[k]:col_off[k] + c["dim"]]
+        if c["form"] == 4:
+            dst[:] = tensor(c["ids_input"], np.float32).reshape(rows, c["dim"])
+            continue
+        if c["form"] == 5:
+            dst[:] = tensor(c["ids_input"], np.float32).astype(np.float64).sum(axis=1)
+            continue
+        table = np.asarray(tables[c["table_input"]], np.float64)
+        if c["id_source"] == 2:
+            ids = np_bucketize(c["boundaries"], tensor(c["ids_input"], np.float32).ravel()).astype(np.int64)
+        else:
+            ids = tensor(c["ids_input"], np.int32 if c["id_source"] == 0 else np.int64).ravel().astype(np.int64)
+        ok = (ids >= 0) & (ids < c["vocab"])
+        if c["form"] == 1:
+            dst[:] = np.where(ok[:, None], table[np.where(ok, ids, 0)], 0.0)
+            continue
+        if c["seg_kind"] == 3:
+            offs = tensor(c["seg_input"], np.int32).ravel()
+        else:
+            raw = tensor(c["seg_input"], np.int32 if c["seg_kind"] == 1 else np.int64).ravel()
+            seg = raw[::max(1, c["seg_stride"])][:ids.size]
+            offs = np_segment_offsets(seg, rows)
+        if c["form"] == 2:
+            mean = c["combiner"] == 2
+            for s in range(rows):
+                lo, hi = int(offs[s]), int(offs[s + 1])
+                sel = ids[lo:hi][ok[lo:hi]]
+                acc = table[sel].sum(axis=0) if sel.size else 0.0
+                dst[s] = acc / (hi - lo) if (mean and hi > lo) else acc
+        else:  # form 3: last id of the row wins
+            for s in range(rows):
+                lo, hi = int(offs[s]), int(offs[s + 1])
+                if hi > lo and ok[hi - 1]:
+                    dst[s] = table[ids[hi - 1]]
+    return outs

@@ -1,0 +1,882 @@
+// fcp_api.hip — host side of libfcp_hip.so: the C ABI declared in
+// include/fcp_hip.h.  Plan building (the non-codegen half of the reference's
+// CudaEmitter), const buffers (CreateConstBuffers, cuda_emitter.cc:2260-2301),
+// the per-request entry (ProcessFeatureColumns, :2303-2494, and its kernel
+// caller :2139-2258) and the host packer of Addons>ConcatInputs
+// (custom_ops/concat_inputs/concat_inputs_ops.cc:42-77).
+//
+// Differences from the reference's per-request host work, on purpose:
+//   * no blocking stream synchronisation anywhere on the request path (the
+//     reference blocks at :2246 and twice more in the ops);
+//   * no per-request H2D of a pageable argument struct (:2216): the shape-
+//     dependent descriptors are cached on the device keyed by the request's
+//     (offsets, shapes, symbols) and re-uploaded from pinned memory only when
+//     the shapes change;
+//   * 64-bit byte offsets and row offsets (the reference's int arithmetic
+//     overflows beyond 2^31).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/fcp_hip.h"
+#include "fcp_internal.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int hip_fail(const char *what, hipError_t e) {
+  g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+  return (e == hipErrorNoDevice || e == hipErrorInvalidDevice || e == hipErrorNoBinaryForGpu ||
+          e == hipErrorInsufficientDriver)
+             ? FCP_ERR_NO_DEVICE
+             : FCP_ERR_HIP;
+}
+
+int fail(int code, const std::string &msg) {
+  g_last_error = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                   \
+  do {                                                  \
+    hipError_t e_ = (expr);                             \
+    if (e_ != hipSuccess) return hip_fail(#expr, e_);   \
+  } while (0)
+
+inline int64_t align128(int64_t x) { return (x + 127) / 128 * 128; } // alignmem, cuda_emitter.cc:967-969
+
+constexpr int kSlots = 8;
+constexpr uint32_t kFlagHostOnly = 1u << 31; // undocumented: plan without device resources (layout queries)
+
+struct HostColumn {
+  fcp_column_desc_t d;
+  std::vector<float> boundaries;
+  int32_t out_off = 0;
+  int64_t const_off = -1; // byte offset of the boundaries in the const buffer
+};
+
+struct DynMeta {
+  std::vector<int32_t> group_rows;
+  std::vector<int64_t> group_base;
+  int64_t arena_bytes = 0;
+  int64_t csr_arena_off = 0;
+  int32_t max_seg_nnz = 0;
+  int32_t grid_blocks = 0;
+  int32_t rows_per_wave = 1;
+  FcpGroupLaunch groups[FCP_MAX_GROUPS];
+};
+
+struct DynSlot {
+  bool valid = false;
+  std::vector<int32_t> key;
+  FcpColDyn *h_dyn = nullptr; // pinned
+  FcpColDyn *d_dyn = nullptr;
+  hipEvent_t uploaded = nullptr;
+  void *stream = nullptr; // the only stream that has used this slot, unless multi
+  bool multi = false;
+  uint64_t tick = 0;
+  DynMeta meta;
+};
+
+} // namespace
+
+struct fcp_plan {
+  fcp_plan_desc_t desc;
+  std::vector<HostColumn> cols;
+  std::vector<int32_t> ranks, elem_sizes, shape_off;
+  std::vector<int32_t> group_width, group_nslots, group_map_off;
+  std::vector<int32_t> seg_cols;
+  int vec = 1;
+  bool dense_only = true;
+  bool host_only = false;
+  int32_t rank_sum = 0;
+
+  uint32_t *d_slot_map = nullptr;
+  FcpColStatic *d_cols = nullptr;
+  std::vector<FcpColStatic> h_cols;
+  char *d_const = nullptr;
+  int32_t *d_seg_cols = nullptr;
+  unsigned long long *d_bad = nullptr;
+  std::vector<const void *> bound_tables;
+  bool tables_bound = false;
+
+  std::mutex mu;
+  DynSlot slots[kSlots];
+  uint64_t tick = 0;
+};
+
+namespace {
+
+struct DeviceGuard {
+  int prev = -1;
+  bool changed = false;
+  int enter(int dev) {
+    hipError_t e = hipGetDevice(&prev);
+    if (e != hipSuccess) return hip_fail("hipGetDevice", e);
+    if (prev != dev) {
+      e = hipSetDevice(dev);
+      if (e != hipSuccess) return hip_fail("hipSetDevice", e);
+      changed = true;
+    }
+    return FCP_OK;
+  }
+  ~DeviceGuard() {
+    if (changed) (void)hipSetDevice(prev);
+  }
+};
+
+int validate_desc(const fcp_plan_desc_t *d) {
+  if (!d) return fail(FCP_ERR_INVALID_ARGUMENT, "null plan descriptor");
+  if (d->abi_version != FCP_ABI_VERSION) return fail(FCP_ERR_INVALID_ARGUMENT, "abi_version mismatch");
+  if (d->n_columns <= 0 || !d->columns) return fail(FCP_ERR_INVALID_ARGUMENT, "plan has no columns");
+  if (d->n_host_inputs < 0 || (d->n_host_inputs > 0 && (!d->host_input_ranks || !d->host_input_elem_sizes)))
+    return fail(FCP_ERR_INVALID_ARGUMENT, "host input attrs missing");
+  if (d->n_groups <= 0 || d->n_groups > FCP_MAX_GROUPS)
+    return fail(FCP_ERR_INVALID_ARGUMENT, "n_groups must be in [1, 16]");
+  if (d->layout != FCP_LAYOUT_CONCAT && d->layout != FCP_LAYOUT_PER_COLUMN)
+    return fail(FCP_ERR_INVALID_ARGUMENT, "bad layout");
+  if (d->shard_world < 1 || d->shard_rank < 0 || d->shard_rank >= d->shard_world)
+    return fail(FCP_ERR_INVALID_ARGUMENT, "bad shard rank/world");
+  for (int i = 0; i < d->n_host_inputs; ++i) {
+    if (d->host_input_ranks[i] < 0 || d->host_input_ranks[i] > 8)
+      return fail(FCP_ERR_INVALID_ARGUMENT, "host input rank out of range");
+    if (d->host_input_elem_sizes[i] <= 0) return fail(FCP_ERR_INVALID_ARGUMENT, "bad element size");
+  }
+  for (int k = 0; k < d->n_columns; ++k) {
+    const fcp_column_desc_t &c = d->columns[k];
+    const std::string where = "column " + std::to_string(k) + ": ";
+    if (c.form < FCP_FORM_GATHER || c.form > FCP_FORM_BATCH_COL_REDUCTION)
+      return fail(FCP_ERR_INVALID_ARGUMENT, where + "bad form");
+    if (c.dim <= 0) return fail(FCP_ERR_INVALID_ARGUMENT, where + "dim must be positive");
+    if (c.concat_group < 0 || c.concat_group >= d->n_groups)
+      return fail(FCP_ERR_INVALID_ARGUMENT, where + "concat_group out of range");
+    if (c.ids_input < 0 || c.ids_input >= d->n_host_inputs)
+      return fail(FCP_ERR_INVALID_ARGUMENT, where + "ids_input out of range");
+    const bool lookup = c.form == FCP_FORM_GATHER || c.form == FCP_FORM_SEGMENT_REDUCE ||
+                        c.form == FCP_FORM_GATHER_SCATTER;
+    if (lookup) {
+      if (c.vocab <= 0) return fail(FCP_ERR_INVALID_ARGUMENT, where + "vocab must be positive");
+      if (c.table_input < 0 || c.table_input >= d->n_device_inputs)
+        return fail(FCP_ERR_INVALID_ARGUMENT, where + "table_input out of range");
+      if (c.id_source < FCP_IDS_I32 || c.id_source > FCP_IDS_F32_BUCKETIZE)
+        return fail(FCP_ERR_INVALID_ARGUMENT, where + "bad id_source");
+      if (c.id_source == FCP_IDS_F32_BUCKETIZE && (c.n_boundaries <= 0 || !c.boundaries))
+        return fail(FCP_ERR_INVALID_ARGUMENT, where + "bucketize needs boundaries");
+      const int esz = d->host_input_elem_sizes[c.ids_input];
+      if (esz != (c.id_source == FCP_IDS_I64 ? 8 : 4))
+        return fail(FCP_ERR_INVALID_ARGUMENT, where + "ids element size does not match id_source");
+    } else if (d->host_input_elem_sizes[c.ids_input] != 4) {
+      return fail(FCP_ERR_INVALID_ARGUMENT, where + "payload must be a 4-byte type");
+    }
+    if (c.form == FCP_FORM_SEGMENT_REDUCE || c.form == FCP_FORM_GATHER_SCATTER) {
+      if (c.seg_kind < FCP_SEG_IDS_I32 || c.seg_kind > FCP_SEG_CSR_I32)
+        return fail(FCP_ERR_INVALID_ARGUMENT, where + "bad seg_kind");
+      if (c.seg_input < 0 || c.seg_input >= d->n_host_inputs)
+        return fail(FCP_ERR_INVALID_ARGUMENT, where + "seg_input out of range");
+      if (c.seg_stride < 1) return fail(FCP_ERR_INVALID_ARGUMENT, where + "seg_stride must be >= 1");
+      if (d->host_input_elem_sizes[c.seg_input] != (c.seg_kind == FCP_SEG_IDS_I64 ? 8 : 4))
+        return fail(FCP_ERR_INVALID_ARGUMENT, where + "segment element size does not match seg_kind");
+      if (c.rows_source == FCP_ROWS_FROM_IDS)
+        return fail(FCP_ERR_INVALID_ARGUMENT, where + "pooled column needs an explicit row source");
+    }
+    if (c.form == FCP_FORM_SEGMENT_REDUCE && c.combiner != FCP_COMBINER_SUM &&
+        c.combiner != FCP_COMBINER_MEAN)
+      return fail(FCP_ERR_INVALID_ARGUMENT, where + "segment-reduce needs sum or mean");
+    if (c.form == FCP_FORM_BATCH_COL_REDUCTION && d->host_input_ranks[c.ids_input] != 3)
+      return fail(FCP_ERR_INVALID_ARGUMENT, where + "BatchColReduction input must be rank 3");
+    if (c.rows_source < FCP_ROWS_FROM_IDS || c.rows_source > FCP_ROWS_FROM_INPUT_DIM0)
+      return fail(FCP_ERR_INVALID_ARGUMENT, where + "bad rows_source");
+    if (c.rows_source == FCP_ROWS_FROM_SYMBOL && (c.rows_arg < 0 || c.rows_arg >= d->n_symbols))
+      return fail(FCP_ERR_INVALID_ARGUMENT, where + "symbol index out of range");
+    if (c.rows_source == FCP_ROWS_FROM_INPUT_DIM0 &&
+        (c.rows_arg < 0 || c.rows_arg >= d->n_host_inputs || d->host_input_ranks[c.rows_arg] < 1))
+      return fail(FCP_ERR_INVALID_ARGUMENT, where + "rows_arg host input out of range");
+    for (int j = 0; j < k; ++j)
+      if (d->columns[j].concat_group == c.concat_group && d->columns[j].concat_slot == c.concat_slot)
+        return fail(FCP_ERR_INVALID_ARGUMENT, where + "duplicate concat slot");
+  }
+  return FCP_OK;
+}
+
+// Run-time shapes -> per-column dynamic records, arena layout and launch
+// geometry.  Mirrors what the generated host code evaluates per call from
+// SymEngine expressions (cuda_emitter.cc:2151-2179, :2410-2455).
+int compute_dyn(const fcp_plan *p, const int32_t *offsets, const int32_t *shapes,
+                const int32_t *symbols, int64_t blob_bytes, FcpColDyn *dyn, DynMeta *m) {
+  const int nc = (int)p->cols.size();
+  const int ng = p->desc.n_groups;
+  auto numel = [&](int i) -> int64_t {
+    int64_t n = 1;
+    for (int j = 0; j < p->ranks[i]; ++j) {
+      const int32_t d = shapes[p->shape_off[i] + j];
+      if (d < 0) return -1;
+      n *= d;
+    }
+    return n;
+  };
+  for (int i = 0; i < (int)p->ranks.size(); ++i) {
+    const int64_t n = numel(i);
+    if (n < 0) return fail(FCP_ERR_SHAPE_MISMATCH, "negative dimension in concated_shapes");
+    if (offsets[i] < 0) return fail(FCP_ERR_SHAPE_MISMATCH, "negative blob offset (int32 overflow?)");
+    if (blob_bytes >= 0 && (int64_t)offsets[i] + n * p->elem_sizes[i] > blob_bytes)
+      return fail(FCP_ERR_SHAPE_MISMATCH, "host input " + std::to_string(i) + " exceeds the blob");
+  }
+  m->group_rows.assign(ng, -1);
+  std::vector<int64_t> col_rows(nc);
+  for (int k = 0; k < nc; ++k) {
+    const fcp_column_desc_t &c = p->cols[k].d;
+    int64_t rows;
+    if (c.rows_source == FCP_ROWS_FROM_IDS) {
+      rows = numel(c.ids_input);
+    } else if (c.rows_source == FCP_ROWS_FROM_SYMBOL) {
+      if (!symbols) return fail(FCP_ERR_INVALID_ARGUMENT, "plan needs the symbols tensor");
+      rows = symbols[c.rows_arg];
+    } else {
+      rows = shapes[p->shape_off[c.rows_arg]];
+    }
+    if (rows < 0 || rows > 0x7fffffff) return fail(FCP_ERR_SHAPE_MISMATCH, "row count out of range");
+    col_rows[k] = rows;
+    int32_t &gr = m->group_rows[c.concat_group];
+    if (gr >= 0 && gr != rows)
+      return fail(FCP_ERR_SHAPE_MISMATCH, "columns of concat group " + std::to_string(c.concat_group) +
+                                              " disagree on the row count");
+    gr = (int32_t)rows;
+  }
+  for (int g = 0; g < ng; ++g)
+    if (m->group_rows[g] < 0) return fail(FCP_ERR_INVALID_ARGUMENT, "concat group without columns");
+
+  // arena: outputs, then CSR scratch (one malloc_buff, cuda_emitter.cc:2151-2163)
+  int64_t cursor = 0;
+  m->group_base.assign(ng, 0);
+  if (p->desc.layout == FCP_LAYOUT_CONCAT) {
+    for (int g = 0; g < ng; ++g) {
+      m->group_base[g] = cursor;
+      cursor += align128((int64_t)m->group_rows[g] * p->group_width[g] * 4);
+    }
+  }
+  m->max_seg_nnz = 0;
+  for (int k = 0; k < nc; ++k) {
+    const HostColumn &hc = p->cols[k];
+    const fcp_column_desc_t &c = hc.d;
+    FcpColDyn &d = dyn[k];
+    std::memset(&d, 0, sizeof(d));
+    const int64_t rows = col_rows[k];
+    d.rows = (int32_t)rows;
+    d.ids_off = offsets[c.ids_input];
+    if (d.ids_off % 4) return fail(FCP_ERR_UNSUPPORTED, "blob tensor not 4-byte aligned");
+    const int64_t n_ids = numel(c.ids_input);
+    d.csr_base = -1;
+    d.inner = 1;
+    if (c.form == FCP_FORM_PASSTHROUGH) {
+      if (n_ids != rows * c.dim) return fail(FCP_ERR_SHAPE_MISMATCH, "passthrough tensor size != rows*dim");
+      d.nnz = (int32_t)rows;
+    } else if (c.form == FCP_FORM_BATCH_COL_REDUCTION) {
+      const int32_t *s = shapes + p->shape_off[c.ids_input];
+      if (s[0] != rows || s[2] != c.dim) return fail(FCP_ERR_SHAPE_MISMATCH, "BatchColReduction shape mismatch");
+      d.inner = s[1];
+      d.nnz = (int32_t)rows;
+    } else {
+      if (n_ids > 0x7fffffff) return fail(FCP_ERR_UNSUPPORTED, "more than 2^31 ids in one column");
+      d.nnz = (int32_t)n_ids;
+      if (c.form == FCP_FORM_GATHER && n_ids != rows)
+        return fail(FCP_ERR_SHAPE_MISMATCH, "gather column: ids count != rows");
+      if (c.form != FCP_FORM_GATHER) {
+        d.seg_off = offsets[c.seg_input];
+        if (d.seg_off % 4) return fail(FCP_ERR_UNSUPPORTED, "blob tensor not 4-byte aligned");
+        const int64_t n_seg = numel(c.seg_input);
+        if (c.seg_kind == FCP_SEG_CSR_I32) {
+          if (n_seg != rows + 1) return fail(FCP_ERR_SHAPE_MISMATCH, "CSR offsets must have rows+1 entries");
+        } else {
+          if (n_seg < n_ids * c.seg_stride - (c.seg_stride - 1) && n_ids > 0)
+            return fail(FCP_ERR_SHAPE_MISMATCH, "segment id tensor shorter than the id stream");
+          if (d.nnz > m->max_seg_nnz) m->max_seg_nnz = d.nnz;
+        }
+      }
+    }
+    if (p->desc.layout == FCP_LAYOUT_CONCAT) {
+      d.out_base = m->group_base[c.concat_group] + (int64_t)hc.out_off * 4;
+      d.out_stride = p->group_width[c.concat_group];
+    } else {
+      d.out_base = cursor;
+      d.out_stride = c.dim;
+      cursor += align128(rows * c.dim * 4);
+    }
+  }
+  m->csr_arena_off = cursor;
+  int64_t csr_cursor = 0; // in int32 elements
+  for (int k : p->seg_cols) {
+    dyn[k].csr_base = (int32_t)csr_cursor;
+    csr_cursor += (col_rows[k] + 1 + 31) / 32 * 32;
+    if (csr_cursor > 0x7fffffff) return fail(FCP_ERR_UNSUPPORTED, "CSR scratch exceeds 2^31 entries");
+  }
+  cursor += csr_cursor * 4;
+  m->arena_bytes = cursor;
+
+  // launch geometry
+  int32_t max_rows = 0;
+  for (int g = 0; g < ng; ++g) max_rows = std::max(max_rows, m->group_rows[g]);
+  int rpw = 1;
+  if (p->dense_only) {
+    while (rpw < 8 && max_rows >= 64 * rpw) rpw *= 2; // 512 rows -> 8, 128 -> 2, < 64 -> 1
+  }
+  m->rows_per_wave = rpw;
+  int32_t blocks = 0;
+  for (int g = 0; g < ng; ++g) {
+    FcpGroupLaunch &G = m->groups[g];
+    G.rows = m->group_rows[g];
+    G.nslots = p->group_nslots[g];
+    const int nspans = (G.nslots + FCP_WAVE - 1) / FCP_WAVE;
+    G.nsp8 = (nspans + 7) / 8;
+    G.block_begin = blocks;
+    G.slot_map_off = p->group_map_off[g];
+    G.pad_ = 0;
+    const int rows_per_block = FCP_WAVES_PER_BLOCK * rpw;
+    const int64_t ntiles = ((int64_t)G.rows + rows_per_block - 1) / rows_per_block;
+    const int64_t nb = 8ll * G.nsp8 * ntiles;
+    if (blocks + nb > 0x7fffffff) return fail(FCP_ERR_UNSUPPORTED, "grid too large");
+    blocks += (int32_t)nb;
+  }
+  m->grid_blocks = blocks;
+  return FCP_OK;
+}
+
+void destroy_device(fcp_plan *p) {
+  if (p->host_only) return;
+  for (auto &s : p->slots) {
+    if (s.h_dyn) (void)hipHostFree(s.h_dyn);
+    if (s.d_dyn) (void)hipFree(s.d_dyn);
+    if (s.uploaded) (void)hipEventDestroy(s.uploaded);
+  }
+  if (p->d_slot_map) (void)hipFree(p->d_slot_map);
+  if (p->d_cols) (void)hipFree(p->d_cols);
+  if (p->d_const) (void)hipFree(p->d_const);
+  if (p->d_seg_cols) (void)hipFree(p->d_seg_cols);
+  if (p->d_bad) (void)hipFree(p->d_bad);
+}
+
+int init_device(fcp_plan *p) {
+  DeviceGuard guard;
+  int rc = guard.enter(p->desc.device);
+  if (rc) return rc;
+  const int nc = (int)p->cols.size();
+  // slot map
+  std::vector<uint32_t> map;
+  for (int g = 0; g < p->desc.n_groups; ++g) {
+    p->group_map_off[g] = (int32_t)map.size();
+    std::vector<int> members;
+    for (int k = 0; k < nc; ++k)
+      if (p->cols[k].d.concat_group == g) members.push_back(k);
+    std::sort(members.begin(), members.end(),
+              [&](int a, int b) { return p->cols[a].out_off < p->cols[b].out_off; });
+    for (int k : members)
+      for (int s = 0; s < p->cols[k].d.dim / p->vec; ++s) map.push_back((uint32_t)k);
+  }
+  HIP_TRY(hipMalloc(&p->d_slot_map, std::max<size_t>(map.size(), 1) * sizeof(uint32_t)));
+  HIP_TRY(hipMemcpy(p->d_slot_map, map.data(), map.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  // const buffers (bucketize boundaries), each 128-byte aligned as the reference's
+  int64_t const_bytes = 0;
+  for (auto &hc : p->cols)
+    if (!hc.boundaries.empty()) {
+      hc.const_off = const_bytes;
+      const_bytes += align128((int64_t)hc.boundaries.size() * 4);
+    }
+  if (const_bytes) {
+    HIP_TRY(hipMalloc(&p->d_const, const_bytes));
+    for (auto &hc : p->cols)
+      if (hc.const_off >= 0)
+        HIP_TRY(hipMemcpy(p->d_const + hc.const_off, hc.boundaries.data(), hc.boundaries.size() * 4,
+                          hipMemcpyHostToDevice));
+  }
+  // static column records (tables are bound on the first request)
+  p->h_cols.resize(nc);
+  for (int k = 0; k < nc; ++k) {
+    const HostColumn &hc = p->cols[k];
+    FcpColStatic &s = p->h_cols[k];
+    s.table = nullptr;
+    s.boundaries = hc.const_off >= 0 ? reinterpret_cast<const float *>(p->d_const + hc.const_off) : nullptr;
+    s.vocab = hc.d.vocab;
+    s.dim = hc.d.dim;
+    s.out_off = hc.out_off;
+    s.flags = FCP_F_PACK(hc.d.form, hc.d.combiner, hc.d.id_source, hc.d.seg_kind);
+    s.n_boundaries = (int32_t)hc.boundaries.size();
+    s.seg_stride = hc.d.seg_stride < 1 ? 1 : hc.d.seg_stride;
+    s.group = hc.d.concat_group;
+  }
+  HIP_TRY(hipMalloc(&p->d_cols, nc * sizeof(FcpColStatic)));
+  HIP_TRY(hipMemcpy(p->d_cols, p->h_cols.data(), nc * sizeof(FcpColStatic), hipMemcpyHostToDevice));
+  if (!p->seg_cols.empty()) {
+    HIP_TRY(hipMalloc(&p->d_seg_cols, p->seg_cols.size() * sizeof(int32_t)));
+    HIP_TRY(hipMemcpy(p->d_seg_cols, p->seg_cols.data(), p->seg_cols.size() * sizeof(int32_t),
+                      hipMemcpyHostToDevice));
+  }
+  if (p->desc.flags & FCP_FLAG_COUNT_BAD_IDS) {
+    HIP_TRY(hipMalloc(&p->d_bad, sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(p->d_bad, 0, sizeof(unsigned long long)));
+  }
+  for (auto &s : p->slots) {
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&s.h_dyn), nc * sizeof(FcpColDyn), hipHostMallocDefault));
+    HIP_TRY(hipMalloc(&s.d_dyn, nc * sizeof(FcpColDyn)));
+    HIP_TRY(hipEventCreateWithFlags(&s.uploaded, hipEventDisableTiming));
+  }
+  p->bound_tables.assign(p->desc.n_device_inputs, nullptr);
+  return FCP_OK;
+}
+
+// Bind the table addresses (FeatureColumnProcess `inputs`).  TF variables keep
+// their address between requests, so this uploads once.
+int bind_tables(fcp_plan *p, const void *const *input_ptrs) {
+  const int nt = p->desc.n_device_inputs;
+  if (p->tables_bound && std::memcmp(p->bound_tables.data(), input_ptrs, nt * sizeof(void *)) == 0)
+    return FCP_OK;
+  if (p->tables_bound) HIP_TRY(hipDeviceSynchronize()); // in-flight requests still read the old table
+  for (int t = 0; t < nt; ++t) p->bound_tables[t] = input_ptrs[t];
+  for (size_t k = 0; k < p->cols.size(); ++k) {
+    const int t = p->cols[k].d.table_input;
+    const bool lookup = p->cols[k].d.form == FCP_FORM_GATHER || p->cols[k].d.form == FCP_FORM_SEGMENT_REDUCE ||
+                        p->cols[k].d.form == FCP_FORM_GATHER_SCATTER;
+    if (lookup) {
+      if (!input_ptrs[t]) return fail(FCP_ERR_INVALID_ARGUMENT, "null table pointer");
+      p->h_cols[k].table = static_cast<const float *>(input_ptrs[t]);
+    }
+  }
+  HIP_TRY(hipMemcpy(p->d_cols, p->h_cols.data(), p->h_cols.size() * sizeof(FcpColStatic),
+                    hipMemcpyHostToDevice));
+  p->tables_bound = true;
+  return FCP_OK;
+}
+
+// Find or build the device-resident dynamic descriptors for these shapes.
+int acquire_slot(fcp_plan *p, const fcp_process_args_t *a, DynSlot **out) {
+  const int nh = (int)p->ranks.size();
+  const int nsym = a->symbols ? p->desc.n_symbols : 0;
+  const size_t key_len = (size_t)nh + p->rank_sum + nsym + 1;
+  thread_local std::vector<int32_t> key;
+  key.resize(key_len);
+  std::memcpy(key.data(), a->concated_offsets, nh * sizeof(int32_t));
+  std::memcpy(key.data() + nh, a->concated_shapes, p->rank_sum * sizeof(int32_t));
+  if (nsym) std::memcpy(key.data() + nh + p->rank_sum, a->symbols, nsym * sizeof(int32_t));
+  key[key_len - 1] = (int32_t)std::min<int64_t>(a->concated_bytes, 0x7fffffff);
+
+  ++p->tick;
+  DynSlot *victim = &p->slots[0];
+  for (auto &s : p->slots) {
+    if (s.valid && s.key == key) {
+      s.tick = p->tick;
+      if (s.stream != a->stream) { // another stream: order after the upload
+        HIP_TRY(hipStreamWaitEvent(static_cast<hipStream_t>(a->stream), s.uploaded, 0));
+        s.multi = true;
+      }
+      *out = &s;
+      return FCP_OK;
+    }
+    if (!s.valid) {
+      if (victim->valid) victim = &s;
+    } else if (victim->valid && s.tick < victim->tick) {
+      victim = &s;
+    }
+  }
+  DynSlot &s = *victim;
+  if (s.valid) {
+    // The pinned mirror may still be the source of an earlier async copy, and
+    // kernels of other streams may still read the device copy.
+    HIP_TRY(hipEventSynchronize(s.uploaded));
+    if (s.multi || s.stream != a->stream) HIP_TRY(hipDeviceSynchronize());
+  }
+  s.valid = false;
+  int rc = compute_dyn(p, a->concated_offsets, a->concated_shapes, a->symbols, a->concated_bytes, s.h_dyn,
+                       &s.meta);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(s.d_dyn, s.h_dyn, p->cols.size() * sizeof(FcpColDyn), hipMemcpyHostToDevice,
+                         static_cast<hipStream_t>(a->stream)));
+  HIP_TRY(hipEventRecord(s.uploaded, static_cast<hipStream_t>(a->stream)));
+  s.key = key;
+  s.stream = a->stream;
+  s.multi = false;
+  s.tick = p->tick;
+  s.valid = true;
+  *out = &s;
+  return FCP_OK;
+}
+
+void fill_launch(const fcp_plan *p, const DynSlot &s, const void *blob, void *arena, FcpLaunch *L) {
+  L->slot_map = p->d_slot_map;
+  L->cols = p->d_cols;
+  L->dyn = s.d_dyn;
+  L->blob = static_cast<const char *>(blob);
+  L->arena = static_cast<char *>(arena);
+  L->bad_ids = p->d_bad;
+  L->csr_arena_off = s.meta.csr_arena_off;
+  L->shard_rank = p->desc.shard_rank;
+  L->shard_world = p->desc.shard_world;
+  L->n_groups = p->desc.n_groups;
+  L->rows_per_wave = s.meta.rows_per_wave;
+  for (int g = 0; g < p->desc.n_groups; ++g) L->groups[g] = s.meta.groups[g];
+}
+
+} // namespace
+
+// =============================== C ABI ======================================
+extern "C" {
+
+int fcp_abi_version(void) { return FCP_ABI_VERSION; }
+
+const char *fcp_status_string(int status) {
+  switch (status) {
+  case FCP_OK: return "ok";
+  case FCP_ERR_INVALID_ARGUMENT: return "invalid argument";
+  case FCP_ERR_SHAPE_MISMATCH: return "run-time shapes do not match the plan";
+  case FCP_ERR_ALLOC: return "allocator callback failed";
+  case FCP_ERR_HIP: return "HIP runtime error";
+  case FCP_ERR_UNSUPPORTED: return "unsupported";
+  case FCP_ERR_NO_DEVICE: return "no usable gfx950 device";
+  default: return "unknown status";
+  }
+}
+
+const char *fcp_last_error(void) { return g_last_error.c_str(); }
+
+// ---- Addons>ConcatInputs, concat_inputs_ops.cc:42-77 -------------------------
+int fcp_concat_inputs_sizes(const fcp_host_tensor_t *inputs, int32_t n, int64_t *blob_bytes,
+                            int32_t *rank_sum) {
+  if (n < 0 || (n > 0 && !inputs)) return fail(FCP_ERR_INVALID_ARGUMENT, "null inputs");
+  int64_t bytes = 0;
+  int32_t ranks = 0;
+  for (int32_t i = 0; i < n; ++i) {
+    const fcp_host_tensor_t &t = inputs[i];
+    if (t.rank < 0 || t.elem_size <= 0 || (t.rank > 0 && !t.dims))
+      return fail(FCP_ERR_INVALID_ARGUMENT, "bad host tensor");
+    int64_t ne = 1;
+    for (int32_t j = 0; j < t.rank; ++j) {
+      if (t.dims[j] < 0) return fail(FCP_ERR_INVALID_ARGUMENT, "negative dimension");
+      ne *= t.dims[j];
+    }
+    bytes += ne * t.elem_size;
+    ranks += t.rank;
+  }
+  if (blob_bytes) *blob_bytes = bytes;
+  if (rank_sum) *rank_sum = ranks;
+  return FCP_OK;
+}
+
+int fcp_concat_inputs(const fcp_host_tensor_t *inputs, int32_t n, void *blob, int64_t blob_capacity,
+                      int32_t *offsets, int32_t *shapes) {
+  int64_t need = 0;
+  int rc = fcp_concat_inputs_sizes(inputs, n, &need, nullptr);
+  if (rc) return rc;
+  if (n > 0 && (!offsets || !shapes)) return fail(FCP_ERR_INVALID_ARGUMENT, "null outputs");
+  if (need > blob_capacity || (need > 0 && !blob)) return fail(FCP_ERR_INVALID_ARGUMENT, "blob too small");
+  // The reference keeps offsets in int32 (:52-60); refuse what it would overflow.
+  if (need > 0x7fffffff) return fail(FCP_ERR_UNSUPPORTED, "blob larger than 2^31 bytes (int32 offsets)");
+  char *itr = static_cast<char *>(blob);
+  int64_t size = 0;
+  int32_t *shape_itr = shapes;
+  for (int32_t i = 0; i < n; ++i) {
+    const fcp_host_tensor_t &t = inputs[i];
+    int64_t ne = 1;
+    for (int32_t j = 0; j < t.rank; ++j) {
+      ne *= t.dims[j];
+      *(shape_itr++) = (int32_t)t.dims[j];
+    }
+    const int64_t nb = ne * t.elem_size;
+    offsets[i] = (int32_t)size;
+    if (nb) {
+      if (!t.data) return fail(FCP_ERR_INVALID_ARGUMENT, "null tensor data");
+      std::memcpy(itr, t.data, (size_t)nb);
+    }
+    itr += nb;
+    size += nb;
+  }
+  return FCP_OK;
+}
+
+// ---- plan ---------------------------------------------------------------------
+int fcp_plan_create(const fcp_plan_desc_t *desc, fcp_plan_t **out) {
+  if (!out) return fail(FCP_ERR_INVALID_ARGUMENT, "null plan out pointer");
+  *out = nullptr;
+  int rc = validate_desc(desc);
+  if (rc) return rc;
+  fcp_plan *p = new (std::nothrow) fcp_plan();
+  if (!p) return fail(FCP_ERR_ALLOC, "out of host memory");
+  p->desc = *desc;
+  p->desc.columns = nullptr;
+  p->desc.host_input_ranks = nullptr;
+  p->desc.host_input_elem_sizes = nullptr;
+  p->host_only = (desc->flags & kFlagHostOnly) != 0;
+  p->ranks.assign(desc->host_input_ranks, desc->host_input_ranks + desc->n_host_inputs);
+  p->elem_sizes.assign(desc->host_input_elem_sizes, desc->host_input_elem_sizes + desc->n_host_inputs);
+  p->shape_off.resize(desc->n_host_inputs);
+  int32_t acc = 0;
+  for (int i = 0; i < desc->n_host_inputs; ++i) {
+    p->shape_off[i] = acc;
+    acc += p->ranks[i];
+  }
+  p->rank_sum = acc;
+  p->cols.resize(desc->n_columns);
+  int gcd4 = 4;
+  for (int k = 0; k < desc->n_columns; ++k) {
+    HostColumn &hc = p->cols[k];
+    hc.d = desc->columns[k];
+    if (hc.d.id_source == FCP_IDS_F32_BUCKETIZE && hc.d.boundaries && hc.d.n_boundaries > 0 &&
+        hc.d.form != FCP_FORM_PASSTHROUGH && hc.d.form != FCP_FORM_BATCH_COL_REDUCTION)
+      hc.boundaries.assign(hc.d.boundaries, hc.d.boundaries + hc.d.n_boundaries);
+    hc.d.boundaries = nullptr;
+    if (hc.d.dim % 4) gcd4 = (hc.d.dim % 2) ? 1 : std::min(gcd4, 2);
+    const int f = hc.d.form;
+    if (f != FCP_FORM_GATHER && f != FCP_FORM_PASSTHROUGH) p->dense_only = false;
+    if ((f == FCP_FORM_SEGMENT_REDUCE || f == FCP_FORM_GATHER_SCATTER) && hc.d.seg_kind != FCP_SEG_CSR_I32)
+      p->seg_cols.push_back(k);
+  }
+  p->vec = gcd4;
+  // concat layout: offsets = prefix sums of dims in slot order
+  // (concat_outputs_op_gpu.cu.cc:74-79)
+  const int ng = desc->n_groups;
+  p->group_width.assign(ng, 0);
+  p->group_nslots.assign(ng, 0);
+  p->group_map_off.assign(ng, 0);
+  for (int g = 0; g < ng; ++g) {
+    std::vector<int> members;
+    for (int k = 0; k < desc->n_columns; ++k)
+      if (p->cols[k].d.concat_group == g) members.push_back(k);
+    if (members.empty()) {
+      delete p;
+      return fail(FCP_ERR_INVALID_ARGUMENT, "concat group without columns");
+    }
+    std::sort(members.begin(), members.end(),
+              [&](int a, int b) { return p->cols[a].d.concat_slot < p->cols[b].d.concat_slot; });
+    int32_t off = 0;
+    for (int k : members) {
+      p->cols[k].out_off = off;
+      off += p->cols[k].d.dim;
+    }
+    p->group_width[g] = off;
+    p->group_nslots[g] = off / p->vec;
+  }
+  if (!p->host_only) {
+    rc = init_device(p);
+    if (rc) {
+      destroy_device(p);
+      delete p;
+      return rc;
+    }
+  } else {
+    int32_t off = 0;
+    for (int g = 0; g < ng; ++g) {
+      p->group_map_off[g] = off;
+      off += p->group_nslots[g];
+    }
+  }
+  *out = p;
+  return FCP_OK;
+}
+
+int fcp_plan_destroy(fcp_plan_t *p) {
+  if (!p) return FCP_OK;
+  if (!p->host_only) {
+    DeviceGuard guard;
+    if (guard.enter(p->desc.device) == FCP_OK) {
+      (void)hipDeviceSynchronize();
+      destroy_device(p);
+    }
+  }
+  delete p;
+  return FCP_OK;
+}
+
+int fcp_plan_group_width(const fcp_plan_t *p, int32_t group, int32_t *width) {
+  if (!p || !width || group < 0 || group >= p->desc.n_groups)
+    return fail(FCP_ERR_INVALID_ARGUMENT, "bad group");
+  *width = p->group_width[group];
+  return FCP_OK;
+}
+
+int fcp_plan_column_offset(const fcp_plan_t *p, int32_t column, int32_t *offset) {
+  if (!p || !offset || column < 0 || column >= (int32_t)p->cols.size())
+    return fail(FCP_ERR_INVALID_ARGUMENT, "bad column");
+  *offset = p->cols[column].out_off;
+  return FCP_OK;
+}
+
+int fcp_plan_arena_bytes(fcp_plan_t *p, const int32_t *concated_shapes, const int32_t *symbols,
+                         int64_t *bytes) {
+  if (!p || !concated_shapes || !bytes) return fail(FCP_ERR_INVALID_ARGUMENT, "null argument");
+  std::vector<FcpColDyn> dyn(p->cols.size());
+  std::vector<int32_t> offsets(p->ranks.size(), 0);
+  DynMeta m;
+  int rc = compute_dyn(p, offsets.data(), concated_shapes, symbols, -1, dyn.data(), &m);
+  if (rc) return rc;
+  *bytes = m.arena_bytes;
+  return FCP_OK;
+}
+
+int fcp_plan_read_bad_ids(fcp_plan_t *p, void *stream, int64_t *count) {
+  if (!p || !count) return fail(FCP_ERR_INVALID_ARGUMENT, "null argument");
+  *count = 0;
+  if (p->host_only) return fail(FCP_ERR_NO_DEVICE, "host-only plan");
+  if (!p->d_bad) return FCP_OK;
+  DeviceGuard guard;
+  int rc = guard.enter(p->desc.device);
+  if (rc) return rc;
+  unsigned long long v = 0;
+  HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+  HIP_TRY(hipMemcpy(&v, p->d_bad, sizeof(v), hipMemcpyDeviceToHost));
+  *count = (int64_t)v;
+  return FCP_OK;
+}
+
+// ---- ProcessFeatureColumns ------------------------------------------------------
+int fcp_process_feature_columns(fcp_plan_t *p, const fcp_process_args_t *a, fcp_process_result_t *r) {
+  if (!p || !a) return fail(FCP_ERR_INVALID_ARGUMENT, "null plan / args");
+  if (p->host_only) return fail(FCP_ERR_NO_DEVICE, "host-only plan cannot run");
+  if (!a->concated_offsets || !a->concated_shapes) {
+    if (!p->ranks.empty()) return fail(FCP_ERR_INVALID_ARGUMENT, "null offsets / shapes");
+  }
+  if (!a->malloc_buff) return fail(FCP_ERR_INVALID_ARGUMENT, "malloc_buff callback is required");
+  if (p->desc.n_device_inputs > 0 && !a->input_ptrs) return fail(FCP_ERR_INVALID_ARGUMENT, "null input_ptrs");
+  if (p->desc.n_symbols > 0 && !a->symbols) return fail(FCP_ERR_INVALID_ARGUMENT, "plan needs symbols");
+  if (a->input_shapes) { // optional cross-check of the table shapes
+    for (const HostColumn &hc : p->cols) {
+      const int f = hc.d.form;
+      if (f == FCP_FORM_PASSTHROUGH || f == FCP_FORM_BATCH_COL_REDUCTION) continue;
+      const int32_t *s = a->input_shapes + 2 * hc.d.table_input;
+      const int64_t local_vocab = p->desc.shard_world > 1
+                                      ? (hc.d.vocab - p->desc.shard_rank + p->desc.shard_world - 1) / p->desc.shard_world
+                                      : hc.d.vocab;
+      if (s[0] != local_vocab || s[1] != hc.d.dim)
+        return fail(FCP_ERR_SHAPE_MISMATCH, "table shape does not match the plan");
+    }
+  }
+  DeviceGuard guard;
+  int rc = guard.enter(p->desc.device);
+  if (rc) return rc;
+  hipStream_t stream = static_cast<hipStream_t>(a->stream);
+
+  std::lock_guard<std::mutex> lock(p->mu);
+  if (p->desc.n_device_inputs > 0) {
+    rc = bind_tables(p, a->input_ptrs);
+    if (rc) return rc;
+  }
+  DynSlot *slot = nullptr;
+  rc = acquire_slot(p, a, &slot);
+  if (rc) return rc;
+  const DynMeta &m = slot->meta;
+  if (m.arena_bytes > 0 && !a->concated_inputs && !p->ranks.empty())
+    return fail(FCP_ERR_INVALID_ARGUMENT, "null blob");
+
+  void *arena = a->malloc_buff(a->malloc_buff_ctx, (size_t)std::max<int64_t>(m.arena_bytes, 1));
+  if (!arena) return fail(FCP_ERR_ALLOC, "malloc_buff returned NULL");
+
+  FcpLaunch L;
+  fill_launch(p, *slot, a->concated_inputs, arena, &L);
+  if (!p->seg_cols.empty()) {
+    FcpSegLaunch S;
+    S.seg_cols = p->d_seg_cols;
+    S.cols = p->d_cols;
+    S.dyn = slot->d_dyn;
+    S.blob = L.blob;
+    S.arena = L.arena;
+    S.csr_arena_off = m.csr_arena_off;
+    const int e = fcp_launch_segment_offsets(S, (int)p->seg_cols.size(), m.max_seg_nnz, stream);
+    if (e) return hip_fail("segment-offsets launch", (hipError_t)e);
+  }
+  const int e = fcp_launch_fused(L, p->vec, p->dense_only, m.grid_blocks, stream);
+  if (e) return hip_fail("fused kernel launch", (hipError_t)e);
+
+  if (r) {
+    const int nc = (int)p->cols.size();
+    for (int k = 0; k < nc; ++k) {
+      if (r->output_ptrs) r->output_ptrs[k] = static_cast<char *>(arena) + slot->h_dyn[k].out_base;
+      if (r->output_shapes) {
+        r->output_shapes[2 * k] = slot->h_dyn[k].rows;
+        r->output_shapes[2 * k + 1] = p->cols[k].d.dim;
+      }
+      if (r->output_row_strides) r->output_row_strides[k] = slot->h_dyn[k].out_stride;
+    }
+    for (int g = 0; g < p->desc.n_groups; ++g) {
+      if (r->group_ptrs)
+        r->group_ptrs[g] = p->desc.layout == FCP_LAYOUT_CONCAT ? static_cast<char *>(arena) + m.group_base[g] : nullptr;
+      if (r->group_shapes) {
+        r->group_shapes[2 * g] = m.group_rows[g];
+        r->group_shapes[2 * g + 1] = p->group_width[g];
+      }
+    }
+    r->buffer = arena;
+    r->buffer_bytes = m.arena_bytes;
+  }
+  return FCP_OK;
+}
+
+// ---- ConcatOutputs ----------------------------------------------------------------
+int fcp_concat_outputs(const void *const *inputs, const int32_t *dims, int32_t n, int64_t prefix_size,
+                       void *out, void *stream) {
+  if (n < 0 || prefix_size < 0) return fail(FCP_ERR_INVALID_ARGUMENT, "negative size");
+  if (n == 0 || prefix_size == 0) return FCP_OK;
+  if (!inputs || !dims || !out) return fail(FCP_ERR_INVALID_ARGUMENT, "null argument");
+  int64_t width = 0;
+  for (int32_t k = 0; k < n; ++k) {
+    if (dims[k] <= 0 || !inputs[k]) return fail(FCP_ERR_INVALID_ARGUMENT, "bad concat input");
+    width += dims[k];
+  }
+  if (width > 0x7fffffff) return fail(FCP_ERR_UNSUPPORTED, "concat width exceeds 2^31");
+  const int e = fcp_launch_concat_outputs(inputs, dims, n, prefix_size, (int32_t)width, 0, out,
+                                          static_cast<hipStream_t>(stream));
+  if (e) return hip_fail("concat-outputs launch", (hipError_t)e);
+  return FCP_OK;
+}
+
+// ---- row-shard finalize -------------------------------------------------------------
+int fcp_shard_finalize(fcp_plan_t *p, const fcp_process_args_t *a, int32_t group, const void *partial_slices,
+                       int32_t world, int64_t row_begin, int64_t row_count, void *out, void *stream_) {
+  if (!p || !a || !partial_slices || !out) return fail(FCP_ERR_INVALID_ARGUMENT, "null argument");
+  if (p->host_only) return fail(FCP_ERR_NO_DEVICE, "host-only plan cannot run");
+  if (group < 0 || group >= p->desc.n_groups || world < 1 || row_begin < 0 || row_count < 0)
+    return fail(FCP_ERR_INVALID_ARGUMENT, "bad group / world / rows");
+  if (row_count > 65535) return fail(FCP_ERR_UNSUPPORTED, "row_count > 65535 per finalize call");
+  DeviceGuard guard;
+  int rc = guard.enter(p->desc.device);
+  if (rc) return rc;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  fcp_process_args_t args = *a;
+  args.stream = stream_;
+  std::lock_guard<std::mutex> lock(p->mu);
+  DynSlot *slot = nullptr;
+  rc = acquire_slot(p, &args, &slot);
+  if (rc) return rc;
+  const DynMeta &m = slot->meta;
+  if (row_begin + row_count > m.group_rows[group]) return fail(FCP_ERR_SHAPE_MISMATCH, "row slice out of range");
+  FcpLaunch L;
+  void *scratch = nullptr;
+  bool need_csr = false;
+  for (int k : p->seg_cols)
+    if (p->cols[k].d.form == FCP_FORM_SEGMENT_REDUCE && p->cols[k].d.combiner == FCP_COMBINER_MEAN) need_csr = true;
+  if (need_csr) {
+    if (!a->malloc_temp) return fail(FCP_ERR_INVALID_ARGUMENT, "malloc_temp is required for mean columns with segment ids");
+    const int64_t bytes = m.arena_bytes - m.csr_arena_off;
+    scratch = a->malloc_temp(a->malloc_temp_ctx, (size_t)std::max<int64_t>(bytes, 1));
+    if (!scratch) return fail(FCP_ERR_ALLOC, "malloc_temp returned NULL");
+  }
+  fill_launch(p, *slot, a->concated_inputs, scratch, &L);
+  L.csr_arena_off = 0;
+  if (need_csr) {
+    FcpSegLaunch S;
+    S.seg_cols = p->d_seg_cols;
+    S.cols = p->d_cols;
+    S.dyn = slot->d_dyn;
+    S.blob = L.blob;
+    S.arena = static_cast<char *>(scratch);
+    S.csr_arena_off = 0;
+    const int e = fcp_launch_segment_offsets(S, (int)p->seg_cols.size(), m.max_seg_nnz, stream);
+    if (e) return hip_fail("segment-offsets launch", (hipError_t)e);
+  }
+  const int e = fcp_launch_shard_finalize(L, group, static_cast<const float *>(partial_slices), world, row_begin,
+                                          row_count, static_cast<float *>(out), p->vec, stream);
+  if (e) return hip_fail("shard-finalize launch", (hipError_t)e);
+  return FCP_OK;
+}
+
+} // extern "C"

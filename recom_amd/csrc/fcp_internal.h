@@ -1,0 +1,94 @@
+// fcp_internal.h — device-visible plan records shared by the host side
+// (fcp_api.hip) and the kernels (fcp_kernels.hip).  gfx950 only.
+//
+// What the reference passes to its generated kernel as one flat `KnlArgs`
+// struct of per-model pointers and ints (graph_optimizers/cuda_emitter.cc
+// :2059-2087, uploaded H2D on every call :2182-2217) is split here into
+//   * FcpColStatic[]  — per-column facts fixed at plan creation (+ table bind),
+//   * FcpColDyn[]     — per-column facts that follow the request's shapes,
+//   * FcpLaunch       — a few scalars passed by value as the kernel argument.
+// Only FcpColDyn is re-uploaded, and only when the request's shapes differ from
+// the previous request's (steady-state serving uploads nothing).
+#pragma once
+#include <stdint.h>
+
+#define FCP_MAX_GROUPS 16
+#define FCP_BLOCK_THREADS 256
+#define FCP_WAVES_PER_BLOCK 4
+#define FCP_WAVE 64
+
+// flags layout of FcpColStatic::flags
+#define FCP_F_FORM(f) ((f) & 0xFu)
+#define FCP_F_COMBINER(f) (((f) >> 4) & 0xFu)
+#define FCP_F_IDSRC(f) (((f) >> 8) & 0xFu)
+#define FCP_F_SEGKIND(f) (((f) >> 12) & 0xFu)
+#define FCP_F_PACK(form, comb, idsrc, segkind) \
+  ((uint32_t)(form) | ((uint32_t)(comb) << 4) | ((uint32_t)(idsrc) << 8) | ((uint32_t)(segkind) << 12))
+
+struct FcpColStatic {      // 48 bytes
+  const float *table;      // device address of the table (bound from input_ptrs)
+  const float *boundaries; // device const buffer (CreateConstBuffers, :2260-2301)
+  int64_t vocab;           // global vocabulary (rows of the unsharded table)
+  int32_t dim;
+  int32_t out_off;         // element offset of the column in its concat row
+  uint32_t flags;          // FCP_F_PACK(...)
+  int32_t n_boundaries;
+  int32_t seg_stride;
+  int32_t group;
+};
+
+struct FcpColDyn {         // 48 bytes
+  int64_t ids_off;         // byte offset of the id / value / payload stream in the blob
+  int64_t seg_off;         // byte offset of seg ids / CSR offsets in the blob
+  int64_t out_base;        // byte offset in the arena of element (0,0) of this column
+  int32_t out_stride;      // row stride of the output in elements
+  int32_t nnz;             // number of ids
+  int32_t csr_base;        // int32 index into the arena CSR scratch (seg-id columns), or -1
+  int32_t inner;           // BatchColReduction: rows reduced per output row
+  int32_t rows;            // output rows (prefix size) of this column
+  int32_t pad_;
+};
+
+struct FcpGroupLaunch {
+  int32_t rows;            // prefix size of the group
+  int32_t nslots;          // concat row width in V-element slots
+  int32_t nsp8;            // ceil(nspans / 8): spans per XCD
+  int32_t block_begin;     // first block of this group in the grid
+  int32_t slot_map_off;    // offset of the group's slot map
+  int32_t pad_;
+};
+
+struct FcpLaunch {
+  const uint32_t *slot_map;  // slot -> column index
+  const FcpColStatic *cols;
+  const FcpColDyn *dyn;
+  const char *blob;
+  char *arena;
+  unsigned long long *bad_ids; // nullable
+  int64_t csr_arena_off;       // byte offset of the CSR scratch inside the arena
+  int32_t shard_rank, shard_world;
+  int32_t n_groups;
+  int32_t rows_per_wave;
+  FcpGroupLaunch groups[FCP_MAX_GROUPS];
+};
+
+// Segment-offset pre-pass (ComputeSegmentOffsets, cuda_emitter.cc:768-818)
+struct FcpSegLaunch {
+  const int32_t *seg_cols;   // indices of the columns whose seg_kind is IDS_*
+  const FcpColStatic *cols;
+  const FcpColDyn *dyn;
+  const char *blob;
+  char *arena;
+  int64_t csr_arena_off;     // byte offset of the CSR scratch in the arena
+};
+
+// ---- launchers implemented in fcp_kernels.hip --------------------------------
+struct ihipStream_t;
+int fcp_launch_fused(const FcpLaunch &L, int vec, bool dense_only, int grid_blocks, ihipStream_t *s);
+int fcp_launch_segment_offsets(const FcpSegLaunch &L, int n_seg_cols, int max_nnz, ihipStream_t *s);
+int fcp_launch_concat_outputs(const void *const *inputs, const int32_t *dims, int32_t n,
+                              int64_t prefix, int32_t width, int32_t first_off, void *out,
+                              ihipStream_t *s);
+int fcp_launch_shard_finalize(const FcpLaunch &L, int group, const float *partials, int world,
+                              int64_t row_begin, int64_t row_count, float *out, int vec,
+                              ihipStream_t *s);

@@ -1,0 +1,497 @@
+// fcp_kernels.hip — hand-written gfx950 (CDNA4, MI355X) kernels of the fused
+// feature-column path.  HBM-bound gather / pool / concat: no MFMA on purpose.
+//
+// Replaces, for every model, what the reference generates as CUDA text:
+//   FusedKnl + struct FCi            graph_optimizers/cuda_emitter.cc:1976-2134
+//   Bucketize                        :233-247
+//   GatherRowsToGlbMem               :250-293
+//   GatherScatterRows                :296-345
+//   SparseSegmentSum / Mean          :402-501 / :564-661
+//   experiment::ComputeSegmentOffsets / SparseSegmentReduce   :768-962
+//   BatchColReduction                :1216-1241
+//   ConcatOutputsKnl / ScatterBlock  custom_ops/concat_outputs/concat_outputs_op_gpu.cu.cc:85-131
+//
+// Work decomposition (the MI355X-first part).  The reference launches ONE
+// 64-thread block per column (`FusedKnl<<<num_fc, 64>>>`, :2234) which walks
+// the whole batch serially — at most #columns waves on the chip.  Here the unit
+// of work is a *slot* of the concatenated output row: the output matrix
+// [rows, sum(dim)] of a concat group is cut into V-float slots (V = 4 when all
+// dims are multiples of 4: one 16-byte access per lane); a wave owns 64
+// consecutive slots (1 KiB of one output row — spanning as many neighbouring
+// columns as fit) for R consecutive batch rows, a 256-thread block owns that
+// span for 4*R rows.  Consequences:
+//   * every store instruction of a wave writes 1 KiB contiguous bytes of the
+//     final concat layout — the concat pass and its intermediate arena vanish;
+//   * a table row of dim floats is read by dim/4 adjacent lanes as one
+//     contiguous run (coalesced into whole 64/128-byte requests);
+//   * the 8 ids (64 B) a wave needs from one column for its R=8 rows share a
+//     cache line, and all lanes of that column broadcast one address;
+//   * 1000 columns x batch 512 give ~1900 blocks / ~7500 waves instead of 1000
+//     waves, enough to keep >16 MB of loads in flight (HBM latency x bandwidth);
+//   * blocks that share a span (the same columns / tables) are given the same
+//     `blockIdx % 8`, i.e. the same XCD and L2 under round-robin dispatch, so
+//     skewed (Zipf) ids and small bucketize tables are served from one L2.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/fcp_hip.h"
+#include "fcp_internal.h"
+
+namespace {
+
+template <int V> struct alignas(4 * V) VF { float v[V]; };
+
+template <int V> __device__ __forceinline__ VF<V> vzero() {
+  VF<V> r;
+#pragma unroll
+  for (int i = 0; i < V; ++i) r.v[i] = 0.0f;
+  return r;
+}
+
+// Blob tensors are only guaranteed 4-byte aligned (ConcatInputs packs bytes
+// back to back, concat_inputs_ops.cc:52-60), so 8-byte ids are read as two
+// dwords.
+__device__ __forceinline__ int64_t ld_i64_a4(const char *p) {
+  const uint32_t *q = reinterpret_cast<const uint32_t *>(p);
+  const uint32_t lo = q[0], hi = q[1];
+  return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
+template <int V> __device__ __forceinline__ VF<V> ld_blob_f32(const char *p) {
+  VF<V> r;
+  const float *q = reinterpret_cast<const float *>(p);
+#pragma unroll
+  for (int i = 0; i < V; ++i) r.v[i] = q[i];
+  return r;
+}
+
+// cuda_emitter.cc:233-247 — r+1 = number of boundaries <= value.
+__device__ __forceinline__ int bucketize(const float *__restrict__ b, int n, float value) {
+  int l = 0, r = n - 1;
+  while (l <= r) {
+    const int mid = (l + r) >> 1;
+    if (value < b[mid]) {
+      r = mid - 1;
+    } else {
+      l = mid + 1;
+    }
+  }
+  return r + 1;
+}
+
+// The index expression the reference inlines per column (EmitInputInline,
+// :1769-1949): raw int32 / int64 ids, or Bucketize(float value).
+__device__ __forceinline__ int64_t load_id(const char *ids, unsigned idsrc, int64_t p,
+                                           const float *bnd, int nb) {
+  if (idsrc == FCP_IDS_I64) return ld_i64_a4(ids + 8 * p);
+  if (idsrc == FCP_IDS_I32) return *reinterpret_cast<const int32_t *>(ids + 4 * p);
+  return bucketize(bnd, nb, *reinterpret_cast<const float *>(ids + 4 * p));
+}
+
+// Validity + row sharding.  Returns true when this GPU must read a row; `id`
+// becomes the local row.  Ids outside [0, vocab) read as zeros (the reference
+// reads out of bounds, TF-GPU GatherV2 returns zeros).
+__device__ __forceinline__ bool resolve_id(int64_t &id, int64_t vocab, int rank, int world,
+                                           bool &bad) {
+  bad = (uint64_t)id >= (uint64_t)vocab;
+  if (bad) return false;
+  if (world > 1) {
+    int64_t q;
+    if (id < 0x7fffffffLL) {
+      q = (int64_t)((uint32_t)id / (uint32_t)world);
+    } else {
+      q = id / world;
+    }
+    if (id - q * world != rank) return false;
+    id = q;
+  }
+  return true;
+}
+
+template <int V>
+__device__ __forceinline__ VF<V> ld_row(const float *__restrict__ table, int64_t id, int dim, int e) {
+  return *reinterpret_cast<const VF<V> *>(table + id * (int64_t)dim + e);
+}
+
+template <int V> __device__ __forceinline__ void st_out(float *p, const VF<V> &v) {
+  *reinterpret_cast<VF<V> *>(p) = v;
+}
+
+// ---------------------------------------------------------------------------
+// The fused kernel.  DENSE = every column of the plan is GATHER or PASSTHROUGH
+// (exactly one source row per output row): R rows per wave, fully unrolled,
+// all id loads issued before all row loads before all stores.  Otherwise the
+// generic per-row path with the ragged segment loop.
+// ---------------------------------------------------------------------------
+template <int V, bool DENSE, int R>
+__global__ void __launch_bounds__(FCP_BLOCK_THREADS) fcp_fused_kernel(const FcpLaunch L) {
+  int bid = blockIdx.x;
+  int g = 0;
+  for (int k = 1; k < L.n_groups; ++k)
+    if (bid >= L.groups[k].block_begin) g = k;
+  const int rows = L.groups[g].rows;
+  const int nslots = L.groups[g].nslots;
+  const int nsp8 = L.groups[g].nsp8;
+  bid -= L.groups[g].block_begin;
+
+  // XCD-aware mapping: blocks with equal (bid & 7) share an XCD under the
+  // round-robin dispatch; give them the same spans (same columns / tables).
+  const int xcd = bid & 7, j = bid >> 3;
+  const int span = (j % nsp8) * 8 + xcd;
+  const int tile = j / nsp8;
+  const int lane = threadIdx.x & (FCP_WAVE - 1);
+  const int wave = threadIdx.x >> 6;
+  const int q = span * FCP_WAVE + lane;
+  const int rpw = DENSE ? R : L.rows_per_wave;
+  const int row0 = (tile * FCP_WAVES_PER_BLOCK + wave) * rpw;
+  if (q >= nslots || row0 >= rows) return;
+
+  const uint32_t c = L.slot_map[L.groups[g].slot_map_off + q];
+  const FcpColStatic cs = L.cols[c];
+  const FcpColDyn cd = L.dyn[c];
+  const int e = q * V - cs.out_off;
+  const unsigned form = FCP_F_FORM(cs.flags);
+  const unsigned idsrc = FCP_F_IDSRC(cs.flags);
+  const char *ids = L.blob + cd.ids_off;
+  float *outp = reinterpret_cast<float *>(L.arena + cd.out_base) + e;
+  const int64_t ostride = cd.out_stride;
+  const int world = L.shard_world, rank = L.shard_rank;
+
+  if (DENSE) {
+    VF<V> v[R];
+    if (form == FCP_FORM_PASSTHROUGH) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int b = row0 + r;
+        v[r] = vzero<V>();
+        // table-free columns belong to shard rank 0
+        if (b < rows && rank == 0) v[r] = ld_blob_f32<V>(ids + 4 * ((int64_t)b * cs.dim + e));
+      }
+    } else {
+      int64_t id[R];
+      bool ok[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int b = row0 + r;
+        id[r] = 0;
+        ok[r] = false;
+        if (b < rows) {
+          id[r] = load_id(ids, idsrc, b, cs.boundaries, cs.n_boundaries);
+          bool bad;
+          ok[r] = resolve_id(id[r], cs.vocab, rank, world, bad);
+          if (bad && e == 0 && L.bad_ids) atomicAdd(L.bad_ids, 1ull);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        v[r] = vzero<V>();
+        if (ok[r]) v[r] = ld_row<V>(cs.table, id[r], cs.dim, e);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int b = row0 + r;
+      if (b < rows) st_out<V>(outp + (int64_t)b * ostride, v[r]);
+    }
+    return;
+  }
+
+  // ---- generic path: one output row at a time, ragged segment loop ---------
+  const unsigned segkind = FCP_F_SEGKIND(cs.flags);
+  const bool mean = FCP_F_COMBINER(cs.flags) == FCP_COMBINER_MEAN && world == 1;
+  const int32_t *csr = nullptr;
+  if (segkind == FCP_SEG_CSR_I32) {
+    csr = reinterpret_cast<const int32_t *>(L.blob + cd.seg_off);
+  } else if (segkind != FCP_SEG_NONE) {
+    csr = reinterpret_cast<const int32_t *>(L.arena + L.csr_arena_off) + cd.csr_base;
+  }
+  const int nnz = cd.nnz;
+
+  for (int r = 0; r < rpw; ++r) {
+    const int b = row0 + r;
+    if (b >= rows) break;
+    VF<V> acc = vzero<V>();
+    if (form == FCP_FORM_PASSTHROUGH) {
+      if (rank == 0) acc = ld_blob_f32<V>(ids + 4 * ((int64_t)b * cs.dim + e));
+    } else if (form == FCP_FORM_BATCH_COL_REDUCTION) {
+      // cuda_emitter.cc:1231-1236: r ascending, sequential fp32 adds
+      const int inner = rank == 0 ? cd.inner : 0; // table-free columns belong to shard rank 0
+      for (int rr = 0; rr < inner; ++rr) {
+        const VF<V> x = ld_blob_f32<V>(ids + 4 * (((int64_t)b * inner + rr) * cs.dim + e));
+#pragma unroll
+        for (int i = 0; i < V; ++i) acc.v[i] = acc.v[i] + x.v[i];
+      }
+    } else {
+      int lo, hi;
+      if (form == FCP_FORM_GATHER) {
+        lo = b;
+        hi = b + 1;
+      } else {
+        lo = csr[b];
+        hi = csr[b + 1];
+        lo = min(max(lo, 0), nnz);
+        hi = min(max(hi, lo), nnz);
+      }
+      const int cnt = hi - lo;
+      if (form != FCP_FORM_SEGMENT_REDUCE) {
+        // GATHER: the row; GATHER_SCATTER: the last id of the row wins, a row
+        // without ids stays zero (pre-zeroed arena, cuda_emitter.cc:1351-1359).
+        if (cnt > 0) {
+          int64_t id = load_id(ids, idsrc, hi - 1, cs.boundaries, cs.n_boundaries);
+          bool bad;
+          if (resolve_id(id, cs.vocab, rank, world, bad)) acc = ld_row<V>(cs.table, id, cs.dim, e);
+          if (bad && e == 0 && L.bad_ids) atomicAdd(L.bad_ids, 1ull);
+        }
+      } else {
+        // Sequential accumulation in id order (deterministic; the order of
+        // TF-CPU and of the oracle).  Four ids and four rows are in flight per
+        // lane before the dependent adds.
+        for (int i = lo; i < hi; i += 4) {
+          int64_t id[4];
+          bool ok[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            id[k] = 0;
+            ok[k] = false;
+            if (i + k < hi) {
+              id[k] = load_id(ids, idsrc, i + k, cs.boundaries, cs.n_boundaries);
+              bool bad;
+              ok[k] = resolve_id(id[k], cs.vocab, rank, world, bad);
+              if (bad && e == 0 && L.bad_ids) atomicAdd(L.bad_ids, 1ull);
+            }
+          }
+          VF<V> w[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            w[k] = vzero<V>();
+            if (ok[k]) w[k] = ld_row<V>(cs.table, id[k], cs.dim, e);
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (ok[k]) {
+#pragma unroll
+              for (int t = 0; t < V; ++t) acc.v[t] = acc.v[t] + w[k].v[t];
+            }
+        }
+        if (mean && cnt > 0) {
+          const float fc = (float)cnt; // sum / count, cuda_emitter.cc:625, :903
+#pragma unroll
+          for (int t = 0; t < V; ++t) acc.v[t] = acc.v[t] / fc;
+        }
+      }
+    }
+    st_out<V>(outp + (int64_t)b * ostride, acc);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Segment-offset pre-pass: sorted segment ids -> CSR offsets[0..rows]
+// (experiment::ComputeSegmentOffsets, cuda_emitter.cc:768-818: position idx
+// writes offsets[id] = idx for id in (seg[idx-1], seg[idx]], seg[-1] = -1,
+// seg[nnz] = rows).  The reference runs this serially inside one block per
+// column; here one thread per position, all columns in one launch; the
+// predecessor's id comes from the neighbouring lane (wave shuffle) and a
+// wave without any segment boundary retires on one ballot.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int64_t load_seg(const char *seg, unsigned segkind, int stride, int64_t i) {
+  if (segkind == FCP_SEG_IDS_I32) return *reinterpret_cast<const int32_t *>(seg + 4 * i * stride);
+  return ld_i64_a4(seg + 8 * i * stride);
+}
+
+__global__ void __launch_bounds__(FCP_BLOCK_THREADS) fcp_segment_offsets_kernel(const FcpSegLaunch L) {
+  const int c = L.seg_cols[blockIdx.y];
+  const FcpColDyn cd = L.dyn[c];
+  const int nnz = cd.nnz;
+  const int64_t base = (int64_t)blockIdx.x * FCP_BLOCK_THREADS;
+  if (base > nnz) return;
+  const FcpColStatic cs = L.cols[c];
+  const unsigned segkind = FCP_F_SEGKIND(cs.flags);
+  const int stride = cs.seg_stride;
+  const int64_t rows = cd.rows;
+  const char *seg = L.blob + cd.seg_off;
+  const int64_t i = base + threadIdx.x;
+  const int lane = threadIdx.x & (FCP_WAVE - 1);
+  const bool active = i <= nnz;
+
+  int64_t cur = rows;
+  if (active && i < nnz) cur = load_seg(seg, segkind, stride, i);
+  if (cur > rows) cur = rows;
+  int64_t prev = __shfl_up(cur, 1);
+  if (lane == 0) {
+    prev = -1;
+    if (active && i > 0) {
+      prev = load_seg(seg, segkind, stride, i - 1);
+      if (prev > rows) prev = rows;
+    }
+  }
+  const bool boundary = active && cur > prev;
+  if (__ballot(boundary) == 0ull) return;
+  if (!boundary) return;
+  int32_t *csr = reinterpret_cast<int32_t *>(L.arena + L.csr_arena_off) + cd.csr_base;
+  for (int64_t id = prev + 1 < 0 ? 0 : prev + 1; id <= cur; ++id) csr[id] = (int32_t)i;
+}
+
+// ---------------------------------------------------------------------------
+// ConcatOutputs (reference layout pass, concat_outputs_op_gpu.cu.cc:85-131):
+// out[p, off_k + e] = in_k[p*dim_k + e].  Only used with FCP_LAYOUT_PER_COLUMN;
+// the fused kernel above writes the concat layout directly.
+// ---------------------------------------------------------------------------
+#define FCP_CONCAT_CHUNK 192
+struct FcpConcatArgs {
+  const float *in[FCP_CONCAT_CHUNK];
+  int32_t off[FCP_CONCAT_CHUNK];
+  int32_t dim[FCP_CONCAT_CHUNK];
+  float *out;
+  int64_t prefix;
+  int32_t width;
+  int32_t n;
+};
+
+__global__ void __launch_bounds__(FCP_BLOCK_THREADS) fcp_concat_outputs_kernel(const FcpConcatArgs A) {
+  const int k = blockIdx.y;
+  const int dim = A.dim[k];
+  const int off = A.off[k];
+  const float *__restrict__ in = A.in[k];
+  const int64_t total = A.prefix * dim;
+  for (int64_t i = (int64_t)blockIdx.x * FCP_BLOCK_THREADS + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * FCP_BLOCK_THREADS) {
+    const int64_t p = i / dim;
+    const int e = (int)(i - p * dim);
+    A.out[p * A.width + off + e] = in[i];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Row-shard finalize (no reference counterpart): after the
+// all-to-all, rank h holds `world` partial-sum slices of its batch slice;
+// add them in rank order (deterministic) and apply the mean division.
+// ---------------------------------------------------------------------------
+template <int V>
+__global__ void __launch_bounds__(FCP_BLOCK_THREADS)
+    fcp_shard_finalize_kernel(const FcpLaunch L, int g, const float *__restrict__ partials, int world,
+                              int64_t row_begin, int64_t row_count, float *__restrict__ out) {
+  const int nslots = L.groups[g].nslots;
+  const int q = blockIdx.x * FCP_BLOCK_THREADS + threadIdx.x;
+  const int64_t bl = blockIdx.y;
+  if (q >= nslots || bl >= row_count) return;
+  const int64_t W = (int64_t)nslots * V;
+  const uint32_t c = L.slot_map[L.groups[g].slot_map_off + q];
+  const FcpColStatic cs = L.cols[c];
+  const FcpColDyn cd = L.dyn[c];
+  VF<V> acc = vzero<V>();
+  for (int w = 0; w < world; ++w) {
+    const VF<V> x = *reinterpret_cast<const VF<V> *>(partials + ((int64_t)w * row_count + bl) * W + (int64_t)q * V);
+#pragma unroll
+    for (int t = 0; t < V; ++t) acc.v[t] = acc.v[t] + x.v[t];
+  }
+  if (FCP_F_FORM(cs.flags) == FCP_FORM_SEGMENT_REDUCE && FCP_F_COMBINER(cs.flags) == FCP_COMBINER_MEAN) {
+    const unsigned segkind = FCP_F_SEGKIND(cs.flags);
+    const int32_t *csr = segkind == FCP_SEG_CSR_I32
+                             ? reinterpret_cast<const int32_t *>(L.blob + cd.seg_off)
+                             : reinterpret_cast<const int32_t *>(L.arena + L.csr_arena_off) + cd.csr_base;
+    const int64_t b = row_begin + bl;
+    int lo = csr[b], hi = csr[b + 1];
+    lo = min(max(lo, 0), cd.nnz);
+    hi = min(max(hi, lo), cd.nnz);
+    if (hi > lo) {
+      const float fc = (float)(hi - lo);
+#pragma unroll
+      for (int t = 0; t < V; ++t) acc.v[t] = acc.v[t] / fc;
+    }
+  }
+  *reinterpret_cast<VF<V> *>(out + bl * W + (int64_t)q * V) = acc;
+}
+
+} // namespace
+
+// ------------------------------- launchers ---------------------------------
+
+#define FCP_LAUNCH_CASE(VV, DD, RR)                                                             \
+  hipLaunchKernelGGL((fcp_fused_kernel<VV, DD, RR>), dim3(grid_blocks), dim3(FCP_BLOCK_THREADS), \
+                     0, s, L)
+
+int fcp_launch_fused(const FcpLaunch &L, int vec, bool dense_only, int grid_blocks, ihipStream_t *s) {
+  if (grid_blocks <= 0) return 0;
+  if (dense_only) {
+    const int R = L.rows_per_wave;
+#define FCP_DENSE_R(VV)                                  \
+  switch (R) {                                           \
+  case 8: FCP_LAUNCH_CASE(VV, true, 8); break;           \
+  case 4: FCP_LAUNCH_CASE(VV, true, 4); break;           \
+  case 2: FCP_LAUNCH_CASE(VV, true, 2); break;           \
+  default: FCP_LAUNCH_CASE(VV, true, 1); break;          \
+  }
+    if (vec == 4) {
+      FCP_DENSE_R(4)
+    } else if (vec == 2) {
+      FCP_DENSE_R(2)
+    } else {
+      FCP_DENSE_R(1)
+    }
+#undef FCP_DENSE_R
+  } else {
+    if (vec == 4) {
+      FCP_LAUNCH_CASE(4, false, 1);
+    } else if (vec == 2) {
+      FCP_LAUNCH_CASE(2, false, 1);
+    } else {
+      FCP_LAUNCH_CASE(1, false, 1);
+    }
+  }
+  return (int)hipGetLastError();
+}
+
+int fcp_launch_segment_offsets(const FcpSegLaunch &L, int n_seg_cols, int max_nnz, ihipStream_t *s) {
+  if (n_seg_cols <= 0) return 0;
+  const int gx = (max_nnz + 1 + FCP_BLOCK_THREADS - 1) / FCP_BLOCK_THREADS;
+  hipLaunchKernelGGL(fcp_segment_offsets_kernel, dim3(gx, n_seg_cols), dim3(FCP_BLOCK_THREADS), 0, s, L);
+  return (int)hipGetLastError();
+}
+
+int fcp_launch_concat_outputs(const void *const *inputs, const int32_t *dims, int32_t n,
+                              int64_t prefix, int32_t width, int32_t first_off, void *out,
+                              ihipStream_t *s) {
+  int32_t off = first_off;
+  for (int32_t begin = 0; begin < n; begin += FCP_CONCAT_CHUNK) {
+    FcpConcatArgs A;
+    const int32_t m = (n - begin) < FCP_CONCAT_CHUNK ? (n - begin) : FCP_CONCAT_CHUNK;
+    int32_t max_dim = 1;
+    for (int32_t k = 0; k < m; ++k) {
+      A.in[k] = static_cast<const float *>(inputs[begin + k]);
+      A.dim[k] = dims[begin + k];
+      A.off[k] = off;
+      off += dims[begin + k];
+      if (dims[begin + k] > max_dim) max_dim = dims[begin + k];
+    }
+    A.out = static_cast<float *>(out);
+    A.prefix = prefix;
+    A.width = width;
+    A.n = m;
+    int64_t gx = (prefix * max_dim + FCP_BLOCK_THREADS - 1) / FCP_BLOCK_THREADS;
+    if (gx < 1) gx = 1;
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(fcp_concat_outputs_kernel, dim3((unsigned)gx, m), dim3(FCP_BLOCK_THREADS), 0, s, A);
+    const int err = (int)hipGetLastError();
+    if (err) return err;
+  }
+  return 0;
+}
+
+int fcp_launch_shard_finalize(const FcpLaunch &L, int group, const float *partials, int world,
+                              int64_t row_begin, int64_t row_count, float *out, int vec,
+                              ihipStream_t *s) {
+  if (row_count <= 0) return 0;
+  const int nslots = L.groups[group].nslots;
+  dim3 grid((nslots + FCP_BLOCK_THREADS - 1) / FCP_BLOCK_THREADS, (unsigned)row_count);
+  if (vec == 4) {
+    hipLaunchKernelGGL((fcp_shard_finalize_kernel<4>), grid, dim3(FCP_BLOCK_THREADS), 0, s, L, group,
+                       partials, world, row_begin, row_count, out);
+  } else if (vec == 2) {
+    hipLaunchKernelGGL((fcp_shard_finalize_kernel<2>), grid, dim3(FCP_BLOCK_THREADS), 0, s, L, group,
+                       partials, world, row_begin, row_count, out);
+  } else {
+    hipLaunchKernelGGL((fcp_shard_finalize_kernel<1>), grid, dim3(FCP_BLOCK_THREADS), 0, s, L, group,
+                       partials, world, row_begin, row_count, out);
+  }
+  return (int)hipGetLastError();
+}

@@ -1,0 +1,139 @@
+"""ctypes binding of ``libfcp_hip.so`` (C ABI: ``include/fcp_hip.h``).
+
+The library is built in-tree by ``__graft_entry__.build()`` (``hipcc
+--offload-arch=gfx950``).  There is NO fallback: if the shared object is
+missing or cannot be loaded, importing the product path fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfcp_hip.so")
+
+FCP_ABI_VERSION = 1
+FCP_OK = 0
+FCP_ERR_INVALID_ARGUMENT = 1
+FCP_ERR_SHAPE_MISMATCH = 2
+FCP_ERR_ALLOC = 3
+FCP_ERR_HIP = 4
+FCP_ERR_UNSUPPORTED = 5
+FCP_ERR_NO_DEVICE = 6
+FLAG_HOST_ONLY = 1 << 31  # plan without device resources (layout queries only)
+
+
+class FcpError(RuntimeError):
+    def __init__(self, status: int, what: str, detail: str = "") -> None:
+        self.status = status
+        super().__init__(f"{what}: status {status}" + (f" ({detail})" if detail else ""))
+
+
+class ColumnDesc(C.Structure):
+    _fields_ = [
+        ("form", C.c_int32), ("combiner", C.c_int32), ("dim", C.c_int32), ("id_source", C.c_int32),
+        ("vocab", C.c_int64),
+        ("table_input", C.c_int32), ("ids_input", C.c_int32), ("seg_input", C.c_int32),
+        ("seg_kind", C.c_int32), ("seg_stride", C.c_int32),
+        ("rows_source", C.c_int32), ("rows_arg", C.c_int32),
+        ("n_boundaries", C.c_int32),
+        ("boundaries", C.POINTER(C.c_float)),
+        ("concat_group", C.c_int32), ("concat_slot", C.c_int32),
+    ]
+
+
+class PlanDesc(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32), ("n_columns", C.c_int32),
+        ("columns", C.POINTER(ColumnDesc)),
+        ("n_host_inputs", C.c_int32),
+        ("host_input_ranks", C.POINTER(C.c_int32)),
+        ("host_input_elem_sizes", C.POINTER(C.c_int32)),
+        ("n_device_inputs", C.c_int32), ("n_groups", C.c_int32), ("n_symbols", C.c_int32),
+        ("layout", C.c_int32), ("device", C.c_int32),
+        ("shard_rank", C.c_int32), ("shard_world", C.c_int32),
+        ("flags", C.c_uint32),
+    ]
+
+
+ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
+
+
+class ProcessArgs(C.Structure):
+    _fields_ = [
+        ("concated_inputs", C.c_void_p), ("concated_bytes", C.c_int64),
+        ("concated_offsets", C.POINTER(C.c_int32)), ("concated_shapes", C.POINTER(C.c_int32)),
+        ("input_ptrs", C.POINTER(C.c_void_p)), ("input_shapes", C.POINTER(C.c_int32)),
+        ("symbols", C.POINTER(C.c_int32)),
+        ("stream", C.c_void_p),
+        ("malloc_temp", ALLOC_FN), ("malloc_temp_ctx", C.c_void_p),
+        ("malloc_buff", ALLOC_FN), ("malloc_buff_ctx", C.c_void_p),
+    ]
+
+
+class ProcessResult(C.Structure):
+    _fields_ = [
+        ("output_ptrs", C.POINTER(C.c_void_p)), ("output_shapes", C.POINTER(C.c_int32)),
+        ("output_row_strides", C.POINTER(C.c_int64)),
+        ("group_ptrs", C.POINTER(C.c_void_p)), ("group_shapes", C.POINTER(C.c_int32)),
+        ("buffer", C.c_void_p), ("buffer_bytes", C.c_int64),
+    ]
+
+
+class HostTensor(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("elem_size", C.c_int32), ("rank", C.c_int32),
+                ("dims", C.POINTER(C.c_int64))]
+
+
+# every symbol include/fcp_hip.h declares
+EXPORTS = [
+    "fcp_abi_version", "fcp_status_string", "fcp_last_error",
+    "fcp_concat_inputs_sizes", "fcp_concat_inputs",
+    "fcp_plan_create", "fcp_plan_destroy", "fcp_plan_group_width", "fcp_plan_column_offset",
+    "fcp_plan_arena_bytes", "fcp_plan_read_bad_ids",
+    "fcp_process_feature_columns", "fcp_concat_outputs", "fcp_shard_finalize",
+]
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libfcp_hip.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback for the product path.")
+    L = C.CDLL(LIB_PATH)
+    L.fcp_abi_version.restype = C.c_int
+    L.fcp_status_string.restype = C.c_char_p
+    L.fcp_status_string.argtypes = [C.c_int]
+    L.fcp_last_error.restype = C.c_char_p
+    L.fcp_concat_inputs_sizes.argtypes = [C.POINTER(HostTensor), C.c_int32, C.POINTER(C.c_int64),
+                                          C.POINTER(C.c_int32)]
+    L.fcp_concat_inputs.argtypes = [C.POINTER(HostTensor), C.c_int32, C.c_void_p, C.c_int64,
+                                    C.c_void_p, C.c_void_p]
+    L.fcp_plan_create.argtypes = [C.POINTER(PlanDesc), C.POINTER(C.c_void_p)]
+    L.fcp_plan_destroy.argtypes = [C.c_void_p]
+    L.fcp_plan_group_width.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
+    L.fcp_plan_column_offset.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
+    L.fcp_plan_arena_bytes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
+    L.fcp_plan_read_bad_ids.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
+    L.fcp_process_feature_columns.argtypes = [C.c_void_p, C.POINTER(ProcessArgs), C.POINTER(ProcessResult)]
+    L.fcp_concat_outputs.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_int32, C.c_int64, C.c_void_p,
+                                     C.c_void_p]
+    L.fcp_shard_finalize.argtypes = [C.c_void_p, C.POINTER(ProcessArgs), C.c_int32, C.c_void_p, C.c_int32,
+                                     C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
+    if L.fcp_abi_version() != FCP_ABI_VERSION:
+        raise ImportError("libfcp_hip.so ABI version mismatch; rebuild")
+    _lib = L
+    return L
+
+
+def check(status: int, what: str) -> None:
+    if status != FCP_OK:
+        L = load()
+        detail = L.fcp_last_error().decode() or L.fcp_status_string(status).decode()
+        raise FcpError(status, what, detail)

@@ -1,0 +1,271 @@
+"""Host-side mirror of the reference's three custom ops, above the C ABI.
+
+Same names, argument meaning and error behaviour as the TensorFlow ops of the
+reference (TensorFlow itself is not available here, so tensors are NumPy on the
+host and ``torch`` tensors on the device — torch is plumbing for device memory
+and streams only):
+
+* :func:`concat_inputs`           — ``Addons>ConcatInputs``
+  (``custom_ops/concat_inputs/concat_inputs_ops.cc:42-88``)
+* :class:`FeatureColumnProcess`   — ``Addons>FeatureColumnProcess[WithSymbols]``
+  (``custom_ops/feature_column_process/feature_column_process_op_gpu.cu.cc:33-175``)
+* :func:`concat_outputs`          — ``Addons>ConcatOutputs[NoHost]``
+  (``custom_ops/concat_outputs/concat_outputs_op_gpu.cu.cc:180-288``)
+
+All compute goes through ``libfcp_hip.so``; there is no Python/CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import lib as _lib
+from .plan import (FORM_BATCH_COL_REDUCTION, FORM_PASSTHROUGH, IDS_F32_BUCKETIZE, LAYOUT_CONCAT, PlanSpec)
+
+
+# ----------------------------------------------------------------------------
+# Addons>ConcatInputs (CPU op)
+# ----------------------------------------------------------------------------
+def concat_inputs(inputs: Sequence[np.ndarray]):
+    """Pack N host tensors into ``(output:int8[sum bytes], offsets:int32[N],
+    shapes:int32[sum rank])`` — bit-exact with ``ConcatInputsOp::Compute``."""
+    L = _lib.load()
+    arrs = [np.require(np.asarray(a), requirements="C") for a in inputs]  # keeps rank-0
+    n = len(arrs)
+    dims_keep = [np.asarray(a.shape, np.int64) for a in arrs]
+    tens = (_lib.HostTensor * max(n, 1))()
+    for i, a in enumerate(arrs):
+        tens[i] = _lib.HostTensor(a.ctypes.data, a.dtype.itemsize, a.ndim,
+                                  dims_keep[i].ctypes.data_as(C.POINTER(C.c_int64)))
+    nbytes = C.c_int64(0)
+    rank_sum = C.c_int32(0)
+    _lib.check(L.fcp_concat_inputs_sizes(tens, n, C.byref(nbytes), C.byref(rank_sum)), "ConcatInputs")
+    blob = np.empty(nbytes.value, np.int8)
+    offsets = np.empty(n, np.int32)
+    shapes = np.empty(rank_sum.value, np.int32)
+    _lib.check(L.fcp_concat_inputs(tens, n, blob.ctypes.data, blob.nbytes, offsets.ctypes.data,
+                                   shapes.ctypes.data), "ConcatInputs")
+    return blob, offsets, shapes
+
+
+# ----------------------------------------------------------------------------
+# plan handle
+# ----------------------------------------------------------------------------
+class Plan:
+    """Owns an ``fcp_plan_t`` (replaces code generation + ``CreateConstBuffers``,
+    ``cuda_emitter.cc:2260-2301``; freed like the op destructor frees
+    ``const_buff``, ``feature_column_process_ops.h:47``)."""
+
+    def __init__(self, spec: PlanSpec, device: int = 0, host_only: bool = False) -> None:
+        spec.validate()
+        self.spec = spec
+        self.device = device
+        self._L = _lib.load()
+        self._keep: List[np.ndarray] = []
+        cols = (_lib.ColumnDesc * spec.n_columns)()
+        for k, c in enumerate(spec.columns):
+            b = None
+            if c.boundaries is not None and c.id_source == IDS_F32_BUCKETIZE and \
+                    c.form not in (FORM_PASSTHROUGH, FORM_BATCH_COL_REDUCTION):
+                b = np.ascontiguousarray(c.boundaries, np.float32)
+                self._keep.append(b)
+            cols[k] = _lib.ColumnDesc(
+                c.form, c.combiner, c.dim, c.id_source, c.vocab, c.table_input, c.ids_input, c.seg_input,
+                c.seg_kind, c.seg_stride, c.rows_source, c.rows_arg, 0 if b is None else len(b),
+                None if b is None else b.ctypes.data_as(C.POINTER(C.c_float)), c.concat_group, c.concat_slot)
+        ranks = np.asarray(spec.host_input_ranks, np.int32)
+        esz = np.asarray(spec.host_input_elem_sizes, np.int32)
+        self._keep += [ranks, esz]
+        flags = spec.flags | (_lib.FLAG_HOST_ONLY if host_only else 0)
+        desc = _lib.PlanDesc(
+            _lib.FCP_ABI_VERSION, spec.n_columns, cols, len(ranks),
+            ranks.ctypes.data_as(C.POINTER(C.c_int32)), esz.ctypes.data_as(C.POINTER(C.c_int32)),
+            spec.n_device_inputs, spec.n_groups, spec.n_symbols, spec.layout, device,
+            spec.shard_rank, spec.shard_world, flags)
+        handle = C.c_void_p()
+        _lib.check(self._L.fcp_plan_create(C.byref(desc), C.byref(handle)), "fcp_plan_create")
+        self.handle = handle
+
+    def close(self) -> None:
+        if getattr(self, "handle", None):
+            self._L.fcp_plan_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self) -> None:  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def group_width(self, group: int) -> int:
+        w = C.c_int32()
+        _lib.check(self._L.fcp_plan_group_width(self.handle, group, C.byref(w)), "fcp_plan_group_width")
+        return w.value
+
+    def column_offset(self, column: int) -> int:
+        o = C.c_int32()
+        _lib.check(self._L.fcp_plan_column_offset(self.handle, column, C.byref(o)), "fcp_plan_column_offset")
+        return o.value
+
+    def arena_bytes(self, shapes, symbols=None) -> int:
+        shapes = np.ascontiguousarray(shapes, np.int32)
+        sym = None if symbols is None else np.ascontiguousarray(symbols, np.int32)
+        out = C.c_int64()
+        _lib.check(self._L.fcp_plan_arena_bytes(self.handle, shapes.ctypes.data,
+                                                None if sym is None else sym.ctypes.data, C.byref(out)),
+                   "fcp_plan_arena_bytes")
+        return out.value
+
+    def read_bad_ids(self, stream: int = 0) -> int:
+        out = C.c_int64()
+        _lib.check(self._L.fcp_plan_read_bad_ids(self.handle, stream, C.byref(out)), "fcp_plan_read_bad_ids")
+        return out.value
+
+
+@dataclass
+class ProcessOutputs:
+    """What ``FeatureColumnProcessOp::Compute`` returns
+    (``feature_column_process_op_gpu.cu.cc:72-126``) plus torch views."""
+    output_ptrs: np.ndarray      # int64[n_columns]  (reference: device int64 tensor)
+    output_shapes: np.ndarray    # int32[2*n_columns] host
+    output_row_strides: np.ndarray
+    buffer: "object"             # torch.uint8 arena (output 2)
+    groups: list                 # torch.float32 [rows, width] views per concat group (CONCAT layout)
+    group_shapes: np.ndarray
+
+    def column(self, k: int):
+        """torch view of column k's output ([rows, dim], possibly strided)."""
+        import torch
+        rows, dim = int(self.output_shapes[2 * k]), int(self.output_shapes[2 * k + 1])
+        off = (int(self.output_ptrs[k]) - self.buffer.data_ptr()) // 4
+        f = self.buffer.view(torch.float32)
+        return f.as_strided((rows, dim), (int(self.output_row_strides[k]), 1), off)
+
+
+class FeatureColumnProcess:
+    """``Addons>FeatureColumnProcess[WithSymbols]``.
+
+    Inputs of ``__call__`` follow the op: ``concated_inputs`` (device int8 blob),
+    ``concated_offsets`` / ``concated_shapes`` (host int32), ``inputs`` (device
+    tables), optional ``symbols`` (host int32).  The ``dlpath`` attr of the
+    reference is replaced by the plan.  Work is enqueued on ``stream`` (default:
+    torch's current stream); nothing blocks.
+    """
+
+    def __init__(self, spec: PlanSpec, device: int = 0) -> None:
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("FeatureColumnProcess needs a GPU (no CPU fallback)")
+        self.torch = torch
+        self.device = torch.device("cuda", device)
+        self.plan = Plan(spec, device)
+        self.spec = spec
+        self._L = self.plan._L
+        n, g = spec.n_columns, spec.n_groups
+        self._out_ptrs = (C.c_void_p * n)()
+        self._out_shapes = (C.c_int32 * (2 * n))()
+        self._out_strides = (C.c_int64 * n)()
+        self._grp_ptrs = (C.c_void_p * g)()
+        self._grp_shapes = (C.c_int32 * (2 * g))()
+        self._arena = None
+
+        def _alloc(_ctx, nbytes):
+            self._arena = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+            return self._arena.data_ptr()
+
+        def _alloc_temp(_ctx, nbytes):
+            t = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+            self._temps.append(t)
+            return t.data_ptr()
+
+        self._temps: list = []
+        self._alloc_cb = _lib.ALLOC_FN(_alloc)
+        self._alloc_temp_cb = _lib.ALLOC_FN(_alloc_temp)
+
+    def _args(self, concated_inputs, concated_offsets, concated_shapes, inputs, symbols, stream):
+        torch = self.torch
+        offs = np.ascontiguousarray(concated_offsets, np.int32)
+        shps = np.ascontiguousarray(concated_shapes, np.int32)
+        sym = None if symbols is None else np.ascontiguousarray(symbols, np.int32)
+        tptrs = (C.c_void_p * max(1, len(inputs)))(*[t.data_ptr() for t in inputs])
+        tshapes = np.asarray([d for t in inputs for d in t.shape], np.int32)
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+        a = _lib.ProcessArgs(
+            concated_inputs.data_ptr() if concated_inputs is not None and concated_inputs.numel() else None,
+            0 if concated_inputs is None else concated_inputs.numel() * concated_inputs.element_size(),
+            offs.ctypes.data_as(C.POINTER(C.c_int32)), shps.ctypes.data_as(C.POINTER(C.c_int32)),
+            tptrs, tshapes.ctypes.data_as(C.POINTER(C.c_int32)) if len(inputs) and all(t.dim() == 2 for t in inputs) else None,
+            None if sym is None else sym.ctypes.data_as(C.POINTER(C.c_int32)),
+            stream, self._alloc_temp_cb, None, self._alloc_cb, None)
+        return a, (offs, shps, sym, tptrs, tshapes)
+
+    def __call__(self, concated_inputs, concated_offsets, concated_shapes, inputs, symbols=None,
+                 stream: Optional[int] = None) -> ProcessOutputs:
+        torch = self.torch
+        a, _keep = self._args(concated_inputs, concated_offsets, concated_shapes, inputs, symbols, stream)
+        res = _lib.ProcessResult(self._out_ptrs, self._out_shapes, self._out_strides, self._grp_ptrs,
+                                 self._grp_shapes, None, 0)
+        self._arena = None
+        _lib.check(self._L.fcp_process_feature_columns(self.plan.handle, C.byref(a), C.byref(res)),
+                   "FeatureColumnProcess")
+        arena = self._arena
+        n, g = self.spec.n_columns, self.spec.n_groups
+        out_ptrs = np.array([self._out_ptrs[k] or 0 for k in range(n)], np.int64)
+        out_shapes = np.array(self._out_shapes[:], np.int32)
+        strides = np.array(self._out_strides[:], np.int64)
+        gshapes = np.array(self._grp_shapes[:], np.int32)
+        groups = []
+        if self.spec.layout == LAYOUT_CONCAT:
+            f = arena.view(torch.float32)
+            for gi in range(g):
+                rows, width = int(gshapes[2 * gi]), int(gshapes[2 * gi + 1])
+                off = ((self._grp_ptrs[gi] or arena.data_ptr()) - arena.data_ptr()) // 4
+                groups.append(f[off:off + rows * width].view(rows, width))
+        return ProcessOutputs(out_ptrs, out_shapes, strides, arena, groups, gshapes)
+
+    def shard_finalize(self, concated_inputs, concated_offsets, concated_shapes, inputs, symbols, group: int,
+                       partial_slices, world: int, row_begin: int, row_count: int, stream: Optional[int] = None):
+        """Sum ``world`` partial slices in rank order + mean division."""
+        torch = self.torch
+        a, _keep = self._args(concated_inputs, concated_offsets, concated_shapes, inputs, symbols, stream)
+        width = self.plan.group_width(group)
+        out = torch.empty((row_count, width), dtype=torch.float32, device=self.device)
+        self._temps.clear()
+        _lib.check(self._L.fcp_shard_finalize(self.plan.handle, C.byref(a), group, partial_slices.data_ptr(),
+                                              world, row_begin, row_count, out.data_ptr(), a.stream),
+                   "fcp_shard_finalize")
+        return out
+
+
+# ----------------------------------------------------------------------------
+# Addons>ConcatOutputs[NoHost]
+# ----------------------------------------------------------------------------
+def concat_outputs(device_inputs: Sequence, stream: Optional[int] = None):
+    """``out[p, off_k:off_k+dim_k] = in_k[p, :]`` for device tensors ``in_k``
+    of shape ``[prefix..., dim_k]`` (``ConcatOutputsKnl``,
+    ``concat_outputs_op_gpu.cu.cc:85-131``).  Needed only with
+    ``LAYOUT_PER_COLUMN``; the fused path writes the concat layout directly."""
+    import torch
+    L = _lib.load()
+    ins = [t.contiguous() for t in device_inputs]
+    if not ins:
+        raise ValueError("concat_outputs needs at least one input")
+    prefix_shape = tuple(ins[0].shape[:-1])
+    for t in ins:
+        if tuple(t.shape[:-1]) != prefix_shape:
+            raise ValueError("concat_outputs: prefix shapes differ")
+        if t.element_size() != 4:
+            raise ValueError("concat_outputs supports 4-byte types (float, int)")
+    prefix = int(np.prod(prefix_shape)) if prefix_shape else 1
+    dims = np.asarray([t.shape[-1] for t in ins], np.int32)
+    out = torch.empty(prefix_shape + (int(dims.sum()),), dtype=ins[0].dtype, device=ins[0].device)
+    ptrs = (C.c_void_p * len(ins))(*[t.data_ptr() for t in ins])
+    if stream is None:
+        stream = torch.cuda.current_stream(ins[0].device).cuda_stream
+    _lib.check(L.fcp_concat_outputs(ptrs, dims.ctypes.data, len(ins), prefix, out.data_ptr(), stream),
+               "ConcatOutputs")
+    return out

@@ -1,0 +1,230 @@
+"""Column plan: the static description of one model's fused feature-column stage.
+
+This is the data the reference carries as *generated CUDA text* — one
+``struct FCi`` per feature column, built by ``CudaEmitter::EmitFCCode``
+(``graph_optimizers/cuda_emitter.cc:975-1178``) and assembled into ``KnlArgs`` /
+``FusedKnl`` (``:2057-2137``).  Here it is a plain table of
+:class:`ColumnSpec` records that pre-compiled gfx950 kernels interpret, so no
+code generation or runtime compiler is needed.
+
+The enums mirror ``include/fcp_hip.h`` one-to-one.  Pure Python, no GPU needed.
+"""
+from __future__ import annotations
+
+import dataclasses
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+# --- enums (== include/fcp_hip.h) -------------------------------------------
+FORM_GATHER = 1            # GatherV2(table, ids)              cuda_emitter.cc:250-293
+FORM_SEGMENT_REDUCE = 2    # SparseSegment{Sum,Mean}WithNumSegments  :402-661, :768-962
+FORM_GATHER_SCATTER = 3    # ScatterNd(rows, GatherV2(...))    :296-345
+FORM_PASSTHROUGH = 4       # ConcatOutputs host_inputs         concat_outputs_op_gpu.cu.cc:186-216
+FORM_BATCH_COL_REDUCTION = 5  # Sum(x, axis=1)                 cuda_emitter.cc:1180-1244
+
+COMBINER_NONE, COMBINER_SUM, COMBINER_MEAN = 0, 1, 2
+IDS_I32, IDS_I64, IDS_F32_BUCKETIZE = 0, 1, 2
+SEG_NONE, SEG_IDS_I32, SEG_IDS_I64, SEG_CSR_I32 = 0, 1, 2, 3
+ROWS_FROM_IDS, ROWS_FROM_SYMBOL, ROWS_FROM_INPUT_DIM0 = 0, 1, 2
+LAYOUT_CONCAT, LAYOUT_PER_COLUMN = 0, 1
+FLAG_COUNT_BAD_IDS = 1
+
+_ID_ELEM_SIZE = {IDS_I32: 4, IDS_I64: 8, IDS_F32_BUCKETIZE: 4}
+_ID_NP_DTYPE = {IDS_I32: np.int32, IDS_I64: np.int64, IDS_F32_BUCKETIZE: np.float32}
+
+
+@dataclass
+class ColumnSpec:
+    """One feature column (one FC subgraph of ``graph_info.cc:209-365``)."""
+
+    form: int
+    dim: int
+    vocab: int = 0
+    combiner: int = COMBINER_NONE
+    id_source: int = IDS_I64
+    table_input: int = -1
+    ids_input: int = -1
+    seg_input: int = -1
+    seg_kind: int = SEG_NONE
+    seg_stride: int = 1
+    rows_source: int = ROWS_FROM_IDS
+    rows_arg: int = 0
+    boundaries: Optional[np.ndarray] = None
+    concat_group: int = 0
+    concat_slot: int = 0
+
+    def validate(self) -> None:
+        if self.form not in (1, 2, 3, 4, 5):
+            raise ValueError(f"bad form {self.form}")
+        if self.dim <= 0:
+            raise ValueError("dim must be positive")
+        if self.form in (FORM_GATHER, FORM_SEGMENT_REDUCE, FORM_GATHER_SCATTER):
+            if self.vocab <= 0 or self.table_input < 0 or self.ids_input < 0:
+                raise ValueError("lookup column needs vocab, table_input, ids_input")
+            if self.id_source == IDS_F32_BUCKETIZE:
+                if self.boundaries is None or len(self.boundaries) == 0:
+                    raise ValueError("bucketize column needs boundaries")
+        if self.form in (FORM_SEGMENT_REDUCE, FORM_GATHER_SCATTER):
+            if self.seg_kind == SEG_NONE or self.seg_input < 0:
+                raise ValueError("pooled/scatter column needs segment input")
+            if self.rows_source == ROWS_FROM_IDS:
+                raise ValueError("pooled/scatter column needs an explicit row count source")
+        if self.form == FORM_SEGMENT_REDUCE and self.combiner not in (COMBINER_SUM, COMBINER_MEAN):
+            raise ValueError("segment-reduce column needs sum or mean")
+
+
+@dataclass
+class PlanSpec:
+    """All columns of a model + the ConcatInputs / FeatureColumnProcess attrs.
+
+    ``host_input_ranks`` / ``host_input_elem_sizes`` are the ``ranks`` / ``T``
+    attrs of ``Addons>ConcatInputs`` (``concat_inputs_ops.cc:82-88``);
+    ``n_device_inputs`` is the length of ``input_types`` of
+    ``Addons>FeatureColumnProcess`` (the embedding tables,
+    ``feature_column_process_op_gpu.cu.cc:133-152``).
+    """
+
+    columns: List[ColumnSpec]
+    host_input_ranks: List[int]
+    host_input_elem_sizes: List[int]
+    n_device_inputs: int
+    n_groups: int = 1
+    n_symbols: int = 0
+    layout: int = LAYOUT_CONCAT
+    shard_rank: int = 0
+    shard_world: int = 1
+    flags: int = 0
+
+    # ---- static layout facts ------------------------------------------------
+    def validate(self) -> None:
+        if len(self.host_input_ranks) != len(self.host_input_elem_sizes):
+            raise ValueError("host_input_ranks / elem_sizes length mismatch")
+        seen = set()
+        for k, c in enumerate(self.columns):
+            c.validate()
+            if not 0 <= c.concat_group < self.n_groups:
+                raise ValueError(f"column {k}: concat_group out of range")
+            key = (c.concat_group, c.concat_slot)
+            if key in seen:
+                raise ValueError(f"column {k}: duplicate concat slot {key}")
+            seen.add(key)
+            for idx in (c.ids_input, c.seg_input):
+                if idx >= len(self.host_input_ranks):
+                    raise ValueError(f"column {k}: host input index out of range")
+            if c.table_input >= self.n_device_inputs:
+                raise ValueError(f"column {k}: table_input out of range")
+            if c.rows_source == ROWS_FROM_SYMBOL and not 0 <= c.rows_arg < self.n_symbols:
+                raise ValueError(f"column {k}: symbol index out of range")
+
+    @property
+    def n_columns(self) -> int:
+        return len(self.columns)
+
+    @property
+    def n_host_inputs(self) -> int:
+        return len(self.host_input_ranks)
+
+    def group_width(self, group: int) -> int:
+        return sum(c.dim for c in self.columns if c.concat_group == group)
+
+    def column_offsets(self) -> List[int]:
+        """Element offset of each column inside its concat group (prefix sums of
+        ``embedd_dims`` in slot order, ``concat_outputs_op_gpu.cu.cc:74-79``)."""
+        offs = [0] * len(self.columns)
+        for g in range(self.n_groups):
+            members = sorted((c.concat_slot, k) for k, c in enumerate(self.columns) if c.concat_group == g)
+            acc = 0
+            for _, k in members:
+                offs[k] = acc
+                acc += self.columns[k].dim
+        return offs
+
+    def shape_offsets(self) -> List[int]:
+        out, acc = [], 0
+        for r in self.host_input_ranks:
+            out.append(acc)
+            acc += r
+        return out
+
+    def to_dict(self) -> dict:
+        """Plain-dict form (what the oracle wrapper consumes; keeps oracle/ free of
+        product imports)."""
+        d = dataclasses.asdict(self)
+        for c, src in zip(d["columns"], self.columns):
+            c["boundaries"] = None if src.boundaries is None else np.asarray(src.boundaries, np.float32)
+        return d
+
+    def with_shard(self, rank: int, world: int) -> "PlanSpec":
+        return dataclasses.replace(self, shard_rank=rank, shard_world=world)
+
+    def with_layout(self, layout: int) -> "PlanSpec":
+        return dataclasses.replace(self, layout=layout)
+
+    # ---- roofline accounting --------------------------------
+    def algorithmic_bytes(self, shapes: Sequence[int], symbols: Optional[Sequence[int]] = None) -> dict:
+        """Algorithmic bytes of one request: table rows read + ids read + CSR
+        offsets / segment ids read + bucketize boundaries + pooled output written
+        once in concat layout.  No intermediate traffic is counted."""
+        so = self.shape_offsets()
+
+        def numel(i: int) -> int:
+            n = 1
+            for j in range(self.host_input_ranks[i]):
+                n *= int(shapes[so[i] + j])
+            return n
+
+        rows_b = ids_b = seg_b = bnd_b = out_b = 0
+        for c in self.columns:
+            rows = self.column_rows(c, shapes, symbols)
+            out_b += rows * c.dim * 4
+            if c.form == FORM_PASSTHROUGH:
+                rows_b += rows * c.dim * 4
+            elif c.form == FORM_BATCH_COL_REDUCTION:
+                rows_b += numel(c.ids_input) * 4
+            else:
+                nnz = numel(c.ids_input)
+                rows_b += nnz * c.dim * 4
+                ids_b += nnz * _ID_ELEM_SIZE[c.id_source]
+                if c.seg_kind == SEG_CSR_I32:
+                    seg_b += (rows + 1) * 4
+                elif c.seg_kind == SEG_IDS_I32:
+                    seg_b += nnz * 4
+                elif c.seg_kind == SEG_IDS_I64:
+                    seg_b += nnz * 8
+                if c.id_source == IDS_F32_BUCKETIZE:
+                    bnd_b += len(c.boundaries) * 4
+        read = rows_b + ids_b + seg_b + bnd_b
+        return {"rows": rows_b, "ids": ids_b, "segments": seg_b, "boundaries": bnd_b,
+                "out": out_b, "read": read, "total": read + out_b}
+
+    def column_rows(self, c: ColumnSpec, shapes: Sequence[int], symbols: Optional[Sequence[int]]) -> int:
+        so = self.shape_offsets()
+        if c.rows_source == ROWS_FROM_IDS:
+            n = 1
+            for j in range(self.host_input_ranks[c.ids_input]):
+                n *= int(shapes[so[c.ids_input] + j])
+            return n
+        if c.rows_source == ROWS_FROM_SYMBOL:
+            if symbols is None:
+                raise ValueError("plan needs symbols")
+            return int(symbols[c.rows_arg])
+        return int(shapes[so[c.rows_arg]])
+
+    def group_rows(self, group: int, shapes: Sequence[int], symbols: Optional[Sequence[int]] = None) -> int:
+        rows = None
+        for c in self.columns:
+            if c.concat_group != group:
+                continue
+            r = self.column_rows(c, shapes, symbols)
+            if rows is not None and r != rows:
+                raise ValueError(f"group {group}: inconsistent row counts {rows} vs {r}")
+            rows = r
+        if rows is None:
+            raise ValueError(f"group {group} has no columns")
+        return rows
+
+
+def id_numpy_dtype(id_source: int):
+    return _ID_NP_DTYPE[id_source]

@@ -1,0 +1,70 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """The C oracle (test infrastructure)."""
+    import fcp_oracle
+    return fcp_oracle.COracle()
+
+
+class GoldenCase:
+    def __init__(self, z, name):
+        self.name = name
+        self.plan = json.loads(bytes(z[f"{name}/plan"]).decode())
+        for c in self.plan["columns"]:
+            if c["boundaries"] is not None:
+                c["boundaries"] = np.asarray(c["boundaries"], np.float32)
+        self.inputs = [z[f"{name}/in{i}"] for i in range(int(z[f"{name}/n_inputs"]))]
+        self.blob = z[f"{name}/blob"]
+        self.offsets = z[f"{name}/offsets"]
+        self.shapes = z[f"{name}/shapes"]
+        sym = z[f"{name}/symbols"]
+        self.symbols = sym if sym.size else None
+        tk = bytes(z[f"{name}/tables_key"]).decode()
+        self.tables = [z[f"{tk}/table{i}"] for i in range(int(z[f"{tk}/n_tables"]))]
+        self.expected = [z[f"{name}/expected{g}"] for g in range(self.plan["n_groups"])]
+        self.copy_cols = z[f"{name}/copy_cols"]
+
+    def spec(self):
+        """PlanSpec rebuilt from the stored plan description."""
+        from recom_amd.plan import ColumnSpec, PlanSpec
+        d = dict(self.plan)
+        cols = [ColumnSpec(**c) for c in d.pop("columns")]
+        return PlanSpec(columns=cols, **d)
+
+
+GOLDEN_NAMES = ["mixed_s0", "mixed_s1", "mixed_empty", "bucketize_kat", "ragged_edges", "scatter"]
+
+
+@pytest.fixture(scope="session")
+def golden():
+    z = np.load(os.path.join(ROOT, "tests", "golden", "fcp_golden.npz"))
+    return {n: GoldenCase(z, n) for n in GOLDEN_NAMES}, z
+
+
+def check_against_expected(case, outs, pooled_atol=1e-5):
+    """Bit-exact on copy-only columns, max-abs-diff < pooled_atol (the north
+    star's fp32 tolerance) on pooled ones."""
+    for g, (o, e) in enumerate(zip(outs, case.expected)):
+        o = np.asarray(o)
+        assert o.shape == e.shape, (case.name, g, o.shape, e.shape)
+        assert np.abs(o.astype(np.float64) - e).max(initial=0.0) < pooled_atol, (case.name, g)
+    for g, off, dim in case.copy_cols:
+        got = np.asarray(outs[g])[:, off:off + dim]
+        want = case.expected[g][:, off:off + dim].astype(np.float32)
+        assert np.array_equal(got, want), (case.name, "copy column not bit-exact", g, off)

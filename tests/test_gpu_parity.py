@@ -1,0 +1,347 @@
+"""GPU parity: the HIP path, called through the C ABI (libfcp_hip.so), against
+the CPU oracle on the same seeded inputs, against the committed golden
+fixtures, and — at BASELINE.json's full sizes — against the closed-form table
+definition.  Bit-exact for index / copy work; pooled vectors are also compared
+bit-exactly with the oracle (same sequential fp32 order) and within the north
+star's 1e-5 max-abs-diff of the float64 expectation.
+"""
+import copy
+import dataclasses
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_NAMES, check_against_expected
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from recom_amd import lib
+    lib.load()  # fail loudly if the HIP extension is missing
+    return torch
+
+
+def run_gpu(torch, spec, inputs, tables_np, symbols, op=None, tables_dev=None):
+    from recom_amd.ops import FeatureColumnProcess, concat_inputs
+    dev = torch.device("cuda", 0)
+    blob, offsets, shapes = concat_inputs(inputs)
+    if tables_dev is None:
+        tables_dev = [torch.from_numpy(np.ascontiguousarray(t)).to(dev) for t in tables_np]
+    if op is None:
+        op = FeatureColumnProcess(spec, 0)
+    d_blob = torch.from_numpy(blob).to(dev) if blob.size else torch.empty(0, dtype=torch.int8, device=dev)
+    out = op(d_blob, offsets, shapes, tables_dev, symbols)
+    torch.cuda.synchronize()
+    return out, (blob, offsets, shapes), op
+
+
+def assert_equal_oracle(oracle, spec, packed, tables_np, symbols, out, exact=True):
+    blob, offsets, shapes = packed
+    want, bad = oracle.process_feature_columns(spec.to_dict(), blob, offsets, shapes, tables_np, symbols)
+    for g, w in zip(out.groups, want):
+        got = g.cpu().numpy()
+        assert got.shape == w.shape
+        if exact:
+            assert np.array_equal(got, w), float(np.abs(got - w).max())
+        else:
+            assert np.abs(got - w).max(initial=0) < 1e-5
+    return want, bad
+
+
+@pytest.mark.parametrize("name", GOLDEN_NAMES)
+def test_golden_through_c_abi(torch_cuda, oracle, golden, name):
+    case = golden[0][name]
+    spec = case.spec()
+    out, packed, _ = run_gpu(torch_cuda, spec, case.inputs, case.tables, case.symbols)
+    # the packer is bit-exact with the stored ConcatInputs outputs
+    assert np.array_equal(packed[0], case.blob) and np.array_equal(packed[1], case.offsets)
+    assert np.array_equal(packed[2], case.shapes)
+    check_against_expected(case, [g.cpu().numpy() for g in out.groups])
+    assert_equal_oracle(oracle, spec, packed, case.tables, case.symbols, out)
+
+
+@pytest.mark.parametrize("batch", [1, 3, 64, 100, 257])
+def test_mixed_model_batches(torch_cuda, oracle, batch):
+    from recom_amd import synth
+    m = synth.model_mixed(batch=batch, vocab=997)
+    tabs = m.numpy_tables()
+    op = None
+    for seed in range(3):
+        req = m.make_request(seed)
+        out, packed, op = run_gpu(torch_cuda, m.spec, req.inputs, tabs, req.symbols, op)
+        assert_equal_oracle(oracle, m.spec, packed, tabs, req.symbols, out)
+        # output_shapes / output_ptrs contract of FeatureColumnProcess
+        for k, c in enumerate(m.spec.columns):
+            assert out.output_shapes[2 * k + 1] == c.dim
+            col = out.column(k).cpu().numpy()
+            off = m.spec.column_offsets()[k]
+            assert np.array_equal(col, out.groups[c.concat_group].cpu().numpy()[:, off:off + c.dim])
+
+
+def test_s1_configuration(torch_cuda, oracle):
+    """BASELINE.json configs[0]: S1 100 columns, dim 16, vocab 10k, batch 128."""
+    from recom_amd import synth
+    m = synth.model_s1()
+    tabs = m.numpy_tables()
+    req = m.make_request(0)
+    out, packed, _ = run_gpu(torch_cuda, m.spec, req.inputs, tabs, req.symbols)
+    assert out.groups[0].shape == (128, 1600)
+    assert_equal_oracle(oracle, m.spec, packed, tabs, req.symbols, out)
+
+
+@pytest.mark.parametrize("seg", ["csr", "indices", "rowids32"])
+def test_ragged_dynamic_shapes(torch_cuda, oracle, seg):
+    """RAGGED (reduced to 64 columns): nnz re-drawn per request; more distinct
+    shapes than descriptor slots, then a repeat (cache hit)."""
+    from recom_amd import synth
+    m = synth.model_ragged(columns=64, vocab=5000, batch=256, seg=seg)
+    tabs = m.numpy_tables()
+    dev_tabs = [torch_cuda.from_numpy(t).cuda() for t in tabs]
+    op = None
+    for seed in list(range(11)) + [3, 3, 0]:
+        req = m.make_request(seed)
+        out, packed, op = run_gpu(torch_cuda, m.spec, req.inputs, tabs, req.symbols, op, dev_tabs)
+        assert_equal_oracle(oracle, m.spec, packed, tabs, req.symbols, out)
+
+
+def test_zipf_and_long_bags(torch_cuda, oracle):
+    from recom_amd import synth
+    m = synth.model_ragged(columns=16, vocab=3000, batch=40, seg="indices", max_len=300, dist="zipf")
+    tabs = m.numpy_tables()
+    req = m.make_request(5)
+    out, packed, _ = run_gpu(torch_cuda, m.spec, req.inputs, tabs, req.symbols)
+    assert_equal_oracle(oracle, m.spec, packed, tabs, req.symbols, out)
+    # fp32 roundoff of 300-long sums of |x|<1 values stays well inside 1e-4
+    import fcp_oracle as O
+    truth = O.np_process_feature_columns(m.spec.to_dict(), *packed, tabs, req.symbols)
+    assert np.abs(out.groups[0].cpu().numpy() - truth[0]).max() < 1e-4
+
+
+@pytest.mark.parametrize("dims", [(6, 10, 2, 14), (3, 5, 1, 7), (4, 6, 8, 10)])
+def test_narrow_vector_widths(torch_cuda, oracle, dims):
+    """dims that are not multiples of 4 select the 8-byte / 4-byte slot kernels."""
+    from recom_amd import synth
+    m = synth.model_ragged(columns=8, vocab=500, batch=37, seg="csr", dims=dims)
+    tabs = m.numpy_tables()
+    req = m.make_request(1)
+    out, packed, _ = run_gpu(torch_cuda, m.spec, req.inputs, tabs, req.symbols)
+    assert_equal_oracle(oracle, m.spec, packed, tabs, req.symbols, out)
+    d = synth.model_s2(columns=12, vocab=300, batch=70, dims=dims)
+    tabs = d.numpy_tables()
+    req = d.make_request(2)
+    out, packed, _ = run_gpu(torch_cuda, d.spec, req.inputs, tabs, req.symbols)
+    assert_equal_oracle(oracle, d.spec, packed, tabs, req.symbols, out)
+
+
+def test_per_column_layout_and_concat_outputs(torch_cuda, oracle):
+    """FCP_LAYOUT_PER_COLUMN reproduces the reference arena (128-byte aligned
+    per-column buffers, cuda_emitter.cc:967-969, :2151-2179); ConcatOutputs
+    (concat_outputs_op_gpu.cu.cc:85-131) then yields the fused result."""
+    from recom_amd import synth
+    from recom_amd.ops import concat_outputs
+    from recom_amd.plan import LAYOUT_PER_COLUMN
+    m = synth.model_mixed(batch=50, vocab=997, n_groups=1)
+    tabs = m.numpy_tables()
+    req = m.make_request(4)
+    fused, packed, _ = run_gpu(torch_cuda, m.spec, req.inputs, tabs, req.symbols)
+    spec_pc = m.spec.with_layout(LAYOUT_PER_COLUMN)
+    pc, _, _ = run_gpu(torch_cuda, spec_pc, req.inputs, tabs, req.symbols)
+    # arena layout: prefix sums of alignmem(rows*dim*4)
+    base = pc.buffer.data_ptr()
+    cursor = 0
+    for k, c in enumerate(spec_pc.columns):
+        assert int(pc.output_ptrs[k]) - base == cursor
+        assert pc.output_row_strides[k] == c.dim
+        cursor += (50 * c.dim * 4 + 127) // 128 * 128
+    order = sorted(range(spec_pc.n_columns), key=lambda k: spec_pc.columns[k].concat_slot)
+    cat = concat_outputs([pc.column(k) for k in order])
+    torch_cuda.cuda.synchronize()
+    assert np.array_equal(cat.cpu().numpy(), fused.groups[0].cpu().numpy())
+    assert_equal_oracle(oracle, m.spec, packed, tabs, req.symbols, fused)
+
+
+def test_concat_outputs_many_inputs(torch_cuda, oracle):
+    from recom_amd.ops import concat_outputs
+    rng = np.random.default_rng(0)
+    xs = [rng.standard_normal((19, int(d))).astype(np.float32) for d in rng.integers(1, 40, 450)]
+    got = concat_outputs([torch_cuda.from_numpy(x).cuda() for x in xs])
+    torch_cuda.cuda.synchronize()
+    assert np.array_equal(got.cpu().numpy(), oracle.concat_outputs(xs))
+
+
+def test_bad_ids_read_as_zero_and_are_counted(torch_cuda, oracle):
+    from recom_amd import synth
+    from recom_amd.plan import FLAG_COUNT_BAD_IDS
+    m = synth.model_mixed(batch=64, vocab=997, n_groups=1)
+    spec = dataclasses.replace(m.spec, flags=FLAG_COUNT_BAD_IDS)
+    tabs = m.numpy_tables()
+    req = m.make_request(7)
+    inputs = [a.copy() for a in req.inputs]
+    c0 = spec.columns[0]       # dense int64 gather
+    inputs[c0.ids_input][[0, 5]] = [-1, 997]
+    c3 = spec.columns[3]       # ragged csr sum
+    inputs[c3.ids_input][:3] = [10 ** 12, -7, 1 << 40]
+    out, packed, op = run_gpu(torch_cuda, spec, inputs, tabs, req.symbols)
+    want, bad = assert_equal_oracle(oracle, spec, packed, tabs, req.symbols, out)
+    assert bad == 5
+    assert op.plan.read_bad_ids() == 5
+    assert not out.column(0).cpu().numpy()[[0, 5]].any()
+
+
+def test_error_codes(torch_cuda):
+    from recom_amd import lib, synth
+    from recom_amd.ops import FeatureColumnProcess, concat_inputs
+    m = synth.model_mixed(batch=16, vocab=97, n_groups=1)
+    tabs = [torch_cuda.from_numpy(t).cuda() for t in m.numpy_tables()]
+    op = FeatureColumnProcess(m.spec, 0)
+    req = m.make_request(0)
+    blob, offsets, shapes = concat_inputs(req.inputs)
+    d_blob = torch_cuda.from_numpy(blob).cuda()
+    with pytest.raises(lib.FcpError) as e:  # missing symbols
+        op(d_blob, offsets, shapes, tabs, None)
+    assert e.value.status == lib.FCP_ERR_INVALID_ARGUMENT
+    with pytest.raises(lib.FcpError) as e:  # groups disagree on the row count
+        op(d_blob, offsets, shapes, tabs, np.asarray([17], np.int32))
+    assert e.value.status == lib.FCP_ERR_SHAPE_MISMATCH
+    with pytest.raises(lib.FcpError) as e:  # blob shorter than the shapes say
+        op(d_blob[:100], offsets, shapes, tabs, req.symbols)
+    assert e.value.status == lib.FCP_ERR_SHAPE_MISMATCH
+    with pytest.raises(lib.FcpError) as e:  # wrong table shape
+        op(d_blob, offsets, shapes, [t[:-1] for t in tabs], req.symbols)
+    assert e.value.status == lib.FCP_ERR_SHAPE_MISMATCH
+    out = op(d_blob, offsets, shapes, tabs, req.symbols)  # still usable afterwards
+    torch_cuda.cuda.synchronize()
+    assert out.groups[0].shape[0] == 16
+
+
+def test_streams_share_a_plan(torch_cuda, oracle):
+    """Re-entrancy: one immutable plan used from several streams."""
+    from recom_amd import synth
+    from recom_amd.ops import FeatureColumnProcess, concat_inputs
+    torch = torch_cuda
+    m = synth.model_ragged(columns=32, vocab=2000, batch=128, seg="indices")
+    tabs_np = m.numpy_tables()
+    tabs = [torch.from_numpy(t).cuda() for t in tabs_np]
+    op = FeatureColumnProcess(m.spec, 0)
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    reqs = [m.make_request(s) for s in range(6)]
+    packed = [concat_inputs(r.inputs) for r in reqs]
+    blobs = [torch.from_numpy(p[0]).cuda() for p in packed]
+    torch.cuda.synchronize()
+    outs = []
+    for i, (r, p, b) in enumerate(zip(reqs, packed, blobs)):
+        s = streams[i % 3]
+        with torch.cuda.stream(s):
+            outs.append(op(b, p[1], p[2], tabs, r.symbols, stream=s.cuda_stream))
+    torch.cuda.synchronize()
+    for r, p, o in zip(reqs, packed, outs):
+        assert_equal_oracle(oracle, m.spec, p, tabs_np, r.symbols, o)
+
+
+def test_row_sharded_partials_and_finalize(torch_cuda, oracle):
+    """SHARD semantics on one GPU: world=4 plans over row shards produce partial
+    sums; fcp_shard_finalize adds the slices in rank order and applies the mean.
+    Dense columns are exact; pooled ones within 1e-5 of the unsharded result."""
+    from recom_amd import synth
+    from recom_amd.ops import FeatureColumnProcess, concat_inputs
+    torch = torch_cuda
+    m = synth.model_mixed(batch=48, vocab=997, n_groups=1)
+    tabs_np = m.numpy_tables()
+    req = m.make_request(3)
+    full, packed, _ = run_gpu(torch, m.spec, req.inputs, tabs_np, req.symbols)
+    world = 4
+    d_blob = torch.from_numpy(packed[0]).cuda()
+    parts, ops, shard_tabs = [], [], []
+    for rank in range(world):
+        spec = m.spec.with_shard(rank, world)
+        tabs = [torch.from_numpy(np.ascontiguousarray(t[rank::world])).cuda() for t in tabs_np]
+        op = FeatureColumnProcess(spec, 0)
+        out = op(d_blob, packed[1], packed[2], tabs, req.symbols)
+        torch.cuda.synchronize()
+        # per-rank partials equal the sharded oracle bit for bit
+        want, _ = oracle.process_feature_columns(spec.to_dict(), *packed, [t[rank::world] for t in tabs_np],
+                                                 req.symbols)
+        assert np.array_equal(out.groups[0].cpu().numpy(), want[0])
+        parts.append(out.groups[0].clone())
+        ops.append(op)
+        shard_tabs.append(tabs)
+    stacked = torch.stack(parts)  # [world, rows, width]
+    rows = stacked.shape[1]
+    # every rank finalizes its batch slice; here rank 1's slice of a 4-way split
+    lo, cnt = rows // 4, rows // 4
+    sl = stacked[:, lo:lo + cnt, :].contiguous()
+    fin = ops[1].shard_finalize(d_blob, packed[1], packed[2], shard_tabs[1], req.symbols, 0, sl, world, lo, cnt)
+    torch.cuda.synchronize()
+    got = fin.cpu().numpy()
+    ref = full.groups[0].cpu().numpy()[lo:lo + cnt]
+    offs = m.spec.column_offsets()
+    for k, c in enumerate(m.spec.columns):
+        a, b = got[:, offs[k]:offs[k] + c.dim], ref[:, offs[k]:offs[k] + c.dim]
+        if c.form in (1, 3, 4, 5):  # exactly one owner (table-free columns: rank 0): exact
+            assert np.array_equal(a, b)
+        else:
+            assert np.abs(a - b).max() < 1e-5
+
+
+def test_dlrm_scaled_vs_oracle(torch_cuda, oracle):
+    from recom_amd import synth
+    cards = [min(c, 40000) for c in synth.CRITEO_KAGGLE_CARDINALITIES]
+    m = synth.model_dlrm(batch=2048, cardinalities=cards)
+    tabs = m.numpy_tables()
+    req = m.make_request(0)
+    out, packed, _ = run_gpu(torch_cuda, m.spec, req.inputs, tabs, req.symbols)
+    assert out.groups[0].shape == (2048, 26 * 16 + 13)
+    assert_equal_oracle(oracle, m.spec, packed, tabs, req.symbols, out)
+
+
+def _closed_form_check(torch, model, req, out):
+    """Full-size property: a gather is a pure copy, so every output row must be
+    exactly the closed-form table row (synth.hash_rows) — no table on the host."""
+    from recom_amd import synth
+    import fcp_oracle as O
+    got = out.groups[0].cpu().numpy()
+    offs = model.spec.column_offsets()
+    for k, c in enumerate(model.spec.columns):
+        sl = got[:, offs[k]:offs[k] + c.dim]
+        raw = req.inputs[c.ids_input]
+        if c.form == 4:
+            assert np.array_equal(sl, raw.reshape(sl.shape))
+            continue
+        ids = O.np_bucketize(c.boundaries, raw) if c.id_source == 2 else raw
+        t = model.tables[c.table_input]
+        assert np.array_equal(sl, synth.hash_rows(t.seed, ids, c.dim)), f"column {k}"
+
+
+def test_dlrm_full_size_closed_form(torch_cuda):
+    """BASELINE.json configs[2]: 26 categorical (Criteo cardinalities) + 13 dense, batch 2048."""
+    from recom_amd import synth
+    torch = torch_cuda
+    m = synth.model_dlrm()
+    tabs = m.torch_tables(torch.device("cuda", 0))
+    req = m.make_request(1)
+    out, _, _ = run_gpu(torch, m.spec, req.inputs, None, req.symbols, tables_dev=tabs)
+    _closed_form_check(torch, m, req, out)
+
+
+def test_s2_full_size_closed_form(torch_cuda):
+    """BASELINE.json configs[1] at full size: 1000 columns, dims 8-64, vocab 1M
+    (120 GB of tables in HBM), batch 512.  Skipped if the device is too small."""
+    from recom_amd import synth
+    torch = torch_cuda
+    m = synth.model_s2()
+    free, _total = torch.cuda.mem_get_info()
+    if free < m.table_bytes() + (8 << 30):
+        pytest.skip(f"needs {m.table_bytes() / 2**30:.0f} GiB of HBM, {free / 2**30:.0f} GiB free")
+    tabs = m.torch_tables(torch.device("cuda", 0))
+    op = None
+    for seed in (0, 1):
+        req = m.make_request(seed)
+        out, _, op = run_gpu(torch, m.spec, req.inputs, None, req.symbols, op, tables_dev=tabs)
+        assert out.groups[0].shape == (512, 30000)
+        _closed_form_check(torch, m, req, out)
+    del tabs
+    torch.cuda.empty_cache()

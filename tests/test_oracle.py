@@ -1,0 +1,174 @@
+"""Pins the CPU oracle (oracle/fcp_oracle.c) — CPU only.
+
+The reference has no tests or golden vectors for this path, so the
+C oracle is pinned against (1) the committed fixtures in tests/golden/ (NumPy
+float64 + PyTorch-CPU expectations, see make_golden.py), (2) PyTorch-CPU
+``embedding_bag`` / ``bucketize`` / ``index_select`` evaluated live, (3) its own
+NumPy restatement, and (4) the reference's dim>20 summation order restated in
+``orc_sparse_segment_reduce_ref8x8`` (tolerance only).
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import fcp_oracle as O
+from conftest import GOLDEN_NAMES, check_against_expected
+
+
+@pytest.mark.parametrize("name", GOLDEN_NAMES)
+def test_oracle_matches_golden(oracle, golden, name):
+    case = golden[0][name]
+    outs, bad = oracle.process_feature_columns(case.plan, case.blob, case.offsets, case.shapes, case.tables,
+                                               case.symbols)
+    assert bad == 0
+    check_against_expected(case, outs)
+
+
+def test_oracle_threads_equal_serial(oracle, golden):
+    case = golden[0]["mixed_s0"]
+    a, _ = oracle.process_feature_columns(case.plan, case.blob, case.offsets, case.shapes, case.tables, case.symbols, 1)
+    b, _ = oracle.process_feature_columns(case.plan, case.blob, case.offsets, case.shapes, case.tables, case.symbols, 4)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+
+
+def test_bucketize_kat(oracle, golden):
+    z = golden[1]
+    case = golden[0]["bucketize_kat"]
+    got = oracle.bucketize(case.plan["columns"][0]["boundaries"], case.inputs[0])
+    assert np.array_equal(got, z["bucketize_kat/expected_buckets"])
+
+
+def test_bucketize_vs_torch_and_numpy(oracle):
+    rng = np.random.default_rng(0)
+    for n in (1, 2, 7, 100, 255):
+        b = np.sort(rng.uniform(-50, 50, n)).astype(np.float32)
+        v = np.concatenate([rng.uniform(-60, 60, 1000).astype(np.float32), b, b - 1e-3, b + 1e-3])
+        got = oracle.bucketize(b, v)
+        assert np.array_equal(got, O.np_bucketize(b, v))
+        t = torch.bucketize(torch.from_numpy(v), torch.from_numpy(b), right=True).numpy()
+        assert np.array_equal(got, t)
+    # NaN never compares below a boundary: last bucket (cuda_emitter.cc:240-244)
+    assert oracle.bucketize(np.arange(5, dtype=np.float32), np.asarray([np.nan], np.float32))[0] == 5
+
+
+def test_gather_rows_vs_torch(oracle):
+    rng = np.random.default_rng(1)
+    for dim in (1, 4, 8, 20, 64):
+        W = rng.standard_normal((300, dim)).astype(np.float32)
+        ids = rng.integers(0, 300, 257)
+        out, bad = oracle.gather_rows(W, ids)
+        assert bad == 0
+        assert np.array_equal(out, torch.from_numpy(W).index_select(0, torch.from_numpy(ids)).numpy())
+    out, bad = oracle.gather_rows(W, np.asarray([0, -1, 300, 299]))
+    assert bad == 2 and not out[1].any() and not out[2].any() and np.array_equal(out[3], W[299])
+
+
+def test_segment_offsets(oracle):
+    rng = np.random.default_rng(2)
+    for B in (1, 5, 64, 200):
+        for _ in range(5):
+            lens = rng.integers(0, 4, B)
+            seg = np.repeat(np.arange(B), lens)
+            off = oracle.segment_offsets(seg, B)
+            assert np.array_equal(off, np.concatenate([[0], np.cumsum(lens)]))
+            assert np.array_equal(off, O.np_segment_offsets(seg, B))
+    assert np.array_equal(oracle.segment_offsets(np.zeros(0, np.int64), 3), [0, 0, 0, 0])
+    # ids beyond num_segments fall off the end
+    assert np.array_equal(oracle.segment_offsets(np.asarray([0, 1, 7, 9]), 3), [0, 1, 2, 2])
+
+
+@pytest.mark.parametrize("mean", [False, True])
+@pytest.mark.parametrize("dim", [4, 8, 20, 32, 64])
+def test_segment_reduce_vs_embedding_bag(oracle, mean, dim):
+    rng = np.random.default_rng(dim + mean)
+    W = rng.standard_normal((500, dim)).astype(np.float32)
+    lens = rng.integers(0, 40, 77)
+    lens[:3] = [0, 1, 130]
+    ids = rng.integers(0, 500, int(lens.sum()))
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    out, bad = oracle.sparse_segment_reduce(W, ids, off, mean)
+    assert bad == 0
+    truth = O.np_sparse_segment_reduce(W, ids, off, mean)
+    # bags of up to 130 N(0,1) rows: |sum| reaches ~30, one fp32 ulp there is 2e-6
+    tol = 1e-5 if mean else 5e-5
+    assert np.abs(out - truth).max() < tol
+    bag = F.embedding_bag(torch.from_numpy(ids), torch.from_numpy(W), torch.from_numpy(off.astype(np.int64)),
+                          mode="mean" if mean else "sum", include_last_offset=True).numpy()
+    assert np.abs(out - bag).max() < tol
+    assert not out[0].any()  # empty segment -> zeros
+    # the reference's own dim>20 summation order differs only by fp32 reassociation
+    ref, _ = oracle.sparse_segment_reduce(W, ids, off, mean, ref_order=True)
+    assert np.abs(ref - truth).max() < tol
+    # a one-id segment is a pure copy in sum mode, in either order
+    if not mean:
+        assert np.array_equal(out[1], W[ids[0]]) and np.array_equal(ref[1], W[ids[0]])
+
+
+def test_gather_scatter(oracle):
+    W = np.arange(40, dtype=np.float32).reshape(10, 4)
+    out, bad = oracle.gather_scatter_rows(W, [1, 2, 3, 9], [0, 2, 2, 5], 7)
+    assert bad == 0
+    assert np.array_equal(out[0], W[1]) and np.array_equal(out[2], W[3]) and np.array_equal(out[5], W[9])
+    assert not out[[1, 3, 4, 6]].any()
+
+
+def test_concat_outputs_and_batch_col_reduction(oracle):
+    rng = np.random.default_rng(3)
+    xs = [rng.standard_normal((9, d)).astype(np.float32) for d in (3, 8, 1, 16)]
+    assert np.array_equal(oracle.concat_outputs(xs), np.concatenate(xs, axis=1))
+    x = rng.standard_normal((6, 5, 7)).astype(np.float32)
+    out = oracle.batch_col_reduction(x)
+    assert np.abs(out - x.astype(np.float64).sum(axis=1)).max() < 1e-5
+    seq = np.zeros((6, 7), np.float32)
+    for r in range(5):
+        seq = seq + x[:, r, :]  # r ascending, fp32 (cuda_emitter.cc:1231-1236)
+    assert np.array_equal(out, seq)
+
+
+def test_concat_inputs(oracle):
+    rng = np.random.default_rng(4)
+    ts = [rng.integers(0, 9, (5,)).astype(np.int64), rng.standard_normal((3, 2)).astype(np.float32),
+          np.zeros((0, 2), np.int64), np.asarray(7, np.int32)]
+    blob, off, shp = oracle.concat_inputs(ts)
+    assert np.array_equal(off, [0, 40, 64, 64])
+    assert np.array_equal(shp, [5, 3, 2, 0, 2])
+    assert blob.nbytes == 68
+    assert blob.tobytes() == b"".join(t.tobytes() for t in ts)
+
+
+def test_sharded_partials_sum_to_unsharded(oracle, golden):
+    """Row sharding: the sum over ranks of the per-rank partial
+    sums, with the mean division applied afterwards, equals the 1-GPU result."""
+    import copy
+    case = golden[0]["mixed_s0"]
+    full, _ = oracle.process_feature_columns(case.plan, case.blob, case.offsets, case.shapes, case.tables,
+                                             case.symbols)
+    world = 4
+    acc = [np.zeros_like(f, dtype=np.float64) for f in full]
+    for rank in range(world):
+        plan = copy.deepcopy(case.plan)
+        plan["shard_rank"], plan["shard_world"] = rank, world
+        tabs = [t[rank::world] for t in case.tables]
+        part, _ = oracle.process_feature_columns(plan, case.blob, case.offsets, case.shapes, tabs, case.symbols)
+        for a, p in zip(acc, part):
+            a += p
+    # apply the mean division to mean columns (table-free columns are written by rank 0 only)
+    from recom_amd.plan import PlanSpec
+    spec = case.spec()
+    offs = spec.column_offsets()
+    so = spec.shape_offsets()
+    for k, c in enumerate(spec.columns):
+        sl = acc[c.concat_group][:, offs[k]:offs[k] + c.dim]
+        if c.form == 2 and c.combiner == 2:
+            rows = sl.shape[0]
+            if c.seg_kind == 3:
+                o = case.inputs[c.seg_input]
+            else:
+                seg = case.inputs[c.seg_input].reshape(-1)[::c.seg_stride]
+                o = O.np_segment_offsets(seg, rows)
+            cnt = np.diff(o).astype(np.float64)
+            sl /= np.where(cnt > 0, cnt, 1.0)[:, None]
+    for a, f in zip(acc, full):
+        assert np.abs(a - f).max() < 1e-5
