@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""bench.py — BASELINE.json's metric on BASELINE.json's config.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload s2|dlrm|ragged|shard]
+
+A *step* is one request: one pass of the fused feature-column path (ids resident
+in HBM -> [batch, sum(dim)] concat output resident in HBM) over one batch of
+synthetic input.  Default workload = BASELINE.json configs[1] "S2": 1000 columns,
+dims 8/16/32/64, vocab 1M (120 GB of tables), batch 512, on 1 MI355X.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): the path shards by
+requests — every rank serves its own requests on its own replica of the tables,
+no data-path collective ("weak" scaling).  Only `--workload shard` (tables larger
+than one GPU's HBM) row-shards the tables and exchanges partial sums with an RCCL
+all-to-all.
+
+The timed loop is native (recom_amd/csrc/fcp_harness.hip); rank 0 prints ONE JSON
+line.  `roofline.achieved` = algorithmic bytes per request (SURVEY.md §8d formula,
+DESIGN.md §5) / average device time per request from HIP events recorded on the
+launch stream around the timed region.  `cpu_baseline` times the CPU oracle
+(oracle/, a port of the reference's TF-CPU semantics; TensorFlow is absent) on
+this box's host cores over a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+METRIC = "inference QPS + p50 latency, 1000-col synth model, batch 512, 1xMI355X"
+
+
+def cpu_baseline(model, budget_s: float = 12.0, sample_columns: int = 40):
+    """Time the CPU oracle (OpenMP over columns, all host cores) on a bounded
+    sample: the first `sample_columns` columns of the workload at full batch.
+    Returned value is scaled to whole-model inferences/s."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import fcp_oracle
+    from recom_amd.ops import concat_inputs
+    from recom_amd.plan import PlanSpec
+
+    cores = len(os.sched_getaffinity(0))
+    spec = model.spec
+    k = min(sample_columns, spec.n_columns)
+    cols = spec.columns[:k]
+    n_host = 1 + max(max(c.ids_input, c.seg_input) for c in cols)
+    n_tab = 1 + max(c.table_input for c in cols)
+    sub = PlanSpec(cols, spec.host_input_ranks[:n_host], spec.host_input_elem_sizes[:n_host], n_tab,
+                   n_groups=1, n_symbols=spec.n_symbols)
+    req = model.make_request(12345)
+    blob, offsets, shapes = concat_inputs(req.inputs[:n_host])
+    # table VALUES do not affect CPU time; fill cheaply instead of hashing GBs in NumPy
+    tables = []
+    for t in model.tables[:n_tab]:
+        a = np.empty((t.vocab, t.dim), np.float32)
+        a.reshape(-1)[:] = np.arange(a.size, dtype=np.float32) % 1024.0
+        tables.append(a)
+    orc = fcp_oracle.COracle()
+    plan = sub.to_dict()
+    rows = sub.group_rows(0, shapes, req.symbols)
+    out = [np.zeros((rows, sub.group_width(0)), np.float32)]
+    orc.process_feature_columns(plan, blob, offsets, shapes, tables, req.symbols, cores, out)  # warm
+    n, t0 = 0, time.perf_counter()
+    while True:
+        orc.process_feature_columns(plan, blob, offsets, shapes, tables, req.symbols, cores, out)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 20000:
+            break
+    per_call = el / n
+    scale = spec.n_columns / k
+    return {
+        "value": rows / (per_call * scale), "unit": "inferences/s", "cores": cores, "kind": "port",
+        "sample": f"first {k} of {spec.n_columns} columns at batch {rows}, {n} calls in {el:.1f} s, "
+                  f"scaled x{scale:.0f} to the whole model; OpenMP C port of TF-CPU semantics (TensorFlow absent)",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--workload", default="s2", choices=["s2", "dlrm", "ragged", "shard"])
+    ap.add_argument("--ids", default="uniform", choices=["uniform", "zipf"])
+    ap.add_argument("--threads", type=int, default=1, help="serve_workers per GPU (reference harness flag)")
+    ap.add_argument("--columns", type=int, default=0, help="override the column count (debug only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from recom_amd import synth
+    from recom_amd.harness import ServingHarness, copy_probe
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        print("bench.py: --gpus > 1 must be launched with torch.distributed.run", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    if args.workload == "shard":
+        from recom_amd.shard import bench_sharded
+        rec = bench_sharded(args, rank, world, local_rank, dist)
+        if rank == 0:
+            print(json.dumps(rec))
+        if dist:
+            dist.destroy_process_group()
+        return
+
+    if args.workload == "s2":
+        model = synth.model_s2(columns=args.columns or 1000, dist=args.ids)
+    elif args.workload == "dlrm":
+        model = synth.model_dlrm()
+    else:
+        model = synth.model_ragged(columns=args.columns or 512)
+
+    h = ServingHarness(model, device=local_rank, n_requests=16, arena_ring=6, n_threads=args.threads,
+                       seed0=1000 * rank)
+    bytes_alg = h.algorithmic_bytes()
+
+    h.run(max(args.warmup, 1))                       # W untimed warm-up steps
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    wall_ms, dev_ms, _ = h.run(args.steps)           # exactly K timed steps (native loop, ends with a stream sync)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # latency percentiles: separate pass with one HIP event pair per request
+    _, _, it = h.run(min(args.steps, 500), per_request=True)
+    batch = model.batch
+    steps_total = args.steps * args.threads
+    ms_per_step = elapsed * 1e3 / steps_total
+    value = world * batch * steps_total / elapsed
+    dev_ms_per_req = dev_ms / args.steps             # worker 0's stream, HIP events over the timed region
+
+    rec = {
+        "metric": METRIC, "value": value, "unit": "inferences/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{model.name}: {model.description}", "batch": batch,
+                   "columns": model.spec.n_columns, "table_bytes": model.table_bytes(),
+                   "parallelism": f"{world} replica(s), requests sharded across ranks, no collective",
+                   "serve_workers": args.threads},
+        "requests_per_s": value / batch,
+        "p50_latency_ms": float(np.percentile(it, 50)), "p95_latency_ms": float(np.percentile(it, 95)),
+    }
+    if rank == 0:
+        achieved = bytes_alg["total"] / (dev_ms_per_req * 1e-3) / 1e9
+        rec["roofline"] = {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "kernel": "fcp_fused_kernel", "kernel_avg_us": dev_ms_per_req * 1e3,
+            "algorithmic_bytes_per_request": bytes_alg,
+            "read_only_frac": bytes_alg["read"] / (dev_ms_per_req * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "measured_copy_peak_GBs": copy_probe() / 1e9,
+        }
+        if not args.no_cpu_baseline:
+            rec["cpu_baseline"] = cpu_baseline(model)
+        print(json.dumps(rec))
+    h.close()
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -324,6 +325,12 @@ int compute_dyn(const fcp_plan *p, const int32_t *offsets, const int32_t *shapes
   int rpw = 1;
   if (p->dense_only) {
     while (rpw < 8 && max_rows >= 64 * rpw) rpw *= 2; // 512 rows -> 8, 128 -> 2, < 64 -> 1
+    static const int forced = [] { // tuning aid: FCP_ROWS_PER_WAVE=1|2|4|8
+      const char *e = std::getenv("FCP_ROWS_PER_WAVE");
+      const int v = e ? std::atoi(e) : 0;
+      return (v == 1 || v == 2 || v == 4 || v == 8) ? v : 0;
+    }();
+    if (forced) rpw = forced;
   }
   m->rows_per_wave = rpw;
   int32_t blocks = 0;

@@ -1,0 +1,256 @@
+// fcp_bench — torch-free native driver for the S2-style workload (used for
+// rocprofv3 PMC passes and kernel ablations; bench.py remains the contract).
+//
+// Counterpart of the reference's `benchmark_multi_thread` CLI
+// (examples/cc/recom_examples.patch:98-263): builds the synthetic model (same
+// closed-form tables and column recipe as recom_amd/synth.py model_s2), keeps
+// `--requests` request blobs resident in HBM and drives libfcp_harness.
+//
+//   fcp_bench [--columns 1000] [--batch 512] [--vocab 1000000] [--steps 300]
+//             [--warmup 50] [--threads 1] [--requests 16] [--ring 6] [--verify 1]
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/fcp_hip.h"
+
+struct fcp_harness;
+extern "C" int fcp_harness_create(fcp_plan_t *, const fcp_process_args_t *, int, int, int, fcp_harness **);
+extern "C" int fcp_harness_run(fcp_harness *, int, double *, float *, float *);
+extern "C" int fcp_harness_destroy(fcp_harness *);
+
+#define CHECK_HIP(e)                                                                        \
+  do {                                                                                      \
+    hipError_t e_ = (e);                                                                    \
+    if (e_ != hipSuccess) {                                                                 \
+      std::fprintf(stderr, "%s:%d %s: %s\n", __FILE__, __LINE__, #e, hipGetErrorString(e_)); \
+      std::exit(1);                                                                         \
+    }                                                                                       \
+  } while (0)
+#define CHECK_FCP(e)                                                                                \
+  do {                                                                                              \
+    int s_ = (e);                                                                                   \
+    if (s_) {                                                                                       \
+      std::fprintf(stderr, "%s:%d %s: %s (%s)\n", __FILE__, __LINE__, #e, fcp_status_string(s_),   \
+                   fcp_last_error());                                                               \
+      std::exit(1);                                                                                 \
+    }                                                                                               \
+  } while (0)
+
+// table[t][r][e] — identical to recom_amd/synth.py hash_rows()
+__host__ __device__ inline float hash_elem(uint32_t seed, uint64_t r, uint32_t e) {
+  uint64_t u = (r * 2654435761ull + (uint64_t)e * 40503ull + ((seed * 7919u + 12345u) & 0xFFFFFFFFull)) & 0xFFFFFFFFull;
+  u ^= u >> 15;
+  u = (u * 0x2C1B3C6Dull) & 0xFFFFFFFFull;
+  u ^= u >> 12;
+  u = (u * 0x297A2D39ull) & 0xFFFFFFFFull;
+  u ^= u >> 15;
+  return (float)(u >> 8) * 1.1920928955078125e-07f - 1.0f; // 2^-23
+}
+
+__global__ void fill_table(float *t, uint32_t seed, uint64_t vocab, uint32_t dim) {
+  const uint64_t n = vocab * dim;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+    t[i] = hash_elem(seed, i / dim, (uint32_t)(i % dim));
+}
+
+static uint64_t splitmix(uint64_t &s) {
+  uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+static int bucketize_host(const std::vector<float> &b, float v) {
+  int l = 0, r = (int)b.size() - 1;
+  while (l <= r) {
+    int mid = (l + r) >> 1;
+    if (v < b[mid]) r = mid - 1; else l = mid + 1;
+  }
+  return r + 1;
+}
+
+static void *plain_alloc(void *ctx, size_t bytes) {
+  void **slot = static_cast<void **>(ctx);
+  if (hipMalloc(slot, bytes) != hipSuccess) return nullptr;
+  return *slot;
+}
+
+int main(int argc, char **argv) {
+  int columns = 1000, batch = 512, steps = 300, warmup = 50, threads = 1, requests = 16, ring = 6, verify = 1;
+  int bucketize_every = 10; // every N-th column is bucketize-f32 sourced (0 = none)
+  long vocab = 1000000;
+  for (int i = 1; i + 1 < argc; i += 2) {
+    std::string k = argv[i];
+    long v = std::atol(argv[i + 1]);
+    if (k == "--columns") columns = (int)v;
+    else if (k == "--batch") batch = (int)v;
+    else if (k == "--vocab") vocab = v;
+    else if (k == "--steps") steps = (int)v;
+    else if (k == "--warmup") warmup = (int)v;
+    else if (k == "--threads") threads = (int)v;
+    else if (k == "--requests") requests = (int)v;
+    else if (k == "--ring") ring = (int)v;
+    else if (k == "--verify") verify = (int)v;
+    else if (k == "--bucketize-every") bucketize_every = (int)v;
+    else { std::fprintf(stderr, "unknown flag %s\n", k.c_str()); return 2; }
+  }
+  const int dims[4] = {8, 16, 32, 64};
+  std::vector<float> boundaries(100);
+  for (int i = 0; i < 100; ++i) boundaries[i] = 5.0f * i;
+
+  // ---- plan (model_s2 of recom_amd/synth.py) ----------------------------------
+  std::vector<fcp_column_desc_t> cols(columns);
+  std::vector<int32_t> ranks(columns, 1), esz(columns);
+  for (int c = 0; c < columns; ++c) {
+    fcp_column_desc_t &d = cols[c];
+    std::memset(&d, 0, sizeof(d));
+    const bool bkt = bucketize_every > 0 && c % bucketize_every == 0;
+    d.form = FCP_FORM_GATHER;
+    d.dim = dims[c % 4];
+    d.vocab = vocab;
+    d.id_source = bkt ? FCP_IDS_F32_BUCKETIZE : FCP_IDS_I64;
+    d.table_input = c;
+    d.ids_input = c;
+    d.seg_input = -1;
+    d.seg_stride = 1;
+    d.rows_source = FCP_ROWS_FROM_IDS;
+    d.n_boundaries = bkt ? 100 : 0;
+    d.boundaries = bkt ? boundaries.data() : nullptr;
+    d.concat_group = 0;
+    d.concat_slot = c;
+    esz[c] = bkt ? 4 : 8;
+  }
+  fcp_plan_desc_t pd;
+  std::memset(&pd, 0, sizeof(pd));
+  pd.abi_version = FCP_ABI_VERSION;
+  pd.n_columns = columns;
+  pd.columns = cols.data();
+  pd.n_host_inputs = columns;
+  pd.host_input_ranks = ranks.data();
+  pd.host_input_elem_sizes = esz.data();
+  pd.n_device_inputs = columns;
+  pd.n_groups = 1;
+  pd.layout = FCP_LAYOUT_CONCAT;
+  pd.shard_world = 1;
+  fcp_plan_t *plan = nullptr;
+  CHECK_FCP(fcp_plan_create(&pd, &plan));
+
+  // ---- tables -------------------------------------------------------------------
+  std::vector<void *> tables(columns);
+  double table_bytes = 0;
+  for (int c = 0; c < columns; ++c) {
+    const size_t bytes = (size_t)vocab * cols[c].dim * 4;
+    CHECK_HIP(hipMalloc(&tables[c], bytes));
+    hipLaunchKernelGGL(fill_table, dim3(2048), dim3(256), 0, 0, (float *)tables[c], (uint32_t)(1000 + c),
+                       (uint64_t)vocab, (uint32_t)cols[c].dim);
+    table_bytes += bytes;
+  }
+  CHECK_HIP(hipDeviceSynchronize());
+
+  // ---- resident requests ------------------------------------------------------------
+  std::vector<std::vector<char>> blobs(requests);
+  std::vector<std::vector<int32_t>> offs(requests), shps(requests);
+  std::vector<void *> d_blobs(requests);
+  std::vector<fcp_process_args_t> variants(requests);
+  uint64_t rng = 0x1234;
+  for (int v = 0; v < requests; ++v) {
+    offs[v].resize(columns);
+    shps[v].assign(columns, batch);
+    size_t size = 0;
+    for (int c = 0; c < columns; ++c) {
+      offs[v][c] = (int32_t)size;
+      size += (size_t)batch * esz[c];
+    }
+    blobs[v].resize(size);
+    for (int c = 0; c < columns; ++c) {
+      char *p = blobs[v].data() + offs[v][c];
+      for (int b = 0; b < batch; ++b) {
+        if (esz[c] == 4) {
+          float x = -5.0f + 505.0f * (float)((splitmix(rng) >> 40) * (1.0 / 16777216.0));
+          std::memcpy(p + 4 * b, &x, 4);
+        } else {
+          int64_t id = (int64_t)(splitmix(rng) % (uint64_t)vocab);
+          std::memcpy(p + 8 * b, &id, 8);
+        }
+      }
+    }
+    CHECK_HIP(hipMalloc(&d_blobs[v], size));
+    CHECK_HIP(hipMemcpy(d_blobs[v], blobs[v].data(), size, hipMemcpyHostToDevice));
+    fcp_process_args_t &a = variants[v];
+    std::memset(&a, 0, sizeof(a));
+    a.concated_inputs = d_blobs[v];
+    a.concated_bytes = (int64_t)size;
+    a.concated_offsets = offs[v].data();
+    a.concated_shapes = shps[v].data();
+    a.input_ptrs = tables.data();
+  }
+
+  // ---- verification of one request against the closed form (bit-exact) -----------------
+  if (verify) {
+    void *arena = nullptr;
+    fcp_process_args_t a = variants[0];
+    a.malloc_buff = plain_alloc;
+    a.malloc_buff_ctx = &arena;
+    std::vector<void *> gp(1);
+    std::vector<int32_t> gs(2);
+    fcp_process_result_t res;
+    std::memset(&res, 0, sizeof(res));
+    res.group_ptrs = gp.data();
+    res.group_shapes = gs.data();
+    CHECK_FCP(fcp_process_feature_columns(plan, &a, &res));
+    CHECK_HIP(hipDeviceSynchronize());
+    const size_t W = gs[1];
+    std::vector<float> out((size_t)batch * W);
+    CHECK_HIP(hipMemcpy(out.data(), gp[0], out.size() * 4, hipMemcpyDeviceToHost));
+    size_t bad = 0, off = 0;
+    for (int c = 0; c < columns; ++c) {
+      const char *p = blobs[0].data() + offs[0][c];
+      for (int b = 0; b < batch; ++b) {
+        int64_t id;
+        if (esz[c] == 4) {
+          float x;
+          std::memcpy(&x, p + 4 * b, 4);
+          id = bucketize_host(boundaries, x);
+        } else {
+          std::memcpy(&id, p + 8 * b, 8);
+        }
+        for (int e = 0; e < cols[c].dim; ++e)
+          if (out[(size_t)b * W + off + e] != hash_elem(1000 + c, (uint64_t)id, e)) ++bad;
+      }
+      off += cols[c].dim;
+    }
+    std::printf("verify: %zu mismatching elements of %zu\n", bad, out.size());
+    CHECK_HIP(hipFree(arena));
+    if (bad) return 3;
+  }
+
+  // ---- timed run ----------------------------------------------------------------------
+  fcp_harness *h = nullptr;
+  CHECK_FCP(fcp_harness_create(plan, variants.data(), requests, ring, threads, &h));
+  double wall = 0;
+  float dev = 0;
+  CHECK_FCP(fcp_harness_run(h, warmup > 0 ? warmup : 1, &wall, &dev, nullptr));
+  CHECK_FCP(fcp_harness_run(h, steps, &wall, &dev, nullptr));
+  double width = 0, idb = 0;
+  for (int c = 0; c < columns; ++c) {
+    width += cols[c].dim;
+    idb += (double)batch * esz[c] + (esz[c] == 4 ? 400.0 : 0.0);
+  }
+  const double alg = 2.0 * batch * width * 4 + idb;
+  const double us = dev * 1e3 / steps;
+  std::printf("{\"columns\": %d, \"batch\": %d, \"table_GB\": %.1f, \"steps\": %d, \"threads\": %d, "
+              "\"wall_us_per_step\": %.3f, \"dev_us_per_step\": %.3f, \"alg_MB\": %.3f, \"alg_GBs\": %.1f, "
+              "\"frac_of_8TBs\": %.4f}\n",
+              columns, batch, table_bytes / 1e9, steps, threads, wall * 1e3 / (steps * threads), us, alg / 1e6,
+              alg / (us * 1e-6) / 1e9, alg / (us * 1e-6) / 8e12);
+  CHECK_FCP(fcp_harness_destroy(h));
+  CHECK_FCP(fcp_plan_destroy(plan));
+  return 0;
+}

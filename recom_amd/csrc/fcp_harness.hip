@@ -48,51 +48,19 @@ void *ring_alloc(void *ctx, size_t bytes) {
 
 } // namespace
 
-extern "C" {
+struct fcp_harness {
+  fcp_plan_t *plan = nullptr;
+  std::vector<fcp_process_args_t> variants;
+  std::vector<Ring> rings;
+  std::vector<hipStream_t> streams;
+  std::vector<int> status;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  long issued = 0; // requests issued so far per worker (variant rotation)
 
-// Runs `warmup` untimed + `steps` timed requests per worker thread.
-//   variants[n_variants]  request descriptors that are cycled through (their
-//                         stream / allocator fields are overwritten here);
-//   arena_ring            number of pre-allocated output arenas per worker;
-//   n_threads             serve_workers: host threads sharing the plan, one
-//                         stream each;
-//   wall_ms               host wall time of the timed region (all workers,
-//                         including the final stream synchronisation);
-//   dev_ms                HIP-event time over worker 0's timed region, taken on
-//                         the stream the kernels are launched on;
-//   iter_ms[steps]        optional: per-request device time of worker 0 from
-//                         HIP event pairs, measured in a SEPARATE pass after the
-//                         timed region (so the events do not perturb it).
-int fcp_harness_run(fcp_plan_t *plan, const fcp_process_args_t *variants, int n_variants, int arena_ring,
-                    int steps, int warmup, int n_threads, double *wall_ms, float *dev_ms, float *iter_ms) {
-  if (!plan || !variants || n_variants < 1 || steps < 1 || n_threads < 1 || arena_ring < 1)
-    return FCP_ERR_INVALID_ARGUMENT;
-  int64_t arena_bytes = 0;
-  for (int v = 0; v < n_variants; ++v) {
-    int64_t b = 0;
-    int rc = fcp_plan_arena_bytes(plan, variants[v].concated_shapes, variants[v].symbols, &b);
-    if (rc) return rc;
-    arena_bytes = std::max(arena_bytes, b);
-  }
-  std::vector<Ring> rings(n_threads);
-  std::vector<hipStream_t> streams(n_threads);
-  for (int t = 0; t < n_threads; ++t) {
-    H_TRY(hipStreamCreateWithFlags(&streams[t], hipStreamNonBlocking));
-    rings[t].bytes = (size_t)arena_bytes;
-    for (int i = 0; i < arena_ring; ++i) {
-      void *p = nullptr;
-      H_TRY(hipMalloc(&p, (size_t)std::max<int64_t>(arena_bytes, 256)));
-      rings[t].bufs.push_back(p);
-    }
-  }
-  hipEvent_t e0, e1;
-  H_TRY(hipEventCreate(&e0));
-  H_TRY(hipEventCreate(&e1));
-
-  std::vector<int> status(n_threads, FCP_OK);
-  auto issue = [&](int t, int begin, int count) {
-    for (int k = begin; k < begin + count; ++k) {
-      fcp_process_args_t a = variants[(k + t) % n_variants];
+  void issue(int t, long begin, int count) {
+    const int nv = (int)variants.size();
+    for (long k = begin; k < begin + count; ++k) {
+      fcp_process_args_t a = variants[(size_t)((k + t) % nv)];
       a.stream = streams[t];
       a.malloc_buff = ring_alloc;
       a.malloc_buff_ctx = &rings[t];
@@ -104,54 +72,102 @@ int fcp_harness_run(fcp_plan_t *plan, const fcp_process_args_t *variants, int n_
         return;
       }
     }
-  };
-
-  // warm-up (binds tables, fills the descriptor cache) — untimed
-  for (int t = 0; t < n_threads; ++t) issue(t, 0, std::max(warmup, 1));
-  for (int t = 0; t < n_threads; ++t) H_TRY(hipStreamSynchronize(streams[t]));
-  for (int t = 0; t < n_threads; ++t)
-    if (status[t]) return status[t];
-
-  // timed region: exactly `steps` requests per worker
-  const auto t0 = std::chrono::steady_clock::now();
-  H_TRY(hipEventRecord(e0, streams[0]));
-  if (n_threads == 1) {
-    issue(0, warmup, steps);
-  } else {
-    std::vector<std::thread> workers;
-    for (int t = 1; t < n_threads; ++t) workers.emplace_back(issue, t, warmup, steps);
-    issue(0, warmup, steps);
-    for (auto &w : workers) w.join();
   }
-  H_TRY(hipEventRecord(e1, streams[0]));
-  for (int t = 0; t < n_threads; ++t) H_TRY(hipStreamSynchronize(streams[t]));
-  const auto t1 = std::chrono::steady_clock::now();
-  for (int t = 0; t < n_threads; ++t)
-    if (status[t]) return status[t];
-  if (wall_ms) *wall_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
-  if (dev_ms) H_TRY(hipEventElapsedTime(dev_ms, e0, e1));
+};
 
-  // separate pass: per-request device latency (p50 / p95 material)
-  if (iter_ms) {
-    std::vector<hipEvent_t> ev(2 * (size_t)steps);
-    for (auto &e : ev) H_TRY(hipEventCreate(&e));
-    for (int k = 0; k < steps; ++k) {
-      H_TRY(hipEventRecord(ev[2 * k], streams[0]));
-      issue(0, warmup + k, 1);
-      H_TRY(hipEventRecord(ev[2 * k + 1], streams[0]));
+extern "C" {
+
+// variants[n_variants]: request descriptors that are cycled through (their
+// stream / allocator fields are overwritten; the arrays they point to must stay
+// alive).  arena_ring: pre-allocated output arenas per worker.  n_threads:
+// serve_workers — host threads sharing the plan, one stream each.
+int fcp_harness_create(fcp_plan_t *plan, const fcp_process_args_t *variants, int n_variants, int arena_ring,
+                       int n_threads, fcp_harness **out) {
+  if (!plan || !variants || !out || n_variants < 1 || n_threads < 1 || arena_ring < 1)
+    return FCP_ERR_INVALID_ARGUMENT;
+  int64_t arena_bytes = 0;
+  for (int v = 0; v < n_variants; ++v) {
+    int64_t b = 0;
+    int rc = fcp_plan_arena_bytes(plan, variants[v].concated_shapes, variants[v].symbols, &b);
+    if (rc) return rc;
+    arena_bytes = std::max(arena_bytes, b);
+  }
+  fcp_harness *h = new fcp_harness();
+  h->plan = plan;
+  h->variants.assign(variants, variants + n_variants);
+  h->rings.resize(n_threads);
+  h->streams.resize(n_threads);
+  h->status.assign(n_threads, FCP_OK);
+  for (int t = 0; t < n_threads; ++t) {
+    H_TRY(hipStreamCreateWithFlags(&h->streams[t], hipStreamNonBlocking));
+    h->rings[t].bytes = (size_t)arena_bytes;
+    for (int i = 0; i < arena_ring; ++i) {
+      void *p = nullptr;
+      H_TRY(hipMalloc(&p, (size_t)std::max<int64_t>(arena_bytes, 256)));
+      h->rings[t].bufs.push_back(p);
     }
-    H_TRY(hipStreamSynchronize(streams[0]));
+  }
+  H_TRY(hipEventCreate(&h->e0));
+  H_TRY(hipEventCreate(&h->e1));
+  *out = h;
+  return FCP_OK;
+}
+
+// Issues exactly `steps` requests per worker and waits for them.
+//   wall_ms   host wall time (issue + final stream synchronisation);
+//   dev_ms    HIP-event time over worker 0's requests, recorded on the stream
+//             the kernels are launched on;
+//   iter_ms   optional float[steps]: per-request device time of worker 0 from
+//             one HIP event pair per request (perturbs throughput slightly — use
+//             a separate call for latency percentiles).
+int fcp_harness_run(fcp_harness *h, int steps, double *wall_ms, float *dev_ms, float *iter_ms) {
+  if (!h || steps < 1) return FCP_ERR_INVALID_ARGUMENT;
+  const int n_threads = (int)h->streams.size();
+  const long begin = h->issued;
+  std::vector<hipEvent_t> ev;
+  if (iter_ms) {
+    ev.resize(2 * (size_t)steps);
+    for (auto &e : ev) H_TRY(hipEventCreate(&e));
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  H_TRY(hipEventRecord(h->e0, h->streams[0]));
+  std::vector<std::thread> workers;
+  for (int t = 1; t < n_threads; ++t) workers.emplace_back([h, t, begin, steps] { h->issue(t, begin, steps); });
+  if (iter_ms) {
+    for (int k = 0; k < steps; ++k) {
+      H_TRY(hipEventRecord(ev[2 * k], h->streams[0]));
+      h->issue(0, begin + k, 1);
+      H_TRY(hipEventRecord(ev[2 * k + 1], h->streams[0]));
+    }
+  } else {
+    h->issue(0, begin, steps);
+  }
+  for (auto &w : workers) w.join();
+  H_TRY(hipEventRecord(h->e1, h->streams[0]));
+  for (int t = 0; t < n_threads; ++t) H_TRY(hipStreamSynchronize(h->streams[t]));
+  const auto t1 = std::chrono::steady_clock::now();
+  h->issued += steps;
+  for (int t = 0; t < n_threads; ++t)
+    if (h->status[t]) return h->status[t];
+  if (wall_ms) *wall_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+  if (dev_ms) H_TRY(hipEventElapsedTime(dev_ms, h->e0, h->e1));
+  if (iter_ms) {
     for (int k = 0; k < steps; ++k) H_TRY(hipEventElapsedTime(&iter_ms[k], ev[2 * k], ev[2 * k + 1]));
     for (auto &e : ev) (void)hipEventDestroy(e);
-    if (status[0]) return status[0];
   }
+  return FCP_OK;
+}
 
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
-  for (int t = 0; t < n_threads; ++t) {
-    for (void *p : rings[t].bufs) (void)hipFree(p);
-    (void)hipStreamDestroy(streams[t]);
+int fcp_harness_destroy(fcp_harness *h) {
+  if (!h) return FCP_OK;
+  for (size_t t = 0; t < h->streams.size(); ++t) {
+    (void)hipStreamSynchronize(h->streams[t]);
+    for (void *p : h->rings[t].bufs) (void)hipFree(p);
+    (void)hipStreamDestroy(h->streams[t]);
   }
+  if (h->e0) (void)hipEventDestroy(h->e0);
+  if (h->e1) (void)hipEventDestroy(h->e1);
+  delete h;
   return FCP_OK;
 }
 

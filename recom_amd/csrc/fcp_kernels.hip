@@ -80,12 +80,56 @@ __device__ __forceinline__ int bucketize(const float *__restrict__ b, int n, flo
 }
 
 // The index expression the reference inlines per column (EmitInputInline,
-// :1769-1949): raw int32 / int64 ids, or Bucketize(float value).
-__device__ __forceinline__ int64_t load_id(const char *ids, unsigned idsrc, int64_t p,
-                                           const float *bnd, int nb) {
-  if (idsrc == FCP_IDS_I64) return ld_i64_a4(ids + 8 * p);
-  if (idsrc == FCP_IDS_I32) return *reinterpret_cast<const int32_t *>(ids + 4 * p);
-  return bucketize(bnd, nb, *reinterpret_cast<const float *>(ids + 4 * p));
+// :1769-1949): raw int32 / int64 ids, or Bucketize(float value).  The fetch is
+// branch-free on purpose — one code path for every id source, so that the
+// compiler can issue the fetches of all rows of a wave back to back and wait
+// once (a switch per id source serialises them behind one s_waitcnt each).
+__device__ __forceinline__ void ld_raw_id(const char *ids, bool is64, int64_t p, uint32_t &lo, uint32_t &hi) {
+  const char *a = ids + (is64 ? 8 : 4) * p;
+  lo = *reinterpret_cast<const uint32_t *>(a);
+  hi = *reinterpret_cast<const uint32_t *>(a + (is64 ? 4 : 0));
+}
+
+__device__ __forceinline__ int64_t raw_to_id(bool is64, uint32_t lo, uint32_t hi) {
+  return is64 ? (int64_t)(((uint64_t)hi << 32) | lo) : (int64_t)(int32_t)lo;
+}
+
+// N binary searches (cuda_emitter.cc:233-247) advanced in lockstep: every step
+// issues N independent boundary loads, so a wave pays ~log2(n) dependent round
+// trips for all its rows together instead of N x log2(n).
+template <int N>
+__device__ __forceinline__ void bucketize_lockstep(const float *__restrict__ bnd, int nb, const uint32_t (&raw)[N],
+                                                   int64_t (&id)[N]) {
+  int l[N], h[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    l[k] = 0;
+    h[k] = nb - 1;
+  }
+  for (int it = 0; it < 32; ++it) {
+    bool any = false;
+    float bv[N];
+    int mid[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      mid[k] = max((l[k] + h[k]) >> 1, 0);
+      bv[k] = bnd[mid[k]];
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      if (l[k] <= h[k]) {
+        if (__uint_as_float(raw[k]) < bv[k]) {
+          h[k] = mid[k] - 1;
+        } else {
+          l[k] = mid[k] + 1;
+        }
+      }
+      any |= l[k] <= h[k];
+    }
+    if (!any) break;
+  }
+#pragma unroll
+  for (int k = 0; k < N; ++k) id[k] = h[k] + 1;
 }
 
 // Validity + row sharding.  Returns true when this GPU must read a row; `id`
@@ -158,40 +202,63 @@ __global__ void __launch_bounds__(FCP_BLOCK_THREADS) fcp_fused_kernel(const FcpL
   const int world = L.shard_world, rank = L.shard_rank;
 
   if (DENSE) {
-    VF<V> v[R];
-    if (form == FCP_FORM_PASSTHROUGH) {
+    // Phase 1: fetch the raw ids of all R rows (branch-free, one wait).
+    const bool is64 = idsrc == FCP_IDS_I64;
+    const bool passthrough = form == FCP_FORM_PASSTHROUGH;
+    uint32_t lo[R], hi[R];
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const int b = row0 + r;
-        v[r] = vzero<V>();
-        // table-free columns belong to shard rank 0
-        if (b < rows && rank == 0) v[r] = ld_blob_f32<V>(ids + 4 * ((int64_t)b * cs.dim + e));
-      }
+    for (int r = 0; r < R; ++r) ld_raw_id(ids, is64, min(row0 + r, rows - 1), lo[r], hi[r]);
+    // Phase 2: ids -> table rows.
+    int64_t id[R];
+    if (idsrc == FCP_IDS_F32_BUCKETIZE && !passthrough) {
+      bucketize_lockstep<R>(cs.boundaries, cs.n_boundaries, lo, id);
     } else {
-      int64_t id[R];
-      bool ok[R];
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const int b = row0 + r;
-        id[r] = 0;
-        ok[r] = false;
-        if (b < rows) {
-          id[r] = load_id(ids, idsrc, b, cs.boundaries, cs.n_boundaries);
-          bool bad;
-          ok[r] = resolve_id(id[r], cs.vocab, rank, world, bad);
-          if (bad && e == 0 && L.bad_ids) atomicAdd(L.bad_ids, 1ull);
-        }
-      }
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        v[r] = vzero<V>();
-        if (ok[r]) v[r] = ld_row<V>(cs.table, id[r], cs.dim, e);
-      }
+      for (int r = 0; r < R; ++r) id[r] = raw_to_id(is64, lo[r], hi[r]);
     }
+    const float *src[R];
+    bool ok[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int b = row0 + r;
+      bool bad = false;
+      ok[r] = b < rows;
+      if (passthrough) {
+        // a tensor of the blob copied into its concat slot; table-free columns
+        // belong to shard rank 0
+        ok[r] = ok[r] && rank == 0;
+        src[r] = reinterpret_cast<const float *>(ids) + (int64_t)min(b, rows - 1) * cs.dim + e;
+      } else {
+        ok[r] = resolve_id(id[r], cs.vocab, rank, world, bad) && ok[r];
+        src[r] = cs.table + (ok[r] ? id[r] : 0) * (int64_t)cs.dim + e;
+        if (bad && b < rows && e == 0 && L.bad_ids) atomicAdd(L.bad_ids, 1ull);
+      }
+    }
+#if defined(FCP_ABLATE) && FCP_ABLATE == 3 // timing-only build: sequential instead of random rows
+#pragma unroll
+    for (int r = 0; r < R; ++r) src[r] = cs.table + (((int64_t)(row0 + r) * 131 + c * 977) % cs.vocab) * cs.dim + e;
+#endif
+    // Phase 3: all row reads in flight together.
+    VF<V> v[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      v[r] = vzero<V>();
+#if !(defined(FCP_ABLATE) && FCP_ABLATE == 1) // timing-only build 1: no table reads
+      if (ok[r]) v[r] = *reinterpret_cast<const VF<V> *>(src[r]);
+#else
+      v[r].v[0] = (float)id[r];
+#endif
+    }
+    // Phase 4: 1 KiB contiguous per wave store, directly in concat layout.
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int b = row0 + r;
+#if defined(FCP_ABLATE) && FCP_ABLATE == 2 // timing-only build 2: no output stores
+      asm volatile("" ::"v"(v[r].v[0]), "v"(v[r].v[V - 1]));
+      if (b < rows && v[r].v[0] == 1234.5f) st_out<V>(outp + (int64_t)b * ostride, v[r]);
+#else
       if (b < rows) st_out<V>(outp + (int64_t)b * ostride, v[r]);
+#endif
     }
     return;
   }
@@ -199,6 +266,7 @@ __global__ void __launch_bounds__(FCP_BLOCK_THREADS) fcp_fused_kernel(const FcpL
   // ---- generic path: one output row at a time, ragged segment loop ---------
   const unsigned segkind = FCP_F_SEGKIND(cs.flags);
   const bool mean = FCP_F_COMBINER(cs.flags) == FCP_COMBINER_MEAN && world == 1;
+  const bool is64 = idsrc == FCP_IDS_I64;
   const int32_t *csr = nullptr;
   if (segkind == FCP_SEG_CSR_I32) {
     csr = reinterpret_cast<const int32_t *>(L.blob + cd.seg_off);
@@ -237,9 +305,16 @@ __global__ void __launch_bounds__(FCP_BLOCK_THREADS) fcp_fused_kernel(const FcpL
         // GATHER: the row; GATHER_SCATTER: the last id of the row wins, a row
         // without ids stays zero (pre-zeroed arena, cuda_emitter.cc:1351-1359).
         if (cnt > 0) {
-          int64_t id = load_id(ids, idsrc, hi - 1, cs.boundaries, cs.n_boundaries);
+          uint32_t rlo[1], rhi[1];
+          int64_t id[1];
+          ld_raw_id(ids, is64, hi - 1, rlo[0], rhi[0]);
+          if (idsrc == FCP_IDS_F32_BUCKETIZE) {
+            bucketize_lockstep<1>(cs.boundaries, cs.n_boundaries, rlo, id);
+          } else {
+            id[0] = raw_to_id(is64, rlo[0], rhi[0]);
+          }
           bool bad;
-          if (resolve_id(id, cs.vocab, rank, world, bad)) acc = ld_row<V>(cs.table, id, cs.dim, e);
+          if (resolve_id(id[0], cs.vocab, rank, world, bad)) acc = ld_row<V>(cs.table, id[0], cs.dim, e);
           if (bad && e == 0 && L.bad_ids) atomicAdd(L.bad_ids, 1ull);
         }
       } else {
@@ -249,16 +324,20 @@ __global__ void __launch_bounds__(FCP_BLOCK_THREADS) fcp_fused_kernel(const FcpL
         for (int i = lo; i < hi; i += 4) {
           int64_t id[4];
           bool ok[4];
+          uint32_t rlo[4], rhi[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) ld_raw_id(ids, is64, min(i + k, hi - 1), rlo[k], rhi[k]);
+          if (idsrc == FCP_IDS_F32_BUCKETIZE) {
+            bucketize_lockstep<4>(cs.boundaries, cs.n_boundaries, rlo, id);
+          } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) id[k] = raw_to_id(is64, rlo[k], rhi[k]);
+          }
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
-            id[k] = 0;
-            ok[k] = false;
-            if (i + k < hi) {
-              id[k] = load_id(ids, idsrc, i + k, cs.boundaries, cs.n_boundaries);
-              bool bad;
-              ok[k] = resolve_id(id[k], cs.vocab, rank, world, bad);
-              if (bad && e == 0 && L.bad_ids) atomicAdd(L.bad_ids, 1ull);
-            }
+            bool bad;
+            ok[k] = resolve_id(id[k], cs.vocab, rank, world, bad) && (i + k < hi);
+            if (bad && (i + k < hi) && e == 0 && L.bad_ids) atomicAdd(L.bad_ids, 1ull);
           }
           VF<V> w[4];
 #pragma unroll

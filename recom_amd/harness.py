@@ -1,0 +1,110 @@
+"""Python face of the native measurement harness (``libfcp_harness.so``).
+
+The timing loops themselves are C++ (``csrc/fcp_harness.hip``), mirroring the
+reference's ``benchmark_multi_thread`` protocol
+(``examples/cc/recom_examples.patch:98-263``): a shared model, ``serve_workers``
+host threads, warm-up, N timed requests, latency + throughput.  Python only
+prepares the model, the requests and the result record.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import lib as _lib
+from .ops import Plan, concat_inputs
+from .synth import Request, SynthModel
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HARNESS_PATH = os.path.join(_HERE, "libfcp_harness.so")
+_h = None
+
+
+def load() -> C.CDLL:
+    global _h
+    if _h is None:
+        _lib.load()
+        if not os.path.exists(HARNESS_PATH):
+            raise ImportError(f"{HARNESS_PATH} not built; run __graft_entry__.build()")
+        H = C.CDLL(HARNESS_PATH)
+        H.fcp_harness_create.argtypes = [C.c_void_p, C.POINTER(_lib.ProcessArgs), C.c_int, C.c_int, C.c_int,
+                                         C.POINTER(C.c_void_p)]
+        H.fcp_harness_run.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_float),
+                                      C.c_void_p]
+        H.fcp_harness_destroy.argtypes = [C.c_void_p]
+        H.fcp_harness_copy_probe.argtypes = [C.c_size_t, C.c_int, C.POINTER(C.c_float)]
+        _h = H
+    return _h
+
+
+class ServingHarness:
+    """A plan + resident tables + a set of resident request blobs, driven by the
+    native loop.  Inputs are already in HBM when a timed region starts."""
+
+    def __init__(self, model: SynthModel, device: int = 0, n_requests: int = 16, arena_ring: int = 6,
+                 n_threads: int = 1, tables=None, spec=None, seed0: int = 0) -> None:
+        import torch
+        self.torch = torch
+        self.model = model
+        self.dev = torch.device("cuda", device)
+        self.H = load()
+        self.spec = spec or model.spec
+        self.plan = Plan(self.spec, device)
+        self.tables = tables if tables is not None else model.torch_tables(self.dev, self.spec.shard_rank,
+                                                                           self.spec.shard_world)
+        self.requests: List[Request] = [model.make_request(seed0 + s) for s in range(n_requests)]
+        self._keep = []
+        self.packed = []
+        args = (_lib.ProcessArgs * n_requests)()
+        tptrs = (C.c_void_p * max(1, len(self.tables)))(*[t.data_ptr() for t in self.tables])
+        self._keep.append(tptrs)
+        for i, r in enumerate(self.requests):
+            blob, offsets, shapes = concat_inputs(r.inputs)
+            d_blob = torch.from_numpy(blob).to(self.dev)
+            sym = None if r.symbols is None else np.ascontiguousarray(r.symbols, np.int32)
+            self._keep += [d_blob, offsets, shapes, sym]
+            self.packed.append((blob, offsets, shapes))
+            args[i] = _lib.ProcessArgs(
+                d_blob.data_ptr(), blob.nbytes, offsets.ctypes.data_as(C.POINTER(C.c_int32)),
+                shapes.ctypes.data_as(C.POINTER(C.c_int32)), tptrs, None,
+                None if sym is None else sym.ctypes.data_as(C.POINTER(C.c_int32)), None,
+                _lib.ALLOC_FN(), None, _lib.ALLOC_FN(), None)
+        self._args = args
+        handle = C.c_void_p()
+        torch.cuda.synchronize()
+        _lib.check(self.H.fcp_harness_create(self.plan.handle, args, n_requests, arena_ring, n_threads,
+                                             C.byref(handle)), "fcp_harness_create")
+        self.handle = handle
+        self.n_threads = n_threads
+
+    def run(self, steps: int, per_request: bool = False):
+        """Returns (wall_ms, dev_ms, iter_ms or None) for exactly `steps` requests per worker."""
+        wall, dev = C.c_double(), C.c_float()
+        it = np.zeros(steps, np.float32) if per_request else None
+        _lib.check(self.H.fcp_harness_run(self.handle, steps, C.byref(wall), C.byref(dev),
+                                          None if it is None else it.ctypes.data), "fcp_harness_run")
+        return wall.value, dev.value, it
+
+    def algorithmic_bytes(self) -> dict:
+        """Mean algorithmic bytes per request over the resident requests."""
+        acc = None
+        for (blob, offsets, shapes), r in zip(self.packed, self.requests):
+            b = self.spec.algorithmic_bytes(shapes, r.symbols)
+            acc = b if acc is None else {k: acc[k] + b[k] for k in b}
+        return {k: v / len(self.requests) for k, v in acc.items()}
+
+    def close(self) -> None:
+        if getattr(self, "handle", None):
+            self.H.fcp_harness_destroy(self.handle)
+            self.handle = None
+        self.plan.close()
+
+
+def copy_probe(nbytes: int = 1 << 30, iters: int = 20) -> float:
+    """Measured float4 copy bandwidth (read + write bytes / s)."""
+    ms = C.c_float()
+    _lib.check(load().fcp_harness_copy_probe(nbytes, iters, C.byref(ms)), "copy probe")
+    return 2.0 * nbytes / (ms.value * 1e-3)
