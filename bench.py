@@ -36,6 +36,17 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 METRIC = "inference QPS + p50 latency, 1000-col synth model, batch 512, 1xMI355X"
 
 
+def measured_traffic(workload):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json:
+    (2 x FETCH_SIZE + WRITE_SIZE) x 1024, the gfx950 correction of MI355X_MICROARCH.md).
+    PMC counters cannot be collected from inside this process."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            return json.load(f)[workload]["traffic_bytes"]
+    except Exception:
+        return None
+
+
 def cpu_baseline(model, budget_s: float = 12.0, sample_columns: int = 40):
     """Time the CPU oracle (OpenMP over columns, all host cores) on a bounded
     sample: the first `sample_columns` columns of the workload at full batch.
@@ -65,20 +76,32 @@ def cpu_baseline(model, budget_s: float = 12.0, sample_columns: int = 40):
     plan = sub.to_dict()
     rows = sub.group_rows(0, shapes, req.symbols)
     out = [np.zeros((rows, sub.group_width(0)), np.float32)]
-    orc.process_feature_columns(plan, blob, offsets, shapes, tables, req.symbols, cores, out)  # warm
-    n, t0 = 0, time.perf_counter()
-    while True:
-        orc.process_feature_columns(plan, blob, offsets, shapes, tables, req.symbols, cores, out)
-        n += 1
-        el = time.perf_counter() - t0
-        if el > budget_s or n >= 20000:
-            break
-    per_call = el / n
+
+    def timed(threads, budget):
+        orc.process_feature_columns(plan, blob, offsets, shapes, tables, req.symbols, threads, out)  # warm
+        n, t0 = 0, time.perf_counter()
+        while True:
+            orc.process_feature_columns(plan, blob, offsets, shapes, tables, req.symbols, threads, out)
+            n += 1
+            el = time.perf_counter() - t0
+            if el > budget or n >= 20000:
+                return el / n, n, el
+
+    # pick the thread count that serves this sample fastest (more threads than the
+    # cgroup grants, or than there are columns, only adds OpenMP overhead)
+    cands = sorted({t for t in (1, 4, 8, 16, 32, 64, cores) if t <= max(cores, 1) and t <= 4 * k})
+    best = None
+    for t in cands:
+        per_call, n, el = timed(t, budget_s / (2 * len(cands)))
+        if best is None or per_call < best[0]:
+            best = (per_call, t)
+    per_call, n, el = timed(best[1], budget_s / 2)
     scale = spec.n_columns / k
     return {
-        "value": rows / (per_call * scale), "unit": "inferences/s", "cores": cores, "kind": "port",
-        "sample": f"first {k} of {spec.n_columns} columns at batch {rows}, {n} calls in {el:.1f} s, "
-                  f"scaled x{scale:.0f} to the whole model; OpenMP C port of TF-CPU semantics (TensorFlow absent)",
+        "value": rows / (per_call * scale), "unit": "inferences/s", "cores": best[1], "kind": "port",
+        "sample": f"first {k} of {spec.n_columns} columns at batch {rows}, {n} calls in {el:.1f} s with "
+                  f"{best[1]} OpenMP threads (best of {cands}; {cores} cores visible), scaled x{scale:.0f} to the "
+                  f"whole model; C port of TF-CPU semantics (TensorFlow absent)",
     }
 
 
@@ -149,6 +172,16 @@ def main():
 
     # latency percentiles: separate pass with one HIP event pair per request
     _, _, it = h.run(min(args.steps, 500), per_request=True)
+    # overlapped serving (the reference harness' serve_workers): independent requests on
+    # 3 streams hide each launch's ramp / tail behind its neighbours.  Extra field only.
+    overlap = None
+    if args.threads == 1 and not dist:
+        h3 = ServingHarness(model, device=local_rank, n_requests=16, arena_ring=6, n_threads=3,
+                            tables=h.tables, seed0=1000 * rank)
+        h3.run(max(args.warmup // 3, 1))
+        w3, _, _ = h3.run(max(args.steps // 3, 1))
+        overlap = {"serve_workers": 3, "us_per_request": w3 * 1e3 / (3 * max(args.steps // 3, 1))}
+        h3.close()
     batch = model.batch
     steps_total = args.steps * args.threads
     ms_per_step = elapsed * 1e3 / steps_total
@@ -170,12 +203,16 @@ def main():
         achieved = bytes_alg["total"] / (dev_ms_per_req * 1e-3) / 1e9
         rec["roofline"] = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-            "kernel": "fcp_fused_kernel", "kernel_avg_us": dev_ms_per_req * 1e3,
+            "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.workload),
+            "kernel": "fcp_dense_kernel" if h.plan.spec is not None and all(c.form in (1, 4) for c in model.spec.columns) else "fcp_fused_kernel", "kernel_avg_us": dev_ms_per_req * 1e3,
             "algorithmic_bytes_per_request": bytes_alg,
             "read_only_frac": bytes_alg["read"] / (dev_ms_per_req * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "measured_copy_peak_GBs": copy_probe() / 1e9,
         }
+        if overlap:
+            overlap["inferences_per_s"] = batch / (overlap["us_per_request"] * 1e-6)
+            overlap["aggregate_frac_of_peak"] = bytes_alg["total"] / (overlap["us_per_request"] * 1e-6) / 1e9 / HBM_PEAK_GBS
+            rec["overlapped_serving"] = overlap
         if not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(model)
         print(json.dumps(rec))

@@ -93,6 +93,10 @@ struct fcp_plan {
   std::vector<int32_t> ranks, elem_sizes, shape_off;
   std::vector<int32_t> group_width, group_nslots, group_map_off;
   std::vector<int32_t> seg_cols;
+  // device arrays are kept in concat order (group-major, ascending concat offset)
+  // so that the columns of one output span are contiguous: order[pos] = column,
+  // pos_of[column] = pos.
+  std::vector<int32_t> order, pos_of;
   int vec = 1;
   bool dense_only = true;
   bool host_only = false;
@@ -265,7 +269,7 @@ int compute_dyn(const fcp_plan *p, const int32_t *offsets, const int32_t *shapes
   for (int k = 0; k < nc; ++k) {
     const HostColumn &hc = p->cols[k];
     const fcp_column_desc_t &c = hc.d;
-    FcpColDyn &d = dyn[k];
+    FcpColDyn &d = dyn[p->pos_of[k]];
     std::memset(&d, 0, sizeof(d));
     const int64_t rows = col_rows[k];
     d.rows = (int32_t)rows;
@@ -312,7 +316,7 @@ int compute_dyn(const fcp_plan *p, const int32_t *offsets, const int32_t *shapes
   m->csr_arena_off = cursor;
   int64_t csr_cursor = 0; // in int32 elements
   for (int k : p->seg_cols) {
-    dyn[k].csr_base = (int32_t)csr_cursor;
+    dyn[p->pos_of[k]].csr_base = (int32_t)csr_cursor;
     csr_cursor += (col_rows[k] + 1 + 31) / 32 * 32;
     if (csr_cursor > 0x7fffffff) return fail(FCP_ERR_UNSUPPORTED, "CSR scratch exceeds 2^31 entries");
   }
@@ -324,7 +328,9 @@ int compute_dyn(const fcp_plan *p, const int32_t *offsets, const int32_t *shapes
   for (int g = 0; g < ng; ++g) max_rows = std::max(max_rows, m->group_rows[g]);
   int rpw = 1;
   if (p->dense_only) {
-    while (rpw < 8 && max_rows >= 64 * rpw) rpw *= 2; // 512 rows -> 8, 128 -> 2, < 64 -> 1
+    // 4 rows per wave (16 per block) measured best on S2 at batch 512 and 2048:
+    // ~2 rounds of blocks de-phase the read and write bursts; 8 rows lose to the tail.
+    while (rpw < 4 && max_rows >= 32 * rpw) rpw *= 2; // >= 64 rows -> 4, 32..63 -> 2, < 32 -> 1
     static const int forced = [] { // tuning aid: FCP_ROWS_PER_WAVE=1|2|4|8
       const char *e = std::getenv("FCP_ROWS_PER_WAVE");
       const int v = e ? std::atoi(e) : 0;
@@ -372,17 +378,15 @@ int init_device(fcp_plan *p) {
   int rc = guard.enter(p->desc.device);
   if (rc) return rc;
   const int nc = (int)p->cols.size();
-  // slot map
+  // slot map: slot -> position in the concat-ordered column arrays
   std::vector<uint32_t> map;
   for (int g = 0; g < p->desc.n_groups; ++g) {
     p->group_map_off[g] = (int32_t)map.size();
-    std::vector<int> members;
-    for (int k = 0; k < nc; ++k)
-      if (p->cols[k].d.concat_group == g) members.push_back(k);
-    std::sort(members.begin(), members.end(),
-              [&](int a, int b) { return p->cols[a].out_off < p->cols[b].out_off; });
-    for (int k : members)
-      for (int s = 0; s < p->cols[k].d.dim / p->vec; ++s) map.push_back((uint32_t)k);
+    for (int pos = 0; pos < nc; ++pos) {
+      const HostColumn &hc = p->cols[p->order[pos]];
+      if (hc.d.concat_group != g) continue;
+      for (int s = 0; s < hc.d.dim / p->vec; ++s) map.push_back((uint32_t)pos);
+    }
   }
   HIP_TRY(hipMalloc(&p->d_slot_map, std::max<size_t>(map.size(), 1) * sizeof(uint32_t)));
   HIP_TRY(hipMemcpy(p->d_slot_map, map.data(), map.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -402,9 +406,9 @@ int init_device(fcp_plan *p) {
   }
   // static column records (tables are bound on the first request)
   p->h_cols.resize(nc);
-  for (int k = 0; k < nc; ++k) {
-    const HostColumn &hc = p->cols[k];
-    FcpColStatic &s = p->h_cols[k];
+  for (int pos = 0; pos < nc; ++pos) {
+    const HostColumn &hc = p->cols[p->order[pos]];
+    FcpColStatic &s = p->h_cols[pos];
     s.table = nullptr;
     s.boundaries = hc.const_off >= 0 ? reinterpret_cast<const float *>(p->d_const + hc.const_off) : nullptr;
     s.vocab = hc.d.vocab;
@@ -418,9 +422,10 @@ int init_device(fcp_plan *p) {
   HIP_TRY(hipMalloc(&p->d_cols, nc * sizeof(FcpColStatic)));
   HIP_TRY(hipMemcpy(p->d_cols, p->h_cols.data(), nc * sizeof(FcpColStatic), hipMemcpyHostToDevice));
   if (!p->seg_cols.empty()) {
-    HIP_TRY(hipMalloc(&p->d_seg_cols, p->seg_cols.size() * sizeof(int32_t)));
-    HIP_TRY(hipMemcpy(p->d_seg_cols, p->seg_cols.data(), p->seg_cols.size() * sizeof(int32_t),
-                      hipMemcpyHostToDevice));
+    std::vector<int32_t> seg_pos;
+    for (int k : p->seg_cols) seg_pos.push_back(p->pos_of[k]);
+    HIP_TRY(hipMalloc(&p->d_seg_cols, seg_pos.size() * sizeof(int32_t)));
+    HIP_TRY(hipMemcpy(p->d_seg_cols, seg_pos.data(), seg_pos.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   }
   if (p->desc.flags & FCP_FLAG_COUNT_BAD_IDS) {
     HIP_TRY(hipMalloc(&p->d_bad, sizeof(unsigned long long)));
@@ -449,7 +454,7 @@ int bind_tables(fcp_plan *p, const void *const *input_ptrs) {
                         p->cols[k].d.form == FCP_FORM_GATHER_SCATTER;
     if (lookup) {
       if (!input_ptrs[t]) return fail(FCP_ERR_INVALID_ARGUMENT, "null table pointer");
-      p->h_cols[k].table = static_cast<const float *>(input_ptrs[t]);
+      p->h_cols[p->pos_of[k]].table = static_cast<const float *>(input_ptrs[t]);
     }
   }
   HIP_TRY(hipMemcpy(p->d_cols, p->h_cols.data(), p->h_cols.size() * sizeof(FcpColStatic),
@@ -636,6 +641,8 @@ int fcp_plan_create(const fcp_plan_desc_t *desc, fcp_plan_t **out) {
     if (hc.d.dim % 4) gcd4 = (hc.d.dim % 2) ? 1 : std::min(gcd4, 2);
     const int f = hc.d.form;
     if (f != FCP_FORM_GATHER && f != FCP_FORM_PASSTHROUGH) p->dense_only = false;
+    // the dense kernel parks local row numbers in LDS as int32
+    if (f == FCP_FORM_GATHER && hc.d.vocab > 0x7fffffffLL) p->dense_only = false;
     if ((f == FCP_FORM_SEGMENT_REDUCE || f == FCP_FORM_GATHER_SCATTER) && hc.d.seg_kind != FCP_SEG_CSR_I32)
       p->seg_cols.push_back(k);
   }
@@ -663,7 +670,10 @@ int fcp_plan_create(const fcp_plan_desc_t *desc, fcp_plan_t **out) {
     }
     p->group_width[g] = off;
     p->group_nslots[g] = off / p->vec;
+    for (int k : members) p->order.push_back(k);
   }
+  p->pos_of.assign(desc->n_columns, 0);
+  for (int pos = 0; pos < desc->n_columns; ++pos) p->pos_of[p->order[pos]] = pos;
   if (!p->host_only) {
     rc = init_device(p);
     if (rc) {
@@ -797,12 +807,13 @@ int fcp_process_feature_columns(fcp_plan_t *p, const fcp_process_args_t *a, fcp_
   if (r) {
     const int nc = (int)p->cols.size();
     for (int k = 0; k < nc; ++k) {
-      if (r->output_ptrs) r->output_ptrs[k] = static_cast<char *>(arena) + slot->h_dyn[k].out_base;
+      const FcpColDyn &d = slot->h_dyn[p->pos_of[k]];
+      if (r->output_ptrs) r->output_ptrs[k] = static_cast<char *>(arena) + d.out_base;
       if (r->output_shapes) {
-        r->output_shapes[2 * k] = slot->h_dyn[k].rows;
+        r->output_shapes[2 * k] = d.rows;
         r->output_shapes[2 * k + 1] = p->cols[k].d.dim;
       }
-      if (r->output_row_strides) r->output_row_strides[k] = slot->h_dyn[k].out_stride;
+      if (r->output_row_strides) r->output_row_strides[k] = d.out_stride;
     }
     for (int g = 0; g < p->desc.n_groups; ++g) {
       if (r->group_ptrs)

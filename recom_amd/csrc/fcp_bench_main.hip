@@ -24,6 +24,8 @@ struct fcp_harness;
 extern "C" int fcp_harness_create(fcp_plan_t *, const fcp_process_args_t *, int, int, int, fcp_harness **);
 extern "C" int fcp_harness_run(fcp_harness *, int, double *, float *, float *);
 extern "C" int fcp_harness_destroy(fcp_harness *);
+extern "C" int fcp_harness_copy_probe(size_t, int, float *);
+extern "C" int fcp_harness_bw_probe(int, size_t, int, float *);
 
 #define CHECK_HIP(e)                                                                        \
   do {                                                                                      \
@@ -85,6 +87,7 @@ static void *plain_alloc(void *ctx, size_t bytes) {
 int main(int argc, char **argv) {
   int columns = 1000, batch = 512, steps = 300, warmup = 50, threads = 1, requests = 16, ring = 6, verify = 1;
   int bucketize_every = 10; // every N-th column is bucketize-f32 sourced (0 = none)
+  int slab = 0;             // 1: all tables carved from ONE hipMalloc (as under TF's BFC allocator)
   long vocab = 1000000;
   for (int i = 1; i + 1 < argc; i += 2) {
     std::string k = argv[i];
@@ -99,6 +102,23 @@ int main(int argc, char **argv) {
     else if (k == "--ring") ring = (int)v;
     else if (k == "--verify") verify = (int)v;
     else if (k == "--bucketize-every") bucketize_every = (int)v;
+    else if (k == "--slab") slab = (int)v;
+    else if (k == "--bw-probe") {
+      const char *names[4] = {"read", "write", "write-nt", "chunked-write-nt"};
+      for (int kind = 0; kind < 4; ++kind) {
+        float ms = 0;
+        const size_t bytes = (size_t)v << 20;
+        fcp_harness_bw_probe(kind, bytes, 20, &ms);
+        std::printf("%s probe %ld MiB: %.1f GB/s  (%.2f us)\n", names[kind], v, bytes / (ms * 1e-3) / 1e9, ms * 1e3);
+      }
+      return 0;
+    }
+    else if (k == "--copy-probe") {
+      float ms = 0;
+      fcp_harness_copy_probe((size_t)v << 20, 20, &ms);
+      std::printf("copy probe %ld MiB: %.1f GB/s (read+write)\n", v, 2.0 * ((size_t)v << 20) / (ms * 1e-3) / 1e9);
+      return 0;
+    }
     else { std::fprintf(stderr, "unknown flag %s\n", k.c_str()); return 2; }
   }
   const int dims[4] = {8, 16, 32, 64};
@@ -145,9 +165,21 @@ int main(int argc, char **argv) {
   // ---- tables -------------------------------------------------------------------
   std::vector<void *> tables(columns);
   double table_bytes = 0;
+  char *slab_base = nullptr;
+  size_t slab_off = 0;
+  if (slab) {
+    size_t total = 0;
+    for (int c = 0; c < columns; ++c) total += ((size_t)vocab * cols[c].dim * 4 + 255) / 256 * 256;
+    CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&slab_base), total));
+  }
   for (int c = 0; c < columns; ++c) {
     const size_t bytes = (size_t)vocab * cols[c].dim * 4;
-    CHECK_HIP(hipMalloc(&tables[c], bytes));
+    if (slab) {
+      tables[c] = slab_base + slab_off;
+      slab_off += (bytes + 255) / 256 * 256;
+    } else {
+      CHECK_HIP(hipMalloc(&tables[c], bytes));
+    }
     hipLaunchKernelGGL(fill_table, dim3(2048), dim3(256), 0, 0, (float *)tables[c], (uint32_t)(1000 + c),
                        (uint64_t)vocab, (uint32_t)cols[c].dim);
     table_bytes += bytes;

@@ -173,9 +173,23 @@ int fcp_harness_destroy(fcp_harness *h) {
 
 // Device-side copy bandwidth probe (float4 copy of `bytes` bytes, `iters`
 // times): the "measured copy peak" the roofline is also quoted against.
-__global__ void fcp_copy_probe_kernel(const float4 *__restrict__ src, float4 *__restrict__ dst, size_t n) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-    dst[i] = src[i];
+__global__ void __launch_bounds__(256) fcp_copy_probe_kernel(const float4 *__restrict__ src,
+                                                             float4 *__restrict__ dst, size_t n) {
+  // 4 independent 16-byte loads in flight per lane, non-temporal both ways
+  typedef float __attribute__((ext_vector_type(4))) f4;
+  const f4 *s = reinterpret_cast<const f4 *>(src);
+  f4 *d = reinterpret_cast<f4 *>(dst);
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + 3 * stride < n; i += 4 * stride) {
+    const f4 a = __builtin_nontemporal_load(s + i), b = __builtin_nontemporal_load(s + i + stride),
+             c = __builtin_nontemporal_load(s + i + 2 * stride), e = __builtin_nontemporal_load(s + i + 3 * stride);
+    __builtin_nontemporal_store(a, d + i);
+    __builtin_nontemporal_store(b, d + i + stride);
+    __builtin_nontemporal_store(c, d + i + 2 * stride);
+    __builtin_nontemporal_store(e, d + i + 3 * stride);
+  }
+  for (; i < n; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(s + i), d + i);
 }
 
 int fcp_harness_copy_probe(size_t bytes, int iters, float *ms_per_iter) {
@@ -199,6 +213,80 @@ int fcp_harness_copy_probe(size_t bytes, int iters, float *ms_per_iter) {
   if (ms_per_iter) *ms_per_iter = ms / iters;
   (void)hipFree(a);
   (void)hipFree(b);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return FCP_OK;
+}
+
+
+// ---- pure read / pure write / chunked-write probes ------------------------------
+typedef float __attribute__((ext_vector_type(4))) probe_f4;
+
+__global__ void __launch_bounds__(256) fcp_read_probe_kernel(const probe_f4 *__restrict__ src, float *sink, size_t n) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  probe_f4 acc = {0, 0, 0, 0};
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + 3 * stride < n; i += 4 * stride) {
+    const probe_f4 a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride),
+                   c = __builtin_nontemporal_load(src + i + 2 * stride), d = __builtin_nontemporal_load(src + i + 3 * stride);
+    acc += a + b + c + d;
+  }
+  if (acc.x + acc.y + acc.z + acc.w == 12345.678f) *sink = acc.x;
+}
+
+__global__ void __launch_bounds__(256) fcp_write_probe_kernel(probe_f4 *__restrict__ dst, size_t n, int nt) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const probe_f4 v = {1.f, 2.f, 3.f, (float)threadIdx.x};
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    if (nt) __builtin_nontemporal_store(v, dst + i); else dst[i] = v;
+  }
+}
+
+// our store shape: a wave writes `chunk` contiguous bytes of one row, a block 4*R rows
+// of a [rows, width_bytes] matrix; blocks cover (row tile, chunk index).
+__global__ void __launch_bounds__(256) fcp_chunk_write_probe_kernel(char *__restrict__ dst, int rows, int width_bytes,
+                                                                    int R, int nchunks) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int chunk = blockIdx.x % nchunks, tile = blockIdx.x / nchunks;
+  const probe_f4 v = {1.f, 2.f, 3.f, (float)lane};
+  const size_t col = (size_t)chunk * 1024 + lane * 16;
+  if (col + 16 > (size_t)width_bytes) return;
+  for (int r = 0; r < R; ++r) {
+    const int b = (tile * 4 + wave) * R + r;
+    if (b < rows) __builtin_nontemporal_store(v, reinterpret_cast<probe_f4 *>(dst + (size_t)b * width_bytes + col));
+  }
+}
+
+// kind: 0 read, 1 write (default policy), 2 write (nt), 3 chunked nt write [rows=512*mult, width=120000 B]
+int fcp_harness_bw_probe(int kind, size_t bytes, int iters, float *ms_per_iter) {
+  void *a = nullptr;
+  float *sink = nullptr;
+  H_TRY(hipMalloc(&a, bytes));
+  H_TRY(hipMalloc(&sink, 4));
+  H_TRY(hipMemset(a, 1, bytes));
+  hipEvent_t e0, e1;
+  H_TRY(hipEventCreate(&e0));
+  H_TRY(hipEventCreate(&e1));
+  const size_t n = bytes / 16;
+  const int width = 120000, rows = (int)(bytes / width), R = 4, nchunks = (width + 1023) / 1024;
+  auto launch = [&]() {
+    if (kind == 0) hipLaunchKernelGGL(fcp_read_probe_kernel, dim3(2048), dim3(256), 0, 0, (const probe_f4 *)a, sink, n);
+    else if (kind == 1) hipLaunchKernelGGL(fcp_write_probe_kernel, dim3(2048), dim3(256), 0, 0, (probe_f4 *)a, n, 0);
+    else if (kind == 2) hipLaunchKernelGGL(fcp_write_probe_kernel, dim3(2048), dim3(256), 0, 0, (probe_f4 *)a, n, 1);
+    else hipLaunchKernelGGL(fcp_chunk_write_probe_kernel, dim3(nchunks * ((rows + 4 * R - 1) / (4 * R))), dim3(256), 0, 0,
+                            (char *)a, rows, width, R, nchunks);
+  };
+  launch();
+  H_TRY(hipDeviceSynchronize());
+  H_TRY(hipEventRecord(e0, 0));
+  for (int i = 0; i < iters; ++i) launch();
+  H_TRY(hipEventRecord(e1, 0));
+  H_TRY(hipDeviceSynchronize());
+  float ms = 0;
+  H_TRY(hipEventElapsedTime(&ms, e0, e1));
+  if (ms_per_iter) *ms_per_iter = ms / iters;
+  (void)hipFree(a);
+  (void)hipFree(sink);
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   return FCP_OK;

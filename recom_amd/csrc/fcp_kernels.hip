@@ -157,17 +157,48 @@ __device__ __forceinline__ VF<V> ld_row(const float *__restrict__ table, int64_t
   return *reinterpret_cast<const VF<V> *>(table + id * (int64_t)dim + e);
 }
 
+template <int V> struct VecType;
+template <> struct VecType<4> { typedef float __attribute__((ext_vector_type(4))) T; };
+template <> struct VecType<2> { typedef float __attribute__((ext_vector_type(2))) T; };
+template <> struct VecType<1> { typedef float T; };
+
+// Output rows are written once and consumed by a later kernel; table rows are
+// read once per request: both use the non-temporal forms (measured on S2:
+// 34.3 -> 30.5 us per request; stores give most of it).  -DFCP_NO_NT restores
+// the default cache policy (tuning builds).
+#if !defined(FCP_NO_NT)
+#define FCP_NT_STORE 1
+#define FCP_NT_LOAD 1
+#endif
 template <int V> __device__ __forceinline__ void st_out(float *p, const VF<V> &v) {
+#if defined(FCP_NT_STORE)
+  typedef typename VecType<V>::T T;
+  T t;
+  __builtin_memcpy(&t, &v, sizeof(T));
+  __builtin_nontemporal_store(t, reinterpret_cast<T *>(p));
+#else
   *reinterpret_cast<VF<V> *>(p) = v;
+#endif
+}
+
+template <int V> __device__ __forceinline__ VF<V> ld_table(const float *p) {
+#if defined(FCP_NT_LOAD)
+  typedef typename VecType<V>::T T;
+  T t = __builtin_nontemporal_load(reinterpret_cast<const T *>(p));
+  VF<V> r;
+  __builtin_memcpy(&r, &t, sizeof(T));
+  return r;
+#else
+  return *reinterpret_cast<const VF<V> *>(p);
+#endif
 }
 
 // ---------------------------------------------------------------------------
-// The fused kernel.  DENSE = every column of the plan is GATHER or PASSTHROUGH
-// (exactly one source row per output row): R rows per wave, fully unrolled,
-// all id loads issued before all row loads before all stores.  Otherwise the
-// generic per-row path with the ragged segment loop.
+// The generic fused kernel: any mix of column forms, one output row per wave at
+// a time, with the ragged segment loop.  Plans whose columns all have exactly
+// one source row per output row use fcp_dense_kernel below instead.
 // ---------------------------------------------------------------------------
-template <int V, bool DENSE, int R>
+template <int V>
 __global__ void __launch_bounds__(FCP_BLOCK_THREADS) fcp_fused_kernel(const FcpLaunch L) {
   int bid = blockIdx.x;
   int g = 0;
@@ -186,7 +217,7 @@ __global__ void __launch_bounds__(FCP_BLOCK_THREADS) fcp_fused_kernel(const FcpL
   const int lane = threadIdx.x & (FCP_WAVE - 1);
   const int wave = threadIdx.x >> 6;
   const int q = span * FCP_WAVE + lane;
-  const int rpw = DENSE ? R : L.rows_per_wave;
+  const int rpw = L.rows_per_wave;
   const int row0 = (tile * FCP_WAVES_PER_BLOCK + wave) * rpw;
   if (q >= nslots || row0 >= rows) return;
 
@@ -200,68 +231,6 @@ __global__ void __launch_bounds__(FCP_BLOCK_THREADS) fcp_fused_kernel(const FcpL
   float *outp = reinterpret_cast<float *>(L.arena + cd.out_base) + e;
   const int64_t ostride = cd.out_stride;
   const int world = L.shard_world, rank = L.shard_rank;
-
-  if (DENSE) {
-    // Phase 1: fetch the raw ids of all R rows (branch-free, one wait).
-    const bool is64 = idsrc == FCP_IDS_I64;
-    const bool passthrough = form == FCP_FORM_PASSTHROUGH;
-    uint32_t lo[R], hi[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) ld_raw_id(ids, is64, min(row0 + r, rows - 1), lo[r], hi[r]);
-    // Phase 2: ids -> table rows.
-    int64_t id[R];
-    if (idsrc == FCP_IDS_F32_BUCKETIZE && !passthrough) {
-      bucketize_lockstep<R>(cs.boundaries, cs.n_boundaries, lo, id);
-    } else {
-#pragma unroll
-      for (int r = 0; r < R; ++r) id[r] = raw_to_id(is64, lo[r], hi[r]);
-    }
-    const float *src[R];
-    bool ok[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int b = row0 + r;
-      bool bad = false;
-      ok[r] = b < rows;
-      if (passthrough) {
-        // a tensor of the blob copied into its concat slot; table-free columns
-        // belong to shard rank 0
-        ok[r] = ok[r] && rank == 0;
-        src[r] = reinterpret_cast<const float *>(ids) + (int64_t)min(b, rows - 1) * cs.dim + e;
-      } else {
-        ok[r] = resolve_id(id[r], cs.vocab, rank, world, bad) && ok[r];
-        src[r] = cs.table + (ok[r] ? id[r] : 0) * (int64_t)cs.dim + e;
-        if (bad && b < rows && e == 0 && L.bad_ids) atomicAdd(L.bad_ids, 1ull);
-      }
-    }
-#if defined(FCP_ABLATE) && FCP_ABLATE == 3 // timing-only build: sequential instead of random rows
-#pragma unroll
-    for (int r = 0; r < R; ++r) src[r] = cs.table + (((int64_t)(row0 + r) * 131 + c * 977) % cs.vocab) * cs.dim + e;
-#endif
-    // Phase 3: all row reads in flight together.
-    VF<V> v[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      v[r] = vzero<V>();
-#if !(defined(FCP_ABLATE) && FCP_ABLATE == 1) // timing-only build 1: no table reads
-      if (ok[r]) v[r] = *reinterpret_cast<const VF<V> *>(src[r]);
-#else
-      v[r].v[0] = (float)id[r];
-#endif
-    }
-    // Phase 4: 1 KiB contiguous per wave store, directly in concat layout.
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int b = row0 + r;
-#if defined(FCP_ABLATE) && FCP_ABLATE == 2 // timing-only build 2: no output stores
-      asm volatile("" ::"v"(v[r].v[0]), "v"(v[r].v[V - 1]));
-      if (b < rows && v[r].v[0] == 1234.5f) st_out<V>(outp + (int64_t)b * ostride, v[r]);
-#else
-      if (b < rows) st_out<V>(outp + (int64_t)b * ostride, v[r]);
-#endif
-    }
-    return;
-  }
 
   // ---- generic path: one output row at a time, ragged segment loop ---------
   const unsigned segkind = FCP_F_SEGKIND(cs.flags);
@@ -360,6 +329,192 @@ __global__ void __launch_bounds__(FCP_BLOCK_THREADS) fcp_fused_kernel(const FcpL
       }
     }
     st_out<V>(outp + (int64_t)b * ostride, acc);
+  }
+}
+
+
+// ---------------------------------------------------------------------------
+// Dense kernel: every column of the plan is GATHER or PASSTHROUGH (exactly one
+// source row per output row) — BASELINE.json's S2 and DLRM shapes.
+//
+// A block owns one span (64 slots = 1 KiB of the output row) for RB = 4*R rows.
+//   phase 0  the span's column records (static + dynamic, contiguous because
+//            the device arrays are kept in concat order) are copied to LDS,
+//            one thread per column;
+//   phase 1  the block's (column, row) id pairs are fetched with one thread
+//            per pair — consecutive threads take consecutive rows of one
+//            column, so every id cache line is requested exactly once — turned
+//            into final local row numbers (Bucketize, range check, row shard)
+//            and parked in LDS;
+//   phase 2  every lane reads its column record and its R row numbers from
+//            LDS (broadcast reads), issues its R 16-byte table reads back to
+//            back, then its R stores: 1 KiB contiguous per wave instruction,
+//            straight into the concat layout.
+// Without the LDS staging every lane fetched its own copy of the id and of the
+// 96-byte column record: ~80 vector-memory instructions per wave and — measured
+// with rocprofv3 — about half of the kernel time in TCP_PENDING_STALL_CYCLES
+// (lanes and waves queueing on the same in-flight cache lines).
+// ---------------------------------------------------------------------------
+struct alignas(16) LdsCol {   // 64 bytes
+  const float *table;         // table base, or the passthrough payload
+  const char *ids;            // id / value stream of this request
+  const float *boundaries;
+  int64_t vocab;
+  int64_t out_base;           // byte offset in the arena of element (0,0)
+  int32_t dim;
+  int32_t out_off;
+  int32_t out_stride;
+  uint32_t flags;
+  int32_t n_boundaries;
+  int32_t pad_;
+};
+
+template <int V, int R>
+__global__ void __launch_bounds__(FCP_BLOCK_THREADS) fcp_dense_kernel(const FcpLaunch L) {
+  constexpr int RB = FCP_WAVES_PER_BLOCK * R; // rows per block
+  constexpr int IDS = RB + 1;                 // padded row of the id tile (LDS banks)
+  constexpr int BND = 1024;                   // floats of bucketize boundaries staged per block
+  __shared__ LdsCol s_col[FCP_WAVE];
+  __shared__ int32_t s_id[FCP_WAVE * IDS];    // local row numbers (< 2^31, checked at plan creation)
+  __shared__ float s_bnd[BND];
+
+  int bid = blockIdx.x;
+  int g = 0;
+  for (int k = 1; k < L.n_groups; ++k)
+    if (bid >= L.groups[k].block_begin) g = k;
+  const int rows = L.groups[g].rows;
+  const int nslots = L.groups[g].nslots;
+  const int nsp8 = L.groups[g].nsp8;
+  const uint32_t *__restrict__ map = L.slot_map + L.groups[g].slot_map_off;
+  bid -= L.groups[g].block_begin;
+  const int xcd = bid & 7, j8 = bid >> 3;
+  const int span = (j8 % nsp8) * 8 + xcd;
+  const int tile = j8 / nsp8;
+  const int q0 = span * FCP_WAVE;
+  const int row_blk = tile * RB;
+  if (q0 >= nslots || row_blk >= rows) return; // uniform: whole block leaves
+
+  const int tid = threadIdx.x;
+  const int lane = tid & (FCP_WAVE - 1);
+  const int wave = tid >> 6;
+  const int q = q0 + lane;
+  const int qc = min(q, nslots - 1);
+  const uint32_t my_col = map[qc];
+  const uint32_t first_col = map[q0];
+  const int ncols = (int)(map[min(q0 + FCP_WAVE - 1, nslots - 1)] - first_col) + 1;
+  const int world = L.shard_world, rank = L.shard_rank;
+
+  // ---- phase 0: column records -> LDS -------------------------------------------
+  if (tid < ncols) {
+    const FcpColStatic cs = L.cols[first_col + tid];
+    const FcpColDyn cd = L.dyn[first_col + tid];
+    LdsCol c;
+    c.ids = L.blob + cd.ids_off;
+    c.table = FCP_F_FORM(cs.flags) == FCP_FORM_PASSTHROUGH ? reinterpret_cast<const float *>(c.ids) : cs.table;
+    c.boundaries = cs.boundaries;
+    c.vocab = cs.vocab;
+    c.out_base = cd.out_base;
+    c.dim = cs.dim;
+    c.out_off = cs.out_off;
+    c.out_stride = cd.out_stride;
+    c.flags = cs.flags;
+    c.n_boundaries = cs.n_boundaries;
+    c.pad_ = -1; // offset of the boundaries in s_bnd, or -1: search in global memory
+    s_col[tid] = c;
+  }
+  __syncthreads();
+
+  // ---- phase 0b: bucketize boundaries -> LDS (cuda_emitter.cc:1818-1825 stages
+  // them per block too).  Wave 0 assigns LDS offsets with a shuffle prefix sum;
+  // then all threads copy.  Columns that do not fit keep searching in L2.
+  if (wave == 0) {
+    int nb = 0;
+    if (lane < ncols && FCP_F_IDSRC(s_col[lane].flags) == FCP_IDS_F32_BUCKETIZE &&
+        FCP_F_FORM(s_col[lane].flags) != FCP_FORM_PASSTHROUGH)
+      nb = s_col[lane].n_boundaries;
+    int incl = nb;
+#pragma unroll
+    for (int d = 1; d < FCP_WAVE; d <<= 1) {
+      const int up = __shfl_up(incl, d);
+      if (lane >= d) incl += up;
+    }
+    if (nb > 0 && incl <= BND) s_col[lane].pad_ = incl - nb;
+  }
+  __syncthreads();
+  for (int j = 0; j < ncols; ++j) {
+    const int off = s_col[j].pad_;
+    if (off < 0) continue;
+    const float *__restrict__ src = s_col[j].boundaries;
+    for (int i = tid; i < s_col[j].n_boundaries; i += FCP_BLOCK_THREADS) s_bnd[off + i] = src[i];
+  }
+  __syncthreads();
+
+  // ---- phase 1: (column, row) pairs -> final row numbers in LDS -------------------
+  for (int p = tid; p < ncols * RB; p += FCP_BLOCK_THREADS) {
+    const int j = p / RB, r = p % RB;
+    const int b = row_blk + r;
+    int64_t id = -1;
+    if (b < rows) {
+      const unsigned flags = s_col[j].flags;
+      if (FCP_F_FORM(flags) == FCP_FORM_PASSTHROUGH) {
+        id = rank == 0 ? b : -1; // table-free columns belong to shard rank 0
+      } else {
+        const unsigned idsrc = FCP_F_IDSRC(flags);
+        const bool is64 = idsrc == FCP_IDS_I64;
+        uint32_t lo[1], hi[1];
+        int64_t v[1];
+        ld_raw_id(s_col[j].ids, is64, b, lo[0], hi[0]);
+        if (idsrc == FCP_IDS_F32_BUCKETIZE) {
+          const int boff = s_col[j].pad_;
+          v[0] = boff >= 0 ? bucketize(s_bnd + boff, s_col[j].n_boundaries, __uint_as_float(lo[0]))
+                           : bucketize(s_col[j].boundaries, s_col[j].n_boundaries, __uint_as_float(lo[0]));
+        } else {
+          v[0] = raw_to_id(is64, lo[0], hi[0]);
+        }
+        bool bad;
+        id = resolve_id(v[0], s_col[j].vocab, rank, world, bad) ? v[0] : -1;
+        if (bad && L.bad_ids) atomicAdd(L.bad_ids, 1ull);
+      }
+    }
+    s_id[j * IDS + r] = (int32_t)id;
+  }
+  __syncthreads();
+  if (q >= nslots) return;
+
+  // ---- phase 2: R table reads in flight per lane, then R coalesced stores -----------
+  const int j = (int)(my_col - first_col);
+  const float *table = s_col[j].table;
+  const int dim = s_col[j].dim;
+  const int e = q * V - s_col[j].out_off;
+  const int64_t ostride = s_col[j].out_stride;
+  float *outp = reinterpret_cast<float *>(L.arena + s_col[j].out_base) + e;
+  const int r0 = wave * R;
+  int64_t id[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) id[r] = s_id[j * IDS + r0 + r];
+#if defined(FCP_ABLATE) && FCP_ABLATE == 3 // timing-only build: sequential instead of random rows
+#pragma unroll
+  for (int r = 0; r < R; ++r) id[r] = ((int64_t)(row_blk + r0 + r) * 131 + my_col * 977) % s_col[j].vocab;
+#endif
+  VF<V> v[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    v[r] = vzero<V>();
+#if !(defined(FCP_ABLATE) && FCP_ABLATE == 1) // timing-only build 1: no table reads
+    if (id[r] >= 0) v[r] = ld_table<V>(table + id[r] * (int64_t)dim + e);
+#else
+    v[r].v[0] = (float)id[r];
+#endif
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int b = row_blk + r0 + r;
+#if defined(FCP_ABLATE) && FCP_ABLATE == 2 // timing-only build 2: no output stores
+    asm volatile("" ::"v"(v[r].v[0]), "v"(v[r].v[V - 1]));
+    if (b < rows && v[r].v[0] == 1234.5f) st_out<V>(outp + (int64_t)b * ostride, v[r]);
+#else
+    if (b < rows) st_out<V>(outp + (int64_t)b * ostride, v[r]);
+#endif
   }
 }
 
@@ -485,20 +640,21 @@ __global__ void __launch_bounds__(FCP_BLOCK_THREADS)
 
 // ------------------------------- launchers ---------------------------------
 
-#define FCP_LAUNCH_CASE(VV, DD, RR)                                                             \
-  hipLaunchKernelGGL((fcp_fused_kernel<VV, DD, RR>), dim3(grid_blocks), dim3(FCP_BLOCK_THREADS), \
-                     0, s, L)
+#define FCP_LAUNCH_DENSE(VV, RR) \
+  hipLaunchKernelGGL((fcp_dense_kernel<VV, RR>), dim3(grid_blocks), dim3(FCP_BLOCK_THREADS), 0, s, L)
+#define FCP_LAUNCH_GENERIC(VV) \
+  hipLaunchKernelGGL((fcp_fused_kernel<VV>), dim3(grid_blocks), dim3(FCP_BLOCK_THREADS), 0, s, L)
 
 int fcp_launch_fused(const FcpLaunch &L, int vec, bool dense_only, int grid_blocks, ihipStream_t *s) {
   if (grid_blocks <= 0) return 0;
   if (dense_only) {
     const int R = L.rows_per_wave;
-#define FCP_DENSE_R(VV)                                  \
-  switch (R) {                                           \
-  case 8: FCP_LAUNCH_CASE(VV, true, 8); break;           \
-  case 4: FCP_LAUNCH_CASE(VV, true, 4); break;           \
-  case 2: FCP_LAUNCH_CASE(VV, true, 2); break;           \
-  default: FCP_LAUNCH_CASE(VV, true, 1); break;          \
+#define FCP_DENSE_R(VV)                         \
+  switch (R) {                                  \
+  case 8: FCP_LAUNCH_DENSE(VV, 8); break;       \
+  case 4: FCP_LAUNCH_DENSE(VV, 4); break;       \
+  case 2: FCP_LAUNCH_DENSE(VV, 2); break;       \
+  default: FCP_LAUNCH_DENSE(VV, 1); break;      \
   }
     if (vec == 4) {
       FCP_DENSE_R(4)
@@ -510,11 +666,11 @@ int fcp_launch_fused(const FcpLaunch &L, int vec, bool dense_only, int grid_bloc
 #undef FCP_DENSE_R
   } else {
     if (vec == 4) {
-      FCP_LAUNCH_CASE(4, false, 1);
+      FCP_LAUNCH_GENERIC(4);
     } else if (vec == 2) {
-      FCP_LAUNCH_CASE(2, false, 1);
+      FCP_LAUNCH_GENERIC(2);
     } else {
-      FCP_LAUNCH_CASE(1, false, 1);
+      FCP_LAUNCH_GENERIC(1);
     }
   }
   return (int)hipGetLastError();
