@@ -115,6 +115,7 @@ def main():
     ap.add_argument("--threads", type=int, default=1, help="serve_workers per GPU (reference harness flag)")
     ap.add_argument("--columns", type=int, default=0, help="override the column count (debug only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--requests", type=int, default=16, help="distinct resident requests cycled through")
     args = ap.parse_args()
 
     import torch
@@ -151,7 +152,7 @@ def main():
     else:
         model = synth.model_ragged(columns=args.columns or 512)
 
-    h = ServingHarness(model, device=local_rank, n_requests=16, arena_ring=6, n_threads=args.threads,
+    h = ServingHarness(model, device=local_rank, n_requests=args.requests, arena_ring=6, n_threads=args.threads,
                        seed0=1000 * rank)
     bytes_alg = h.algorithmic_bytes()
 
@@ -176,7 +177,7 @@ def main():
     # 3 streams hide each launch's ramp / tail behind its neighbours.  Extra field only.
     overlap = None
     if args.threads == 1 and not dist:
-        h3 = ServingHarness(model, device=local_rank, n_requests=16, arena_ring=6, n_threads=3,
+        h3 = ServingHarness(model, device=local_rank, n_requests=args.requests, arena_ring=6, n_threads=3,
                             tables=h.tables, seed0=1000 * rank)
         h3.run(max(args.warmup // 3, 1))
         w3, _, _ = h3.run(max(args.steps // 3, 1))

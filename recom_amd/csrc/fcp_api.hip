@@ -76,7 +76,8 @@ struct DynMeta {
 struct DynSlot {
   bool valid = false;
   std::vector<int32_t> key;
-  FcpColDyn *h_dyn = nullptr; // pinned
+  FcpColDyn *h_dyn = nullptr; // pinned, mapped
+  void *h_dyn_dev = nullptr;  // device-side address of h_dyn
   FcpColDyn *d_dyn = nullptr;
   hipEvent_t uploaded = nullptr;
   void *stream = nullptr; // the only stream that has used this slot, unless multi
@@ -337,6 +338,14 @@ int compute_dyn(const fcp_plan *p, const int32_t *offsets, const int32_t *shapes
       return (v == 1 || v == 2 || v == 4 || v == 8) ? v : 0;
     }();
     if (forced) rpw = forced;
+  } else {
+    rpw = 1; // ragged kernel: 1 row per wave measured best on RAGGED (34.2 vs 36.0 us at 2)
+    static const int forced = [] {
+      const char *e = std::getenv("FCP_RAGGED_ROWS_PER_WAVE");
+      const int v = e ? std::atoi(e) : 0;
+      return (v == 1 || v == 2) ? v : 0;
+    }();
+    if (forced) rpw = forced;
   }
   m->rows_per_wave = rpw;
   int32_t blocks = 0;
@@ -432,8 +441,11 @@ int init_device(fcp_plan *p) {
     HIP_TRY(hipMemset(p->d_bad, 0, sizeof(unsigned long long)));
   }
   for (auto &s : p->slots) {
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&s.h_dyn), nc * sizeof(FcpColDyn), hipHostMallocDefault));
-    HIP_TRY(hipMalloc(&s.d_dyn, nc * sizeof(FcpColDyn)));
+    // rounded up to 16 bytes: the upload kernel moves uint4s
+    const size_t dyn_bytes = (nc * sizeof(FcpColDyn) + 15) / 16 * 16;
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&s.h_dyn), dyn_bytes, hipHostMallocMapped));
+    HIP_TRY(hipHostGetDevicePointer(&s.h_dyn_dev, s.h_dyn, 0));
+    HIP_TRY(hipMalloc(&s.d_dyn, dyn_bytes));
     HIP_TRY(hipEventCreateWithFlags(&s.uploaded, hipEventDisableTiming));
   }
   p->bound_tables.assign(p->desc.n_device_inputs, nullptr);
@@ -504,8 +516,11 @@ int acquire_slot(fcp_plan *p, const fcp_process_args_t *a, DynSlot **out) {
   int rc = compute_dyn(p, a->concated_offsets, a->concated_shapes, a->symbols, a->concated_bytes, s.h_dyn,
                        &s.meta);
   if (rc) return rc;
-  HIP_TRY(hipMemcpyAsync(s.d_dyn, s.h_dyn, p->cols.size() * sizeof(FcpColDyn), hipMemcpyHostToDevice,
-                         static_cast<hipStream_t>(a->stream)));
+  {
+    const int e = fcp_launch_upload(s.h_dyn_dev, s.d_dyn, p->cols.size() * sizeof(FcpColDyn),
+                                    static_cast<hipStream_t>(a->stream));
+    if (e) return hip_fail("descriptor upload launch", (hipError_t)e);
+  }
   HIP_TRY(hipEventRecord(s.uploaded, static_cast<hipStream_t>(a->stream)));
   s.key = key;
   s.stream = a->stream;

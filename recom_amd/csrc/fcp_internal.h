@@ -10,6 +10,7 @@
 // Only FcpColDyn is re-uploaded, and only when the request's shapes differ from
 // the previous request's (steady-state serving uploads nothing).
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
 
 #define FCP_MAX_GROUPS 16
@@ -85,6 +86,7 @@ struct FcpSegLaunch {
 // ---- launchers implemented in fcp_kernels.hip --------------------------------
 struct ihipStream_t;
 int fcp_launch_fused(const FcpLaunch &L, int vec, bool dense_only, int grid_blocks, ihipStream_t *s);
+int fcp_launch_upload(const void *host_mapped_src, void *dst, size_t bytes, ihipStream_t *s);
 int fcp_launch_segment_offsets(const FcpSegLaunch &L, int n_seg_cols, int max_nnz, ihipStream_t *s);
 int fcp_launch_concat_outputs(const void *const *inputs, const int32_t *dims, int32_t n,
                               int64_t prefix, int32_t width, int32_t first_off, void *out,

@@ -94,44 +94,6 @@ __device__ __forceinline__ int64_t raw_to_id(bool is64, uint32_t lo, uint32_t hi
   return is64 ? (int64_t)(((uint64_t)hi << 32) | lo) : (int64_t)(int32_t)lo;
 }
 
-// N binary searches (cuda_emitter.cc:233-247) advanced in lockstep: every step
-// issues N independent boundary loads, so a wave pays ~log2(n) dependent round
-// trips for all its rows together instead of N x log2(n).
-template <int N>
-__device__ __forceinline__ void bucketize_lockstep(const float *__restrict__ bnd, int nb, const uint32_t (&raw)[N],
-                                                   int64_t (&id)[N]) {
-  int l[N], h[N];
-#pragma unroll
-  for (int k = 0; k < N; ++k) {
-    l[k] = 0;
-    h[k] = nb - 1;
-  }
-  for (int it = 0; it < 32; ++it) {
-    bool any = false;
-    float bv[N];
-    int mid[N];
-#pragma unroll
-    for (int k = 0; k < N; ++k) {
-      mid[k] = max((l[k] + h[k]) >> 1, 0);
-      bv[k] = bnd[mid[k]];
-    }
-#pragma unroll
-    for (int k = 0; k < N; ++k) {
-      if (l[k] <= h[k]) {
-        if (__uint_as_float(raw[k]) < bv[k]) {
-          h[k] = mid[k] - 1;
-        } else {
-          l[k] = mid[k] + 1;
-        }
-      }
-      any |= l[k] <= h[k];
-    }
-    if (!any) break;
-  }
-#pragma unroll
-  for (int k = 0; k < N; ++k) id[k] = h[k] + 1;
-}
-
 // Validity + row sharding.  Returns true when this GPU must read a row; `id`
 // becomes the local row.  Ids outside [0, vocab) read as zeros (the reference
 // reads out of bounds, TF-GPU GatherV2 returns zeros).
@@ -194,146 +156,6 @@ template <int V> __device__ __forceinline__ VF<V> ld_table(const float *p) {
 }
 
 // ---------------------------------------------------------------------------
-// The generic fused kernel: any mix of column forms, one output row per wave at
-// a time, with the ragged segment loop.  Plans whose columns all have exactly
-// one source row per output row use fcp_dense_kernel below instead.
-// ---------------------------------------------------------------------------
-template <int V>
-__global__ void __launch_bounds__(FCP_BLOCK_THREADS) fcp_fused_kernel(const FcpLaunch L) {
-  int bid = blockIdx.x;
-  int g = 0;
-  for (int k = 1; k < L.n_groups; ++k)
-    if (bid >= L.groups[k].block_begin) g = k;
-  const int rows = L.groups[g].rows;
-  const int nslots = L.groups[g].nslots;
-  const int nsp8 = L.groups[g].nsp8;
-  bid -= L.groups[g].block_begin;
-
-  // XCD-aware mapping: blocks with equal (bid & 7) share an XCD under the
-  // round-robin dispatch; give them the same spans (same columns / tables).
-  const int xcd = bid & 7, j = bid >> 3;
-  const int span = (j % nsp8) * 8 + xcd;
-  const int tile = j / nsp8;
-  const int lane = threadIdx.x & (FCP_WAVE - 1);
-  const int wave = threadIdx.x >> 6;
-  const int q = span * FCP_WAVE + lane;
-  const int rpw = L.rows_per_wave;
-  const int row0 = (tile * FCP_WAVES_PER_BLOCK + wave) * rpw;
-  if (q >= nslots || row0 >= rows) return;
-
-  const uint32_t c = L.slot_map[L.groups[g].slot_map_off + q];
-  const FcpColStatic cs = L.cols[c];
-  const FcpColDyn cd = L.dyn[c];
-  const int e = q * V - cs.out_off;
-  const unsigned form = FCP_F_FORM(cs.flags);
-  const unsigned idsrc = FCP_F_IDSRC(cs.flags);
-  const char *ids = L.blob + cd.ids_off;
-  float *outp = reinterpret_cast<float *>(L.arena + cd.out_base) + e;
-  const int64_t ostride = cd.out_stride;
-  const int world = L.shard_world, rank = L.shard_rank;
-
-  // ---- generic path: one output row at a time, ragged segment loop ---------
-  const unsigned segkind = FCP_F_SEGKIND(cs.flags);
-  const bool mean = FCP_F_COMBINER(cs.flags) == FCP_COMBINER_MEAN && world == 1;
-  const bool is64 = idsrc == FCP_IDS_I64;
-  const int32_t *csr = nullptr;
-  if (segkind == FCP_SEG_CSR_I32) {
-    csr = reinterpret_cast<const int32_t *>(L.blob + cd.seg_off);
-  } else if (segkind != FCP_SEG_NONE) {
-    csr = reinterpret_cast<const int32_t *>(L.arena + L.csr_arena_off) + cd.csr_base;
-  }
-  const int nnz = cd.nnz;
-
-  for (int r = 0; r < rpw; ++r) {
-    const int b = row0 + r;
-    if (b >= rows) break;
-    VF<V> acc = vzero<V>();
-    if (form == FCP_FORM_PASSTHROUGH) {
-      if (rank == 0) acc = ld_blob_f32<V>(ids + 4 * ((int64_t)b * cs.dim + e));
-    } else if (form == FCP_FORM_BATCH_COL_REDUCTION) {
-      // cuda_emitter.cc:1231-1236: r ascending, sequential fp32 adds
-      const int inner = rank == 0 ? cd.inner : 0; // table-free columns belong to shard rank 0
-      for (int rr = 0; rr < inner; ++rr) {
-        const VF<V> x = ld_blob_f32<V>(ids + 4 * (((int64_t)b * inner + rr) * cs.dim + e));
-#pragma unroll
-        for (int i = 0; i < V; ++i) acc.v[i] = acc.v[i] + x.v[i];
-      }
-    } else {
-      int lo, hi;
-      if (form == FCP_FORM_GATHER) {
-        lo = b;
-        hi = b + 1;
-      } else {
-        lo = csr[b];
-        hi = csr[b + 1];
-        lo = min(max(lo, 0), nnz);
-        hi = min(max(hi, lo), nnz);
-      }
-      const int cnt = hi - lo;
-      if (form != FCP_FORM_SEGMENT_REDUCE) {
-        // GATHER: the row; GATHER_SCATTER: the last id of the row wins, a row
-        // without ids stays zero (pre-zeroed arena, cuda_emitter.cc:1351-1359).
-        if (cnt > 0) {
-          uint32_t rlo[1], rhi[1];
-          int64_t id[1];
-          ld_raw_id(ids, is64, hi - 1, rlo[0], rhi[0]);
-          if (idsrc == FCP_IDS_F32_BUCKETIZE) {
-            bucketize_lockstep<1>(cs.boundaries, cs.n_boundaries, rlo, id);
-          } else {
-            id[0] = raw_to_id(is64, rlo[0], rhi[0]);
-          }
-          bool bad;
-          if (resolve_id(id[0], cs.vocab, rank, world, bad)) acc = ld_row<V>(cs.table, id[0], cs.dim, e);
-          if (bad && e == 0 && L.bad_ids) atomicAdd(L.bad_ids, 1ull);
-        }
-      } else {
-        // Sequential accumulation in id order (deterministic; the order of
-        // TF-CPU and of the oracle).  Four ids and four rows are in flight per
-        // lane before the dependent adds.
-        for (int i = lo; i < hi; i += 4) {
-          int64_t id[4];
-          bool ok[4];
-          uint32_t rlo[4], rhi[4];
-#pragma unroll
-          for (int k = 0; k < 4; ++k) ld_raw_id(ids, is64, min(i + k, hi - 1), rlo[k], rhi[k]);
-          if (idsrc == FCP_IDS_F32_BUCKETIZE) {
-            bucketize_lockstep<4>(cs.boundaries, cs.n_boundaries, rlo, id);
-          } else {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) id[k] = raw_to_id(is64, rlo[k], rhi[k]);
-          }
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            bool bad;
-            ok[k] = resolve_id(id[k], cs.vocab, rank, world, bad) && (i + k < hi);
-            if (bad && (i + k < hi) && e == 0 && L.bad_ids) atomicAdd(L.bad_ids, 1ull);
-          }
-          VF<V> w[4];
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            w[k] = vzero<V>();
-            if (ok[k]) w[k] = ld_row<V>(cs.table, id[k], cs.dim, e);
-          }
-#pragma unroll
-          for (int k = 0; k < 4; ++k)
-            if (ok[k]) {
-#pragma unroll
-              for (int t = 0; t < V; ++t) acc.v[t] = acc.v[t] + w[k].v[t];
-            }
-        }
-        if (mean && cnt > 0) {
-          const float fc = (float)cnt; // sum / count, cuda_emitter.cc:625, :903
-#pragma unroll
-          for (int t = 0; t < V; ++t) acc.v[t] = acc.v[t] / fc;
-        }
-      }
-    }
-    st_out<V>(outp + (int64_t)b * ostride, acc);
-  }
-}
-
-
-// ---------------------------------------------------------------------------
 // Dense kernel: every column of the plan is GATHER or PASSTHROUGH (exactly one
 // source row per output row) — BASELINE.json's S2 and DLRM shapes.
 //
@@ -355,10 +177,11 @@ __global__ void __launch_bounds__(FCP_BLOCK_THREADS) fcp_fused_kernel(const FcpL
 // with rocprofv3 — about half of the kernel time in TCP_PENDING_STALL_CYCLES
 // (lanes and waves queueing on the same in-flight cache lines).
 // ---------------------------------------------------------------------------
-struct alignas(16) LdsCol {   // 64 bytes
+struct alignas(16) LdsCol {   // 80 bytes
   const float *table;         // table base, or the passthrough payload
   const char *ids;            // id / value stream of this request
   const float *boundaries;
+  const int32_t *csr;         // CSR offsets of this request (blob or arena scratch), ragged kernel only
   int64_t vocab;
   int64_t out_base;           // byte offset in the arena of element (0,0)
   int32_t dim;
@@ -366,8 +189,49 @@ struct alignas(16) LdsCol {   // 64 bytes
   int32_t out_stride;
   uint32_t flags;
   int32_t n_boundaries;
-  int32_t pad_;
+  int32_t bnd_off;            // offset of the staged boundaries in LDS, or -1
+  int32_t nnz;
+  int32_t inner;
 };
+
+__device__ __forceinline__ LdsCol make_lds_col(const FcpLaunch &L, const FcpColStatic &cs, const FcpColDyn &cd) {
+  LdsCol c;
+  c.ids = L.blob + cd.ids_off;
+  c.table = FCP_F_FORM(cs.flags) == FCP_FORM_PASSTHROUGH ? reinterpret_cast<const float *>(c.ids) : cs.table;
+  c.boundaries = cs.boundaries;
+  const unsigned segkind = FCP_F_SEGKIND(cs.flags);
+  c.csr = segkind == FCP_SEG_CSR_I32   ? reinterpret_cast<const int32_t *>(L.blob + cd.seg_off)
+          : segkind != FCP_SEG_NONE    ? reinterpret_cast<const int32_t *>(L.arena + L.csr_arena_off) + cd.csr_base
+                                       : nullptr;
+  c.vocab = cs.vocab;
+  c.out_base = cd.out_base;
+  c.dim = cs.dim;
+  c.out_off = cs.out_off;
+  c.out_stride = cd.out_stride;
+  c.flags = cs.flags;
+  c.n_boundaries = cs.n_boundaries;
+  c.bnd_off = -1;
+  c.nnz = cd.nnz;
+  c.inner = cd.inner;
+  return c;
+}
+
+// One id of a column -> final local row number, or -1 (out of range / owned by
+// another shard).  `bnd` = boundaries in LDS when staged, else nullptr.
+__device__ __forceinline__ int64_t fetch_row_number(const LdsCol &c, int64_t pos, const float *bnd, int rank,
+                                                    int world, bool &bad) {
+  const unsigned idsrc = FCP_F_IDSRC(c.flags);
+  const bool is64 = idsrc == FCP_IDS_I64;
+  uint32_t lo, hi;
+  ld_raw_id(c.ids, is64, pos, lo, hi);
+  int64_t v;
+  if (idsrc == FCP_IDS_F32_BUCKETIZE) {
+    v = bucketize(bnd ? bnd : c.boundaries, c.n_boundaries, __uint_as_float(lo));
+  } else {
+    v = raw_to_id(is64, lo, hi);
+  }
+  return resolve_id(v, c.vocab, rank, world, bad) ? v : -1;
+}
 
 template <int V, int R>
 __global__ void __launch_bounds__(FCP_BLOCK_THREADS) fcp_dense_kernel(const FcpLaunch L) {
@@ -405,23 +269,7 @@ __global__ void __launch_bounds__(FCP_BLOCK_THREADS) fcp_dense_kernel(const FcpL
   const int world = L.shard_world, rank = L.shard_rank;
 
   // ---- phase 0: column records -> LDS -------------------------------------------
-  if (tid < ncols) {
-    const FcpColStatic cs = L.cols[first_col + tid];
-    const FcpColDyn cd = L.dyn[first_col + tid];
-    LdsCol c;
-    c.ids = L.blob + cd.ids_off;
-    c.table = FCP_F_FORM(cs.flags) == FCP_FORM_PASSTHROUGH ? reinterpret_cast<const float *>(c.ids) : cs.table;
-    c.boundaries = cs.boundaries;
-    c.vocab = cs.vocab;
-    c.out_base = cd.out_base;
-    c.dim = cs.dim;
-    c.out_off = cs.out_off;
-    c.out_stride = cd.out_stride;
-    c.flags = cs.flags;
-    c.n_boundaries = cs.n_boundaries;
-    c.pad_ = -1; // offset of the boundaries in s_bnd, or -1: search in global memory
-    s_col[tid] = c;
-  }
+  if (tid < ncols) s_col[tid] = make_lds_col(L, L.cols[first_col + tid], L.dyn[first_col + tid]);
   __syncthreads();
 
   // ---- phase 0b: bucketize boundaries -> LDS (cuda_emitter.cc:1818-1825 stages
@@ -438,11 +286,11 @@ __global__ void __launch_bounds__(FCP_BLOCK_THREADS) fcp_dense_kernel(const FcpL
       const int up = __shfl_up(incl, d);
       if (lane >= d) incl += up;
     }
-    if (nb > 0 && incl <= BND) s_col[lane].pad_ = incl - nb;
+    if (nb > 0 && incl <= BND) s_col[lane].bnd_off = incl - nb;
   }
   __syncthreads();
   for (int j = 0; j < ncols; ++j) {
-    const int off = s_col[j].pad_;
+    const int off = s_col[j].bnd_off;
     if (off < 0) continue;
     const float *__restrict__ src = s_col[j].boundaries;
     for (int i = tid; i < s_col[j].n_boundaries; i += FCP_BLOCK_THREADS) s_bnd[off + i] = src[i];
@@ -459,20 +307,9 @@ __global__ void __launch_bounds__(FCP_BLOCK_THREADS) fcp_dense_kernel(const FcpL
       if (FCP_F_FORM(flags) == FCP_FORM_PASSTHROUGH) {
         id = rank == 0 ? b : -1; // table-free columns belong to shard rank 0
       } else {
-        const unsigned idsrc = FCP_F_IDSRC(flags);
-        const bool is64 = idsrc == FCP_IDS_I64;
-        uint32_t lo[1], hi[1];
-        int64_t v[1];
-        ld_raw_id(s_col[j].ids, is64, b, lo[0], hi[0]);
-        if (idsrc == FCP_IDS_F32_BUCKETIZE) {
-          const int boff = s_col[j].pad_;
-          v[0] = boff >= 0 ? bucketize(s_bnd + boff, s_col[j].n_boundaries, __uint_as_float(lo[0]))
-                           : bucketize(s_col[j].boundaries, s_col[j].n_boundaries, __uint_as_float(lo[0]));
-        } else {
-          v[0] = raw_to_id(is64, lo[0], hi[0]);
-        }
         bool bad;
-        id = resolve_id(v[0], s_col[j].vocab, rank, world, bad) ? v[0] : -1;
+        const int boff = s_col[j].bnd_off;
+        id = fetch_row_number(s_col[j], b, boff >= 0 ? s_bnd + boff : nullptr, rank, world, bad);
         if (bad && L.bad_ids) atomicAdd(L.bad_ids, 1ull);
       }
     }
@@ -515,6 +352,226 @@ __global__ void __launch_bounds__(FCP_BLOCK_THREADS) fcp_dense_kernel(const FcpL
 #else
     if (b < rows) st_out<V>(outp + (int64_t)b * ostride, v[r]);
 #endif
+  }
+}
+
+
+// ---------------------------------------------------------------------------
+// Ragged kernel: any mix of column forms (dynamic shapes: multi-hot bags of
+// variable length, scatter columns, passthrough, Sum(axis=1)).
+//
+// Same block shape as the dense kernel with R = 1 or 2 output rows per wave.
+//   phase 0  column records -> LDS;
+//   phase 1  one thread per (column, row) pair reads the pair's CSR range
+//            [lo, lo+cnt) — the LDS-staged row-offset buffer — and a block-wide
+//            scan of the counts (wave shuffle scan + per-wave totals) assigns
+//            every bag a slice of the LDS id tile; then one thread per *id*
+//            (its bag found by binary search over the scanned offsets) fetches
+//            it and stores the final local row number (Bucketize, range check,
+//            row shard: once per id instead of once per lane, all ids of the
+//            block in one memory round trip);
+//   phase 2  every lane walks its bag in LDS: 8 row numbers -> 8 independent
+//            16-byte table reads in flight -> 8 adds in id order (sequential
+//            fp32 order: deterministic, equal to TF-CPU's and the oracle's),
+//            divides for mean (sum / count, cuda_emitter.cc:625, :903), and the
+//            wave stores 1 KiB contiguous of the concat row.
+// Bags longer than 64 ids, or bags that do not fit the 1536-entry tile, are
+// walked from global memory by the lanes themselves (same arithmetic order).
+// ---------------------------------------------------------------------------
+template <int V, int R>
+__global__ void __launch_bounds__(FCP_BLOCK_THREADS) fcp_ragged_kernel(const FcpLaunch L) {
+  constexpr int RB = FCP_WAVES_PER_BLOCK * R; // rows per block, R per wave
+  constexpr int NP = FCP_WAVE * RB;           // (column, row) pairs per block, at most
+  constexpr int PT = NP / FCP_BLOCK_THREADS;  // pairs per thread (= R)
+  constexpr int CAP = 1536;                   // staged row numbers per block
+  constexpr int LONG_BAG = 64;
+  __shared__ LdsCol s_col[FCP_WAVE];
+  __shared__ int32_t s_lo[NP], s_cnt[NP];
+  __shared__ int32_t s_offx[NP + 1];          // exclusive scan of the staged counts
+  __shared__ int32_t s_ids[CAP];
+  __shared__ int32_t s_wsum[PT * FCP_WAVES_PER_BLOCK];
+
+  int bid = blockIdx.x;
+  int g = 0;
+  for (int k = 1; k < L.n_groups; ++k)
+    if (bid >= L.groups[k].block_begin) g = k;
+  const int rows = L.groups[g].rows;
+  const int nslots = L.groups[g].nslots;
+  const int nsp8 = L.groups[g].nsp8;
+  const uint32_t *__restrict__ map = L.slot_map + L.groups[g].slot_map_off;
+  bid -= L.groups[g].block_begin;
+  const int xcd = bid & 7, j8 = bid >> 3;
+  const int span = (j8 % nsp8) * 8 + xcd;
+  const int tile = j8 / nsp8;
+  const int q0 = span * FCP_WAVE;
+  const int row_blk = tile * RB;
+  if (q0 >= nslots || row_blk >= rows) return;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & (FCP_WAVE - 1);
+  const int wave = tid >> 6;
+  const int q = q0 + lane;
+  const uint32_t my_col = map[min(q, nslots - 1)];
+  const uint32_t first_col = map[q0];
+  const int ncols = (int)(map[min(q0 + FCP_WAVE - 1, nslots - 1)] - first_col) + 1;
+  const int npairs = ncols * RB;
+  const int world = L.shard_world, rank = L.shard_rank;
+
+  // ---- phase 0: column records -> LDS --------------------------------------------
+  if (tid < ncols) s_col[tid] = make_lds_col(L, L.cols[first_col + tid], L.dyn[first_col + tid]);
+  __syncthreads();
+
+  // ---- phase 1a: row ranges of the block's (column, row) pairs + scan -------------
+  int want[PT];
+#pragma unroll
+  for (int h = 0; h < PT; ++h) {
+    const int p = h * FCP_BLOCK_THREADS + tid;
+    int lo = 0, cnt = 0;
+    if (p < npairs) {
+      const int pj = p / RB, pr = p % RB;
+      const int b = row_blk + pr;
+      if (b < rows) {
+        const unsigned form = FCP_F_FORM(s_col[pj].flags);
+        if (form == FCP_FORM_GATHER) {
+          lo = b;
+          cnt = 1;
+        } else if (form == FCP_FORM_SEGMENT_REDUCE || form == FCP_FORM_GATHER_SCATTER) {
+          const int nnz = s_col[pj].nnz;
+          const int32_t *__restrict__ csr = s_col[pj].csr;
+          lo = min(max(csr[b], 0), nnz);
+          const int hi = min(max(csr[b + 1], lo), nnz);
+          cnt = hi - lo;
+          if (form == FCP_FORM_GATHER_SCATTER && cnt > 0) { // the last id of the row wins
+            lo = hi - 1;
+            cnt = 1;
+          }
+        }
+      }
+      s_lo[p] = lo;
+      s_cnt[p] = cnt;
+    }
+    want[h] = cnt <= LONG_BAG ? cnt : 0;
+  }
+  int incl[PT];
+#pragma unroll
+  for (int h = 0; h < PT; ++h) {
+    incl[h] = want[h];
+#pragma unroll
+    for (int d = 1; d < FCP_WAVE; d <<= 1) {
+      const int up = __shfl_up(incl[h], d);
+      if (lane >= d) incl[h] += up;
+    }
+    if (lane == FCP_WAVE - 1) s_wsum[h * FCP_WAVES_PER_BLOCK + wave] = incl[h];
+  }
+  __syncthreads();
+  int total = 0;
+#pragma unroll
+  for (int h = 0; h < PT; ++h) {
+    int base = 0;
+    for (int w = 0; w < h * FCP_WAVES_PER_BLOCK + wave; ++w) base += s_wsum[w];
+    s_offx[h * FCP_BLOCK_THREADS + tid] = base + incl[h] - want[h];
+  }
+  for (int w = 0; w < PT * FCP_WAVES_PER_BLOCK; ++w) total += s_wsum[w];
+  if (tid == 0) s_offx[NP] = total;
+  __syncthreads();
+
+  // ---- phase 1b: one thread per staged id -> final row number in LDS -----------------
+  // (ids that do not fit the tile are walked from global memory in phase 2)
+  for (int k = tid; k < min(total, CAP); k += FCP_BLOCK_THREADS) {
+    int lo_p = 0, hi_p = NP; // last pair with s_offx[p] <= k
+    while (hi_p - lo_p > 1) {
+      const int mid = (lo_p + hi_p) >> 1;
+      if (s_offx[mid] <= k) lo_p = mid; else hi_p = mid;
+    }
+    const int p = lo_p;
+    if (s_offx[p] + s_cnt[p] <= CAP) {
+      bool bad;
+      const int64_t id = fetch_row_number(s_col[p / RB], s_lo[p] + (k - s_offx[p]), nullptr, rank, world, bad);
+      if (bad && L.bad_ids) atomicAdd(L.bad_ids, 1ull);
+      s_ids[k] = (int32_t)id;
+    }
+  }
+  __syncthreads();
+  if (q >= nslots) return;
+
+  // ---- phase 2 --------------------------------------------------------------------
+  const int j = (int)(my_col - first_col);
+  const LdsCol &C = s_col[j];
+  const unsigned form = FCP_F_FORM(C.flags);
+  const float *table = C.table;
+  const int dim = C.dim;
+  const int e = q * V - C.out_off;
+  const bool mean = FCP_F_COMBINER(C.flags) == FCP_COMBINER_MEAN && world == 1;
+
+  for (int r = 0; r < R; ++r) {
+    const int b = row_blk + wave * R + r;
+    if (b >= rows) break;
+    float *outp = reinterpret_cast<float *>(L.arena + C.out_base) + e + (int64_t)b * C.out_stride;
+    const int p = j * RB + wave * R + r;
+    const int plo = s_lo[p], pcnt = s_cnt[p];
+    const int poff = (pcnt <= LONG_BAG && s_offx[p] + pcnt <= CAP) ? s_offx[p] : -1;
+    VF<V> acc = vzero<V>();
+
+    if (form == FCP_FORM_PASSTHROUGH) {
+      if (rank == 0) acc = ld_blob_f32<V>(C.ids + 4 * ((int64_t)b * dim + e)); // table-free: shard rank 0
+    } else if (form == FCP_FORM_BATCH_COL_REDUCTION) {
+      // cuda_emitter.cc:1231-1236: r ascending, sequential fp32 adds
+      const int inner = rank == 0 ? C.inner : 0;
+      for (int rr = 0; rr < inner; ++rr) {
+        const VF<V> x = ld_blob_f32<V>(C.ids + 4 * (((int64_t)b * inner + rr) * dim + e));
+#pragma unroll
+        for (int t = 0; t < V; ++t) acc.v[t] = acc.v[t] + x.v[t];
+      }
+    } else if (form != FCP_FORM_SEGMENT_REDUCE) {
+      // GATHER / GATHER_SCATTER: a pure copy of one row (rows without ids stay zero)
+      if (pcnt > 0) {
+        int64_t id;
+        if (poff >= 0) {
+          id = s_ids[poff];
+        } else {
+          bool bad;
+          id = fetch_row_number(C, plo, nullptr, rank, world, bad);
+          if (bad && e == 0 && L.bad_ids) atomicAdd(L.bad_ids, 1ull);
+        }
+        if (id >= 0) acc = ld_table<V>(table + id * (int64_t)dim + e);
+      }
+    } else {
+      for (int i = 0; i < pcnt; i += 8) {
+        int64_t id[8];
+        if (poff >= 0) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) id[k] = (i + k < pcnt) ? (int64_t)s_ids[poff + i + k] : -1;
+        } else {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            id[k] = -1;
+            if (i + k < pcnt) {
+              bool bad;
+              id[k] = fetch_row_number(C, plo + i + k, nullptr, rank, world, bad);
+              if (bad && e == 0 && L.bad_ids) atomicAdd(L.bad_ids, 1ull);
+            }
+          }
+        }
+        VF<V> w[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          w[k] = vzero<V>();
+          if (id[k] >= 0) w[k] = ld_table<V>(table + id[k] * (int64_t)dim + e);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (id[k] >= 0) {
+#pragma unroll
+            for (int t = 0; t < V; ++t) acc.v[t] = acc.v[t] + w[k].v[t];
+          }
+      }
+      if (mean && pcnt > 0) {
+        const float fc = (float)pcnt; // sum / count
+#pragma unroll
+        for (int t = 0; t < V; ++t) acc.v[t] = acc.v[t] / fc;
+      }
+    }
+    st_out<V>(outp, acc);
   }
 }
 
@@ -636,14 +693,33 @@ __global__ void __launch_bounds__(FCP_BLOCK_THREADS)
   *reinterpret_cast<VF<V> *>(out + bl * W + (int64_t)q * V) = acc;
 }
 
+
+// ---------------------------------------------------------------------------
+// Descriptor upload: copies the request's FcpColDyn[] from pinned host memory
+// (read over PCIe through its device mapping) into device memory.  Stands in
+// for the reference's per-call cudaMemcpyAsync of KnlArgs (cuda_emitter.cc
+// :2216); hipMemcpyAsync of these ~10-50 KB cost ~28 us per request end to end
+// on this path, a 2-block kernel costs a few.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(FCP_BLOCK_THREADS) fcp_upload_kernel(const uint4 *__restrict__ src,
+                                                                       uint4 *__restrict__ dst, int n16) {
+  for (int i = blockIdx.x * FCP_BLOCK_THREADS + threadIdx.x; i < n16; i += gridDim.x * FCP_BLOCK_THREADS)
+    dst[i] = src[i];
+}
+
 } // namespace
 
 // ------------------------------- launchers ---------------------------------
 
 #define FCP_LAUNCH_DENSE(VV, RR) \
   hipLaunchKernelGGL((fcp_dense_kernel<VV, RR>), dim3(grid_blocks), dim3(FCP_BLOCK_THREADS), 0, s, L)
-#define FCP_LAUNCH_GENERIC(VV) \
-  hipLaunchKernelGGL((fcp_fused_kernel<VV>), dim3(grid_blocks), dim3(FCP_BLOCK_THREADS), 0, s, L)
+#define FCP_LAUNCH_GENERIC(VV)                                                                          \
+  do {                                                                                                  \
+    if (L.rows_per_wave >= 2)                                                                           \
+      hipLaunchKernelGGL((fcp_ragged_kernel<VV, 2>), dim3(grid_blocks), dim3(FCP_BLOCK_THREADS), 0, s, L); \
+    else                                                                                                \
+      hipLaunchKernelGGL((fcp_ragged_kernel<VV, 1>), dim3(grid_blocks), dim3(FCP_BLOCK_THREADS), 0, s, L); \
+  } while (0)
 
 int fcp_launch_fused(const FcpLaunch &L, int vec, bool dense_only, int grid_blocks, ihipStream_t *s) {
   if (grid_blocks <= 0) return 0;
@@ -673,6 +749,15 @@ int fcp_launch_fused(const FcpLaunch &L, int vec, bool dense_only, int grid_bloc
       FCP_LAUNCH_GENERIC(1);
     }
   }
+  return (int)hipGetLastError();
+}
+
+int fcp_launch_upload(const void *host_mapped_src, void *dst, size_t bytes, ihipStream_t *s) {
+  const int n16 = (int)((bytes + 15) / 16);
+  if (n16 <= 0) return 0;
+  const int blocks = n16 >= 4096 ? 8 : (n16 >= 1024 ? 4 : 1);
+  hipLaunchKernelGGL(fcp_upload_kernel, dim3(blocks), dim3(FCP_BLOCK_THREADS), 0, s,
+                     static_cast<const uint4 *>(host_mapped_src), static_cast<uint4 *>(dst), n16);
   return (int)hipGetLastError();
 }
 

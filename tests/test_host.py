@@ -1,0 +1,235 @@
+"""CPU-only tests: the C-ABI library loads and exports every symbol the header
+declares, the host-side pieces (ConcatInputs packer, plan validation, layout
+arithmetic, error codes) behave like the reference's ops, and the synthetic
+model generator is self-consistent.  No compute call needs a GPU here."""
+import ctypes as C
+import dataclasses
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def L():
+    from recom_amd import lib
+    return lib.load()
+
+
+def test_library_exports_every_declared_symbol(L):
+    from recom_amd import lib
+    hdr = open(os.path.join(ROOT, "include", "fcp_hip.h")).read()
+    declared = set(re.findall(r"\b(fcp_[a-z_0-9]+)\s*\(", hdr)) - {"fcp_alloc_fn"}
+    assert declared == set(lib.EXPORTS), declared ^ set(lib.EXPORTS)
+    for name in declared:
+        assert hasattr(L, name), name
+    assert L.fcp_abi_version() == lib.FCP_ABI_VERSION
+    assert L.fcp_status_string(0) == b"ok"
+    assert b"shape" in L.fcp_status_string(lib.FCP_ERR_SHAPE_MISMATCH)
+
+
+def test_no_torch_or_tf_types_in_the_abi():
+    hdr = open(os.path.join(ROOT, "include", "fcp_hip.h")).read()
+    code = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    for banned in ("std::", "torch", "at::", "tensorflow", "hipStream_t", "#include <hip"):
+        assert banned not in code, banned
+
+
+def test_concat_inputs_matches_reference_semantics(oracle):
+    """Addons>ConcatInputs (concat_inputs_ops.cc:42-77): byte concatenation, int32
+    byte offsets, all dims in order — bit-exact with the oracle restatement."""
+    from recom_amd.ops import concat_inputs
+    rng = np.random.default_rng(0)
+    ts = [rng.integers(0, 9, (5,)).astype(np.int64), rng.standard_normal((3, 2)).astype(np.float32),
+          np.zeros((0, 2), np.int64), np.asarray(7, np.int32), rng.integers(0, 100, (4, 2)).astype(np.int64),
+          np.frombuffer(b"abc", np.uint8)]
+    blob, off, shp = concat_inputs(ts)
+    b2, o2, s2 = oracle.concat_inputs(ts)
+    assert blob.dtype == np.int8 and off.dtype == np.int32 and shp.dtype == np.int32
+    assert np.array_equal(blob, b2) and np.array_equal(off, o2) and np.array_equal(shp, s2)
+    assert np.array_equal(off, [0, 40, 64, 64, 68, 132])
+    assert np.array_equal(shp, [5, 3, 2, 0, 2, 4, 2, 3])
+    assert blob.tobytes() == b"".join(t.tobytes() for t in ts)
+    e_blob, e_off, e_shp = concat_inputs([])
+    assert e_blob.size == 0 and e_off.size == 0 and e_shp.size == 0
+
+
+def test_concat_inputs_error_codes(L):
+    from recom_amd import lib
+    t = lib.HostTensor(None, 4, 1, (C.c_int64 * 1)(-3))
+    n = C.c_int64()
+    assert L.fcp_concat_inputs_sizes(C.byref(t), 1, C.byref(n), None) == lib.FCP_ERR_INVALID_ARGUMENT
+    dims = (C.c_int64 * 1)(4)
+    data = np.arange(4, dtype=np.float32)
+    t = lib.HostTensor(data.ctypes.data, 4, 1, dims)
+    off, shp = np.zeros(1, np.int32), np.zeros(1, np.int32)
+    small = np.zeros(8, np.int8)
+    assert L.fcp_concat_inputs(C.byref(t), 1, small.ctypes.data, 8, off.ctypes.data, shp.ctypes.data) == \
+        lib.FCP_ERR_INVALID_ARGUMENT  # blob too small
+    assert b"blob" in L.fcp_last_error()
+
+
+def _host_plan(spec):
+    from recom_amd.ops import Plan
+    return Plan(spec, 0, host_only=True)
+
+
+def test_plan_layout_queries_host_only():
+    from recom_amd import synth
+    from recom_amd.plan import LAYOUT_PER_COLUMN
+    m = synth.model_mixed(batch=33, vocab=211)
+    p = _host_plan(m.spec)
+    offs = m.spec.column_offsets()
+    for k in range(m.spec.n_columns):
+        assert p.column_offset(k) == offs[k]
+    for g in range(m.spec.n_groups):
+        assert p.group_width(g) == m.spec.group_width(g)
+    # arena = sum over groups of alignmem(rows*width*4) + CSR scratch for seg-id columns
+    req = m.make_request(0)
+    from recom_amd.ops import concat_inputs
+    _, _, shapes = concat_inputs(req.inputs)
+    al = lambda x: (x + 127) // 128 * 128  # alignmem, cuda_emitter.cc:967-969
+    rows = 33
+    out_bytes = sum(al(rows * m.spec.group_width(g) * 4) for g in range(m.spec.n_groups))
+    n_seg = sum(1 for c in m.spec.columns if c.form in (2, 3) and c.seg_kind in (1, 2))
+    csr = n_seg * ((rows + 1 + 31) // 32 * 32) * 4
+    assert p.arena_bytes(shapes, req.symbols) == out_bytes + csr
+    # the reference arena: one 128-byte aligned buffer per column (cuda_emitter.cc:2151-2179)
+    pc = _host_plan(m.spec.with_layout(LAYOUT_PER_COLUMN))
+    assert pc.arena_bytes(shapes, req.symbols) == sum(al(rows * c.dim * 4) for c in m.spec.columns) + csr
+    p.close()
+    pc.close()
+
+
+def test_host_only_plan_cannot_run_and_real_plan_needs_a_gpu():
+    import torch
+    from recom_amd import lib, synth
+    from recom_amd.ops import Plan
+    m = synth.model_s1(columns=4, batch=8)
+    p = _host_plan(m.spec)
+    a = lib.ProcessArgs()
+    assert p._L.fcp_process_feature_columns(p.handle, C.byref(a), None) == lib.FCP_ERR_NO_DEVICE
+    p.close()
+    if not torch.cuda.is_available():
+        with pytest.raises(lib.FcpError) as e:
+            Plan(m.spec, 0)  # no silent CPU fallback: creation fails loudly
+        assert e.value.status in (lib.FCP_ERR_NO_DEVICE, lib.FCP_ERR_HIP)
+
+
+@pytest.mark.parametrize("mutate,needle", [
+    (lambda s: dataclasses.replace(s, n_groups=0), "n_groups"),
+    (lambda s: dataclasses.replace(s, n_groups=17), "n_groups"),
+    (lambda s: dataclasses.replace(s, shard_rank=2, shard_world=2), "shard"),
+    (lambda s: dataclasses.replace(s, layout=7), "layout"),
+])
+def test_plan_descriptor_validation(mutate, needle):
+    """Bad attrs are refused like OP_REQUIRES in the op constructors
+    (feature_column_process_op_gpu.cu.cc:39-44), with FCP_ERR_INVALID_ARGUMENT."""
+    from recom_amd import lib, synth
+    from recom_amd.ops import Plan
+    m = synth.model_s1(columns=4, batch=8)
+    spec = mutate(m.spec)
+    spec.validate = lambda: None  # bypass the Python-side check: the C side must catch it
+    with pytest.raises(lib.FcpError) as e:
+        Plan(spec, 0, host_only=True)
+    assert e.value.status == lib.FCP_ERR_INVALID_ARGUMENT and needle in str(e.value)
+
+
+def test_column_descriptor_validation():
+    from recom_amd import lib, synth
+    from recom_amd.ops import Plan
+    base = synth.model_mixed(batch=8, vocab=50, n_groups=1).spec
+
+    def broken(k, **kw):
+        cols = list(base.columns)
+        cols[k] = dataclasses.replace(cols[k], **kw)
+        s = dataclasses.replace(base, columns=cols)
+        s.validate = lambda: None
+        for c in cols:
+            c.validate = lambda: None
+        return s
+
+    cases = [broken(0, dim=0), broken(0, vocab=0), broken(0, table_input=99), broken(0, ids_input=-1),
+             broken(1, boundaries=None), broken(3, seg_kind=0), broken(3, rows_source=0), broken(3, combiner=0),
+             broken(0, concat_slot=1), broken(0, id_source=0), broken(4, seg_stride=0)]
+    for s in cases:
+        with pytest.raises(lib.FcpError) as e:
+            Plan(s, 0, host_only=True)
+        assert e.value.status == lib.FCP_ERR_INVALID_ARGUMENT
+    Plan(base, 0, host_only=True).close()
+
+
+def test_runtime_shape_checks_host_only():
+    """Run-time shape errors surface as FCP_ERR_SHAPE_MISMATCH from the layout
+    query (the same code path the request entry uses)."""
+    from recom_amd import lib, synth
+    from recom_amd.ops import concat_inputs
+    m = synth.model_mixed(batch=16, vocab=97, n_groups=1)
+    p = _host_plan(m.spec)
+    req = m.make_request(0)
+    _, _, shapes = concat_inputs(req.inputs)
+    assert p.arena_bytes(shapes, req.symbols) > 0
+    with pytest.raises(lib.FcpError) as e:
+        p.arena_bytes(shapes, np.asarray([17], np.int32))
+    assert e.value.status == lib.FCP_ERR_SHAPE_MISMATCH
+    with pytest.raises(lib.FcpError) as e:
+        p.arena_bytes(shapes, None)
+    assert e.value.status == lib.FCP_ERR_INVALID_ARGUMENT
+    bad = shapes.copy()
+    bad[0] = -1
+    with pytest.raises(lib.FcpError) as e:
+        p.arena_bytes(bad, req.symbols)
+    assert e.value.status == lib.FCP_ERR_SHAPE_MISMATCH
+    p.close()
+
+
+def test_s2_algorithmic_bytes_match_the_survey():
+    """rows 61.44 MB + ids + out 61.44 MB for S2 (ids are 4 bytes on
+    the 100 bucketize-sourced columns, 8 bytes elsewhere)."""
+    from recom_amd import synth
+    from recom_amd.ops import concat_inputs
+    m = synth.model_s2()
+    assert m.spec.n_columns == 1000 and m.spec.group_width(0) == 30000
+    assert m.table_bytes() == 120_000_000_000
+    req = m.make_request(0)
+    _, _, shapes = concat_inputs(req.inputs)
+    b = m.spec.algorithmic_bytes(shapes, req.symbols)
+    assert b["rows"] == 512 * 30000 * 4 == 61_440_000
+    assert b["out"] == 61_440_000
+    assert b["ids"] == 512 * (900 * 8 + 100 * 4)
+    assert b["boundaries"] == 100 * 100 * 4
+    assert b["total"] == b["rows"] + b["ids"] + b["boundaries"] + b["out"]
+
+
+def test_baseline_configs_are_well_formed():
+    from recom_amd import synth
+    s1 = synth.model_s1()
+    assert (s1.spec.n_columns, s1.batch, s1.spec.group_width(0)) == (100, 128, 1600)
+    d = synth.model_dlrm()
+    assert d.spec.n_columns == 27 and d.spec.group_width(0) == 26 * 16 + 13 and d.batch == 2048
+    r = synth.model_ragged()
+    assert r.spec.n_columns == 512 and r.batch == 256
+    req = r.make_request(0)
+    lens = np.diff(req.inputs[1])
+    assert lens.min() == 0 and lens.max() == 10  # ids/row ~ U{0..10}
+    assert any(not np.array_equal(r.make_request(1).inputs[1], req.inputs[1]) for _ in range(1))  # nnz re-drawn
+    sh = synth.model_shard()
+    assert sh.spec.n_columns == 4000 and sh.table_bytes() == 480_000_000_000
+    for m in (s1, d, r):
+        m.spec.validate()
+
+
+def test_closed_form_tables_agree_between_numpy_and_torch():
+    import torch
+    from recom_amd import synth
+    a = synth.hash_table_numpy(1003, 257, 12)
+    b = synth.hash_table_torch(1003, 257, 12, "cpu").numpy()
+    assert np.array_equal(a, b)
+    assert np.array_equal(synth.hash_rows(1003, [0, 5, 256], 12), a[[0, 5, 256]])
+    # one shard of a row-sharded table
+    c = synth.hash_table_torch(1003, 257, 12, "cpu", 2, 4).numpy()
+    assert np.array_equal(c, a[2::4])
+    assert a.min() >= -1.0 and a.max() < 1.0 and abs(float(a.mean())) < 0.05
