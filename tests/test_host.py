@@ -233,3 +233,19 @@ def test_closed_form_tables_agree_between_numpy_and_torch():
     c = synth.hash_table_torch(1003, 257, 12, "cpu", 2, 4).numpy()
     assert np.array_equal(c, a[2::4])
     assert a.min() >= -1.0 and a.max() < 1.0 and abs(float(a.mean())) < 0.05
+
+
+def test_plan_file_round_trip(tmp_path):
+    """The `dlpath` plan file read by the TF shim (tf_shim/fcp_tf_ops.cc) and by Python."""
+    from recom_amd import synth
+    from recom_amd.plan_io import load_plan, save_plan
+    m = synth.model_mixed(batch=9, vocab=50)
+    path = str(tmp_path / "plan.fcp")
+    save_plan(m.spec, path)
+    back = load_plan(path)
+    a, b = m.spec.to_dict(), back.to_dict()
+    for ca, cb in zip(a.pop("columns"), b.pop("columns")):
+        ba, bb = ca.pop("boundaries"), cb.pop("boundaries")
+        assert ca == cb
+        assert (ba is None and bb is None) or np.array_equal(ba, bb)
+    assert a == b
