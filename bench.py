@@ -116,6 +116,7 @@ def main():
     ap.add_argument("--columns", type=int, default=0, help="override the column count (debug only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--requests", type=int, default=16, help="distinct resident requests cycled through")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) normally; gloo only to exercise the N>1 control flow on a 1-GPU box")
     args = ap.parse_args()
 
     import torch
@@ -125,6 +126,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("FCP_BENCH_DEVICE"):  # testing aid: several ranks on one GPU (with --dist-backend gloo)
+        local_rank = int(os.environ["FCP_BENCH_DEVICE"])
     if args.gpus > 1 and world == 1:
         print("bench.py: --gpus > 1 must be launched with torch.distributed.run", file=sys.stderr)
         sys.exit(2)
@@ -133,8 +136,10 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
 
     if args.workload == "shard":
         from recom_amd.shard import bench_sharded

@@ -102,6 +102,14 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch (device memory / stream plumbing of the Python host side) bundles its
+    # own HIP runtime.  Load it first so the process ends up with ONE runtime: if
+    # libfcp_hip.so pulled in /opt/rocm's copy before torch initialised its own, the
+    # second runtime to start would not see the GPU.
+    try:
+        import torch  # noqa: F401
+    except ImportError:  # the C ABI itself does not need torch
+        pass
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
