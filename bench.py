@@ -115,6 +115,8 @@ def main():
     ap.add_argument("--threads", type=int, default=1, help="serve_workers per GPU (reference harness flag)")
     ap.add_argument("--columns", type=int, default=0, help="override the column count (debug only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--vocab", type=int, default=0, help="override the vocabulary size (debug only)")
+    ap.add_argument("--batch", type=int, default=0, help="override the batch size (debug only)")
     ap.add_argument("--requests", type=int, default=16, help="distinct resident requests cycled through")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) normally; gloo only to exercise the N>1 control flow on a 1-GPU box")
     args = ap.parse_args()
@@ -151,11 +153,12 @@ def main():
         return
 
     if args.workload == "s2":
-        model = synth.model_s2(columns=args.columns or 1000, dist=args.ids)
+        model = synth.model_s2(columns=args.columns or 1000, dist=args.ids, **({'batch': args.batch} if args.batch else {}))
     elif args.workload == "dlrm":
         model = synth.model_dlrm()
     else:
-        model = synth.model_ragged(columns=args.columns or 512)
+        model = synth.model_ragged(columns=args.columns or 512, **({'batch': args.batch} if args.batch else {}),
+                                   **({'vocab': args.vocab} if args.vocab else {}))
 
     h = ServingHarness(model, device=local_rank, n_requests=args.requests, arena_ring=6, n_threads=args.threads,
                        seed0=1000 * rank)

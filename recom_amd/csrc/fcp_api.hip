@@ -281,6 +281,7 @@ int compute_dyn(const fcp_plan *p, const int32_t *offsets, const int32_t *shapes
     d.inner = 1;
     if (c.form == FCP_FORM_PASSTHROUGH) {
       if (n_ids != rows * c.dim) return fail(FCP_ERR_SHAPE_MISMATCH, "passthrough tensor size != rows*dim");
+      if (n_ids / p->vec >= 0xFFFFFFFFLL) return fail(FCP_ERR_UNSUPPORTED, "passthrough tensor exceeds 2^32 slots");
       d.nnz = (int32_t)rows;
     } else if (c.form == FCP_FORM_BATCH_COL_REDUCTION) {
       const int32_t *s = shapes + p->shape_off[c.ids_input];
@@ -332,20 +333,14 @@ int compute_dyn(const fcp_plan *p, const int32_t *offsets, const int32_t *shapes
     // 4 rows per wave (16 per block) measured best on S2 at batch 512 and 2048:
     // ~2 rounds of blocks de-phase the read and write bursts; 8 rows lose to the tail.
     while (rpw < 4 && max_rows >= 32 * rpw) rpw *= 2; // >= 64 rows -> 4, 32..63 -> 2, < 32 -> 1
-    static const int forced = [] { // tuning aid: FCP_ROWS_PER_WAVE=1|2|4|8
+    static const int forced = [] { // tuning aid: FCP_ROWS_PER_WAVE=1|2|4
       const char *e = std::getenv("FCP_ROWS_PER_WAVE");
       const int v = e ? std::atoi(e) : 0;
-      return (v == 1 || v == 2 || v == 4 || v == 8) ? v : 0;
+      return (v == 1 || v == 2 || v == 4) ? v : 0;
     }();
     if (forced) rpw = forced;
   } else {
-    rpw = 1; // ragged kernel: 1 row per wave measured best on RAGGED (34.2 vs 36.0 us at 2)
-    static const int forced = [] {
-      const char *e = std::getenv("FCP_RAGGED_ROWS_PER_WAVE");
-      const int v = e ? std::atoi(e) : 0;
-      return (v == 1 || v == 2) ? v : 0;
-    }();
-    if (forced) rpw = forced;
+    rpw = 1; // ragged kernel: one row per wave (2 interleaved rows measured slower: 33.7 vs 31.6 us)
   }
   m->rows_per_wave = rpw;
   int32_t blocks = 0;
@@ -656,12 +651,22 @@ int fcp_plan_create(const fcp_plan_desc_t *desc, fcp_plan_t **out) {
     if (hc.d.dim % 4) gcd4 = (hc.d.dim % 2) ? 1 : std::min(gcd4, 2);
     const int f = hc.d.form;
     if (f != FCP_FORM_GATHER && f != FCP_FORM_PASSTHROUGH) p->dense_only = false;
-    // the dense kernel parks local row numbers in LDS as int32
-    if (f == FCP_FORM_GATHER && hc.d.vocab > 0x7fffffffLL) p->dense_only = false;
     if ((f == FCP_FORM_SEGMENT_REDUCE || f == FCP_FORM_GATHER_SCATTER) && hc.d.seg_kind != FCP_SEG_CSR_I32)
       p->seg_cols.push_back(k);
   }
   p->vec = gcd4;
+  // The kernels address table rows by a 32-bit slot offset (row * dim / vec): one
+  // table (or one shard of it) may hold up to 2^32 slots = 64 GB at vec 4.  (The
+  // reference's int arithmetic stops at 2^31 elements = 8 GB, cuda_emitter.cc:270-271.)
+  for (int k = 0; k < desc->n_columns; ++k) {
+    const fcp_column_desc_t &c = p->cols[k].d;
+    if (c.form == FCP_FORM_PASSTHROUGH || c.form == FCP_FORM_BATCH_COL_REDUCTION) continue;
+    const int64_t local_vocab = (c.vocab - desc->shard_rank + desc->shard_world - 1) / desc->shard_world;
+    if (local_vocab * (c.dim / p->vec) >= 0xFFFFFFFFLL) {
+      delete p;
+      return fail(FCP_ERR_UNSUPPORTED, "column " + std::to_string(k) + ": table shard exceeds 2^32 slots");
+    }
+  }
   // concat layout: offsets = prefix sums of dims in slot order
   // (concat_outputs_op_gpu.cu.cc:74-79)
   const int ng = desc->n_groups;

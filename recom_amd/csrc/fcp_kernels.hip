@@ -24,9 +24,10 @@
 //     final concat layout — the concat pass and its intermediate arena vanish;
 //   * a table row of dim floats is read by dim/4 adjacent lanes as one
 //     contiguous run (coalesced into whole 64/128-byte requests);
-//   * the 8 ids (64 B) a wave needs from one column for its R=8 rows share a
-//     cache line, and all lanes of that column broadcast one address;
-//   * 1000 columns x batch 512 give ~1900 blocks / ~7500 waves instead of 1000
+//   * per block, the column records, the CSR row ranges and the ids of the
+//     span are fetched ONCE (coalesced, one request per cache line) and staged in
+//     LDS; the lanes then read them as LDS broadcasts;
+//   * 1000 columns x batch 512 give 3840 blocks / 15360 waves instead of 1000
 //     waves, enough to keep >16 MB of loads in flight (HBM latency x bandwidth);
 //   * blocks that share a span (the same columns / tables) are given the same
 //     `blockIdx % 8`, i.e. the same XCD and L2 under round-robin dispatch, so
@@ -39,6 +40,21 @@
 
 namespace {
 
+// Pointers that travel through LDS records (or are computed from them) lose their
+// address space: hipcc then emits FLAT loads, which probe the LDS aperture as well
+// and complete out of order.  Every such access is cast back to the global address
+// space so that it becomes a plain global_load / global_store.
+#define FCP_GLOBAL __attribute__((address_space(1)))
+template <typename T> __device__ __forceinline__ const FCP_GLOBAL T *as_global(const T *p) {
+  return (const FCP_GLOBAL T *)(p);
+}
+template <typename T> __device__ __forceinline__ FCP_GLOBAL T *as_global(T *p) { return (FCP_GLOBAL T *)(p); }
+
+template <int V> struct VecType;
+template <> struct VecType<4> { typedef float __attribute__((ext_vector_type(4))) T; };
+template <> struct VecType<2> { typedef float __attribute__((ext_vector_type(2))) T; };
+template <> struct VecType<1> { typedef float T; };
+
 template <int V> struct alignas(4 * V) VF { float v[V]; };
 
 template <int V> __device__ __forceinline__ VF<V> vzero() {
@@ -48,25 +64,55 @@ template <int V> __device__ __forceinline__ VF<V> vzero() {
   return r;
 }
 
-// Blob tensors are only guaranteed 4-byte aligned (ConcatInputs packs bytes
-// back to back, concat_inputs_ops.cc:52-60), so 8-byte ids are read as two
-// dwords.
-__device__ __forceinline__ int64_t ld_i64_a4(const char *p) {
-  const uint32_t *q = reinterpret_cast<const uint32_t *>(p);
-  const uint32_t lo = q[0], hi = q[1];
-  return (int64_t)(((uint64_t)hi << 32) | lo);
+// Output rows are written once and consumed by a later kernel; table rows are
+// read once per request: both use the non-temporal forms (measured on S2:
+// 34.3 -> 30.5 us per request; stores give most of it).  -DFCP_NO_NT restores
+// the default cache policy (tuning builds).
+template <int V> __device__ __forceinline__ void st_out(float *p, const VF<V> &v) {
+  typedef typename VecType<V>::T T;
+  T t;
+  __builtin_memcpy(&t, &v, sizeof(T));
+#if !defined(FCP_NO_NT)
+  __builtin_nontemporal_store(t, as_global(reinterpret_cast<T *>(p)));
+#else
+  *as_global(reinterpret_cast<T *>(p)) = t;
+#endif
 }
 
+// Slot `off` (units of V floats) of a table whose lane-specific base is `tb`:
+// one v_lshl_add_u64 + one global_load.
+template <int V> __device__ __forceinline__ VF<V> ld_slot(const float *tb, uint32_t off) {
+  typedef typename VecType<V>::T T;
+  const FCP_GLOBAL T *g = as_global(reinterpret_cast<const T *>(tb)) + off;
+#if !defined(FCP_NO_NT)
+  T t = __builtin_nontemporal_load(g);
+#else
+  T t = *g;
+#endif
+  VF<V> r;
+  __builtin_memcpy(&r, &t, sizeof(T));
+  return r;
+}
+
+// Blob tensors are only guaranteed 4-byte aligned (ConcatInputs packs bytes
+// back to back, concat_inputs_ops.cc:52-60): payloads are read dword by dword,
+// 8-byte ids as two dwords.
 template <int V> __device__ __forceinline__ VF<V> ld_blob_f32(const char *p) {
   VF<V> r;
-  const float *q = reinterpret_cast<const float *>(p);
+  const FCP_GLOBAL float *q = as_global(reinterpret_cast<const float *>(p));
 #pragma unroll
   for (int i = 0; i < V; ++i) r.v[i] = q[i];
   return r;
 }
 
+__device__ __forceinline__ int64_t ld_i64_a4(const char *p) {
+  const FCP_GLOBAL uint32_t *q = as_global(reinterpret_cast<const uint32_t *>(p));
+  const uint32_t lo = q[0], hi = q[1];
+  return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
 // cuda_emitter.cc:233-247 — r+1 = number of boundaries <= value.
-__device__ __forceinline__ int bucketize(const float *__restrict__ b, int n, float value) {
+template <typename P> __device__ __forceinline__ int bucketize(P b, int n, float value) {
   int l = 0, r = n - 1;
   while (l <= r) {
     const int mid = (l + r) >> 1;
@@ -79,109 +125,14 @@ __device__ __forceinline__ int bucketize(const float *__restrict__ b, int n, flo
   return r + 1;
 }
 
-// The index expression the reference inlines per column (EmitInputInline,
-// :1769-1949): raw int32 / int64 ids, or Bucketize(float value).  The fetch is
-// branch-free on purpose — one code path for every id source, so that the
-// compiler can issue the fetches of all rows of a wave back to back and wait
-// once (a switch per id source serialises them behind one s_waitcnt each).
-__device__ __forceinline__ void ld_raw_id(const char *ids, bool is64, int64_t p, uint32_t &lo, uint32_t &hi) {
-  const char *a = ids + (is64 ? 8 : 4) * p;
-  lo = *reinterpret_cast<const uint32_t *>(a);
-  hi = *reinterpret_cast<const uint32_t *>(a + (is64 ? 4 : 0));
-}
+constexpr uint32_t kNoRow = 0xFFFFFFFFu; // "this id contributes nothing"
 
-__device__ __forceinline__ int64_t raw_to_id(bool is64, uint32_t lo, uint32_t hi) {
-  return is64 ? (int64_t)(((uint64_t)hi << 32) | lo) : (int64_t)(int32_t)lo;
-}
-
-// Validity + row sharding.  Returns true when this GPU must read a row; `id`
-// becomes the local row.  Ids outside [0, vocab) read as zeros (the reference
-// reads out of bounds, TF-GPU GatherV2 returns zeros).
-__device__ __forceinline__ bool resolve_id(int64_t &id, int64_t vocab, int rank, int world,
-                                           bool &bad) {
-  bad = (uint64_t)id >= (uint64_t)vocab;
-  if (bad) return false;
-  if (world > 1) {
-    int64_t q;
-    if (id < 0x7fffffffLL) {
-      q = (int64_t)((uint32_t)id / (uint32_t)world);
-    } else {
-      q = id / world;
-    }
-    if (id - q * world != rank) return false;
-    id = q;
-  }
-  return true;
-}
-
-template <int V>
-__device__ __forceinline__ VF<V> ld_row(const float *__restrict__ table, int64_t id, int dim, int e) {
-  return *reinterpret_cast<const VF<V> *>(table + id * (int64_t)dim + e);
-}
-
-template <int V> struct VecType;
-template <> struct VecType<4> { typedef float __attribute__((ext_vector_type(4))) T; };
-template <> struct VecType<2> { typedef float __attribute__((ext_vector_type(2))) T; };
-template <> struct VecType<1> { typedef float T; };
-
-// Output rows are written once and consumed by a later kernel; table rows are
-// read once per request: both use the non-temporal forms (measured on S2:
-// 34.3 -> 30.5 us per request; stores give most of it).  -DFCP_NO_NT restores
-// the default cache policy (tuning builds).
-#if !defined(FCP_NO_NT)
-#define FCP_NT_STORE 1
-#define FCP_NT_LOAD 1
-#endif
-template <int V> __device__ __forceinline__ void st_out(float *p, const VF<V> &v) {
-#if defined(FCP_NT_STORE)
-  typedef typename VecType<V>::T T;
-  T t;
-  __builtin_memcpy(&t, &v, sizeof(T));
-  __builtin_nontemporal_store(t, reinterpret_cast<T *>(p));
-#else
-  *reinterpret_cast<VF<V> *>(p) = v;
-#endif
-}
-
-template <int V> __device__ __forceinline__ VF<V> ld_table(const float *p) {
-#if defined(FCP_NT_LOAD)
-  typedef typename VecType<V>::T T;
-  T t = __builtin_nontemporal_load(reinterpret_cast<const T *>(p));
-  VF<V> r;
-  __builtin_memcpy(&r, &t, sizeof(T));
-  return r;
-#else
-  return *reinterpret_cast<const VF<V> *>(p);
-#endif
-}
-
-// ---------------------------------------------------------------------------
-// Dense kernel: every column of the plan is GATHER or PASSTHROUGH (exactly one
-// source row per output row) — BASELINE.json's S2 and DLRM shapes.
-//
-// A block owns one span (64 slots = 1 KiB of the output row) for RB = 4*R rows.
-//   phase 0  the span's column records (static + dynamic, contiguous because
-//            the device arrays are kept in concat order) are copied to LDS,
-//            one thread per column;
-//   phase 1  the block's (column, row) id pairs are fetched with one thread
-//            per pair — consecutive threads take consecutive rows of one
-//            column, so every id cache line is requested exactly once — turned
-//            into final local row numbers (Bucketize, range check, row shard)
-//            and parked in LDS;
-//   phase 2  every lane reads its column record and its R row numbers from
-//            LDS (broadcast reads), issues its R 16-byte table reads back to
-//            back, then its R stores: 1 KiB contiguous per wave instruction,
-//            straight into the concat layout.
-// Without the LDS staging every lane fetched its own copy of the id and of the
-// 96-byte column record: ~80 vector-memory instructions per wave and — measured
-// with rocprofv3 — about half of the kernel time in TCP_PENDING_STALL_CYCLES
-// (lanes and waves queueing on the same in-flight cache lines).
-// ---------------------------------------------------------------------------
+// One column of the span, staged in LDS by the block.
 struct alignas(16) LdsCol {   // 80 bytes
   const float *table;         // table base, or the passthrough payload
   const char *ids;            // id / value stream of this request
   const float *boundaries;
-  const int32_t *csr;         // CSR offsets of this request (blob or arena scratch), ragged kernel only
+  const int32_t *csr;         // CSR offsets of this request (blob or arena scratch)
   int64_t vocab;
   int64_t out_base;           // byte offset in the arena of element (0,0)
   int32_t dim;
@@ -216,68 +167,119 @@ __device__ __forceinline__ LdsCol make_lds_col(const FcpLaunch &L, const FcpColS
   return c;
 }
 
-// One id of a column -> final local row number, or -1 (out of range / owned by
-// another shard).  `bnd` = boundaries in LDS when staged, else nullptr.
-__device__ __forceinline__ int64_t fetch_row_number(const LdsCol &c, int64_t pos, const float *bnd, int rank,
-                                                    int world, bool &bad) {
+// The index expression the reference inlines per column (EmitInputInline,
+// cuda_emitter.cc:1769-1949: raw int32 / int64 ids, or Bucketize(float value)),
+// the range check and the row shard, folded into ONE number per id: the offset of
+// the table row in units of V floats (row * dim / V; < 2^32 is checked when the
+// plan is created), or kNoRow.  Ids outside [0, vocab) read as zeros (the
+// reference reads out of bounds, TF-GPU GatherV2 returns zeros); under row
+// sharding an id owned by another rank contributes nothing here.
+template <int V, bool SHARDED>
+__device__ __forceinline__ uint32_t fetch_slot_offset(const LdsCol &c, int64_t pos, const float *lds_bnd, int rank,
+                                                      int world, bool &bad) {
   const unsigned idsrc = FCP_F_IDSRC(c.flags);
   const bool is64 = idsrc == FCP_IDS_I64;
-  uint32_t lo, hi;
-  ld_raw_id(c.ids, is64, pos, lo, hi);
-  int64_t v;
+  // branch-free fetch: one code path for every id source
+  const char *a = c.ids + (is64 ? 8 : 4) * pos;
+  const uint32_t lo = *as_global(reinterpret_cast<const uint32_t *>(a));
+  const uint32_t hi = *as_global(reinterpret_cast<const uint32_t *>(a + (is64 ? 4 : 0)));
+  int64_t id;
   if (idsrc == FCP_IDS_F32_BUCKETIZE) {
-    v = bucketize(bnd ? bnd : c.boundaries, c.n_boundaries, __uint_as_float(lo));
+    id = lds_bnd ? bucketize(lds_bnd, c.n_boundaries, __uint_as_float(lo))
+                 : bucketize(as_global(c.boundaries), c.n_boundaries, __uint_as_float(lo));
   } else {
-    v = raw_to_id(is64, lo, hi);
+    id = is64 ? (int64_t)(((uint64_t)hi << 32) | lo) : (int64_t)(int32_t)lo;
   }
-  return resolve_id(v, c.vocab, rank, world, bad) ? v : -1;
+  bad = (uint64_t)id >= (uint64_t)c.vocab;
+  if (bad) return kNoRow;
+  if (SHARDED) {
+    const int64_t q = id < 0x7fffffffLL ? (int64_t)((uint32_t)id / (uint32_t)world) : id / world;
+    if (id - q * world != rank) return kNoRow;
+    id = q;
+  }
+  return (uint32_t)id * (uint32_t)(c.dim / V);
 }
 
-template <int V, int R>
-__global__ void __launch_bounds__(FCP_BLOCK_THREADS) fcp_dense_kernel(const FcpLaunch L) {
-  constexpr int RB = FCP_WAVES_PER_BLOCK * R; // rows per block
-  constexpr int IDS = RB + 1;                 // padded row of the id tile (LDS banks)
-  constexpr int BND = 1024;                   // floats of bucketize boundaries staged per block
-  __shared__ LdsCol s_col[FCP_WAVE];
-  __shared__ int32_t s_id[FCP_WAVE * IDS];    // local row numbers (< 2^31, checked at plan creation)
-  __shared__ float s_bnd[BND];
+// Common block header: which group / span / row tile this block owns.
+struct BlockPos {
+  int rows, nslots, q0, row_blk, ncols;
+  uint32_t first_col;
+  const uint32_t *map;
+};
 
+template <int RB> __device__ __forceinline__ bool locate_block(const FcpLaunch &L, BlockPos &B) {
   int bid = blockIdx.x;
   int g = 0;
   for (int k = 1; k < L.n_groups; ++k)
     if (bid >= L.groups[k].block_begin) g = k;
-  const int rows = L.groups[g].rows;
-  const int nslots = L.groups[g].nslots;
+  B.rows = L.groups[g].rows;
+  B.nslots = L.groups[g].nslots;
   const int nsp8 = L.groups[g].nsp8;
-  const uint32_t *__restrict__ map = L.slot_map + L.groups[g].slot_map_off;
+  B.map = L.slot_map + L.groups[g].slot_map_off;
   bid -= L.groups[g].block_begin;
+  // XCD-aware mapping: blocks with equal (bid & 7) share an XCD under the
+  // round-robin dispatch; give them the same spans (same columns / tables).
   const int xcd = bid & 7, j8 = bid >> 3;
   const int span = (j8 % nsp8) * 8 + xcd;
   const int tile = j8 / nsp8;
-  const int q0 = span * FCP_WAVE;
-  const int row_blk = tile * RB;
-  if (q0 >= nslots || row_blk >= rows) return; // uniform: whole block leaves
+  B.q0 = span * FCP_WAVE;
+  B.row_blk = tile * RB;
+  if (B.q0 >= B.nslots || B.row_blk >= B.rows) return false; // uniform: whole block leaves
+  B.first_col = B.map[B.q0];
+  B.ncols = (int)(B.map[min(B.q0 + FCP_WAVE - 1, B.nslots - 1)] - B.first_col) + 1;
+  return true;
+}
 
+// ---------------------------------------------------------------------------
+// Dense kernel: every column of the plan is GATHER or PASSTHROUGH (exactly one
+// source row per output row) — BASELINE.json's S2 and DLRM shapes.
+//
+// A block owns one span (64 slots = 1 KiB of the output row) for RB = 4*R rows.
+//   phase 0  the span's column records (static + dynamic, contiguous because
+//            the device arrays are kept in concat order) are copied to LDS,
+//            one thread per column;
+//   phase 0b bucketize boundaries -> LDS (the reference stages them per block
+//            too, cuda_emitter.cc:1818-1825); wave 0 assigns LDS offsets with a
+//            shuffle prefix sum, columns that do not fit keep searching in L2;
+//   phase 1  the block's (column, row) id pairs are fetched with one thread
+//            per pair — consecutive threads take consecutive rows of one
+//            column, so every id cache line is requested exactly once — turned
+//            into table slot offsets and parked in LDS;
+//   phase 2  every lane reads its column record and its R slot offsets from
+//            LDS (broadcast reads), issues its R 16-byte table reads back to
+//            back, then its R stores: 1 KiB contiguous per wave instruction,
+//            straight into the concat layout.
+// Without the LDS staging every lane fetched its own copy of the id and of the
+// 96-byte column record: ~80 vector-memory instructions per wave and — measured
+// with rocprofv3 — about half of the kernel time queueing on the same in-flight
+// cache lines (profiles/r01_s2_pmc_before_lds_staging.txt).
+// ---------------------------------------------------------------------------
+template <int V, int R, bool SHARDED>
+__global__ void __launch_bounds__(FCP_BLOCK_THREADS) fcp_dense_kernel(const FcpLaunch L) {
+  constexpr int RB = FCP_WAVES_PER_BLOCK * R; // rows per block
+  constexpr int IDS = RB + 1;                 // padded row of the offset tile (LDS banks)
+  constexpr int BND = 1024;                   // floats of bucketize boundaries staged per block
+  __shared__ LdsCol s_col[FCP_WAVE];
+  __shared__ uint32_t s_off[FCP_WAVE * IDS];
+  __shared__ float s_bnd[BND];
+
+  BlockPos B;
+  if (!locate_block<RB>(L, B)) return;
   const int tid = threadIdx.x;
   const int lane = tid & (FCP_WAVE - 1);
   const int wave = tid >> 6;
-  const int q = q0 + lane;
-  const int qc = min(q, nslots - 1);
-  const uint32_t my_col = map[qc];
-  const uint32_t first_col = map[q0];
-  const int ncols = (int)(map[min(q0 + FCP_WAVE - 1, nslots - 1)] - first_col) + 1;
+  const int q = B.q0 + lane;
+  const uint32_t my_col = B.map[min(q, B.nslots - 1)];
   const int world = L.shard_world, rank = L.shard_rank;
 
-  // ---- phase 0: column records -> LDS -------------------------------------------
-  if (tid < ncols) s_col[tid] = make_lds_col(L, L.cols[first_col + tid], L.dyn[first_col + tid]);
+  // ---- phase 0 ----------------------------------------------------------------------
+  if (tid < B.ncols) s_col[tid] = make_lds_col(L, L.cols[B.first_col + tid], L.dyn[B.first_col + tid]);
   __syncthreads();
 
-  // ---- phase 0b: bucketize boundaries -> LDS (cuda_emitter.cc:1818-1825 stages
-  // them per block too).  Wave 0 assigns LDS offsets with a shuffle prefix sum;
-  // then all threads copy.  Columns that do not fit keep searching in L2.
+  // ---- phase 0b -----------------------------------------------------------------------
   if (wave == 0) {
     int nb = 0;
-    if (lane < ncols && FCP_F_IDSRC(s_col[lane].flags) == FCP_IDS_F32_BUCKETIZE &&
+    if (lane < B.ncols && FCP_F_IDSRC(s_col[lane].flags) == FCP_IDS_F32_BUCKETIZE &&
         FCP_F_FORM(s_col[lane].flags) != FCP_FORM_PASSTHROUGH)
       nb = s_col[lane].n_boundaries;
     int incl = nb;
@@ -289,290 +291,270 @@ __global__ void __launch_bounds__(FCP_BLOCK_THREADS) fcp_dense_kernel(const FcpL
     if (nb > 0 && incl <= BND) s_col[lane].bnd_off = incl - nb;
   }
   __syncthreads();
-  for (int j = 0; j < ncols; ++j) {
+  for (int j = 0; j < B.ncols; ++j) {
     const int off = s_col[j].bnd_off;
     if (off < 0) continue;
-    const float *__restrict__ src = s_col[j].boundaries;
+    const FCP_GLOBAL float *src = as_global(s_col[j].boundaries);
     for (int i = tid; i < s_col[j].n_boundaries; i += FCP_BLOCK_THREADS) s_bnd[off + i] = src[i];
   }
   __syncthreads();
 
-  // ---- phase 1: (column, row) pairs -> final row numbers in LDS -------------------
-  for (int p = tid; p < ncols * RB; p += FCP_BLOCK_THREADS) {
+  // ---- phase 1: (column, row) pairs -> table slot offsets in LDS ------------------------
+  for (int p = tid; p < B.ncols * RB; p += FCP_BLOCK_THREADS) {
     const int j = p / RB, r = p % RB;
-    const int b = row_blk + r;
-    int64_t id = -1;
-    if (b < rows) {
-      const unsigned flags = s_col[j].flags;
-      if (FCP_F_FORM(flags) == FCP_FORM_PASSTHROUGH) {
-        id = rank == 0 ? b : -1; // table-free columns belong to shard rank 0
+    const int b = B.row_blk + r;
+    uint32_t off = kNoRow;
+    if (b < B.rows) {
+      if (FCP_F_FORM(s_col[j].flags) == FCP_FORM_PASSTHROUGH) {
+        // a tensor of the blob copied into its concat slot; table-free columns
+        // belong to shard rank 0
+        if (rank == 0) off = (uint32_t)b * (uint32_t)(s_col[j].dim / V);
       } else {
         bool bad;
         const int boff = s_col[j].bnd_off;
-        id = fetch_row_number(s_col[j], b, boff >= 0 ? s_bnd + boff : nullptr, rank, world, bad);
+        off = fetch_slot_offset<V, SHARDED>(s_col[j], b, boff >= 0 ? s_bnd + boff : nullptr, rank, world, bad);
         if (bad && L.bad_ids) atomicAdd(L.bad_ids, 1ull);
       }
     }
-    s_id[j * IDS + r] = (int32_t)id;
+    s_off[j * IDS + r] = off;
   }
   __syncthreads();
-  if (q >= nslots) return;
+  if (q >= B.nslots) return;
 
-  // ---- phase 2: R table reads in flight per lane, then R coalesced stores -----------
-  const int j = (int)(my_col - first_col);
-  const float *table = s_col[j].table;
-  const int dim = s_col[j].dim;
+  // ---- phase 2: R table reads in flight per lane, then R coalesced stores -------------------
+  const int j = (int)(my_col - B.first_col);
   const int e = q * V - s_col[j].out_off;
+  const float *tb = s_col[j].table + e;
   const int64_t ostride = s_col[j].out_stride;
   float *outp = reinterpret_cast<float *>(L.arena + s_col[j].out_base) + e;
   const int r0 = wave * R;
-  int64_t id[R];
+  uint32_t off[R];
 #pragma unroll
-  for (int r = 0; r < R; ++r) id[r] = s_id[j * IDS + r0 + r];
+  for (int r = 0; r < R; ++r) off[r] = s_off[j * IDS + r0 + r];
 #if defined(FCP_ABLATE) && FCP_ABLATE == 3 // timing-only build: sequential instead of random rows
 #pragma unroll
-  for (int r = 0; r < R; ++r) id[r] = ((int64_t)(row_blk + r0 + r) * 131 + my_col * 977) % s_col[j].vocab;
+  for (int r = 0; r < R; ++r)
+    off[r] = (uint32_t)((((int64_t)(B.row_blk + r0 + r) * 131 + my_col * 977) % s_col[j].vocab) * (s_col[j].dim / V));
 #endif
   VF<V> v[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     v[r] = vzero<V>();
 #if !(defined(FCP_ABLATE) && FCP_ABLATE == 1) // timing-only build 1: no table reads
-    if (id[r] >= 0) v[r] = ld_table<V>(table + id[r] * (int64_t)dim + e);
+    if (off[r] != kNoRow) v[r] = ld_slot<V>(tb, off[r]);
 #else
-    v[r].v[0] = (float)id[r];
+    v[r].v[0] = (float)off[r];
 #endif
   }
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    const int b = row_blk + r0 + r;
+    const int b = B.row_blk + r0 + r;
 #if defined(FCP_ABLATE) && FCP_ABLATE == 2 // timing-only build 2: no output stores
     asm volatile("" ::"v"(v[r].v[0]), "v"(v[r].v[V - 1]));
-    if (b < rows && v[r].v[0] == 1234.5f) st_out<V>(outp + (int64_t)b * ostride, v[r]);
+    if (b < B.rows && v[r].v[0] == 1234.5f) st_out<V>(outp + (int64_t)b * ostride, v[r]);
 #else
-    if (b < rows) st_out<V>(outp + (int64_t)b * ostride, v[r]);
+    if (b < B.rows) st_out<V>(outp + (int64_t)b * ostride, v[r]);
 #endif
   }
 }
-
 
 // ---------------------------------------------------------------------------
 // Ragged kernel: any mix of column forms (dynamic shapes: multi-hot bags of
 // variable length, scatter columns, passthrough, Sum(axis=1)).
 //
-// Same block shape as the dense kernel with R = 1 or 2 output rows per wave.
+// Same block shape as the dense kernel, one output row per wave (RB = 4).
 //   phase 0  column records -> LDS;
 //   phase 1  one thread per (column, row) pair reads the pair's CSR range
 //            [lo, lo+cnt) — the LDS-staged row-offset buffer — and a block-wide
 //            scan of the counts (wave shuffle scan + per-wave totals) assigns
-//            every bag a slice of the LDS id tile; then one thread per *id*
-//            (its bag found by binary search over the scanned offsets) fetches
-//            it and stores the final local row number (Bucketize, range check,
-//            row shard: once per id instead of once per lane, all ids of the
-//            block in one memory round trip);
-//   phase 2  every lane walks its bag in LDS: 8 row numbers -> 8 independent
-//            16-byte table reads in flight -> 8 adds in id order (sequential
-//            fp32 order: deterministic, equal to TF-CPU's and the oracle's),
-//            divides for mean (sum / count, cuda_emitter.cc:625, :903), and the
-//            wave stores 1 KiB contiguous of the concat row.
+//            every bag a slice of the LDS offset tile; then one thread per *id*
+//            (its bag looked up in an LDS owner table the bags fill) fetches it
+//            and stores the table slot offset (Bucketize, range check, row shard:
+//            once per id instead of once per lane, all ids of the block in one
+//            memory round trip);
+//   phase 2  every lane walks its bag in LDS: 8 (then 4) slot offsets -> as many
+//            independent 16-byte table reads in flight -> adds in id order
+//            (sequential fp32 order: deterministic, equal to TF-CPU's and the
+//            oracle's), divides for mean (sum / count, cuda_emitter.cc:625,
+//            :903); the wave stores 1 KiB contiguous of the concat row.
 // Bags longer than 64 ids, or bags that do not fit the 1536-entry tile, are
 // walked from global memory by the lanes themselves (same arithmetic order).
+// The kernel is instruction-issue bound rather than HBM bound (rocprofv3: ~490
+// VALU per wave before this layout), hence the pre-scaled 32-bit slot offsets:
+// a table read costs one LDS read, one compare, one 64-bit shift-add, one load.
 // ---------------------------------------------------------------------------
-template <int V, int R>
+template <int V, bool SHARDED>
 __global__ void __launch_bounds__(FCP_BLOCK_THREADS) fcp_ragged_kernel(const FcpLaunch L) {
-  constexpr int RB = FCP_WAVES_PER_BLOCK * R; // rows per block, R per wave
-  constexpr int NP = FCP_WAVE * RB;           // (column, row) pairs per block, at most
-  constexpr int PT = NP / FCP_BLOCK_THREADS;  // pairs per thread (= R)
-  constexpr int CAP = 1536;                   // staged row numbers per block
+  constexpr int RB = FCP_WAVES_PER_BLOCK; // rows per block, one per wave
+  constexpr int NP = FCP_WAVE * RB;       // (column, row) pairs per block, at most (= 256 threads)
+  constexpr int CAP = 1536;               // staged slot offsets per block
   constexpr int LONG_BAG = 64;
   __shared__ LdsCol s_col[FCP_WAVE];
   __shared__ int32_t s_lo[NP], s_cnt[NP];
-  __shared__ int32_t s_offx[NP + 1];          // exclusive scan of the staged counts
-  __shared__ int32_t s_ids[CAP];
-  __shared__ int32_t s_wsum[PT * FCP_WAVES_PER_BLOCK];
+  __shared__ int32_t s_offx[NP];          // exclusive scan of the staged counts
+  __shared__ uint32_t s_ids[CAP];
+  __shared__ uint16_t s_owner[CAP];       // staged id slot -> its (column, row) pair
+  __shared__ int32_t s_wsum[FCP_WAVES_PER_BLOCK];
 
-  int bid = blockIdx.x;
-  int g = 0;
-  for (int k = 1; k < L.n_groups; ++k)
-    if (bid >= L.groups[k].block_begin) g = k;
-  const int rows = L.groups[g].rows;
-  const int nslots = L.groups[g].nslots;
-  const int nsp8 = L.groups[g].nsp8;
-  const uint32_t *__restrict__ map = L.slot_map + L.groups[g].slot_map_off;
-  bid -= L.groups[g].block_begin;
-  const int xcd = bid & 7, j8 = bid >> 3;
-  const int span = (j8 % nsp8) * 8 + xcd;
-  const int tile = j8 / nsp8;
-  const int q0 = span * FCP_WAVE;
-  const int row_blk = tile * RB;
-  if (q0 >= nslots || row_blk >= rows) return;
-
+  BlockPos B;
+  if (!locate_block<RB>(L, B)) return;
   const int tid = threadIdx.x;
   const int lane = tid & (FCP_WAVE - 1);
   const int wave = tid >> 6;
-  const int q = q0 + lane;
-  const uint32_t my_col = map[min(q, nslots - 1)];
-  const uint32_t first_col = map[q0];
-  const int ncols = (int)(map[min(q0 + FCP_WAVE - 1, nslots - 1)] - first_col) + 1;
-  const int npairs = ncols * RB;
+  const int q = B.q0 + lane;
+  const uint32_t my_col = B.map[min(q, B.nslots - 1)];
   const int world = L.shard_world, rank = L.shard_rank;
 
-  // ---- phase 0: column records -> LDS --------------------------------------------
-  if (tid < ncols) s_col[tid] = make_lds_col(L, L.cols[first_col + tid], L.dyn[first_col + tid]);
+  // ---- phase 0 ----------------------------------------------------------------------
+  if (tid < B.ncols) s_col[tid] = make_lds_col(L, L.cols[B.first_col + tid], L.dyn[B.first_col + tid]);
   __syncthreads();
 
-  // ---- phase 1a: row ranges of the block's (column, row) pairs + scan -------------
-  int want[PT];
-#pragma unroll
-  for (int h = 0; h < PT; ++h) {
-    const int p = h * FCP_BLOCK_THREADS + tid;
-    int lo = 0, cnt = 0;
-    if (p < npairs) {
-      const int pj = p / RB, pr = p % RB;
-      const int b = row_blk + pr;
-      if (b < rows) {
-        const unsigned form = FCP_F_FORM(s_col[pj].flags);
-        if (form == FCP_FORM_GATHER) {
-          lo = b;
+  // ---- phase 1a: row ranges of the block's (column, row) pairs + scan ----------------
+  int lo = 0, cnt = 0;
+  if (tid < B.ncols * RB) {
+    const int pj = tid / RB, pr = tid % RB;
+    const int b = B.row_blk + pr;
+    if (b < B.rows) {
+      const unsigned form = FCP_F_FORM(s_col[pj].flags);
+      if (form == FCP_FORM_GATHER) {
+        lo = b;
+        cnt = 1;
+      } else if (form == FCP_FORM_SEGMENT_REDUCE || form == FCP_FORM_GATHER_SCATTER) {
+        const int nnz = s_col[pj].nnz;
+        const FCP_GLOBAL int32_t *csr = as_global(s_col[pj].csr);
+        lo = min(max(csr[b], 0), nnz);
+        const int hi = min(max(csr[b + 1], lo), nnz);
+        cnt = hi - lo;
+        if (form == FCP_FORM_GATHER_SCATTER && cnt > 0) { // the last id of the row wins
+          lo = hi - 1;
           cnt = 1;
-        } else if (form == FCP_FORM_SEGMENT_REDUCE || form == FCP_FORM_GATHER_SCATTER) {
-          const int nnz = s_col[pj].nnz;
-          const int32_t *__restrict__ csr = s_col[pj].csr;
-          lo = min(max(csr[b], 0), nnz);
-          const int hi = min(max(csr[b + 1], lo), nnz);
-          cnt = hi - lo;
-          if (form == FCP_FORM_GATHER_SCATTER && cnt > 0) { // the last id of the row wins
-            lo = hi - 1;
-            cnt = 1;
-          }
         }
       }
-      s_lo[p] = lo;
-      s_cnt[p] = cnt;
     }
-    want[h] = cnt <= LONG_BAG ? cnt : 0;
   }
-  int incl[PT];
+  s_lo[tid] = lo;
+  s_cnt[tid] = cnt;
+  const int want = cnt <= LONG_BAG ? cnt : 0;
+  int incl = want;
 #pragma unroll
-  for (int h = 0; h < PT; ++h) {
-    incl[h] = want[h];
-#pragma unroll
-    for (int d = 1; d < FCP_WAVE; d <<= 1) {
-      const int up = __shfl_up(incl[h], d);
-      if (lane >= d) incl[h] += up;
-    }
-    if (lane == FCP_WAVE - 1) s_wsum[h * FCP_WAVES_PER_BLOCK + wave] = incl[h];
+  for (int d = 1; d < FCP_WAVE; d <<= 1) {
+    const int up = __shfl_up(incl, d);
+    if (lane >= d) incl += up;
   }
+  if (lane == FCP_WAVE - 1) s_wsum[wave] = incl;
   __syncthreads();
-  int total = 0;
+  int offx = incl - want, total = 0;
 #pragma unroll
-  for (int h = 0; h < PT; ++h) {
-    int base = 0;
-    for (int w = 0; w < h * FCP_WAVES_PER_BLOCK + wave; ++w) base += s_wsum[w];
-    s_offx[h * FCP_BLOCK_THREADS + tid] = base + incl[h] - want[h];
+  for (int w = 0; w < FCP_WAVES_PER_BLOCK; ++w) {
+    if (w < wave) offx += s_wsum[w];
+    total += s_wsum[w];
   }
-  for (int w = 0; w < PT * FCP_WAVES_PER_BLOCK; ++w) total += s_wsum[w];
-  if (tid == 0) s_offx[NP] = total;
+  const bool staged = want > 0 && offx + want <= CAP;
+  s_offx[tid] = staged ? offx : -1;
+  if (staged)
+    for (int i = 0; i < want; ++i) s_owner[offx + i] = (uint16_t)tid; // fire-and-forget LDS writes
   __syncthreads();
 
-  // ---- phase 1b: one thread per staged id -> final row number in LDS -----------------
-  // (ids that do not fit the tile are walked from global memory in phase 2)
+  // ---- phase 1b: one thread per staged id -> table slot offset in LDS ------------------
   for (int k = tid; k < min(total, CAP); k += FCP_BLOCK_THREADS) {
-    int lo_p = 0, hi_p = NP; // last pair with s_offx[p] <= k
-    while (hi_p - lo_p > 1) {
-      const int mid = (lo_p + hi_p) >> 1;
-      if (s_offx[mid] <= k) lo_p = mid; else hi_p = mid;
-    }
-    const int p = lo_p;
-    if (s_offx[p] + s_cnt[p] <= CAP) {
+    const int p = s_owner[k];
+    const int px = p < NP ? s_offx[p] : -1;
+    if (px >= 0 && px <= k && k < px + s_cnt[p]) { // stale owner entries (unstaged bags) fail this test
       bool bad;
-      const int64_t id = fetch_row_number(s_col[p / RB], s_lo[p] + (k - s_offx[p]), nullptr, rank, world, bad);
+      s_ids[k] = fetch_slot_offset<V, SHARDED>(s_col[p / RB], s_lo[p] + (k - px), nullptr, rank, world, bad);
       if (bad && L.bad_ids) atomicAdd(L.bad_ids, 1ull);
-      s_ids[k] = (int32_t)id;
     }
   }
   __syncthreads();
-  if (q >= nslots) return;
+  const int b = B.row_blk + wave;
+  if (q >= B.nslots || b >= B.rows) return;
 
-  // ---- phase 2 --------------------------------------------------------------------
-  const int j = (int)(my_col - first_col);
+  // ---- phase 2 ------------------------------------------------------------------------
+  const int j = (int)(my_col - B.first_col);
   const LdsCol &C = s_col[j];
   const unsigned form = FCP_F_FORM(C.flags);
-  const float *table = C.table;
   const int dim = C.dim;
   const int e = q * V - C.out_off;
-  const bool mean = FCP_F_COMBINER(C.flags) == FCP_COMBINER_MEAN && world == 1;
+  const float *tb = C.table + e;
+  const int p = j * RB + wave;
+  const int plo = s_lo[p], pcnt = s_cnt[p], poff = s_offx[p];
+  VF<V> acc = vzero<V>();
 
-  for (int r = 0; r < R; ++r) {
-    const int b = row_blk + wave * R + r;
-    if (b >= rows) break;
-    float *outp = reinterpret_cast<float *>(L.arena + C.out_base) + e + (int64_t)b * C.out_stride;
-    const int p = j * RB + wave * R + r;
-    const int plo = s_lo[p], pcnt = s_cnt[p];
-    const int poff = (pcnt <= LONG_BAG && s_offx[p] + pcnt <= CAP) ? s_offx[p] : -1;
-    VF<V> acc = vzero<V>();
-
-    if (form == FCP_FORM_PASSTHROUGH) {
-      if (rank == 0) acc = ld_blob_f32<V>(C.ids + 4 * ((int64_t)b * dim + e)); // table-free: shard rank 0
-    } else if (form == FCP_FORM_BATCH_COL_REDUCTION) {
-      // cuda_emitter.cc:1231-1236: r ascending, sequential fp32 adds
-      const int inner = rank == 0 ? C.inner : 0;
-      for (int rr = 0; rr < inner; ++rr) {
-        const VF<V> x = ld_blob_f32<V>(C.ids + 4 * (((int64_t)b * inner + rr) * dim + e));
+  if (form == FCP_FORM_PASSTHROUGH) {
+    if (rank == 0) acc = ld_blob_f32<V>(C.ids + 4 * ((int64_t)b * dim + e)); // table-free: shard rank 0
+  } else if (form == FCP_FORM_BATCH_COL_REDUCTION) {
+    // cuda_emitter.cc:1231-1236: r ascending, sequential fp32 adds
+    const int inner = rank == 0 ? C.inner : 0;
+    for (int rr = 0; rr < inner; ++rr) {
+      const VF<V> x = ld_blob_f32<V>(C.ids + 4 * (((int64_t)b * inner + rr) * dim + e));
 #pragma unroll
-        for (int t = 0; t < V; ++t) acc.v[t] = acc.v[t] + x.v[t];
-      }
-    } else if (form != FCP_FORM_SEGMENT_REDUCE) {
-      // GATHER / GATHER_SCATTER: a pure copy of one row (rows without ids stay zero)
-      if (pcnt > 0) {
-        int64_t id;
-        if (poff >= 0) {
-          id = s_ids[poff];
+      for (int t = 0; t < V; ++t) acc.v[t] = acc.v[t] + x.v[t];
+    }
+  } else if (poff < 0) {
+    // slow path (long or unstaged bags): one id at a time from global memory
+#pragma unroll 1
+    for (int i = 0; i < pcnt; ++i) {
+      bool bad;
+      const uint32_t off = fetch_slot_offset<V, SHARDED>(C, plo + i, nullptr, rank, world, bad);
+      if (bad && e == 0 && L.bad_ids) atomicAdd(L.bad_ids, 1ull);
+      if (off != kNoRow) {
+        const VF<V> w = ld_slot<V>(tb, off);
+        if (form == FCP_FORM_SEGMENT_REDUCE) {
+#pragma unroll
+          for (int t = 0; t < V; ++t) acc.v[t] = acc.v[t] + w.v[t];
         } else {
-          bool bad;
-          id = fetch_row_number(C, plo, nullptr, rank, world, bad);
-          if (bad && e == 0 && L.bad_ids) atomicAdd(L.bad_ids, 1ull);
+          acc = w;
         }
-        if (id >= 0) acc = ld_table<V>(table + id * (int64_t)dim + e);
-      }
-    } else {
-      for (int i = 0; i < pcnt; i += 8) {
-        int64_t id[8];
-        if (poff >= 0) {
-#pragma unroll
-          for (int k = 0; k < 8; ++k) id[k] = (i + k < pcnt) ? (int64_t)s_ids[poff + i + k] : -1;
-        } else {
-#pragma unroll
-          for (int k = 0; k < 8; ++k) {
-            id[k] = -1;
-            if (i + k < pcnt) {
-              bool bad;
-              id[k] = fetch_row_number(C, plo + i + k, nullptr, rank, world, bad);
-              if (bad && e == 0 && L.bad_ids) atomicAdd(L.bad_ids, 1ull);
-            }
-          }
-        }
-        VF<V> w[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          w[k] = vzero<V>();
-          if (id[k] >= 0) w[k] = ld_table<V>(table + id[k] * (int64_t)dim + e);
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k)
-          if (id[k] >= 0) {
-#pragma unroll
-            for (int t = 0; t < V; ++t) acc.v[t] = acc.v[t] + w[k].v[t];
-          }
-      }
-      if (mean && pcnt > 0) {
-        const float fc = (float)pcnt; // sum / count
-#pragma unroll
-        for (int t = 0; t < V; ++t) acc.v[t] = acc.v[t] / fc;
       }
     }
-    st_out<V>(outp, acc);
+  } else if (form != FCP_FORM_SEGMENT_REDUCE) {
+    // GATHER / GATHER_SCATTER: a pure copy of one row (rows without ids stay zero)
+    if (pcnt > 0) {
+      const uint32_t off = s_ids[poff];
+      if (off != kNoRow) acc = ld_slot<V>(tb, off);
+    }
+  } else {
+    // Adding the zero vector of a skipped id is exact (acc is never -0.0: it
+    // starts at +0.0), so the adds need no predicate.
+    int i = 0;
+    while (pcnt - i > 4) {
+      uint32_t off[8];
+      VF<V> w[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) off[k] = (i + k < pcnt) ? s_ids[poff + i + k] : kNoRow;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        w[k] = vzero<V>();
+        if (off[k] != kNoRow) w[k] = ld_slot<V>(tb, off[k]);
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+#pragma unroll
+        for (int t = 0; t < V; ++t) acc.v[t] = acc.v[t] + w[k].v[t]; // id order
+      i += 8;
+    }
+    if (pcnt - i > 0) {
+      uint32_t off[4];
+      VF<V> w[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) off[k] = (i + k < pcnt) ? s_ids[poff + i + k] : kNoRow;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        w[k] = vzero<V>();
+        if (off[k] != kNoRow) w[k] = ld_slot<V>(tb, off[k]);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int t = 0; t < V; ++t) acc.v[t] = acc.v[t] + w[k].v[t];
+    }
   }
+  if (form == FCP_FORM_SEGMENT_REDUCE && !SHARDED && FCP_F_COMBINER(C.flags) == FCP_COMBINER_MEAN && pcnt > 0) {
+    const float fc = (float)pcnt; // sum / count
+#pragma unroll
+    for (int t = 0; t < V; ++t) acc.v[t] = acc.v[t] / fc;
+  }
+  st_out<V>(reinterpret_cast<float *>(L.arena + C.out_base) + e + (int64_t)b * C.out_stride, acc);
 }
 
 // ---------------------------------------------------------------------------
@@ -711,23 +693,28 @@ __global__ void __launch_bounds__(FCP_BLOCK_THREADS) fcp_upload_kernel(const uin
 
 // ------------------------------- launchers ---------------------------------
 
-#define FCP_LAUNCH_DENSE(VV, RR) \
-  hipLaunchKernelGGL((fcp_dense_kernel<VV, RR>), dim3(grid_blocks), dim3(FCP_BLOCK_THREADS), 0, s, L)
-#define FCP_LAUNCH_GENERIC(VV)                                                                          \
-  do {                                                                                                  \
-    if (L.rows_per_wave >= 2)                                                                           \
-      hipLaunchKernelGGL((fcp_ragged_kernel<VV, 2>), dim3(grid_blocks), dim3(FCP_BLOCK_THREADS), 0, s, L); \
-    else                                                                                                \
-      hipLaunchKernelGGL((fcp_ragged_kernel<VV, 1>), dim3(grid_blocks), dim3(FCP_BLOCK_THREADS), 0, s, L); \
+#define FCP_LAUNCH_DENSE(VV, RR)                                                                            \
+  do {                                                                                                      \
+    if (L.shard_world > 1)                                                                                  \
+      hipLaunchKernelGGL((fcp_dense_kernel<VV, RR, true>), dim3(grid_blocks), dim3(FCP_BLOCK_THREADS), 0, s, L); \
+    else                                                                                                    \
+      hipLaunchKernelGGL((fcp_dense_kernel<VV, RR, false>), dim3(grid_blocks), dim3(FCP_BLOCK_THREADS), 0, s, L); \
+  } while (0)
+#define FCP_LAUNCH_RAGGED(VV)                                                                               \
+  do {                                                                                                      \
+    if (L.shard_world > 1)                                                                                  \
+      hipLaunchKernelGGL((fcp_ragged_kernel<VV, true>), dim3(grid_blocks), dim3(FCP_BLOCK_THREADS), 0, s, L); \
+    else                                                                                                    \
+      hipLaunchKernelGGL((fcp_ragged_kernel<VV, false>), dim3(grid_blocks), dim3(FCP_BLOCK_THREADS), 0, s, L); \
   } while (0)
 
+// rows_per_wave: dense 1 | 2 | 4 (rows per block = 4 x that); ragged always 1.
 int fcp_launch_fused(const FcpLaunch &L, int vec, bool dense_only, int grid_blocks, ihipStream_t *s) {
   if (grid_blocks <= 0) return 0;
   if (dense_only) {
     const int R = L.rows_per_wave;
 #define FCP_DENSE_R(VV)                         \
   switch (R) {                                  \
-  case 8: FCP_LAUNCH_DENSE(VV, 8); break;       \
   case 4: FCP_LAUNCH_DENSE(VV, 4); break;       \
   case 2: FCP_LAUNCH_DENSE(VV, 2); break;       \
   default: FCP_LAUNCH_DENSE(VV, 1); break;      \
@@ -742,11 +729,11 @@ int fcp_launch_fused(const FcpLaunch &L, int vec, bool dense_only, int grid_bloc
 #undef FCP_DENSE_R
   } else {
     if (vec == 4) {
-      FCP_LAUNCH_GENERIC(4);
+      FCP_LAUNCH_RAGGED(4);
     } else if (vec == 2) {
-      FCP_LAUNCH_GENERIC(2);
+      FCP_LAUNCH_RAGGED(2);
     } else {
-      FCP_LAUNCH_GENERIC(1);
+      FCP_LAUNCH_RAGGED(1);
     }
   }
   return (int)hipGetLastError();
