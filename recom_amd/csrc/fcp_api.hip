@@ -76,12 +76,14 @@ struct DynMeta {
 struct DynSlot {
   bool valid = false;
   std::vector<int32_t> key;
-  FcpColDyn *h_dyn = nullptr; // pinned, mapped
+  FcpColDyn *h_dyn = nullptr; // pinned, mapped (host copy; source of the upload-kernel path)
   void *h_dyn_dev = nullptr;  // device-side address of h_dyn
-  FcpColDyn *d_dyn = nullptr;
-  hipEvent_t uploaded = nullptr;
-  void *stream = nullptr; // the only stream that has used this slot, unless multi
-  bool multi = false;
+  FcpColDyn *d_dyn = nullptr; // what the kernels read
+  hipEvent_t uploaded = nullptr; // upload-kernel path: recorded after the upload
+  hipEvent_t done = nullptr;     // recorded after the first kernel that used this content
+  bool need_done = false;        // the next kernel launch on this slot must record `done`
+  bool done_valid = false;       // `done` covers every kernel that has used this content so far
+  void *stream = nullptr;        // stream of the request that installed this content
   uint64_t tick = 0;
   DynMeta meta;
 };
@@ -112,6 +114,13 @@ struct fcp_plan {
   std::vector<const void *> bound_tables;
   bool tables_bound = false;
 
+  // How new shape-dependent descriptors reach the device (dynamic shapes: every
+  // request).  With a large PCIe BAR the descriptor ring lives in fine-grained
+  // device memory and the HOST writes it directly (posted writes, ~0.3 us for 24 KiB,
+  // nothing on the GPU's critical path); otherwise a small kernel on the request's
+  // stream copies it from pinned host memory.  FCP_DYN_UPLOAD=kernel forces the latter.
+  bool host_writes_dyn = false;
+  hipEvent_t fence = nullptr;
   std::mutex mu;
   DynSlot slots[kSlots];
   uint64_t tick = 0;
@@ -217,29 +226,31 @@ int compute_dyn(const fcp_plan *p, const int32_t *offsets, const int32_t *shapes
                 const int32_t *symbols, int64_t blob_bytes, FcpColDyn *dyn, DynMeta *m) {
   const int nc = (int)p->cols.size();
   const int ng = p->desc.n_groups;
-  auto numel = [&](int i) -> int64_t {
+  const int nh = (int)p->ranks.size();
+  // element counts of all host inputs, one pass (this function is on the request
+  // path whenever shapes change: no allocation, no string building unless it fails)
+  thread_local std::vector<int64_t> numel_v, col_rows;
+  numel_v.resize(nh);
+  col_rows.resize(nc);
+  for (int i = 0; i < nh; ++i) {
     int64_t n = 1;
+    const int32_t *d = shapes + p->shape_off[i];
     for (int j = 0; j < p->ranks[i]; ++j) {
-      const int32_t d = shapes[p->shape_off[i] + j];
-      if (d < 0) return -1;
-      n *= d;
+      if (d[j] < 0) return fail(FCP_ERR_SHAPE_MISMATCH, "negative dimension in concated_shapes");
+      n *= d[j];
     }
-    return n;
-  };
-  for (int i = 0; i < (int)p->ranks.size(); ++i) {
-    const int64_t n = numel(i);
-    if (n < 0) return fail(FCP_ERR_SHAPE_MISMATCH, "negative dimension in concated_shapes");
+    numel_v[i] = n;
     if (offsets[i] < 0) return fail(FCP_ERR_SHAPE_MISMATCH, "negative blob offset (int32 overflow?)");
     if (blob_bytes >= 0 && (int64_t)offsets[i] + n * p->elem_sizes[i] > blob_bytes)
       return fail(FCP_ERR_SHAPE_MISMATCH, "host input " + std::to_string(i) + " exceeds the blob");
   }
+  const int64_t *numel = numel_v.data();
   m->group_rows.assign(ng, -1);
-  std::vector<int64_t> col_rows(nc);
   for (int k = 0; k < nc; ++k) {
     const fcp_column_desc_t &c = p->cols[k].d;
     int64_t rows;
     if (c.rows_source == FCP_ROWS_FROM_IDS) {
-      rows = numel(c.ids_input);
+      rows = numel[c.ids_input];
     } else if (c.rows_source == FCP_ROWS_FROM_SYMBOL) {
       if (!symbols) return fail(FCP_ERR_INVALID_ARGUMENT, "plan needs the symbols tensor");
       rows = symbols[c.rows_arg];
@@ -271,12 +282,13 @@ int compute_dyn(const fcp_plan *p, const int32_t *offsets, const int32_t *shapes
     const HostColumn &hc = p->cols[k];
     const fcp_column_desc_t &c = hc.d;
     FcpColDyn &d = dyn[p->pos_of[k]];
-    std::memset(&d, 0, sizeof(d));
+    d.seg_off = 0;
+    d.pad_ = 0;
     const int64_t rows = col_rows[k];
     d.rows = (int32_t)rows;
     d.ids_off = offsets[c.ids_input];
     if (d.ids_off % 4) return fail(FCP_ERR_UNSUPPORTED, "blob tensor not 4-byte aligned");
-    const int64_t n_ids = numel(c.ids_input);
+    const int64_t n_ids = numel[c.ids_input];
     d.csr_base = -1;
     d.inner = 1;
     if (c.form == FCP_FORM_PASSTHROUGH) {
@@ -296,7 +308,7 @@ int compute_dyn(const fcp_plan *p, const int32_t *offsets, const int32_t *shapes
       if (c.form != FCP_FORM_GATHER) {
         d.seg_off = offsets[c.seg_input];
         if (d.seg_off % 4) return fail(FCP_ERR_UNSUPPORTED, "blob tensor not 4-byte aligned");
-        const int64_t n_seg = numel(c.seg_input);
+        const int64_t n_seg = numel[c.seg_input];
         if (c.seg_kind == FCP_SEG_CSR_I32) {
           if (n_seg != rows + 1) return fail(FCP_ERR_SHAPE_MISMATCH, "CSR offsets must have rows+1 entries");
         } else {
@@ -349,13 +361,15 @@ int compute_dyn(const fcp_plan *p, const int32_t *offsets, const int32_t *shapes
     G.rows = m->group_rows[g];
     G.nslots = p->group_nslots[g];
     const int nspans = (G.nslots + FCP_WAVE - 1) / FCP_WAVE;
-    G.nsp8 = (nspans + 7) / 8;
+    // spans are dealt to XCDs in groups of 8; a group with fewer than 8 spans
+    // is not padded (nsp8 = -nspans selects the plain mapping in the kernels)
+    G.nsp8 = nspans >= 8 ? (nspans + 7) / 8 : -nspans;
     G.block_begin = blocks;
     G.slot_map_off = p->group_map_off[g];
     G.pad_ = 0;
     const int rows_per_block = FCP_WAVES_PER_BLOCK * rpw;
     const int64_t ntiles = ((int64_t)G.rows + rows_per_block - 1) / rows_per_block;
-    const int64_t nb = 8ll * G.nsp8 * ntiles;
+    const int64_t nb = (G.nsp8 > 0 ? 8ll * G.nsp8 : (int64_t)nspans) * ntiles;
     if (blocks + nb > 0x7fffffff) return fail(FCP_ERR_UNSUPPORTED, "grid too large");
     blocks += (int32_t)nb;
   }
@@ -369,7 +383,9 @@ void destroy_device(fcp_plan *p) {
     if (s.h_dyn) (void)hipHostFree(s.h_dyn);
     if (s.d_dyn) (void)hipFree(s.d_dyn);
     if (s.uploaded) (void)hipEventDestroy(s.uploaded);
+    if (s.done) (void)hipEventDestroy(s.done);
   }
+  if (p->fence) (void)hipEventDestroy(p->fence);
   if (p->d_slot_map) (void)hipFree(p->d_slot_map);
   if (p->d_cols) (void)hipFree(p->d_cols);
   if (p->d_const) (void)hipFree(p->d_const);
@@ -435,14 +451,36 @@ int init_device(fcp_plan *p) {
     HIP_TRY(hipMalloc(&p->d_bad, sizeof(unsigned long long)));
     HIP_TRY(hipMemset(p->d_bad, 0, sizeof(unsigned long long)));
   }
+  {
+    int large_bar = 0;
+    (void)hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, p->desc.device);
+    const char *mode = std::getenv("FCP_DYN_UPLOAD");
+    p->host_writes_dyn = large_bar != 0 && !(mode && std::string(mode) == "kernel");
+  }
   for (auto &s : p->slots) {
     // rounded up to 16 bytes: the upload kernel moves uint4s
     const size_t dyn_bytes = (nc * sizeof(FcpColDyn) + 15) / 16 * 16;
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&s.h_dyn), dyn_bytes, hipHostMallocMapped));
     HIP_TRY(hipHostGetDevicePointer(&s.h_dyn_dev, s.h_dyn, 0));
-    HIP_TRY(hipMalloc(&s.d_dyn, dyn_bytes));
-    HIP_TRY(hipEventCreateWithFlags(&s.uploaded, hipEventDisableTiming));
+    if (p->host_writes_dyn) {
+      if (hipExtMallocWithFlags(reinterpret_cast<void **>(&s.d_dyn), dyn_bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+        (void)hipGetLastError();
+        p->host_writes_dyn = false; // fall back for every slot: nothing has been used yet
+        for (auto &t : p->slots)
+          if (t.d_dyn) {
+            (void)hipFree(t.d_dyn);
+            t.d_dyn = nullptr;
+          }
+      }
+    }
   }
+  for (auto &s : p->slots) {
+    const size_t dyn_bytes = (nc * sizeof(FcpColDyn) + 15) / 16 * 16;
+    if (!s.d_dyn) HIP_TRY(hipMalloc(&s.d_dyn, dyn_bytes));
+    HIP_TRY(hipEventCreateWithFlags(&s.uploaded, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+  }
+  HIP_TRY(hipEventCreateWithFlags(&p->fence, hipEventDisableTiming));
   p->bound_tables.assign(p->desc.n_device_inputs, nullptr);
   return FCP_OK;
 }
@@ -487,10 +525,9 @@ int acquire_slot(fcp_plan *p, const fcp_process_args_t *a, DynSlot **out) {
   for (auto &s : p->slots) {
     if (s.valid && s.key == key) {
       s.tick = p->tick;
-      if (s.stream != a->stream) { // another stream: order after the upload
+      if (s.stream != a->stream && !p->host_writes_dyn) // another stream than the uploader's: order after the upload
         HIP_TRY(hipStreamWaitEvent(static_cast<hipStream_t>(a->stream), s.uploaded, 0));
-        s.multi = true;
-      }
+      if (!s.need_done) s.done_valid = false; // one more user that `done` does not cover
       *out = &s;
       return FCP_OK;
     }
@@ -501,25 +538,37 @@ int acquire_slot(fcp_plan *p, const fcp_process_args_t *a, DynSlot **out) {
     }
   }
   DynSlot &s = *victim;
+  hipStream_t stream = static_cast<hipStream_t>(a->stream);
   if (s.valid) {
-    // The pinned mirror may still be the source of an earlier async copy, and
-    // kernels of other streams may still read the device copy.
-    HIP_TRY(hipEventSynchronize(s.uploaded));
-    if (s.multi || s.stream != a->stream) HIP_TRY(hipDeviceSynchronize());
+    // Kernels of earlier requests may still read the slot (the host runs ahead of the
+    // GPU): wait for the last one.  `done` covers it unless the slot was re-used by
+    // cache hits since; then fence the caller's stream (shape-stable -> dynamic only).
+    if (!s.done_valid) {
+      HIP_TRY(hipEventRecord(p->fence, stream));
+      HIP_TRY(hipEventSynchronize(p->fence));
+      if (s.stream != a->stream) HIP_TRY(hipDeviceSynchronize());
+    } else if (hipEventQuery(s.done) != hipSuccess) {
+      HIP_TRY(hipEventSynchronize(s.done)); // back-pressure: at most kSlots requests in flight
+    }
+    if (!p->host_writes_dyn && hipEventQuery(s.uploaded) != hipSuccess) HIP_TRY(hipEventSynchronize(s.uploaded));
   }
   s.valid = false;
   int rc = compute_dyn(p, a->concated_offsets, a->concated_shapes, a->symbols, a->concated_bytes, s.h_dyn,
                        &s.meta);
   if (rc) return rc;
-  {
-    const int e = fcp_launch_upload(s.h_dyn_dev, s.d_dyn, p->cols.size() * sizeof(FcpColDyn),
-                                    static_cast<hipStream_t>(a->stream));
+  const size_t dyn_bytes = p->cols.size() * sizeof(FcpColDyn);
+  if (p->host_writes_dyn) {
+    std::memcpy(s.d_dyn, s.h_dyn, dyn_bytes); // CPU stores through the BAR into fine-grained VRAM
+    __builtin_ia32_sfence();                  // posted before the launch's doorbell write
+  } else {
+    const int e = fcp_launch_upload(s.h_dyn_dev, s.d_dyn, dyn_bytes, stream);
     if (e) return hip_fail("descriptor upload launch", (hipError_t)e);
+    HIP_TRY(hipEventRecord(s.uploaded, stream));
   }
-  HIP_TRY(hipEventRecord(s.uploaded, static_cast<hipStream_t>(a->stream)));
+  s.need_done = true;
+  s.done_valid = false;
   s.key = key;
   s.stream = a->stream;
-  s.multi = false;
   s.tick = p->tick;
   s.valid = true;
   *out = &s;
@@ -823,6 +872,11 @@ int fcp_process_feature_columns(fcp_plan_t *p, const fcp_process_args_t *a, fcp_
   }
   const int e = fcp_launch_fused(L, p->vec, p->dense_only, m.grid_blocks, stream);
   if (e) return hip_fail("fused kernel launch", (hipError_t)e);
+  if (slot->need_done) { // first kernel on freshly uploaded descriptors: lets a later upload reuse the slot precisely
+    HIP_TRY(hipEventRecord(slot->done, stream));
+    slot->need_done = false;
+    slot->done_valid = true;
+  }
 
   if (r) {
     const int nc = (int)p->cols.size();

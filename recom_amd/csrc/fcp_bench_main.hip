@@ -10,6 +10,7 @@
 //             [--warmup 50] [--threads 1] [--requests 16] [--ring 6] [--verify 1]
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -55,6 +56,8 @@ __host__ __device__ inline float hash_elem(uint32_t seed, uint64_t r, uint32_t e
   u ^= u >> 15;
   return (float)(u >> 8) * 1.1920928955078125e-07f - 1.0f; // 2^-23
 }
+
+__global__ void noop_kernel(int *p) { if (p) *p = 1; }
 
 __global__ void fill_table(float *t, uint32_t seed, uint64_t vocab, uint32_t dim) {
   const uint64_t n = vocab * dim;
@@ -111,6 +114,48 @@ int main(int argc, char **argv) {
         fcp_harness_bw_probe(kind, bytes, 20, &ms);
         std::printf("%s probe %ld MiB: %.1f GB/s  (%.2f us)\n", names[kind], v, bytes / (ms * 1e-3) / 1e9, ms * 1e3);
       }
+      return 0;
+    }
+    else if (k == "--api-probe") {
+      // host-side cost of the HIP calls on the request path (us per call)
+      hipStream_t s1, s2;
+      hipEvent_t e1, e2;
+      CHECK_HIP(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking));
+      CHECK_HIP(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+      CHECK_HIP(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
+      CHECK_HIP(hipEventCreateWithFlags(&e2, hipEventDisableTiming));
+      const int n = (int)v;
+      auto now = [] { return std::chrono::steady_clock::now(); };
+      auto us = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::micro>(now() - a).count() / n; };
+      auto t = now();
+      for (int i = 0; i < n; ++i) hipLaunchKernelGGL(noop_kernel, dim3(1), dim3(64), 0, s1, nullptr);
+      std::printf("kernel launch          %.2f us\n", us(t));
+      CHECK_HIP(hipDeviceSynchronize());
+      t = now();
+      for (int i = 0; i < n; ++i) CHECK_HIP(hipEventRecord(e1, s1));
+      std::printf("hipEventRecord         %.2f us\n", us(t));
+      CHECK_HIP(hipDeviceSynchronize());
+      t = now();
+      for (int i = 0; i < n; ++i) CHECK_HIP(hipStreamWaitEvent(s2, e1, 0));
+      std::printf("hipStreamWaitEvent     %.2f us\n", us(t));
+      CHECK_HIP(hipDeviceSynchronize());
+      t = now();
+      for (int i = 0; i < n; ++i) (void)hipEventQuery(e1);
+      std::printf("hipEventQuery          %.2f us\n", us(t));
+      t = now();
+      for (int i = 0; i < n; ++i) CHECK_HIP(hipEventSynchronize(e1));
+      std::printf("hipEventSynchronize    %.2f us\n", us(t));
+      t = now();
+      for (int i = 0; i < n; ++i) {
+        hipLaunchKernelGGL(noop_kernel, dim3(1), dim3(64), 0, s2, nullptr);
+        CHECK_HIP(hipEventRecord(e2, s2));
+        CHECK_HIP(hipStreamWaitEvent(s1, e2, 0));
+        hipLaunchKernelGGL(noop_kernel, dim3(1), dim3(64), 0, s1, nullptr);
+        CHECK_HIP(hipEventRecord(e1, s1));
+      }
+      std::printf("upload+record+wait+launch+record  %.2f us (host issue)\n", us(t));
+      CHECK_HIP(hipDeviceSynchronize());
+      std::printf("  ... including drain  %.2f us\n", us(t));
       return 0;
     }
     else if (k == "--copy-probe") {

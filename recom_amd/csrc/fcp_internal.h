@@ -53,7 +53,7 @@ struct FcpColDyn {         // 48 bytes
 struct FcpGroupLaunch {
   int32_t rows;            // prefix size of the group
   int32_t nslots;          // concat row width in V-element slots
-  int32_t nsp8;            // ceil(nspans / 8): spans per XCD
+  int32_t nsp8;            // ceil(nspans / 8): spans per XCD; or -nspans when nspans < 8 (no XCD padding)
   int32_t block_begin;     // first block of this group in the grid
   int32_t slot_map_off;    // offset of the group's slot map
   int32_t pad_;

@@ -219,9 +219,15 @@ template <int RB> __device__ __forceinline__ bool locate_block(const FcpLaunch &
   bid -= L.groups[g].block_begin;
   // XCD-aware mapping: blocks with equal (bid & 7) share an XCD under the
   // round-robin dispatch; give them the same spans (same columns / tables).
-  const int xcd = bid & 7, j8 = bid >> 3;
-  const int span = (j8 % nsp8) * 8 + xcd;
-  const int tile = j8 / nsp8;
+  int span, tile;
+  if (nsp8 > 0) {
+    const int xcd = bid & 7, j8 = bid >> 3;
+    span = (j8 % nsp8) * 8 + xcd;
+    tile = j8 / nsp8;
+  } else { // fewer than 8 spans: no padding to 8 (nsp8 = -nspans)
+    span = bid % (-nsp8);
+    tile = bid / (-nsp8);
+  }
   B.q0 = span * FCP_WAVE;
   B.row_blk = tile * RB;
   if (B.q0 >= B.nslots || B.row_blk >= B.rows) return false; // uniform: whole block leaves
