@@ -198,7 +198,8 @@ def main():
     dev_ms_per_req = dev_ms / args.steps             # worker 0's stream, HIP events over the timed region
 
     rec = {
-        "metric": METRIC, "value": value, "unit": "inferences/s", "n_gpus": world, "steps": args.steps,
+        "metric": METRIC if args.workload == "s2" else f"inference QPS + p50 latency, {model.name} config, batch {batch}, 1xMI355X",
+        "value": value, "unit": "inferences/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{model.name}: {model.description}", "batch": batch,
