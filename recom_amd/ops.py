@@ -164,26 +164,23 @@ class FeatureColumnProcess:
         self.plan = Plan(spec, device)
         self.spec = spec
         self._L = self.plan._L
-        n, g = spec.n_columns, spec.n_groups
-        self._out_ptrs = (C.c_void_p * n)()
-        self._out_shapes = (C.c_int32 * (2 * n))()
-        self._out_strides = (C.c_int64 * n)()
-        self._grp_ptrs = (C.c_void_p * g)()
-        self._grp_shapes = (C.c_int32 * (2 * g))()
-        self._arena = None
+
+    def _allocators(self):
+        """Per-call allocator callbacks (malloc_buff = the op's allocate_output(2),
+        malloc_temp = allocate_temp): per-call state keeps __call__ re-entrant."""
+        torch, dev = self.torch, self.device
+        state = {"arena": None, "temps": []}
 
         def _alloc(_ctx, nbytes):
-            self._arena = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
-            return self._arena.data_ptr()
+            state["arena"] = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+            return state["arena"].data_ptr()
 
         def _alloc_temp(_ctx, nbytes):
-            t = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
-            self._temps.append(t)
+            t = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+            state["temps"].append(t)
             return t.data_ptr()
 
-        self._temps: list = []
-        self._alloc_cb = _lib.ALLOC_FN(_alloc)
-        self._alloc_temp_cb = _lib.ALLOC_FN(_alloc_temp)
+        return state, _lib.ALLOC_FN(_alloc), _lib.ALLOC_FN(_alloc_temp)
 
     def _args(self, concated_inputs, concated_offsets, concated_shapes, inputs, symbols, stream):
         torch = self.torch
@@ -194,36 +191,40 @@ class FeatureColumnProcess:
         tshapes = np.asarray([d for t in inputs for d in t.shape], np.int32)
         if stream is None:
             stream = torch.cuda.current_stream(self.device).cuda_stream
+        state, alloc_cb, alloc_temp_cb = self._allocators()
         a = _lib.ProcessArgs(
             concated_inputs.data_ptr() if concated_inputs is not None and concated_inputs.numel() else None,
             0 if concated_inputs is None else concated_inputs.numel() * concated_inputs.element_size(),
             offs.ctypes.data_as(C.POINTER(C.c_int32)), shps.ctypes.data_as(C.POINTER(C.c_int32)),
             tptrs, tshapes.ctypes.data_as(C.POINTER(C.c_int32)) if len(inputs) and all(t.dim() == 2 for t in inputs) else None,
             None if sym is None else sym.ctypes.data_as(C.POINTER(C.c_int32)),
-            stream, self._alloc_temp_cb, None, self._alloc_cb, None)
-        return a, (offs, shps, sym, tptrs, tshapes)
+            stream, alloc_temp_cb, None, alloc_cb, None)
+        return a, (offs, shps, sym, tptrs, tshapes, state, alloc_cb, alloc_temp_cb)
 
     def __call__(self, concated_inputs, concated_offsets, concated_shapes, inputs, symbols=None,
                  stream: Optional[int] = None) -> ProcessOutputs:
         torch = self.torch
-        a, _keep = self._args(concated_inputs, concated_offsets, concated_shapes, inputs, symbols, stream)
-        res = _lib.ProcessResult(self._out_ptrs, self._out_shapes, self._out_strides, self._grp_ptrs,
-                                 self._grp_shapes, None, 0)
-        self._arena = None
+        a, keep = self._args(concated_inputs, concated_offsets, concated_shapes, inputs, symbols, stream)
+        n, g = self.spec.n_columns, self.spec.n_groups
+        _out_ptrs = (C.c_void_p * n)()
+        _out_shapes = (C.c_int32 * (2 * n))()
+        _out_strides = (C.c_int64 * n)()
+        _grp_ptrs = (C.c_void_p * g)()
+        _grp_shapes = (C.c_int32 * (2 * g))()
+        res = _lib.ProcessResult(_out_ptrs, _out_shapes, _out_strides, _grp_ptrs, _grp_shapes, None, 0)
         _lib.check(self._L.fcp_process_feature_columns(self.plan.handle, C.byref(a), C.byref(res)),
                    "FeatureColumnProcess")
-        arena = self._arena
-        n, g = self.spec.n_columns, self.spec.n_groups
-        out_ptrs = np.array([self._out_ptrs[k] or 0 for k in range(n)], np.int64)
-        out_shapes = np.array(self._out_shapes[:], np.int32)
-        strides = np.array(self._out_strides[:], np.int64)
-        gshapes = np.array(self._grp_shapes[:], np.int32)
+        arena = keep[5]["arena"]
+        out_ptrs = np.array([_out_ptrs[k] or 0 for k in range(n)], np.int64)
+        out_shapes = np.array(_out_shapes[:], np.int32)
+        strides = np.array(_out_strides[:], np.int64)
+        gshapes = np.array(_grp_shapes[:], np.int32)
         groups = []
         if self.spec.layout == LAYOUT_CONCAT:
             f = arena.view(torch.float32)
             for gi in range(g):
                 rows, width = int(gshapes[2 * gi]), int(gshapes[2 * gi + 1])
-                off = ((self._grp_ptrs[gi] or arena.data_ptr()) - arena.data_ptr()) // 4
+                off = ((_grp_ptrs[gi] or arena.data_ptr()) - arena.data_ptr()) // 4
                 groups.append(f[off:off + rows * width].view(rows, width))
         return ProcessOutputs(out_ptrs, out_shapes, strides, arena, groups, gshapes)
 
@@ -234,7 +235,6 @@ class FeatureColumnProcess:
         a, _keep = self._args(concated_inputs, concated_offsets, concated_shapes, inputs, symbols, stream)
         width = self.plan.group_width(group)
         out = torch.empty((row_count, width), dtype=torch.float32, device=self.device)
-        self._temps.clear()
         _lib.check(self._L.fcp_shard_finalize(self.plan.handle, C.byref(a), group, partial_slices.data_ptr(),
                                               world, row_begin, row_count, out.data_ptr(), a.stream),
                    "fcp_shard_finalize")

@@ -1,0 +1,183 @@
+"""Randomised parity: random column plans (forms, dims, id sources, segment
+encodings, concat groups, batch sizes, bag lengths) through the C ABI against the
+oracle — bit-exact, including pooled columns (same sequential fp32 order).  Also
+host threads sharing one plan on their own streams with ever-changing shapes."""
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from recom_amd.plan import (COMBINER_MEAN, COMBINER_NONE, COMBINER_SUM, FORM_BATCH_COL_REDUCTION, FORM_GATHER,  # noqa: E402
+                            FORM_GATHER_SCATTER, FORM_PASSTHROUGH, FORM_SEGMENT_REDUCE, IDS_F32_BUCKETIZE, IDS_I32,
+                            IDS_I64, ROWS_FROM_IDS, ROWS_FROM_INPUT_DIM0, ROWS_FROM_SYMBOL, SEG_CSR_I32, SEG_IDS_I32,
+                            SEG_IDS_I64, SEG_NONE, ColumnSpec, PlanSpec)
+
+
+def random_model(rng, dense_only=False):
+    """Returns (spec, tables, make_inputs(batch per group) -> (inputs, symbols))."""
+    vec = int(rng.choice([4, 4, 4, 2, 1]))
+    n_groups = int(rng.integers(1, 4))
+    n_cols = int(rng.integers(1, 40))
+    cols, ranks, esz, tables, gens = [], [], [], [], []
+    slots = [0] * n_groups
+
+    def host(rank, e):
+        ranks.append(rank)
+        esz.append(e)
+        return len(ranks) - 1
+
+    for _ in range(n_cols):
+        g = int(rng.integers(0, n_groups))
+        dim = vec * int(rng.integers(1, 17 if vec < 4 else 33))
+        vocab = int(rng.integers(1, 400))
+        forms = [FORM_GATHER, FORM_PASSTHROUGH] if dense_only else \
+            [FORM_GATHER, FORM_SEGMENT_REDUCE, FORM_SEGMENT_REDUCE, FORM_GATHER_SCATTER, FORM_PASSTHROUGH,
+             FORM_BATCH_COL_REDUCTION]
+        form = int(rng.choice(forms))
+        slot = slots[g]
+        slots[g] += 1
+        if form == FORM_PASSTHROUGH:
+            i = host(2, 4)
+            gens.append((g, lambda r, B, dim=dim: [r.standard_normal((B, dim)).astype(np.float32)]))
+            cols.append(ColumnSpec(form, dim, 0, COMBINER_NONE, IDS_I32, -1, i, -1, SEG_NONE, 1, ROWS_FROM_INPUT_DIM0, i,
+                                   None, g, slot))
+            continue
+        if form == FORM_BATCH_COL_REDUCTION:
+            i = host(3, 4)
+            inner = int(rng.integers(0, 6))
+            gens.append((g, lambda r, B, dim=dim, inner=inner: [r.standard_normal((B, inner, dim)).astype(np.float32)]))
+            cols.append(ColumnSpec(form, dim, 0, COMBINER_NONE, IDS_I32, -1, i, -1, SEG_NONE, 1, ROWS_FROM_INPUT_DIM0, i,
+                                   None, g, slot))
+            continue
+        tables.append(rng.standard_normal((vocab, dim)).astype(np.float32))
+        t = len(tables) - 1
+        src = int(rng.choice([IDS_I32, IDS_I64, IDS_I64, IDS_F32_BUCKETIZE]))
+        bnd = None
+        if src == IDS_F32_BUCKETIZE:
+            nb = vocab - 1 if vocab > 1 else 1
+            bnd = np.sort(rng.uniform(-10, 10, nb)).astype(np.float32)
+            if vocab == 1:  # buckets 0..1 would overflow a 1-row table: bad ids are part of the test
+                pass
+        id_esz = 8 if src == IDS_I64 else 4
+
+        def draw_ids(r, n, src=src, vocab=vocab, bnd=bnd):
+            if src == IDS_F32_BUCKETIZE:
+                return r.uniform(-12, 12, n).astype(np.float32)
+            return r.integers(0, vocab, n).astype(np.int64 if src == IDS_I64 else np.int32)
+
+        if form == FORM_GATHER:
+            i = host(1, id_esz)
+            gens.append((g, lambda r, B, d=draw_ids: [d(r, B)]))
+            cols.append(ColumnSpec(form, dim, vocab, COMBINER_NONE, src, t, i, -1, SEG_NONE, 1, ROWS_FROM_IDS, 0, bnd, g, slot))
+            continue
+        seg = str(rng.choice(["csr", "indices", "rowids32"]))
+        max_len = 1 if form == FORM_GATHER_SCATTER else int(rng.choice([0, 1, 3, 10, 10, 70, 200]))
+        i = host(1, id_esz)
+        if seg == "csr":
+            si, kind, stride = host(1, 4), SEG_CSR_I32, 1
+        elif seg == "indices":
+            si, kind, stride = host(2, 8), SEG_IDS_I64, 2
+        else:
+            si, kind, stride = host(1, 4), SEG_IDS_I32, 1
+
+        def gen(r, B, d=draw_ids, seg=seg, max_len=max_len):
+            lens = r.integers(0, max_len + 1, B)
+            nnz = int(lens.sum())
+            rows = np.repeat(np.arange(B, dtype=np.int64), lens)
+            if seg == "csr":
+                s = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+            elif seg == "indices":
+                s = np.stack([rows, np.zeros_like(rows)], axis=1).astype(np.int64).reshape(nnz, 2)
+            else:
+                s = rows.astype(np.int32)
+            return [d(r, nnz), s]
+
+        gens.append((g, gen))
+        comb = int(rng.choice([COMBINER_SUM, COMBINER_MEAN])) if form == FORM_SEGMENT_REDUCE else COMBINER_NONE
+        cols.append(ColumnSpec(form, dim, vocab, comb, src, t, i, si, kind, stride, ROWS_FROM_SYMBOL, g, bnd, g, slot))
+    # every group needs a column
+    for g in range(n_groups):
+        if slots[g] == 0:
+            i = host(2, 4)
+            gens.append((g, lambda r, B: [r.standard_normal((B, vec)).astype(np.float32)]))
+            cols.append(ColumnSpec(FORM_PASSTHROUGH, vec, 0, COMBINER_NONE, IDS_I32, -1, i, -1, SEG_NONE, 1,
+                                   ROWS_FROM_INPUT_DIM0, i, None, g, 0))
+            slots[g] = 1
+    spec = PlanSpec(cols, ranks, esz, len(tables), n_groups=n_groups, n_symbols=n_groups)
+    spec.validate()
+
+    def make(r, batches):
+        inputs = []
+        for g, gen in gens:
+            inputs.extend(gen(r, batches[g]))
+        return inputs, np.asarray(batches, np.int32)
+
+    return spec, tables, make
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_plans_match_oracle(oracle, seed):
+    import torch
+    from recom_amd.ops import FeatureColumnProcess, concat_inputs
+    rng = np.random.default_rng(1000 + seed)
+    spec, tables, make = random_model(rng, dense_only=(seed % 4 == 3))
+    dev = torch.device("cuda", 0)
+    d_tabs = [torch.from_numpy(t).to(dev) for t in tables]
+    op = FeatureColumnProcess(spec, 0)
+    for trial in range(4):
+        batches = [int(rng.choice([1, 2, 5, 33, 64, 130, 257])) for _ in range(spec.n_groups)]
+        inputs, symbols = make(rng, batches)
+        blob, offsets, shapes = concat_inputs(inputs)
+        d_blob = torch.from_numpy(blob).to(dev) if blob.size else torch.empty(0, dtype=torch.int8, device=dev)
+        out = op(d_blob, offsets, shapes, d_tabs, symbols)
+        torch.cuda.synchronize()
+        want, _bad = oracle.process_feature_columns(spec.to_dict(), blob, offsets, shapes, tables, symbols)
+        for g, w in enumerate(want):
+            got = out.groups[g].cpu().numpy()
+            assert got.shape == w.shape, (seed, trial, g)
+            assert np.array_equal(got, w), (seed, trial, g, float(np.abs(got - w).max()))
+
+
+def test_host_threads_share_a_plan_with_changing_shapes(oracle):
+    """serve_workers: several host threads, one plan, one stream each, a new shape on
+    every request (descriptor slots churn under contention)."""
+    import torch
+    from recom_amd import synth
+    from recom_amd.ops import FeatureColumnProcess, concat_inputs
+    m = synth.model_ragged(columns=48, vocab=3000, batch=96, seg="indices")
+    tabs_np = m.numpy_tables()
+    dev = torch.device("cuda", 0)
+    tabs = [torch.from_numpy(t).to(dev) for t in tabs_np]
+    op = FeatureColumnProcess(m.spec, 0)
+    n_threads, per_thread = 4, 12
+    reqs = [[m.make_request(100 * t + k) for k in range(per_thread)] for t in range(n_threads)]
+    packed = [[concat_inputs(r.inputs) for r in rs] for rs in reqs]
+    blobs = [[torch.from_numpy(p[0]).to(dev) for p in ps] for ps in packed]
+    torch.cuda.synchronize()
+    results = [[None] * per_thread for _ in range(n_threads)]
+    errors = []
+
+    def worker(t):
+        try:
+            s = torch.cuda.Stream(device=dev)
+            for k in range(per_thread):
+                results[t][k] = op(blobs[t][k], packed[t][k][1], packed[t][k][2], tabs, reqs[t][k].symbols,
+                                   stream=s.cuda_stream)  # ctypes drops the GIL: calls really overlap
+            s.synchronize()
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(n_threads)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    assert not errors, errors
+    torch.cuda.synchronize()
+    spec_d = m.spec.to_dict()
+    for t in range(n_threads):
+        for k in range(per_thread):
+            want, _ = oracle.process_feature_columns(spec_d, *packed[t][k], tabs_np, reqs[t][k].symbols)
+            assert np.array_equal(results[t][k].groups[0].cpu().numpy(), want[0]), (t, k)
