@@ -250,6 +250,24 @@ int fcp_process_feature_columns(fcp_plan_t *plan,
 int fcp_concat_outputs(const void *const *inputs, const int32_t *dims,
                        int32_t n, int64_t prefix_size, void *out, void *stream);
 
+/* ---- request staging: ConcatInputs + the H2D copy as one step -- */
+/* The reference packs N host tensors with N mempcpy calls on one CPU thread into a
+ * pageable TF tensor (concat_inputs_ops.cc:69-76) which TF then copies H2D.  A
+ * stager owns a ring of pinned host buffers with device twins: fcp_stager_stage
+ * packs the tensors (same bytes, offsets and shapes as fcp_concat_inputs) with
+ * `n_threads` worker threads straight into pinned memory and enqueues ONE
+ * hipMemcpyAsync on `stream`.  The returned pointers stay valid until the slot is
+ * reused, i.e. for the next depth-1 calls. */
+typedef struct fcp_stager fcp_stager_t;
+int fcp_stager_create(int32_t device, int64_t capacity_bytes, int32_t max_inputs,
+                      int32_t max_rank_sum, int32_t depth, int32_t n_threads,
+                      fcp_stager_t **stager);
+int fcp_stager_stage(fcp_stager_t *stager, const fcp_host_tensor_t *inputs,
+                     int32_t n_inputs, void *stream, const void **device_blob,
+                     int64_t *blob_bytes, const int32_t **offsets,
+                     const int32_t **shapes);
+int fcp_stager_destroy(fcp_stager_t *stager);
+
 /* ---- multi-GPU finalize (no reference counterpart) --------- */
 /* After the all-to-all of per-rank partial sums: out = sum over `world`
  * slices in rank order; for MEAN columns divide by the segment length read

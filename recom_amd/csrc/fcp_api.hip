@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <new>
 #include <string>
@@ -968,6 +969,209 @@ int fcp_shard_finalize(fcp_plan_t *p, const fcp_process_args_t *a, int32_t group
   const int e = fcp_launch_shard_finalize(L, group, static_cast<const float *>(partial_slices), world, row_begin,
                                           row_count, static_cast<float *>(out), p->vec, stream);
   if (e) return hip_fail("shard-finalize launch", (hipError_t)e);
+  return FCP_OK;
+}
+
+} // extern "C"
+
+// ============================ request staging ===============================
+// ConcatInputs + H2D as one step.  See include/fcp_hip.h.
+#include <atomic>
+#include <condition_variable>
+#include <thread>
+
+namespace {
+
+// Minimal persistent worker pool: parallel_for over [0, n) in contiguous chunks.
+class PackPool {
+public:
+  explicit PackPool(int n_threads) {
+    for (int t = 1; t < n_threads; ++t) workers_.emplace_back([this] { loop(); });
+  }
+  ~PackPool() {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      stop_ = true;
+      ++epoch_;
+    }
+    cv_.notify_all();
+    for (auto &w : workers_) w.join();
+  }
+  template <typename F> void run(int n_chunks, F &&fn) {
+    if (workers_.empty() || n_chunks <= 1) {
+      for (int c = 0; c < n_chunks; ++c) fn(c);
+      return;
+    }
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      fn_ = [&fn](int c) { fn(c); };
+      n_chunks_ = n_chunks;
+      next_.store(0);
+      pending_.store(n_chunks);
+      ++epoch_;
+    }
+    cv_.notify_all();
+    work(); // the caller helps
+    while (pending_.load(std::memory_order_acquire) > 0) std::this_thread::yield();
+  }
+
+private:
+  void work() {
+    for (;;) {
+      const int c = next_.fetch_add(1);
+      if (c >= n_chunks_) return;
+      fn_(c);
+      pending_.fetch_sub(1, std::memory_order_release);
+    }
+  }
+  void loop() {
+    uint64_t seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return epoch_ != seen; });
+        seen = epoch_;
+        if (stop_) return;
+      }
+      work();
+    }
+  }
+  std::vector<std::thread> workers_;
+  std::mutex mu_;
+  std::condition_variable cv_;
+  std::function<void(int)> fn_;
+  std::atomic<int> next_{0}, pending_{0};
+  int n_chunks_ = 0;
+  uint64_t epoch_ = 0;
+  bool stop_ = false;
+};
+
+struct StageSlot {
+  char *h_blob = nullptr; // pinned
+  char *d_blob = nullptr;
+  int32_t *offsets = nullptr, *shapes = nullptr;
+  hipEvent_t copied = nullptr;
+};
+
+} // namespace
+
+struct fcp_stager {
+  int device = 0;
+  int64_t capacity = 0;
+  int32_t max_inputs = 0, max_rank_sum = 0;
+  std::vector<StageSlot> slots;
+  size_t next = 0;
+  PackPool *pool = nullptr;
+  int n_threads = 1;
+  std::mutex mu;
+  std::vector<int64_t> byte_off; // scratch
+};
+
+extern "C" {
+
+int fcp_stager_create(int32_t device, int64_t capacity_bytes, int32_t max_inputs, int32_t max_rank_sum,
+                      int32_t depth, int32_t n_threads, fcp_stager_t **out) {
+  if (!out || capacity_bytes <= 0 || capacity_bytes > 0x7fffffff || max_inputs <= 0 || max_rank_sum < 0 ||
+      depth < 1 || n_threads < 1)
+    return fail(FCP_ERR_INVALID_ARGUMENT, "bad stager parameters (capacity is limited to 2^31 bytes: int32 offsets)");
+  *out = nullptr;
+  DeviceGuard guard;
+  int rc = guard.enter(device);
+  if (rc) return rc;
+  fcp_stager *s = new (std::nothrow) fcp_stager();
+  if (!s) return fail(FCP_ERR_ALLOC, "out of host memory");
+  s->device = device;
+  s->capacity = capacity_bytes;
+  s->max_inputs = max_inputs;
+  s->max_rank_sum = max_rank_sum;
+  s->n_threads = n_threads;
+  s->slots.resize(depth);
+  for (auto &sl : s->slots) {
+    if (hipHostMalloc(reinterpret_cast<void **>(&sl.h_blob), capacity_bytes, hipHostMallocDefault) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&sl.d_blob), capacity_bytes) != hipSuccess ||
+        hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming) != hipSuccess) {
+      fcp_stager_destroy(s);
+      return hip_fail("stager allocation", hipGetLastError());
+    }
+    sl.offsets = new int32_t[max_inputs];
+    sl.shapes = new int32_t[max_rank_sum > 0 ? max_rank_sum : 1];
+  }
+  s->pool = new PackPool(n_threads);
+  s->byte_off.resize(max_inputs + 1);
+  *out = s;
+  return FCP_OK;
+}
+
+int fcp_stager_stage(fcp_stager_t *s, const fcp_host_tensor_t *inputs, int32_t n, void *stream,
+                     const void **device_blob, int64_t *blob_bytes, const int32_t **offsets,
+                     const int32_t **shapes) {
+  if (!s || n < 0 || (n > 0 && !inputs)) return fail(FCP_ERR_INVALID_ARGUMENT, "null argument");
+  if (n > s->max_inputs) return fail(FCP_ERR_INVALID_ARGUMENT, "more inputs than the stager was created for");
+  DeviceGuard guard;
+  int rc = guard.enter(s->device);
+  if (rc) return rc;
+  std::lock_guard<std::mutex> lock(s->mu);
+  StageSlot &sl = s->slots[s->next];
+  s->next = (s->next + 1) % s->slots.size();
+  // the slot's previous copy must have left the pinned buffer
+  if (hipEventQuery(sl.copied) != hipSuccess) HIP_TRY(hipEventSynchronize(sl.copied));
+  // sizes / offsets / shapes: exactly ConcatInputsOp::Compute (concat_inputs_ops.cc:52-66)
+  int64_t size = 0;
+  int32_t rank_sum = 0;
+  for (int32_t i = 0; i < n; ++i) {
+    const fcp_host_tensor_t &t = inputs[i];
+    if (t.rank < 0 || t.elem_size <= 0 || (t.rank > 0 && !t.dims)) return fail(FCP_ERR_INVALID_ARGUMENT, "bad host tensor");
+    if (rank_sum + t.rank > s->max_rank_sum) return fail(FCP_ERR_INVALID_ARGUMENT, "more dims than the stager was created for");
+    int64_t ne = 1;
+    for (int32_t j = 0; j < t.rank; ++j) {
+      if (t.dims[j] < 0) return fail(FCP_ERR_INVALID_ARGUMENT, "negative dimension");
+      ne *= t.dims[j];
+      sl.shapes[rank_sum++] = (int32_t)t.dims[j];
+    }
+    s->byte_off[i] = size;
+    sl.offsets[i] = (int32_t)size;
+    size += ne * t.elem_size;
+    if (size > s->capacity) return fail(FCP_ERR_INVALID_ARGUMENT, "request larger than the stager capacity");
+    if (ne && !t.data) return fail(FCP_ERR_INVALID_ARGUMENT, "null tensor data");
+  }
+  s->byte_off[n] = size;
+  // pack: contiguous ranges of inputs per chunk, ~equal bytes
+  const int chunks = (int)std::min<int64_t>(std::max<int64_t>(1, size / (64 << 10)), 4 * s->n_threads);
+  const int64_t *bo = s->byte_off.data();
+  char *dst = sl.h_blob;
+  s->pool->run(chunks, [&](int c) {
+    const int64_t b0 = size * c / chunks, b1 = size * (c + 1) / chunks;
+    // inputs whose start offset falls in [b0, b1)
+    int lo = (int)(std::lower_bound(bo, bo + n, b0) - bo);
+    const int hi = (int)(std::lower_bound(bo, bo + n, b1) - bo);
+    for (; lo < hi; ++lo)
+      if (bo[lo + 1] > bo[lo]) std::memcpy(dst + bo[lo], inputs[lo].data, (size_t)(bo[lo + 1] - bo[lo]));
+  });
+  if (size) HIP_TRY(hipMemcpyAsync(sl.d_blob, sl.h_blob, (size_t)size, hipMemcpyHostToDevice, static_cast<hipStream_t>(stream)));
+  HIP_TRY(hipEventRecord(sl.copied, static_cast<hipStream_t>(stream)));
+  if (device_blob) *device_blob = sl.d_blob;
+  if (blob_bytes) *blob_bytes = size;
+  if (offsets) *offsets = sl.offsets;
+  if (shapes) *shapes = sl.shapes;
+  return FCP_OK;
+}
+
+int fcp_stager_destroy(fcp_stager_t *s) {
+  if (!s) return FCP_OK;
+  DeviceGuard guard;
+  (void)guard.enter(s->device);
+  delete s->pool;
+  for (auto &sl : s->slots) {
+    if (sl.copied) {
+      (void)hipEventSynchronize(sl.copied);
+      (void)hipEventDestroy(sl.copied);
+    }
+    if (sl.h_blob) (void)hipHostFree(sl.h_blob);
+    if (sl.d_blob) (void)hipFree(sl.d_blob);
+    delete[] sl.offsets;
+    delete[] sl.shapes;
+  }
+  delete s;
   return FCP_OK;
 }
 

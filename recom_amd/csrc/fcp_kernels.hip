@@ -34,6 +34,7 @@
 //     skewed (Zipf) ids and small bucketize tables are served from one L2.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/fcp_hip.h"
 #include "fcp_internal.h"
@@ -702,9 +703,9 @@ __global__ void __launch_bounds__(FCP_BLOCK_THREADS) fcp_upload_kernel(const uin
 #define FCP_LAUNCH_DENSE(VV, RR)                                                                            \
   do {                                                                                                      \
     if (L.shard_world > 1)                                                                                  \
-      hipLaunchKernelGGL((fcp_dense_kernel<VV, RR, true>), dim3(grid_blocks), dim3(FCP_BLOCK_THREADS), 0, s, L); \
+      hipLaunchKernelGGL((fcp_dense_kernel<VV, RR, true>), dim3(grid_blocks), dim3(FCP_BLOCK_THREADS), lds_pad, s, L); \
     else                                                                                                    \
-      hipLaunchKernelGGL((fcp_dense_kernel<VV, RR, false>), dim3(grid_blocks), dim3(FCP_BLOCK_THREADS), 0, s, L); \
+      hipLaunchKernelGGL((fcp_dense_kernel<VV, RR, false>), dim3(grid_blocks), dim3(FCP_BLOCK_THREADS), lds_pad, s, L); \
   } while (0)
 #define FCP_LAUNCH_RAGGED(VV)                                                                               \
   do {                                                                                                      \
@@ -717,6 +718,11 @@ __global__ void __launch_bounds__(FCP_BLOCK_THREADS) fcp_upload_kernel(const uin
 // rows_per_wave: dense 1 | 2 | 4 (rows per block = 4 x that); ragged always 1.
 int fcp_launch_fused(const FcpLaunch &L, int vec, bool dense_only, int grid_blocks, ihipStream_t *s) {
   if (grid_blocks <= 0) return 0;
+  // tuning aid: FCP_LDS_PAD=<bytes> of unused dynamic LDS caps the blocks per CU
+  static const int lds_pad = [] {
+    const char *e = getenv("FCP_LDS_PAD");
+    return e ? atoi(e) : 0;
+  }();
   if (dense_only) {
     const int R = L.rows_per_wave;
 #define FCP_DENSE_R(VV)                         \

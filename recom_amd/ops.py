@@ -269,3 +269,46 @@ def concat_outputs(device_inputs: Sequence, stream: Optional[int] = None):
     _lib.check(L.fcp_concat_outputs(ptrs, dims.ctypes.data, len(ins), prefix, out.data_ptr(), stream),
                "ConcatOutputs")
     return out
+
+
+# ----------------------------------------------------------------------------
+# request staging: ConcatInputs + H2D in one step
+# ----------------------------------------------------------------------------
+class RequestStager:
+    """Ring of pinned host buffers with device twins: ``stage(inputs)`` packs the host
+    tensors exactly like :func:`concat_inputs` (multi-threaded, straight into pinned
+    memory) and enqueues one async H2D copy.  Returns ``(device_blob_ptr, nbytes,
+    offsets, shapes)``; the device blob stays valid for the next ``depth - 1`` calls."""
+
+    def __init__(self, capacity_bytes: int, max_inputs: int, max_rank_sum: int, device: int = 0, depth: int = 4,
+                 n_threads: int = 8) -> None:
+        self._L = _lib.load()
+        h = C.c_void_p()
+        _lib.check(self._L.fcp_stager_create(device, capacity_bytes, max_inputs, max_rank_sum, depth, n_threads,
+                                             C.byref(h)), "fcp_stager_create")
+        self.handle = h
+
+    def stage(self, inputs: Sequence[np.ndarray], stream: Optional[int] = None):
+        import torch
+        arrs = [np.require(np.asarray(a), requirements="C") for a in inputs]
+        n = len(arrs)
+        dims_keep = [np.asarray(a.shape, np.int64) for a in arrs]
+        tens = (_lib.HostTensor * max(n, 1))()
+        for i, a in enumerate(arrs):
+            tens[i] = _lib.HostTensor(a.ctypes.data, a.dtype.itemsize, a.ndim,
+                                      dims_keep[i].ctypes.data_as(C.POINTER(C.c_int64)))
+        if stream is None:
+            stream = torch.cuda.current_stream().cuda_stream
+        blob, nbytes = C.c_void_p(), C.c_int64()
+        offs, shps = C.POINTER(C.c_int32)(), C.POINTER(C.c_int32)()
+        _lib.check(self._L.fcp_stager_stage(self.handle, tens, n, stream, C.byref(blob), C.byref(nbytes),
+                                            C.byref(offs), C.byref(shps)), "fcp_stager_stage")
+        rank_sum = sum(a.ndim for a in arrs)
+        offsets = np.ctypeslib.as_array(offs, shape=(n,)).copy() if n else np.zeros(0, np.int32)
+        shapes = np.ctypeslib.as_array(shps, shape=(rank_sum,)).copy() if rank_sum else np.zeros(0, np.int32)
+        return blob.value, nbytes.value, offsets, shapes
+
+    def close(self) -> None:
+        if getattr(self, "handle", None):
+            self._L.fcp_stager_destroy(self.handle)
+            self.handle = None

@@ -345,3 +345,33 @@ def test_s2_full_size_closed_form(torch_cuda):
         _closed_form_check(torch, m, req, out)
     del tabs
     torch.cuda.empty_cache()
+
+
+def test_request_stager_matches_concat_inputs_and_feeds_the_kernel(torch_cuda, oracle):
+    """ConcatInputs + H2D as one step.  The staged device blob is
+    byte-identical to ConcatInputs' output; offsets / shapes are the same arrays; the
+    kernel result through it equals the oracle."""
+    import ctypes as C
+    from recom_amd import lib, synth
+    from recom_amd.ops import FeatureColumnProcess, RequestStager, concat_inputs
+    torch = torch_cuda
+    m = synth.model_mixed(batch=70, vocab=997, n_groups=1)
+    tabs_np = m.numpy_tables()
+    tabs = [torch.from_numpy(t).cuda() for t in tabs_np]
+    op = FeatureColumnProcess(m.spec, 0)
+    st = RequestStager(1 << 20, m.spec.n_host_inputs, sum(m.spec.host_input_ranks), depth=3, n_threads=4)
+    for seed in range(7):  # more requests than ring slots
+        req = m.make_request(seed)
+        blob, offsets, shapes = concat_inputs(req.inputs)
+        d_ptr, nbytes, off2, shp2 = st.stage(req.inputs)
+        assert nbytes == blob.nbytes and np.array_equal(off2, offsets) and np.array_equal(shp2, shapes)
+        torch.cuda.synchronize()
+        tmp = torch.empty(nbytes, dtype=torch.int8, device="cuda")
+        hip = C.CDLL("libamdhip64.so")  # already loaded by torch: device-to-device copy of the staged blob
+        assert hip.hipMemcpy(C.c_void_p(tmp.data_ptr()), C.c_void_p(d_ptr), C.c_size_t(nbytes), 3) == 0
+        assert np.array_equal(tmp.cpu().numpy(), blob)
+        out = op(tmp, off2, shp2, tabs, req.symbols)
+        torch.cuda.synchronize()
+        want, _ = oracle.process_feature_columns(m.spec.to_dict(), blob, offsets, shapes, tabs_np, req.symbols)
+        assert np.array_equal(out.groups[0].cpu().numpy(), want[0])
+    st.close()
