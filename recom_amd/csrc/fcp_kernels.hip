@@ -176,20 +176,15 @@ __device__ __forceinline__ LdsCol make_lds_col(const FcpLaunch &L, const FcpColS
 // reference reads out of bounds, TF-GPU GatherV2 returns zeros); under row
 // sharding an id owned by another rank contributes nothing here.
 template <int V, bool SHARDED>
-__device__ __forceinline__ uint32_t fetch_slot_offset(const LdsCol &c, int64_t pos, const float *lds_bnd, int rank,
-                                                      int world, bool &bad) {
+__device__ __forceinline__ uint32_t slot_offset_from_raw(const LdsCol &c, uint32_t lo, uint32_t hi, const float *lds_bnd,
+                                                         int rank, int world, bool &bad) {
   const unsigned idsrc = FCP_F_IDSRC(c.flags);
-  const bool is64 = idsrc == FCP_IDS_I64;
-  // branch-free fetch: one code path for every id source
-  const char *a = c.ids + (is64 ? 8 : 4) * pos;
-  const uint32_t lo = *as_global(reinterpret_cast<const uint32_t *>(a));
-  const uint32_t hi = *as_global(reinterpret_cast<const uint32_t *>(a + (is64 ? 4 : 0)));
   int64_t id;
   if (idsrc == FCP_IDS_F32_BUCKETIZE) {
     id = lds_bnd ? bucketize(lds_bnd, c.n_boundaries, __uint_as_float(lo))
                  : bucketize(as_global(c.boundaries), c.n_boundaries, __uint_as_float(lo));
   } else {
-    id = is64 ? (int64_t)(((uint64_t)hi << 32) | lo) : (int64_t)(int32_t)lo;
+    id = idsrc == FCP_IDS_I64 ? (int64_t)(((uint64_t)hi << 32) | lo) : (int64_t)(int32_t)lo;
   }
   bad = (uint64_t)id >= (uint64_t)c.vocab;
   if (bad) return kNoRow;
@@ -199,6 +194,17 @@ __device__ __forceinline__ uint32_t fetch_slot_offset(const LdsCol &c, int64_t p
     id = q;
   }
   return (uint32_t)id * (uint32_t)(c.dim / V);
+}
+
+template <int V, bool SHARDED>
+__device__ __forceinline__ uint32_t fetch_slot_offset(const LdsCol &c, int64_t pos, const float *lds_bnd, int rank,
+                                                      int world, bool &bad) {
+  const bool is64 = FCP_F_IDSRC(c.flags) == FCP_IDS_I64;
+  // branch-free fetch: one code path for every id source
+  const char *a = c.ids + (is64 ? 8 : 4) * pos;
+  const uint32_t lo = *as_global(reinterpret_cast<const uint32_t *>(a));
+  const uint32_t hi = *as_global(reinterpret_cast<const uint32_t *>(a + (is64 ? 4 : 0)));
+  return slot_offset_from_raw<V, SHARDED>(c, lo, hi, lds_bnd, rank, world, bad);
 }
 
 // Common block header: which group / span / row tile this block owns.
@@ -283,43 +289,68 @@ __global__ void __launch_bounds__(FCP_BLOCK_THREADS) fcp_dense_kernel(const FcpL
   if (tid < B.ncols) s_col[tid] = make_lds_col(L, L.cols[B.first_col + tid], L.dyn[B.first_col + tid]);
   __syncthreads();
 
-  // ---- phase 0b -----------------------------------------------------------------------
-  if (wave == 0) {
-    int nb = 0;
-    if (lane < B.ncols && FCP_F_IDSRC(s_col[lane].flags) == FCP_IDS_F32_BUCKETIZE &&
-        FCP_F_FORM(s_col[lane].flags) != FCP_FORM_PASSTHROUGH)
-      nb = s_col[lane].n_boundaries;
-    int incl = nb;
+  // ---- phase 1a: raw id words of this thread's (column, row) pairs ------------------------
+  // issued before the boundary staging so that the two memory round trips overlap
+  constexpr int PT = (FCP_WAVE * RB + FCP_BLOCK_THREADS - 1) / FCP_BLOCK_THREADS; // pairs per thread, at most
+  uint32_t raw_lo[PT], raw_hi[PT];
+  const int npairs = B.ncols * RB;
 #pragma unroll
-    for (int d = 1; d < FCP_WAVE; d <<= 1) {
-      const int up = __shfl_up(incl, d);
-      if (lane >= d) incl += up;
+  for (int h = 0; h < PT; ++h) {
+    const int p = tid + h * FCP_BLOCK_THREADS;
+    raw_lo[h] = raw_hi[h] = 0;
+    if (p < npairs) {
+      const int j = p / RB, b = B.row_blk + p % RB;
+      if (b < B.rows && FCP_F_FORM(s_col[j].flags) != FCP_FORM_PASSTHROUGH) {
+        const bool is64 = FCP_F_IDSRC(s_col[j].flags) == FCP_IDS_I64;
+        const char *a = s_col[j].ids + (is64 ? 8 : 4) * (int64_t)b;
+        raw_lo[h] = *as_global(reinterpret_cast<const uint32_t *>(a));
+        raw_hi[h] = *as_global(reinterpret_cast<const uint32_t *>(a + (is64 ? 4 : 0)));
+      }
     }
-    if (nb > 0 && incl <= BND) s_col[lane].bnd_off = incl - nb;
   }
-  __syncthreads();
-  for (int j = 0; j < B.ncols; ++j) {
-    const int off = s_col[j].bnd_off;
-    if (off < 0) continue;
-    const FCP_GLOBAL float *src = as_global(s_col[j].boundaries);
-    for (int i = tid; i < s_col[j].n_boundaries; i += FCP_BLOCK_THREADS) s_bnd[off + i] = src[i];
-  }
-  __syncthreads();
 
-  // ---- phase 1: (column, row) pairs -> table slot offsets in LDS ------------------------
-  for (int p = tid; p < B.ncols * RB; p += FCP_BLOCK_THREADS) {
+  // ---- phase 0b: bucketize boundaries -> LDS (skipped when the span has none) --------------
+  const bool my_bkt = tid < B.ncols && FCP_F_IDSRC(s_col[tid].flags) == FCP_IDS_F32_BUCKETIZE &&
+                      FCP_F_FORM(s_col[tid].flags) != FCP_FORM_PASSTHROUGH;
+  if (__syncthreads_or(my_bkt)) {
+    if (wave == 0) {
+      const int nb = my_bkt ? s_col[lane].n_boundaries : 0;
+      int incl = nb;
+#pragma unroll
+      for (int d = 1; d < FCP_WAVE; d <<= 1) {
+        const int up = __shfl_up(incl, d);
+        if (lane >= d) incl += up;
+      }
+      if (nb > 0 && incl <= BND) s_col[lane].bnd_off = incl - nb;
+    }
+    __syncthreads();
+    for (int j = 0; j < B.ncols; ++j) {
+      const int off = s_col[j].bnd_off;
+      if (off < 0) continue;
+      const FCP_GLOBAL float *src = as_global(s_col[j].boundaries);
+      for (int i = tid; i < s_col[j].n_boundaries; i += FCP_BLOCK_THREADS) s_bnd[off + i] = src[i];
+    }
+    __syncthreads();
+  }
+
+  // ---- phase 1b: raw ids -> table slot offsets in LDS -----------------------------------------
+#pragma unroll
+  for (int h = 0; h < PT; ++h) {
+    const int p = tid + h * FCP_BLOCK_THREADS;
+    if (p >= npairs) break;
     const int j = p / RB, r = p % RB;
     const int b = B.row_blk + r;
     uint32_t off = kNoRow;
     if (b < B.rows) {
-      if (FCP_F_FORM(s_col[j].flags) == FCP_FORM_PASSTHROUGH) {
+      const LdsCol &c = s_col[j];
+      if (FCP_F_FORM(c.flags) == FCP_FORM_PASSTHROUGH) {
         // a tensor of the blob copied into its concat slot; table-free columns
         // belong to shard rank 0
-        if (rank == 0) off = (uint32_t)b * (uint32_t)(s_col[j].dim / V);
+        if (rank == 0) off = (uint32_t)b * (uint32_t)(c.dim / V);
       } else {
         bool bad;
-        const int boff = s_col[j].bnd_off;
-        off = fetch_slot_offset<V, SHARDED>(s_col[j], b, boff >= 0 ? s_bnd + boff : nullptr, rank, world, bad);
+        off = slot_offset_from_raw<V, SHARDED>(c, raw_lo[h], raw_hi[h], c.bnd_off >= 0 ? s_bnd + c.bnd_off : nullptr,
+                                               rank, world, bad);
         if (bad && L.bad_ids) atomicAdd(L.bad_ids, 1ull);
       }
     }

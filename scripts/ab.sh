@@ -1,0 +1,6 @@
+#!/bin/bash
+# interleaved A/B of two builds in one session: build/prev vs recom_amd
+cd $GRAFT_REPO_ROOT
+for round in 1 2 3; do
+  for v in build/prev recom_amd; do echo -n "$v: "; ./$v/fcp_bench --steps 600 --verify $((round==1)) $* | tail -1 | sed 's/.*"dev_us_per_step": \([0-9.]*\).*/\1/'; done
+done
