@@ -84,6 +84,11 @@ template <int V> __device__ __forceinline__ void st_out(float *p, const VF<V> &v
 // one v_lshl_add_u64 + one global_load.
 template <int V> __device__ __forceinline__ VF<V> ld_slot(const float *tb, uint32_t off) {
   typedef typename VecType<V>::T T;
+#if defined(FCP_ABLATE) && FCP_ABLATE == 4 // timing-only build 4: no table reads at all (ragged kernel too)
+  VF<V> z = vzero<V>();
+  z.v[0] = (float)off;
+  return z;
+#endif
   const FCP_GLOBAL T *g = as_global(reinterpret_cast<const T *>(tb)) + off;
 #if !defined(FCP_NO_NT)
   T t = __builtin_nontemporal_load(g);

@@ -19,7 +19,7 @@ from .ops import Plan, concat_inputs
 from .synth import Request, SynthModel
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-HARNESS_PATH = os.path.join(_HERE, "libfcp_harness.so")
+HARNESS_PATH = os.path.join(os.environ.get("FCP_LIB_DIR", _HERE), "libfcp_harness.so")
 _h = None
 
 

@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfcp_hip.so")
+# FCP_LIB_DIR: tuning aid, loads an alternative build (e.g. build/abl4) of the same sources
+LIB_PATH = os.path.join(os.environ.get("FCP_LIB_DIR", _HERE), "libfcp_hip.so")
 
 FCP_ABI_VERSION = 1
 FCP_OK = 0
