@@ -214,7 +214,8 @@ def main():
         rec["roofline"] = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.workload),
-            "kernel": "fcp_dense_kernel" if h.plan.spec is not None and all(c.form in (1, 4) for c in model.spec.columns) else "fcp_fused_kernel", "kernel_avg_us": dev_ms_per_req * 1e3,
+            "kernel": "fcp_dense_kernel" if all(c.form in (1, 4) for c in model.spec.columns) else "fcp_ragged_kernel",
+            "kernel_avg_us": dev_ms_per_req * 1e3,
             "algorithmic_bytes_per_request": bytes_alg,
             "read_only_frac": bytes_alg["read"] / (dev_ms_per_req * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "measured_copy_peak_GBs": copy_probe() / 1e9,
@@ -223,7 +224,7 @@ def main():
             overlap["inferences_per_s"] = batch / (overlap["us_per_request"] * 1e-6)
             overlap["aggregate_frac_of_peak"] = bytes_alg["total"] / (overlap["us_per_request"] * 1e-6) / 1e9 / HBM_PEAK_GBS
             rec["overlapped_serving"] = overlap
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
             rec["cpu_baseline"] = cpu_baseline(model)
         print(json.dumps(rec))
     h.close()

@@ -746,9 +746,9 @@ __global__ void __launch_bounds__(FCP_BLOCK_THREADS) fcp_upload_kernel(const uin
 #define FCP_LAUNCH_RAGGED(VV)                                                                               \
   do {                                                                                                      \
     if (L.shard_world > 1)                                                                                  \
-      hipLaunchKernelGGL((fcp_ragged_kernel<VV, true>), dim3(grid_blocks), dim3(FCP_BLOCK_THREADS), 0, s, L); \
+      hipLaunchKernelGGL((fcp_ragged_kernel<VV, true>), dim3(grid_blocks), dim3(FCP_BLOCK_THREADS), lds_pad, s, L); \
     else                                                                                                    \
-      hipLaunchKernelGGL((fcp_ragged_kernel<VV, false>), dim3(grid_blocks), dim3(FCP_BLOCK_THREADS), 0, s, L); \
+      hipLaunchKernelGGL((fcp_ragged_kernel<VV, false>), dim3(grid_blocks), dim3(FCP_BLOCK_THREADS), lds_pad, s, L); \
   } while (0)
 
 // rows_per_wave: dense 1 | 2 | 4 (rows per block = 4 x that); ragged always 1.

@@ -187,8 +187,13 @@ class FeatureColumnProcess:
         offs = np.ascontiguousarray(concated_offsets, np.int32)
         shps = np.ascontiguousarray(concated_shapes, np.int32)
         sym = None if symbols is None else np.ascontiguousarray(symbols, np.int32)
-        tptrs = (C.c_void_p * max(1, len(inputs)))(*[t.data_ptr() for t in inputs])
-        tshapes = np.asarray([d for t in inputs for d in t.shape], np.int32)
+        cached = getattr(self, "_tab_cache", None)
+        if cached is not None and cached[0] is inputs and len(inputs) == cached[3]:
+            tptrs, tshapes = cached[1], cached[2]  # same table list object as last time (hundreds of tables)
+        else:
+            tptrs = (C.c_void_p * max(1, len(inputs)))(*[t.data_ptr() for t in inputs])
+            tshapes = np.asarray([d for t in inputs for d in t.shape], np.int32)
+            self._tab_cache = (inputs, tptrs, tshapes, len(inputs))
         if stream is None:
             stream = torch.cuda.current_stream(self.device).cuda_stream
         state, alloc_cb, alloc_temp_cb = self._allocators()
@@ -200,6 +205,27 @@ class FeatureColumnProcess:
             None if sym is None else sym.ctypes.data_as(C.POINTER(C.c_int32)),
             stream, alloc_temp_cb, None, alloc_cb, None)
         return a, (offs, shps, sym, tptrs, tshapes, state, alloc_cb, alloc_temp_cb)
+
+    def groups_only(self, concated_inputs, concated_offsets, concated_shapes, inputs, symbols=None,
+                    stream: Optional[int] = None) -> list:
+        """Lean call: returns only the per-group concat matrices (no per-column pointer /
+        shape arrays are materialised in Python).  FCP_LAYOUT_CONCAT plans only."""
+        torch = self.torch
+        a, keep = self._args(concated_inputs, concated_offsets, concated_shapes, inputs, symbols, stream)
+        g = self.spec.n_groups
+        _grp_ptrs = (C.c_void_p * g)()
+        _grp_shapes = (C.c_int32 * (2 * g))()
+        res = _lib.ProcessResult(None, None, None, _grp_ptrs, _grp_shapes, None, 0)
+        _lib.check(self._L.fcp_process_feature_columns(self.plan.handle, C.byref(a), C.byref(res)),
+                   "FeatureColumnProcess")
+        arena = keep[5]["arena"]
+        f = arena.view(torch.float32)
+        out = []
+        for gi in range(g):
+            rows, width = _grp_shapes[2 * gi], _grp_shapes[2 * gi + 1]
+            off = ((_grp_ptrs[gi] or arena.data_ptr()) - arena.data_ptr()) // 4
+            out.append(f[off:off + rows * width].view(rows, width))
+        return out
 
     def __call__(self, concated_inputs, concated_offsets, concated_shapes, inputs, symbols=None,
                  stream: Optional[int] = None) -> ProcessOutputs:

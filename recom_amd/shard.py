@@ -103,7 +103,7 @@ class ShardedFeatureColumns:
         op, tables = self.op, self.tables
 
         def partial():
-            return op(d_blob, offsets, shapes, tables, symbols).groups[group]
+            return op.groups_only(d_blob, offsets, shapes, tables, symbols)[group]
 
         def finalize(slices, begin, count):
             return op.shard_finalize(d_blob, offsets, shapes, tables, symbols, group, slices.contiguous(),
