@@ -855,7 +855,7 @@ int fcp_process_feature_columns(fcp_plan_t *p, const fcp_process_args_t *a, fcp_
   if (m.arena_bytes > 0 && !a->concated_inputs && !p->ranks.empty())
     return fail(FCP_ERR_INVALID_ARGUMENT, "null blob");
 
-  void *arena = a->malloc_buff(a->malloc_buff_ctx, (size_t)std::max<int64_t>(m.arena_bytes, 1));
+  void *arena = a->malloc_buff(a->malloc_buff_ctx, (size_t)std::max<int64_t>(m.arena_bytes, 128)); // never a zero-size request
   if (!arena) return fail(FCP_ERR_ALLOC, "malloc_buff returned NULL");
 
   FcpLaunch L;

@@ -375,3 +375,65 @@ def test_request_stager_matches_concat_inputs_and_feeds_the_kernel(torch_cuda, o
         want, _ = oracle.process_feature_columns(m.spec.to_dict(), blob, offsets, shapes, tabs_np, req.symbols)
         assert np.array_equal(out.groups[0].cpu().numpy(), want[0])
     st.close()
+
+
+def test_empty_batch(torch_cuda, oracle):
+    """A request with zero rows: nothing is launched, shapes are still reported."""
+    from recom_amd import synth
+    m = synth.model_mixed(batch=0, vocab=97, n_groups=1)
+    tabs = m.numpy_tables()
+    req = m.make_request(0)
+    out, packed, _ = run_gpu(torch_cuda, m.spec, req.inputs, tabs, req.symbols)
+    assert out.groups[0].shape == (0, m.spec.group_width(0))
+    assert all(int(x) == 0 for x in out.output_shapes[0::2])
+    d = synth.model_s2(columns=5, vocab=50, batch=0)
+    req = d.make_request(0)
+    out, _, _ = run_gpu(torch_cuda, d.spec, req.inputs, d.numpy_tables(), req.symbols)
+    assert out.groups[0].shape[0] == 0
+
+
+def test_wide_columns_and_large_boundary_lists(torch_cuda, oracle):
+    """A 1024-wide column spans four 1-KiB spans; 3000 boundaries exceed the 1024-float
+    LDS staging area (the search then runs from global memory); dim-4 columns put 64
+    columns into one span."""
+    from recom_amd.plan import (COMBINER_MEAN, COMBINER_NONE, FORM_GATHER, FORM_SEGMENT_REDUCE, IDS_F32_BUCKETIZE,
+                                IDS_I64, ROWS_FROM_IDS, ROWS_FROM_SYMBOL, SEG_CSR_I32, SEG_NONE, ColumnSpec, PlanSpec)
+    rng = np.random.default_rng(5)
+    B = 37
+    bnd = np.sort(rng.uniform(-100, 100, 3000)).astype(np.float32)
+    cols, ranks, esz, tables, inputs = [], [], [], [], []
+
+    def add_input(a):
+        inputs.append(a)
+        ranks.append(a.ndim)
+        esz.append(a.dtype.itemsize)
+        return len(inputs) - 1
+
+    slot = 0
+    tables.append(rng.standard_normal((50, 1024)).astype(np.float32))  # wide gather column
+    cols.append(ColumnSpec(FORM_GATHER, 1024, 50, COMBINER_NONE, IDS_I64, 0, add_input(rng.integers(0, 50, B)), -1,
+                           SEG_NONE, 1, ROWS_FROM_IDS, 0, None, 0, slot))
+    slot += 1
+    tables.append(rng.standard_normal((3001, 8)).astype(np.float32))   # big boundary list
+    cols.append(ColumnSpec(FORM_GATHER, 8, 3001, COMBINER_NONE, IDS_F32_BUCKETIZE, 1,
+                           add_input(rng.uniform(-110, 110, B).astype(np.float32)), -1, SEG_NONE, 1, ROWS_FROM_IDS, 0,
+                           bnd, 0, slot))
+    slot += 1
+    for k in range(70):                                               # 70 dim-4 columns: >64 per span
+        tables.append(rng.standard_normal((20, 4)).astype(np.float32))
+        cols.append(ColumnSpec(FORM_GATHER, 4, 20, COMBINER_NONE, IDS_I64, 2 + k, add_input(rng.integers(0, 20, B)), -1,
+                               SEG_NONE, 1, ROWS_FROM_IDS, 0, None, 0, slot))
+        slot += 1
+    dense = PlanSpec(cols, ranks, esz, len(tables))
+    out, packed, _ = run_gpu(torch_cuda, dense, inputs, tables, None)
+    assert_equal_oracle(oracle, dense, packed, tables, None, out)
+    # the same columns behind the ragged kernel (one pooled column makes the plan non-dense)
+    lens = rng.integers(0, 5, B)
+    ids = rng.integers(0, 50, int(lens.sum()))
+    csr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    cols2 = list(cols) + [ColumnSpec(FORM_SEGMENT_REDUCE, 1024, 50, COMBINER_MEAN, IDS_I64, 0, len(inputs),
+                                     len(inputs) + 1, SEG_CSR_I32, 1, ROWS_FROM_SYMBOL, 0, None, 0, slot)]
+    mixed = PlanSpec(cols2, ranks + [1, 1], esz + [8, 4], len(tables), n_symbols=1)
+    sym = np.asarray([B], np.int32)
+    out, packed, _ = run_gpu(torch_cuda, mixed, inputs + [ids, csr], tables, sym)
+    assert_equal_oracle(oracle, mixed, packed, tables, sym, out)
