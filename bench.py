@@ -110,7 +110,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--workload", default="s2", choices=["s2", "dlrm", "ragged", "shard"])
+    ap.add_argument("--workload", default="s2", choices=["s2", "dlrm", "ragged", "shard", "e", "f"])
     ap.add_argument("--ids", default="uniform", choices=["uniform", "zipf"])
     ap.add_argument("--threads", type=int, default=1, help="serve_workers per GPU (reference harness flag)")
     ap.add_argument("--columns", type=int, default=0, help="override the column count (debug only)")
@@ -156,6 +156,8 @@ def main():
         model = synth.model_s2(columns=args.columns or 1000, dist=args.ids, **({'batch': args.batch} if args.batch else {}))
     elif args.workload == "dlrm":
         model = synth.model_dlrm()
+    elif args.workload in ("e", "f"):
+        model = synth.model_ae(args.workload, **({'batch': args.batch} if args.batch else {}))
     else:
         model = synth.model_ragged(columns=args.columns or 512, **({'batch': args.batch} if args.batch else {}),
                                    **({'vocab': args.vocab} if args.vocab else {}))

@@ -69,9 +69,13 @@ struct DynMeta {
   int64_t arena_bytes = 0;
   int64_t csr_arena_off = 0;
   int32_t max_seg_nnz = 0;
-  int32_t grid_blocks = 0;
-  int32_t rows_per_wave = 1;
-  FcpGroupLaunch groups[FCP_MAX_GROUPS];
+  // launch geometry per kernel kind: [0] dense kernel (spans whose columns all have exactly
+  // one source row per output row), [1] ragged kernel (spans with pooled / scatter / reduction columns)
+  struct Geo {
+    int32_t grid_blocks = 0;
+    int32_t rows_per_wave = 1;
+    FcpGroupLaunch groups[FCP_MAX_GROUPS];
+  } geo[2];
 };
 
 struct DynSlot {
@@ -102,7 +106,11 @@ struct fcp_plan {
   // pos_of[column] = pos.
   std::vector<int32_t> order, pos_of;
   int vec = 1;
-  bool dense_only = true;
+  bool dense_only = true;   // no span needs the ragged kernel
+  // hybrid dispatch: per group, the spans served by the dense kernel and by the ragged kernel
+  std::vector<uint32_t> span_list;                 // host copy of d_span_list
+  std::vector<int32_t> list_off[2], list_n[2];     // [kind][group]
+  uint32_t *d_span_list = nullptr;
   bool host_only = false;
   int32_t rank_sum = 0;
 
@@ -338,43 +346,45 @@ int compute_dyn(const fcp_plan *p, const int32_t *offsets, const int32_t *shapes
   cursor += csr_cursor * 4;
   m->arena_bytes = cursor;
 
-  // launch geometry
+  // launch geometry, one set per kernel kind
   int32_t max_rows = 0;
   for (int g = 0; g < ng; ++g) max_rows = std::max(max_rows, m->group_rows[g]);
-  int rpw = 1;
-  if (p->dense_only) {
-    // 4 rows per wave (16 per block) measured best on S2 at batch 512 and 2048:
-    // ~2 rounds of blocks de-phase the read and write bursts; 8 rows lose to the tail.
-    while (rpw < 4 && max_rows >= 32 * rpw) rpw *= 2; // >= 64 rows -> 4, 32..63 -> 2, < 32 -> 1
-    static const int forced = [] { // tuning aid: FCP_ROWS_PER_WAVE=1|2|4
-      const char *e = std::getenv("FCP_ROWS_PER_WAVE");
-      const int v = e ? std::atoi(e) : 0;
-      return (v == 1 || v == 2 || v == 4) ? v : 0;
-    }();
-    if (forced) rpw = forced;
-  } else {
-    rpw = 1; // ragged kernel: one row per wave (2 interleaved rows measured slower: 33.7 vs 31.6 us)
+  for (int kind = 0; kind < 2; ++kind) {
+    DynMeta::Geo &G2 = m->geo[kind];
+    int rpw = 1;
+    if (kind == 0) {
+      // 4 rows per wave (16 per block) measured best on S2 at batch 512 and 2048:
+      // ~2 rounds of blocks de-phase the read and write bursts; 8 rows lose to the tail.
+      while (rpw < 4 && max_rows >= 32 * rpw) rpw *= 2; // >= 64 rows -> 4, 32..63 -> 2, < 32 -> 1
+      static const int forced = [] { // tuning aid: FCP_ROWS_PER_WAVE=1|2|4
+        const char *e = std::getenv("FCP_ROWS_PER_WAVE");
+        const int v = e ? std::atoi(e) : 0;
+        return (v == 1 || v == 2 || v == 4) ? v : 0;
+      }();
+      if (forced) rpw = forced;
+    } // ragged kernel: one row per wave (2 interleaved rows measured slower: 33.7 vs 31.6 us)
+    G2.rows_per_wave = rpw;
+    int32_t blocks = 0;
+    for (int g = 0; g < ng; ++g) {
+      FcpGroupLaunch &G = G2.groups[g];
+      G.rows = m->group_rows[g];
+      G.nslots = p->group_nslots[g];
+      G.nlist = p->list_n[kind][g];
+      G.span_list_off = p->list_off[kind][g];
+      // listed spans are dealt to XCDs in groups of 8; fewer than 8 are not padded
+      // (nsp8 = -nlist selects the plain mapping in the kernels)
+      G.nsp8 = G.nlist >= 8 ? (G.nlist + 7) / 8 : -std::max(G.nlist, 1);
+      G.block_begin = blocks;
+      G.slot_map_off = p->group_map_off[g];
+      G.pad_ = 0;
+      const int rows_per_block = FCP_WAVES_PER_BLOCK * rpw;
+      const int64_t ntiles = ((int64_t)G.rows + rows_per_block - 1) / rows_per_block;
+      const int64_t nb = G.nlist == 0 ? 0 : (G.nsp8 > 0 ? 8ll * G.nsp8 : (int64_t)G.nlist) * ntiles;
+      if (blocks + nb > 0x7fffffff) return fail(FCP_ERR_UNSUPPORTED, "grid too large");
+      blocks += (int32_t)nb;
+    }
+    G2.grid_blocks = blocks;
   }
-  m->rows_per_wave = rpw;
-  int32_t blocks = 0;
-  for (int g = 0; g < ng; ++g) {
-    FcpGroupLaunch &G = m->groups[g];
-    G.rows = m->group_rows[g];
-    G.nslots = p->group_nslots[g];
-    const int nspans = (G.nslots + FCP_WAVE - 1) / FCP_WAVE;
-    // spans are dealt to XCDs in groups of 8; a group with fewer than 8 spans
-    // is not padded (nsp8 = -nspans selects the plain mapping in the kernels)
-    G.nsp8 = nspans >= 8 ? (nspans + 7) / 8 : -nspans;
-    G.block_begin = blocks;
-    G.slot_map_off = p->group_map_off[g];
-    G.pad_ = 0;
-    const int rows_per_block = FCP_WAVES_PER_BLOCK * rpw;
-    const int64_t ntiles = ((int64_t)G.rows + rows_per_block - 1) / rows_per_block;
-    const int64_t nb = (G.nsp8 > 0 ? 8ll * G.nsp8 : (int64_t)nspans) * ntiles;
-    if (blocks + nb > 0x7fffffff) return fail(FCP_ERR_UNSUPPORTED, "grid too large");
-    blocks += (int32_t)nb;
-  }
-  m->grid_blocks = blocks;
   return FCP_OK;
 }
 
@@ -388,6 +398,7 @@ void destroy_device(fcp_plan *p) {
   }
   if (p->fence) (void)hipEventDestroy(p->fence);
   if (p->d_slot_map) (void)hipFree(p->d_slot_map);
+  if (p->d_span_list) (void)hipFree(p->d_span_list);
   if (p->d_cols) (void)hipFree(p->d_cols);
   if (p->d_const) (void)hipFree(p->d_const);
   if (p->d_seg_cols) (void)hipFree(p->d_seg_cols);
@@ -409,21 +420,34 @@ int init_device(fcp_plan *p) {
       for (int s = 0; s < hc.d.dim / p->vec; ++s) map.push_back((uint32_t)pos);
     }
   }
+  HIP_TRY(hipMalloc(&p->d_span_list, std::max<size_t>(p->span_list.size(), 1) * sizeof(uint32_t)));
+  HIP_TRY(hipMemcpy(p->d_span_list, p->span_list.data(), p->span_list.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
   HIP_TRY(hipMalloc(&p->d_slot_map, std::max<size_t>(map.size(), 1) * sizeof(uint32_t)));
   HIP_TRY(hipMemcpy(p->d_slot_map, map.data(), map.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
   // const buffers (bucketize boundaries), each 128-byte aligned as the reference's
+  // identical boundary arrays (the usual case: hundreds of bucketized features with one
+  // boundary list) are stored once, so that neighbouring columns can share one LDS copy
   int64_t const_bytes = 0;
-  for (auto &hc : p->cols)
-    if (!hc.boundaries.empty()) {
+  std::vector<int> owners; // indices of columns whose array was stored
+  for (size_t k = 0; k < p->cols.size(); ++k) {
+    HostColumn &hc = p->cols[k];
+    if (hc.boundaries.empty()) continue;
+    for (int o : owners)
+      if (p->cols[o].boundaries == hc.boundaries) {
+        hc.const_off = p->cols[o].const_off;
+        break;
+      }
+    if (hc.const_off < 0) {
       hc.const_off = const_bytes;
       const_bytes += align128((int64_t)hc.boundaries.size() * 4);
+      owners.push_back((int)k);
     }
+  }
   if (const_bytes) {
     HIP_TRY(hipMalloc(&p->d_const, const_bytes));
-    for (auto &hc : p->cols)
-      if (hc.const_off >= 0)
-        HIP_TRY(hipMemcpy(p->d_const + hc.const_off, hc.boundaries.data(), hc.boundaries.size() * 4,
-                          hipMemcpyHostToDevice));
+    for (int o : owners)
+      HIP_TRY(hipMemcpy(p->d_const + p->cols[o].const_off, p->cols[o].boundaries.data(),
+                        p->cols[o].boundaries.size() * 4, hipMemcpyHostToDevice));
   }
   // static column records (tables are bound on the first request)
   p->h_cols.resize(nc);
@@ -576,8 +600,9 @@ int acquire_slot(fcp_plan *p, const fcp_process_args_t *a, DynSlot **out) {
   return FCP_OK;
 }
 
-void fill_launch(const fcp_plan *p, const DynSlot &s, const void *blob, void *arena, FcpLaunch *L) {
+void fill_launch(const fcp_plan *p, const DynSlot &s, int kind, const void *blob, void *arena, FcpLaunch *L) {
   L->slot_map = p->d_slot_map;
+  L->span_list = p->d_span_list;
   L->cols = p->d_cols;
   L->dyn = s.d_dyn;
   L->blob = static_cast<const char *>(blob);
@@ -587,8 +612,8 @@ void fill_launch(const fcp_plan *p, const DynSlot &s, const void *blob, void *ar
   L->shard_rank = p->desc.shard_rank;
   L->shard_world = p->desc.shard_world;
   L->n_groups = p->desc.n_groups;
-  L->rows_per_wave = s.meta.rows_per_wave;
-  for (int g = 0; g < p->desc.n_groups; ++g) L->groups[g] = s.meta.groups[g];
+  L->rows_per_wave = s.meta.geo[kind].rows_per_wave;
+  for (int g = 0; g < p->desc.n_groups; ++g) L->groups[g] = s.meta.geo[kind].groups[g];
 }
 
 } // namespace
@@ -700,7 +725,6 @@ int fcp_plan_create(const fcp_plan_desc_t *desc, fcp_plan_t **out) {
     hc.d.boundaries = nullptr;
     if (hc.d.dim % 4) gcd4 = (hc.d.dim % 2) ? 1 : std::min(gcd4, 2);
     const int f = hc.d.form;
-    if (f != FCP_FORM_GATHER && f != FCP_FORM_PASSTHROUGH) p->dense_only = false;
     if ((f == FCP_FORM_SEGMENT_REDUCE || f == FCP_FORM_GATHER_SCATTER) && hc.d.seg_kind != FCP_SEG_CSR_I32)
       p->seg_cols.push_back(k);
   }
@@ -744,6 +768,30 @@ int fcp_plan_create(const fcp_plan_desc_t *desc, fcp_plan_t **out) {
   }
   p->pos_of.assign(desc->n_columns, 0);
   for (int pos = 0; pos < desc->n_columns; ++pos) p->pos_of[p->order[pos]] = pos;
+  // hybrid dispatch: classify every 64-slot span of every group
+  for (int kind = 0; kind < 2; ++kind) {
+    p->list_off[kind].assign(ng, -1);
+    p->list_n[kind].assign(ng, 0);
+  }
+  p->dense_only = true;
+  for (int g = 0; g < ng; ++g) {
+    const int nspans = (p->group_nslots[g] + FCP_WAVE - 1) / FCP_WAVE;
+    std::vector<char> ragged(nspans, 0);
+    for (int k = 0; k < desc->n_columns; ++k) {
+      const HostColumn &hc = p->cols[k];
+      if (hc.d.concat_group != g) continue;
+      if (hc.d.form == FCP_FORM_GATHER || hc.d.form == FCP_FORM_PASSTHROUGH) continue;
+      const int s0 = hc.out_off / p->vec / FCP_WAVE, s1 = (hc.out_off + hc.d.dim - 1) / p->vec / FCP_WAVE;
+      for (int sp = s0; sp <= s1 && sp < nspans; ++sp) ragged[sp] = 1;
+    }
+    for (int kind = 0; kind < 2; ++kind) {
+      p->list_off[kind][g] = (int32_t)p->span_list.size();
+      for (int sp = 0; sp < nspans; ++sp)
+        if (ragged[sp] == kind) p->span_list.push_back((uint32_t)sp);
+      p->list_n[kind][g] = (int32_t)p->span_list.size() - p->list_off[kind][g];
+    }
+    if (p->list_n[1][g] > 0) p->dense_only = false;
+  }
   if (!p->host_only) {
     rc = init_device(p);
     if (rc) {
@@ -859,7 +907,7 @@ int fcp_process_feature_columns(fcp_plan_t *p, const fcp_process_args_t *a, fcp_
   if (!arena) return fail(FCP_ERR_ALLOC, "malloc_buff returned NULL");
 
   FcpLaunch L;
-  fill_launch(p, *slot, a->concated_inputs, arena, &L);
+  fill_launch(p, *slot, 1, a->concated_inputs, arena, &L);
   if (!p->seg_cols.empty()) {
     FcpSegLaunch S;
     S.seg_cols = p->d_seg_cols;
@@ -871,8 +919,20 @@ int fcp_process_feature_columns(fcp_plan_t *p, const fcp_process_args_t *a, fcp_
     const int e = fcp_launch_segment_offsets(S, (int)p->seg_cols.size(), m.max_seg_nnz, stream);
     if (e) return hip_fail("segment-offsets launch", (hipError_t)e);
   }
-  const int e = fcp_launch_fused(L, p->vec, p->dense_only, m.grid_blocks, stream);
-  if (e) return hip_fail("fused kernel launch", (hipError_t)e);
+  // hybrid dispatch: spans with pooled columns -> ragged body, all other spans -> dense body
+  if (m.geo[1].grid_blocks > 0 && m.geo[0].grid_blocks > 0) {
+    FcpLaunch Ld;
+    fill_launch(p, *slot, 0, a->concated_inputs, arena, &Ld);
+    const int e = fcp_launch_hybrid(Ld, m.geo[0].grid_blocks, L, m.geo[1].grid_blocks, p->vec, stream);
+    if (e) return hip_fail("hybrid kernel launch", (hipError_t)e);
+  } else if (m.geo[1].grid_blocks > 0) {
+    const int e = fcp_launch_fused(L, p->vec, false, m.geo[1].grid_blocks, stream);
+    if (e) return hip_fail("ragged kernel launch", (hipError_t)e);
+  } else if (m.geo[0].grid_blocks > 0) {
+    fill_launch(p, *slot, 0, a->concated_inputs, arena, &L);
+    const int e = fcp_launch_fused(L, p->vec, true, m.geo[0].grid_blocks, stream);
+    if (e) return hip_fail("dense kernel launch", (hipError_t)e);
+  }
   if (slot->need_done) { // first kernel on freshly uploaded descriptors: lets a later upload reuse the slot precisely
     HIP_TRY(hipEventRecord(slot->done, stream));
     slot->need_done = false;
@@ -953,7 +1013,7 @@ int fcp_shard_finalize(fcp_plan_t *p, const fcp_process_args_t *a, int32_t group
     scratch = a->malloc_temp(a->malloc_temp_ctx, (size_t)std::max<int64_t>(bytes, 1));
     if (!scratch) return fail(FCP_ERR_ALLOC, "malloc_temp returned NULL");
   }
-  fill_launch(p, *slot, a->concated_inputs, scratch, &L);
+  fill_launch(p, *slot, 1, a->concated_inputs, scratch, &L);
   L.csr_arena_off = 0;
   if (need_csr) {
     FcpSegLaunch S;

@@ -53,14 +53,17 @@ struct FcpColDyn {         // 48 bytes
 struct FcpGroupLaunch {
   int32_t rows;            // prefix size of the group
   int32_t nslots;          // concat row width in V-element slots
-  int32_t nsp8;            // ceil(nspans / 8): spans per XCD; or -nspans when nspans < 8 (no XCD padding)
+  int32_t nsp8;            // ceil(nlist / 8): listed spans per XCD; or -nlist when nlist < 8 (no XCD padding)
   int32_t block_begin;     // first block of this group in the grid
   int32_t slot_map_off;    // offset of the group's slot map
+  int32_t span_list_off;   // offset into FcpLaunch::span_list of the spans this launch covers, or -1: all spans
+  int32_t nlist;           // number of spans this launch covers in this group
   int32_t pad_;
 };
 
 struct FcpLaunch {
   const uint32_t *slot_map;  // slot -> column index
+  const uint32_t *span_list; // span indices per (group, kernel kind): hybrid dense / ragged dispatch
   const FcpColStatic *cols;
   const FcpColDyn *dyn;
   const char *blob;
@@ -85,7 +88,9 @@ struct FcpSegLaunch {
 
 // ---- launchers implemented in fcp_kernels.hip --------------------------------
 struct ihipStream_t;
-int fcp_launch_fused(const FcpLaunch &L, int vec, bool dense_only, int grid_blocks, ihipStream_t *s);
+int fcp_launch_fused(const FcpLaunch &L, int vec, bool dense_kernel, int grid_blocks, ihipStream_t *s);
+int fcp_launch_hybrid(const FcpLaunch &Ldense, int dense_blocks, const FcpLaunch &Lragged, int ragged_blocks, int vec,
+                      ihipStream_t *s);
 int fcp_launch_upload(const void *host_mapped_src, void *dst, size_t bytes, ihipStream_t *s);
 int fcp_launch_segment_offsets(const FcpSegLaunch &L, int n_seg_cols, int max_nnz, ihipStream_t *s);
 int fcp_launch_concat_outputs(const void *const *inputs, const int32_t *dims, int32_t n,

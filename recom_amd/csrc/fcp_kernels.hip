@@ -219,8 +219,7 @@ struct BlockPos {
   const uint32_t *map;
 };
 
-template <int RB> __device__ __forceinline__ bool locate_block(const FcpLaunch &L, BlockPos &B) {
-  int bid = blockIdx.x;
+template <int RB> __device__ __forceinline__ bool locate_block(const FcpLaunch &L, int bid, BlockPos &B) {
   int g = 0;
   for (int k = 1; k < L.n_groups; ++k)
     if (bid >= L.groups[k].block_begin) g = k;
@@ -231,18 +230,21 @@ template <int RB> __device__ __forceinline__ bool locate_block(const FcpLaunch &
   bid -= L.groups[g].block_begin;
   // XCD-aware mapping: blocks with equal (bid & 7) share an XCD under the
   // round-robin dispatch; give them the same spans (same columns / tables).
-  int span, tile;
+  int idx, tile; // idx: position in the list of spans this launch covers
   if (nsp8 > 0) {
     const int xcd = bid & 7, j8 = bid >> 3;
-    span = (j8 % nsp8) * 8 + xcd;
+    idx = (j8 % nsp8) * 8 + xcd;
     tile = j8 / nsp8;
-  } else { // fewer than 8 spans: no padding to 8 (nsp8 = -nspans)
-    span = bid % (-nsp8);
+  } else { // fewer than 8 spans: no padding to 8 (nsp8 = -nlist)
+    idx = bid % (-nsp8);
     tile = bid / (-nsp8);
   }
+  if (idx >= L.groups[g].nlist) return false; // uniform: whole block leaves
+  const int lo = L.groups[g].span_list_off;
+  const int span = lo >= 0 ? (int)L.span_list[lo + idx] : idx;
   B.q0 = span * FCP_WAVE;
   B.row_blk = tile * RB;
-  if (B.q0 >= B.nslots || B.row_blk >= B.rows) return false; // uniform: whole block leaves
+  if (B.q0 >= B.nslots || B.row_blk >= B.rows) return false;
   B.first_col = B.map[B.q0];
   B.ncols = (int)(B.map[min(B.q0 + FCP_WAVE - 1, B.nslots - 1)] - B.first_col) + 1;
   return true;
@@ -272,17 +274,25 @@ template <int RB> __device__ __forceinline__ bool locate_block(const FcpLaunch &
 // with rocprofv3 — about half of the kernel time queueing on the same in-flight
 // cache lines (profiles/r01_s2_pmc_before_lds_staging.txt).
 // ---------------------------------------------------------------------------
+template <int R> struct DenseLds {
+  static constexpr int RB = FCP_WAVES_PER_BLOCK * R; // rows per block
+  static constexpr int IDS = RB + 1;                 // padded row of the offset tile (LDS banks)
+  static constexpr int BND = 1024;                   // floats of bucketize boundaries staged per block
+  LdsCol col[FCP_WAVE];
+  uint32_t off[FCP_WAVE * IDS];
+  float bnd[BND];
+};
+
 template <int V, int R, bool SHARDED>
-__global__ void __launch_bounds__(FCP_BLOCK_THREADS) fcp_dense_kernel(const FcpLaunch L) {
-  constexpr int RB = FCP_WAVES_PER_BLOCK * R; // rows per block
-  constexpr int IDS = RB + 1;                 // padded row of the offset tile (LDS banks)
-  constexpr int BND = 1024;                   // floats of bucketize boundaries staged per block
-  __shared__ LdsCol s_col[FCP_WAVE];
-  __shared__ uint32_t s_off[FCP_WAVE * IDS];
-  __shared__ float s_bnd[BND];
+__device__ __forceinline__ void dense_body(const FcpLaunch &L, int bid, char *smem) {
+  constexpr int RB = DenseLds<R>::RB, IDS = DenseLds<R>::IDS, BND = DenseLds<R>::BND;
+  DenseLds<R> &S = *reinterpret_cast<DenseLds<R> *>(smem);
+  LdsCol *s_col = S.col;
+  uint32_t *s_off = S.off;
+  float *s_bnd = S.bnd;
 
   BlockPos B;
-  if (!locate_block<RB>(L, B)) return;
+  if (!locate_block<RB>(L, bid, B)) return;
   const int tid = threadIdx.x;
   const int lane = tid & (FCP_WAVE - 1);
   const int wave = tid >> 6;
@@ -319,19 +329,25 @@ __global__ void __launch_bounds__(FCP_BLOCK_THREADS) fcp_dense_kernel(const FcpL
                       FCP_F_FORM(s_col[tid].flags) != FCP_FORM_PASSTHROUGH;
   if (__syncthreads_or(my_bkt)) {
     if (wave == 0) {
-      const int nb = my_bkt ? s_col[lane].n_boundaries : 0;
+      // neighbouring columns that share one boundary array (deduplicated at plan
+      // creation) stage it once: only the first lane of a run contributes
+      const float *mine = my_bkt ? s_col[lane].boundaries : nullptr;
+      const float *prev = reinterpret_cast<const float *>(__shfl_up((unsigned long long)mine, 1));
+      const bool leader = my_bkt && (lane == 0 || prev != mine);
+      const int nb_all = my_bkt ? s_col[lane].n_boundaries : 0;
+      const int nb = leader ? nb_all : 0;
       int incl = nb;
 #pragma unroll
       for (int d = 1; d < FCP_WAVE; d <<= 1) {
         const int up = __shfl_up(incl, d);
         if (lane >= d) incl += up;
       }
-      if (nb > 0 && incl <= BND) s_col[lane].bnd_off = incl - nb;
+      if (nb_all > 0 && incl <= BND && incl >= nb_all) s_col[lane].bnd_off = incl - nb_all; // followers: their leader's slice
     }
     __syncthreads();
     for (int j = 0; j < B.ncols; ++j) {
       const int off = s_col[j].bnd_off;
-      if (off < 0) continue;
+      if (off < 0 || (j > 0 && s_col[j - 1].bnd_off == off)) continue; // already staged by the run's leader
       const FCP_GLOBAL float *src = as_global(s_col[j].boundaries);
       for (int i = tid; i < s_col[j].n_boundaries; i += FCP_BLOCK_THREADS) s_bnd[off + i] = src[i];
     }
@@ -401,6 +417,12 @@ __global__ void __launch_bounds__(FCP_BLOCK_THREADS) fcp_dense_kernel(const FcpL
   }
 }
 
+template <int V, int R, bool SHARDED>
+__global__ void __launch_bounds__(FCP_BLOCK_THREADS) fcp_dense_kernel(const FcpLaunch L) {
+  __shared__ __attribute__((aligned(16))) char smem[sizeof(DenseLds<R>)];
+  dense_body<V, R, SHARDED>(L, blockIdx.x, smem);
+}
+
 // ---------------------------------------------------------------------------
 // Ragged kernel: any mix of column forms (dynamic shapes: multi-hot bags of
 // variable length, scatter columns, passthrough, Sum(axis=1)).
@@ -426,21 +448,30 @@ __global__ void __launch_bounds__(FCP_BLOCK_THREADS) fcp_dense_kernel(const FcpL
 // VALU per wave before this layout), hence the pre-scaled 32-bit slot offsets:
 // a table read costs one LDS read, one compare, one 64-bit shift-add, one load.
 // ---------------------------------------------------------------------------
+struct RaggedLds {
+  static constexpr int RB = FCP_WAVES_PER_BLOCK; // rows per block, one per wave
+  static constexpr int NP = FCP_WAVE * RB;       // (column, row) pairs per block, at most (= 256 threads)
+  static constexpr int CAP = 1536;               // staged slot offsets per block
+  LdsCol col[FCP_WAVE];
+  int32_t lo[NP], cnt[NP];
+  int32_t offx[NP];                              // exclusive scan of the staged counts
+  uint32_t ids[CAP];
+  uint16_t owner[CAP];                           // staged id slot -> its (column, row) pair
+  int32_t wsum[FCP_WAVES_PER_BLOCK];
+};
+
 template <int V, bool SHARDED>
-__global__ void __launch_bounds__(FCP_BLOCK_THREADS) fcp_ragged_kernel(const FcpLaunch L) {
-  constexpr int RB = FCP_WAVES_PER_BLOCK; // rows per block, one per wave
-  constexpr int NP = FCP_WAVE * RB;       // (column, row) pairs per block, at most (= 256 threads)
-  constexpr int CAP = 1536;               // staged slot offsets per block
+__device__ __forceinline__ void ragged_body(const FcpLaunch &L, int bid, char *smem) {
+  constexpr int RB = RaggedLds::RB, NP = RaggedLds::NP, CAP = RaggedLds::CAP;
   constexpr int LONG_BAG = 64;
-  __shared__ LdsCol s_col[FCP_WAVE];
-  __shared__ int32_t s_lo[NP], s_cnt[NP];
-  __shared__ int32_t s_offx[NP];          // exclusive scan of the staged counts
-  __shared__ uint32_t s_ids[CAP];
-  __shared__ uint16_t s_owner[CAP];       // staged id slot -> its (column, row) pair
-  __shared__ int32_t s_wsum[FCP_WAVES_PER_BLOCK];
+  RaggedLds &S = *reinterpret_cast<RaggedLds *>(smem);
+  LdsCol *s_col = S.col;
+  int32_t *s_lo = S.lo, *s_cnt = S.cnt, *s_offx = S.offx, *s_wsum = S.wsum;
+  uint32_t *s_ids = S.ids;
+  uint16_t *s_owner = S.owner;
 
   BlockPos B;
-  if (!locate_block<RB>(L, B)) return;
+  if (!locate_block<RB>(L, bid, B)) return;
   const int tid = threadIdx.x;
   const int lane = tid & (FCP_WAVE - 1);
   const int wave = tid >> 6;
@@ -600,6 +631,38 @@ __global__ void __launch_bounds__(FCP_BLOCK_THREADS) fcp_ragged_kernel(const Fcp
   st_out<V>(reinterpret_cast<float *>(L.arena + C.out_base) + e + (int64_t)b * C.out_stride, acc);
 }
 
+template <int V, bool SHARDED>
+__global__ void __launch_bounds__(FCP_BLOCK_THREADS) fcp_ragged_kernel(const FcpLaunch L) {
+  __shared__ __attribute__((aligned(16))) char smem[sizeof(RaggedLds)];
+  ragged_body<V, SHARDED>(L, blockIdx.x, smem);
+}
+
+// ---------------------------------------------------------------------------
+// Hybrid launch: plans that mix one-hot and pooled columns (the reference's models
+// E / F: ~98 % bucketize / hash one-hot columns plus a few multi-hot ones).  Spans
+// whose columns are all GATHER / PASSTHROUGH run the dense body, the other spans
+// the ragged body — in ONE launch (block-uniform branch, one LDS buffer carved by
+// either body), because these models are launch-latency bound: as separate
+// dependent launches they cost 27.6 us per request, see DESIGN.md.
+// ---------------------------------------------------------------------------
+struct FcpHybridLaunch {
+  FcpLaunch ragged; // blocks [0, ragged_blocks)
+  FcpLaunch dense;  // blocks [ragged_blocks, grid)
+  int32_t ragged_blocks;
+};
+
+template <int V, int R, bool SHARDED>
+__global__ void __launch_bounds__(FCP_BLOCK_THREADS) fcp_hybrid_kernel(const FcpHybridLaunch H) {
+  constexpr size_t kSmem = sizeof(RaggedLds) > sizeof(DenseLds<R>) ? sizeof(RaggedLds) : sizeof(DenseLds<R>);
+  __shared__ __attribute__((aligned(16))) char smem[kSmem];
+  const int bid = blockIdx.x;
+  if (bid < H.ragged_blocks) {
+    ragged_body<V, SHARDED>(H.ragged, bid, smem); // the longer-running blocks are dispatched first
+  } else {
+    dense_body<V, R, SHARDED>(H.dense, bid - H.ragged_blocks, smem);
+  }
+}
+
 // ---------------------------------------------------------------------------
 // Segment-offset pre-pass: sorted segment ids -> CSR offsets[0..rows]
 // (experiment::ComputeSegmentOffsets, cuda_emitter.cc:768-818: position idx
@@ -752,14 +815,14 @@ __global__ void __launch_bounds__(FCP_BLOCK_THREADS) fcp_upload_kernel(const uin
   } while (0)
 
 // rows_per_wave: dense 1 | 2 | 4 (rows per block = 4 x that); ragged always 1.
-int fcp_launch_fused(const FcpLaunch &L, int vec, bool dense_only, int grid_blocks, ihipStream_t *s) {
+int fcp_launch_fused(const FcpLaunch &L, int vec, bool dense_kernel, int grid_blocks, ihipStream_t *s) {
   if (grid_blocks <= 0) return 0;
   // tuning aid: FCP_LDS_PAD=<bytes> of unused dynamic LDS caps the blocks per CU
   static const int lds_pad = [] {
     const char *e = getenv("FCP_LDS_PAD");
     return e ? atoi(e) : 0;
   }();
-  if (dense_only) {
+  if (dense_kernel) {
     const int R = L.rows_per_wave;
 #define FCP_DENSE_R(VV)                         \
   switch (R) {                                  \
@@ -784,6 +847,39 @@ int fcp_launch_fused(const FcpLaunch &L, int vec, bool dense_only, int grid_bloc
       FCP_LAUNCH_RAGGED(1);
     }
   }
+  return (int)hipGetLastError();
+}
+
+int fcp_launch_hybrid(const FcpLaunch &Ldense, int dense_blocks, const FcpLaunch &Lragged, int ragged_blocks, int vec,
+                      ihipStream_t *s) {
+  FcpHybridLaunch H;
+  H.ragged = Lragged;
+  H.dense = Ldense;
+  H.ragged_blocks = ragged_blocks;
+  const dim3 grid(dense_blocks + ragged_blocks), block(FCP_BLOCK_THREADS);
+  const bool sharded = Ldense.shard_world > 1;
+#define FCP_HYB(VV, RR)                                                                   \
+  do {                                                                                    \
+    if (sharded)                                                                          \
+      hipLaunchKernelGGL((fcp_hybrid_kernel<VV, RR, true>), grid, block, 0, s, H);        \
+    else                                                                                  \
+      hipLaunchKernelGGL((fcp_hybrid_kernel<VV, RR, false>), grid, block, 0, s, H);       \
+  } while (0)
+#define FCP_HYB_R(VV)                        \
+  switch (Ldense.rows_per_wave) {            \
+  case 4: FCP_HYB(VV, 4); break;             \
+  case 2: FCP_HYB(VV, 2); break;             \
+  default: FCP_HYB(VV, 1); break;            \
+  }
+  if (vec == 4) {
+    FCP_HYB_R(4)
+  } else if (vec == 2) {
+    FCP_HYB_R(2)
+  } else {
+    FCP_HYB_R(1)
+  }
+#undef FCP_HYB_R
+#undef FCP_HYB
   return (int)hipGetLastError();
 }
 

@@ -346,7 +346,52 @@ def model_mixed(batch: int = 33, vocab: int = 997, seed_dims: Sequence[int] = (4
     return m
 
 
+def model_ae(which: str = "E", batch: int = 512, large_rows: int = 1 << 23) -> SynthModel:
+    """The reference's own AE models E / F (``examples/python/dlrm.py:140-203``) in
+    post-rewrite form: E = (880, 50, 50, 15, 5), F = (1000, 90, 100, 7, 3) columns of
+    {bucketize(100 boundaries 0,5,..,495 -> 101 rows, dim 8, mean, 1 value/row),
+     hash-int (100 rows, dim 8, mean), hash-str (10 000 rows, dim 8, mean),
+     sparse hash-str (10 000 rows, dim 8, sum, 1-10 ids/row),
+     large sparse hash-str (2^23 rows, dim 32, sum, 1-10 ids/row)}.
+    Hashing / string splitting is CPU id preprocessing upstream of the path
+    (SURVEY.md §8f-3): ids arrive already hashed.  On MI355X the 1 GiB tables the
+    reference leaves on the CPU (256 MiB gate, ``fc_optimize_pass.cc:71``) stay on the GPU."""
+    counts = {"E": (880, 50, 50, 15, 5), "F": (1000, 90, 100, 7, 3)}[which.upper()]
+    b = _Builder()
+    slot = 0
+    for _ in range(counts[0]):
+        t = b.table(101, 8)
+        i = b.host_input(1, 4)
+        b.gens.append(lambda rng, B: [rng.integers(0, 100, size=B).astype(np.float32)])  # make_num_input
+        b.columns.append(ColumnSpec(FORM_GATHER, 8, 101, COMBINER_NONE, IDS_F32_BUCKETIZE, t, i, -1, SEG_NONE, 1,
+                                    ROWS_FROM_IDS, 0, MICROBENCH_BOUNDARIES, 0, slot))
+        slot += 1
+    for rows, n in ((100, counts[1]), (10_000, counts[2])):
+        for _ in range(n):
+            _add_dense(b, rows, 8, slot)
+            slot += 1
+    for rows, dim, n in ((10_000, 8, counts[3]), (large_rows, 32, counts[4])):
+        for _ in range(n):
+            t = b.table(rows, dim)
+            ids_in, seg_in = b.host_input(1, 8), b.host_input(2, 8)
+
+            def gen(rng, B, rows=rows):
+                lens = rng.integers(1, 11, size=B)  # random.randint(1, input_cols)
+                nnz = int(lens.sum())
+                r = np.repeat(np.arange(B, dtype=np.int64), lens)
+                pos = np.concatenate([np.arange(l, dtype=np.int64) for l in lens])
+                return [rng.integers(0, rows, size=nnz, dtype=np.int64), np.stack([r, pos], axis=1)]
+
+            b.gens.append(gen)
+            b.columns.append(ColumnSpec(FORM_SEGMENT_REDUCE, dim, rows, COMBINER_SUM, IDS_I64, t, ids_in, seg_in,
+                                        SEG_IDS_I64, 2, ROWS_FROM_SYMBOL, 0, None, 0, slot))
+            slot += 1
+    return _finish(f"AE-{which.upper()}", b, batch, n_symbols=1,
+                   description=f"reference model {which.upper()}: {counts} columns of bucketize/hash-int/hash-str/sparse/"
+                               f"large-sparse, B {batch}")
+
+
 MODELS = {
     "s1": model_s1, "s2": model_s2, "dlrm": model_dlrm, "ragged": model_ragged, "shard": model_shard,
-    "mixed": model_mixed,
+    "mixed": model_mixed, "e": lambda **kw: model_ae("E", **kw), "f": lambda **kw: model_ae("F", **kw),
 }

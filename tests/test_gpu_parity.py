@@ -437,3 +437,15 @@ def test_wide_columns_and_large_boundary_lists(torch_cuda, oracle):
     sym = np.asarray([B], np.int32)
     out, packed, _ = run_gpu(torch_cuda, mixed, inputs + [ids, csr], tables, sym)
     assert_equal_oracle(oracle, mixed, packed, tables, sym, out)
+
+
+def test_reference_ae_model_e_reduced(torch_cuda, oracle):
+    """The reference's own model E recipe (examples/python/dlrm.py:140-203), with the
+    2^23-row tables reduced so the oracle can hold them."""
+    from recom_amd import synth
+    m = synth.model_ae("E", batch=64, large_rows=50_000)
+    assert m.spec.n_columns == 1000 and m.spec.group_width(0) == 995 * 8 + 5 * 32
+    tabs = m.numpy_tables()
+    req = m.make_request(0)
+    out, packed, _ = run_gpu(torch_cuda, m.spec, req.inputs, tabs, req.symbols)
+    assert_equal_oracle(oracle, m.spec, packed, tabs, req.symbols, out)
