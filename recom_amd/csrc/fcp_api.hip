@@ -120,6 +120,7 @@ struct fcp_plan {
   char *d_const = nullptr;
   int32_t *d_seg_cols = nullptr;
   unsigned long long *d_bad = nullptr;
+  unsigned long long *d_stamps = nullptr; // diagnostic builds only (-DFCP_STAMPS)
   std::vector<const void *> bound_tables;
   bool tables_bound = false;
 
@@ -403,6 +404,7 @@ void destroy_device(fcp_plan *p) {
   if (p->d_const) (void)hipFree(p->d_const);
   if (p->d_seg_cols) (void)hipFree(p->d_seg_cols);
   if (p->d_bad) (void)hipFree(p->d_bad);
+  if (p->d_stamps) (void)hipFree(p->d_stamps);
 }
 
 int init_device(fcp_plan *p) {
@@ -482,6 +484,10 @@ int init_device(fcp_plan *p) {
     const char *mode = std::getenv("FCP_DYN_UPLOAD");
     p->host_writes_dyn = large_bar != 0 && !(mode && std::string(mode) == "kernel");
   }
+#if defined(FCP_STAMPS)
+  HIP_TRY(hipMalloc(&p->d_stamps, 4 * sizeof(unsigned long long) * 65536));
+  HIP_TRY(hipMemset(p->d_stamps, 0, 4 * sizeof(unsigned long long) * 65536));
+#endif
   for (auto &s : p->slots) {
     // rounded up to 16 bytes: the upload kernel moves uint4s
     const size_t dyn_bytes = (nc * sizeof(FcpColDyn) + 15) / 16 * 16;
@@ -608,6 +614,7 @@ void fill_launch(const fcp_plan *p, const DynSlot &s, int kind, const void *blob
   L->blob = static_cast<const char *>(blob);
   L->arena = static_cast<char *>(arena);
   L->bad_ids = p->d_bad;
+  L->stamps = p->d_stamps;
   L->csr_arena_off = s.meta.csr_arena_off;
   L->shard_rank = p->desc.shard_rank;
   L->shard_world = p->desc.shard_world;
@@ -1236,3 +1243,13 @@ int fcp_stager_destroy(fcp_stager_t *s) {
 }
 
 } // extern "C"
+
+#if defined(FCP_STAMPS)
+// diagnostic builds only: per-block timestamps of the LAST dense launch (4 x u64 per block, 100 MHz ticks)
+extern "C" int fcp_debug_read_stamps(fcp_plan_t *p, unsigned long long *out, int n_blocks) {
+  if (!p || !p->d_stamps || n_blocks > 65536) return FCP_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(out, p->d_stamps, 4 * sizeof(unsigned long long) * (size_t)n_blocks, hipMemcpyDeviceToHost));
+  return FCP_OK;
+}
+#endif

@@ -10,6 +10,7 @@
 //             [--warmup 50] [--threads 1] [--requests 16] [--ring 6] [--verify 1]
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdint>
@@ -26,6 +27,9 @@ extern "C" int fcp_harness_create(fcp_plan_t *, const fcp_process_args_t *, int,
 extern "C" int fcp_harness_run(fcp_harness *, int, double *, float *, float *);
 extern "C" int fcp_harness_destroy(fcp_harness *);
 extern "C" int fcp_harness_copy_probe(size_t, int, float *);
+#if defined(FCP_STAMPS)
+extern "C" int fcp_debug_read_stamps(fcp_plan_t *, unsigned long long *, int);
+#endif
 extern "C" int fcp_harness_bw_probe(int, size_t, int, float *);
 
 #define CHECK_HIP(e)                                                                        \
@@ -381,6 +385,40 @@ int main(int argc, char **argv) {
               "\"frac_of_8TBs\": %.4f}\n",
               columns, batch, table_bytes / 1e9, steps, threads, wall * 1e3 / (steps * threads), us, alg / 1e6,
               alg / (us * 1e-6) / 1e9, alg / (us * 1e-6) / 8e12);
+#if defined(FCP_STAMPS)
+  {
+    // per-block timeline of the last launch (diagnostic build)
+    const int nb = 8 * ((int)((width / 4 + 63) / 64 + 7) / 8) * ((batch + 15) / 16);
+    std::vector<unsigned long long> st(4 * (size_t)nb);
+    CHECK_FCP(fcp_debug_read_stamps(plan, st.data(), nb));
+    unsigned long long t0 = ~0ull, t1 = 0;
+    int live = 0;
+    for (int b = 0; b < nb; ++b)
+      if (st[4 * b + 3]) {
+        ++live;
+        t0 = std::min(t0, st[4 * b]);
+        t1 = std::max(t1, st[4 * b + 3]);
+      }
+    std::printf("stamps: %d live blocks, kernel span %.2f us (100 MHz ticks)\n", live, (t1 - t0) / 100.0);
+    // histogram of block begin / end times and mean phase durations in 2-us bins of begin time
+    const int nbins = (int)((t1 - t0) / 200) + 1;
+    std::vector<int> begins(nbins, 0), ends(nbins, 0);
+    std::vector<double> d_desc(nbins, 0), d_ids(nbins, 0), d_rows(nbins, 0);
+    for (int b = 0; b < nb; ++b) {
+      if (!st[4 * b + 3]) continue;
+      const int bb = (int)((st[4 * b] - t0) / 200), be = (int)((st[4 * b + 3] - t0) / 200);
+      ++begins[bb];
+      ++ends[be];
+      d_desc[bb] += (st[4 * b + 1] - st[4 * b]) / 100.0;
+      d_ids[bb] += (st[4 * b + 2] - st[4 * b + 1]) / 100.0;
+      d_rows[bb] += (st[4 * b + 3] - st[4 * b + 2]) / 100.0;
+    }
+    for (int i = 0; i < nbins; ++i)
+      std::printf("  t=%5.1f us  begin %5d  end %5d   mean us: desc %.2f ids %.2f rows+stores %.2f\n", i * 2.0, begins[i],
+                  ends[i], begins[i] ? d_desc[i] / begins[i] : 0, begins[i] ? d_ids[i] / begins[i] : 0,
+                  begins[i] ? d_rows[i] / begins[i] : 0);
+  }
+#endif
   CHECK_FCP(fcp_harness_destroy(h));
   CHECK_FCP(fcp_plan_destroy(plan));
   return 0;

@@ -69,6 +69,7 @@ struct FcpLaunch {
   const char *blob;
   char *arena;
   unsigned long long *bad_ids; // nullable
+  unsigned long long *stamps;  // diagnostic builds (-DFCP_STAMPS) only: 4 timestamps per block
   int64_t csr_arena_off;       // byte offset of the CSR scratch inside the arena
   int32_t shard_rank, shard_world;
   int32_t n_groups;

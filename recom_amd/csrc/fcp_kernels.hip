@@ -292,6 +292,9 @@ __device__ __forceinline__ void dense_body(const FcpLaunch &L, int bid, char *sm
   float *s_bnd = S.bnd;
 
   BlockPos B;
+#if defined(FCP_STAMPS) // diagnostic build: where does a block spend its time (never shipped)
+  const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
+#endif
   if (!locate_block<RB>(L, bid, B)) return;
   const int tid = threadIdx.x;
   const int lane = tid & (FCP_WAVE - 1);
@@ -303,6 +306,9 @@ __device__ __forceinline__ void dense_body(const FcpLaunch &L, int bid, char *sm
   // ---- phase 0 ----------------------------------------------------------------------
   if (tid < B.ncols) s_col[tid] = make_lds_col(L, L.cols[B.first_col + tid], L.dyn[B.first_col + tid]);
   __syncthreads();
+#if defined(FCP_STAMPS)
+  const unsigned long long t_desc = __builtin_amdgcn_s_memrealtime();
+#endif
 
   // ---- phase 1a: raw id words of this thread's (column, row) pairs ------------------------
   // issued before the boundary staging so that the two memory round trips overlap
@@ -378,6 +384,9 @@ __device__ __forceinline__ void dense_body(const FcpLaunch &L, int bid, char *sm
     s_off[j * IDS + r] = off;
   }
   __syncthreads();
+#if defined(FCP_STAMPS)
+  const unsigned long long t_ids = __builtin_amdgcn_s_memrealtime();
+#endif
   if (q >= B.nslots) return;
 
   // ---- phase 2: R table reads in flight per lane, then R coalesced stores -------------------
@@ -415,6 +424,16 @@ __device__ __forceinline__ void dense_body(const FcpLaunch &L, int bid, char *sm
     if (b < B.rows) st_out<V>(outp + (int64_t)b * ostride, v[r]);
 #endif
   }
+#if defined(FCP_STAMPS)
+  if (L.stamps && tid == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's row reads have landed, its stores are issued and acknowledged
+    unsigned long long *o = L.stamps + 4ull * bid;
+    o[0] = t_begin;
+    o[1] = t_desc;
+    o[2] = t_ids;
+    o[3] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
 }
 
 template <int V, int R, bool SHARDED>
