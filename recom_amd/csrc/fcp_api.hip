@@ -374,7 +374,8 @@ int compute_dyn(const fcp_plan *p, const int32_t *offsets, const int32_t *shapes
       G.span_list_off = p->list_off[kind][g];
       // listed spans are dealt to XCDs in groups of 8; fewer than 8 are not padded
       // (nsp8 = -nlist selects the plain mapping in the kernels)
-      G.nsp8 = G.nlist >= 8 ? (G.nlist + 7) / 8 : -std::max(G.nlist, 1);
+      static const bool no_xcd_map = std::getenv("FCP_NO_XCD_MAP") != nullptr; // tuning aid: plain span order
+      G.nsp8 = (G.nlist >= 8 && !no_xcd_map) ? (G.nlist + 7) / 8 : -std::max(G.nlist, 1);
       G.block_begin = blocks;
       G.slot_map_off = p->group_map_off[g];
       G.pad_ = 0;
