@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — BASELINE.json's metric on BASELINE.json's config.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload s2|dlrm|ragged|shard]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload s2|dlrm|ragged|shard|shard-col|e|f]
 
 A *step* is one request: one pass of the fused feature-column path (ids resident
 in HBM -> [batch, sum(dim)] concat output resident in HBM) over one batch of
@@ -10,9 +10,9 @@ dims 8/16/32/64, vocab 1M (120 GB of tables), batch 512, on 1 MI355X.
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): the path shards by
 requests — every rank serves its own requests on its own replica of the tables,
-no data-path collective ("weak" scaling).  Only `--workload shard` (tables larger
-than one GPU's HBM) row-shards the tables and exchanges partial sums with an RCCL
-all-to-all.
+no data-path collective ("weak" scaling).  Only `--workload shard` / `shard-col`
+(tables larger than one GPU's HBM) shard the tables — by rows (partial sums) or by
+columns (final column blocks) — and exchange with one RCCL all-to-all.
 
 The timed loop is native (recom_amd/csrc/fcp_harness.hip); rank 0 prints ONE JSON
 line.  `roofline.achieved` = algorithmic bytes per request (SURVEY.md §8d formula,
@@ -110,7 +110,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--workload", default="s2", choices=["s2", "dlrm", "ragged", "shard", "e", "f"])
+    ap.add_argument("--workload", default="s2", choices=["s2", "dlrm", "ragged", "shard", "shard-col", "e", "f"])
     ap.add_argument("--ids", default="uniform", choices=["uniform", "zipf"])
     ap.add_argument("--threads", type=int, default=1, help="serve_workers per GPU (reference harness flag)")
     ap.add_argument("--columns", type=int, default=0, help="override the column count (debug only)")
@@ -143,9 +143,9 @@ def main():
         else:
             dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
 
-    if args.workload == "shard":
+    if args.workload in ("shard", "shard-col"):
         from recom_amd.shard import bench_sharded
-        rec = bench_sharded(args, rank, world, local_rank, dist)
+        rec = bench_sharded(args, rank, world, local_rank, dist, mode="row" if args.workload == "shard" else "col")
         if rank == 0:
             print(json.dumps(rec))
         if dist:

@@ -162,6 +162,37 @@ class PlanSpec:
     def with_layout(self, layout: int) -> "PlanSpec":
         return dataclasses.replace(self, layout=layout)
 
+    def column_subset(self, keep: Sequence[int]) -> "SubPlan":
+        """Plan over the columns ``keep`` only (column-sharded serving: one such plan
+        per GPU).  Host inputs and tables are renumbered to the ones those columns
+        reference, in their original order; concat slots are kept, so the subset's
+        group matrix is the matching column block of the full one."""
+        keep = list(keep)
+        host, dev = set(), set()
+        for k in keep:
+            c = self.columns[k]
+            for i in (c.ids_input, c.seg_input):
+                if i >= 0:
+                    host.add(i)
+            if c.rows_source == ROWS_FROM_INPUT_DIM0:
+                host.add(c.rows_arg)
+            if c.table_input >= 0:
+                dev.add(c.table_input)
+        host_l, dev_l = sorted(host), sorted(dev)
+        hmap = {i: n for n, i in enumerate(host_l)}
+        dmap = {i: n for n, i in enumerate(dev_l)}
+        cols = []
+        for k in keep:
+            c = self.columns[k]
+            cols.append(dataclasses.replace(
+                c, ids_input=hmap.get(c.ids_input, -1), seg_input=hmap.get(c.seg_input, -1),
+                table_input=dmap.get(c.table_input, -1),
+                rows_arg=hmap[c.rows_arg] if c.rows_source == ROWS_FROM_INPUT_DIM0 else c.rows_arg))
+        spec = dataclasses.replace(self, columns=cols, host_input_ranks=[self.host_input_ranks[i] for i in host_l],
+                                   host_input_elem_sizes=[self.host_input_elem_sizes[i] for i in host_l],
+                                   n_device_inputs=len(dev_l))
+        return SubPlan(spec, keep, host_l, dev_l)
+
     # ---- roofline accounting (SURVEY.md §8d) --------------------------------
     def algorithmic_bytes(self, shapes: Sequence[int], symbols: Optional[Sequence[int]] = None) -> dict:
         """Algorithmic bytes of one request: table rows read + ids read + CSR
@@ -224,6 +255,16 @@ class PlanSpec:
         if rows is None:
             raise ValueError(f"group {group} has no columns")
         return rows
+
+
+@dataclass
+class SubPlan:
+    """Result of :meth:`PlanSpec.column_subset`: the sub-plan and which columns /
+    host inputs / tables of the full plan it uses (indices into the full plan)."""
+    spec: PlanSpec
+    columns: List[int]
+    host_inputs: List[int]
+    device_inputs: List[int]
 
 
 def id_numpy_dtype(id_source: int):

@@ -1,4 +1,5 @@
-"""Row-sharded tables across the GPUs of one node (BASELINE.json configs[4]).
+"""Tables sharded across the GPUs of one node (BASELINE.json configs[4]): by rows
+(:class:`RowShardedPath`) or by columns (:class:`ColumnShardedPath`).
 
 The reference has no multi-GPU code at all; this is the
 MI355X-native addition for models whose tables exceed one GPU's 288 GB HBM.
@@ -21,7 +22,7 @@ across replicas (``bench.py`` default).
 from __future__ import annotations
 
 import time
-from typing import Callable, List, Optional, Tuple
+from typing import Callable, List, Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -85,6 +86,106 @@ class RowShardedPath:
         return torch.cat([p[:c] for p, (_, c) in zip(parts, sl)], dim=0)
 
 
+def assign_columns(spec, world: int, weights: Optional[Sequence[float]] = None) -> List[List[int]]:
+    """Column (table-wise) sharding: split every concat group's columns, in concat
+    order, into ``world`` contiguous ranges of about equal weight (default weight:
+    ``dim`` — the HBM traffic per batch row, and the table bytes when vocabularies are
+    alike).  Contiguous in concat order, so rank ``g``'s result is one column block of
+    the group matrix.  Returns the column indices per rank (all groups)."""
+    out: List[List[int]] = [[] for _ in range(world)]
+    for g in range(spec.n_groups):
+        members = [k for _, k in sorted((c.concat_slot, k) for k, c in enumerate(spec.columns) if c.concat_group == g)]
+        if len(members) < world:
+            raise ValueError(f"group {g}: {len(members)} columns cannot be split over {world} ranks")
+        w = np.asarray([float(weights[k]) if weights is not None else float(spec.columns[k].dim) for k in members])
+        acc = np.concatenate([[0.0], np.cumsum(w)])
+        cuts = [0]
+        for r in range(1, world):
+            c = int(np.searchsorted(acc, acc[-1] * r / world, side="left"))
+            c = min(max(c, cuts[-1] + 1), len(members) - (world - r))  # every rank gets >= 1 column
+            cuts.append(c)
+        cuts.append(len(members))
+        for r in range(world):
+            out[r].extend(members[cuts[r]:cuts[r + 1]])
+    return out
+
+
+class ColumnShardedPath:
+    """Table-wise sharding (SURVEY.md §8e "cheaper alternative"): rank ``g`` owns whole
+    columns, pools them for the whole batch, and one all-to-all partitioned along the
+    batch hands rank ``h`` the rows ``rows_h`` of every rank's column block.  No
+    partial sums cross the wire, so every column — pooled ones included — is
+    bit-identical to the single-GPU result.  Valid while no single table exceeds one
+    GPU; row sharding (:class:`RowShardedPath`) covers the rest."""
+
+    def __init__(self, rank: int, world: int, group=None) -> None:
+        self.rank, self.world, self.group = rank, world, group
+
+    def exchange(self, block, widths: Sequence[int]):
+        """``block [rows, widths[rank]]`` -> list of ``world`` tensors
+        ``[count, widths[g]]`` (this rank's batch rows of every rank's block)."""
+        import torch
+        import torch.distributed as dist
+        rows, width = block.shape
+        assert width == widths[self.rank]
+        sl = batch_slices(rows, self.world)
+        begin, count = sl[self.rank]
+        if self.world == 1:
+            return [block], begin, count
+        recv = torch.empty(count * int(sum(widths)), dtype=block.dtype, device=block.device)
+        dist.all_to_all_single(recv, block.contiguous().view(-1),
+                               output_split_sizes=[count * int(w) for w in widths],
+                               input_split_sizes=[c * width for _, c in sl], group=self.group)
+        parts, pos = [], 0
+        for w in widths:
+            parts.append(recv[pos:pos + count * int(w)].view(count, int(w)))
+            pos += count * int(w)
+        return parts, begin, count
+
+    def run(self, block_fn: Callable, widths: Sequence[int], concat_fn: Callable):
+        parts, begin, count = self.exchange(block_fn(), widths)
+        return concat_fn(parts), begin, count
+
+
+class ColumnShardedFeatureColumns:
+    """GPU implementation: one plan per rank over the columns it owns; the final
+    ``[count, width]`` matrix is assembled by ``fcp_concat_outputs`` from the received
+    column blocks."""
+
+    def __init__(self, model, rank: int, world: int, device: int, group=None) -> None:
+        import torch
+        from .ops import FeatureColumnProcess
+        self.torch = torch
+        self.model = model
+        self.assignment = assign_columns(model.spec, world)
+        self.sub = model.spec.column_subset(self.assignment[rank])
+        self.dev = torch.device("cuda", device)
+        self.op = FeatureColumnProcess(self.sub.spec, device)
+        self.tables = self._tables(model)
+        self.path = ColumnShardedPath(rank, world, group)
+        self.widths = [[sum(model.spec.columns[k].dim for k in cols if model.spec.columns[k].concat_group == g)
+                        for cols in self.assignment] for g in range(model.spec.n_groups)]
+
+    def _tables(self, model):
+        from .synth import hash_table_torch
+        return [hash_table_torch(model.tables[i].seed, model.tables[i].vocab, model.tables[i].dim, self.dev)
+                for i in self.sub.device_inputs]
+
+    def request_inputs(self, inputs):
+        """The host tensors of a full request this rank needs."""
+        return [inputs[i] for i in self.sub.host_inputs]
+
+    def __call__(self, d_blob, offsets, shapes, symbols, group: int = 0):
+        from .ops import concat_outputs
+        op, tables = self.op, self.tables
+
+        def block():
+            return op.groups_only(d_blob, offsets, shapes, tables, symbols)[group]
+
+        return self.path.run(block, self.widths[group], lambda parts: concat_outputs(parts) if len(parts) > 1
+                             else parts[0])
+
+
 class ShardedFeatureColumns:
     """GPU implementation: one row-sharded plan per rank."""
 
@@ -112,20 +213,26 @@ class ShardedFeatureColumns:
         return self.path.run(partial, finalize)
 
 
-def bench_sharded(args, rank: int, world: int, local_rank: int, dist) -> dict:
-    """`bench.py --workload shard`: S2-shaped model with 500 columns per GPU
-    (60 GB of table rows per GPU; 4000 columns / 480 GB at 8 GPUs), tables
-    row-sharded, one all-to-all of partial sums per request."""
+def bench_sharded(args, rank: int, world: int, local_rank: int, dist, mode: str = "row") -> dict:
+    """`bench.py --workload shard` (mode "row") / `--workload shard-col` (mode "col"):
+    S2-shaped model with 500 columns per GPU (60 GB of table rows per GPU; 4000 columns
+    / 480 GB at 8 GPUs).  "row": tables row-sharded, one all-to-all of partial sums per
+    request + finalize.  "col": whole columns per GPU, one all-to-all of final column
+    blocks per request + concat."""
     import torch
     from . import synth
     from .ops import concat_inputs
 
     columns = args.columns or 500 * world
     model = synth.model_s2(columns=columns)
-    model.name = "SHARD"
-    sfc = ShardedFeatureColumns(model, rank, world, local_rank)
+    model.name = "SHARD" if mode == "row" else "SHARD-COL"
     reqs = [model.make_request(s) for s in range(8)]  # identical on every rank (ids replicated)
-    packed = [concat_inputs(r.inputs) for r in reqs]
+    if mode == "row":
+        sfc = ShardedFeatureColumns(model, rank, world, local_rank)
+        packed = [concat_inputs(r.inputs) for r in reqs]
+    else:
+        sfc = ColumnShardedFeatureColumns(model, rank, world, local_rank)
+        packed = [concat_inputs(sfc.request_inputs(r.inputs)) for r in reqs]
     blobs = [torch.from_numpy(p[0]).to(sfc.dev) for p in packed]
 
     def step(i):
@@ -153,21 +260,32 @@ def bench_sharded(args, rank: int, world: int, local_rank: int, dist) -> dict:
         elapsed = float(t.item())
     batch = model.batch
     width = model.spec.group_width(0)
-    bytes_alg = model.spec.algorithmic_bytes(packed[0][2], reqs[0].symbols)
-    # per-GPU algorithmic bytes: 1/world of the table rows, all ids, the partial
-    # [rows, width] written once, its slices sent / received, the final slice written
-    per_gpu = bytes_alg["rows"] / world + bytes_alg["ids"] + bytes_alg["boundaries"] + batch * width * 4 * (
-        1 + 2.0 * (world - 1) / world + 1.0 / world)
+    full_req = concat_inputs(reqs[0].inputs)
+    bytes_alg = model.spec.algorithmic_bytes(full_req[2], reqs[0].symbols)
+    if mode == "row":
+        # per-GPU algorithmic bytes: 1/world of the table rows, all ids, the partial
+        # [rows, width] written once, its slices sent / received, the final slice written
+        per_gpu = bytes_alg["rows"] / world + bytes_alg["ids"] + bytes_alg["boundaries"] + batch * width * 4 * (
+            1 + 2.0 * (world - 1) / world + 1.0 / world)
+        par = f"row-sharded x{world}, all_to_all_single of partial sums (RCCL)"
+    else:
+        # 1/world of the rows, ids and output; the block's remote slices sent / received,
+        # and (world > 1) the final [count, width] slice read + written by the concat
+        per_gpu = bytes_alg["total"] / world + batch * width * 4 / world * (
+            2.0 * (world - 1) / world + (2.0 if world > 1 else 0.0))
+        par = f"column-sharded x{world}, all_to_all_single of final column blocks (RCCL)"
     dev_s = e0.elapsed_time(e1) * 1e-3 / args.steps
     return {
-        "metric": "inference QPS, row-sharded tables (SHARD config)", "value": batch * args.steps / elapsed,
+        "metric": f"inference QPS, {'row' if mode == 'row' else 'column'}-sharded tables (SHARD config)",
+        "value": batch * args.steps / elapsed,
         "unit": "inferences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"SHARD: {model.description}; {columns} columns, tables row-sharded over {world} GPU(s)",
+        "config": {"workload": f"{model.name}: {model.description}; {columns} columns, tables "
+                               f"{'row' if mode == 'row' else 'column'}-sharded over {world} GPU(s)",
                    "batch": batch, "columns": columns, "table_bytes": model.table_bytes(),
-                   "parallelism": f"row-sharded x{world}, all_to_all_single of partial sums (RCCL)"},
+                   "parallelism": par},
         "roofline": {"bound": "hbm", "achieved": per_gpu / dev_s / 1e9, "peak": 8000.0, "unit": "GB/s",
                      "frac": per_gpu / dev_s / 1e9 / 8000.0, "traffic": None,
-                     "note": "per GPU, whole step (partial kernel + exchange + finalize), torch events on the compute stream"},
+                     "note": "per GPU, whole step (kernel + exchange + finalize/concat), torch events on the compute stream"},
     }

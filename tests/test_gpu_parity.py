@@ -287,6 +287,39 @@ def test_row_sharded_partials_and_finalize(torch_cuda, oracle):
             assert np.abs(a - b).max() < 1e-5
 
 
+def test_column_sharded_blocks_concat(torch_cuda, oracle):
+    """Column (table-wise) sharding on one GPU: world=3 sub-plans over whole columns
+    produce column blocks; the batch slices of the blocks, put side by side by
+    fcp_concat_outputs, are bit-identical to the unsharded result (pooled columns too)."""
+    from recom_amd import synth
+    from recom_amd.ops import FeatureColumnProcess, concat_inputs, concat_outputs
+    from recom_amd.shard import assign_columns, batch_slices
+    torch = torch_cuda
+    m = synth.model_mixed(batch=50, vocab=997, n_groups=1)
+    tabs_np = m.numpy_tables()
+    req = m.make_request(5)
+    full, _, _ = run_gpu(torch, m.spec, req.inputs, tabs_np, req.symbols)
+    world = 3
+    assignment = assign_columns(m.spec, world)
+    blocks = []
+    for rank in range(world):
+        sub = m.spec.column_subset(assignment[rank])
+        packed = concat_inputs([req.inputs[i] for i in sub.host_inputs])
+        tabs = [torch.from_numpy(tabs_np[i]).cuda() for i in sub.device_inputs]
+        op = FeatureColumnProcess(sub.spec, 0)
+        out = op(torch.from_numpy(packed[0]).cuda(), packed[1], packed[2], tabs, req.symbols)
+        torch.cuda.synchronize()
+        want, _ = oracle.process_feature_columns(sub.spec.to_dict(), *packed, [tabs_np[i] for i in sub.device_inputs],
+                                                 req.symbols)
+        assert np.array_equal(out.groups[0].cpu().numpy(), want[0])
+        blocks.append(out.groups[0].clone())
+    ref = full.groups[0].cpu().numpy()
+    for begin, count in batch_slices(ref.shape[0], world):
+        got = concat_outputs([b[begin:begin + count].contiguous() for b in blocks])
+        torch.cuda.synchronize()
+        assert np.array_equal(got.cpu().numpy(), ref[begin:begin + count])
+
+
 def test_dlrm_scaled_vs_oracle(torch_cuda, oracle):
     from recom_amd import synth
     cards = [min(c, 40000) for c in synth.CRITEO_KAGGLE_CARDINALITIES]

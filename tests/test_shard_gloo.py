@@ -96,3 +96,59 @@ def test_batch_slices():
     assert batch_slices(33, 2) == [(0, 17), (17, 16)]
     assert batch_slices(512, 8) == [(64 * r, 64) for r in range(8)]
     assert batch_slices(3, 4) == [(0, 1), (1, 1), (2, 1), (3, 0)]
+
+
+def _col_worker(rank, world, port, out_dir, case_name):
+    for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import fcp_oracle as O
+    from conftest import GoldenCase
+    from recom_amd.shard import ColumnShardedPath, assign_columns, batch_slices
+
+    z = np.load(os.path.join(ROOT, "tests", "golden", "fcp_golden.npz"))
+    case = GoldenCase(z, case_name)
+    orc = O.COracle()
+    spec = case.spec()
+    assignment = assign_columns(spec, world)
+    assert sorted(k for cols in assignment for k in cols) == list(range(spec.n_columns))
+    sub = spec.column_subset(assignment[rank])
+    sub.spec.validate()
+    blob, offsets, shapes = orc.concat_inputs([case.inputs[i] for i in sub.host_inputs])
+    tabs = [case.tables[i] for i in sub.device_inputs]
+    blocks, _ = orc.process_feature_columns(sub.spec.to_dict(), blob, offsets, shapes, tabs, case.symbols)
+    full, _ = orc.process_feature_columns(case.plan, case.blob, case.offsets, case.shapes, case.tables, case.symbols)
+    path = ColumnShardedPath(rank, world)
+    for g in range(spec.n_groups):
+        widths = [sum(spec.columns[k].dim for k in cols if spec.columns[k].concat_group == g) for cols in assignment]
+        assert sum(widths) == spec.group_width(g)
+        mine, begin, count = path.run(lambda: torch.from_numpy(blocks[g]), widths, lambda parts: torch.cat(parts, 1))
+        assert (begin, count) == batch_slices(full[g].shape[0], world)[rank]
+        # whole columns live on one rank: every column (pooled too) is bit-identical
+        assert np.array_equal(mine.numpy(), full[g][begin:begin + count]), f"rank {rank} group {g}"
+    open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,case", [(2, "mixed_s0"), (2, "mixed_s1"), (3, "ragged_edges")])
+def test_column_sharded_exchange_gloo(world, case, tmp_path):
+    mp.spawn(_col_worker, args=(world, _free_port(), str(tmp_path), case), nprocs=world, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(world))
+
+
+def test_assign_columns_balanced():
+    from recom_amd import synth
+    from recom_amd.shard import assign_columns
+    m = synth.model_s2(columns=1000)
+    a = assign_columns(m.spec, 8)
+    w = [sum(m.spec.columns[k].dim for k in cols) for cols in a]
+    assert sum(len(c) for c in a) == 1000 and max(w) - min(w) <= 64
+    offs = m.spec.column_offsets()
+    for cols in a:  # contiguous column block of the concat matrix
+        o = [offs[k] for k in cols]
+        assert o == sorted(o) and o[-1] + m.spec.columns[cols[-1]].dim - o[0] == sum(m.spec.columns[k].dim for k in cols)
+    with pytest.raises(ValueError):
+        assign_columns(synth.model_s1(columns=3).spec, 4)
