@@ -1,0 +1,415 @@
+"""Plan builder: rewritten GraphDef → column plan.
+
+The non-codegen half of the reference's ``CudaEmitter``: the same walk over every
+feature-column subgraph, but each column becomes one :class:`ColumnSpec` record the
+pre-compiled gfx950 kernels interpret, instead of a ``struct FCi`` of CUDA text.
+
+Input: the GraphDef the reference's emitter sees, i.e. after ``PreLookupOptimizer``
+/ ``LookupOptimizer`` brought every ``embedding_column`` to one of the canonical
+forms (``lookup_optimizer.cc:157-440``):
+
+* form 1 ``GatherV2(table, ids, 0)``                                  (``RewriteDenseInput`` ``:270-322``)
+* form 2 ``SparseSegment{Sum,Mean}WithNumSegments(table, ids, seg, n)`` (``RewriteSeedWithNumSegments`` ``:157-268``)
+* form 3 ``ScatterNd(rows, GatherV2(table, ids, 0), shape)``            (``RewriteGatherScatter`` ``:324-440``)
+* ``Sum(x, axis=1)`` (BatchColReduction, ``cuda_emitter.cc:1146-1149``)
+
+all converging on ``ConcatV2`` nodes (``cuda_emitter.cc:2543-2581``).
+
+What follows the reference, and where:
+
+* a table is a ``VariableV2`` / ``Const`` whose consumers (through ``Identity``) are
+  only ``*Gather*`` / ``SparseSegment*`` ops — ``graph_info.cc:209-259``;
+* the value node of a concat input is found through trailing ``Reshape`` /
+  ``ExpandDims`` / ``Squeeze`` nodes — ``FindFCOutputs`` ``cuda_emitter.cc:1060-1069``;
+* dispatch on the value node's op — ``EmitSubgraphCode`` ``:1096-1152``;
+* index inputs are followed through ``Reshape``-likes, ``Cast``, ``Bucketize`` and the
+  ``[:, 0:1]`` ``StridedSlice`` of a 2-D index matrix, and end at the first other node,
+  whose tensor becomes a ConcatInputs input — ``EmitInputInline`` ``:1769-1949``;
+* tables become FeatureColumnProcess device inputs, deduplicated by tensor name —
+  ``:1262-1279``;
+* the three ops that replace the subgraphs are wired as ``Rewrite`` ``:2496-2656``
+  does (:mod:`recom_amd.graph.rewrite`).
+
+Differences by design: a concat input that is not a lookup (the
+reference's ``host_inputs`` of ConcatOutputs) becomes a ``FORM_PASSTHROUGH`` column
+fed through ConcatInputs, so the concat matrix is written once by the fused kernel;
+row counts that the reference derives with SymEngine are *symbols* evaluated by
+ordinary TF ops in the rewritten graph (``symbols`` input of
+``FeatureColumnProcessWithSymbols``, ``cuda_emitter.cc:2446-2458``); there is no
+256 MiB table gate (``check_table_size`` ``:1080-1094``) — every table fits 288 GB.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+from ..plan import (COMBINER_MEAN, COMBINER_NONE, COMBINER_SUM, FORM_BATCH_COL_REDUCTION, FORM_GATHER,
+                    FORM_GATHER_SCATTER, FORM_PASSTHROUGH, FORM_SEGMENT_REDUCE, IDS_F32_BUCKETIZE, IDS_I32, IDS_I64,
+                    ROWS_FROM_IDS, ROWS_FROM_INPUT_DIM0, ROWS_FROM_SYMBOL, SEG_IDS_I32, SEG_IDS_I64, SEG_NONE,
+                    ColumnSpec, PlanSpec)
+from . import tf_proto as P
+from .view import GraphView, tensor_name
+
+RESHAPE_LIKE = ("Reshape", "ExpandDims", "Squeeze")          # IsReshape, cuda_emitter.cc:62-73
+SEGMENT_OPS = {"SparseSegmentSumWithNumSegments": COMBINER_SUM, "SparseSegmentMeanWithNumSegments": COMBINER_MEAN}
+_ELEM_SIZE = {P.DT_FLOAT: 4, P.DT_INT32: 4, P.DT_INT64: 8}
+
+
+class Unsupported(Exception):
+    """This subgraph is not one the fused path takes; the caller falls back."""
+
+
+@dataclass
+class IndexSource:
+    """Where an index operand really comes from (``EmitInputInline``)."""
+    tensor: str                 # graph tensor that ConcatInputs receives
+    dtype: int
+    rank: int
+    stride: int = 1             # element stride into `tensor` (StridedSlice [:, 0:1] of [n, k] → k)
+    boundaries: Optional[np.ndarray] = None
+
+
+@dataclass
+class SymbolDef:
+    """symbol value = ``reshape(tensor, [-1])[index]`` at request time."""
+    tensor: str
+    index: int
+
+
+@dataclass
+class ColumnInfo:
+    value_tensor: str           # output tensor of the value node (before trailing reshapes)
+    concat_input: str           # the tensor name as written in the ConcatV2 input list
+    concat_index: int
+
+
+@dataclass
+class GroupInfo:
+    concat_node: str
+    dtype: int
+    n_inputs: int
+    columns: List[int] = field(default_factory=list)     # plan column index per concat input position
+
+
+@dataclass
+class BuiltPlan:
+    spec: PlanSpec
+    host_inputs: List[Tuple[str, int, int]]               # (tensor, dtype, rank)  → ConcatInputs `inputs`, `T`, `ranks`
+    device_inputs: List[Tuple[str, int, int]]             # (tensor, dtype, rank)  → FeatureColumnProcess `inputs`
+    symbols: List[SymbolDef]
+    groups: List[GroupInfo]
+    columns: List[ColumnInfo]
+    skipped: List[Tuple[str, str]]                        # (node, reason) — left to TensorFlow
+
+    def describe(self) -> str:
+        names = {1: "gather", 2: "segment-reduce", 3: "gather-scatter", 4: "passthrough", 5: "batch-col-reduction"}
+        lines = [f"{len(self.groups)} concat group(s), {self.spec.n_columns} column(s), "
+                 f"{len(self.host_inputs)} host input(s), {len(self.device_inputs)} table(s), "
+                 f"{len(self.symbols)} symbol(s)"]
+        for g, gi in enumerate(self.groups):
+            forms: Dict[str, int] = {}
+            for k in gi.columns:
+                n = names[self.spec.columns[k].form]
+                forms[n] = forms.get(n, 0) + 1
+            lines.append(f"  group {g}: {gi.concat_node}  width {self.spec.group_width(g)}  " +
+                         ", ".join(f"{v}x {k}" for k, v in sorted(forms.items())))
+        for node, why in self.skipped:
+            lines.append(f"  skipped {node}: {why}")
+        return "\n".join(lines)
+
+
+class PlanBuilder:
+    def __init__(self, graph_def) -> None:
+        self.g = GraphView(graph_def)
+        self.tables = self._find_tables()
+        self._host: Dict[str, int] = {}
+        self._host_list: List[Tuple[str, int, int]] = []
+        self._dev: Dict[str, int] = {}
+        self._dev_list: List[Tuple[str, int, int]] = []
+        self._sym: Dict[Tuple[str, int], int] = {}
+        self._sym_list: List[SymbolDef] = []
+
+    # ---- tables (graph_info.cc:209-259) ----------------------------------------
+    def _find_tables(self) -> Dict[str, Tuple[int, int]]:
+        out: Dict[str, Tuple[int, int]] = {}
+        for n in self.g.gd.node:
+            if n.op not in ("VariableV2", "Const"):
+                continue
+            if self.g.out_dtype(n) != P.DT_FLOAT:
+                continue
+            shape = self.g.static_shape(n)
+            if shape is None or len(shape) != 2 or None in shape or min(shape) <= 0:
+                continue
+            stack, lookups, ok = [n.name], 0, True
+            while stack and ok:
+                for c, i in self.g.data_consumers(stack.pop()):
+                    if c.op == "Identity":
+                        stack.append(c.name)
+                    elif c.op in ("Assign", "SaveV2"):
+                        pass
+                    elif ("Gather" in c.op or "SparseSegment" in c.op) and i == 0:
+                        lookups += 1
+                    else:
+                        ok = False
+                        break
+            if ok and lookups:
+                out[n.name] = (int(shape[0]), int(shape[1]))
+        return out
+
+    def _table_of(self, node, port: int) -> Tuple[str, int, int]:
+        while node.op == "Identity" and port == 0:
+            node, port = self.g.input(node, 0)
+        if node.name not in self.tables or port != 0:
+            raise Unsupported(f"{node.name} ({node.op}) is not an embedding table")
+        return (node.name,) + self.tables[node.name]
+
+    # ---- operand bookkeeping ------------------------------------------------------
+    def _host_input(self, tensor: str, dtype: int, rank: int) -> int:
+        if tensor not in self._host:
+            self._host[tensor] = len(self._host_list)
+            self._host_list.append((tensor, dtype, rank))
+        return self._host[tensor]
+
+    def _device_input(self, tensor: str) -> int:
+        if tensor not in self._dev:
+            self._dev[tensor] = len(self._dev_list)
+            self._dev_list.append((tensor, P.DT_FLOAT, 2))
+        return self._dev[tensor]
+
+    def _symbol(self, tensor: str, index: int) -> int:
+        key = (tensor, index)
+        if key not in self._sym:
+            self._sym[key] = len(self._sym_list)
+            self._sym_list.append(SymbolDef(tensor, index))
+        return self._sym[key]
+
+    # ---- EmitInputInline (cuda_emitter.cc:1769-1949) ---------------------------------
+    def _terminal(self, node, port: int) -> IndexSource:
+        dtype = self.g.out_dtype(node, port)
+        shape = self.g.static_shape(node, port)
+        if shape is None:
+            raise Unsupported(f"rank of {node.name} unknown")
+        return IndexSource(tensor_name(node.name, port), dtype, len(shape))
+
+    def trace_index(self, node, port: int) -> IndexSource:
+        """Follow an index operand to the tensor the host must ship.  Ops that can be
+        evaluated on the fly are absorbed; the walk ends at the first other node."""
+        try:
+            return self._trace_inline(node, port)
+        except Unsupported:
+            return self._terminal(node, port)
+
+    def _trace_inline(self, node, port: int) -> IndexSource:
+        g = self.g
+        if port != 0:
+            raise Unsupported("not an inlinable op")
+        if node.op in RESHAPE_LIKE or node.op == "Identity":
+            return self.trace_index(*g.input(node, 0))          # flat element index unchanged
+        if node.op == "Cast":
+            src = self.trace_index(*g.input(node, 0))
+            dst = node.attr["DstT"].type
+            ints = (P.DT_INT32, P.DT_INT64)
+            # integer width changes and the int32→int64 cast TF puts after Bucketize keep the
+            # value; a float→int cast has no id source and stays on the host
+            if dst in ints and (src.dtype in ints or src.boundaries is not None):
+                return src
+            raise Unsupported("cast changes the value")
+        if node.op == "Bucketize":
+            src = self.trace_index(*g.input(node, 0))
+            if src.dtype != P.DT_FLOAT or src.boundaries is not None or src.stride != 1:
+                raise Unsupported("Bucketize over a non-float32 operand")
+            b = np.asarray(list(node.attr["boundaries"].list.f), np.float32)
+            if b.size == 0:
+                raise Unsupported("Bucketize without boundaries")
+            src.boundaries = b
+            return src
+        if node.op == "StridedSlice":
+            # the one case the reference inlines: [n, k] → column 0 (:1864-1873), with or
+            # without the shrink the lookup optimizer adds for segment ids (lookup_optimizer.cc:240-242)
+            spec = g.strided_slice_spec(node)
+            in_node, in_port = g.input(node, 0)
+            in_shape = g.static_shape(in_node, in_port)
+            if spec is None or in_shape is None or len(in_shape) != 2 or in_shape[1] is None:
+                raise Unsupported("StridedSlice operand shape unknown")
+            if spec["ellipsis_mask"] or spec["new_axis_mask"] or spec["shrink_axis_mask"] not in (0, 2):
+                raise Unsupported("StridedSlice masks")
+            if len(spec["begin"]) != 2 or spec["strides"] != [1, 1]:
+                raise Unsupported("StridedSlice is not a 2-D unit-stride slice")
+            if not ((spec["begin_mask"] & 1 or spec["begin"][0] == 0) and spec["end_mask"] & 1):
+                raise Unsupported("StridedSlice does not keep all rows")
+            if spec["begin_mask"] & 2 or spec["end_mask"] & 2 or spec["begin"][1] != 0 or spec["end"][1] != 1:
+                raise Unsupported("StridedSlice does not select column 0")
+            src = self.trace_index(in_node, in_port)
+            if src.boundaries is not None:
+                raise Unsupported("slice of bucketized values")
+            src.stride *= int(in_shape[1])
+            return src
+        raise Unsupported("not an inlinable op")
+
+    def _ids_operand(self, node, port: int) -> Tuple[int, int, Optional[np.ndarray]]:
+        src = self.trace_index(node, port)
+        if src.stride != 1:                       # no strided id source in the column record
+            src = self._terminal(node, port)
+        if src.boundaries is not None:
+            id_source = IDS_F32_BUCKETIZE
+        elif src.dtype == P.DT_INT32:
+            id_source = IDS_I32
+        elif src.dtype == P.DT_INT64:
+            id_source = IDS_I64
+        else:
+            raise Unsupported(f"ids tensor {src.tensor} has dtype {src.dtype}")
+        return self._host_input(src.tensor, src.dtype, src.rank), id_source, src.boundaries
+
+    def _seg_operand(self, node, port: int) -> Tuple[int, int, int]:
+        src = self.trace_index(node, port)
+        if src.boundaries is not None:
+            src = self._terminal(node, port)
+        kind = {P.DT_INT32: SEG_IDS_I32, P.DT_INT64: SEG_IDS_I64}.get(src.dtype)
+        if kind is None:
+            raise Unsupported(f"segment ids {src.tensor} have dtype {src.dtype}")
+        return self._host_input(src.tensor, src.dtype, src.rank), kind, src.stride
+
+    # ---- EmitSubgraphCode dispatch (cuda_emitter.cc:1096-1152) --------------------------
+    def _match_gather(self, node) -> Tuple[str, int, int, int, int, Optional[np.ndarray]]:
+        axis = self.g.const_array(*self.g.input(node, 2))
+        if axis is None or int(axis.reshape(-1)[0]) != 0:
+            raise Unsupported("GatherV2 axis is not 0")
+        if "batch_dims" in node.attr and node.attr["batch_dims"].i != 0:
+            raise Unsupported("GatherV2 batch_dims")
+        table, vocab, dim = self._table_of(*self.g.input(node, 0))
+        ids_in, id_source, boundaries = self._ids_operand(*self.g.input(node, 1))
+        return table, vocab, dim, ids_in, id_source, boundaries
+
+    def match_column(self, node, port: int, group: int, slot: int) -> ColumnSpec:
+        g = self.g
+        if port != 0:
+            raise Unsupported("value is not output 0")
+        if node.op == "GatherV2":                                                   # EmitGatherRows :1246-1330
+            table, vocab, dim, ids_in, id_source, bnd = self._match_gather(node)
+            return ColumnSpec(FORM_GATHER, dim, vocab, COMBINER_NONE, id_source, self._device_input(table), ids_in,
+                              -1, SEG_NONE, 1, ROWS_FROM_IDS, 0, bnd, group, slot)
+        if node.op in SEGMENT_OPS:                                                  # EmitSparseSegmentReduce* :1444-1760
+            table, vocab, dim = self._table_of(*g.input(node, 0))
+            ids_in, id_source, bnd = self._ids_operand(*g.input(node, 1))
+            seg_in, seg_kind, stride = self._seg_operand(*g.input(node, 2))
+            n_node, n_port = g.input(node, 3)
+            while n_node.op in RESHAPE_LIKE and n_port == 0:                        # Squeeze(num_segments) lookup_optimizer.cc:248-254
+                n_node, n_port = g.input(n_node, 0)
+            sym = self._symbol(tensor_name(n_node.name, n_port), 0)
+            return ColumnSpec(FORM_SEGMENT_REDUCE, dim, vocab, SEGMENT_OPS[node.op], id_source,
+                              self._device_input(table), ids_in, seg_in, seg_kind, stride, ROWS_FROM_SYMBOL, sym, bnd,
+                              group, slot)
+        if node.op in ("SparseSegmentSum", "SparseSegmentMean"):
+            raise Unsupported("row count is data dependent without num_segments")
+        if node.op == "ScatterNd":                                                  # EmitGatherScatterRows :1332-1442
+            upd, upd_port = g.input(node, 1)
+            if upd.op != "GatherV2" or upd_port != 0:
+                raise Unsupported("ScatterNd updates are not a GatherV2")
+            table, vocab, dim, ids_in, id_source, bnd = self._match_gather(upd)
+            seg_in, seg_kind, stride = self._seg_operand(*g.input(node, 0))
+            shp, shp_port = g.input(node, 2)
+            sym = self._symbol(tensor_name(shp.name, shp_port), 0)
+            return ColumnSpec(FORM_GATHER_SCATTER, dim, vocab, COMBINER_NONE, id_source, self._device_input(table),
+                              ids_in, seg_in, seg_kind, stride, ROWS_FROM_SYMBOL, sym, bnd, group, slot)
+        if node.op == "Sum":                                                        # EmitBatchColReduction :1180-1244
+            axis = g.const_array(*g.input(node, 1))
+            if axis is None or axis.size != 1 or int(axis.reshape(-1)[0]) != 1:
+                raise Unsupported("Sum is not over axis 1")
+            if "keep_dims" in node.attr and node.attr["keep_dims"].b:
+                raise Unsupported("Sum keep_dims")
+            x, x_port = g.input(node, 0)
+            shape = g.static_shape(x, x_port)
+            if g.out_dtype(x, x_port) != P.DT_FLOAT or shape is None or len(shape) != 3 or shape[2] is None:
+                raise Unsupported("Sum operand is not a float32 [b, r, c] tensor with static c")
+            i = self._host_input(tensor_name(x.name, x_port), P.DT_FLOAT, 3)
+            return ColumnSpec(FORM_BATCH_COL_REDUCTION, int(shape[2]), 0, COMBINER_NONE, IDS_I32, -1, i, -1, SEG_NONE,
+                              1, ROWS_FROM_INPUT_DIM0, i, None, group, slot)
+        raise Unsupported(f"op {node.op} is not a lookup")
+
+    def _passthrough(self, tensor: str, group: int, slot: int) -> ColumnSpec:
+        name, port = tensor.partition(":")[0], int(tensor.partition(":")[2] or 0)
+        node = self.g.nodes[name]
+        shape = self.g.static_shape(node, port)
+        if self.g.out_dtype(node, port) != P.DT_FLOAT or shape is None or len(shape) != 2 or shape[1] is None:
+            raise Unsupported(f"{tensor}: not a float32 [rows, dim] tensor with static dim")
+        i = self._host_input(tensor, P.DT_FLOAT, 2)
+        return ColumnSpec(FORM_PASSTHROUGH, int(shape[1]), 0, COMBINER_NONE, IDS_I32, -1, i, -1, SEG_NONE, 1,
+                          ROWS_FROM_INPUT_DIM0, i, None, group, slot)
+
+    # ---- the walk ------------------------------------------------------------------------
+    def build(self) -> BuiltPlan:
+        g = self.g
+        columns: List[ColumnSpec] = []
+        infos: List[ColumnInfo] = []
+        groups: List[GroupInfo] = []
+        skipped: List[Tuple[str, str]] = []
+        for concat in g.gd.node:
+            if concat.op != "ConcatV2":
+                continue
+            ins = g.data_inputs(concat)
+            n = int(concat.attr["N"].i) if "N" in concat.attr else len(ins) - 1
+            axis = g.const_array(*g.input(concat, n))
+            dtype = g.out_dtype(concat)
+            if axis is None or int(axis.reshape(-1)[0]) not in (1, -1) or dtype != P.DT_FLOAT:
+                continue
+            # snapshot: a group that turns out unusable must not leave operands behind
+            snap = (dict(self._host), list(self._host_list), dict(self._dev), list(self._dev_list), dict(self._sym),
+                    list(self._sym_list))
+            group = len(groups)
+            cols: List[ColumnSpec] = []
+            cinfo: List[ColumnInfo] = []
+            lookups = 0
+            try:
+                for i in range(n):
+                    node, port = g.input(concat, i)
+                    while node.op in RESHAPE_LIKE and port == 0:                    # FindFCOutputs :1060-1066
+                        node, port = g.input(node, 0)
+                    try:
+                        col = self.match_column(node, port, group, i)
+                        lookups += 1
+                        value = tensor_name(node.name, port)
+                    except Unsupported as why:
+                        col = self._passthrough(ins[i], group, i)
+                        value = ins[i]
+                        if node.name in self.tables or any(t in self.tables for t in self._upstream_tables(node)):
+                            skipped.append((node.name, str(why)))
+                    cols.append(col)
+                    cinfo.append(ColumnInfo(value, ins[i], i))
+                if lookups == 0:
+                    raise Unsupported("no lookup column converges here")
+            except Unsupported as why:
+                (self._host, self._host_list, self._dev, self._dev_list, self._sym, self._sym_list) = snap
+                if lookups:
+                    skipped.append((concat.name, str(why)))
+                continue
+            gi = GroupInfo(concat.name, dtype, n, list(range(len(columns), len(columns) + n)))
+            columns.extend(cols)
+            infos.extend(cinfo)
+            groups.append(gi)
+        if not groups:
+            raise Unsupported("no ConcatV2 with embedding lookups found")
+        spec = PlanSpec(columns, [r for _, _, r in self._host_list],
+                        [_ELEM_SIZE[d] for _, d, _ in self._host_list], len(self._dev_list), n_groups=len(groups),
+                        n_symbols=len(self._sym_list))
+        spec.validate()
+        return BuiltPlan(spec, list(self._host_list), list(self._dev_list), list(self._sym_list), groups, infos,
+                         skipped)
+
+    def _upstream_tables(self, node, limit: int = 256) -> List[str]:
+        seen, stack, found = set(), [node], []
+        while stack and len(seen) < limit:
+            n = stack.pop()
+            if n.name in seen:
+                continue
+            seen.add(n.name)
+            if n.name in self.tables:
+                found.append(n.name)
+            for k in range(len(self.g.data_inputs(n))):
+                stack.append(self.g.input(n, k)[0])
+        return found
+
+
+def build_plan(graph_def) -> BuiltPlan:
+    return PlanBuilder(graph_def).build()

@@ -1,0 +1,161 @@
+"""Graph rewrite: replace the matched feature-column subgraphs with the three ops.
+
+Node for node what ``CudaEmitter::Rewrite`` emits (``cuda_emitter.cc:2496-2656``):
+
+* ``ConcatInputs`` (``Addons>ConcatInputs``): inputs = the plan's host tensors, attrs
+  ``T`` / ``ranks`` (``:2518-2524``);
+* ``FeatureColumnProcess`` (``Addons>FeatureColumnProcess``, ``…WithSymbols`` when the
+  plan has symbols, ``:2650-2653``): inputs ``ConcatInputs:0..2`` + the tables (+
+  symbols), attrs ``input_types`` / ``input_ranks`` / ``output_types`` /
+  ``output_ranks`` / ``dlpath`` (``:2501-2512, 2526-2539``) — ``dlpath`` names the plan
+  file (``recom_amd.plan_io``) instead of a JIT ``.so``;
+* one ``Addons>ConcatOutputsNoHost`` per concat group that takes over the ConcatV2's
+  name, the original being renamed ``<name>_removed`` (``:2645-2646``), with attrs ``T``,
+  ``BLOCK_THREADS``, ``prefix_begin`` / ``prefix_end``, ``output_dir``,
+  ``device_concat_indices`` / ``device_input_indices``, ``N`` = 0, ``host_concat_indices``
+  = [], ``embedd_dims``, ``buffer_types`` and the lifetime-extending ``tensor_buffers``
+  inputs blob, tables, arena (``:2547-2643``).
+
+Symbols (row counts the reference derives with SymEngine and ships through a
+``ShapeConstruct`` node, ``:2446-2458``) are computed by plain TF ops here:
+``Cast(GatherV2(Reshape(t, [-1]), index))`` packed into one int32 vector.
+
+Nodes that only fed the removed concats are pruned (the reference leaves that to its
+``UselessNodesPruner`` / TensorFlow's own pruning).
+"""
+from __future__ import annotations
+
+from typing import List
+
+import numpy as np
+
+from . import tf_proto as P
+from .plan_builder import BuiltPlan
+from .view import GraphView, numpy_to_tensor, split_tensor
+
+BLOCK_THREADS = 64  # CudaEmitter(graph_info, 1 << 28, 64), fc_optimize_pass.cc:71
+
+
+def _const(gd, name: str, value: np.ndarray):
+    n = gd.node.add(name=name, op="Const")
+    n.attr["dtype"].type = {np.dtype(np.int32): P.DT_INT32, np.dtype(np.int64): P.DT_INT64}[value.dtype]
+    numpy_to_tensor(value, n.attr["value"].tensor)
+    return n
+
+
+def rewrite_graph(graph_def, built: BuiltPlan, plan_path: str, prune: bool = True):
+    """Returns a new GraphDef; ``graph_def`` is left untouched."""
+    gd = P.GraphDef()
+    gd.CopyFrom(graph_def)
+    view = GraphView(gd)
+    for reserved in ("ConcatInputs", "FeatureColumnProcess"):
+        if reserved in view.nodes:
+            raise ValueError(f"graph already has a node named {reserved}")
+
+    concat_in = gd.node.add(name="ConcatInputs", op="Addons>ConcatInputs")
+    for tensor, dtype, rank in built.host_inputs:
+        concat_in.input.append(tensor)
+        concat_in.attr["T"].list.type.append(dtype)
+        concat_in.attr["ranks"].list.i.append(rank)
+
+    fuse = gd.node.add(name="FeatureColumnProcess", op="Addons>FeatureColumnProcess")
+    fuse.attr["dlpath"].s = plan_path.encode()
+    fuse.input.extend(["ConcatInputs", "ConcatInputs:1", "ConcatInputs:2"])
+    fuse.attr["input_types"].list.SetInParent()
+    fuse.attr["input_ranks"].list.SetInParent()
+    for tensor, dtype, rank in built.device_inputs:
+        fuse.input.append(tensor)
+        fuse.attr["input_types"].list.type.append(dtype)
+        fuse.attr["input_ranks"].list.i.append(rank)
+    for _ in built.spec.columns:                       # every column output is [prefix, dim]
+        fuse.attr["output_types"].list.type.append(P.DT_FLOAT)
+        fuse.attr["output_ranks"].list.i.append(2)
+
+    if built.symbols:
+        _const(gd, "FeatureColumnProcess/symbols/flat_shape", np.asarray([-1], np.int32))
+        _const(gd, "FeatureColumnProcess/symbols/axis", np.asarray(0, np.int32))
+        pack = gd.node.add(name="FeatureColumnProcess/symbols", op="Pack")
+        pack.attr["N"].i = len(built.symbols)
+        pack.attr["T"].type = P.DT_INT32
+        pack.attr["axis"].i = 0
+        for k, sym in enumerate(built.symbols):
+            src, port = split_tensor(sym.tensor)
+            dtype = view.out_dtype(view.nodes[src], port)
+            base = f"FeatureColumnProcess/symbols/s{k}"
+            flat = gd.node.add(name=base + "/flat", op="Reshape")
+            flat.input.extend([sym.tensor, "FeatureColumnProcess/symbols/flat_shape"])
+            flat.attr["T"].type = dtype
+            flat.attr["Tshape"].type = P.DT_INT32
+            _const(gd, base + "/index", np.asarray(sym.index, np.int32))
+            pick = gd.node.add(name=base + "/pick", op="GatherV2")
+            pick.input.extend([flat.name, base + "/index", "FeatureColumnProcess/symbols/axis"])
+            pick.attr["Tparams"].type = dtype
+            pick.attr["Tindices"].type = P.DT_INT32
+            pick.attr["Taxis"].type = P.DT_INT32
+            pick.attr["batch_dims"].i = 0
+            cast = gd.node.add(name=base, op="Cast")
+            cast.input.append(pick.name)
+            cast.attr["SrcT"].type = dtype
+            cast.attr["DstT"].type = P.DT_INT32
+            pack.input.append(cast.name)
+        fuse.op = "Addons>FeatureColumnProcessWithSymbols"
+        fuse.input.append(pack.name)
+
+    removed: List[str] = []
+    nodes = {n.name: n for n in gd.node}
+    for gi in built.groups:
+        orig = nodes[gi.concat_node]
+        new = gd.node.add(op="Addons>ConcatOutputsNoHost")
+        a = new.attr
+        a["T"].type = gi.dtype
+        a["BLOCK_THREADS"].i = BLOCK_THREADS
+        first = gi.columns[0]
+        a["prefix_begin"].i = 2 * first                 # index into output_shapes (rank 2 per output)
+        a["prefix_end"].i = 2 * first + 1
+        a["output_dir"].s = b""
+        a["N"].i = 0
+        a["host_concat_indices"].list.SetInParent()
+        for pos, col in enumerate(gi.columns):
+            a["device_concat_indices"].list.i.append(pos)
+            a["device_input_indices"].list.i.append(col)
+            a["embedd_dims"].list.i.append(built.spec.columns[col].dim)
+        new.input.extend(["FeatureColumnProcess", "FeatureColumnProcess:1"])
+        # tensor_buffers: keep blob, tables and arena alive until the concat output is consumed
+        new.input.append("ConcatInputs")
+        a["buffer_types"].list.type.append(P.DT_INT8)
+        for tensor, dtype, _ in built.device_inputs:
+            new.input.append(tensor)
+            a["buffer_types"].list.type.append(dtype)
+        new.input.append("FeatureColumnProcess:2")
+        a["buffer_types"].list.type.append(P.DT_INT8)
+        new.name = orig.name
+        orig.name = orig.name + "_removed"
+        removed.append(orig.name)
+
+    if prune:
+        _prune(gd, removed)
+    return gd
+
+
+def _prune(gd, roots: List[str]) -> None:
+    """Drop the removed concats and every node that only fed them."""
+    nodes = {n.name: n for n in gd.node}
+    uses = {n.name: 0 for n in gd.node}
+    for n in gd.node:
+        for t in n.input:
+            uses[split_tensor(t)[0]] += 1
+    dead, stack = set(), list(roots)
+    while stack:
+        name = stack.pop()
+        if name in dead or uses[name] != 0:
+            continue
+        if nodes[name].op in ("Placeholder", "VariableV2", "VarHandleOp"):
+            continue                                     # graph interface stays
+        dead.add(name)
+        for t in nodes[name].input:
+            src = split_tensor(t)[0]
+            uses[src] -= 1
+            stack.append(src)
+    keep = [n for n in gd.node if n.name not in dead]
+    del gd.node[:]
+    gd.node.extend(keep)

@@ -1,0 +1,231 @@
+"""Synthetic GraphDefs in the canonical post-LookupOptimizer form the reference's
+emitter consumes (``lookup_optimizer.cc:157-440``), built with the run-time GraphDef
+messages of ``recom_amd.graph.tf_proto`` (TensorFlow is absent here, so no real
+SavedModel can be exported; node patterns follow what the reference's rewrites emit)."""
+import numpy as np
+
+from recom_amd.graph import tf_proto as P
+from recom_amd.graph.view import numpy_to_tensor
+
+DT = {np.dtype(np.float32): P.DT_FLOAT, np.dtype(np.int32): P.DT_INT32, np.dtype(np.int64): P.DT_INT64}
+
+
+class GB:
+    def __init__(self):
+        self.gd = P.GraphDef()
+        self.gd.versions.producer = 808  # TF 2.6 graph version
+        self._consts = {}
+
+    def node(self, name, op, inputs=(), **attrs):
+        n = self.gd.node.add(name=name, op=op)
+        n.input.extend(inputs)
+        for k, v in attrs.items():
+            a = n.attr[k]
+            if isinstance(v, bool):
+                a.b = v
+            elif isinstance(v, int):
+                a.i = v
+            elif isinstance(v, tuple) and v[0] == "type":
+                a.type = v[1]
+            elif isinstance(v, tuple) and v[0] == "shape":
+                for d in v[1]:
+                    a.shape.dim.add(size=d)
+            elif isinstance(v, tuple) and v[0] == "floats":
+                a.list.f.extend(v[1])
+            elif isinstance(v, tuple) and v[0] == "ints":
+                a.list.i.extend(v[1])
+            elif isinstance(v, tuple) and v[0] == "shapes":
+                for s in v[1]:
+                    sh = a.list.shape.add()
+                    for d in s:
+                        sh.dim.add(size=d)
+            else:
+                raise TypeError((k, v))
+        return name
+
+    def placeholder(self, name, dtype, shape):
+        return self.node(name, "Placeholder", dtype=("type", DT[np.dtype(dtype)]), shape=("shape", shape))
+
+    def const(self, name, value):
+        value = np.asarray(value)
+        n = self.gd.node.add(name=name, op="Const")
+        n.attr["dtype"].type = DT[value.dtype]
+        numpy_to_tensor(value, n.attr["value"].tensor)
+        return name
+
+    def variable(self, name, vocab, dim):
+        return self.node(name, "VariableV2", dtype=("type", P.DT_FLOAT), shape=("shape", [vocab, dim]))
+
+    def gather(self, name, table, ids, ids_dtype):
+        zero = self.const(name + "/zero", np.asarray(0, np.int32))
+        return self.node(name, "GatherV2", [table, ids, zero], Tparams=("type", P.DT_FLOAT),
+                         Tindices=("type", DT[np.dtype(ids_dtype)]), Taxis=("type", P.DT_INT32), batch_dims=0)
+
+    def slice_col0(self, name, indices, shrink):
+        """indices[:, 0] (shrink, lookup_optimizer.cc:229-243) or indices[:, 0:1] (:399-412)."""
+        b = self.const(name + "/begin_node", np.asarray([0, 0], np.int64))
+        e = self.const(name + "/end_node", np.asarray([0, 1], np.int64))
+        s = self.const(name + "/stride_node", np.asarray([1, 1], np.int64))
+        extra = {"shrink_axis_mask": 2} if shrink else {}
+        return self.node(name, "StridedSlice", [indices, b, e, s], T=("type", P.DT_INT64), Index=("type", P.DT_INT64),
+                         begin_mask=1, end_mask=1, **extra)
+
+
+MICRO_BOUNDARIES = [float(x) for x in range(0, 500, 5)]  # microbenchmark.py:46
+
+
+def canonical_model(B=19, seed=0, unsupported=False):
+    """Returns (graph_def, feeds, variables, fetches).  Two concat groups; every column
+    form; shared table and shared ids; trailing reshapes; a second prefix size."""
+    rng = np.random.default_rng(seed)
+    g = GB()
+    feeds, variables = {}, {}
+
+    def table(name, vocab, dim):
+        g.variable(name, vocab, dim)
+        variables[name] = rng.standard_normal((vocab, dim)).astype(np.float32)
+        return name
+
+    def sparse(prefix, rows, vocab, max_len, min_len=0):
+        lens = rng.integers(min_len, max_len + 1, size=rows)
+        nnz = int(lens.sum())
+        idx = np.stack([np.repeat(np.arange(rows), lens),
+                        np.concatenate([np.arange(l) for l in lens]) if nnz else np.zeros(0, np.int64)], 1)
+        g.placeholder(prefix + "/values", np.int64, [-1])
+        g.placeholder(prefix + "/indices", np.int64, [-1, 2])
+        g.placeholder(prefix + "/dense_shape", np.int64, [2])
+        feeds[prefix + "/values"] = rng.integers(0, vocab, size=nnz).astype(np.int64)
+        feeds[prefix + "/indices"] = idx.astype(np.int64).reshape(nnz, 2)
+        feeds[prefix + "/dense_shape"] = np.asarray([rows, max(1, int(lens.max(initial=0)))], np.int64)
+        # num_segments = dense_shape[0] (the reference builds it with ShapeConstruct; any scalar works)
+        b = g.const(prefix + "/ns/b", np.asarray([0], np.int32))
+        e = g.const(prefix + "/ns/e", np.asarray([1], np.int32))
+        s = g.const(prefix + "/ns/s", np.asarray([1], np.int32))
+        g.node(prefix + "/num_segments", "StridedSlice", [prefix + "/dense_shape", b, e, s], T=("type", P.DT_INT64),
+               Index=("type", P.DT_INT32))
+        g.node(prefix + "/num_segments_squeeze", "Squeeze", [prefix + "/num_segments"], T=("type", P.DT_INT64),
+               squeeze_dims=("ints", [0]))
+        return prefix + "/values", prefix + "/indices", prefix + "/num_segments_squeeze"
+
+    concat0 = []
+    # 1. form 1, int64 ids [B]
+    t_a = table("input_layer/a_embedding/embedding_weights", 97, 8)
+    g.placeholder("a_ids", np.int64, [-1])
+    feeds["a_ids"] = rng.integers(0, 97, size=B).astype(np.int64)
+    concat0.append(g.gather("input_layer/a_embedding/GatherDense", t_a, "a_ids", np.int64))
+    # 2. form 1 through Bucketize → Cast → Reshape (reference microbenchmark column)
+    t_b = table("input_layer/b_embedding/embedding_weights", 101, 8)
+    g.placeholder("b_value", np.float32, [-1, 1])
+    feeds["b_value"] = rng.uniform(-10, 510, size=(B, 1)).astype(np.float32)
+    kat = np.float32([0.0, 495.0, -1.0, 5.0])[:B]      # exact boundary hits and below the first one
+    feeds["b_value"][:kat.size, 0] = kat
+    g.node("b/Bucketize", "Bucketize", ["b_value"], T=("type", P.DT_FLOAT), boundaries=("floats", MICRO_BOUNDARIES))
+    g.node("b/Cast", "Cast", ["b/Bucketize"], SrcT=("type", P.DT_INT32), DstT=("type", P.DT_INT64))
+    g.const("b/flat", np.asarray([-1], np.int32))
+    g.node("b/Reshape", "Reshape", ["b/Cast", "b/flat"], T=("type", P.DT_INT64), Tshape=("type", P.DT_INT32))
+    concat0.append(g.gather("input_layer/b_embedding/GatherDense", t_b, "b/Reshape", np.int64))
+    # 3. form 1, int32 ids [B, 1] → [B, 1, 12] → trailing Reshape [-1, 12]; shares table with column 9
+    t_c = table("input_layer/c_embedding/embedding_weights", 53, 12)
+    g.placeholder("c_ids", np.int32, [-1, 1])
+    feeds["c_ids"] = rng.integers(0, 53, size=(B, 1)).astype(np.int32)
+    g.gather("input_layer/c_embedding/GatherDense", t_c, "c_ids", np.int32)
+    g.const("c/out_shape", np.asarray([-1, 12], np.int32))
+    concat0.append(g.node("c/Reshape", "Reshape", ["input_layer/c_embedding/GatherDense", "c/out_shape"],
+                          T=("type", P.DT_FLOAT), Tshape=("type", P.DT_INT32)))
+    # 4. form 2 mean, segment ids = indices[:, 0]
+    t_d = table("input_layer/d_embedding/embedding_weights", 211, 16)
+    v, i, n = sparse("d", B, 211, 6)
+    seg = g.slice_col0("d/added_strided_slice", i, shrink=True)
+    concat0.append(g.node("d/SparseSegmentMean_with_num_segments", "SparseSegmentMeanWithNumSegments",
+                          [t_d, v, seg, n], T=("type", P.DT_FLOAT), Tidx=("type", P.DT_INT64),
+                          Tsegmentids=("type", P.DT_INT64), Tnumsegments=("type", P.DT_INT64)))
+    # 5. form 2 sum, dim 32 (> 20: the reference's "experiment" template), segment ids cast to int32
+    t_e = table("input_layer/e_embedding/embedding_weights", 300, 32)
+    v, i, n = sparse("e", B, 300, 9)
+    seg = g.slice_col0("e/added_strided_slice", i, shrink=True)
+    g.node("e/Cast", "Cast", [seg], SrcT=("type", P.DT_INT64), DstT=("type", P.DT_INT32))
+    concat0.append(g.node("e/SparseSegmentSum_with_num_segments", "SparseSegmentSumWithNumSegments",
+                          [t_e, v, "e/Cast", n], T=("type", P.DT_FLOAT), Tidx=("type", P.DT_INT64),
+                          Tsegmentids=("type", P.DT_INT32), Tnumsegments=("type", P.DT_INT64)))
+    # 6. form 3: ScatterNd(indices[:, 0:1], GatherV2, [B, dim])
+    t_f = table("input_layer/f_embedding/embedding_weights", 64, 4)
+    v, i, n = sparse("f", B, 64, 1)
+    rows = g.slice_col0("f/added_strided_slice", i, shrink=False)
+    g.gather("input_layer/f_embedding/GatherScatter/Gather", t_f, v, np.int64)
+    g.const("f/dim", np.asarray(4, np.int64))
+    g.node("f/Scatter_shape", "Pack", [n, "f/dim"], N=2, T=("type", P.DT_INT64), axis=0)
+    concat0.append(g.node("input_layer/f_embedding/GatherScatter/Scatter", "ScatterNd",
+                          [rows, "input_layer/f_embedding/GatherScatter/Gather", "f/Scatter_shape"],
+                          T=("type", P.DT_FLOAT), Tindices=("type", P.DT_INT64)))
+    # 7. dense features straight into the concat (ConcatOutputs host input in the reference)
+    g.placeholder("dense_features", np.float32, [-1, 13])
+    feeds["dense_features"] = rng.standard_normal((B, 13)).astype(np.float32)
+    concat0.append("dense_features")
+    # 8. Sum(x, axis=1)
+    g.placeholder("seq_features", np.float32, [-1, 3, 8])
+    feeds["seq_features"] = rng.standard_normal((B, 3, 8)).astype(np.float32)
+    g.const("seq/axis", np.asarray(1, np.int32))
+    concat0.append(g.node("seq/Sum", "Sum", ["seq_features", "seq/axis"], T=("type", P.DT_FLOAT),
+                          Tidx=("type", P.DT_INT32), keep_dims=False))
+    # 9. second lookup into table c with the ids of column 1 (shared table, shared host input)
+    g.node("c2/Cast", "Cast", ["a_ids"], SrcT=("type", P.DT_INT64), DstT=("type", P.DT_INT32))
+    feeds["a_ids"] = feeds["a_ids"] % 53
+    concat0.append(g.gather("input_layer/c2_embedding/GatherDense", t_c, "c2/Cast", np.int32))
+    if unsupported:
+        # 10. SparseSegmentSum without num_segments: row count is data dependent → stays in TF
+        t_u = table("input_layer/u_embedding/embedding_weights", 40, 4)
+        v, i, n = sparse("u", B, 40, 3, min_len=1)
+        seg = g.slice_col0("u/added_strided_slice", i, shrink=True)
+        concat0.append(g.node("u/SparseSegmentSum", "SparseSegmentSum", [t_u, v, seg], T=("type", P.DT_FLOAT),
+                              Tidx=("type", P.DT_INT64), Tsegmentids=("type", P.DT_INT64),
+                              _output_shapes=("shapes", [[-1, 4]])))
+    g.const("concat/axis", np.asarray(1, np.int32))
+    g.node("input_layer/concat", "ConcatV2", concat0 + ["concat/axis"], N=len(concat0), T=("type", P.DT_FLOAT),
+           Tidx=("type", P.DT_INT32))
+
+    # second concat with its own prefix size
+    B2 = B + 5
+    t_g = table("seq_layer/g_embedding/embedding_weights", 77, 8)
+    v, i, n = sparse("g", B2, 77, 4)
+    seg = g.slice_col0("g/added_strided_slice", i, shrink=True)
+    g.node("g/SparseSegmentSum_with_num_segments", "SparseSegmentSumWithNumSegments", [t_g, v, seg, n],
+           T=("type", P.DT_FLOAT), Tidx=("type", P.DT_INT64), Tsegmentids=("type", P.DT_INT64),
+           Tnumsegments=("type", P.DT_INT64))
+    t_h = table("seq_layer/h_embedding/embedding_weights", 31, 20)
+    g.placeholder("h_ids", np.int64, [-1])
+    feeds["h_ids"] = rng.integers(0, 31, size=B2).astype(np.int64)
+    g.gather("seq_layer/h_embedding/GatherDense", t_h, "h_ids", np.int64)
+    g.const("concat2/axis", np.asarray(-1, np.int32))
+    g.node("seq_layer/concat", "ConcatV2", ["g/SparseSegmentSum_with_num_segments",
+                                            "seq_layer/h_embedding/GatherDense", "concat2/axis"],
+           N=2, T=("type", P.DT_FLOAT), Tidx=("type", P.DT_INT32))
+
+    # consumers of the concats + something unrelated that must survive the rewrite
+    g.node("output_0", "Identity", ["input_layer/concat"], T=("type", P.DT_FLOAT))
+    g.node("output_1", "Identity", ["seq_layer/concat"], T=("type", P.DT_FLOAT))
+    g.node("dense_copy", "Identity", ["dense_features"], T=("type", P.DT_FLOAT))
+    return g.gd, feeds, variables, ["output_0", "output_1"]
+
+
+def microbenchmark_model(columns=6, B=32, seed=0):
+    """The reference micro-benchmark's model (microbenchmark.py:40-66) in rewritten form:
+    N × {f32 value → Bucketize(0,5,…,495) → 101-row, dim-8 table → GatherV2}, one concat."""
+    rng = np.random.default_rng(seed)
+    g = GB()
+    feeds, variables, ins = {}, {}, []
+    for c in range(columns):
+        t = g.variable(f"input_layer/col{c}_embedding/embedding_weights", 101, 8)
+        variables[t] = rng.standard_normal((101, 8)).astype(np.float32)
+        g.placeholder(f"col{c}", np.float32, [-1, 1])
+        feeds[f"col{c}"] = rng.integers(-1, 10000, size=(B, 1)).astype(np.float32)  # microbenchmark.py:66
+        g.node(f"col{c}/Bucketize", "Bucketize", [f"col{c}"], T=("type", P.DT_FLOAT),
+               boundaries=("floats", MICRO_BOUNDARIES))
+        g.const(f"col{c}/flat", np.asarray([-1], np.int32))
+        g.node(f"col{c}/Reshape", "Reshape", [f"col{c}/Bucketize", f"col{c}/flat"], T=("type", P.DT_INT32),
+               Tshape=("type", P.DT_INT32))
+        ins.append(g.gather(f"input_layer/col{c}_embedding/GatherDense", t, f"col{c}/Reshape", np.int32))
+    g.const("concat/axis", np.asarray(1, np.int32))
+    g.node("input_layer/concat", "ConcatV2", ins + ["concat/axis"], N=columns, T=("type", P.DT_FLOAT),
+           Tidx=("type", P.DT_INT32))
+    g.node("output", "Identity", ["input_layer/concat"], T=("type", P.DT_FLOAT))
+    return g.gd, feeds, variables, ["output"]

@@ -320,6 +320,50 @@ def test_column_sharded_blocks_concat(torch_cuda, oracle):
         assert np.array_equal(got.cpu().numpy(), ref[begin:begin + count])
 
 
+@pytest.mark.parametrize("B,seed", [(19, 0), (300, 3)])
+def test_graphdef_to_hip_path(torch_cuda, tmp_path, B, seed):
+    """SURVEY §8f-1 end to end: a GraphDef in the reference's canonical rewritten form →
+    plan builder → plan file → rewritten graph whose three Addons> ops run the HIP path;
+    the concat outputs equal the original graph evaluated op by op in NumPy (TF-CPU
+    semantics, fp32 adds in id order) bit for bit."""
+    from graph_fixtures import canonical_model
+    from tf_graph_eval import GraphEvaluator
+    from recom_amd.graph import build_plan, parse_graphdef, rewrite_graph
+    from recom_amd.ops import FeatureColumnProcess, concat_inputs
+    from recom_amd.plan_io import load_plan, save_plan
+    torch = torch_cuda
+    gd, feeds, variables, fetches = canonical_model(B=B, seed=seed)
+    expected = GraphEvaluator(gd, variables).run(fetches, feeds)
+    built = build_plan(gd)
+    path = str(tmp_path / "model.fcp")
+    save_plan(built.spec, path)
+    out_gd = parse_graphdef(rewrite_graph(gd, built, path).SerializeToString())
+    ops = {}
+
+    def process(node, x):
+        op = ops.setdefault(node.name, FeatureColumnProcess(load_plan(node.attr["dlpath"].s.decode()), 0))
+        n_tab = len(node.attr["input_types"].list.type)
+        tables = [torch.from_numpy(np.ascontiguousarray(t)).cuda() for t in x[3:3 + n_tab]]
+        symbols = x[3 + n_tab] if node.op.endswith("WithSymbols") else None
+        assert symbols is None or symbols.dtype == np.int32
+        res = op(torch.from_numpy(x[0]).cuda(), x[1], x[2], tables, symbols)
+        torch.cuda.synchronize()
+        return [res.output_ptrs, res.output_shapes, res]
+
+    def concat_outputs(node, x):
+        res = x[-1]
+        group = built.spec.columns[int(node.attr["device_input_indices"].list.i[0])].concat_group
+        assert int(x[1][int(node.attr["prefix_begin"].i)]) == res.groups[group].shape[0]
+        return [res.groups[group].cpu().numpy()]
+
+    custom = {"Addons>ConcatInputs": lambda node, x: list(concat_inputs(x)),
+              "Addons>FeatureColumnProcess": process, "Addons>FeatureColumnProcessWithSymbols": process,
+              "Addons>ConcatOutputsNoHost": concat_outputs}
+    got = GraphEvaluator(out_gd, variables, custom).run(fetches, feeds)
+    for e, o in zip(expected, got):
+        assert e.shape == o.shape and np.array_equal(e, o)
+
+
 def test_dlrm_scaled_vs_oracle(torch_cuda, oracle):
     from recom_amd import synth
     cards = [min(c, 40000) for c in synth.CRITEO_KAGGLE_CARDINALITIES]

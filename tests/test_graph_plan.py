@@ -1,0 +1,212 @@
+"""Plan builder from a rewritten GraphDef, CPU side.
+
+original GraphDef --NumPy evaluator (oracle/tf_graph_eval.py)--> expected concat outputs
+original GraphDef --build_plan + rewrite_graph--> Addons> ops, evaluated with the C oracle
+                                                  behind them --> must be identical
+(the GPU twin, with the HIP path behind the ops, is in tests/test_gpu_parity.py)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from graph_fixtures import MICRO_BOUNDARIES, canonical_model, microbenchmark_model
+from recom_amd import plan as PL
+from recom_amd.graph import Unsupported, build_plan, parse_graphdef, rewrite_graph
+from recom_amd.graph import tf_proto as P
+from recom_amd.plan_io import load_plan, save_plan
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def oracle_ops(oracle, built, variables):
+    """The three Addons> ops with the C oracle behind them (CPU stand-in for the shim)."""
+    def concat_inputs(node, x):
+        assert [int(r) for r in node.attr["ranks"].list.i] == [a.ndim for a in x]
+        blob, offsets, shapes = oracle.concat_inputs(x)
+        return [blob, offsets, shapes]
+
+    def process(node, x):
+        spec = load_plan(node.attr["dlpath"].s.decode())
+        n_tab = len(node.attr["input_types"].list.type)
+        tables = x[3:3 + n_tab]
+        symbols = x[3 + n_tab] if node.op.endswith("WithSymbols") else None
+        groups, bad = oracle.process_feature_columns(spec.to_dict(), x[0], x[1], x[2], tables, symbols)
+        assert bad == 0
+        # output_shapes: [prefix, dim] per column output (feature_column_process_op_gpu.cu.cc:113-118)
+        shapes = np.asarray([v for c in spec.columns for v in (groups[c.concat_group].shape[0], c.dim)], np.int32)
+        return [np.zeros(spec.n_columns, np.int64), shapes, groups]
+
+    def concat_outputs(node, x):
+        col = int(node.attr["device_input_indices"].list.i[0])
+        group = built.spec.columns[col].concat_group
+        out = x[-1][group]                                    # FeatureColumnProcess:2 is wired last
+        shapes = x[1]
+        assert out.shape[0] == shapes[int(node.attr["prefix_begin"].i)]
+        assert out.shape[1] == sum(int(d) for d in node.attr["embedd_dims"].list.i)
+        return [out]
+
+    return {"Addons>ConcatInputs": concat_inputs, "Addons>FeatureColumnProcess": process,
+            "Addons>FeatureColumnProcessWithSymbols": process, "Addons>ConcatOutputsNoHost": concat_outputs}
+
+
+def test_graphdef_roundtrip_binary_and_text():
+    gd, *_ = canonical_model()
+    data = gd.SerializeToString()
+    assert parse_graphdef(data) == gd
+    from google.protobuf import text_format
+    assert parse_graphdef(text_format.MessageToString(gd).encode()) == gd
+    # wire compatibility with tensorflow.GraphDef: NodeDef{name=1, op=2, input=3, attr=5}, GraphDef{node=1}
+    g = P.GraphDef()
+    n = g.node.add(name="x", op="Placeholder")
+    n.attr["dtype"].type = P.DT_FLOAT
+    assert g.SerializeToString() == b"\n\x1d\n\x01x\x12\x0bPlaceholder*\x0b\n\x05dtype\x12\x020\x01"
+
+
+def test_build_plan_canonical_forms():
+    gd, feeds, variables, _ = canonical_model()
+    built = build_plan(gd)
+    spec = built.spec
+    assert [g.concat_node for g in built.groups] == ["input_layer/concat", "seq_layer/concat"]
+    forms = [c.form for c in spec.columns]
+    assert forms == [1, 1, 1, 2, 2, 3, 4, 5, 1, 2, 1]
+    c = spec.columns
+    # column 2: Bucketize + Cast + Reshape absorbed, the float placeholder is shipped
+    assert c[1].id_source == PL.IDS_F32_BUCKETIZE and np.array_equal(c[1].boundaries, np.float32(MICRO_BOUNDARIES))
+    assert built.host_inputs[c[1].ids_input] == ("b_value", P.DT_FLOAT, 2)
+    assert c[0].id_source == PL.IDS_I64 and c[2].id_source == PL.IDS_I32 and c[2].dim == 12
+    # segment ids: indices[:, 0] of the [nnz, 2] matrix, read in place with stride 2 (cast absorbed)
+    for k in (3, 4, 9):
+        assert c[k].seg_kind == PL.SEG_IDS_I64 and c[k].seg_stride == 2 and c[k].rows_source == PL.ROWS_FROM_SYMBOL
+        assert built.host_inputs[c[k].seg_input][0].endswith("/indices")
+    assert c[3].combiner == PL.COMBINER_MEAN and c[4].combiner == PL.COMBINER_SUM and c[4].dim == 32
+    assert c[5].seg_stride == 2 and built.symbols[c[5].rows_arg].tensor == "f/Scatter_shape"
+    assert built.symbols[c[3].rows_arg].tensor == "d/num_segments" and built.symbols[c[3].rows_arg].index == 0
+    assert c[6].dim == 13 and built.host_inputs[c[6].ids_input][0] == "dense_features"
+    assert c[7].dim == 8 and built.host_inputs[c[7].ids_input] == ("seq_features", P.DT_FLOAT, 3)
+    # shared table and shared placeholder are bound once; the int cast of the ids is absorbed
+    assert c[8].table_input == c[2].table_input and c[8].ids_input == c[0].ids_input and c[8].id_source == PL.IDS_I64
+    assert len(built.device_inputs) == 8 and len({t for t, _, _ in built.device_inputs}) == 8
+    assert [c[k].concat_group for k in (9, 10)] == [1, 1] and [c[k].concat_slot for k in (9, 10)] == [0, 1]
+    assert spec.group_width(0) == 8 + 8 + 12 + 16 + 32 + 4 + 13 + 8 + 12 and spec.group_width(1) == 28
+    assert not built.skipped
+    assert "2 concat group(s), 11 column(s)" in built.describe()
+
+
+def test_plan_file_roundtrip(tmp_path):
+    built = build_plan(canonical_model()[0])
+    path = str(tmp_path / "m.fcp")
+    save_plan(built.spec, path)
+    again = load_plan(path)
+    assert again.to_dict().keys() == built.spec.to_dict().keys()
+    for a, b in zip(again.columns, built.spec.columns):
+        da, db = dict(a.__dict__), dict(b.__dict__)
+        ba, bb = da.pop("boundaries"), db.pop("boundaries")
+        assert da == db and (ba is None) == (bb is None) and (ba is None or np.array_equal(ba, bb))
+
+
+def test_rewrite_matches_reference_wiring(tmp_path):
+    gd, feeds, variables, _ = canonical_model()
+    built = build_plan(gd)
+    out = rewrite_graph(gd, built, "/models/m.fcp")
+    nodes = {n.name: n for n in out.node}
+    ci, fc = nodes["ConcatInputs"], nodes["FeatureColumnProcess"]
+    assert ci.op == "Addons>ConcatInputs" and list(ci.input) == [t for t, _, _ in built.host_inputs]
+    assert list(ci.attr["T"].list.type) == [d for _, d, _ in built.host_inputs]
+    assert list(ci.attr["ranks"].list.i) == [r for _, _, r in built.host_inputs]
+    assert fc.op == "Addons>FeatureColumnProcessWithSymbols" and fc.attr["dlpath"].s == b"/models/m.fcp"
+    assert list(fc.input[:3]) == ["ConcatInputs", "ConcatInputs:1", "ConcatInputs:2"]
+    assert list(fc.input[3:-1]) == [t for t, _, _ in built.device_inputs]
+    assert fc.input[-1] == "FeatureColumnProcess/symbols" and nodes[fc.input[-1]].op == "Pack"
+    assert list(fc.attr["output_ranks"].list.i) == [2] * 11 and list(fc.attr["input_ranks"].list.i) == [2] * 8
+    for g, gi in enumerate(built.groups):
+        co = nodes[gi.concat_node]
+        assert co.op == "Addons>ConcatOutputsNoHost" and co.attr["N"].i == 0
+        assert gi.concat_node + "_removed" not in nodes                     # pruned
+        assert list(co.input[:2]) == ["FeatureColumnProcess", "FeatureColumnProcess:1"]
+        assert co.input[2] == "ConcatInputs" and co.input[-1] == "FeatureColumnProcess:2"
+        assert list(co.attr["device_input_indices"].list.i) == gi.columns
+        assert list(co.attr["device_concat_indices"].list.i) == list(range(gi.n_inputs))
+        assert list(co.attr["embedd_dims"].list.i) == [built.spec.columns[k].dim for k in gi.columns]
+        assert co.attr["prefix_begin"].i == 2 * gi.columns[0] and co.attr["prefix_end"].i == 2 * gi.columns[0] + 1
+        assert list(co.attr["buffer_types"].list.type) == [P.DT_INT8] + [P.DT_FLOAT] * 8 + [P.DT_INT8]
+        assert co.attr["BLOCK_THREADS"].i == 64
+    # consumers keep their input names; the lookups are gone; unrelated nodes and the interface stay
+    assert list(nodes["output_0"].input) == ["input_layer/concat"]
+    assert not any(n.op in ("GatherV2", "ScatterNd", "Bucketize") or n.op.startswith("SparseSegment")
+                   for n in out.node if not n.name.startswith("FeatureColumnProcess/symbols"))
+    assert "dense_copy" in nodes and "a_ids" in nodes and "d/num_segments" in nodes
+    # the input graph is untouched
+    assert "ConcatInputs" not in {n.name for n in gd.node}
+    with pytest.raises(ValueError):
+        rewrite_graph(out, built, "x")
+
+
+@pytest.mark.parametrize("B,seed", [(19, 0), (1, 1), (64, 2)])
+def test_rewritten_graph_equals_original(oracle, tmp_path, B, seed):
+    from tf_graph_eval import GraphEvaluator
+    gd, feeds, variables, fetches = canonical_model(B=B, seed=seed)
+    expected = GraphEvaluator(gd, variables).run(fetches, feeds)
+    assert expected[0].shape == (B, 113) and expected[1].shape == (B + 5, 28)
+    built = build_plan(gd)
+    path = str(tmp_path / "m.fcp")
+    save_plan(built.spec, path)
+    out = parse_graphdef(rewrite_graph(gd, built, path).SerializeToString())
+    got = GraphEvaluator(out, variables, oracle_ops(oracle, built, variables)).run(fetches, feeds)
+    for e, o in zip(expected, got):
+        assert o.dtype == np.float32 and np.array_equal(e, o)              # same fp32 add order: bit-exact
+
+
+def test_unsupported_lookup_stays_in_tensorflow(oracle, tmp_path):
+    from tf_graph_eval import GraphEvaluator
+    gd, feeds, variables, fetches = canonical_model(unsupported=True)
+    built = build_plan(gd)
+    assert ("u/SparseSegmentSum", "row count is data dependent without num_segments") in built.skipped
+    k = built.groups[0].columns[-1]
+    assert built.spec.columns[k].form == PL.FORM_PASSTHROUGH
+    assert built.host_inputs[built.spec.columns[k].ids_input][0] == "u/SparseSegmentSum"
+    path = str(tmp_path / "m.fcp")
+    save_plan(built.spec, path)
+    out = rewrite_graph(gd, built, path)
+    assert any(n.name == "u/SparseSegmentSum" for n in out.node)            # still computed by TF
+    expected = GraphEvaluator(gd, variables).run(fetches, feeds)
+    got = GraphEvaluator(out, variables, oracle_ops(oracle, built, variables)).run(fetches, feeds)
+    assert all(np.array_equal(e, o) for e, o in zip(expected, got))
+
+
+def test_microbenchmark_graph(oracle, tmp_path):
+    from tf_graph_eval import GraphEvaluator
+    gd, feeds, variables, fetches = microbenchmark_model(columns=6, B=32)
+    built = build_plan(gd)
+    assert all(c.form == PL.FORM_GATHER and c.id_source == PL.IDS_F32_BUCKETIZE and c.vocab == 101 and c.dim == 8
+               for c in built.spec.columns)
+    assert built.spec.n_symbols == 0
+    path = str(tmp_path / "m.fcp")
+    save_plan(built.spec, path)
+    out = rewrite_graph(gd, built, path)
+    assert {n.name: n for n in out.node}["FeatureColumnProcess"].op == "Addons>FeatureColumnProcess"
+    expected = GraphEvaluator(gd, variables).run(fetches, feeds)
+    got = GraphEvaluator(out, variables, oracle_ops(oracle, built, variables)).run(fetches, feeds)
+    assert np.array_equal(expected[0], got[0])
+
+
+def test_nothing_to_fuse():
+    g = P.GraphDef()
+    n = g.node.add(name="x", op="Placeholder")
+    n.attr["dtype"].type = P.DT_FLOAT
+    with pytest.raises(Unsupported):
+        build_plan(g)
+
+
+def test_cli(tmp_path):
+    gd, *_ = canonical_model()
+    src = tmp_path / "model.pb"
+    src.write_bytes(gd.SerializeToString())
+    r = subprocess.run([sys.executable, "-m", "recom_amd.graph", str(src), "--plan", str(tmp_path / "m.fcp"),
+                        "--out", str(tmp_path / "out.pbtxt")], cwd=ROOT, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "2 concat group(s), 11 column(s)" in r.stdout
+    assert load_plan(str(tmp_path / "m.fcp")).n_columns == 11
+    out = parse_graphdef((tmp_path / "out.pbtxt").read_bytes())
+    assert any(n.op == "Addons>FeatureColumnProcessWithSymbols" for n in out.node)
