@@ -17,6 +17,7 @@
 //   hipcc -std=c++17 -shared -fPIC fcp_tf_ops.cc -o librecom_fcp.so \
 //     $(python -c 'import tensorflow as tf; print(" ".join(tf.sysconfig.get_compile_flags()+tf.sysconfig.get_link_flags()))') \
 //     -I../../include -L.. -lfcp_hip -Wl,-rpath,'$ORIGIN/..' -DTENSORFLOW_USE_ROCM=1
+#include <algorithm>
 #include <fstream>
 #include <numeric>
 #include <string>
@@ -198,13 +199,12 @@ public:
     r.output_ptrs = out_ptrs.data();
     r.output_shapes = shapes_t->flat<int32>().data();
     OP_REQUIRES_OK(c, FcpStatus(fcp_process_feature_columns(plan_, &a, &r), "FeatureColumnProcess"));
-    // output 0 (device int64[n_out]) is kept for signature compatibility only: the
-    // ConcatOutputs below derives everything from `buffer` and never dereferences
-    // it, so the reference's H2D copy + cudaStreamSynchronize
-    // (feature_column_process_op_gpu.cu.cc:119-123) are not needed.  Zero it
-    // asynchronously so the tensor is defined.
-    se::DeviceMemoryBase ptrs_mem(ptrs_t->data(), n_out * sizeof(int64));
-    c->op_device_context()->stream()->ThenMemZero(&ptrs_mem, n_out * sizeof(int64));
+    // output 0: in this shim `output_ptrs` is a HOST tensor (kernel registration below; the op
+    // signature is unchanged), so publishing the pointers is a plain store — the reference's H2D
+    // copy + cudaStreamSynchronize (feature_column_process_op_gpu.cu.cc:119-123) are not needed.
+    // ConcatOutputs only uses them to find its group's matrix inside the arena.
+    auto ptrs = ptrs_t->flat<int64>();
+    for (int i = 0; i < n_out; ++i) ptrs(i) = reinterpret_cast<int64>(out_ptrs[i]);
   }
 
 private:
@@ -226,6 +226,11 @@ public:
     OP_REQUIRES_OK(c, c->GetAttr("prefix_end", &prefix_end_));
     OP_REQUIRES(c, n_host_ == 0, errors::Unimplemented("route host concat inputs through ConcatInputs as PASSTHROUGH columns"));
     width_ = std::accumulate(embedd_dims_.begin(), embedd_dims_.end(), 0);
+    std::vector<int> input_idx, concat_idx;
+    OP_REQUIRES_OK(c, c->GetAttr("device_input_indices", &input_idx));
+    OP_REQUIRES_OK(c, c->GetAttr("device_concat_indices", &concat_idx));
+    OP_REQUIRES(c, !input_idx.empty() && input_idx.size() == concat_idx.size(), errors::InvalidArgument("device indices"));
+    first_input_ = input_idx[std::min_element(concat_idx.begin(), concat_idx.end()) - concat_idx.begin()];
   }
   void Compute(OpKernelContext *c) override {
     const int32 *shapes = c->input(1).flat<int32>().data();
@@ -233,12 +238,17 @@ public:
     for (int i = prefix_begin_; i < prefix_end_; ++i) out_shape.AddDim(shapes[i]);
     out_shape.AddDim(width_);
     const Tensor &arena = c->input(c->num_inputs() - 1); // FeatureColumnProcess:2 is wired last (cuda_emitter.cc:2632-2643)
+    // the group's matrix starts where the column at concat position 0 starts (host `output_ptrs`)
+    const int64 base = c->input(0).flat<int64>()(first_input_);
+    const int64 begin = base - reinterpret_cast<int64>(arena.data());
+    const int64 bytes = out_shape.num_elements() * static_cast<int64>(sizeof(T));
+    OP_REQUIRES(c, begin >= 0 && begin + bytes <= arena.NumElements(), errors::Internal("group outside the arena"));
     Tensor out;
-    OP_REQUIRES_OK(c, out.BitcastFrom(arena.Slice(0, out_shape.num_elements() * sizeof(T)), DataTypeToEnum<T>::value, out_shape));
+    OP_REQUIRES_OK(c, out.BitcastFrom(arena.Slice(begin, begin + bytes), DataTypeToEnum<T>::value, out_shape));
     c->set_output(0, out);
   }
 private:
-  int n_host_, prefix_begin_, prefix_end_, width_;
+  int n_host_, prefix_begin_, prefix_end_, width_, first_input_ = 0;
   std::vector<int> embedd_dims_;
 };
 
@@ -256,9 +266,9 @@ REGISTER_KERNEL_BUILDER(Name("Addons>ConcatInputs").Device(DEVICE_CPU), ConcatIn
 FCP_REGISTER_PROCESS("Addons>FeatureColumnProcess", );
 FCP_REGISTER_PROCESS("Addons>FeatureColumnProcessWithSymbols", .Input("symbols: int32"));
 REGISTER_KERNEL_BUILDER(Name("Addons>FeatureColumnProcess").Device(DEVICE_GPU).HostMemory("concated_offsets")
-                            .HostMemory("concated_shapes").HostMemory("output_shapes"), FeatureColumnProcessOp);
+                            .HostMemory("concated_shapes").HostMemory("output_ptrs").HostMemory("output_shapes"), FeatureColumnProcessOp);
 REGISTER_KERNEL_BUILDER(Name("Addons>FeatureColumnProcessWithSymbols").Device(DEVICE_GPU).HostMemory("concated_offsets")
-                            .HostMemory("concated_shapes").HostMemory("symbols").HostMemory("output_shapes"),
+                            .HostMemory("concated_shapes").HostMemory("symbols").HostMemory("output_ptrs").HostMemory("output_shapes"),
                         FeatureColumnProcessOp);
 
 #define FCP_CONCAT_ATTRS                                                                                   \
@@ -272,9 +282,9 @@ REGISTER_OP("Addons>ConcatOutputsNoHost").Input("device_input_ptrs: int64").Inpu
     .Input("tensor_buffers: buffer_types") FCP_CONCAT_ATTRS;
 #define FCP_REGISTER_CONCAT(T)                                                                             \
   REGISTER_KERNEL_BUILDER(Name("Addons>ConcatOutputs").Device(DEVICE_GPU).TypeConstraint<T>("T")           \
-                              .HostMemory("host_inputs").HostMemory("device_input_shapes"), ConcatOutputsOp<T>); \
+                              .HostMemory("host_inputs").HostMemory("device_input_ptrs").HostMemory("device_input_shapes"), ConcatOutputsOp<T>); \
   REGISTER_KERNEL_BUILDER(Name("Addons>ConcatOutputsNoHost").Device(DEVICE_GPU).TypeConstraint<T>("T")     \
-                              .HostMemory("device_input_shapes"), ConcatOutputsOp<T>);
+                              .HostMemory("device_input_ptrs").HostMemory("device_input_shapes"), ConcatOutputsOp<T>);
 FCP_REGISTER_CONCAT(float);
 FCP_REGISTER_CONCAT(int);
 
