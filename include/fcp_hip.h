@@ -256,8 +256,16 @@ int fcp_concat_outputs(const void *const *inputs, const int32_t *dims,
  * stager owns a ring of pinned host buffers with device twins: fcp_stager_stage
  * packs the tensors (same bytes, offsets and shapes as fcp_concat_inputs) with
  * `n_threads` worker threads straight into pinned memory and enqueues ONE
- * hipMemcpyAsync on `stream`.  The returned pointers stay valid until the slot is
- * reused, i.e. for the next depth-1 calls. */
+ * hipMemcpyAsync on the stager's own copy stream (so the copy of request k+1
+ * overlaps the kernel of request k); `stream` is made to wait for that copy.  The
+ * returned pointers stay valid until the slot is reused, i.e. for the next depth-1
+ * calls; the work that reads them must be enqueued on `stream` before the next call.
+ *
+ * fcp_stager_stage_narrow additionally converts the int64 inputs flagged in
+ * `narrow_int64[n_inputs]` to int32 while packing (values outside [0, 2^31) become
+ * -1, an invalid id / row either way): half the PCIe bytes for id and index tensors.
+ * The plan consuming such a blob declares those inputs as 4-byte (FCP_IDS_I32 /
+ * FCP_SEG_IDS_I32); results are unchanged. */
 typedef struct fcp_stager fcp_stager_t;
 int fcp_stager_create(int32_t device, int64_t capacity_bytes, int32_t max_inputs,
                       int32_t max_rank_sum, int32_t depth, int32_t n_threads,
@@ -266,6 +274,10 @@ int fcp_stager_stage(fcp_stager_t *stager, const fcp_host_tensor_t *inputs,
                      int32_t n_inputs, void *stream, const void **device_blob,
                      int64_t *blob_bytes, const int32_t **offsets,
                      const int32_t **shapes);
+int fcp_stager_stage_narrow(fcp_stager_t *stager, const fcp_host_tensor_t *inputs,
+                            int32_t n_inputs, const uint8_t *narrow_int64, void *stream,
+                            const void **device_blob, int64_t *blob_bytes,
+                            const int32_t **offsets, const int32_t **shapes);
 int fcp_stager_destroy(fcp_stager_t *stager);
 
 /* ---- multi-GPU finalize (no reference counterpart) --------- */

@@ -1044,81 +1044,18 @@ int fcp_shard_finalize(fcp_plan_t *p, const fcp_process_args_t *a, int32_t group
 
 // ============================ request staging ===============================
 // ConcatInputs + H2D as one step.  See include/fcp_hip.h.
-#include <atomic>
-#include <condition_variable>
-#include <thread>
+#include "numa_util.h"
+#include "pack_pool.h"
 
 namespace {
-
-// Minimal persistent worker pool: parallel_for over [0, n) in contiguous chunks.
-class PackPool {
-public:
-  explicit PackPool(int n_threads) {
-    for (int t = 1; t < n_threads; ++t) workers_.emplace_back([this] { loop(); });
-  }
-  ~PackPool() {
-    {
-      std::lock_guard<std::mutex> lk(mu_);
-      stop_ = true;
-      ++epoch_;
-    }
-    cv_.notify_all();
-    for (auto &w : workers_) w.join();
-  }
-  template <typename F> void run(int n_chunks, F &&fn) {
-    if (workers_.empty() || n_chunks <= 1) {
-      for (int c = 0; c < n_chunks; ++c) fn(c);
-      return;
-    }
-    {
-      std::lock_guard<std::mutex> lk(mu_);
-      fn_ = [&fn](int c) { fn(c); };
-      n_chunks_ = n_chunks;
-      next_.store(0);
-      pending_.store(n_chunks);
-      ++epoch_;
-    }
-    cv_.notify_all();
-    work(); // the caller helps
-    while (pending_.load(std::memory_order_acquire) > 0) std::this_thread::yield();
-  }
-
-private:
-  void work() {
-    for (;;) {
-      const int c = next_.fetch_add(1);
-      if (c >= n_chunks_) return;
-      fn_(c);
-      pending_.fetch_sub(1, std::memory_order_release);
-    }
-  }
-  void loop() {
-    uint64_t seen = 0;
-    for (;;) {
-      {
-        std::unique_lock<std::mutex> lk(mu_);
-        cv_.wait(lk, [&] { return epoch_ != seen; });
-        seen = epoch_;
-        if (stop_) return;
-      }
-      work();
-    }
-  }
-  std::vector<std::thread> workers_;
-  std::mutex mu_;
-  std::condition_variable cv_;
-  std::function<void(int)> fn_;
-  std::atomic<int> next_{0}, pending_{0};
-  int n_chunks_ = 0;
-  uint64_t epoch_ = 0;
-  bool stop_ = false;
-};
 
 struct StageSlot {
   char *h_blob = nullptr; // pinned
   char *d_blob = nullptr;
   int32_t *offsets = nullptr, *shapes = nullptr;
-  hipEvent_t copied = nullptr;
+  hipEvent_t copied = nullptr;   // H2D of this slot done (copy stream)
+  hipEvent_t consumed = nullptr; // consumer work of this slot enqueued before this point (caller's stream)
+  bool consumed_valid = false;
 };
 
 } // namespace
@@ -1129,7 +1066,9 @@ struct fcp_stager {
   int32_t max_inputs = 0, max_rank_sum = 0;
   std::vector<StageSlot> slots;
   size_t next = 0;
-  PackPool *pool = nullptr;
+  int last = -1;                 // slot handed out by the previous call
+  hipStream_t copy_stream = nullptr;
+  fcp::PackPool *pool = nullptr;
   int n_threads = 1;
   std::mutex mu;
   std::vector<int64_t> byte_off; // scratch
@@ -1157,38 +1096,59 @@ int fcp_stager_create(int32_t device, int64_t capacity_bytes, int32_t max_inputs
   for (auto &sl : s->slots) {
     if (hipHostMalloc(reinterpret_cast<void **>(&sl.h_blob), capacity_bytes, hipHostMallocDefault) != hipSuccess ||
         hipMalloc(reinterpret_cast<void **>(&sl.d_blob), capacity_bytes) != hipSuccess ||
-        hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&sl.consumed, hipEventDisableTiming) != hipSuccess) {
       fcp_stager_destroy(s);
       return hip_fail("stager allocation", hipGetLastError());
     }
     sl.offsets = new int32_t[max_inputs];
     sl.shapes = new int32_t[max_rank_sum > 0 ? max_rank_sum : 1];
   }
-  s->pool = new PackPool(n_threads);
+  if (hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking) != hipSuccess) {
+    fcp_stager_destroy(s);
+    return hip_fail("stager copy stream", hipGetLastError());
+  }
+  {
+    // pack next to the GPU: the H2D copy reads the pinned ring from that socket's memory
+    cpu_set_t near;
+    static const bool no_pin = std::getenv("FCP_STAGER_NO_PIN") != nullptr; // tuning aid
+    const bool pin = !no_pin && fcp::cpus_near_device(device, &near);
+    s->pool = new fcp::PackPool(n_threads, pin ? &near : nullptr);
+  }
   s->byte_off.resize(max_inputs + 1);
   *out = s;
   return FCP_OK;
 }
 
-int fcp_stager_stage(fcp_stager_t *s, const fcp_host_tensor_t *inputs, int32_t n, void *stream,
-                     const void **device_blob, int64_t *blob_bytes, const int32_t **offsets,
-                     const int32_t **shapes) {
+int fcp_stager_stage_narrow(fcp_stager_t *s, const fcp_host_tensor_t *inputs, int32_t n, const uint8_t *narrow,
+                            void *stream, const void **device_blob, int64_t *blob_bytes, const int32_t **offsets,
+                            const int32_t **shapes) {
   if (!s || n < 0 || (n > 0 && !inputs)) return fail(FCP_ERR_INVALID_ARGUMENT, "null argument");
   if (n > s->max_inputs) return fail(FCP_ERR_INVALID_ARGUMENT, "more inputs than the stager was created for");
   DeviceGuard guard;
   int rc = guard.enter(s->device);
   if (rc) return rc;
+  hipStream_t user = static_cast<hipStream_t>(stream);
   std::lock_guard<std::mutex> lock(s->mu);
+  // whatever consumes the previous slot has been enqueued on the caller's stream by now
+  if (s->last >= 0) {
+    StageSlot &prev = s->slots[s->last];
+    HIP_TRY(hipEventRecord(prev.consumed, user));
+    prev.consumed_valid = true;
+  }
+  const int slot_idx = (int)s->next;
   StageSlot &sl = s->slots[s->next];
   s->next = (s->next + 1) % s->slots.size();
   // the slot's previous copy must have left the pinned buffer
   if (hipEventQuery(sl.copied) != hipSuccess) HIP_TRY(hipEventSynchronize(sl.copied));
-  // sizes / offsets / shapes: exactly ConcatInputsOp::Compute (concat_inputs_ops.cc:52-66)
+  // sizes / offsets / shapes: exactly ConcatInputsOp::Compute (concat_inputs_ops.cc:52-66),
+  // except that a narrowed int64 input occupies 4 bytes per element
   int64_t size = 0;
   int32_t rank_sum = 0;
   for (int32_t i = 0; i < n; ++i) {
     const fcp_host_tensor_t &t = inputs[i];
     if (t.rank < 0 || t.elem_size <= 0 || (t.rank > 0 && !t.dims)) return fail(FCP_ERR_INVALID_ARGUMENT, "bad host tensor");
+    if (narrow && narrow[i] && t.elem_size != 8) return fail(FCP_ERR_INVALID_ARGUMENT, "only 8-byte inputs can be narrowed");
     if (rank_sum + t.rank > s->max_rank_sum) return fail(FCP_ERR_INVALID_ARGUMENT, "more dims than the stager was created for");
     int64_t ne = 1;
     for (int32_t j = 0; j < t.rank; ++j) {
@@ -1198,7 +1158,7 @@ int fcp_stager_stage(fcp_stager_t *s, const fcp_host_tensor_t *inputs, int32_t n
     }
     s->byte_off[i] = size;
     sl.offsets[i] = (int32_t)size;
-    size += ne * t.elem_size;
+    size += ne * ((narrow && narrow[i]) ? 4 : t.elem_size);
     if (size > s->capacity) return fail(FCP_ERR_INVALID_ARGUMENT, "request larger than the stager capacity");
     if (ne && !t.data) return fail(FCP_ERR_INVALID_ARGUMENT, "null tensor data");
   }
@@ -1212,11 +1172,28 @@ int fcp_stager_stage(fcp_stager_t *s, const fcp_host_tensor_t *inputs, int32_t n
     // inputs whose start offset falls in [b0, b1)
     int lo = (int)(std::lower_bound(bo, bo + n, b0) - bo);
     const int hi = (int)(std::lower_bound(bo, bo + n, b1) - bo);
-    for (; lo < hi; ++lo)
-      if (bo[lo + 1] > bo[lo]) std::memcpy(dst + bo[lo], inputs[lo].data, (size_t)(bo[lo + 1] - bo[lo]));
+    for (; lo < hi; ++lo) {
+      if (bo[lo + 1] <= bo[lo]) continue;
+      if (narrow && narrow[lo]) {
+        // int64 -> int32; values that do not fit are not valid ids / rows anyway: -1 (reads as zeros)
+        const int64_t *src = static_cast<const int64_t *>(inputs[lo].data);
+        int32_t *d32 = reinterpret_cast<int32_t *>(dst + bo[lo]);
+        const int64_t ne = (bo[lo + 1] - bo[lo]) / 4;
+        for (int64_t k = 0; k < ne; ++k) {
+          const int64_t v = src[k];
+          d32[k] = (v >= 0 && v <= 0x7fffffff) ? (int32_t)v : -1;
+        }
+      } else {
+        std::memcpy(dst + bo[lo], inputs[lo].data, (size_t)(bo[lo + 1] - bo[lo]));
+      }
+    }
   });
-  if (size) HIP_TRY(hipMemcpyAsync(sl.d_blob, sl.h_blob, (size_t)size, hipMemcpyHostToDevice, static_cast<hipStream_t>(stream)));
-  HIP_TRY(hipEventRecord(sl.copied, static_cast<hipStream_t>(stream)));
+  // the device twin is free once the work that read its previous contents has run
+  if (sl.consumed_valid) HIP_TRY(hipStreamWaitEvent(s->copy_stream, sl.consumed, 0));
+  if (size) HIP_TRY(hipMemcpyAsync(sl.d_blob, sl.h_blob, (size_t)size, hipMemcpyHostToDevice, s->copy_stream));
+  HIP_TRY(hipEventRecord(sl.copied, s->copy_stream));
+  HIP_TRY(hipStreamWaitEvent(user, sl.copied, 0));
+  s->last = slot_idx;
   if (device_blob) *device_blob = sl.d_blob;
   if (blob_bytes) *blob_bytes = size;
   if (offsets) *offsets = sl.offsets;
@@ -1224,16 +1201,27 @@ int fcp_stager_stage(fcp_stager_t *s, const fcp_host_tensor_t *inputs, int32_t n
   return FCP_OK;
 }
 
+int fcp_stager_stage(fcp_stager_t *s, const fcp_host_tensor_t *inputs, int32_t n, void *stream,
+                     const void **device_blob, int64_t *blob_bytes, const int32_t **offsets,
+                     const int32_t **shapes) {
+  return fcp_stager_stage_narrow(s, inputs, n, nullptr, stream, device_blob, blob_bytes, offsets, shapes);
+}
+
 int fcp_stager_destroy(fcp_stager_t *s) {
   if (!s) return FCP_OK;
   DeviceGuard guard;
   (void)guard.enter(s->device);
   delete s->pool;
+  if (s->copy_stream) {
+    (void)hipStreamSynchronize(s->copy_stream);
+    (void)hipStreamDestroy(s->copy_stream);
+  }
   for (auto &sl : s->slots) {
     if (sl.copied) {
       (void)hipEventSynchronize(sl.copied);
       (void)hipEventDestroy(sl.copied);
     }
+    if (sl.consumed) (void)hipEventDestroy(sl.consumed);
     if (sl.h_blob) (void)hipHostFree(sl.h_blob);
     if (sl.d_blob) (void)hipFree(sl.d_blob);
     delete[] sl.offsets;

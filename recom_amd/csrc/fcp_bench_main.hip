@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "../../include/fcp_hip.h"
+#include "numa_util.h"
 
 struct fcp_harness;
 extern "C" int fcp_harness_create(fcp_plan_t *, const fcp_process_args_t *, int, int, int, fcp_harness **);
@@ -96,6 +97,7 @@ int main(int argc, char **argv) {
   int bucketize_every = 10; // every N-th column is bucketize-f32 sourced (0 = none)
   int slab = 0;             // 1: all tables carved from ONE hipMalloc (as under TF's BFC allocator)
   int h2d = 0;              // 1: PCIe-inclusive loop: stage (pack + H2D) every request, then process
+  int narrow = 0;           // with --h2d: ship int64 ids as int32 (fcp_stager_stage_narrow)
   int pack_threads = 8;
   long vocab = 1000000;
   for (int i = 1; i + 1 < argc; i += 2) {
@@ -113,6 +115,7 @@ int main(int argc, char **argv) {
     else if (k == "--bucketize-every") bucketize_every = (int)v;
     else if (k == "--slab") slab = (int)v;
     else if (k == "--h2d") h2d = (int)v;
+    else if (k == "--narrow") narrow = (int)v;
     else if (k == "--pack-threads") pack_threads = (int)v;
     else if (k == "--bw-probe") {
       const char *names[4] = {"read", "write", "write-nt", "chunked-write-nt"};
@@ -318,8 +321,31 @@ int main(int argc, char **argv) {
 
   // ---- PCIe-inclusive loop: host tensors -> pinned ring -> H2D -> kernel ----
   if (h2d) {
+    {
+      // the driver thread packs too: keep it on the GPU's socket (what `numactl` would do for a server)
+      cpu_set_t near;
+      if (!std::getenv("FCP_STAGER_NO_PIN") && fcp::cpus_near_device(0, &near)) (void)sched_setaffinity(0, sizeof(near), &near);
+    }
     fcp_stager_t *st = nullptr;
     CHECK_FCP(fcp_stager_create(0, (int64_t)blobs[0].size() + 4096, columns, columns, 4, pack_threads, &st));
+    std::vector<uint8_t> nflags(columns, 0);
+    size_t shipped = blobs[0].size();
+    if (narrow) {
+      // same model, ids declared 4-byte: the stager converts while packing
+      shipped = 0;
+      for (int c = 0; c < columns; ++c) {
+        if (cols[c].id_source == FCP_IDS_I64) {
+          cols[c].id_source = FCP_IDS_I32;
+          esz[c] = 4;
+          nflags[c] = 1;
+        }
+        shipped += (size_t)batch * 4;
+      }
+      CHECK_FCP(fcp_plan_destroy(plan));
+      CHECK_FCP(fcp_plan_create(&pd, &plan));
+      for (int c = 0; c < columns; ++c)
+        if (nflags[c]) esz[c] = 8; // host tensors stay int64
+    }
     std::vector<std::vector<fcp_host_tensor_t>> host(requests, std::vector<fcp_host_tensor_t>(columns));
     std::vector<int64_t> dims(1, batch);
     for (int v = 0; v < requests; ++v)
@@ -336,8 +362,9 @@ int main(int argc, char **argv) {
       const int v = k % requests;
       fcp_process_args_t a;
       std::memset(&a, 0, sizeof(a));
-      CHECK_FCP(fcp_stager_stage(st, host[v].data(), columns, stream, &a.concated_inputs, &a.concated_bytes,
-                                 &a.concated_offsets, &a.concated_shapes));
+      CHECK_FCP(fcp_stager_stage_narrow(st, host[v].data(), columns, narrow ? nflags.data() : nullptr, stream,
+                                        &a.concated_inputs, &a.concated_bytes, &a.concated_offsets,
+                                        &a.concated_shapes));
       a.input_ptrs = tables.data();
       a.stream = stream;
       a.malloc_buff_ctx = &rc;
@@ -360,7 +387,7 @@ int main(int argc, char **argv) {
     }
     std::printf("{\"pcie_inclusive\": true, \"pack_threads\": %d, \"blob_MB\": %.2f, \"us_per_request_pipelined\": %.2f, "
                 "\"us_latency_single\": %.2f, \"inferences_per_s\": %.0f}\n",
-                pack_threads, blobs[0].size() / 1e6, us, lat / 50, batch / (us * 1e-6));
+                pack_threads, shipped / 1e6, us, lat / 50, batch / (us * 1e-6));
     CHECK_FCP(fcp_stager_destroy(st));
     CHECK_FCP(fcp_plan_destroy(plan));
     return 0;

@@ -1,0 +1,119 @@
+// pack_pool.h — worker pool of the request stager (fcp_stager_*, include/fcp_hip.h).
+// Plain C++ (no HIP) so that tests/native/pack_pool_stress.cc can run it under
+// ThreadSanitizer on the CPU.
+#pragma once
+#include <atomic>
+#include <condition_variable>
+#include <cstdint>
+#include <mutex>
+#include <pthread.h>
+#include <sched.h>
+#include <thread>
+#include <type_traits>
+#include <vector>
+
+namespace fcp {
+
+// Persistent worker pool: parallel_for over [0, n_chunks).  Requests arrive every few tens of
+// microseconds, so workers spin for a short while after each job before they go to sleep
+// (a futex wake-up costs more than packing one request).  Chunk claims carry the job's
+// epoch and chunk count together with the next chunk index in one 64-bit word and advance by
+// compare-exchange, so a worker that is late leaving job e can neither run nor skip a chunk
+// of job e+1.
+class PackPool {
+public:
+  // `affinity` (optional): CPUs the workers may run on
+  explicit PackPool(int n_threads, const cpu_set_t *affinity = nullptr) {
+    if (affinity) {
+      affinity_ = *affinity;
+      pinned_ = true;
+    }
+    for (int t = 1; t < n_threads; ++t)
+      workers_.emplace_back([this] {
+        if (pinned_) (void)pthread_setaffinity_np(pthread_self(), sizeof(affinity_), &affinity_);
+        loop();
+      });
+  }
+  ~PackPool() {
+    stop_.store(true, std::memory_order_release);
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+    }
+    cv_.notify_all();
+    for (auto &w : workers_) w.join();
+  }
+  template <typename F> void run(int n_chunks, F &&fn) {
+    if (workers_.empty() || n_chunks <= 1) {
+      for (int c = 0; c < n_chunks; ++c) fn(c);
+      return;
+    }
+    if (n_chunks > kMaxChunks) n_chunks = kMaxChunks; // never reached by the stager (<= 4 x threads)
+    using Fn = typename std::remove_reference<F>::type;
+    call_ = [](void *p, int c) { (*static_cast<Fn *>(p))(c); };
+    ctx_ = const_cast<void *>(static_cast<const void *>(&fn));
+    const uint64_t e = epoch_.load(std::memory_order_relaxed) + 1;
+    pending_.store(n_chunks, std::memory_order_relaxed);
+    // one word = job epoch | chunk count | next chunk: a claim can only succeed against the
+    // job it was computed for; the release store publishes call_/ctx_ to every claimer
+    next_.store(pack(e, n_chunks, 0), std::memory_order_release);
+    epoch_.store(e, std::memory_order_release);
+    {
+      std::lock_guard<std::mutex> lk(mu_); // a worker between its predicate check and its wait holds mu_
+    }
+    cv_.notify_all();
+    work(e); // the caller helps
+    while (pending_.load(std::memory_order_acquire) > 0) __builtin_ia32_pause();
+  }
+
+private:
+  static constexpr int kIdxBits = 20, kMaxChunks = (1 << kIdxBits) - 1;
+  static uint64_t pack(uint64_t e, int n, int idx) {
+    return (e << (2 * kIdxBits)) | ((uint64_t)n << kIdxBits) | (uint64_t)idx;
+  }
+  void work(uint64_t e) {
+    const uint64_t tag = pack(e, 0, 0) >> (2 * kIdxBits);
+    for (;;) {
+      uint64_t cur = next_.load(std::memory_order_acquire);
+      int idx;
+      for (;;) {
+        idx = (int)(cur & kMaxChunks);
+        if ((cur >> (2 * kIdxBits)) != tag || idx >= (int)((cur >> kIdxBits) & kMaxChunks)) return;
+        if (next_.compare_exchange_weak(cur, cur + 1, std::memory_order_acq_rel, std::memory_order_acquire)) break;
+      }
+      call_(ctx_, idx); // job e cannot end before this chunk is counted below
+      pending_.fetch_sub(1, std::memory_order_release);
+    }
+  }
+  void loop() {
+    uint64_t seen = 0;
+    for (;;) {
+      uint64_t e;
+      int spins = 0;
+      while ((e = epoch_.load(std::memory_order_acquire)) == seen) {
+        if (stop_.load(std::memory_order_acquire)) return;
+        if (++spins < kSpins) {
+          __builtin_ia32_pause();
+        } else {
+          std::unique_lock<std::mutex> lk(mu_);
+          cv_.wait(lk, [&] { return epoch_.load(std::memory_order_acquire) != seen || stop_.load(std::memory_order_acquire); });
+          spins = 0;
+        }
+      }
+      seen = e;
+      work(e);
+    }
+  }
+  static constexpr int kSpins = 1 << 16; // ~1-2 ms of pause instructions: longer than the gap between requests under load
+  cpu_set_t affinity_;
+  bool pinned_ = false;
+  std::vector<std::thread> workers_;
+  std::mutex mu_;
+  std::condition_variable cv_;
+  void (*call_)(void *, int) = nullptr;
+  void *ctx_ = nullptr;
+  std::atomic<uint64_t> next_{0}, epoch_{0};
+  std::atomic<int> pending_{0};
+  std::atomic<bool> stop_{false};
+};
+
+} // namespace fcp

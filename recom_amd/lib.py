@@ -93,7 +93,7 @@ EXPORTS = [
     "fcp_plan_create", "fcp_plan_destroy", "fcp_plan_group_width", "fcp_plan_column_offset",
     "fcp_plan_arena_bytes", "fcp_plan_read_bad_ids",
     "fcp_process_feature_columns", "fcp_concat_outputs", "fcp_shard_finalize",
-    "fcp_stager_create", "fcp_stager_stage", "fcp_stager_destroy",
+    "fcp_stager_create", "fcp_stager_stage", "fcp_stager_stage_narrow", "fcp_stager_destroy",
 ]
 
 _lib = None
@@ -141,6 +141,9 @@ def load() -> C.CDLL:
     L.fcp_stager_stage.argtypes = [C.c_void_p, C.POINTER(HostTensor), C.c_int32, C.c_void_p, C.POINTER(C.c_void_p),
                                    C.POINTER(C.c_int64), C.POINTER(C.POINTER(C.c_int32)),
                                    C.POINTER(C.POINTER(C.c_int32))]
+    L.fcp_stager_stage_narrow.argtypes = [C.c_void_p, C.POINTER(HostTensor), C.c_int32, C.POINTER(C.c_uint8),
+                                          C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
+                                          C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.POINTER(C.c_int32))]
     L.fcp_stager_destroy.argtypes = [C.c_void_p]
     if L.fcp_abi_version() != FCP_ABI_VERSION:
         raise ImportError("libfcp_hip.so ABI version mismatch; rebuild")

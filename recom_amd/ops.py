@@ -303,8 +303,9 @@ def concat_outputs(device_inputs: Sequence, stream: Optional[int] = None):
 class RequestStager:
     """Ring of pinned host buffers with device twins: ``stage(inputs)`` packs the host
     tensors exactly like :func:`concat_inputs` (multi-threaded, straight into pinned
-    memory) and enqueues one async H2D copy.  Returns ``(device_blob_ptr, nbytes,
-    offsets, shapes)``; the device blob stays valid for the next ``depth - 1`` calls."""
+    memory) and enqueues one async H2D copy on the stager's copy stream (``stream`` waits
+    for it).  Returns ``(device_blob_ptr, nbytes, offsets, shapes)``; the device blob
+    stays valid for the next ``depth - 1`` calls."""
 
     def __init__(self, capacity_bytes: int, max_inputs: int, max_rank_sum: int, device: int = 0, depth: int = 4,
                  n_threads: int = 8) -> None:
@@ -314,7 +315,10 @@ class RequestStager:
                                              C.byref(h)), "fcp_stager_create")
         self.handle = h
 
-    def stage(self, inputs: Sequence[np.ndarray], stream: Optional[int] = None):
+    def stage(self, inputs: Sequence[np.ndarray], stream: Optional[int] = None,
+              narrow: Optional[Sequence[bool]] = None):
+        """``narrow[i]``: ship int64 input ``i`` as int32 (``PlanSpec.narrowed()`` gives the
+        flags and the matching plan)."""
         import torch
         arrs = [np.require(np.asarray(a), requirements="C") for a in inputs]
         n = len(arrs)
@@ -327,8 +331,12 @@ class RequestStager:
             stream = torch.cuda.current_stream().cuda_stream
         blob, nbytes = C.c_void_p(), C.c_int64()
         offs, shps = C.POINTER(C.c_int32)(), C.POINTER(C.c_int32)()
-        _lib.check(self._L.fcp_stager_stage(self.handle, tens, n, stream, C.byref(blob), C.byref(nbytes),
-                                            C.byref(offs), C.byref(shps)), "fcp_stager_stage")
+        flags = None
+        if narrow is not None:
+            flags = (C.c_uint8 * max(n, 1))(*[1 if f else 0 for f in narrow])
+        _lib.check(self._L.fcp_stager_stage_narrow(self.handle, tens, n, flags, stream, C.byref(blob),
+                                                   C.byref(nbytes), C.byref(offs), C.byref(shps)),
+                   "fcp_stager_stage")
         rank_sum = sum(a.ndim for a in arrs)
         offsets = np.ctypeslib.as_array(offs, shape=(n,)).copy() if n else np.zeros(0, np.int32)
         shapes = np.ctypeslib.as_array(shps, shape=(rank_sum,)).copy() if rank_sum else np.zeros(0, np.int32)

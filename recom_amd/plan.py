@@ -162,6 +162,34 @@ class PlanSpec:
     def with_layout(self, layout: int) -> "PlanSpec":
         return dataclasses.replace(self, layout=layout)
 
+    def narrowed(self) -> "tuple[PlanSpec, List[bool]]":
+        """Plan for blobs staged with ``fcp_stager_stage_narrow``: every int64 id / segment-id
+        input is declared int32 (half the PCIe bytes; ids and rows are < 2^31).  Returns
+        the plan and the per-host-input narrow flags for the stager."""
+        flags = [False] * self.n_host_inputs
+        for c in self.columns:
+            if c.form in (FORM_GATHER, FORM_SEGMENT_REDUCE, FORM_GATHER_SCATTER):
+                if c.id_source == IDS_I64 and c.vocab <= 0x7fffffff:
+                    flags[c.ids_input] = True
+                if c.seg_kind == SEG_IDS_I64:
+                    flags[c.seg_input] = True
+        # an input stays 8-byte unless every column reading it agrees
+        for c in self.columns:
+            if c.form in (FORM_GATHER, FORM_SEGMENT_REDUCE, FORM_GATHER_SCATTER):
+                if c.id_source != IDS_I64 or c.vocab > 0x7fffffff:
+                    if c.ids_input >= 0 and self.host_input_elem_sizes[c.ids_input] == 8:
+                        flags[c.ids_input] = False
+        cols = []
+        for c in self.columns:
+            r = {}
+            if c.ids_input >= 0 and flags[c.ids_input] and c.id_source == IDS_I64:
+                r["id_source"] = IDS_I32
+            if c.seg_input >= 0 and flags[c.seg_input] and c.seg_kind == SEG_IDS_I64:
+                r["seg_kind"] = SEG_IDS_I32
+            cols.append(dataclasses.replace(c, **r) if r else c)
+        sizes = [4 if f else e for f, e in zip(flags, self.host_input_elem_sizes)]
+        return dataclasses.replace(self, columns=cols, host_input_elem_sizes=sizes), flags
+
     def column_subset(self, keep: Sequence[int]) -> "SubPlan":
         """Plan over the columns ``keep`` only (column-sharded serving: one such plan
         per GPU).  Host inputs and tables are renumbered to the ones those columns

@@ -454,6 +454,40 @@ def test_request_stager_matches_concat_inputs_and_feeds_the_kernel(torch_cuda, o
     st.close()
 
 
+def test_request_stager_narrows_int64_ids(torch_cuda, oracle):
+    """fcp_stager_stage_narrow: int64 ids / SparseTensor indices cross PCIe as int32; the
+    narrowed plan gives the same bits as the int64 request through the oracle —
+    including ids that do not fit (they are invalid in both: zeros)."""
+    import ctypes as C
+    from recom_amd import synth
+    from recom_amd.ops import FeatureColumnProcess, RequestStager, concat_inputs
+    torch = torch_cuda
+    m = synth.model_mixed(batch=70, vocab=997, n_groups=1)
+    nspec, flags = m.spec.narrowed()
+    assert any(flags) and nspec.validate() is None
+    tabs_np = m.numpy_tables()
+    tabs = [torch.from_numpy(t).cuda() for t in tabs_np]
+    op = FeatureColumnProcess(nspec, 0)
+    st = RequestStager(1 << 20, m.spec.n_host_inputs, sum(m.spec.host_input_ranks), depth=2, n_threads=3)
+    hip = C.CDLL("libamdhip64.so")
+    for seed in range(5):
+        req = m.make_request(seed)
+        ids0 = req.inputs[m.spec.columns[0].ids_input]
+        ids0[:3] = [(1 << 33) + 5, -3, 2 ** 31]          # none is a valid id; none fits int32 as itself
+        blob, offsets, shapes = concat_inputs(req.inputs)
+        d_ptr, nbytes, off2, shp2 = st.stage(req.inputs, narrow=flags)
+        assert nbytes == blob.nbytes - 4 * sum(req.inputs[i].size for i, f in enumerate(flags) if f)
+        assert np.array_equal(shp2, shapes)
+        tmp = torch.empty(nbytes, dtype=torch.int8, device="cuda")
+        torch.cuda.synchronize()
+        assert hip.hipMemcpy(C.c_void_p(tmp.data_ptr()), C.c_void_p(d_ptr), C.c_size_t(nbytes), 3) == 0
+        out = op(tmp, off2, shp2, tabs, req.symbols)
+        torch.cuda.synchronize()
+        want, _ = oracle.process_feature_columns(m.spec.to_dict(), blob, offsets, shapes, tabs_np, req.symbols)
+        assert np.array_equal(out.groups[0].cpu().numpy(), want[0])
+    st.close()
+
+
 def test_empty_batch(torch_cuda, oracle):
     """A request with zero rows: nothing is launched, shapes are still reported."""
     from recom_amd import synth

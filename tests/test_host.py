@@ -249,3 +249,57 @@ def test_plan_file_round_trip(tmp_path):
         assert ca == cb
         assert (ba is None and bb is None) or np.array_equal(ba, bb)
     assert a == b
+
+
+def test_narrowed_plan_and_column_subset():
+    """Host-side plan transforms: `narrowed()` (int64 ids shipped as int32 by the stager)
+    and `column_subset()` (column-sharded serving)."""
+    from recom_amd import synth
+    from recom_amd import plan as PL
+    m = synth.model_mixed(batch=9, vocab=97, n_groups=2)
+    n, flags = m.spec.narrowed()
+    n.validate()
+    for c0, c1 in zip(m.spec.columns, n.columns):
+        if c0.form in (1, 2, 3) and c0.id_source == PL.IDS_I64:
+            assert c1.id_source == PL.IDS_I32 and flags[c0.ids_input] and n.host_input_elem_sizes[c0.ids_input] == 4
+        if c0.seg_kind == PL.SEG_IDS_I64:
+            assert c1.seg_kind == PL.SEG_IDS_I32 and c1.seg_stride == c0.seg_stride and flags[c0.seg_input]
+        if c0.id_source == PL.IDS_F32_BUCKETIZE:
+            assert c1.id_source == c0.id_source
+        if c0.seg_kind == PL.SEG_CSR_I32:
+            assert c1.seg_kind == c0.seg_kind
+    assert not any(f and e != 8 for f, e in zip(flags, m.spec.host_input_elem_sizes))
+    # a vocabulary beyond int32 keeps 8-byte ids
+    big = synth.model_s2(columns=4, vocab=1 << 33)
+    nb, fb = big.spec.narrowed()
+    assert not any(fb) and nb.host_input_elem_sizes == big.spec.host_input_elem_sizes
+    # column subset: renumbered operands, same concat slots
+    keep = [k for k, c in enumerate(m.spec.columns) if c.concat_group == 0][2:6]
+    sub = m.spec.column_subset(keep)
+    sub.spec.validate()
+    assert sub.columns == keep and sub.spec.n_columns == 4
+    for k, c in zip(keep, sub.spec.columns):
+        o = m.spec.columns[k]
+        assert c.dim == o.dim and c.concat_slot == o.concat_slot
+        assert sub.host_inputs[c.ids_input] == o.ids_input
+        assert o.table_input < 0 or sub.device_inputs[c.table_input] == o.table_input
+
+
+def test_pack_pool_under_thread_sanitizer(tmp_path):
+    """The stager's worker pool (recom_amd/csrc/pack_pool.h) hammered with short
+    back-to-back jobs under ThreadSanitizer (CPU build; GPU sanitizers are unavailable)."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    exe = str(tmp_path / "pack_pool_stress")
+    build = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=thread",
+                            "-I", os.path.join(ROOT, "recom_amd", "csrc"),
+                            os.path.join(ROOT, "tests", "native", "pack_pool_stress.cc"), "-o", exe, "-lpthread"],
+                           capture_output=True, text=True)
+    if build.returncode != 0 and "tsan" in build.stderr.lower():
+        pytest.skip("libtsan not installed")
+    assert build.returncode == 0, build.stderr
+    for threads, jobs in ((4, 6000), (7, 3000)):
+        run = subprocess.run([exe, str(threads), str(jobs)], capture_output=True, text=True, timeout=300)
+        assert run.returncode == 0 and "ThreadSanitizer" not in run.stderr, run.stdout + run.stderr[-3000:]
