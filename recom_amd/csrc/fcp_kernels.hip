@@ -65,10 +65,12 @@ template <int V> __device__ __forceinline__ VF<V> vzero() {
   return r;
 }
 
-// Output rows are written once and consumed by a later kernel; table rows are
-// read once per request: both use the non-temporal forms (measured on S2:
-// 34.3 -> 30.5 us per request; stores give most of it).  -DFCP_NO_NT restores
-// the default cache policy (tuning builds).
+// Output rows are written once and consumed by a later kernel: non-temporal stores
+// (measured on S2: 34.3 -> 30.5 us per request).  Table rows are read with the DEFAULT
+// cache policy: streaming them (-DFCP_NT_LOADS) changes nothing on S2 (1M-row tables,
+// uniform ids) but costs the reference's models E / F 4.5 us per request — their ~1000
+// bucketize / hash tables of ~100 rows are re-read by every row and belong in L2.
+// -DFCP_NO_NT restores the default policy for stores as well (tuning builds).
 template <int V> __device__ __forceinline__ void st_out(float *p, const VF<V> &v) {
   typedef typename VecType<V>::T T;
   T t;
@@ -90,7 +92,7 @@ template <int V> __device__ __forceinline__ VF<V> ld_slot(const float *tb, uint3
   return z;
 #endif
   const FCP_GLOBAL T *g = as_global(reinterpret_cast<const T *>(tb)) + off;
-#if !defined(FCP_NO_NT)
+#if defined(FCP_NT_LOADS) // tuning build: stream table rows too (see the comment above st_out)
   T t = __builtin_nontemporal_load(g);
 #else
   T t = *g;
@@ -119,6 +121,9 @@ __device__ __forceinline__ int64_t ld_i64_a4(const char *p) {
 
 // cuda_emitter.cc:233-247 — r+1 = number of boundaries <= value.
 template <typename P> __device__ __forceinline__ int bucketize(P b, int n, float value) {
+#if defined(FCP_ABLATE) && FCP_ABLATE == 5 // timing-only build 5: no boundary search
+  return (int)value & 63;
+#endif
   int l = 0, r = n - 1;
   while (l <= r) {
     const int mid = (l + r) >> 1;

@@ -117,6 +117,22 @@ class SynthModel:
         return sum(t.vocab * t.dim * 4 for t in self.tables)
 
 
+def submodel(model: SynthModel, keep: Sequence[int], name: Optional[str] = None) -> SynthModel:
+    """The model restricted to the columns ``keep`` (same tables, same request stream:
+    request ``seed`` of the sub-model carries exactly the kept columns' tensors of request
+    ``seed`` of the full model).  Used for column-sharded serving and for timing parts of
+    a model in isolation."""
+    sub = model.spec.column_subset(keep)
+
+    def make_request(seed: int, B: int = model.batch) -> Request:
+        r = model.make_request(seed, B)
+        return Request([r.inputs[i] for i in sub.host_inputs], r.symbols)
+
+    return SynthModel(name or f"{model.name}[{len(sub.columns)} cols]", sub.spec,
+                      [model.tables[i] for i in sub.device_inputs], model.batch, make_request,
+                      f"{len(sub.columns)} of {model.spec.n_columns} columns of: {model.description}")
+
+
 class _Builder:
     """Assigns host-input / table slots while columns are added."""
 
