@@ -158,6 +158,39 @@ int fcp_harness_run(fcp_harness *h, int steps, double *wall_ms, float *dev_ms, f
   return FCP_OK;
 }
 
+// Same protocol, but `group` consecutive requests of worker 0 are captured ONCE into a HIP
+// graph (fcp_process_feature_columns is capture-safe when its descriptors are cached: it then
+// only enqueues kernels) and the graph is replayed steps / group times.  For fixed-shape
+// models (one-hot columns: S2, DLRM); a request with new shapes needs a new capture.
+int fcp_harness_run_graph(fcp_harness *h, int steps, int group, double *wall_ms, float *dev_ms) {
+  if (!h || group < 1 || steps < group || steps % group) return FCP_ERR_INVALID_ARGUMENT;
+  hipStream_t s = h->streams[0];
+  h->issue(0, 0, group); // descriptors of the captured variants are now resident
+  H_TRY(hipStreamSynchronize(s));
+  if (h->status[0]) return h->status[0];
+  h->rings[0].next = 0;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  H_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+  h->issue(0, 0, group);
+  H_TRY(hipStreamEndCapture(s, &graph));
+  if (h->status[0]) return h->status[0];
+  H_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+  H_TRY(hipGraphLaunch(exec, s)); // warm-up replay
+  H_TRY(hipStreamSynchronize(s));
+  const auto t0 = std::chrono::steady_clock::now();
+  H_TRY(hipEventRecord(h->e0, s));
+  for (int k = 0; k < steps / group; ++k) H_TRY(hipGraphLaunch(exec, s));
+  H_TRY(hipEventRecord(h->e1, s));
+  H_TRY(hipStreamSynchronize(s));
+  const auto t1 = std::chrono::steady_clock::now();
+  if (wall_ms) *wall_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+  if (dev_ms) H_TRY(hipEventElapsedTime(dev_ms, h->e0, h->e1));
+  (void)hipGraphExecDestroy(exec);
+  (void)hipGraphDestroy(graph);
+  return FCP_OK;
+}
+
 int fcp_harness_destroy(fcp_harness *h) {
   if (!h) return FCP_OK;
   for (size_t t = 0; t < h->streams.size(); ++t) {

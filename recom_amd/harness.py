@@ -34,6 +34,8 @@ def load() -> C.CDLL:
                                          C.POINTER(C.c_void_p)]
         H.fcp_harness_run.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_float),
                                       C.c_void_p]
+        H.fcp_harness_run_graph.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double),
+                                            C.POINTER(C.c_float)]
         H.fcp_harness_destroy.argtypes = [C.c_void_p]
         H.fcp_harness_copy_probe.argtypes = [C.c_size_t, C.c_int, C.POINTER(C.c_float)]
         _h = H
@@ -87,6 +89,14 @@ class ServingHarness:
         _lib.check(self.H.fcp_harness_run(self.handle, steps, C.byref(wall), C.byref(dev),
                                           None if it is None else it.ctypes.data), "fcp_harness_run")
         return wall.value, dev.value, it
+
+    def run_graph(self, steps: int, group: int):
+        """`group` requests captured once into a HIP graph, replayed steps / group times
+        (fixed-shape models only).  Returns (wall_ms, dev_ms)."""
+        wall, dev = C.c_double(), C.c_float()
+        _lib.check(self.H.fcp_harness_run_graph(self.handle, steps, group, C.byref(wall), C.byref(dev)),
+                   "fcp_harness_run_graph")
+        return wall.value, dev.value
 
     def algorithmic_bytes(self) -> dict:
         """Mean algorithmic bytes per request over the resident requests."""

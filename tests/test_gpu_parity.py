@@ -488,6 +488,39 @@ def test_request_stager_narrows_int64_ids(torch_cuda, oracle):
     st.close()
 
 
+def test_process_call_is_hip_graph_capturable(torch_cuda, oracle):
+    """With its descriptors cached, fcp_process_feature_columns only enqueues kernels (here the
+    segment-offset pre-pass + the ragged kernel), so a serving loop can capture it into a HIP
+    graph; a replay reads the current contents of the blob."""
+    from recom_amd import synth
+    from recom_amd.ops import FeatureColumnProcess, concat_inputs
+    torch = torch_cuda
+    m = synth.model_mixed(batch=64, vocab=997, n_groups=1)
+    tabs_np = m.numpy_tables()
+    tabs = [torch.from_numpy(t).cuda() for t in tabs_np]
+    op = FeatureColumnProcess(m.spec, 0)
+    req = m.make_request(1)
+    blob, offsets, shapes = concat_inputs(req.inputs)
+    d_blob = torch.from_numpy(blob).cuda()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        op(d_blob, offsets, shapes, tabs, req.symbols)        # descriptors become resident
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        out = op(d_blob, offsets, shapes, tabs, req.symbols)
+    ids0 = req.inputs[m.spec.columns[0].ids_input]
+    for bump in (1, 7):                                        # same shapes, new ids
+        ids0[:] = (ids0 + bump) % 997
+        blob2, o2, s2 = concat_inputs(req.inputs)
+        assert np.array_equal(o2, offsets) and np.array_equal(s2, shapes)
+        d_blob.copy_(torch.from_numpy(blob2))
+        g.replay()
+        torch.cuda.synchronize()
+        want, _ = oracle.process_feature_columns(m.spec.to_dict(), blob2, offsets, shapes, tabs_np, req.symbols)
+        assert np.array_equal(out.groups[0].cpu().numpy(), want[0])
+
+
 def test_empty_batch(torch_cuda, oracle):
     """A request with zero rows: nothing is launched, shapes are still reported."""
     from recom_amd import synth
