@@ -424,6 +424,36 @@ def test_s2_full_size_closed_form(torch_cuda):
     torch.cuda.empty_cache()
 
 
+def test_ragged_full_size_closed_form(torch_cuda):
+    """BASELINE.json configs[3] at full size: 512 multi-hot columns, vocab 100k (6 GB of
+    tables), batch 256, 0..10 ids per row, CSR offsets, sum / mean alternating.  Every pooled
+    vector is rebuilt from the closed-form table rows with fp32 adds in id order — bit-exact."""
+    from recom_amd import synth
+    from recom_amd.plan import COMBINER_MEAN
+    torch = torch_cuda
+    m = synth.model_ragged()
+    tabs = m.torch_tables(torch.device("cuda", 0))
+    op = None
+    for seed in (0, 5):                                     # different nnz: new descriptors
+        req = m.make_request(seed)
+        out, _, op = run_gpu(torch, m.spec, req.inputs, None, req.symbols, op, tables_dev=tabs)
+        got = out.groups[0].cpu().numpy()
+        assert got.shape == (256, 15360)
+        offs = m.spec.column_offsets()
+        for k, c in enumerate(m.spec.columns):
+            ids, csr = req.inputs[c.ids_input], req.inputs[c.seg_input].astype(np.int64)
+            rows = synth.hash_rows(m.tables[c.table_input].seed, ids, c.dim)
+            want = np.zeros((256, c.dim), np.float32)
+            seg = np.repeat(np.arange(256), np.diff(csr))
+            np.add.at(want, seg, rows)                       # unbuffered: adds in id order, fp32
+            if c.combiner == COMBINER_MEAN:
+                cnt = np.diff(csr).astype(np.float32)
+                want[cnt > 0] = want[cnt > 0] / cnt[cnt > 0, None]
+            assert np.array_equal(got[:, offs[k]:offs[k] + c.dim], want), f"column {k}"
+    del tabs
+    torch.cuda.empty_cache()
+
+
 def test_request_stager_matches_concat_inputs_and_feeds_the_kernel(torch_cuda, oracle):
     """ConcatInputs + H2D as one step.  The staged device blob is
     byte-identical to ConcatInputs' output; offsets / shapes are the same arrays; the
