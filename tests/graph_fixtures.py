@@ -229,3 +229,110 @@ def microbenchmark_model(columns=6, B=32, seed=0):
            Tidx=("type", P.DT_INT32))
     g.node("output", "Identity", ["input_layer/concat"], T=("type", P.DT_FLOAT))
     return g.gd, feeds, variables, ["output"]
+
+
+def random_model(seed):
+    """Random rewritten graph: 1-3 concat groups (each with its own row count), 2-14 columns per
+    group of random kind / dim / vocabulary / id dtype, occasionally sharing a table with the
+    previous lookup of the same dim.  Returns (graph_def, feeds, variables, fetches, kinds)."""
+    rng = np.random.default_rng(1000 + seed)
+    g = GB()
+    feeds, variables, fetches, kinds = {}, {}, [], []
+    uid = [0]
+
+    def name(s):
+        uid[0] += 1
+        return f"n{uid[0]}_{s}"
+
+    last_table = {}
+
+    def table(dim):
+        if dim in last_table and rng.random() < 0.25:
+            return last_table[dim]
+        vocab = int(rng.integers(3, 400))
+        t = g.variable(name("emb") + "/embedding_weights", vocab, dim)
+        variables[t] = rng.standard_normal((vocab, dim)).astype(np.float32)
+        last_table[dim] = (t, vocab)
+        return t, vocab
+
+    def sparse(rows, vocab, max_len):
+        p = name("sp")
+        lens = rng.integers(0, max_len + 1, size=rows)
+        nnz = int(lens.sum())
+        k = int(rng.integers(2, 4))                      # rank of the SparseTensor: indices [nnz, 2] or [nnz, 3]
+        cols = [np.repeat(np.arange(rows), lens)] + [np.zeros(nnz, np.int64)] * (k - 1)
+        g.placeholder(p + "/values", np.int64, [-1])
+        g.placeholder(p + "/indices", np.int64, [-1, k])
+        g.placeholder(p + "/rows", np.int64, [1])
+        feeds[p + "/values"] = rng.integers(0, vocab, size=nnz).astype(np.int64)
+        feeds[p + "/indices"] = np.stack(cols, 1).astype(np.int64).reshape(nnz, k)
+        feeds[p + "/rows"] = np.asarray([rows], np.int64)
+        g.node(p + "/n", "Squeeze", [p + "/rows"], T=("type", P.DT_INT64), squeeze_dims=("ints", [0]))
+        return p, p + "/values", p + "/indices", p + "/n"
+
+    for grp in range(int(rng.integers(1, 4))):
+        B = int(rng.integers(1, 40))
+        ins = []
+        for _ in range(int(rng.integers(2, 15))):
+            kind = str(rng.choice(["dense64", "dense32", "bucket", "mean", "sum", "scatter", "pass", "sum3d"]))
+            dim = int(rng.choice([4, 8, 12, 16, 20, 32, 64]))
+            kinds.append(kind)
+            if kind in ("dense64", "dense32"):
+                (t, vocab), dt = table(dim), (np.int64 if kind == "dense64" else np.int32)
+                two_d = rng.random() < 0.5
+                ph = name("ids")
+                g.placeholder(ph, dt, [-1, 1] if two_d else [-1])
+                feeds[ph] = rng.integers(0, vocab, size=(B, 1) if two_d else (B,)).astype(dt)
+                out = g.gather(name("GatherDense"), t, ph, dt)
+                if two_d:
+                    shp = g.const(name("shape"), np.asarray([-1, dim], np.int32))
+                    out = g.node(name("Reshape"), "Reshape", [out, shp], T=("type", P.DT_FLOAT),
+                                 Tshape=("type", P.DT_INT32))
+                ins.append(out)
+            elif kind == "bucket":
+                nb = int(rng.integers(1, 60))
+                bnd = np.sort(rng.uniform(-50, 50, nb)).astype(np.float32)
+                t = g.variable(name("emb") + "/embedding_weights", nb + 1, dim)
+                variables[t] = rng.standard_normal((nb + 1, dim)).astype(np.float32)
+                ph = name("val")
+                g.placeholder(ph, np.float32, [-1])
+                v = rng.uniform(-60, 60, B).astype(np.float32)
+                v[: min(B, nb)] = bnd[: min(B, nb)]          # exact boundary hits
+                feeds[ph] = v
+                bk = g.node(name("Bucketize"), "Bucketize", [ph], T=("type", P.DT_FLOAT),
+                            boundaries=("floats", [float(x) for x in bnd]))
+                ins.append(g.gather(name("GatherDense"), t, bk, np.int32))
+            elif kind in ("mean", "sum"):
+                t, vocab = table(dim)
+                p, v, i, n = sparse(B, vocab, int(rng.integers(1, 12)))
+                seg = g.slice_col0(p + "/added_strided_slice", i, shrink=True)
+                op = "SparseSegmentMeanWithNumSegments" if kind == "mean" else "SparseSegmentSumWithNumSegments"
+                ins.append(g.node(name(op), op, [t, v, seg, n], T=("type", P.DT_FLOAT), Tidx=("type", P.DT_INT64),
+                                  Tsegmentids=("type", P.DT_INT64), Tnumsegments=("type", P.DT_INT64)))
+            elif kind == "scatter":
+                t, vocab = table(dim)
+                p, v, i, n = sparse(B, vocab, 1)
+                rows = g.slice_col0(p + "/added_strided_slice", i, shrink=False)
+                gat = g.gather(name("Gather"), t, v, np.int64)
+                d = g.const(name("dim"), np.asarray(dim, np.int64))
+                shp = g.node(name("Scatter_shape"), "Pack", [n, d], N=2, T=("type", P.DT_INT64), axis=0)
+                ins.append(g.node(name("Scatter"), "ScatterNd", [rows, gat, shp], T=("type", P.DT_FLOAT),
+                                  Tindices=("type", P.DT_INT64)))
+            elif kind == "pass":
+                ph = name("dense")
+                g.placeholder(ph, np.float32, [-1, dim])
+                feeds[ph] = rng.standard_normal((B, dim)).astype(np.float32)
+                ins.append(ph)
+            else:
+                r = int(rng.integers(1, 6))
+                ph = name("seq")
+                g.placeholder(ph, np.float32, [-1, r, dim])
+                feeds[ph] = rng.standard_normal((B, r, dim)).astype(np.float32)
+                ax = g.const(name("axis"), np.asarray(1, np.int32))
+                ins.append(g.node(name("Sum"), "Sum", [ph, ax], T=("type", P.DT_FLOAT), Tidx=("type", P.DT_INT32),
+                                  keep_dims=False))
+        ax = g.const(name("concat_axis"), np.asarray(1, np.int32))
+        c = g.node(f"group{grp}/concat", "ConcatV2", ins + [ax], N=len(ins), T=("type", P.DT_FLOAT),
+                   Tidx=("type", P.DT_INT32))
+        fetches.append(g.node(f"output_{grp}", "Identity", [c], T=("type", P.DT_FLOAT)))
+    return g.gd, feeds, variables, fetches, kinds

@@ -320,19 +320,12 @@ def test_column_sharded_blocks_concat(torch_cuda, oracle):
         assert np.array_equal(got.cpu().numpy(), ref[begin:begin + count])
 
 
-@pytest.mark.parametrize("B,seed", [(19, 0), (300, 3)])
-def test_graphdef_to_hip_path(torch_cuda, tmp_path, B, seed):
-    """SURVEY §8f-1 end to end: a GraphDef in the reference's canonical rewritten form →
-    plan builder → plan file → rewritten graph whose three Addons> ops run the HIP path;
-    the concat outputs equal the original graph evaluated op by op in NumPy (TF-CPU
-    semantics, fp32 adds in id order) bit for bit."""
-    from graph_fixtures import canonical_model
+def _graph_through_hip(torch, gd, feeds, variables, fetches, tmp_path):
+    """original graph in NumPy vs rewritten graph with the HIP path behind the Addons> ops"""
     from tf_graph_eval import GraphEvaluator
     from recom_amd.graph import build_plan, parse_graphdef, rewrite_graph
     from recom_amd.ops import FeatureColumnProcess, concat_inputs
     from recom_amd.plan_io import load_plan, save_plan
-    torch = torch_cuda
-    gd, feeds, variables, fetches = canonical_model(B=B, seed=seed)
     expected = GraphEvaluator(gd, variables).run(fetches, feeds)
     built = build_plan(gd)
     path = str(tmp_path / "model.fcp")
@@ -362,6 +355,26 @@ def test_graphdef_to_hip_path(torch_cuda, tmp_path, B, seed):
     got = GraphEvaluator(out_gd, variables, custom).run(fetches, feeds)
     for e, o in zip(expected, got):
         assert e.shape == o.shape and np.array_equal(e, o)
+    return built
+
+
+@pytest.mark.parametrize("B,seed", [(19, 0), (300, 3)])
+def test_graphdef_to_hip_path(torch_cuda, tmp_path, B, seed):
+    """SURVEY §8f-1 end to end: a GraphDef in the reference's canonical rewritten form →
+    plan builder → plan file → rewritten graph whose three Addons> ops run the HIP path;
+    the concat outputs equal the original graph evaluated op by op in NumPy (TF-CPU
+    semantics, fp32 adds in id order) bit for bit."""
+    from graph_fixtures import canonical_model
+    gd, feeds, variables, fetches = canonical_model(B=B, seed=seed)
+    built = _graph_through_hip(torch_cuda, gd, feeds, variables, fetches, tmp_path)
+    assert built.spec.n_columns == 11 and built.spec.n_groups == 2
+
+
+@pytest.mark.parametrize("seed", [0, 3, 7, 10])
+def test_random_graphdefs_to_hip_path(torch_cuda, tmp_path, seed):
+    from graph_fixtures import random_model
+    gd, feeds, variables, fetches, _ = random_model(seed)
+    _graph_through_hip(torch_cuda, gd, feeds, variables, fetches, tmp_path)
 
 
 def test_dlrm_scaled_vs_oracle(torch_cuda, oracle):

@@ -11,7 +11,7 @@ import sys
 import numpy as np
 import pytest
 
-from graph_fixtures import MICRO_BOUNDARIES, canonical_model, microbenchmark_model
+from graph_fixtures import MICRO_BOUNDARIES, canonical_model, microbenchmark_model, random_model
 from recom_amd import plan as PL
 from recom_amd.graph import Unsupported, build_plan, parse_graphdef, rewrite_graph
 from recom_amd.graph import tf_proto as P
@@ -189,6 +189,27 @@ def test_microbenchmark_graph(oracle, tmp_path):
     expected = GraphEvaluator(gd, variables).run(fetches, feeds)
     got = GraphEvaluator(out, variables, oracle_ops(oracle, built, variables)).run(fetches, feeds)
     assert np.array_equal(expected[0], got[0])
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_graphs(oracle, tmp_path, seed):
+    """Random rewritten graphs (kinds, dims, vocabularies, id dtypes, SparseTensor ranks, shared
+    tables, 1-3 concat groups): the plan builder never mislabels a column — the rewritten graph
+    reproduces the original bit for bit — and every lookup is taken by the fused path."""
+    from tf_graph_eval import GraphEvaluator
+    gd, feeds, variables, fetches, kinds = random_model(seed)
+    expected = GraphEvaluator(gd, variables).run(fetches, feeds)
+    built = build_plan(gd)
+    want_form = {"dense64": 1, "dense32": 1, "bucket": 1, "mean": 2, "sum": 2, "scatter": 3, "pass": 4, "sum3d": 5}
+    groups_with_lookup = {c.concat_group for c in built.spec.columns if c.form in (1, 2, 3)}
+    assert [c.form for c in built.spec.columns] == [want_form[k] for k in kinds] or len(groups_with_lookup) < len(fetches)
+    assert not built.skipped
+    path = str(tmp_path / "m.fcp")
+    save_plan(built.spec, path)
+    out = parse_graphdef(rewrite_graph(gd, built, path).SerializeToString())
+    got = GraphEvaluator(out, variables, oracle_ops(oracle, built, variables)).run(fetches, feeds)
+    for e, o in zip(expected, got):
+        assert e.shape == o.shape and np.array_equal(e, o)
 
 
 def test_nothing_to_fuse():
