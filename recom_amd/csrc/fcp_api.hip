@@ -63,12 +63,16 @@ struct HostColumn {
   int64_t const_off = -1; // byte offset of the boundaries in the const buffer
 };
 
+constexpr int64_t kSegSearchMaxPairs = 32768;
+
 struct DynMeta {
   std::vector<int32_t> group_rows;
   std::vector<int64_t> group_base;
   int64_t arena_bytes = 0;
   int64_t csr_arena_off = 0;
   int32_t max_seg_nnz = 0;
+  int64_t seg_pairs = 0;   // sum of rows over the segment-id columns: cost of the in-block search
+  bool seg_search = false; // this request: blocks search the segment ids (no pre-pass launch)
   // launch geometry per kernel kind: [0] dense kernel (spans whose columns all have exactly
   // one source row per output row), [1] ragged kernel (spans with pooled / scatter / reduction columns)
   struct Geo {
@@ -101,6 +105,7 @@ struct fcp_plan {
   std::vector<int32_t> ranks, elem_sizes, shape_off;
   std::vector<int32_t> group_width, group_nslots, group_map_off;
   std::vector<int32_t> seg_cols;
+  bool seg_search = false;  // blocks search the segment ids themselves; no segment-offset pre-pass
   // device arrays are kept in concat order (group-major, ascending concat offset)
   // so that the columns of one output span are contiguous: order[pos] = column,
   // pos_of[column] = pos.
@@ -288,6 +293,7 @@ int compute_dyn(const fcp_plan *p, const int32_t *offsets, const int32_t *shapes
     }
   }
   m->max_seg_nnz = 0;
+  m->seg_pairs = 0;
   for (int k = 0; k < nc; ++k) {
     const HostColumn &hc = p->cols[k];
     const fcp_column_desc_t &c = hc.d;
@@ -325,6 +331,7 @@ int compute_dyn(const fcp_plan *p, const int32_t *offsets, const int32_t *shapes
           if (n_seg < n_ids * c.seg_stride - (c.seg_stride - 1) && n_ids > 0)
             return fail(FCP_ERR_SHAPE_MISMATCH, "segment id tensor shorter than the id stream");
           if (d.nnz > m->max_seg_nnz) m->max_seg_nnz = d.nnz;
+          m->seg_pairs += rows;
         }
       }
     }
@@ -337,6 +344,11 @@ int compute_dyn(const fcp_plan *p, const int32_t *offsets, const int32_t *shapes
       cursor += align128(rows * c.dim * 4);
     }
   }
+  // A few segment-id columns (the reference's models E / F: 10-20 multi-hot columns next to ~1000
+  // one-hot ones): searching inside the blocks beats a second, dependent launch (E 15.6 -> 13.5 us).
+  // Hundreds of them (RAGGED with SparseTensor indices): every row block would repeat the search on
+  // the same arrays, and the one coalesced pre-pass scan wins (39.8 us vs 42.7-58.9 us).
+  m->seg_search = p->seg_search && m->seg_pairs <= kSegSearchMaxPairs;
   m->csr_arena_off = cursor;
   int64_t csr_cursor = 0; // in int32 elements
   for (int k : p->seg_cols) {
@@ -621,6 +633,7 @@ void fill_launch(const fcp_plan *p, const DynSlot &s, int kind, const void *blob
   L->shard_world = p->desc.shard_world;
   L->n_groups = p->desc.n_groups;
   L->rows_per_wave = s.meta.geo[kind].rows_per_wave;
+  L->seg_search = s.meta.seg_search ? 1 : 0;
   for (int g = 0; g < p->desc.n_groups; ++g) L->groups[g] = s.meta.geo[kind].groups[g];
 }
 
@@ -737,6 +750,13 @@ int fcp_plan_create(const fcp_plan_desc_t *desc, fcp_plan_t **out) {
       p->seg_cols.push_back(k);
   }
   p->vec = gcd4;
+  // Segment-id columns (SparseTensor indices / row ids): unsharded plans let every block find its rows'
+  // ranges with a 16-ary search (fcp_kernels.hip::seg_lower_bound) instead of running the
+  // ComputeSegmentOffsets pre-pass as a second, dependent launch.  Row-sharded plans keep the
+  // pre-pass: fcp_shard_finalize needs the row lengths as CSR.  FCP_SEG_PREPASS=1: tuning aid.
+  p->seg_search = desc->shard_world <= 1 && std::getenv("FCP_SEG_PREPASS") == nullptr;
+  for (const HostColumn &hc : p->cols)
+    if (hc.d.seg_kind != FCP_SEG_NONE && hc.d.seg_stride > 0xffff) p->seg_search = false; // stride rides in 16 flag bits
   // The kernels address table rows by a 32-bit slot offset (row * dim / vec): one
   // table (or one shard of it) may hold up to 2^32 slots = 64 GB at vec 4.  (The
   // reference's int arithmetic stops at 2^31 elements = 8 GB, cuda_emitter.cc:270-271.)
@@ -916,7 +936,7 @@ int fcp_process_feature_columns(fcp_plan_t *p, const fcp_process_args_t *a, fcp_
 
   FcpLaunch L;
   fill_launch(p, *slot, 1, a->concated_inputs, arena, &L);
-  if (!p->seg_cols.empty()) {
+  if (!p->seg_cols.empty() && !m.seg_search) {
     FcpSegLaunch S;
     S.seg_cols = p->d_seg_cols;
     S.cols = p->d_cols;

@@ -74,6 +74,7 @@ struct FcpLaunch {
   int32_t shard_rank, shard_world;
   int32_t n_groups;
   int32_t rows_per_wave;
+  int32_t seg_search;          // 1: blocks find their rows' ranges in the sorted segment ids themselves (no pre-pass)
   FcpGroupLaunch groups[FCP_MAX_GROUPS];
 };
 

@@ -143,7 +143,7 @@ struct alignas(16) LdsCol {   // 80 bytes
   const float *table;         // table base, or the passthrough payload
   const char *ids;            // id / value stream of this request
   const float *boundaries;
-  const int32_t *csr;         // CSR offsets of this request (blob or arena scratch)
+  const int32_t *csr;         // CSR offsets of this request (blob or arena scratch), or — L.seg_search — the segment ids
   int64_t vocab;
   int64_t out_base;           // byte offset in the arena of element (0,0)
   int32_t dim;
@@ -162,15 +162,16 @@ __device__ __forceinline__ LdsCol make_lds_col(const FcpLaunch &L, const FcpColS
   c.table = FCP_F_FORM(cs.flags) == FCP_FORM_PASSTHROUGH ? reinterpret_cast<const float *>(c.ids) : cs.table;
   c.boundaries = cs.boundaries;
   const unsigned segkind = FCP_F_SEGKIND(cs.flags);
-  c.csr = segkind == FCP_SEG_CSR_I32   ? reinterpret_cast<const int32_t *>(L.blob + cd.seg_off)
-          : segkind != FCP_SEG_NONE    ? reinterpret_cast<const int32_t *>(L.arena + L.csr_arena_off) + cd.csr_base
-                                       : nullptr;
+  c.csr = (segkind == FCP_SEG_CSR_I32 || (segkind != FCP_SEG_NONE && L.seg_search))
+              ? reinterpret_cast<const int32_t *>(L.blob + cd.seg_off)
+          : segkind != FCP_SEG_NONE ? reinterpret_cast<const int32_t *>(L.arena + L.csr_arena_off) + cd.csr_base
+                                    : nullptr;
   c.vocab = cs.vocab;
   c.out_base = cd.out_base;
   c.dim = cs.dim;
   c.out_off = cs.out_off;
   c.out_stride = cd.out_stride;
-  c.flags = cs.flags;
+  c.flags = cs.flags | ((uint32_t)cs.seg_stride << 16); // FCP_F_PACK uses the low 16 bits; stride < 2^16 is checked at plan creation
   c.n_boundaries = cs.n_boundaries;
   c.bnd_off = -1;
   c.nnz = cd.nnz;
@@ -472,6 +473,36 @@ __global__ void __launch_bounds__(FCP_BLOCK_THREADS) fcp_dense_kernel(const FcpL
 // VALU per wave before this layout), hence the pre-scaled 32-bit slot offsets:
 // a table read costs one LDS read, one compare, one 64-bit shift-add, one load.
 // ---------------------------------------------------------------------------
+// First position i in [0, n] whose segment id is >= target, in the sorted id stream of one
+// column (int32, or int64 read as two dwords; element i lives at index i * stride) — the
+// CSR offset ComputeSegmentOffsets (cuda_emitter.cc:768-818) would store for row `target`.
+// 16-ary search: every level issues 16 independent probes, so a column with nnz ids costs
+// ceil(log16 nnz) memory round trips (3 for nnz <= 4096) instead of log2 nnz.
+__device__ __forceinline__ int seg_lower_bound(const char *seg, bool is64, int stride, int n, int target) {
+  int a = 0, z = n; // the answer lies in [a, z]; everything before a is < target, everything from z on is >= target
+  while (z > a) {
+    const int step = (z - a + 15) >> 4;
+    int64_t v[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int p = a + k * step;
+      v[k] = INT64_MAX;
+      if (p < z) {
+        const int64_t e = (int64_t)p * stride;
+        v[k] = is64 ? ld_i64_a4(seg + 8 * e) : (int64_t)*as_global(reinterpret_cast<const int32_t *>(seg + 4 * e));
+      }
+    }
+    int c = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) c += v[k] < (int64_t)target ? 1 : 0;
+    const int valid = (z - a + step - 1) / step; // probes that were inside [a, z)
+    const int na = c ? a + (c - 1) * step + 1 : a;
+    if (c < valid) z = a + c * step; // probe c is >= target
+    a = na;
+  }
+  return a;
+}
+
 struct RaggedLds {
   static constexpr int RB = FCP_WAVES_PER_BLOCK; // rows per block, one per wave
   static constexpr int NP = FCP_WAVE * RB;       // (column, row) pairs per block, at most (= 256 threads)
@@ -482,6 +513,7 @@ struct RaggedLds {
   uint32_t ids[CAP];
   uint16_t owner[CAP];                           // staged id slot -> its (column, row) pair
   int32_t wsum[FCP_WAVES_PER_BLOCK];
+  int32_t bound[FCP_WAVE * (FCP_WAVES_PER_BLOCK + 1)]; // seg_search: row offsets r0..r0+RB of every column
 };
 
 template <int V, bool SHARDED>
@@ -507,6 +539,20 @@ __device__ __forceinline__ void ragged_body(const FcpLaunch &L, int bid, char *s
   if (tid < B.ncols) s_col[tid] = make_lds_col(L, L.cols[B.first_col + tid], L.dyn[B.first_col + tid]);
   __syncthreads();
 
+  // ---- phase 1a': segment-id columns without a pre-pass: RB+1 row offsets per column ---
+  if (L.seg_search) {
+    for (int u = tid; u < B.ncols * (RB + 1); u += FCP_BLOCK_THREADS) {
+      const LdsCol &c = s_col[u / (RB + 1)];
+      const unsigned sk = FCP_F_SEGKIND(c.flags), f = FCP_F_FORM(c.flags);
+      int v = 0;
+      if ((sk == FCP_SEG_IDS_I32 || sk == FCP_SEG_IDS_I64) && (f == FCP_FORM_SEGMENT_REDUCE || f == FCP_FORM_GATHER_SCATTER))
+        v = seg_lower_bound(reinterpret_cast<const char *>(c.csr), sk == FCP_SEG_IDS_I64, (int)(c.flags >> 16), c.nnz,
+                            min(B.row_blk + u % (RB + 1), B.rows));
+      S.bound[u] = v;
+    }
+    __syncthreads();
+  }
+
   // ---- phase 1a: row ranges of the block's (column, row) pairs + scan ----------------
   int lo = 0, cnt = 0;
   if (tid < B.ncols * RB) {
@@ -519,9 +565,17 @@ __device__ __forceinline__ void ragged_body(const FcpLaunch &L, int bid, char *s
         cnt = 1;
       } else if (form == FCP_FORM_SEGMENT_REDUCE || form == FCP_FORM_GATHER_SCATTER) {
         const int nnz = s_col[pj].nnz;
-        const FCP_GLOBAL int32_t *csr = as_global(s_col[pj].csr);
-        lo = min(max(csr[b], 0), nnz);
-        const int hi = min(max(csr[b + 1], lo), nnz);
+        int o0, o1;
+        if (L.seg_search && FCP_F_SEGKIND(s_col[pj].flags) != FCP_SEG_CSR_I32) {
+          o0 = S.bound[pj * (RB + 1) + pr];
+          o1 = S.bound[pj * (RB + 1) + pr + 1];
+        } else {
+          const FCP_GLOBAL int32_t *csr = as_global(s_col[pj].csr);
+          o0 = csr[b];
+          o1 = csr[b + 1];
+        }
+        lo = min(max(o0, 0), nnz);
+        const int hi = min(max(o1, lo), nnz);
         cnt = hi - lo;
         if (form == FCP_FORM_GATHER_SCATTER && cnt > 0) { // the last id of the row wins
           lo = hi - 1;

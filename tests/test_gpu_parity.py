@@ -93,11 +93,17 @@ def test_s1_configuration(torch_cuda, oracle):
     assert_equal_oracle(oracle, m.spec, packed, tabs, req.symbols, out)
 
 
-@pytest.mark.parametrize("seg", ["csr", "indices", "rowids32"])
-def test_ragged_dynamic_shapes(torch_cuda, oracle, seg):
+@pytest.mark.parametrize("seg,prepass", [("csr", False), ("indices", False), ("rowids32", False),
+                                         ("indices", True), ("rowids32", True)])
+def test_ragged_dynamic_shapes(torch_cuda, oracle, monkeypatch, seg, prepass):
     """RAGGED (reduced to 64 columns): nnz re-drawn per request; more distinct
-    shapes than descriptor slots, then a repeat (cache hit)."""
+    shapes than descriptor slots, then a repeat (cache hit).  Segment-id encodings run both
+    ways: row ranges searched inside the blocks (64 columns x 256 rows is under the
+    threshold) and the ComputeSegmentOffsets pre-pass (forced, as for plans with many such
+    columns)."""
     from recom_amd import synth
+    if prepass:
+        monkeypatch.setenv("FCP_SEG_PREPASS", "1")
     m = synth.model_ragged(columns=64, vocab=5000, batch=256, seg=seg)
     tabs = m.numpy_tables()
     dev_tabs = [torch_cuda.from_numpy(t).cuda() for t in tabs]
@@ -108,9 +114,12 @@ def test_ragged_dynamic_shapes(torch_cuda, oracle, seg):
         assert_equal_oracle(oracle, m.spec, packed, tabs, req.symbols, out)
 
 
-def test_zipf_and_long_bags(torch_cuda, oracle):
+@pytest.mark.parametrize("columns", [16, 900])
+def test_zipf_and_long_bags(torch_cuda, oracle, columns):
+    """Bags of up to 300 ids (walked from global memory); 900 columns x 40 rows exceeds the
+    in-block search threshold, so that plan takes the pre-pass by itself."""
     from recom_amd import synth
-    m = synth.model_ragged(columns=16, vocab=3000, batch=40, seg="indices", max_len=300, dist="zipf")
+    m = synth.model_ragged(columns=columns, vocab=3000, batch=40, seg="indices", max_len=300, dist="zipf")
     tabs = m.numpy_tables()
     req = m.make_request(5)
     out, packed, _ = run_gpu(torch_cuda, m.spec, req.inputs, tabs, req.symbols)
