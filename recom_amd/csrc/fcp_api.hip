@@ -498,8 +498,8 @@ int init_device(fcp_plan *p) {
     p->host_writes_dyn = large_bar != 0 && !(mode && std::string(mode) == "kernel");
   }
 #if defined(FCP_STAMPS)
-  HIP_TRY(hipMalloc(&p->d_stamps, 4 * sizeof(unsigned long long) * 65536));
-  HIP_TRY(hipMemset(p->d_stamps, 0, 4 * sizeof(unsigned long long) * 65536));
+  HIP_TRY(hipMalloc(&p->d_stamps, 8 * sizeof(unsigned long long) * 65536));
+  HIP_TRY(hipMemset(p->d_stamps, 0, 8 * sizeof(unsigned long long) * 65536));
 #endif
   for (auto &s : p->slots) {
     // rounded up to 16 bytes: the upload kernel moves uint4s
@@ -1254,11 +1254,11 @@ int fcp_stager_destroy(fcp_stager_t *s) {
 } // extern "C"
 
 #if defined(FCP_STAMPS)
-// diagnostic builds only: per-block timestamps of the LAST dense launch (4 x u64 per block, 100 MHz ticks)
+// diagnostic builds only: per-block timestamps of the LAST dense launch (8 x u64 per block, 100 MHz ticks)
 extern "C" int fcp_debug_read_stamps(fcp_plan_t *p, unsigned long long *out, int n_blocks) {
   if (!p || !p->d_stamps || n_blocks > 65536) return FCP_ERR_INVALID_ARGUMENT;
   HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(out, p->d_stamps, 4 * sizeof(unsigned long long) * (size_t)n_blocks, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(out, p->d_stamps, 8 * sizeof(unsigned long long) * (size_t)n_blocks, hipMemcpyDeviceToHost));
   return FCP_OK;
 }
 #endif

@@ -98,6 +98,7 @@ int main(int argc, char **argv) {
   int slab = 0;             // 1: all tables carved from ONE hipMalloc (as under TF's BFC allocator)
   int h2d = 0;              // 1: PCIe-inclusive loop: stage (pack + H2D) every request, then process
   int narrow = 0;           // with --h2d: ship int64 ids as int32 (fcp_stager_stage_narrow)
+  int fixed_dim = 0;        // 0: dims cycle 8/16/32/64 (S2); D: every column has dim D (E/F-like models: --dim 8)
   int pack_threads = 8;
   long vocab = 1000000;
   for (int i = 1; i + 1 < argc; i += 2) {
@@ -116,6 +117,7 @@ int main(int argc, char **argv) {
     else if (k == "--slab") slab = (int)v;
     else if (k == "--h2d") h2d = (int)v;
     else if (k == "--narrow") narrow = (int)v;
+    else if (k == "--dim") fixed_dim = (int)v;
     else if (k == "--pack-threads") pack_threads = (int)v;
     else if (k == "--bw-probe") {
       const char *names[4] = {"read", "write", "write-nt", "chunked-write-nt"};
@@ -189,7 +191,7 @@ int main(int argc, char **argv) {
     std::memset(&d, 0, sizeof(d));
     const bool bkt = bucketize_every > 0 && c % bucketize_every == 0;
     d.form = FCP_FORM_GATHER;
-    d.dim = dims[c % 4];
+    d.dim = fixed_dim > 0 ? fixed_dim : dims[c % 4];
     d.vocab = vocab;
     d.id_source = bkt ? FCP_IDS_F32_BUCKETIZE : FCP_IDS_I64;
     d.table_input = c;
@@ -416,34 +418,44 @@ int main(int argc, char **argv) {
   {
     // per-block timeline of the last launch (diagnostic build)
     const int nb = 8 * ((int)((width / 4 + 63) / 64 + 7) / 8) * ((batch + 15) / 16);
-    std::vector<unsigned long long> st(4 * (size_t)nb);
+    std::vector<unsigned long long> st(8 * (size_t)nb);
     CHECK_FCP(fcp_debug_read_stamps(plan, st.data(), nb));
     unsigned long long t0 = ~0ull, t1 = 0;
     int live = 0;
     for (int b = 0; b < nb; ++b)
-      if (st[4 * b + 3]) {
+      if (st[8 * b + 3]) {
         ++live;
-        t0 = std::min(t0, st[4 * b]);
-        t1 = std::max(t1, st[4 * b + 3]);
+        t0 = std::min(t0, st[8 * b]);
+        t1 = std::max(t1, st[8 * b + 3]);
       }
     std::printf("stamps: %d live blocks, kernel span %.2f us (100 MHz ticks)\n", live, (t1 - t0) / 100.0);
-    // histogram of block begin / end times and mean phase durations in 2-us bins of begin time
-    const int nbins = (int)((t1 - t0) / 200) + 1;
+    // histogram of block begin / end times and mean phase durations per bin of begin time:
+    // desc = phase 0; or = raw-id issue + first barrier; stage = boundary staging; raw = extra wait
+    // until the raw ids have landed; conv = phase 1b; rows = phase 2 (reads + stores acknowledged)
+    const unsigned long long bin = (t1 - t0) < 1600 ? 50 : 200; // ticks per histogram bin (0.5 or 2 us)
+    const int nbins = (int)((t1 - t0) / bin) + 1;
     std::vector<int> begins(nbins, 0), ends(nbins, 0);
-    std::vector<double> d_desc(nbins, 0), d_ids(nbins, 0), d_rows(nbins, 0);
+    std::vector<std::vector<double>> d(6, std::vector<double>(nbins, 0.0));
     for (int b = 0; b < nb; ++b) {
-      if (!st[4 * b + 3]) continue;
-      const int bb = (int)((st[4 * b] - t0) / 200), be = (int)((st[4 * b + 3] - t0) / 200);
+      const unsigned long long *o = &st[8 * (size_t)b];
+      if (!o[3]) continue;
+      const int bb = (int)((o[0] - t0) / bin), be = (int)((o[3] - t0) / bin);
       ++begins[bb];
       ++ends[be];
-      d_desc[bb] += (st[4 * b + 1] - st[4 * b]) / 100.0;
-      d_ids[bb] += (st[4 * b + 2] - st[4 * b + 1]) / 100.0;
-      d_rows[bb] += (st[4 * b + 3] - st[4 * b + 2]) / 100.0;
+      d[0][bb] += (o[1] - o[0]) / 100.0;
+      d[1][bb] += (o[4] - o[1]) / 100.0;
+      d[2][bb] += (o[5] - o[4]) / 100.0;
+      d[3][bb] += (o[6] - o[5]) / 100.0;
+      d[4][bb] += (o[2] - o[6]) / 100.0;
+      d[5][bb] += (o[3] - o[2]) / 100.0;
     }
-    for (int i = 0; i < nbins; ++i)
-      std::printf("  t=%5.1f us  begin %5d  end %5d   mean us: desc %.2f ids %.2f rows+stores %.2f\n", i * 2.0, begins[i],
-                  ends[i], begins[i] ? d_desc[i] / begins[i] : 0, begins[i] ? d_ids[i] / begins[i] : 0,
-                  begins[i] ? d_rows[i] / begins[i] : 0);
+    for (int i = 0; i < nbins; ++i) {
+      if (!begins[i] && !ends[i]) continue;
+      const double n = begins[i] ? begins[i] : 1;
+      std::printf("  t=%5.1f us  begin %5d  end %5d   mean us: desc %.2f or %.2f stage %.2f raw %.2f conv %.2f rows+stores %.2f\n",
+                  i * (bin / 100.0), begins[i], ends[i], d[0][i] / n, d[1][i] / n, d[2][i] / n, d[3][i] / n, d[4][i] / n,
+                  d[5][i] / n);
+    }
   }
 #endif
   CHECK_FCP(fcp_harness_destroy(h));

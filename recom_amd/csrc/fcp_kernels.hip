@@ -337,35 +337,48 @@ __device__ __forceinline__ void dense_body(const FcpLaunch &L, int bid, char *sm
   }
 
   // ---- phase 0b: bucketize boundaries -> LDS (skipped when the span has none) --------------
-  const bool my_bkt = tid < B.ncols && FCP_F_IDSRC(s_col[tid].flags) == FCP_IDS_F32_BUCKETIZE &&
-                      FCP_F_FORM(s_col[tid].flags) != FCP_FORM_PASSTHROUGH;
-  if (__syncthreads_or(my_bkt)) {
-    if (wave == 0) {
-      // neighbouring columns that share one boundary array (deduplicated at plan
-      // creation) stage it once: only the first lane of a run contributes
-      const float *mine = my_bkt ? s_col[lane].boundaries : nullptr;
-      const float *prev = reinterpret_cast<const float *>(__shfl_up((unsigned long long)mine, 1));
-      const bool leader = my_bkt && (lane == 0 || prev != mine);
-      const int nb_all = my_bkt ? s_col[lane].n_boundaries : 0;
-      const int nb = leader ? nb_all : 0;
-      int incl = nb;
+  // Every wave derives the same staging plan from the column records (lane l looks at column
+  // l): which columns bucketize, which of them lead a run of neighbours sharing one boundary
+  // array (deduplicated at plan creation), and where each run's copy goes (wave-shuffle prefix
+  // sum).  No block-wide vote, no per-column LDS round trips: the leaders' (pointer, length,
+  // offset) triples travel by lane broadcast, all 256 threads copy, one barrier publishes.
+  const bool my_bkt = lane < B.ncols && FCP_F_IDSRC(s_col[lane].flags) == FCP_IDS_F32_BUCKETIZE &&
+                      FCP_F_FORM(s_col[lane].flags) != FCP_FORM_PASSTHROUGH;
+  const unsigned long long any_bkt = __ballot(my_bkt);
+#if defined(FCP_STAMPS)
+  const unsigned long long t_or = __builtin_amdgcn_s_memrealtime();
+#endif
+  if (any_bkt) {
+    const float *mine = my_bkt ? s_col[lane].boundaries : nullptr;
+    const float *prev = reinterpret_cast<const float *>(__shfl_up((unsigned long long)mine, 1));
+    const bool leader = my_bkt && (lane == 0 || prev != mine);
+    const int nb_all = my_bkt ? s_col[lane].n_boundaries : 0;
+    const int nb = leader ? nb_all : 0;
+    int incl = nb;
 #pragma unroll
-      for (int d = 1; d < FCP_WAVE; d <<= 1) {
-        const int up = __shfl_up(incl, d);
-        if (lane >= d) incl += up;
-      }
-      if (nb_all > 0 && incl <= BND && incl >= nb_all) s_col[lane].bnd_off = incl - nb_all; // followers: their leader's slice
+    for (int d = 1; d < FCP_WAVE; d <<= 1) {
+      const int up = __shfl_up(incl, d);
+      if (lane >= d) incl += up;
     }
-    __syncthreads();
-    for (int j = 0; j < B.ncols; ++j) {
-      const int off = s_col[j].bnd_off;
-      if (off < 0 || (j > 0 && s_col[j - 1].bnd_off == off)) continue; // already staged by the run's leader
-      const FCP_GLOBAL float *src = as_global(s_col[j].boundaries);
-      for (int i = tid; i < s_col[j].n_boundaries; i += FCP_BLOCK_THREADS) s_bnd[off + i] = src[i];
+    // followers take their leader's slice; arrays that do not fit stay in global memory (-1)
+    const int boff = (nb_all > 0 && incl <= BND && incl >= nb_all) ? incl - nb_all : -1;
+    if (wave == 0 && boff >= 0) s_col[lane].bnd_off = boff;
+    unsigned long long todo = __ballot(leader && boff >= 0);
+    while (todo) {
+      const int j = __ffsll((long long)todo) - 1;
+      todo &= todo - 1;
+      const FCP_GLOBAL float *src = as_global(reinterpret_cast<const float *>(__shfl((unsigned long long)mine, j)));
+      const int n = __shfl(nb_all, j), off = __shfl(boff, j);
+      for (int i = tid; i < n; i += FCP_BLOCK_THREADS) s_bnd[off + i] = src[i];
     }
     __syncthreads();
   }
 
+#if defined(FCP_STAMPS)
+  const unsigned long long t_stage = __builtin_amdgcn_s_memrealtime();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // diagnostic: when have the raw ids landed?
+  const unsigned long long t_raw = __builtin_amdgcn_s_memrealtime();
+#endif
   // ---- phase 1b: raw ids -> table slot offsets in LDS -----------------------------------------
 #pragma unroll
   for (int h = 0; h < PT; ++h) {
@@ -433,7 +446,10 @@ __device__ __forceinline__ void dense_body(const FcpLaunch &L, int bid, char *sm
 #if defined(FCP_STAMPS)
   if (L.stamps && tid == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's row reads have landed, its stores are issued and acknowledged
-    unsigned long long *o = L.stamps + 4ull * bid;
+    unsigned long long *o = L.stamps + 8ull * bid;
+    o[4] = t_or;
+    o[5] = t_stage;
+    o[6] = t_raw;
     o[0] = t_begin;
     o[1] = t_desc;
     o[2] = t_ids;
