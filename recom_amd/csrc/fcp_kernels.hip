@@ -543,6 +543,9 @@ __device__ __forceinline__ void ragged_body(const FcpLaunch &L, int bid, char *s
   uint16_t *s_owner = S.owner;
 
   BlockPos B;
+#if defined(FCP_STAMPS)
+  const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
+#endif
   if (!locate_block<RB>(L, bid, B)) return;
   const int tid = threadIdx.x;
   const int lane = tid & (FCP_WAVE - 1);
@@ -554,6 +557,9 @@ __device__ __forceinline__ void ragged_body(const FcpLaunch &L, int bid, char *s
   // ---- phase 0 ----------------------------------------------------------------------
   if (tid < B.ncols) s_col[tid] = make_lds_col(L, L.cols[B.first_col + tid], L.dyn[B.first_col + tid]);
   __syncthreads();
+#if defined(FCP_STAMPS)
+  const unsigned long long t_desc = __builtin_amdgcn_s_memrealtime();
+#endif
 
   // ---- phase 1a': segment-id columns without a pre-pass: RB+1 row offsets per column ---
   if (L.seg_search) {
@@ -569,6 +575,9 @@ __device__ __forceinline__ void ragged_body(const FcpLaunch &L, int bid, char *s
     __syncthreads();
   }
 
+#if defined(FCP_STAMPS)
+  const unsigned long long t_seg = __builtin_amdgcn_s_memrealtime();
+#endif
   // ---- phase 1a: row ranges of the block's (column, row) pairs + scan ----------------
   int lo = 0, cnt = 0;
   if (tid < B.ncols * RB) {
@@ -623,6 +632,9 @@ __device__ __forceinline__ void ragged_body(const FcpLaunch &L, int bid, char *s
     for (int i = 0; i < want; ++i) s_owner[offx + i] = (uint16_t)tid; // fire-and-forget LDS writes
   __syncthreads();
 
+#if defined(FCP_STAMPS)
+  const unsigned long long t_scan = __builtin_amdgcn_s_memrealtime();
+#endif
   // ---- phase 1b: one thread per staged id -> table slot offset in LDS ------------------
   for (int k = tid; k < min(total, CAP); k += FCP_BLOCK_THREADS) {
     const int p = s_owner[k];
@@ -634,6 +646,9 @@ __device__ __forceinline__ void ragged_body(const FcpLaunch &L, int bid, char *s
     }
   }
   __syncthreads();
+#if defined(FCP_STAMPS)
+  const unsigned long long t_ids = __builtin_amdgcn_s_memrealtime();
+#endif
   const int b = B.row_blk + wave;
   if (q >= B.nslots || b >= B.rows) return;
 
@@ -685,21 +700,24 @@ __device__ __forceinline__ void ragged_body(const FcpLaunch &L, int bid, char *s
     // Adding the zero vector of a skipped id is exact (acc is never -0.0: it
     // starts at +0.0), so the adds need no predicate.
     int i = 0;
+#if !defined(FCP_WALK)
+#define FCP_WALK 8
+#endif
     while (pcnt - i > 4) {
-      uint32_t off[8];
-      VF<V> w[8];
+      uint32_t off[FCP_WALK];
+      VF<V> w[FCP_WALK];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) off[k] = (i + k < pcnt) ? s_ids[poff + i + k] : kNoRow;
+      for (int k = 0; k < FCP_WALK; ++k) off[k] = (i + k < pcnt) ? s_ids[poff + i + k] : kNoRow;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
+      for (int k = 0; k < FCP_WALK; ++k) {
         w[k] = vzero<V>();
         if (off[k] != kNoRow) w[k] = ld_slot<V>(tb, off[k]);
       }
 #pragma unroll
-      for (int k = 0; k < 8; ++k)
+      for (int k = 0; k < FCP_WALK; ++k)
 #pragma unroll
         for (int t = 0; t < V; ++t) acc.v[t] = acc.v[t] + w[k].v[t]; // id order
-      i += 8;
+      i += FCP_WALK;
     }
     if (pcnt - i > 0) {
       uint32_t off[4];
@@ -723,6 +741,19 @@ __device__ __forceinline__ void ragged_body(const FcpLaunch &L, int bid, char *s
     for (int t = 0; t < V; ++t) acc.v[t] = acc.v[t] / fc;
   }
   st_out<V>(reinterpret_cast<float *>(L.arena + C.out_base) + e + (int64_t)b * C.out_stride, acc);
+#if defined(FCP_STAMPS)
+  if (L.stamps && tid == 0) { // wave 0 = first row of the block
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned long long *o = L.stamps + 8ull * bid;
+    o[0] = t_begin;
+    o[1] = t_desc;
+    o[4] = t_seg;
+    o[5] = t_scan;
+    o[6] = t_scan;
+    o[2] = t_ids;
+    o[3] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
 }
 
 template <int V, bool SHARDED>
