@@ -494,28 +494,50 @@ __global__ void __launch_bounds__(FCP_BLOCK_THREADS) fcp_dense_kernel(const FcpL
 // CSR offset ComputeSegmentOffsets (cuda_emitter.cc:768-818) would store for row `target`.
 // 16-ary search: every level issues 16 independent probes, so a column with nnz ids costs
 // ceil(log16 nnz) memory round trips (3 for nnz <= 4096) instead of log2 nnz.
-__device__ __forceinline__ int seg_lower_bound(const char *seg, bool is64, int stride, int n, int target) {
-  int a = 0, z = n; // the answer lies in [a, z]; everything before a is < target, everything from z on is >= target
-  while (z > a) {
-    const int step = (z - a + 15) >> 4;
-    int64_t v[16];
+__device__ __forceinline__ int64_t seg_at(const char *seg, bool is64, int stride, int p) {
+  const int64_t e = (int64_t)p * stride;
+  return is64 ? ld_i64_a4(seg + 8 * e) : (int64_t)*as_global(reinterpret_cast<const int32_t *>(seg + 4 * e));
+}
+
+// One level of the 16-ary search on [a, z]: 16 independent probes, then the interval shrinks to
+// less than a 16th.
+__device__ __forceinline__ void seg_narrow(const char *seg, bool is64, int stride, int target, int &a, int &z) {
+  const int step = (z - a + 15) >> 4;
+  int64_t v[16];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const int p = a + k * step;
-      v[k] = INT64_MAX;
-      if (p < z) {
-        const int64_t e = (int64_t)p * stride;
-        v[k] = is64 ? ld_i64_a4(seg + 8 * e) : (int64_t)*as_global(reinterpret_cast<const int32_t *>(seg + 4 * e));
-      }
-    }
-    int c = 0;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) c += v[k] < (int64_t)target ? 1 : 0;
-    const int valid = (z - a + step - 1) / step; // probes that were inside [a, z)
-    const int na = c ? a + (c - 1) * step + 1 : a;
-    if (c < valid) z = a + c * step; // probe c is >= target
-    a = na;
+  for (int k = 0; k < 16; ++k) {
+    const int p = a + k * step;
+    v[k] = INT64_MAX;
+    if (p < z) v[k] = seg_at(seg, is64, stride, p);
   }
+  int c = 0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) c += v[k] < (int64_t)target ? 1 : 0;
+  const int valid = (z - a + step - 1) / step; // probes that were inside [a, z)
+  const int na = c ? a + (c - 1) * step + 1 : a;
+  if (c < valid) z = a + c * step; // probe c is >= target
+  a = na;
+}
+
+__device__ __forceinline__ int seg_lower_bound(const char *seg, bool is64, int stride, int n, int target, int rows) {
+  int a = 0, z = n; // the answer lies in [a, z]; everything before a is < target, everything from z on is >= target
+  if (n > 256 && rows > 0) {
+    // Rows hold about nnz / rows ids each, so row `target` starts near target * nnz / rows.  Search a
+    // 256-wide window around that guess speculatively, together with the two probes that tell whether
+    // the window brackets the answer (same round trip); if it does, one level is saved, if not the
+    // full search starts over.
+    const int g = (int)((int64_t)target * n / rows);
+    const int lo = max(g - 128, 0), hi = min(lo + 256, n);
+    const int64_t below = lo > 0 ? seg_at(seg, is64, stride, lo - 1) : INT64_MIN;
+    const int64_t above = hi < n ? seg_at(seg, is64, stride, hi) : INT64_MAX;
+    int wa = lo, wz = hi;
+    seg_narrow(seg, is64, stride, target, wa, wz);
+    if (below < (int64_t)target && above >= (int64_t)target) {
+      a = wa;
+      z = wz;
+    }
+  }
+  while (z > a) seg_narrow(seg, is64, stride, target, a, z);
   return a;
 }
 
@@ -569,7 +591,7 @@ __device__ __forceinline__ void ragged_body(const FcpLaunch &L, int bid, char *s
       int v = 0;
       if ((sk == FCP_SEG_IDS_I32 || sk == FCP_SEG_IDS_I64) && (f == FCP_FORM_SEGMENT_REDUCE || f == FCP_FORM_GATHER_SCATTER))
         v = seg_lower_bound(reinterpret_cast<const char *>(c.csr), sk == FCP_SEG_IDS_I64, (int)(c.flags >> 16), c.nnz,
-                            min(B.row_blk + u % (RB + 1), B.rows));
+                            min(B.row_blk + u % (RB + 1), B.rows), B.rows);
       S.bound[u] = v;
     }
     __syncthreads();
