@@ -464,6 +464,12 @@ __global__ void __launch_bounds__(FCP_BLOCK_THREADS) fcp_dense_kernel(const FcpL
   dense_body<V, R, SHARDED>(L, blockIdx.x, smem);
 }
 
+// Table reads a lane of the ragged kernel keeps in flight while it walks a bag (tuning builds:
+// 12 / 16 need 71 / 87 VGPRs and lose more to occupancy than they gain).
+#if !defined(FCP_WALK)
+#define FCP_WALK 8
+#endif
+
 // ---------------------------------------------------------------------------
 // Ragged kernel: any mix of column forms (dynamic shapes: multi-hot bags of
 // variable length, scatter columns, passthrough, Sum(axis=1)).
@@ -722,9 +728,6 @@ __device__ __forceinline__ void ragged_body(const FcpLaunch &L, int bid, char *s
     // Adding the zero vector of a skipped id is exact (acc is never -0.0: it
     // starts at +0.0), so the adds need no predicate.
     int i = 0;
-#if !defined(FCP_WALK)
-#define FCP_WALK 8
-#endif
     while (pcnt - i > 4) {
       uint32_t off[FCP_WALK];
       VF<V> w[FCP_WALK];
