@@ -33,7 +33,12 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-METRIC = "inference QPS + p50 latency, 1000-col synth model, batch 512, 1xMI355X"
+METRIC = "inference QPS + p50 latency, 1000-col synth model, batch 512, 1\u00d7MI355X"  # == BASELINE.json "metric"
+try:
+    with open(os.path.join(ROOT, "BASELINE.json")) as _f:
+        METRIC = json.load(_f).get("metric", METRIC)
+except (OSError, ValueError):
+    pass
 
 
 def measured_traffic(workload):
