@@ -224,8 +224,25 @@ int fcp_concat_inputs(const fcp_host_tensor_t *inputs, int32_t n_inputs,
 
 /* ---- plan: replaces code generation + CreateConstBuffers ------------------ */
 int fcp_plan_create(const fcp_plan_desc_t *desc, fcp_plan_t **plan);
+/* The same from a column-plan FILE — what the `dlpath` attr of
+ * Addons>FeatureColumnProcess names in this build (the reference dlopen()s a
+ * JIT-compiled .so there, feature_column_process_op_gpu.cu.cc:49-62).  Text
+ * format, written by recom_amd.plan_io.save_plan / `python -m recom_amd.graph`:
+ *   fcp_plan 1 / layout L / groups G symbols S device_inputs D / host_inputs N,
+ *   N lines "rank elem_size" / columns C, C lines "form combiner dim id_source
+ *   vocab table_input ids_input seg_input seg_kind seg_stride rows_source
+ *   rows_arg concat_group concat_slot n_boundaries b0 b1 ...".
+ * `flags`: fcp_plan_desc_t::flags.  FCP_ERR_INVALID_ARGUMENT for a missing or
+ * malformed file. */
+int fcp_plan_create_from_file(const char *path, int32_t device, uint32_t flags,
+                              fcp_plan_t **plan);
 int fcp_plan_destroy(fcp_plan_t *plan);
-/* Static facts: total concat width of a group (sum of dims in slot order)
+/* Static facts: number of columns / groups / host inputs / tables / symbols
+ * (any pointer may be NULL), */
+int fcp_plan_counts(const fcp_plan_t *plan, int32_t *n_columns, int32_t *n_groups,
+                    int32_t *n_host_inputs, int32_t *n_device_inputs,
+                    int32_t *n_symbols);
+/* total concat width of a group (sum of dims in slot order)
  * and the element offset of a column inside its group. */
 int fcp_plan_group_width(const fcp_plan_t *plan, int32_t group, int32_t *width);
 int fcp_plan_column_offset(const fcp_plan_t *plan, int32_t column,

@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <functional>
@@ -835,6 +836,75 @@ int fcp_plan_create(const fcp_plan_desc_t *desc, fcp_plan_t **out) {
     }
   }
   *out = p;
+  return FCP_OK;
+}
+
+int fcp_plan_create_from_file(const char *path, int32_t device, uint32_t flags, fcp_plan_t **out) {
+  if (!path || !out) return fail(FCP_ERR_INVALID_ARGUMENT, "null argument");
+  *out = nullptr;
+  std::FILE *f = std::fopen(path, "r");
+  if (!f) return fail(FCP_ERR_INVALID_ARGUMENT, std::string("cannot open column plan ") + path);
+  struct Closer {
+    std::FILE *f;
+    ~Closer() { std::fclose(f); }
+  } closer{f};
+  const std::string where = std::string("column plan ") + path + ": ";
+  char tag[32], t2[32], t3[32];
+  int version = 0, n_host = 0, n_cols = 0;
+  fcp_plan_desc_t d;
+  std::memset(&d, 0, sizeof(d));
+  if (std::fscanf(f, "%31s %d", tag, &version) != 2 || std::strcmp(tag, "fcp_plan") || version != 1)
+    return fail(FCP_ERR_INVALID_ARGUMENT, where + "bad header");
+  if (std::fscanf(f, "%31s %d", tag, &d.layout) != 2 || std::strcmp(tag, "layout"))
+    return fail(FCP_ERR_INVALID_ARGUMENT, where + "expected 'layout'");
+  if (std::fscanf(f, "%31s %d %31s %d %31s %d", tag, &d.n_groups, t2, &d.n_symbols, t3, &d.n_device_inputs) != 6 ||
+      std::strcmp(tag, "groups") || std::strcmp(t2, "symbols") || std::strcmp(t3, "device_inputs"))
+    return fail(FCP_ERR_INVALID_ARGUMENT, where + "expected 'groups G symbols S device_inputs D'");
+  if (std::fscanf(f, "%31s %d", tag, &n_host) != 2 || std::strcmp(tag, "host_inputs") || n_host < 0 || n_host > (1 << 24))
+    return fail(FCP_ERR_INVALID_ARGUMENT, where + "expected 'host_inputs N'");
+  std::vector<int32_t> ranks(n_host), esz(n_host);
+  for (int i = 0; i < n_host; ++i)
+    if (std::fscanf(f, "%d %d", &ranks[i], &esz[i]) != 2) return fail(FCP_ERR_INVALID_ARGUMENT, where + "truncated host input list");
+  if (std::fscanf(f, "%31s %d", tag, &n_cols) != 2 || std::strcmp(tag, "columns") || n_cols < 0 || n_cols > (1 << 24))
+    return fail(FCP_ERR_INVALID_ARGUMENT, where + "expected 'columns C'");
+  std::vector<fcp_column_desc_t> cols(n_cols);
+  std::vector<std::vector<float>> bnd(n_cols);
+  for (int k = 0; k < n_cols; ++k) {
+    fcp_column_desc_t &c = cols[k];
+    std::memset(&c, 0, sizeof(c));
+    long long vocab = 0;
+    if (std::fscanf(f, "%d %d %d %d %lld %d %d %d %d %d %d %d %d %d %d", &c.form, &c.combiner, &c.dim, &c.id_source, &vocab,
+                    &c.table_input, &c.ids_input, &c.seg_input, &c.seg_kind, &c.seg_stride, &c.rows_source, &c.rows_arg,
+                    &c.concat_group, &c.concat_slot, &c.n_boundaries) != 15 ||
+        c.n_boundaries < 0 || c.n_boundaries > (1 << 24))
+      return fail(FCP_ERR_INVALID_ARGUMENT, where + "truncated or malformed column " + std::to_string(k));
+    c.vocab = vocab;
+    bnd[k].resize(c.n_boundaries);
+    for (int b = 0; b < c.n_boundaries; ++b)
+      if (std::fscanf(f, "%f", &bnd[k][b]) != 1) return fail(FCP_ERR_INVALID_ARGUMENT, where + "truncated boundary list");
+    c.boundaries = c.n_boundaries ? bnd[k].data() : nullptr;
+  }
+  d.abi_version = FCP_ABI_VERSION;
+  d.n_columns = n_cols;
+  d.columns = cols.data();
+  d.n_host_inputs = n_host;
+  d.host_input_ranks = ranks.data();
+  d.host_input_elem_sizes = esz.data();
+  d.device = device;
+  d.shard_rank = 0;
+  d.shard_world = 1;
+  d.flags = flags;
+  return fcp_plan_create(&d, out);
+}
+
+int fcp_plan_counts(const fcp_plan_t *p, int32_t *n_columns, int32_t *n_groups, int32_t *n_host_inputs,
+                    int32_t *n_device_inputs, int32_t *n_symbols) {
+  if (!p) return fail(FCP_ERR_INVALID_ARGUMENT, "null plan");
+  if (n_columns) *n_columns = p->desc.n_columns;
+  if (n_groups) *n_groups = p->desc.n_groups;
+  if (n_host_inputs) *n_host_inputs = p->desc.n_host_inputs;
+  if (n_device_inputs) *n_device_inputs = p->desc.n_device_inputs;
+  if (n_symbols) *n_symbols = p->desc.n_symbols;
   return FCP_OK;
 }
 

@@ -90,7 +90,8 @@ class HostTensor(C.Structure):
 EXPORTS = [
     "fcp_abi_version", "fcp_status_string", "fcp_last_error",
     "fcp_concat_inputs_sizes", "fcp_concat_inputs",
-    "fcp_plan_create", "fcp_plan_destroy", "fcp_plan_group_width", "fcp_plan_column_offset",
+    "fcp_plan_create", "fcp_plan_create_from_file", "fcp_plan_counts", "fcp_plan_destroy", "fcp_plan_group_width",
+    "fcp_plan_column_offset",
     "fcp_plan_arena_bytes", "fcp_plan_read_bad_ids",
     "fcp_process_feature_columns", "fcp_concat_outputs", "fcp_shard_finalize",
     "fcp_stager_create", "fcp_stager_stage", "fcp_stager_stage_narrow", "fcp_stager_destroy",
@@ -126,6 +127,8 @@ def load() -> C.CDLL:
     L.fcp_concat_inputs.argtypes = [C.POINTER(HostTensor), C.c_int32, C.c_void_p, C.c_int64,
                                     C.c_void_p, C.c_void_p]
     L.fcp_plan_create.argtypes = [C.POINTER(PlanDesc), C.POINTER(C.c_void_p)]
+    L.fcp_plan_create_from_file.argtypes = [C.c_char_p, C.c_int32, C.c_uint32, C.POINTER(C.c_void_p)]
+    L.fcp_plan_counts.argtypes = [C.c_void_p] + [C.POINTER(C.c_int32)] * 5
     L.fcp_plan_destroy.argtypes = [C.c_void_p]
     L.fcp_plan_group_width.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
     L.fcp_plan_column_offset.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]

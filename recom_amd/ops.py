@@ -89,6 +89,28 @@ class Plan:
         _lib.check(self._L.fcp_plan_create(C.byref(desc), C.byref(handle)), "fcp_plan_create")
         self.handle = handle
 
+    @classmethod
+    def from_file(cls, path: str, device: int = 0, host_only: bool = False) -> "Plan":
+        """The plan a column-plan file describes, parsed by the library itself
+        (``fcp_plan_create_from_file`` — what the TF shim calls with the op's ``dlpath``)."""
+        from .plan_io import load_plan
+        self = cls.__new__(cls)
+        self.device = device
+        self._L = _lib.load()
+        self._keep = []
+        self.handle = None
+        handle = C.c_void_p()
+        _lib.check(self._L.fcp_plan_create_from_file(path.encode(), device, _lib.FLAG_HOST_ONLY if host_only else 0,
+                                                     C.byref(handle)), "fcp_plan_create_from_file")
+        self.handle = handle
+        self.spec = load_plan(path)          # Python-side bookkeeping only
+        return self
+
+    def counts(self) -> dict:
+        v = [C.c_int32() for _ in range(5)]
+        _lib.check(self._L.fcp_plan_counts(self.handle, *[C.byref(x) for x in v]), "fcp_plan_counts")
+        return dict(zip(("columns", "groups", "host_inputs", "device_inputs", "symbols"), (x.value for x in v)))
+
     def close(self) -> None:
         if getattr(self, "handle", None):
             self._L.fcp_plan_destroy(self.handle)
@@ -155,15 +177,21 @@ class FeatureColumnProcess:
     torch's current stream); nothing blocks.
     """
 
-    def __init__(self, spec: PlanSpec, device: int = 0) -> None:
+    def __init__(self, spec: PlanSpec, device: int = 0, plan: Optional[Plan] = None) -> None:
         import torch
         if not torch.cuda.is_available():
             raise RuntimeError("FeatureColumnProcess needs a GPU (no CPU fallback)")
         self.torch = torch
         self.device = torch.device("cuda", device)
-        self.plan = Plan(spec, device)
+        self.plan = plan if plan is not None else Plan(spec, device)
         self.spec = spec
         self._L = self.plan._L
+
+    @classmethod
+    def from_plan_file(cls, dlpath: str, device: int = 0) -> "FeatureColumnProcess":
+        """The op as the shim builds it: ``dlpath`` attr -> ``fcp_plan_create_from_file``."""
+        plan = Plan.from_file(dlpath, device)
+        return cls(plan.spec, device, plan)
 
     def _allocators(self):
         """Per-call allocator callbacks (malloc_buff = the op's allocate_output(2),

@@ -33,7 +33,10 @@ def load_plan(path: str) -> PlanSpec:
     it = iter(tok)
 
     def nxt():
-        return next(it)
+        try:
+            return next(it)
+        except StopIteration:
+            raise ValueError(f"truncated column plan {path}") from None
 
     if nxt() != "fcp_plan" or int(nxt()) != 1:
         raise ValueError("bad plan header")

@@ -343,7 +343,9 @@ def _graph_through_hip(torch, gd, feeds, variables, fetches, tmp_path):
     ops = {}
 
     def process(node, x):
-        op = ops.setdefault(node.name, FeatureColumnProcess(load_plan(node.attr["dlpath"].s.decode()), 0))
+        if node.name not in ops:                # what the shim does with the `dlpath` attr
+            ops[node.name] = FeatureColumnProcess.from_plan_file(node.attr["dlpath"].s.decode(), 0)
+        op = ops[node.name]
         n_tab = len(node.attr["input_types"].list.type)
         tables = [torch.from_numpy(np.ascontiguousarray(t)).cuda() for t in x[3:3 + n_tab]]
         symbols = x[3 + n_tab] if node.op.endswith("WithSymbols") else None

@@ -303,3 +303,31 @@ def test_pack_pool_under_thread_sanitizer(tmp_path):
     for threads, jobs in ((4, 6000), (7, 3000)):
         run = subprocess.run([exe, str(threads), str(jobs)], capture_output=True, text=True, timeout=300)
         assert run.returncode == 0 and "ThreadSanitizer" not in run.stderr, run.stdout + run.stderr[-3000:]
+
+
+def test_plan_file_loaded_by_the_library(tmp_path):
+    """fcp_plan_create_from_file (what the TF shim calls with `dlpath`) parses what
+    plan_io.save_plan / the graph front end write: same layout facts as a plan created
+    from the descriptor; malformed files are rejected with a status, not a crash."""
+    from recom_amd import lib, synth
+    from recom_amd.ops import Plan, concat_inputs
+    from recom_amd.plan_io import save_plan
+    m = synth.model_mixed(batch=21, vocab=97, n_groups=2)
+    path = str(tmp_path / "m.fcp")
+    save_plan(m.spec, path)
+    a, b = Plan(m.spec, host_only=True), Plan.from_file(path, host_only=True)
+    assert b.counts() == {"columns": m.spec.n_columns, "groups": 2, "host_inputs": m.spec.n_host_inputs,
+                          "device_inputs": m.spec.n_device_inputs, "symbols": m.spec.n_symbols}
+    assert [a.group_width(g) for g in range(2)] == [b.group_width(g) for g in range(2)]
+    assert [a.column_offset(k) for k in range(m.spec.n_columns)] == [b.column_offset(k) for k in range(m.spec.n_columns)]
+    req = m.make_request(0)
+    _, _, shapes = concat_inputs(req.inputs)
+    assert a.arena_bytes(shapes, req.symbols) == b.arena_bytes(shapes, req.symbols)
+    text = open(path).read()
+    for bad in ("", "fcp_plan 2\n", text[: len(text) // 2], text.replace("columns", "colums")):
+        open(path, "w").write(bad)
+        with pytest.raises(lib.FcpError) as e:
+            Plan.from_file(path, host_only=True)
+        assert e.value.status == lib.FCP_ERR_INVALID_ARGUMENT
+    with pytest.raises(lib.FcpError):
+        Plan.from_file(str(tmp_path / "missing.fcp"), host_only=True)
