@@ -637,6 +637,47 @@ def test_wide_columns_and_large_boundary_lists(torch_cuda, oracle):
     assert_equal_oracle(oracle, mixed, packed, tables, sym, out)
 
 
+@pytest.mark.parametrize("columns,batch,vocab", [(40, 100_000, 5000), (5000, 8, 300), (1, 1, 7), (3, 70_001, 50)])
+def test_extreme_shapes_dense(torch_cuda, oracle, columns, batch, vocab):
+    """Very tall, very wide and degenerate one-hot requests (grid / span / slot-map limits)."""
+    from recom_amd import synth
+    m = synth.model_s2(columns=columns, vocab=vocab, batch=batch)
+    tabs = m.numpy_tables()
+    req = m.make_request(2)
+    out, packed, _ = run_gpu(torch_cuda, m.spec, req.inputs, tabs, req.symbols)
+    assert_equal_oracle(oracle, m.spec, packed, tabs, req.symbols, out)
+
+
+@pytest.mark.parametrize("seg", ["csr", "indices"])
+def test_extreme_shapes_ragged(torch_cuda, oracle, seg):
+    """One row holding 60 000 ids among empty rows (bag walked from global memory; the segment
+    search / pre-pass see one huge run), and 20 000 rows of short bags."""
+    from recom_amd import synth
+    from recom_amd.synth import Request
+    m = synth.model_ragged(columns=6, vocab=4000, batch=9, seg=seg)
+    req = m.make_request(0)
+    rng = np.random.default_rng(3)
+    inputs = []
+    for c in m.spec.columns:                                  # rebuild every column: row 4 gets 60 000 ids
+        lens = np.zeros(9, np.int64)
+        lens[4], lens[7] = 60_000, 3
+        ids = rng.integers(0, 4000, size=int(lens.sum())).astype(np.int64)
+        rows = np.repeat(np.arange(9, dtype=np.int64), lens)
+        if seg == "csr":
+            inputs += [ids, np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)]
+        else:
+            inputs += [ids, np.stack([rows, np.zeros_like(rows)], 1).astype(np.int64)]
+    tabs = m.numpy_tables()
+    out, packed, _ = run_gpu(torch_cuda, m.spec, inputs, tabs, req.symbols)
+    want, _ = oracle.process_feature_columns(m.spec.to_dict(), *packed, tabs, req.symbols)
+    got = out.groups[0].cpu().numpy()
+    assert np.array_equal(got, want[0])                       # same fp32 add order even over 60 000 terms
+    tall = synth.model_ragged(columns=4, vocab=4000, batch=20_000, seg=seg, max_len=3)
+    r2 = tall.make_request(1)
+    out, packed, _ = run_gpu(torch_cuda, tall.spec, r2.inputs, tall.numpy_tables(), r2.symbols)
+    assert_equal_oracle(oracle, tall.spec, packed, tall.numpy_tables(), r2.symbols, out)
+
+
 def test_reference_ae_model_e_reduced(torch_cuda, oracle):
     """The reference's own model E recipe (examples/python/dlrm.py:140-203), with the
     2^23-row tables reduced so the oracle can hold them."""
