@@ -27,6 +27,8 @@ def load() -> C.CDLL:
     global _h
     if _h is None:
         _lib.load()
+        if not os.path.exists(HARNESS_PATH) and "FCP_LIB_DIR" not in os.environ:
+            _lib._build_in_tree()
         if not os.path.exists(HARNESS_PATH):
             raise ImportError(f"{HARNESS_PATH} not built; run __graft_entry__.build()")
         H = C.CDLL(HARNESS_PATH)

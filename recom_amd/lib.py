@@ -100,6 +100,20 @@ EXPORTS = [
 _lib = None
 
 
+def _build_in_tree() -> None:
+    """`make -C recom_amd/csrc` (hipcc --offload-arch=gfx950) when the shared objects are missing,
+    e.g. in a fresh checkout.  Silent no-op when there is no hipcc: load() then fails loudly."""
+    import shutil
+    import subprocess
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not (os.path.exists(hipcc) or shutil.which("hipcc")) or not shutil.which("make"):
+        return
+    try:
+        subprocess.check_call(["make", "-C", os.path.join(_HERE, "csrc")], stdout=subprocess.DEVNULL)
+    except (subprocess.CalledProcessError, OSError):
+        pass
+
+
 def load() -> C.CDLL:
     """Load libfcp_hip.so; raises if it has not been built (no fallback)."""
     global _lib
@@ -113,6 +127,8 @@ def load() -> C.CDLL:
         import torch  # noqa: F401
     except ImportError:  # the C ABI itself does not need torch
         pass
+    if not os.path.exists(LIB_PATH) and "FCP_LIB_DIR" not in os.environ:
+        _build_in_tree()                     # fresh checkout on a box with hipcc: build, never fall back
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
