@@ -69,8 +69,12 @@ def cpu_baseline(model, budget_s: float = 12.0, sample_columns: int = 40):
     n_tab = 1 + max(c.table_input for c in cols)
     sub = PlanSpec(cols, spec.host_input_ranks[:n_host], spec.host_input_elem_sizes[:n_host], n_tab,
                    n_groups=1, n_symbols=spec.n_symbols)
-    req = model.make_request(12345)
-    blob, offsets, shapes = concat_inputs(req.inputs[:n_host])
+    # 64 distinct requests, rotated, so that the touched rows are not cache-resident
+    reqs = [model.make_request(12345 + i) for i in range(64)]
+    packed = [concat_inputs(r.inputs[:n_host]) for r in reqs]
+    req = reqs[0]
+    blob, offsets, shapes = packed[0]
+    blobs = [p[0] for p in packed]
     # table VALUES do not affect CPU time; fill cheaply instead of hashing GBs in NumPy
     tables = []
     for t in model.tables[:n_tab]:
@@ -86,7 +90,7 @@ def cpu_baseline(model, budget_s: float = 12.0, sample_columns: int = 40):
         orc.process_feature_columns(plan, blob, offsets, shapes, tables, req.symbols, threads, out)  # warm
         n, t0 = 0, time.perf_counter()
         while True:
-            orc.process_feature_columns(plan, blob, offsets, shapes, tables, req.symbols, threads, out)
+            orc.process_feature_columns(plan, *packed[n % len(packed)], tables, req.symbols, threads, out)
             n += 1
             el = time.perf_counter() - t0
             if el > budget or n >= 20000:
@@ -100,13 +104,31 @@ def cpu_baseline(model, budget_s: float = 12.0, sample_columns: int = 40):
         per_call, n, el = timed(t, budget_s / (2 * len(cands)))
         if best is None or per_call < best[0]:
             best = (per_call, t)
-    per_call, n, el = timed(best[1], budget_s / 2)
+    per_call, n, el = timed(best[1], budget_s / 4)
     scale = spec.n_columns / k
+    intra = rows / (per_call * scale)
+    # serving style (the reference harness' serve_workers on TF-CPU): independent single-threaded
+    # workers, one request each at a time; the better of the two modes is reported
+    serve_best = None
+    per_thread_calls = max(4, int(0.25 / max(per_call * best[1], 1e-6)))      # ~0.25 s per probe
+    serve_cands = sorted({t for t in (8, 16, 32, 64, 128, cores) if t <= max(cores, 1)})
+    for t in serve_cands:
+        sec = orc.serve_throughput(plan, packed, tables, req.symbols, t, per_thread_calls)
+        rate = rows * t * per_thread_calls / sec / scale
+        if serve_best is None or rate > serve_best[0]:
+            serve_best = (rate, t)
+    calls = max(per_thread_calls, int(per_thread_calls * (budget_s / 4) / 0.25))
+    sec = orc.serve_throughput(plan, packed, tables, req.symbols, serve_best[1], calls)
+    serve = rows * serve_best[1] * calls / sec / scale
+    mode, value, used = ("serve_workers", serve, serve_best[1]) if serve > intra else ("intra-request OpenMP", intra, best[1])
     return {
-        "value": rows / (per_call * scale), "unit": "inferences/s", "cores": best[1], "kind": "port",
-        "sample": f"first {k} of {spec.n_columns} columns at batch {rows}, {n} calls in {el:.1f} s with "
-                  f"{best[1]} OpenMP threads (best of {cands}; {cores} cores visible), scaled x{scale:.0f} to the "
-                  f"whole model; C port of TF-CPU semantics (TensorFlow absent)",
+        "value": value, "unit": "inferences/s", "cores": used, "kind": "port",
+        "sample": f"first {k} of {spec.n_columns} columns at batch {rows}, {len(blobs)} distinct requests rotated, scaled "
+                  f"x{scale:.0f} to the whole model; "
+                  f"best of two modes = {mode}: intra-request OpenMP {intra:.0f} inf/s with {best[1]} threads "
+                  f"(of {cands}), {serve_best[1]} independent single-threaded workers {serve:.0f} inf/s (of {serve_cands}; "
+                  f"{calls} requests each in {sec:.1f} s); {cores} cores visible; C port of TF-CPU semantics "
+                  f"(TensorFlow absent)",
     }
 
 

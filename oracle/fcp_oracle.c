@@ -502,3 +502,63 @@ int64_t orc_process_feature_columns(const orc_plan_t *p, const int8_t *blob,
   free(col_offs);
   return bad;
 }
+
+/* Serving-style CPU throughput (what TF-CPU does with many Session::Run threads, the
+ * reference harness' serve_workers, examples/cc/recom_examples.patch:210-216): n_threads
+ * workers each process whole requests on their own, single-threaded, into private
+ * outputs; no synchronisation inside the timed region.  Requests rotate over `n_blobs`
+ * requests (blob + offsets + shapes; equal row counts, nnz may differ) so that the touched
+ * table rows are not cache-resident.
+ * Returns the elapsed seconds for n_threads * calls_per_thread requests, or -1. */
+double orc_serve_throughput(const orc_plan_t *p, const int8_t *const *blobs, int32_t n_blobs,
+                            const int32_t *const *offsets, const int32_t *const *shapes,
+                            const float *const *tables, const int32_t *symbols, int32_t n_threads,
+                            int32_t calls_per_thread) {
+#ifdef _OPENMP
+  if (n_threads < 1 || calls_per_thread < 1 || n_blobs < 1) return -1.0;
+  for (int32_t r = 0; r < n_blobs; ++r)
+    for (int32_t g = 0; g < p->n_groups; ++g)
+      if (orc_group_rows(p, g, shapes[r], symbols) < 0 ||
+          orc_group_rows(p, g, shapes[r], symbols) != orc_group_rows(p, g, shapes[0], symbols))
+        return -1.0; /* requests may differ in nnz, not in rows */
+  double t0 = 0.0, t1 = 0.0;
+  int failed = 0;
+#pragma omp parallel num_threads(n_threads)
+  {
+    float **out = (float **)malloc(sizeof(float *) * (size_t)p->n_groups);
+    int ok = out != NULL;
+    for (int32_t g = 0; ok && g < p->n_groups; ++g) {
+      const size_t n = (size_t)orc_group_rows(p, g, shapes[0], symbols) * (size_t)orc_group_width(p, g);
+      out[g] = (float *)calloc(n ? n : 1, sizeof(float));
+      if (!out[g]) ok = 0;
+    }
+    const int32_t first = (int32_t)(((int64_t)omp_get_thread_num() * calls_per_thread) % n_blobs);
+    if (ok) (void)orc_process_feature_columns(p, blobs[first], offsets[first], shapes[first], tables, symbols, out, 1); /* warm */
+#pragma omp barrier
+#pragma omp master
+    t0 = omp_get_wtime();
+    if (ok)
+      for (int32_t i = 0; i < calls_per_thread; ++i)
+      {
+          const int32_t r = (first + 1 + i) % n_blobs;
+          (void)orc_process_feature_columns(p, blobs[r], offsets[r], shapes[r], tables, symbols, out, 1);
+        }
+#pragma omp barrier
+#pragma omp master
+    t1 = omp_get_wtime();
+    if (!ok) {
+#pragma omp atomic write
+      failed = 1;
+    }
+    if (out) {
+      for (int32_t g = 0; g < p->n_groups; ++g) free(out[g]);
+      free(out);
+    }
+  }
+  return failed ? -1.0 : t1 - t0;
+#else
+  (void)p; (void)blobs; (void)n_blobs; (void)offsets; (void)shapes; (void)tables; (void)symbols; (void)n_threads; (void)calls_per_thread;
+  return -1.0;
+#endif
+}
+

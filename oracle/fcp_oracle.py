@@ -100,6 +100,9 @@ class COracle:
         L.orc_process_feature_columns.restype = C.c_int64
         L.orc_process_feature_columns.argtypes = [C.POINTER(_Plan), C.c_void_p, C.c_void_p, C.c_void_p,
                                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
+        L.orc_serve_throughput.restype = C.c_double
+        L.orc_serve_throughput.argtypes = [C.POINTER(_Plan), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_int32, C.c_int32]
         L.orc_group_rows.restype = C.c_int64
         L.orc_group_rows.argtypes = [C.POINTER(_Plan), C.c_int32, C.c_void_p, C.c_void_p]
         L.orc_group_width.restype = C.c_int32
@@ -210,6 +213,28 @@ class COracle:
                   esz.ctypes.data_as(C.POINTER(C.c_int32)), plan["n_groups"],
                   plan.get("shard_rank", 0), plan.get("shard_world", 1))
         return p, (arr, keep)
+
+    def serve_throughput(self, plan: dict, requests: Sequence, tables: Sequence[np.ndarray], symbols=None,
+                         n_threads: int = 1, calls_per_thread: int = 1) -> float:
+        """Elapsed seconds for n_threads x calls_per_thread requests served by independent
+        single-threaded workers rotating over `requests` = [(blob, offsets, shapes), ...]
+        (equal row counts; orc_serve_throughput)."""
+        p, _keep = self._make_plan(plan)
+        bl = [np.ascontiguousarray(r[0]).view(np.int8) for r in requests]
+        of = [_i32(r[1]) for r in requests]
+        sh = [_i32(r[2]) for r in requests]
+        n = len(bl)
+        bptrs = (C.c_void_p * n)(*[b.ctypes.data for b in bl])
+        optrs = (C.c_void_p * n)(*[o.ctypes.data for o in of])
+        sptrs = (C.c_void_p * n)(*[x.ctypes.data for x in sh])
+        sym = None if symbols is None else _i32(symbols)
+        tabs = [np.ascontiguousarray(t, np.float32) for t in tables]
+        tptrs = (C.c_void_p * max(1, len(tabs)))(*[t.ctypes.data for t in tabs])
+        el = self.lib.orc_serve_throughput(C.byref(p), bptrs, n, optrs, sptrs, tptrs,
+                                           None if sym is None else sym.ctypes.data, n_threads, calls_per_thread)
+        if el < 0:
+            raise ValueError("oracle: serve_throughput failed")
+        return float(el)
 
     def process_feature_columns(self, plan: dict, blob: np.ndarray, offsets, shapes,
                                 tables: Sequence[np.ndarray], symbols=None, n_threads: int = 1,
