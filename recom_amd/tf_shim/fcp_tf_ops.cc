@@ -12,10 +12,11 @@
 // recom_amd.plan_io.save_plan / the plan builder) instead of a JIT-compiled .so.
 // All compute is behind the C ABI (include/fcp_hip.h); this file holds no kernels.
 //
-// NOT compiled in this repository's container (TensorFlow is absent).  Build where a
+// NOT compiled in this repository's container (TensorFlow is absent); tests/test_host.py only checks
+// that it parses and type-checks against a minimal mock of the TF op-kernel API (tests/native/tf_mock).  Build where a
 // TF-ROCm wheel exists:
-//   hipcc -std=c++17 -shared -fPIC fcp_tf_ops.cc -o librecom_fcp.so \
-//     $(python -c 'import tensorflow as tf; print(" ".join(tf.sysconfig.get_compile_flags()+tf.sysconfig.get_link_flags()))') \
+//   hipcc -std=c++17 -shared -fPIC fcp_tf_ops.cc -o librecom_fcp.so
+//     $(python -c 'import tensorflow as tf; print(" ".join(tf.sysconfig.get_compile_flags()+tf.sysconfig.get_link_flags()))')
 //     -I../../include -L.. -lfcp_hip -Wl,-rpath,'$ORIGIN/..' -DTENSORFLOW_USE_ROCM=1
 #include <algorithm>
 #include <numeric>

@@ -1,0 +1,1 @@
+#include "tf_mock.h"

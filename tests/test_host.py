@@ -331,3 +331,16 @@ def test_plan_file_loaded_by_the_library(tmp_path):
         assert e.value.status == lib.FCP_ERR_INVALID_ARGUMENT
     with pytest.raises(lib.FcpError):
         Plan.from_file(str(tmp_path / "missing.fcp"), host_only=True)
+
+
+def test_tf_shim_parses_against_a_mock_of_the_tf_api():
+    """recom_amd/tf_shim/fcp_tf_ops.cc cannot be built here (no TensorFlow); at least it must
+    parse and type-check against include/fcp_hip.h and a minimal mock of the TF op-kernel API."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Wextra", "-Werror",
+                        "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "tests", "native", "tf_mock"),
+                        os.path.join(ROOT, "recom_amd", "tf_shim", "fcp_tf_ops.cc")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
