@@ -678,6 +678,39 @@ def test_extreme_shapes_ragged(torch_cuda, oracle, seg):
     assert_equal_oracle(oracle, tall.spec, packed, tall.numpy_tables(), r2.symbols, out)
 
 
+def test_plan_and_stager_lifecycle_does_not_leak(torch_cuda):
+    """200 create / run / destroy cycles of a plan and a stager leave the device memory where it was."""
+    from recom_amd import synth
+    from recom_amd.ops import FeatureColumnProcess, RequestStager, concat_inputs
+    torch = torch_cuda
+    m = synth.model_mixed(batch=16, vocab=97, n_groups=1)
+    tabs = [torch.from_numpy(t).cuda() for t in m.numpy_tables()]
+    req = m.make_request(0)
+    blob, offsets, shapes = concat_inputs(req.inputs)
+    d_blob = torch.from_numpy(blob).cuda()
+
+    def cycle():
+        op = FeatureColumnProcess(m.spec, 0)
+        op(d_blob, offsets, shapes, tabs, req.symbols)
+        st = RequestStager(1 << 16, m.spec.n_host_inputs, sum(m.spec.host_input_ranks), depth=2, n_threads=2)
+        st.stage(req.inputs)
+        torch.cuda.synchronize()
+        st.close()
+        op.plan.close()
+
+    for _ in range(5):
+        cycle()
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(200):
+        cycle()
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < (8 << 20), f"device memory shrank by {(free0 - free1) >> 20} MiB"
+
+
 def test_reference_ae_model_e_reduced(torch_cuda, oracle):
     """The reference's own model E recipe (examples/python/dlrm.py:140-203), with the
     2^23-row tables reduced so the oracle can hold them."""
