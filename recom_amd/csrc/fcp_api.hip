@@ -111,6 +111,15 @@ struct fcp_plan {
   // so that the columns of one output span are contiguous: order[pos] = column,
   // pos_of[column] = pos.
   std::vector<int32_t> order, pos_of;
+  // compact per-column facts in concat (pos) order + one representative column per group:
+  // what compute_dyn_fast walks on the request path
+  struct FastCol {
+    int32_t ids_input, seg_input, rows_arg, dim, seg_stride;
+    int64_t out_off_bytes;
+    uint8_t form, rows_source, seg_kind, group;
+  };
+  std::vector<FastCol> fast_cols;
+  std::vector<int32_t> group_rep;
   int vec = 1;
   bool dense_only = true;   // no span needs the ragged kernel
   // hybrid dispatch: per group, the spans served by the dense kernel and by the ragged kernel
@@ -238,8 +247,10 @@ int validate_desc(const fcp_plan_desc_t *d) {
 // Run-time shapes -> per-column dynamic records, arena layout and launch
 // geometry.  Mirrors what the generated host code evaluates per call from
 // SymEngine expressions (cuda_emitter.cc:2151-2179, :2410-2455).
-int compute_dyn(const fcp_plan *p, const int32_t *offsets, const int32_t *shapes,
-                const int32_t *symbols, int64_t blob_bytes, FcpColDyn *dyn, DynMeta *m) {
+int finish_geometry(const fcp_plan *p, DynMeta *m);
+
+int compute_dyn_slow(const fcp_plan *p, const int32_t *offsets, const int32_t *shapes,
+                     const int32_t *symbols, int64_t blob_bytes, FcpColDyn *dyn, DynMeta *m) {
   const int nc = (int)p->cols.size();
   const int ng = p->desc.n_groups;
   const int nh = (int)p->ranks.size();
@@ -360,7 +371,12 @@ int compute_dyn(const fcp_plan *p, const int32_t *offsets, const int32_t *shapes
   cursor += csr_cursor * 4;
   m->arena_bytes = cursor;
 
-  // launch geometry, one set per kernel kind
+  return finish_geometry(p, m);
+}
+
+// launch geometry, one set per kernel kind (shared by both compute_dyn variants)
+int finish_geometry(const fcp_plan *p, DynMeta *m) {
+  const int ng = p->desc.n_groups;
   int32_t max_rows = 0;
   for (int g = 0; g < ng; ++g) max_rows = std::max(max_rows, m->group_rows[g]);
   for (int kind = 0; kind < 2; ++kind) {
@@ -401,6 +417,112 @@ int compute_dyn(const fcp_plan *p, const int32_t *offsets, const int32_t *shapes
     G2.grid_blocks = blocks;
   }
   return FCP_OK;
+}
+
+// The same records for FCP_LAYOUT_CONCAT plans in ONE pass over compact per-column facts
+// (fcp_plan::fast_cols, concat order = the order of `dyn`): this is the host's critical path when
+// every request brings new shapes (1000 columns: ~13 us with the general routine).  Any
+// irregularity returns -1 and the general routine runs instead, so every error message comes from
+// one place.
+int compute_dyn_fast(const fcp_plan *p, const int32_t *offsets, const int32_t *shapes, const int32_t *symbols,
+                     int64_t blob_bytes, FcpColDyn *dyn, DynMeta *m) {
+  const int nc = (int)p->fast_cols.size();
+  const int ng = p->desc.n_groups;
+  const int nh = (int)p->ranks.size();
+  thread_local std::vector<int64_t> numel_v;
+  numel_v.resize(nh);
+  int64_t *numel = numel_v.data();
+  for (int i = 0; i < nh; ++i) {
+    int64_t n = 1;
+    const int32_t *d = shapes + p->shape_off[i];
+    const int rank = p->ranks[i];
+    for (int j = 0; j < rank; ++j) {
+      if (d[j] < 0) return -1;
+      n *= d[j];
+    }
+    numel[i] = n;
+    if (offsets[i] < 0 || (offsets[i] & 3)) return -1;
+    if (blob_bytes >= 0 && (int64_t)offsets[i] + n * p->elem_sizes[i] > blob_bytes) return -1;
+  }
+  auto rows_of = [&](const fcp_plan::FastCol &c) -> int64_t {
+    if (c.rows_source == FCP_ROWS_FROM_IDS) return numel[c.ids_input];
+    if (c.rows_source == FCP_ROWS_FROM_SYMBOL) return symbols ? (int64_t)symbols[c.rows_arg] : -1;
+    return shapes[p->shape_off[c.rows_arg]];
+  };
+  m->group_rows.resize(ng);
+  m->group_base.resize(ng);
+  int64_t cursor = 0;
+  for (int g = 0; g < ng; ++g) {
+    const int64_t rows = rows_of(p->fast_cols[p->group_rep[g]]);
+    if (rows < 0 || rows > 0x7fffffff) return -1;
+    m->group_rows[g] = (int32_t)rows;
+    m->group_base[g] = cursor;
+    cursor += align128(rows * p->group_width[g] * 4);
+  }
+  int32_t max_seg_nnz = 0;
+  int64_t seg_pairs = 0;
+  for (int i = 0; i < nc; ++i) {
+    const fcp_plan::FastCol &c = p->fast_cols[i];
+    const int64_t rows = rows_of(c);
+    if (rows != m->group_rows[c.group]) return -1;
+    FcpColDyn &d = dyn[i];
+    const int64_t n_ids = numel[c.ids_input];
+    d.ids_off = offsets[c.ids_input];
+    d.seg_off = 0;
+    d.out_base = m->group_base[c.group] + c.out_off_bytes;
+    d.out_stride = p->group_width[c.group];
+    d.csr_base = -1;
+    d.inner = 1;
+    d.rows = (int32_t)rows;
+    d.pad_ = 0;
+    if (c.form == FCP_FORM_GATHER) {
+      if (n_ids != rows) return -1;
+      d.nnz = (int32_t)n_ids;
+    } else if (c.form == FCP_FORM_PASSTHROUGH) {
+      if (n_ids != rows * c.dim || n_ids / p->vec >= 0xFFFFFFFFLL) return -1;
+      d.nnz = (int32_t)rows;
+    } else if (c.form == FCP_FORM_BATCH_COL_REDUCTION) {
+      const int32_t *sh = shapes + p->shape_off[c.ids_input];
+      if (sh[0] != rows || sh[2] != c.dim) return -1;
+      d.inner = sh[1];
+      d.nnz = (int32_t)rows;
+    } else {
+      if (n_ids > 0x7fffffff) return -1;
+      d.nnz = (int32_t)n_ids;
+      d.seg_off = offsets[c.seg_input];
+      const int64_t n_seg = numel[c.seg_input];
+      if (c.seg_kind == FCP_SEG_CSR_I32) {
+        if (n_seg != rows + 1) return -1;
+      } else {
+        if (n_seg < n_ids * c.seg_stride - (c.seg_stride - 1) && n_ids > 0) return -1;
+        if (d.nnz > max_seg_nnz) max_seg_nnz = d.nnz;
+        seg_pairs += rows;
+      }
+    }
+  }
+  m->max_seg_nnz = max_seg_nnz;
+  m->seg_pairs = seg_pairs;
+  m->seg_search = p->seg_search && seg_pairs <= kSegSearchMaxPairs;
+  m->csr_arena_off = cursor;
+  int64_t csr_cursor = 0; // in int32 elements
+  for (int k : p->seg_cols) {
+    FcpColDyn &d = dyn[p->pos_of[k]];
+    d.csr_base = (int32_t)csr_cursor;
+    csr_cursor += ((int64_t)d.rows + 1 + 31) / 32 * 32;
+    if (csr_cursor > 0x7fffffff) return -1;
+  }
+  m->arena_bytes = cursor + csr_cursor * 4;
+  return finish_geometry(p, m);
+}
+
+int compute_dyn(const fcp_plan *p, const int32_t *offsets, const int32_t *shapes, const int32_t *symbols,
+                int64_t blob_bytes, FcpColDyn *dyn, DynMeta *m) {
+  const bool slow_only = std::getenv("FCP_DYN_GENERAL") != nullptr; // test aid (read per call: only on a descriptor miss)
+  if (!slow_only && !p->fast_cols.empty()) {
+    const int rc = compute_dyn_fast(p, offsets, shapes, symbols, blob_bytes, dyn, m);
+    if (rc >= 0) return rc;
+  }
+  return compute_dyn_slow(p, offsets, shapes, symbols, blob_bytes, dyn, m);
 }
 
 void destroy_device(fcp_plan *p) {
@@ -523,7 +645,10 @@ int init_device(fcp_plan *p) {
     const size_t dyn_bytes = (nc * sizeof(FcpColDyn) + 15) / 16 * 16;
     if (!s.d_dyn) HIP_TRY(hipMalloc(&s.d_dyn, dyn_bytes));
     HIP_TRY(hipEventCreateWithFlags(&s.uploaded, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+    // `done` only tells the host that a kernel has finished READING the slot; nothing the host or another
+    // device reads depends on it, so it needs no system-scope fence (a fenced record costs 2.9 us of
+    // GPU timeline between two kernels, an unfenced one 1.1 us: RAGGED with new shapes 33.5 -> 31.5 us)
+    HIP_TRY(hipEventCreateWithFlags(&s.done, hipEventDisableTiming | hipEventDisableSystemFence));
   }
   HIP_TRY(hipEventCreateWithFlags(&p->fence, hipEventDisableTiming));
   p->bound_tables.assign(p->desc.n_device_inputs, nullptr);
@@ -797,6 +922,27 @@ int fcp_plan_create(const fcp_plan_desc_t *desc, fcp_plan_t **out) {
   }
   p->pos_of.assign(desc->n_columns, 0);
   for (int pos = 0; pos < desc->n_columns; ++pos) p->pos_of[p->order[pos]] = pos;
+  if (desc->layout == FCP_LAYOUT_CONCAT && desc->n_groups <= 255) {
+    p->fast_cols.resize(desc->n_columns);
+    p->group_rep.assign(desc->n_groups, -1);
+    for (int pos = 0; pos < desc->n_columns; ++pos) {
+      const HostColumn &hc = p->cols[p->order[pos]];
+      fcp_plan::FastCol &f = p->fast_cols[pos];
+      f.ids_input = hc.d.ids_input;
+      f.seg_input = hc.d.seg_input;
+      f.rows_arg = hc.d.rows_arg;
+      f.dim = hc.d.dim;
+      f.seg_stride = hc.d.seg_stride < 1 ? 1 : hc.d.seg_stride;
+      f.out_off_bytes = (int64_t)hc.out_off * 4;
+      f.form = (uint8_t)hc.d.form;
+      f.rows_source = (uint8_t)hc.d.rows_source;
+      f.seg_kind = (uint8_t)hc.d.seg_kind;
+      f.group = (uint8_t)hc.d.concat_group;
+      if (p->group_rep[hc.d.concat_group] < 0) p->group_rep[hc.d.concat_group] = pos;
+    }
+    for (int g = 0; g < desc->n_groups; ++g)
+      if (p->group_rep[g] < 0) p->fast_cols.clear(); // a group without columns: let the general routine report it
+  }
   // hybrid dispatch: classify every 64-slot span of every group
   for (int kind = 0; kind < 2; ++kind) {
     p->list_off[kind].assign(ng, -1);

@@ -344,3 +344,29 @@ def test_tf_shim_parses_against_a_mock_of_the_tf_api():
                         "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "tests", "native", "tf_mock"),
                         os.path.join(ROOT, "recom_amd", "tf_shim", "fcp_tf_ops.cc")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
+
+
+def test_fast_and_general_shape_evaluation_agree(monkeypatch):
+    """compute_dyn_fast (one pass, concat-layout plans) and the general routine give the same
+    arena size for every synthetic model, and the same error for an inconsistent request."""
+    from recom_amd import lib, synth
+    from recom_amd.ops import Plan, concat_inputs
+    models = [synth.model_mixed(batch=21, vocab=97, n_groups=2), synth.model_s1(), synth.model_ragged(columns=40, batch=17),
+              synth.model_ragged(columns=9, batch=5, seg="indices"), synth.model_dlrm(batch=33), synth.model_ae("E", batch=19)]
+    for m in models:
+        p = Plan(m.spec, host_only=True)
+        for seed in range(3):
+            req = m.make_request(seed)
+            _, _, shapes = concat_inputs(req.inputs)
+            monkeypatch.delenv("FCP_DYN_GENERAL", raising=False)
+            fast = p.arena_bytes(shapes, req.symbols)
+            monkeypatch.setenv("FCP_DYN_GENERAL", "1")
+            assert p.arena_bytes(shapes, req.symbols) == fast > 0
+        monkeypatch.delenv("FCP_DYN_GENERAL", raising=False)
+        gather = [c for c in m.spec.columns if c.form == 1]
+        if gather:                                    # a one-hot column one element longer: row counts disagree
+            bad = np.array(shapes, np.int32)
+            bad[m.spec.shape_offsets()[gather[0].ids_input]] += 1
+            with pytest.raises(lib.FcpError) as e:
+                p.arena_bytes(bad, req.symbols)
+            assert e.value.status == lib.FCP_ERR_SHAPE_MISMATCH
