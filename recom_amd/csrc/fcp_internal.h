@@ -13,7 +13,9 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#ifndef FCP_MAX_GROUPS
 #define FCP_MAX_GROUPS 16
+#endif
 #define FCP_BLOCK_THREADS 256
 #define FCP_WAVES_PER_BLOCK 4
 #define FCP_WAVE 64

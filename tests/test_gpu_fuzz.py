@@ -141,8 +141,9 @@ def test_random_plans_match_oracle(oracle, seed):
 
 
 def test_host_threads_share_a_plan_with_changing_shapes(oracle):
-    """serve_workers: several host threads, one plan, one stream each, a new shape on
-    every request (descriptor slots churn under contention)."""
+    """serve_workers: ten host threads (more than descriptor slots), one plan, one stream each; half of
+    them bring a new shape on every request, the other half share three requests (slots hit from
+    several streams, pinned while their launches run outside the plan mutex, evicted under contention)."""
     import torch
     from recom_amd import synth
     from recom_amd.ops import FeatureColumnProcess, concat_inputs
@@ -151,8 +152,11 @@ def test_host_threads_share_a_plan_with_changing_shapes(oracle):
     dev = torch.device("cuda", 0)
     tabs = [torch.from_numpy(t).to(dev) for t in tabs_np]
     op = FeatureColumnProcess(m.spec, 0)
-    n_threads, per_thread = 4, 12
-    reqs = [[m.make_request(100 * t + k) for k in range(per_thread)] for t in range(n_threads)]
+    n_threads, per_thread = 10, 30
+    # even threads: a new shape on every request; odd threads: all cycle over the SAME three requests, so
+    # that one descriptor slot is used from several streams at once and then evicted by the others
+    reqs = [[m.make_request(100 * t + k) if t % 2 == 0 else m.make_request(7000 + k % 3) for k in range(per_thread)]
+            for t in range(n_threads)]
     packed = [[concat_inputs(r.inputs) for r in rs] for rs in reqs]
     blobs = [[torch.from_numpy(p[0]).to(dev) for p in ps] for ps in packed]
     torch.cuda.synchronize()
