@@ -66,7 +66,7 @@ struct HostColumn {
 };
 
 constexpr int64_t kSegSearchMaxPairs = 32768;
-constexpr int kAllSlotsBusy = -2; // acquire_slot: every slot is pinned by a concurrent request
+constexpr int kAllSlotsBusy = -2; // find_or_reserve: every slot is pinned by a concurrent request
 
 struct DynMeta {
   std::vector<int32_t> group_rows;
@@ -92,14 +92,16 @@ struct DynSlot {
   void *h_dyn_dev = nullptr;  // device-side address of h_dyn
   FcpColDyn *d_dyn = nullptr; // what the kernels read
   hipEvent_t uploaded = nullptr; // upload-kernel path: recorded after the upload
-  hipEvent_t done = nullptr;     // recorded after the first kernel that used this content
-  bool need_done = false;        // the next kernel launch on this slot must record `done`
+  hipEvent_t done = nullptr;     // recorded after the first kernel that used this content; one event per
+                                 // (slot, stream) — re-recording an event last used on ANOTHER stream costs
+                                 // ~20 us under concurrency (HIP serialises it), on its own stream < 1 us
+  std::vector<std::pair<void *, hipEvent_t>> done_pool;
   bool done_valid = false;       // `done` covers every kernel that has used this content so far
   void *stream = nullptr;        // stream of the request that installed this content
   uint64_t tick = 0;
   int users = 0;                 // requests between "slot chosen" and "kernels enqueued": not evictable
   int uses = 0;                  // requests that have used this content since it was installed
-  bool multi_stream = false;     // ... and some of them ran on another stream than `stream`
+  bool was_valid = false;        // reserved for installation: the previous content had readers to wait for
   DynMeta meta;
 };
 
@@ -150,7 +152,6 @@ struct fcp_plan {
   // nothing on the GPU's critical path); otherwise a small kernel on the request's
   // stream copies it from pinned host memory.  FCP_DYN_UPLOAD=kernel forces the latter.
   bool host_writes_dyn = false;
-  hipEvent_t fence = nullptr;
   std::mutex mu;
   DynSlot slots[kSlots];
   uint64_t tick = 0;
@@ -536,9 +537,8 @@ void destroy_device(fcp_plan *p) {
     if (s.h_dyn) (void)hipHostFree(s.h_dyn);
     if (s.d_dyn) (void)hipFree(s.d_dyn);
     if (s.uploaded) (void)hipEventDestroy(s.uploaded);
-    if (s.done) (void)hipEventDestroy(s.done);
+    for (auto &e : s.done_pool) (void)hipEventDestroy(e.second);
   }
-  if (p->fence) (void)hipEventDestroy(p->fence);
   if (p->d_slot_map) (void)hipFree(p->d_slot_map);
   if (p->d_span_list) (void)hipFree(p->d_span_list);
   if (p->d_cols) (void)hipFree(p->d_cols);
@@ -650,12 +650,8 @@ int init_device(fcp_plan *p) {
     const size_t dyn_bytes = (nc * sizeof(FcpColDyn) + 15) / 16 * 16;
     if (!s.d_dyn) HIP_TRY(hipMalloc(&s.d_dyn, dyn_bytes));
     HIP_TRY(hipEventCreateWithFlags(&s.uploaded, hipEventDisableTiming));
-    // `done` only tells the host that a kernel has finished READING the slot; nothing the host or another
-    // device reads depends on it, so it needs no system-scope fence (a fenced record costs 2.9 us of
-    // GPU timeline between two kernels, an unfenced one 1.1 us: RAGGED with new shapes 33.5 -> 31.5 us)
-    HIP_TRY(hipEventCreateWithFlags(&s.done, hipEventDisableTiming | hipEventDisableSystemFence));
+    s.done = nullptr; // created per stream on first use (done_event_for)
   }
-  HIP_TRY(hipEventCreateWithFlags(&p->fence, hipEventDisableTiming));
   p->bound_tables.assign(p->desc.n_device_inputs, nullptr);
   return FCP_OK;
 }
@@ -683,14 +679,35 @@ int bind_tables(fcp_plan *p, const void *const *input_ptrs) {
   return FCP_OK;
 }
 
-// Find or build the device-resident dynamic descriptors for these shapes.
-int acquire_slot(fcp_plan *p, const fcp_process_args_t *a, DynSlot **out) {
+// `done` only tells the host that a kernel has finished READING the slot; nothing the host or another
+// device reads depends on it, so it needs no system-scope fence (a fenced record costs 2.9 us of GPU
+// timeline between two kernels, an unfenced one 1.1 us: RAGGED with new shapes 33.5 -> 31.5 us).
+int done_event_for(DynSlot &s, void *stream) {
+  for (auto &e : s.done_pool)
+    if (e.first == stream) {
+      s.done = e.second;
+      return FCP_OK;
+    }
+  hipEvent_t ev = nullptr;
+  HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming | hipEventDisableSystemFence));
+  s.done_pool.emplace_back(stream, ev);
+  s.done = ev;
+  return FCP_OK;
+}
+
+// Device-resident dynamic descriptors for a request's shapes, in three steps so that the plan
+// mutex is only held for the bookkeeping:
+//   find_or_reserve (locked)   a slot that already holds these shapes for this stream, or a victim
+//                              reserved (pinned, invalid) for this request to fill;
+//   install_slot    (unlocked) wait for the victim's old readers, evaluate the shapes, write the
+//                              records through the BAR (or enqueue the upload kernel);
+//   publish_slot    (locked)   make the slot findable.
+void build_key(const fcp_plan *p, const fcp_process_args_t *a, std::vector<int32_t> &key) {
   const int nh = (int)p->ranks.size();
   const int nsym = a->symbols ? p->desc.n_symbols : 0;
   // The stream is part of the key: descriptors are never shared between streams, so the `done` event
-  // of a slot (recorded on its stream) or a fence on that stream always covers every kernel that read it.
+  // of a slot (recorded on its stream) or a synchronisation of that stream covers every kernel that read it.
   const size_t key_len = (size_t)nh + p->rank_sum + nsym + 3;
-  thread_local std::vector<int32_t> key;
   key.resize(key_len);
   std::memcpy(key.data(), a->concated_offsets, nh * sizeof(int32_t));
   std::memcpy(key.data() + nh, a->concated_shapes, p->rank_sum * sizeof(int32_t));
@@ -699,46 +716,54 @@ int acquire_slot(fcp_plan *p, const fcp_process_args_t *a, DynSlot **out) {
   const uint64_t stream_bits = (uint64_t)reinterpret_cast<uintptr_t>(a->stream);
   key[key_len - 2] = (int32_t)(uint32_t)stream_bits;
   key[key_len - 1] = (int32_t)(uint32_t)(stream_bits >> 32);
+}
 
+int find_or_reserve(fcp_plan *p, const std::vector<int32_t> &key, DynSlot **out, bool *install) {
   ++p->tick;
   DynSlot *victim = nullptr;
   for (auto &s : p->slots) {
     if (s.valid && s.key == key) {
       s.tick = p->tick;
-      if (s.stream != a->stream && !p->host_writes_dyn) // another stream than the uploader's: order after the upload
-        HIP_TRY(hipStreamWaitEvent(static_cast<hipStream_t>(a->stream), s.uploaded, 0));
+      ++s.users;
+      ++s.uses;
+      s.done_valid = false; // one more reader that `done` (recorded by the installer) does not cover
       *out = &s;
+      *install = false;
       return FCP_OK;
     }
-    if (s.users > 0) continue; // another request is between choosing this slot and enqueuing its kernels
+    if (s.users > 0) continue; // being filled, or its kernels are being enqueued right now
     // preference: an empty slot; then the least recently used slot whose `done` event covers all of its
-    // kernels (one event wait); only then slots that were shared by several requests (stream fence or,
-    // across streams, a device synchronisation)
+    // readers (one event wait); only then slots that were hit again after they were installed
     auto rank = [](const DynSlot &x) { return !x.valid ? 0 : (x.done_valid ? 1 : 2); };
     if (!victim || rank(s) < rank(*victim) || (rank(s) == rank(*victim) && s.tick < victim->tick)) victim = &s;
   }
   if (!victim) return kAllSlotsBusy; // more concurrent requests than slots: the caller retries
-  DynSlot &s = *victim;
+  victim->was_valid = victim->valid;
+  victim->valid = false;
+  victim->users = 1;
+  *out = victim;
+  *install = true;
+  return FCP_OK;
+}
+
+int install_slot(fcp_plan *p, const fcp_process_args_t *a, DynSlot &s) {
   hipStream_t stream = static_cast<hipStream_t>(a->stream);
-  if (s.valid) {
-    // Kernels of earlier requests may still read the slot (the host runs ahead of the
-    // GPU): wait for the last one.  `done` covers it unless the slot was re-used by
-    // cache hits since; then fence the caller's stream (shape-stable -> dynamic only).
+  if (s.was_valid) {
+    // Kernels of earlier requests may still read the slot (the host runs ahead of the GPU): wait
+    // for the last one.  `done` covers it unless the slot was hit again after its installation;
+    // then everything enqueued on its stream so far has to drain.
     if (!s.done_valid) {
-      if (s.multi_stream || s.stream != a->stream) {
-        HIP_TRY(hipDeviceSynchronize()); // users on streams this call cannot fence
+      if (s.stream == a->stream) {
+        HIP_TRY(hipStreamSynchronize(stream));
       } else {
-        HIP_TRY(hipEventRecord(p->fence, stream));
-        HIP_TRY(hipEventSynchronize(p->fence));
+        HIP_TRY(hipDeviceSynchronize());
       }
     } else if (hipEventQuery(s.done) != hipSuccess) {
       HIP_TRY(hipEventSynchronize(s.done)); // back-pressure: at most kSlots requests in flight
     }
     if (!p->host_writes_dyn && hipEventQuery(s.uploaded) != hipSuccess) HIP_TRY(hipEventSynchronize(s.uploaded));
   }
-  s.valid = false;
-  int rc = compute_dyn(p, a->concated_offsets, a->concated_shapes, a->symbols, a->concated_bytes, s.h_dyn,
-                       &s.meta);
+  int rc = compute_dyn(p, a->concated_offsets, a->concated_shapes, a->symbols, a->concated_bytes, s.h_dyn, &s.meta);
   if (rc) return rc;
   const size_t dyn_bytes = p->cols.size() * sizeof(FcpColDyn);
   if (p->host_writes_dyn) {
@@ -749,16 +774,16 @@ int acquire_slot(fcp_plan *p, const fcp_process_args_t *a, DynSlot **out) {
     if (e) return hip_fail("descriptor upload launch", (hipError_t)e);
     HIP_TRY(hipEventRecord(s.uploaded, stream));
   }
-  s.need_done = true;
+  return done_event_for(s, a->stream);
+}
+
+void publish_slot(fcp_plan *p, DynSlot &s, const std::vector<int32_t> &key, void *stream) {
   s.done_valid = false;
-  s.uses = 0;
-  s.multi_stream = false;
+  s.uses = 1;
   s.key = key;
-  s.stream = a->stream;
+  s.stream = stream;
   s.tick = p->tick;
   s.valid = true;
-  *out = &s;
-  return FCP_OK;
 }
 
 void fill_launch(const fcp_plan *p, const DynSlot &s, int kind, const void *blob, void *arena, FcpLaunch *L) {
@@ -1151,42 +1176,43 @@ int fcp_process_feature_columns(fcp_plan_t *p, const fcp_process_args_t *a, fcp_
   if (rc) return rc;
   hipStream_t stream = static_cast<hipStream_t>(a->stream);
 
-  // The plan mutex covers table binding and the descriptor-slot bookkeeping only.  The chosen
-  // slot is pinned (`users`) while this request calls the allocator and enqueues its kernels
-  // outside the lock, so that host threads serving different streams overlap their launches
-  // (a launch is ~4-5 us of HIP runtime: 3 serve workers 4.4 -> 1.7 us per request aggregate).
+  // The plan mutex covers table binding and the descriptor-slot bookkeeping only.  The slot is
+  // pinned (`users`) while this request evaluates new shapes, calls the allocator and enqueues its
+  // kernels outside the lock, so host threads serving different streams overlap (a launch alone is
+  // ~4-5 us of HIP runtime: 3 serve workers 4.4 -> 1.8 us of host time per request, cached shapes).
   DynSlot *slot = nullptr;
-  bool records_done = false;
+  bool install = false;
+  thread_local std::vector<int32_t> key;
+  build_key(p, a, key);
   {
     std::unique_lock<std::mutex> lock(p->mu);
     if (p->desc.n_device_inputs > 0) {
       rc = bind_tables(p, a->input_ptrs);
       if (rc) return rc;
     }
-    while ((rc = acquire_slot(p, a, &slot)) == kAllSlotsBusy) {
+    while ((rc = find_or_reserve(p, key, &slot, &install)) == kAllSlotsBusy) {
       lock.unlock();
       std::this_thread::yield();
       lock.lock();
     }
     if (rc) return rc;
-    ++slot->users;
-    ++slot->uses;
-    if (slot->stream != a->stream) slot->multi_stream = true;
-    if (slot->need_done) { // this request installed the content: its kernel is the one `done` will follow
-      records_done = true;
-      slot->need_done = false;
-    } else {
-      slot->done_valid = false; // one more user that `done` does not cover
-    }
   }
-  struct Unpin { // every exit path: give the slot back
+  struct Unpin { // every exit path: publish what `done` covers and give the slot back
     fcp_plan *p;
     DynSlot *s;
+    bool recorded;
     ~Unpin() {
       std::lock_guard<std::mutex> lock(p->mu);
+      if (recorded) s->done_valid = s->uses == 1; // hits that joined meanwhile are not covered by `done`
       --s->users;
     }
-  } unpin{p, slot};
+  } unpin{p, slot, false};
+  if (install) {
+    rc = install_slot(p, a, *slot); // on failure the slot stays invalid and is released by `unpin`
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lock(p->mu);
+    publish_slot(p, *slot, key, a->stream);
+  }
   const DynMeta &m = slot->meta;
   if (m.arena_bytes > 0 && !a->concated_inputs && !p->ranks.empty())
     return fail(FCP_ERR_INVALID_ARGUMENT, "null blob");
@@ -1221,10 +1247,9 @@ int fcp_process_feature_columns(fcp_plan_t *p, const fcp_process_args_t *a, fcp_
     const int e = fcp_launch_fused(L, p->vec, true, m.geo[0].grid_blocks, stream);
     if (e) return hip_fail("dense kernel launch", (hipError_t)e);
   }
-  if (records_done) { // first kernel on freshly installed descriptors: lets a later install reuse the slot precisely
+  if (install) { // first kernel on freshly installed descriptors: lets a later install reuse the slot precisely
     HIP_TRY(hipEventRecord(slot->done, stream));
-    std::lock_guard<std::mutex> lock(p->mu);
-    slot->done_valid = slot->uses == 1; // other requests joined meanwhile: `done` does not cover their kernels
+    unpin.recorded = true;
   }
 
   if (r) {
@@ -1286,15 +1311,24 @@ int fcp_shard_finalize(fcp_plan_t *p, const fcp_process_args_t *a, int32_t group
   args.stream = stream_;
   std::unique_lock<std::mutex> lock(p->mu); // held throughout: finalize is not on the multi-worker hot path
   DynSlot *slot = nullptr;
-  while ((rc = acquire_slot(p, &args, &slot)) == kAllSlotsBusy) {
+  bool install = false;
+  thread_local std::vector<int32_t> key;
+  build_key(p, &args, key);
+  while ((rc = find_or_reserve(p, key, &slot, &install)) == kAllSlotsBusy) {
     lock.unlock();
     std::this_thread::yield();
     lock.lock();
   }
   if (rc) return rc;
-  ++slot->uses;
-  if (slot->stream != args.stream) slot->multi_stream = true;
-  if (!slot->need_done) slot->done_valid = false; // one more user that `done` does not cover
+  struct Release { // the lock is still held when this runs
+    DynSlot *s;
+    ~Release() { --s->users; }
+  } release{slot};
+  if (install) {
+    rc = install_slot(p, &args, *slot);
+    if (rc) return rc;
+    publish_slot(p, *slot, key, args.stream);
+  }
   const DynMeta &m = slot->meta;
   if (row_begin + row_count > m.group_rows[group]) return fail(FCP_ERR_SHAPE_MISMATCH, "row slice out of range");
   FcpLaunch L;
@@ -1324,9 +1358,8 @@ int fcp_shard_finalize(fcp_plan_t *p, const fcp_process_args_t *a, int32_t group
   const int e = fcp_launch_shard_finalize(L, group, static_cast<const float *>(partial_slices), world, row_begin,
                                           row_count, static_cast<float *>(out), p->vec, stream);
   if (e) return hip_fail("shard-finalize launch", (hipError_t)e);
-  if (slot->need_done) { // the descriptors were installed by this call
+  if (install) { // the descriptors were installed by this call
     HIP_TRY(hipEventRecord(slot->done, stream));
-    slot->need_done = false;
     slot->done_valid = slot->uses == 1;
   }
   return FCP_OK;
