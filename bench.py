@@ -142,6 +142,8 @@ def main():
     ap.add_argument("--threads", type=int, default=1, help="serve_workers per GPU (reference harness flag)")
     ap.add_argument("--columns", type=int, default=0, help="override the column count (debug only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="skip the extra overlapped-serving pass (3 streams): keeps a kernel trace of this run single-stream")
     ap.add_argument("--vocab", type=int, default=0, help="override the vocabulary size (debug only)")
     ap.add_argument("--batch", type=int, default=0, help="override the batch size (debug only)")
     ap.add_argument("--requests", type=int, default=16, help="distinct resident requests cycled through")
@@ -213,7 +215,7 @@ def main():
     # overlapped serving (the reference harness' serve_workers): independent requests on
     # 3 streams hide each launch's ramp / tail behind its neighbours.  Extra field only.
     overlap = None
-    if args.threads == 1 and not dist:
+    if args.threads == 1 and not dist and not args.no_overlap:
         h3 = ServingHarness(model, device=local_rank, n_requests=args.requests, arena_ring=6, n_threads=3,
                             tables=h.tables, seed0=1000 * rank)
         h3.run(max(args.warmup // 3, 1))

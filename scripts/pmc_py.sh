@@ -4,7 +4,7 @@ TAG=${1:-x}; shift || true
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmcpy_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $GRAFT_REPO_ROOT/bench.py --steps 60 --warmup 10 --no-cpu-baseline $*"
+BENCH="python3 $GRAFT_REPO_ROOT/bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-overlap $*"
 i=0
 while read -r line; do
   [ -z "$line" ] && continue
