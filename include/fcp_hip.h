@@ -29,8 +29,13 @@
  * Threading: a plan is immutable after creation; fcp_process_feature_columns
  * and fcp_concat_outputs are re-entrant on a shared plan (the reference ops
  * keep no per-call state in members either, SURVEY.md §8b "Threading").
- * No entry point synchronises the stream: work is enqueued and the call
- * returns (the reference blocks three times per request).
+ * Concurrent calls (serve workers, one stream each) serialise only on the
+ * plan's descriptor-slot bookkeeping; shape evaluation, the allocator callback
+ * and the kernel launches of different callers overlap.  No entry point
+ * synchronises the stream in the steady state: work is enqueued and the call
+ * returns (the reference blocks three times per request).  A
+ * call may wait for an EARLIER request's kernel when more than 8 requests with
+ * new shapes are in flight (back-pressure on the descriptor slots).
  */
 #ifndef FCP_HIP_H_
 #define FCP_HIP_H_
