@@ -406,7 +406,9 @@ int finish_geometry(const fcp_plan *p, DynMeta *m) {
       G.rows = m->group_rows[g];
       G.nslots = p->group_nslots[g];
       G.nlist = p->list_n[kind][g];
-      G.span_list_off = p->list_off[kind][g];
+      // a list that names every span in order is the identity: -1 spares the blocks a dependent load
+      const int nspans_g = (p->group_nslots[g] + FCP_WAVE - 1) / FCP_WAVE;
+      G.span_list_off = G.nlist == nspans_g ? -1 : p->list_off[kind][g];
       // listed spans are dealt to XCDs in groups of 8; fewer than 8 are not padded
       // (nsp8 = -nlist selects the plain mapping in the kernels)
       static const bool no_xcd_map = std::getenv("FCP_NO_XCD_MAP") != nullptr; // tuning aid: plain span order
