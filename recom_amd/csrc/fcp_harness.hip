@@ -204,25 +204,17 @@ int fcp_harness_destroy(fcp_harness *h) {
   return FCP_OK;
 }
 
-// Device-side copy bandwidth probe (float4 copy of `bytes` bytes, `iters`
-// times): the "measured copy peak" the roofline is also quoted against.
+// Device-side copy bandwidth probe (float4 copy of `bytes` bytes, `iters` times): the "measured copy
+// peak" the roofline is also quoted against.  One element per thread — the shape that reaches the
+// highest rate on MI355X (6.0-6.25 TB/s read+write; a grid-stride loop over the same buffers only
+// reaches 4.6-4.95 TB/s, scripts/probes/copy_variants.hip).
 __global__ void __launch_bounds__(256) fcp_copy_probe_kernel(const float4 *__restrict__ src,
                                                              float4 *__restrict__ dst, size_t n) {
-  // 4 independent 16-byte loads in flight per lane, non-temporal both ways
   typedef float __attribute__((ext_vector_type(4))) f4;
-  const f4 *s = reinterpret_cast<const f4 *>(src);
-  f4 *d = reinterpret_cast<f4 *>(dst);
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  for (; i + 3 * stride < n; i += 4 * stride) {
-    const f4 a = __builtin_nontemporal_load(s + i), b = __builtin_nontemporal_load(s + i + stride),
-             c = __builtin_nontemporal_load(s + i + 2 * stride), e = __builtin_nontemporal_load(s + i + 3 * stride);
-    __builtin_nontemporal_store(a, d + i);
-    __builtin_nontemporal_store(b, d + i + stride);
-    __builtin_nontemporal_store(c, d + i + 2 * stride);
-    __builtin_nontemporal_store(e, d + i + 3 * stride);
-  }
-  for (; i < n; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(s + i), d + i);
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n)
+    __builtin_nontemporal_store(__builtin_nontemporal_load(reinterpret_cast<const f4 *>(src) + i),
+                                reinterpret_cast<f4 *>(dst) + i);
 }
 
 int fcp_harness_copy_probe(size_t bytes, int iters, float *ms_per_iter) {
@@ -234,11 +226,11 @@ int fcp_harness_copy_probe(size_t bytes, int iters, float *ms_per_iter) {
   H_TRY(hipEventCreate(&e0));
   H_TRY(hipEventCreate(&e1));
   const size_t n = bytes / 16;
-  hipLaunchKernelGGL(fcp_copy_probe_kernel, dim3(256 * 8), dim3(256), 0, 0, (const float4 *)a, (float4 *)b, n);
+  hipLaunchKernelGGL(fcp_copy_probe_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, (const float4 *)a, (float4 *)b, n);
   H_TRY(hipDeviceSynchronize());
   H_TRY(hipEventRecord(e0, 0));
   for (int i = 0; i < iters; ++i)
-    hipLaunchKernelGGL(fcp_copy_probe_kernel, dim3(256 * 8), dim3(256), 0, 0, (const float4 *)a, (float4 *)b, n);
+    hipLaunchKernelGGL(fcp_copy_probe_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, (const float4 *)a, (float4 *)b, n);
   H_TRY(hipEventRecord(e1, 0));
   H_TRY(hipDeviceSynchronize());
   float ms = 0;
