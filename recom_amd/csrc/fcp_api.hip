@@ -1216,7 +1216,9 @@ int fcp_process_feature_columns(fcp_plan_t *p, const fcp_process_args_t *a, fcp_
     publish_slot(p, *slot, key, a->stream);
   }
   const DynMeta &m = slot->meta;
-  if (m.arena_bytes > 0 && !a->concated_inputs && !p->ranks.empty())
+  // an empty blob (every input tensor empty: all bags empty) may come with a null pointer, as an empty
+  // TF tensor does; nothing dereferences it then
+  if (m.arena_bytes > 0 && !a->concated_inputs && !p->ranks.empty() && a->concated_bytes != 0)
     return fail(FCP_ERR_INVALID_ARGUMENT, "null blob");
 
   void *arena = a->malloc_buff(a->malloc_buff_ctx, (size_t)std::max<int64_t>(m.arena_bytes, 128)); // never a zero-size request

@@ -711,6 +711,39 @@ def test_plan_and_stager_lifecycle_does_not_leak(torch_cuda):
     assert free0 - free1 < (8 << 20), f"device memory shrank by {(free0 - free1) >> 20} MiB"
 
 
+@pytest.mark.parametrize("seg", ["csr", "indices", "rowids32"])
+@pytest.mark.parametrize("prepass", [False, True])
+def test_all_bags_empty_and_all_ids_in_one_row(torch_cuda, oracle, monkeypatch, seg, prepass):
+    """nnz = 0 for every column (zero-length id / segment tensors), then every id in the last row,
+    then every id in row 0 — through the in-block segment search and through the pre-pass."""
+    from recom_amd import synth
+    if prepass:
+        monkeypatch.setenv("FCP_SEG_PREPASS", "1")
+    B = 37
+    m = synth.model_ragged(columns=10, vocab=500, batch=B, seg=seg, max_len=0)
+    tabs = m.numpy_tables()
+    req = m.make_request(0)
+    assert all(a.size == 0 for a in req.inputs[0::2])
+    out, packed, op = run_gpu(torch_cuda, m.spec, req.inputs, tabs, req.symbols)
+    assert_equal_oracle(oracle, m.spec, packed, tabs, req.symbols, out)
+    assert not out.groups[0].cpu().numpy().any()
+    rng = np.random.default_rng(1)
+    for row in (B - 1, 0):
+        inputs = []
+        for _ in m.spec.columns:
+            ids = rng.integers(0, 500, size=23).astype(np.int64)
+            lens = np.zeros(B, np.int64)
+            lens[row] = 23
+            if seg == "csr":
+                inputs += [ids, np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)]
+            elif seg == "indices":
+                inputs += [ids, np.stack([np.full(23, row, np.int64), np.arange(23, dtype=np.int64)], 1)]
+            else:
+                inputs += [ids, np.full(23, row, np.int32)]
+        out, packed, op = run_gpu(torch_cuda, m.spec, inputs, tabs, req.symbols, op)
+        assert_equal_oracle(oracle, m.spec, packed, tabs, req.symbols, out)
+
+
 def test_reference_ae_model_e_reduced(torch_cuda, oracle):
     """The reference's own model E recipe (examples/python/dlrm.py:140-203), with the
     2^23-row tables reduced so the oracle can hold them."""
