@@ -744,6 +744,40 @@ def test_all_bags_empty_and_all_ids_in_one_row(torch_cuda, oracle, monkeypatch, 
         assert_equal_oracle(oracle, m.spec, packed, tabs, req.symbols, out)
 
 
+@pytest.mark.parametrize("prepass", [False, True])
+def test_out_of_range_segment_ids_and_nonfinite_bucketize_values(torch_cuda, oracle, monkeypatch, prepass):
+    """Sorted segment ids that start below 0 and end beyond the row count (those ids belong to no
+    row), and NaN / +-inf / -0.0 fed to Bucketize: the HIP path and the oracle agree bit for bit
+    (upper_bound semantics: NaN and +inf land in the last bucket)."""
+    from recom_amd.plan import (COMBINER_MEAN, COMBINER_NONE, COMBINER_SUM, FORM_GATHER, FORM_SEGMENT_REDUCE,
+                                IDS_F32_BUCKETIZE, IDS_I64, ROWS_FROM_IDS, ROWS_FROM_SYMBOL, SEG_IDS_I32, SEG_IDS_I64,
+                                SEG_NONE, ColumnSpec, PlanSpec)
+    if prepass:
+        monkeypatch.setenv("FCP_SEG_PREPASS", "1")
+    rng = np.random.default_rng(11)
+    B, vocab = 12, 60
+    bnd = np.asarray([-3.0, 0.0, 1.5, 7.0, 100.0], np.float32)
+    cols = [
+        ColumnSpec(FORM_SEGMENT_REDUCE, 8, vocab, COMBINER_SUM, IDS_I64, 0, 0, 1, SEG_IDS_I64, 2, ROWS_FROM_SYMBOL, 0, None, 0, 0),
+        ColumnSpec(FORM_SEGMENT_REDUCE, 4, vocab, COMBINER_MEAN, IDS_I64, 1, 2, 3, SEG_IDS_I32, 1, ROWS_FROM_SYMBOL, 0, None, 0, 1),
+        ColumnSpec(FORM_GATHER, 12, len(bnd) + 1, COMBINER_NONE, IDS_F32_BUCKETIZE, 2, 4, -1, SEG_NONE, 1, ROWS_FROM_IDS, 0, bnd, 0, 2),
+    ]
+    spec = PlanSpec(cols, [1, 2, 1, 1, 1], [8, 8, 8, 4, 4], 3, n_groups=1, n_symbols=1)
+    seg = np.sort(np.concatenate([[-5, -1, -1], rng.integers(0, B, 40), [B, B + 3, 10 ** 6]])).astype(np.int64)
+    idx = np.stack([seg, np.zeros_like(seg)], 1)
+    vals = np.float32([np.nan, np.inf, -np.inf, -0.0, 0.0, -3.0, 100.0, 99.99, 1e30, -1e30, 1.5, 7.0])
+    inputs = [rng.integers(0, vocab, seg.size).astype(np.int64), idx,
+              rng.integers(0, vocab, seg.size).astype(np.int64), seg.astype(np.int32), vals]
+    tabs = [rng.standard_normal((vocab, 8)).astype(np.float32), rng.standard_normal((vocab, 4)).astype(np.float32),
+            rng.standard_normal((len(bnd) + 1, 12)).astype(np.float32)]
+    out, packed, _ = run_gpu(torch_cuda, spec, inputs, tabs, np.asarray([B], np.int32))
+    want, _ = assert_equal_oracle(oracle, spec, packed, tabs, np.asarray([B], np.int32), out)
+    got = out.groups[0].cpu().numpy()
+    assert np.array_equal(got[0, 12:], tabs[2][len(bnd)])      # NaN: every comparison false -> last bucket
+    assert np.array_equal(got[2, 12:], tabs[2][0])             # -inf: below the first boundary
+    assert np.array_equal(got[3, 12:], tabs[2][2]) and np.array_equal(got[4, 12:], tabs[2][2])  # -0.0 == 0.0 >= boundary 0.0
+
+
 def test_reference_ae_model_e_reduced(torch_cuda, oracle):
     """The reference's own model E recipe (examples/python/dlrm.py:140-203), with the
     2^23-row tables reduced so the oracle can hold them."""
