@@ -2,6 +2,7 @@
 encodings, concat groups, batch sizes, bag lengths) through the C ABI against the
 oracle — bit-exact, including pooled columns (same sequential fp32 order).  Also
 host threads sharing one plan on their own streams with ever-changing shapes."""
+import os
 import threading
 
 import numpy as np
@@ -117,7 +118,8 @@ def random_model(rng, dense_only=False):
     return spec, tables, make
 
 
-@pytest.mark.parametrize("seed", range(24))
+# FCP_FUZZ_SEEDS=<n>: longer soak runs (the suite keeps 24)
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FCP_FUZZ_SEEDS", "24"))))
 def test_random_plans_match_oracle(oracle, seed):
     import torch
     from recom_amd.ops import FeatureColumnProcess, concat_inputs
