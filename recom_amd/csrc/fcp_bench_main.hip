@@ -32,6 +32,7 @@ extern "C" int fcp_harness_copy_probe(size_t, int, float *);
 extern "C" int fcp_debug_read_stamps(fcp_plan_t *, unsigned long long *, int);
 #endif
 extern "C" int fcp_harness_bw_probe(int, size_t, int, float *);
+extern "C" int fcp_harness_gather_probe(size_t, int, int, int, float *, double *);
 
 #define CHECK_HIP(e)                                                                        \
   do {                                                                                      \
@@ -126,6 +127,19 @@ int main(int argc, char **argv) {
         const size_t bytes = (size_t)v << 20;
         fcp_harness_bw_probe(kind, bytes, 20, &ms);
         std::printf("%s probe %ld MiB: %.1f GB/s  (%.2f us)\n", names[kind], v, bytes / (ms * 1e-3) / 1e9, ms * 1e3);
+      }
+      return 0;
+    }
+    else if (k == "--gather-probe") {
+      // random row gathers from a v-MiB buffer: useful GB/s by row size and rows in flight per lane
+      for (int row_bytes : {32, 64, 128, 256}) {
+        for (int depth : {4, 8}) {
+          float ms = 0;
+          double useful = 0;
+          fcp_harness_gather_probe((size_t)v << 20, row_bytes, depth, 10, &ms, &useful);
+          std::printf("gather probe %ld MiB, %3d-byte rows, %d in flight: %.1f GB/s useful (%.2f us per launch)\n", v, row_bytes,
+                      depth, useful / (ms * 1e-3) / 1e9, ms * 1e3);
+        }
       }
       return 0;
     }

@@ -283,6 +283,68 @@ __global__ void __launch_bounds__(256) fcp_chunk_write_probe_kernel(char *__rest
 }
 
 // kind: 0 read, 1 write (default policy), 2 write (nt), 3 chunked nt write [rows=512*mult, width=120000 B]
+// Random-gather read probe: the memory system's ceiling for THIS path's access shape.  Every group of
+// row_bytes/16 lanes reads one pseudo-random, row_bytes-aligned row of a `bytes`-sized buffer (16 B per
+// lane), `depth` independent rows in flight per lane, nothing is written.  Returns the useful bytes
+// gathered per launch through *useful.
+__global__ void __launch_bounds__(256) fcp_gather_probe_kernel(const probe_f4 *__restrict__ src, float *sink,
+                                                               unsigned long long n_rows, int lanes_per_row,
+                                                               int depth, int rounds) {
+  const unsigned long long gid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned long long grp = gid / lanes_per_row;
+  const int part = (int)(gid % lanes_per_row);
+  probe_f4 acc = {0, 0, 0, 0};
+  unsigned long long x = grp * 0x9E3779B97F4A7C15ull + 12345;
+  for (int r = 0; r < rounds; ++r) {
+    probe_f4 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      x ^= x >> 29;
+      x *= 0xBF58476D1CE4E5B9ull;
+      x ^= x >> 32;
+      const unsigned long long row = x % n_rows;
+      v[k] = k < depth ? src[row * lanes_per_row + part] : probe_f4{0, 0, 0, 0};
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc += v[k];
+  }
+  if (acc.x + acc.y + acc.z + acc.w == 12345.678f) *sink = acc.x;
+}
+
+int fcp_harness_gather_probe(size_t bytes, int row_bytes, int depth, int iters, float *ms_per_iter, double *useful) {
+  if (row_bytes < 16 || row_bytes % 16 || depth < 1 || depth > 8) return FCP_ERR_INVALID_ARGUMENT;
+  void *a = nullptr;
+  float *sink = nullptr;
+  H_TRY(hipMalloc(&a, bytes));
+  H_TRY(hipMalloc(&sink, 4));
+  H_TRY(hipMemset(a, 1, bytes));
+  hipEvent_t e0, e1;
+  H_TRY(hipEventCreate(&e0));
+  H_TRY(hipEventCreate(&e1));
+  const int lanes_per_row = row_bytes / 16, rounds = 4;
+  const unsigned long long n_rows = bytes / row_bytes;
+  const int blocks = 256 * 8 * 4; // 8 blocks per CU resident, four generations
+  auto launch = [&]() {
+    hipLaunchKernelGGL(fcp_gather_probe_kernel, dim3(blocks), dim3(256), 0, 0, (const probe_f4 *)a, sink, n_rows,
+                       lanes_per_row, depth, rounds);
+  };
+  launch();
+  H_TRY(hipDeviceSynchronize());
+  H_TRY(hipEventRecord(e0, 0));
+  for (int i = 0; i < iters; ++i) launch();
+  H_TRY(hipEventRecord(e1, 0));
+  H_TRY(hipDeviceSynchronize());
+  float ms = 0;
+  H_TRY(hipEventElapsedTime(&ms, e0, e1));
+  if (ms_per_iter) *ms_per_iter = ms / iters;
+  if (useful) *useful = (double)blocks * 256 * 16.0 * depth * rounds;
+  (void)hipFree(a);
+  (void)hipFree(sink);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return FCP_OK;
+}
+
 int fcp_harness_bw_probe(int kind, size_t bytes, int iters, float *ms_per_iter) {
   void *a = nullptr;
   float *sink = nullptr;
