@@ -132,6 +132,41 @@ def cpu_baseline(model, budget_s: float = 12.0, sample_columns: int = 40):
     }
 
 
+def access_mix_floor(model, h, bytes_alg, measured_us):
+    """What the memory system itself needs for this request mix, from probes run now on this GPU: random
+    row gathers at each row size (the memory system fetches 128 bytes whatever the row size; tables of
+    <= 1 MiB, or all tables of a model that fits the Infinity Cache, are taken as cache-resident), the output at the best store rate of the kernel's store
+    shape, ids / offsets as a sequential read; reads and writes summed (they hardly overlap on HBM).
+    `frac` = floor / measured time — close to 1 means memory-system bound, small means latency bound."""
+    from recom_amd.harness import gather_probe, read_probe, write_probe
+    rates = {rb: gather_probe(rb) for rb in (32, 64, 128, 256)}
+    per_class = {rb: 0.0 for rb in rates}
+    packed, reqs = h.packed, h.requests
+    all_tables = model.table_bytes()
+    for (blob, offsets, shapes), r in zip(packed, reqs):
+        so = model.spec.shape_offsets()
+        for c in model.spec.columns:
+            if c.form not in (1, 2, 3):
+                continue
+            nnz = 1
+            for j in range(model.spec.host_input_ranks[c.ids_input]):
+                nnz *= int(shapes[so[c.ids_input] + j])
+            rb = c.dim * 4
+            if all_tables <= (128 << 20) or c.vocab * rb <= (1 << 20):
+                continue  # cache-resident (whole model within the Infinity Cache, or an L2-sized hot table)
+            cls = 32 if rb <= 32 else 64 if rb <= 64 else 128 if rb <= 128 else 256
+            per_class[cls] += nnz * rb / len(packed)
+    w_rate, r_rate = write_probe(), read_probe()
+    gather_us = sum(per_class[rb] / rates[rb] for rb in rates) * 1e6
+    other_read = bytes_alg["ids"] + bytes_alg["segments"] + bytes_alg["boundaries"]
+    floor_us = gather_us + bytes_alg["out"] / w_rate * 1e6 + max(other_read, 0.0) / r_rate * 1e6
+    return {"gather_GBs_by_row_bytes": {str(k): v / 1e9 for k, v in rates.items()}, "store_GBs": w_rate / 1e9,
+            "sequential_read_GBs": r_rate / 1e9, "gather_us": gather_us, "floor_us": floor_us,
+            "frac": floor_us / measured_us,
+            "note": "floor = row gathers at the probed rate of their row size + output at the probed store rate + "
+                    "ids/offsets at the sequential read rate; frac = floor / measured device time per request"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -251,6 +286,7 @@ def main():
             "read_only_frac": bytes_alg["read"] / (dev_ms_per_req * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "measured_copy_peak_GBs": copy_probe() / 1e9,
         }
+        rec["roofline"]["access_mix"] = access_mix_floor(model, h, bytes_alg, dev_ms_per_req * 1e3)
         if overlap:
             overlap["inferences_per_s"] = batch / (overlap["us_per_request"] * 1e-6)
             overlap["aggregate_frac_of_peak"] = bytes_alg["total"] / (overlap["us_per_request"] * 1e-6) / 1e9 / HBM_PEAK_GBS

@@ -40,6 +40,9 @@ def load() -> C.CDLL:
                                             C.POINTER(C.c_float)]
         H.fcp_harness_destroy.argtypes = [C.c_void_p]
         H.fcp_harness_copy_probe.argtypes = [C.c_size_t, C.c_int, C.POINTER(C.c_float)]
+        H.fcp_harness_gather_probe.argtypes = [C.c_size_t, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float),
+                                               C.POINTER(C.c_double)]
+        H.fcp_harness_bw_probe.argtypes = [C.c_int, C.c_size_t, C.c_int, C.POINTER(C.c_float)]
         _h = H
     return _h
 
@@ -120,3 +123,25 @@ def copy_probe(nbytes: int = 1 << 30, iters: int = 20) -> float:
     ms = C.c_float()
     _lib.check(load().fcp_harness_copy_probe(nbytes, iters, C.byref(ms)), "copy probe")
     return 2.0 * nbytes / (ms.value * 1e-3)
+
+
+def gather_probe(row_bytes: int, nbytes: int = 8 << 30, depth: int = 8, iters: int = 5) -> float:
+    """Useful bytes / s of random `row_bytes`-sized row gathers from an `nbytes` buffer (nothing written)."""
+    ms, useful = C.c_float(), C.c_double()
+    _lib.check(load().fcp_harness_gather_probe(nbytes, row_bytes, depth, iters, C.byref(ms), C.byref(useful)),
+               "gather probe")
+    return useful.value / (ms.value * 1e-3)
+
+
+def write_probe(nbytes: int = 4 << 30, iters: int = 5) -> float:
+    """Bytes / s of non-temporal stores in the kernel's store shape (1-KiB chunks per wave)."""
+    ms = C.c_float()
+    _lib.check(load().fcp_harness_bw_probe(3, nbytes, iters, C.byref(ms)), "write probe")
+    return nbytes / (ms.value * 1e-3)
+
+
+def read_probe(nbytes: int = 4 << 30, iters: int = 5) -> float:
+    ms = C.c_float()
+    _lib.check(load().fcp_harness_bw_probe(0, nbytes, iters, C.byref(ms)), "read probe")
+    return nbytes / (ms.value * 1e-3)
+
