@@ -398,15 +398,7 @@ int finish_geometry(const fcp_plan *p, DynMeta *m) {
         return (v == 1 || v == 2 || v == 4) ? v : 0;
       }();
       if (forced) rpw = forced;
-    } else {
-      // ragged kernel: one row per wave, or two walked one after the other (experiment: FCP_RAGGED_RPW=2;
-      // vec 4, unsharded plans only).  Two INTERLEAVED rows measured slower: 33.7 vs 31.6 us.
-      static const int ragged_rpw = [] {
-        const char *e = std::getenv("FCP_RAGGED_RPW");
-        return e ? std::atoi(e) : 1;
-      }();
-      if (ragged_rpw == 2 && p->vec == 4 && p->desc.shard_world <= 1 && max_rows >= 64) rpw = 2;
-    }
+    } // ragged kernel: one row per wave (2 interleaved rows measured slower: 33.7 vs 31.6 us)
     G2.rows_per_wave = rpw;
     int32_t blocks = 0;
     for (int g = 0; g < ng; ++g) {

@@ -547,33 +547,26 @@ __device__ __forceinline__ int seg_lower_bound(const char *seg, bool is64, int s
   return a;
 }
 
-// RPW = rows per wave, walked one after the other (RB = 4 * RPW rows per block).  RPW = 2 halves
-// the number of blocks, so that a request of the RAGGED shape (3840 -> 1920 blocks) is resident in
-// ONE generation and its staging chain is paid once per 8 rows; its LDS layout is trimmed to keep
-// 8 blocks per CU (19.5 KB).
-template <int RPW> struct RaggedLdsT {
-  static constexpr int RB = FCP_WAVES_PER_BLOCK * RPW; // rows per block
-  static constexpr int NP = FCP_WAVE * RB;             // (column, row) pairs per block, at most
-  static constexpr int CAP = RPW == 1 ? 1536 : 1152;   // staged slot offsets per block
+struct RaggedLds {
+  static constexpr int RB = FCP_WAVES_PER_BLOCK; // rows per block, one per wave
+  static constexpr int NP = FCP_WAVE * RB;       // (column, row) pairs per block, at most (= 256 threads)
+  static constexpr int CAP = 1536;               // staged slot offsets per block
   LdsCol col[FCP_WAVE];
   int32_t lo[NP], cnt[NP];
-  int16_t offx[NP];                                    // exclusive scan of the staged counts (< CAP), or -1
+  int32_t offx[NP];                              // exclusive scan of the staged counts
   uint32_t ids[CAP];
-  uint16_t owner[CAP];                                 // staged id slot -> its (column, row) pair
+  uint16_t owner[CAP];                           // staged id slot -> its (column, row) pair
   int32_t wsum[FCP_WAVES_PER_BLOCK];
-  int32_t bound[FCP_WAVE * (RB + 1)];                  // seg_search: row offsets r0..r0+RB of every column
+  int32_t bound[FCP_WAVE * (FCP_WAVES_PER_BLOCK + 1)]; // seg_search: row offsets r0..r0+RB of every column
 };
-typedef RaggedLdsT<1> RaggedLds;
 
-template <int V, bool SHARDED, int RPW = 1>
+template <int V, bool SHARDED>
 __device__ __forceinline__ void ragged_body(const FcpLaunch &L, int bid, char *smem) {
-  typedef RaggedLdsT<RPW> Lds;
-  constexpr int RB = Lds::RB, NP = Lds::NP, CAP = Lds::CAP;
+  constexpr int RB = RaggedLds::RB, NP = RaggedLds::NP, CAP = RaggedLds::CAP;
   constexpr int LONG_BAG = 64;
-  Lds &S = *reinterpret_cast<Lds *>(smem);
+  RaggedLds &S = *reinterpret_cast<RaggedLds *>(smem);
   LdsCol *s_col = S.col;
-  int32_t *s_lo = S.lo, *s_cnt = S.cnt, *s_wsum = S.wsum;
-  int16_t *s_offx = S.offx;
+  int32_t *s_lo = S.lo, *s_cnt = S.cnt, *s_offx = S.offx, *s_wsum = S.wsum;
   uint32_t *s_ids = S.ids;
   uint16_t *s_owner = S.owner;
 
@@ -614,67 +607,57 @@ __device__ __forceinline__ void ragged_body(const FcpLaunch &L, int bid, char *s
   const unsigned long long t_seg = __builtin_amdgcn_s_memrealtime();
 #endif
   // ---- phase 1a: row ranges of the block's (column, row) pairs + scan ----------------
-  // 256 pairs per round (one per thread); `carry` = staged ids of the earlier rounds
-  const int npairs = B.ncols * RB;
-  int total = 0;
-  for (int base = 0; base < npairs; base += FCP_BLOCK_THREADS) {
-    const int pp = base + tid;
-    int lo = 0, cnt = 0;
-    if (pp < npairs) {
-      const int pj = pp / RB, pr = pp % RB;
-      const int b = B.row_blk + pr;
-      if (b < B.rows) {
-        const unsigned form = FCP_F_FORM(s_col[pj].flags);
-        if (form == FCP_FORM_GATHER) {
-          lo = b;
+  int lo = 0, cnt = 0;
+  if (tid < B.ncols * RB) {
+    const int pj = tid / RB, pr = tid % RB;
+    const int b = B.row_blk + pr;
+    if (b < B.rows) {
+      const unsigned form = FCP_F_FORM(s_col[pj].flags);
+      if (form == FCP_FORM_GATHER) {
+        lo = b;
+        cnt = 1;
+      } else if (form == FCP_FORM_SEGMENT_REDUCE || form == FCP_FORM_GATHER_SCATTER) {
+        const int nnz = s_col[pj].nnz;
+        int o0, o1;
+        if (L.seg_search && FCP_F_SEGKIND(s_col[pj].flags) != FCP_SEG_CSR_I32) {
+          o0 = S.bound[pj * (RB + 1) + pr];
+          o1 = S.bound[pj * (RB + 1) + pr + 1];
+        } else {
+          const FCP_GLOBAL int32_t *csr = as_global(s_col[pj].csr);
+          o0 = csr[b];
+          o1 = csr[b + 1];
+        }
+        lo = min(max(o0, 0), nnz);
+        const int hi = min(max(o1, lo), nnz);
+        cnt = hi - lo;
+        if (form == FCP_FORM_GATHER_SCATTER && cnt > 0) { // the last id of the row wins
+          lo = hi - 1;
           cnt = 1;
-        } else if (form == FCP_FORM_SEGMENT_REDUCE || form == FCP_FORM_GATHER_SCATTER) {
-          const int nnz = s_col[pj].nnz;
-          int o0, o1;
-          if (L.seg_search && FCP_F_SEGKIND(s_col[pj].flags) != FCP_SEG_CSR_I32) {
-            o0 = S.bound[pj * (RB + 1) + pr];
-            o1 = S.bound[pj * (RB + 1) + pr + 1];
-          } else {
-            const FCP_GLOBAL int32_t *csr = as_global(s_col[pj].csr);
-            o0 = csr[b];
-            o1 = csr[b + 1];
-          }
-          lo = min(max(o0, 0), nnz);
-          const int hi = min(max(o1, lo), nnz);
-          cnt = hi - lo;
-          if (form == FCP_FORM_GATHER_SCATTER && cnt > 0) { // the last id of the row wins
-            lo = hi - 1;
-            cnt = 1;
-          }
         }
       }
-      s_lo[pp] = lo;
-      s_cnt[pp] = cnt;
-    }
-    const int want = cnt <= LONG_BAG ? cnt : 0;
-    int incl = want;
-#pragma unroll
-    for (int d = 1; d < FCP_WAVE; d <<= 1) {
-      const int up = __shfl_up(incl, d);
-      if (lane >= d) incl += up;
-    }
-    if (base) __syncthreads(); // the previous round has read wsum
-    if (lane == FCP_WAVE - 1) s_wsum[wave] = incl;
-    __syncthreads();
-    int offx = total + incl - want, round_total = 0;
-#pragma unroll
-    for (int w = 0; w < FCP_WAVES_PER_BLOCK; ++w) {
-      if (w < wave) offx += s_wsum[w];
-      round_total += s_wsum[w];
-    }
-    total += round_total;
-    if (pp < npairs) {
-      const bool staged = want > 0 && offx + want <= CAP;
-      s_offx[pp] = staged ? (int16_t)offx : (int16_t)-1;
-      if (staged)
-        for (int i = 0; i < want; ++i) s_owner[offx + i] = (uint16_t)pp; // fire-and-forget LDS writes
     }
   }
+  s_lo[tid] = lo;
+  s_cnt[tid] = cnt;
+  const int want = cnt <= LONG_BAG ? cnt : 0;
+  int incl = want;
+#pragma unroll
+  for (int d = 1; d < FCP_WAVE; d <<= 1) {
+    const int up = __shfl_up(incl, d);
+    if (lane >= d) incl += up;
+  }
+  if (lane == FCP_WAVE - 1) s_wsum[wave] = incl;
+  __syncthreads();
+  int offx = incl - want, total = 0;
+#pragma unroll
+  for (int w = 0; w < FCP_WAVES_PER_BLOCK; ++w) {
+    if (w < wave) offx += s_wsum[w];
+    total += s_wsum[w];
+  }
+  const bool staged = want > 0 && offx + want <= CAP;
+  s_offx[tid] = staged ? offx : -1;
+  if (staged)
+    for (int i = 0; i < want; ++i) s_owner[offx + i] = (uint16_t)tid; // fire-and-forget LDS writes
   __syncthreads();
 
 #if defined(FCP_STAMPS)
@@ -694,7 +677,8 @@ __device__ __forceinline__ void ragged_body(const FcpLaunch &L, int bid, char *s
 #if defined(FCP_STAMPS)
   const unsigned long long t_ids = __builtin_amdgcn_s_memrealtime();
 #endif
-  if (q >= B.nslots) return;
+  const int b = B.row_blk + wave;
+  if (q >= B.nslots || b >= B.rows) return;
 
   // ---- phase 2 ------------------------------------------------------------------------
   const int j = (int)(my_col - B.first_col);
@@ -703,12 +687,7 @@ __device__ __forceinline__ void ragged_body(const FcpLaunch &L, int bid, char *s
   const int dim = C.dim;
   const int e = q * V - C.out_off;
   const float *tb = C.table + e;
-#pragma unroll 1
-  for (int rw = 0; rw < RPW; ++rw) {
-  const int rr = wave + FCP_WAVES_PER_BLOCK * rw; // this wave's rw-th row of the block
-  const int b = B.row_blk + rr;
-  if (b >= B.rows) break;
-  const int p = j * RB + rr;
+  const int p = j * RB + wave;
   const int plo = s_lo[p], pcnt = s_cnt[p], poff = s_offx[p];
   VF<V> acc = vzero<V>();
 
@@ -787,7 +766,6 @@ __device__ __forceinline__ void ragged_body(const FcpLaunch &L, int bid, char *s
     for (int t = 0; t < V; ++t) acc.v[t] = acc.v[t] / fc;
   }
   st_out<V>(reinterpret_cast<float *>(L.arena + C.out_base) + e + (int64_t)b * C.out_stride, acc);
-  } // rows of this wave
 #if defined(FCP_STAMPS)
   if (L.stamps && tid == 0) { // wave 0 = first row of the block
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -803,10 +781,10 @@ __device__ __forceinline__ void ragged_body(const FcpLaunch &L, int bid, char *s
 #endif
 }
 
-template <int V, bool SHARDED, int RPW = 1>
-__global__ void __launch_bounds__(FCP_BLOCK_THREADS, 8) fcp_ragged_kernel(const FcpLaunch L) { // 8 waves per SIMD: <= 64 VGPRs
-  __shared__ __attribute__((aligned(16))) char smem[sizeof(RaggedLdsT<RPW>)];
-  ragged_body<V, SHARDED, RPW>(L, blockIdx.x, smem);
+template <int V, bool SHARDED>
+__global__ void __launch_bounds__(FCP_BLOCK_THREADS) fcp_ragged_kernel(const FcpLaunch L) {
+  __shared__ __attribute__((aligned(16))) char smem[sizeof(RaggedLds)];
+  ragged_body<V, SHARDED>(L, blockIdx.x, smem);
 }
 
 // ---------------------------------------------------------------------------
@@ -823,14 +801,13 @@ struct FcpHybridLaunch {
   int32_t ragged_blocks;
 };
 
-template <int V, int R, bool SHARDED, int RPW = 1>
-__global__ void __launch_bounds__(FCP_BLOCK_THREADS, 8) fcp_hybrid_kernel(const FcpHybridLaunch H) {
-  constexpr size_t kSmem =
-      sizeof(RaggedLdsT<RPW>) > sizeof(DenseLds<R>) ? sizeof(RaggedLdsT<RPW>) : sizeof(DenseLds<R>);
+template <int V, int R, bool SHARDED>
+__global__ void __launch_bounds__(FCP_BLOCK_THREADS) fcp_hybrid_kernel(const FcpHybridLaunch H) {
+  constexpr size_t kSmem = sizeof(RaggedLds) > sizeof(DenseLds<R>) ? sizeof(RaggedLds) : sizeof(DenseLds<R>);
   __shared__ __attribute__((aligned(16))) char smem[kSmem];
   const int bid = blockIdx.x;
   if (bid < H.ragged_blocks) {
-    ragged_body<V, SHARDED, RPW>(H.ragged, bid, smem); // the longer-running blocks are dispatched first
+    ragged_body<V, SHARDED>(H.ragged, bid, smem); // the longer-running blocks are dispatched first
   } else {
     dense_body<V, R, SHARDED>(H.dense, bid - H.ragged_blocks, smem);
   }
@@ -983,13 +960,11 @@ __global__ void __launch_bounds__(FCP_BLOCK_THREADS) fcp_upload_kernel(const uin
   do {                                                                                                      \
     if (L.shard_world > 1)                                                                                  \
       hipLaunchKernelGGL((fcp_ragged_kernel<VV, true>), dim3(grid_blocks), dim3(FCP_BLOCK_THREADS), lds_pad, s, L); \
-    else if (VV == 4 && L.rows_per_wave == 2)                                                               \
-      hipLaunchKernelGGL((fcp_ragged_kernel<4, false, 2>), dim3(grid_blocks), dim3(FCP_BLOCK_THREADS), lds_pad, s, L); \
     else                                                                                                    \
       hipLaunchKernelGGL((fcp_ragged_kernel<VV, false>), dim3(grid_blocks), dim3(FCP_BLOCK_THREADS), lds_pad, s, L); \
   } while (0)
 
-// rows_per_wave: dense 1 | 2 | 4 (rows per block = 4 x that); ragged 1, or 2 (vec 4, unsharded plans only).
+// rows_per_wave: dense 1 | 2 | 4 (rows per block = 4 x that); ragged always 1.
 int fcp_launch_fused(const FcpLaunch &L, int vec, bool dense_kernel, int grid_blocks, ihipStream_t *s) {
   if (grid_blocks <= 0) return 0;
   // tuning aid: FCP_LDS_PAD=<bytes> of unused dynamic LDS caps the blocks per CU
@@ -1037,8 +1012,6 @@ int fcp_launch_hybrid(const FcpLaunch &Ldense, int dense_blocks, const FcpLaunch
   do {                                                                                    \
     if (sharded)                                                                          \
       hipLaunchKernelGGL((fcp_hybrid_kernel<VV, RR, true>), grid, block, 0, s, H);        \
-    else if (VV == 4 && Lragged.rows_per_wave == 2)                                       \
-      hipLaunchKernelGGL((fcp_hybrid_kernel<4, RR, false, 2>), grid, block, 0, s, H);     \
     else                                                                                  \
       hipLaunchKernelGGL((fcp_hybrid_kernel<VV, RR, false>), grid, block, 0, s, H);       \
   } while (0)
