@@ -63,6 +63,8 @@ __host__ __device__ inline float hash_elem(uint32_t seed, uint64_t r, uint32_t e
   return (float)(u >> 8) * 1.1920928955078125e-07f - 1.0f; // 2^-23
 }
 
+struct BigArg { char bytes[640]; };
+__global__ void noop_big_kernel(BigArg a) { if (a.bytes[0] == 77) __builtin_trap(); }
 __global__ void noop_kernel(int *p) { if (p) *p = 1; }
 
 __global__ void fill_table(float *t, uint32_t seed, uint64_t vocab, uint32_t dim) {
@@ -154,6 +156,24 @@ int main(int argc, char **argv) {
       const int n = (int)v;
       auto now = [] { return std::chrono::steady_clock::now(); };
       auto us = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::micro>(now() - a).count() / n; };
+      {
+        // the same launch through the module API with a pre-resolved function handle and a raw argument
+        // buffer of the size of FcpLaunch (what fcp_launch_fused would pass)
+        hipFunction_t f = nullptr;
+        CHECK_HIP(hipGetFuncBySymbol(&f, reinterpret_cast<const void *>(noop_big_kernel)));
+        BigArg arg;
+        std::memset(&arg, 0, sizeof(arg));
+        size_t arg_size = sizeof(arg);
+        void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &arg, HIP_LAUNCH_PARAM_BUFFER_SIZE, &arg_size, HIP_LAUNCH_PARAM_END};
+        auto t = now();
+        for (int i = 0; i < n; ++i) hipLaunchKernelGGL(noop_big_kernel, dim3(1), dim3(64), 0, s1, arg);
+        std::printf("hipLaunchKernelGGL, 640-byte argument    %.2f us\n", us(t));
+        CHECK_HIP(hipStreamSynchronize(s1));
+        t = now();
+        for (int i = 0; i < n; ++i) CHECK_HIP(hipModuleLaunchKernel(f, 1, 1, 1, 64, 1, 1, 0, s1, nullptr, extra));
+        std::printf("hipModuleLaunchKernel, same argument     %.2f us\n", us(t));
+        CHECK_HIP(hipStreamSynchronize(s1));
+      }
       auto t = now();
       for (int i = 0; i < n; ++i) hipLaunchKernelGGL(noop_kernel, dim3(1), dim3(64), 0, s1, nullptr);
       std::printf("kernel launch          %.2f us\n", us(t));
