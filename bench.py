@@ -41,15 +41,28 @@ except (OSError, ValueError):
     pass
 
 
+def kernels_sha16():
+    import hashlib
+    with open(os.path.join(ROOT, "recom_amd", "csrc", "fcp_kernels.hip"), "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
 def measured_traffic(workload):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json:
     (2 x FETCH_SIZE + WRITE_SIZE) x 1024, the gfx950 correction of MI355X_MICROARCH.md).
-    PMC counters cannot be collected from inside this process."""
+    PMC counters cannot be collected from inside this process, so the figure is a RECORD of a separate
+    pass (scripts/pmc.sh); it is reported only while the kernels are the ones that pass measured
+    (traffic.json carries the sha of fcp_kernels.hip), otherwise null.  Returns (bytes or None, source)."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            return json.load(f)[workload]["traffic_bytes"]
+            rec = json.load(f)
+        entry = rec[workload]
     except Exception:
-        return None
+        return None, "no PMC record for this workload in profiles/traffic.json"
+    sha = rec.get("kernels_sha16")
+    if sha is not None and sha != kernels_sha16():
+        return None, f"profiles/traffic.json was collected on kernels {sha}, this build is {kernels_sha16()}: stale, not reported"
+    return entry["traffic_bytes"], "profiles/traffic.json: separate rocprofv3 --pmc passes (scripts/pmc.sh), per launch"
 
 
 def cpu_baseline(model, budget_s: float = 12.0, sample_columns: int = 40):
@@ -112,9 +125,11 @@ def cpu_baseline(model, budget_s: float = 12.0, sample_columns: int = 40):
     serve_best = None
     per_thread_calls = max(4, int(0.25 / max(per_call * best[1], 1e-6)))      # ~0.25 s per probe
     serve_cands = sorted({t for t in (8, 16, 32, 64, 128, cores) if t <= max(cores, 1)})
+    by_workers = {}
     for t in serve_cands:
         sec = orc.serve_throughput(plan, packed, tables, req.symbols, t, per_thread_calls)
         rate = rows * t * per_thread_calls / sec / scale
+        by_workers[t] = rate
         if serve_best is None or rate > serve_best[0]:
             serve_best = (rate, t)
     calls = max(per_thread_calls, int(per_thread_calls * (budget_s / 4) / 0.25))
@@ -123,6 +138,10 @@ def cpu_baseline(model, budget_s: float = 12.0, sample_columns: int = 40):
     mode, value, used = ("serve_workers", serve, serve_best[1]) if serve > intra else ("intra-request OpenMP", intra, best[1])
     return {
         "value": value, "unit": "inferences/s", "cores": used, "kind": "port",
+        # the reference's TF-CPU budget is 32 cores (AE/build_and_run.py:57); both figures stated
+        "cores_32_inferences_per_s": by_workers.get(32), "all_cores": cores,
+        "all_cores_inferences_per_s": by_workers.get(cores),
+        "serve_workers_sweep": {str(k): v for k, v in sorted(by_workers.items())},
         "sample": f"first {k} of {spec.n_columns} columns at batch {rows}, {len(blobs)} distinct requests rotated, scaled "
                   f"x{scale:.0f} to the whole model; "
                   f"best of two modes = {mode}: intra-request OpenMP {intra:.0f} inf/s with {best[1]} threads "
@@ -245,17 +264,22 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # latency percentiles: separate pass with one HIP event pair per request
-    _, _, it = h.run(min(args.steps, 500), per_request=True)
+    # latency percentiles: separate pass with one HIP event pair per request, at least 200 samples
+    # whatever --steps is
+    _, _, it = h.run(min(max(args.steps, 200), 500), per_request=True)
     # overlapped serving (the reference harness' serve_workers): independent requests on
     # 3 streams hide each launch's ramp / tail behind its neighbours.  Extra field only.
     overlap = None
     if args.threads == 1 and not dist and not args.no_overlap:
         h3 = ServingHarness(model, device=local_rank, n_requests=args.requests, arena_ring=6, n_threads=3,
                             tables=h.tables, seed0=1000 * rank)
-        h3.run(max(args.warmup // 3, 1))
-        w3, _, _ = h3.run(max(args.steps // 3, 1))
-        overlap = {"serve_workers": 3, "us_per_request": w3 * 1e3 / (3 * max(args.steps // 3, 1))}
+        # its own floor whatever --steps / --warmup are: 3 workers need some tens of requests each to reach
+        # steady overlap (round 1: the driver's --steps 20 gave 6 requests per worker and no overlap)
+        ov_warm, ov_steps = max(args.warmup // 3, 50), max(args.steps // 3, 400)
+        h3.run(ov_warm)
+        w3, _, _ = h3.run(ov_steps)
+        overlap = {"serve_workers": 3, "requests_per_worker": ov_steps, "warmup_per_worker": ov_warm,
+                   "us_per_request": w3 * 1e3 / (3 * ov_steps)}
         h3.close()
     batch = model.batch
     steps_total = args.steps * args.threads
@@ -274,12 +298,15 @@ def main():
                    "serve_workers": args.threads},
         "requests_per_s": value / batch,
         "p50_latency_ms": float(np.percentile(it, 50)), "p95_latency_ms": float(np.percentile(it, 95)),
+        "latency_scope": f"device latency of one request (HIP event pair around it on the launch stream, {len(it)} samples), "
+                         "inputs resident in HBM; host packing + H2D are reported separately (DESIGN.md section 4, PCIe-inclusive rate)",
     }
     if rank == 0:
         achieved = bytes_alg["total"] / (dev_ms_per_req * 1e-3) / 1e9
+        traffic, traffic_source = measured_traffic(args.workload)
         rec["roofline"] = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.workload),
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
             "kernel": "fcp_dense_kernel" if all(c.form in (1, 4) for c in model.spec.columns) else "fcp_ragged_kernel",
             "kernel_avg_us": dev_ms_per_req * 1e3,
             "algorithmic_bytes_per_request": bytes_alg,

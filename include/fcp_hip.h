@@ -77,7 +77,16 @@ enum {
   FCP_FORM_PASSTHROUGH = 4,
   /* Sum(x, axis=1) on a rank-3 [B,R,C] tensor of the blob
    * cuda_emitter.cc:1180-1244 (BatchColReduction) */
-  FCP_FORM_BATCH_COL_REDUCTION = 5
+  FCP_FORM_BATCH_COL_REDUCTION = 5,
+  /* A concat slot somebody else fills: an Addons>ConcatOutputs `host_inputs`
+   * tensor (concat_outputs_op_gpu.cu.cc:186-216; Rewrite wires every non-FC
+   * input of the ConcatV2 that way, cuda_emitter.cc:2594-2611).  The plan only
+   * reserves [rows, dim] at the slot's concat offset — the kernels never touch
+   * it — and fcp_concat_outputs_host copies the host tensor there.  It is NOT an
+   * output of FeatureColumnProcess (fcp_plan_output_columns skips it), has no
+   * inputs (ids_input = table_input = -1) and takes its row count from its
+   * group (FCP_ROWS_FROM_GROUP).  FCP_LAYOUT_CONCAT only. */
+  FCP_FORM_EXTERNAL = 6
 };
 
 enum { FCP_COMBINER_NONE = 0, FCP_COMBINER_SUM = 1, FCP_COMBINER_MEAN = 2 };
@@ -105,7 +114,8 @@ enum {
   FCP_ROWS_FROM_IDS = 0,    /* rows = number of elements of the ids tensor (form 1) */
   FCP_ROWS_FROM_SYMBOL = 1, /* rows = symbols[rows_arg] (Addons>ShapeConstruct
                                result, cuda_emitter.cc:2438-2455)             */
-  FCP_ROWS_FROM_INPUT_DIM0 = 2 /* rows = shape[0] of host input rows_arg       */
+  FCP_ROWS_FROM_INPUT_DIM0 = 2, /* rows = shape[0] of host input rows_arg      */
+  FCP_ROWS_FROM_GROUP = 3   /* FCP_FORM_EXTERNAL: rows of the other columns of its concat group */
 };
 
 /* Output arena layouts. */
@@ -247,6 +257,16 @@ int fcp_plan_destroy(fcp_plan_t *plan);
 int fcp_plan_counts(const fcp_plan_t *plan, int32_t *n_columns, int32_t *n_groups,
                     int32_t *n_host_inputs, int32_t *n_device_inputs,
                     int32_t *n_symbols);
+/* The plan columns that are outputs of Addons>FeatureColumnProcess, in plan order
+ * (every column except FCP_FORM_EXTERNAL ones): `indices` receives up to `capacity`
+ * column indices, *n the count (either may be NULL). */
+int fcp_plan_output_columns(const fcp_plan_t *plan, int32_t *n, int32_t *indices,
+                            int32_t capacity);
+/* Bytes of embedding tables this plan reads on THIS device (its shard of every
+ * table, shared tables counted once) and the largest single table's bytes
+ * (unsharded) — the inputs of the placement gate, fcp_placement_decide. */
+int fcp_plan_table_bytes(const fcp_plan_t *plan, int64_t *shard_bytes,
+                         int64_t *max_table_bytes_unsharded);
 /* total concat width of a group (sum of dims in slot order)
  * and the element offset of a column inside its group. */
 int fcp_plan_group_width(const fcp_plan_t *plan, int32_t group, int32_t *width);
@@ -271,6 +291,29 @@ int fcp_process_feature_columns(fcp_plan_t *plan,
  * (reference registers float and int, :250-251). */
 int fcp_concat_outputs(const void *const *inputs, const int32_t *dims,
                        int32_t n, int64_t prefix_size, void *out, void *stream);
+
+/* The same with explicit destinations: input k ([prefix, dims[k]], contiguous, device)
+ * goes to columns [col_offsets[k], col_offsets[k] + dims[k]) of the row-major
+ * matrix `out` [prefix, out_width].  (ScatterBlock<EmbedDim, Offset>,
+ * concat_outputs_op_gpu.cu.cc:85-99, with run-time offsets.) */
+int fcp_concat_outputs_scatter(const void *const *inputs, const int32_t *dims,
+                               const int32_t *col_offsets, int32_t n,
+                               int64_t prefix_size, int32_t out_width, void *out,
+                               void *stream);
+/* Addons>ConcatOutputs `host_inputs` (concat_outputs_op_gpu.cu.cc:186-216): the n
+ * HOST tensors ([prefix, dims[k]], 4-byte elements) are packed into one pinned
+ * staging buffer (library-owned, per device), copied H2D with ONE asynchronous
+ * copy on `stream` into scratch obtained from `malloc_temp` (the reference's
+ * allocate_temp, :189-193) and scattered into columns [col_offsets[k], +dims[k])
+ * of `out` [prefix, out_width] — with FCP_LAYOUT_CONCAT `out` is the group's
+ * matrix inside the FeatureColumnProcess arena, whose FCP_FORM_EXTERNAL slots are
+ * exactly these columns.  No stream synchronisation (the reference blocks, :234);
+ * the host tensors may be reused when the call returns. */
+int fcp_concat_outputs_host(const void *const *host_inputs, const int32_t *dims,
+                            const int32_t *col_offsets, int32_t n,
+                            int64_t prefix_size, int32_t out_width, void *out,
+                            fcp_alloc_fn malloc_temp, void *malloc_temp_ctx,
+                            int32_t device, void *stream);
 
 /* ---- request staging: ConcatInputs + the H2D copy as one step -- */
 /* The reference packs N host tensors with N mempcpy calls on one CPU thread into a

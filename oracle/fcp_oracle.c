@@ -259,6 +259,8 @@ static int64_t input_numel(const orc_plan_t *p, int32_t input, const int32_t *sh
   return n;
 }
 
+int64_t orc_group_rows(const orc_plan_t *p, int32_t group, const int32_t *shapes, const int32_t *symbols);
+
 static int64_t column_rows(const orc_plan_t *p, const orc_column_t *c,
                            const int32_t *shapes, const int32_t *symbols) {
   switch (c->rows_source) {
@@ -268,6 +270,8 @@ static int64_t column_rows(const orc_plan_t *p, const orc_column_t *c,
     return symbols ? symbols[c->rows_arg] : -1;
   case ORC_ROWS_FROM_INPUT_DIM0:
     return shapes[shape_offset(p, c->rows_arg)];
+  case ORC_ROWS_FROM_GROUP:
+    return orc_group_rows(p, c->concat_group, shapes, symbols);
   default:
     return -1;
   }
@@ -277,7 +281,7 @@ int64_t orc_group_rows(const orc_plan_t *p, int32_t group, const int32_t *shapes
                        const int32_t *symbols) {
   int64_t rows = -1;
   for (int32_t k = 0; k < p->n_columns; ++k) {
-    if (p->columns[k].concat_group != group) continue;
+    if (p->columns[k].concat_group != group || p->columns[k].rows_source == ORC_ROWS_FROM_GROUP) continue;
     int64_t r = column_rows(p, &p->columns[k], shapes, symbols);
     if (r < 0 || (rows >= 0 && r != rows)) return -1;
     rows = r;
@@ -355,6 +359,7 @@ static int64_t process_column(const orc_plan_t *p, int32_t k, const int8_t *blob
                               float *const *group_out, const int32_t *widths,
                               const int32_t *col_offs) {
   const orc_column_t *c = &p->columns[k];
+  if (c->form == ORC_FORM_EXTERNAL) return 0; /* filled by ConcatOutputs from a host input: not ours to write */
   const int32_t width = widths[c->concat_group];
   const int32_t off = col_offs[k];
   const int64_t rows = column_rows(p, c, shapes, symbols);

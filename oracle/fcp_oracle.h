@@ -27,11 +27,15 @@ extern "C" {
 
 /* Same numeric values as include/fcp_hip.h (kept separate on purpose). */
 enum { ORC_FORM_GATHER = 1, ORC_FORM_SEGMENT_REDUCE = 2, ORC_FORM_GATHER_SCATTER = 3,
-       ORC_FORM_PASSTHROUGH = 4, ORC_FORM_BATCH_COL_REDUCTION = 5 };
+       ORC_FORM_PASSTHROUGH = 4, ORC_FORM_BATCH_COL_REDUCTION = 5,
+       /* a concat slot filled by Addons>ConcatOutputs `host_inputs` (concat_outputs_op_gpu.cu.cc:186-216):
+          ProcessFeatureColumns leaves it untouched */
+       ORC_FORM_EXTERNAL = 6 };
 enum { ORC_COMBINER_NONE = 0, ORC_COMBINER_SUM = 1, ORC_COMBINER_MEAN = 2 };
 enum { ORC_IDS_I32 = 0, ORC_IDS_I64 = 1, ORC_IDS_F32_BUCKETIZE = 2 };
 enum { ORC_SEG_NONE = 0, ORC_SEG_IDS_I32 = 1, ORC_SEG_IDS_I64 = 2, ORC_SEG_CSR_I32 = 3 };
-enum { ORC_ROWS_FROM_IDS = 0, ORC_ROWS_FROM_SYMBOL = 1, ORC_ROWS_FROM_INPUT_DIM0 = 2 };
+enum { ORC_ROWS_FROM_IDS = 0, ORC_ROWS_FROM_SYMBOL = 1, ORC_ROWS_FROM_INPUT_DIM0 = 2,
+       ORC_ROWS_FROM_GROUP = 3 /* external slots: the row count of the other columns of the group */ };
 
 typedef struct orc_column {
   int32_t form, combiner, dim, id_source;

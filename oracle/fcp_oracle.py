@@ -316,6 +316,8 @@ def np_process_feature_columns(plan: dict, blob: np.ndarray, offsets, shapes, ta
             acc += cols[k]["dim"]
 
     def rows_of(c):
+        if c["rows_source"] == 3:   # external slot: rows of the other columns of its group
+            return next(rows_of(o) for o in cols if o["concat_group"] == c["concat_group"] and o["rows_source"] != 3)
         if c["rows_source"] == 0:
             return int(np.prod(shapes[so[c["ids_input"]]:so[c["ids_input"] + 1]]))
         if c["rows_source"] == 1:
@@ -329,6 +331,8 @@ def np_process_feature_columns(plan: dict, blob: np.ndarray, offsets, shapes, ta
         if outs[g] is None:
             outs[g] = np.zeros((rows, widths[g]), np.float64)
         dst = outs[g][:, col_off[k]:col_off[k] + c["dim"]]
+        if c["form"] == 6:          # external slot: left as it is (zeros here)
+            continue
         if c["form"] == 4:
             dst[:] = tensor(c["ids_input"], np.float32).reshape(rows, c["dim"])
             continue

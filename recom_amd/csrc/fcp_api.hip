@@ -197,11 +197,21 @@ int validate_desc(const fcp_plan_desc_t *d) {
   for (int k = 0; k < d->n_columns; ++k) {
     const fcp_column_desc_t &c = d->columns[k];
     const std::string where = "column " + std::to_string(k) + ": ";
-    if (c.form < FCP_FORM_GATHER || c.form > FCP_FORM_BATCH_COL_REDUCTION)
+    if (c.form < FCP_FORM_GATHER || c.form > FCP_FORM_EXTERNAL)
       return fail(FCP_ERR_INVALID_ARGUMENT, where + "bad form");
     if (c.dim <= 0) return fail(FCP_ERR_INVALID_ARGUMENT, where + "dim must be positive");
     if (c.concat_group < 0 || c.concat_group >= d->n_groups)
       return fail(FCP_ERR_INVALID_ARGUMENT, where + "concat_group out of range");
+    if (c.form == FCP_FORM_EXTERNAL) {
+      // a slot reserved for an Addons>ConcatOutputs host input: no inputs of its own
+      if (d->layout != FCP_LAYOUT_CONCAT) return fail(FCP_ERR_INVALID_ARGUMENT, where + "external slots need FCP_LAYOUT_CONCAT");
+      if (c.rows_source != FCP_ROWS_FROM_GROUP) return fail(FCP_ERR_INVALID_ARGUMENT, where + "external slot takes its rows from its group");
+      for (int j = 0; j < k; ++j)
+        if (d->columns[j].concat_group == c.concat_group && d->columns[j].concat_slot == c.concat_slot)
+          return fail(FCP_ERR_INVALID_ARGUMENT, where + "duplicate concat slot");
+      continue;
+    }
+    if (c.rows_source == FCP_ROWS_FROM_GROUP) return fail(FCP_ERR_INVALID_ARGUMENT, where + "only external slots take their rows from the group");
     if (c.ids_input < 0 || c.ids_input >= d->n_host_inputs)
       return fail(FCP_ERR_INVALID_ARGUMENT, where + "ids_input out of range");
     const bool lookup = c.form == FCP_FORM_GATHER || c.form == FCP_FORM_SEGMENT_REDUCE ||
@@ -282,6 +292,7 @@ int compute_dyn_slow(const fcp_plan *p, const int32_t *offsets, const int32_t *s
   for (int k = 0; k < nc; ++k) {
     const fcp_column_desc_t &c = p->cols[k].d;
     int64_t rows;
+    if (c.form == FCP_FORM_EXTERNAL) continue; // rows of its group, below
     if (c.rows_source == FCP_ROWS_FROM_IDS) {
       rows = numel[c.ids_input];
     } else if (c.rows_source == FCP_ROWS_FROM_SYMBOL) {
@@ -300,6 +311,8 @@ int compute_dyn_slow(const fcp_plan *p, const int32_t *offsets, const int32_t *s
   }
   for (int g = 0; g < ng; ++g)
     if (m->group_rows[g] < 0) return fail(FCP_ERR_INVALID_ARGUMENT, "concat group without columns");
+  for (int k = 0; k < nc; ++k)
+    if (p->cols[k].d.form == FCP_FORM_EXTERNAL) col_rows[k] = m->group_rows[p->cols[k].d.concat_group];
 
   // arena: outputs, then CSR scratch (one malloc_buff, cuda_emitter.cc:2151-2163)
   int64_t cursor = 0;
@@ -320,12 +333,14 @@ int compute_dyn_slow(const fcp_plan *p, const int32_t *offsets, const int32_t *s
     d.pad_ = 0;
     const int64_t rows = col_rows[k];
     d.rows = (int32_t)rows;
-    d.ids_off = offsets[c.ids_input];
+    d.ids_off = c.form == FCP_FORM_EXTERNAL ? 0 : offsets[c.ids_input];
     if (d.ids_off % 4) return fail(FCP_ERR_UNSUPPORTED, "blob tensor not 4-byte aligned");
-    const int64_t n_ids = numel[c.ids_input];
+    const int64_t n_ids = c.form == FCP_FORM_EXTERNAL ? 0 : numel[c.ids_input];
     d.csr_base = -1;
     d.inner = 1;
-    if (c.form == FCP_FORM_PASSTHROUGH) {
+    if (c.form == FCP_FORM_EXTERNAL) {
+      d.nnz = 0;
+    } else if (c.form == FCP_FORM_PASSTHROUGH) {
       if (n_ids != rows * c.dim) return fail(FCP_ERR_SHAPE_MISMATCH, "passthrough tensor size != rows*dim");
       if (n_ids / p->vec >= 0xFFFFFFFFLL) return fail(FCP_ERR_UNSUPPORTED, "passthrough tensor exceeds 2^32 slots");
       d.nnz = (int32_t)rows;
@@ -453,6 +468,7 @@ int compute_dyn_fast(const fcp_plan *p, const int32_t *offsets, const int32_t *s
     if (blob_bytes >= 0 && (int64_t)offsets[i] + n * p->elem_sizes[i] > blob_bytes) return -1;
   }
   auto rows_of = [&](const fcp_plan::FastCol &c) -> int64_t {
+    if (c.rows_source == FCP_ROWS_FROM_GROUP) return m->group_rows[c.group];
     if (c.rows_source == FCP_ROWS_FROM_IDS) return numel[c.ids_input];
     if (c.rows_source == FCP_ROWS_FROM_SYMBOL) return symbols ? (int64_t)symbols[c.rows_arg] : -1;
     return shapes[p->shape_off[c.rows_arg]];
@@ -474,8 +490,9 @@ int compute_dyn_fast(const fcp_plan *p, const int32_t *offsets, const int32_t *s
     const int64_t rows = rows_of(c);
     if (rows != m->group_rows[c.group]) return -1;
     FcpColDyn &d = dyn[i];
-    const int64_t n_ids = numel[c.ids_input];
-    d.ids_off = offsets[c.ids_input];
+    const bool external = c.form == FCP_FORM_EXTERNAL;
+    const int64_t n_ids = external ? 0 : numel[c.ids_input];
+    d.ids_off = external ? 0 : offsets[c.ids_input];
     d.seg_off = 0;
     d.out_base = m->group_base[c.group] + c.out_off_bytes;
     d.out_stride = p->group_width[c.group];
@@ -486,6 +503,8 @@ int compute_dyn_fast(const fcp_plan *p, const int32_t *offsets, const int32_t *s
     if (c.form == FCP_FORM_GATHER) {
       if (n_ids != rows) return -1;
       d.nnz = (int32_t)n_ids;
+    } else if (external) {
+      d.nnz = 0;
     } else if (c.form == FCP_FORM_PASSTHROUGH) {
       if (n_ids != rows * c.dim || n_ids / p->vec >= 0xFFFFFFFFLL) return -1;
       d.nnz = (int32_t)rows;
@@ -788,6 +807,17 @@ void publish_slot(fcp_plan *p, DynSlot &s, const std::vector<int32_t> &key, void
   s.valid = true;
 }
 
+struct SlotUnpin { // every exit path of a request: publish what `done` covers and give the slot back
+  fcp_plan *p;
+  DynSlot *s;
+  bool recorded;
+  ~SlotUnpin() {
+    std::lock_guard<std::mutex> lock(p->mu);
+    if (recorded) s->done_valid = s->uses == 1; // hits that joined meanwhile are not covered by `done`
+    --s->users;
+  }
+};
+
 void fill_launch(const fcp_plan *p, const DynSlot &s, int kind, const void *blob, void *arena, FcpLaunch *L) {
   L->slot_map = p->d_slot_map;
   L->span_list = p->d_span_list;
@@ -910,7 +940,7 @@ int fcp_plan_create(const fcp_plan_desc_t *desc, fcp_plan_t **out) {
     HostColumn &hc = p->cols[k];
     hc.d = desc->columns[k];
     if (hc.d.id_source == FCP_IDS_F32_BUCKETIZE && hc.d.boundaries && hc.d.n_boundaries > 0 &&
-        hc.d.form != FCP_FORM_PASSTHROUGH && hc.d.form != FCP_FORM_BATCH_COL_REDUCTION)
+        hc.d.form != FCP_FORM_PASSTHROUGH && hc.d.form != FCP_FORM_BATCH_COL_REDUCTION && hc.d.form != FCP_FORM_EXTERNAL)
       hc.boundaries.assign(hc.d.boundaries, hc.d.boundaries + hc.d.n_boundaries);
     hc.d.boundaries = nullptr;
     if (hc.d.dim % 4) gcd4 = (hc.d.dim % 2) ? 1 : std::min(gcd4, 2);
@@ -931,7 +961,7 @@ int fcp_plan_create(const fcp_plan_desc_t *desc, fcp_plan_t **out) {
   // reference's int arithmetic stops at 2^31 elements = 8 GB, cuda_emitter.cc:270-271.)
   for (int k = 0; k < desc->n_columns; ++k) {
     const fcp_column_desc_t &c = p->cols[k].d;
-    if (c.form == FCP_FORM_PASSTHROUGH || c.form == FCP_FORM_BATCH_COL_REDUCTION) continue;
+    if (c.form == FCP_FORM_PASSTHROUGH || c.form == FCP_FORM_BATCH_COL_REDUCTION || c.form == FCP_FORM_EXTERNAL) continue;
     const int64_t local_vocab = (c.vocab - desc->shard_rank + desc->shard_world - 1) / desc->shard_world;
     if (local_vocab * (c.dim / p->vec) >= 0xFFFFFFFFLL) {
       delete p;
@@ -981,7 +1011,7 @@ int fcp_plan_create(const fcp_plan_desc_t *desc, fcp_plan_t **out) {
       f.rows_source = (uint8_t)hc.d.rows_source;
       f.seg_kind = (uint8_t)hc.d.seg_kind;
       f.group = (uint8_t)hc.d.concat_group;
-      if (p->group_rep[hc.d.concat_group] < 0) p->group_rep[hc.d.concat_group] = pos;
+      if (p->group_rep[hc.d.concat_group] < 0 && hc.d.form != FCP_FORM_EXTERNAL) p->group_rep[hc.d.concat_group] = pos;
     }
     for (int g = 0; g < desc->n_groups; ++g)
       if (p->group_rep[g] < 0) p->fast_cols.clear(); // a group without columns: let the general routine report it
@@ -998,7 +1028,7 @@ int fcp_plan_create(const fcp_plan_desc_t *desc, fcp_plan_t **out) {
     for (int k = 0; k < desc->n_columns; ++k) {
       const HostColumn &hc = p->cols[k];
       if (hc.d.concat_group != g) continue;
-      if (hc.d.form == FCP_FORM_GATHER || hc.d.form == FCP_FORM_PASSTHROUGH) continue;
+      if (hc.d.form == FCP_FORM_GATHER || hc.d.form == FCP_FORM_PASSTHROUGH || hc.d.form == FCP_FORM_EXTERNAL) continue;
       const int s0 = hc.out_off / p->vec / FCP_WAVE, s1 = (hc.out_off + hc.d.dim - 1) / p->vec / FCP_WAVE;
       for (int sp = s0; sp <= s1 && sp < nspans; ++sp) ragged[sp] = 1;
     }
@@ -1097,6 +1127,40 @@ int fcp_plan_counts(const fcp_plan_t *p, int32_t *n_columns, int32_t *n_groups, 
   return FCP_OK;
 }
 
+int fcp_plan_output_columns(const fcp_plan_t *p, int32_t *n, int32_t *indices, int32_t capacity) {
+  if (!p) return fail(FCP_ERR_INVALID_ARGUMENT, "null plan");
+  int32_t count = 0;
+  for (int32_t k = 0; k < (int32_t)p->cols.size(); ++k) {
+    if (p->cols[k].d.form == FCP_FORM_EXTERNAL) continue;
+    if (indices && count < capacity) indices[count] = k;
+    ++count;
+  }
+  if (n) *n = count;
+  return FCP_OK;
+}
+
+int fcp_plan_table_bytes(const fcp_plan_t *p, int64_t *shard_bytes, int64_t *max_table_bytes_unsharded) {
+  if (!p) return fail(FCP_ERR_INVALID_ARGUMENT, "null plan");
+  // a table input may feed several columns (shared embeddings): count each once
+  std::vector<int64_t> local(p->desc.n_device_inputs, 0), whole(p->desc.n_device_inputs, 0);
+  for (const HostColumn &hc : p->cols) {
+    const int f = hc.d.form;
+    if (f != FCP_FORM_GATHER && f != FCP_FORM_SEGMENT_REDUCE && f != FCP_FORM_GATHER_SCATTER) continue;
+    const int64_t local_vocab =
+        (hc.d.vocab - p->desc.shard_rank + p->desc.shard_world - 1) / p->desc.shard_world;
+    local[hc.d.table_input] = std::max(local[hc.d.table_input], local_vocab * hc.d.dim * 4);
+    whole[hc.d.table_input] = std::max(whole[hc.d.table_input], hc.d.vocab * hc.d.dim * 4);
+  }
+  int64_t sum = 0, mx = 0;
+  for (int t = 0; t < p->desc.n_device_inputs; ++t) {
+    sum += local[t];
+    mx = std::max(mx, whole[t]);
+  }
+  if (shard_bytes) *shard_bytes = sum;
+  if (max_table_bytes_unsharded) *max_table_bytes_unsharded = mx;
+  return FCP_OK;
+}
+
 int fcp_plan_destroy(fcp_plan_t *p) {
   if (!p) return FCP_OK;
   if (!p->host_only) {
@@ -1164,7 +1228,7 @@ int fcp_process_feature_columns(fcp_plan_t *p, const fcp_process_args_t *a, fcp_
   if (a->input_shapes) { // optional cross-check of the table shapes
     for (const HostColumn &hc : p->cols) {
       const int f = hc.d.form;
-      if (f == FCP_FORM_PASSTHROUGH || f == FCP_FORM_BATCH_COL_REDUCTION) continue;
+      if (f == FCP_FORM_PASSTHROUGH || f == FCP_FORM_BATCH_COL_REDUCTION || f == FCP_FORM_EXTERNAL) continue;
       const int32_t *s = a->input_shapes + 2 * hc.d.table_input;
       const int64_t local_vocab = p->desc.shard_world > 1
                                       ? (hc.d.vocab - p->desc.shard_rank + p->desc.shard_world - 1) / p->desc.shard_world
@@ -1199,16 +1263,7 @@ int fcp_process_feature_columns(fcp_plan_t *p, const fcp_process_args_t *a, fcp_
     }
     if (rc) return rc;
   }
-  struct Unpin { // every exit path: publish what `done` covers and give the slot back
-    fcp_plan *p;
-    DynSlot *s;
-    bool recorded;
-    ~Unpin() {
-      std::lock_guard<std::mutex> lock(p->mu);
-      if (recorded) s->done_valid = s->uses == 1; // hits that joined meanwhile are not covered by `done`
-      --s->users;
-    }
-  } unpin{p, slot, false};
+  SlotUnpin unpin{p, slot, false};
   if (install) {
     rc = install_slot(p, a, *slot); // on failure the slot stays invalid and is released by `unpin`
     if (rc) return rc;
@@ -1293,8 +1348,101 @@ int fcp_concat_outputs(const void *const *inputs, const int32_t *dims, int32_t n
     width += dims[k];
   }
   if (width > 0x7fffffff) return fail(FCP_ERR_UNSUPPORTED, "concat width exceeds 2^31");
-  const int e = fcp_launch_concat_outputs(inputs, dims, n, prefix_size, (int32_t)width, 0, out,
+  const int e = fcp_launch_concat_outputs(inputs, dims, nullptr, n, prefix_size, (int32_t)width, 0, out,
                                           static_cast<hipStream_t>(stream));
+  if (e) return hip_fail("concat-outputs launch", (hipError_t)e);
+  return FCP_OK;
+}
+
+namespace {
+int check_scatter_args(const void *const *inputs, const int32_t *dims, const int32_t *col_offsets, int32_t n,
+                       int64_t prefix_size, int32_t out_width, const void *out) {
+  if (n < 0 || prefix_size < 0 || out_width < 0) return fail(FCP_ERR_INVALID_ARGUMENT, "negative size");
+  if (n == 0 || prefix_size == 0) return FCP_OK;
+  if (!inputs || !dims || !col_offsets || !out) return fail(FCP_ERR_INVALID_ARGUMENT, "null argument");
+  for (int32_t k = 0; k < n; ++k) {
+    if (dims[k] <= 0 || !inputs[k]) return fail(FCP_ERR_INVALID_ARGUMENT, "bad concat input");
+    if (col_offsets[k] < 0 || (int64_t)col_offsets[k] + dims[k] > out_width)
+      return fail(FCP_ERR_INVALID_ARGUMENT, "concat input " + std::to_string(k) + " does not fit the output row");
+  }
+  return FCP_OK;
+}
+
+// Pinned staging for Addons>ConcatOutputs host inputs: a small ring per device, grown on demand.  A slot is
+// reused once the copy that read it has completed (its event), so the call never waits for the GPU in the
+// steady state and never hands pageable memory to an asynchronous copy.
+struct HostStageSlot {
+  char *buf = nullptr;
+  size_t cap = 0;
+  hipEvent_t copied = nullptr;
+};
+struct HostStageRing {
+  std::mutex mu;
+  HostStageSlot slots[4];
+  size_t next = 0;
+};
+HostStageRing *host_stage_ring(int device) {
+  static std::mutex mu;
+  static std::vector<HostStageRing *> rings;
+  std::lock_guard<std::mutex> lock(mu);
+  if ((int)rings.size() <= device) rings.resize(device + 1, nullptr);
+  if (!rings[device]) rings[device] = new HostStageRing(); // lives as long as the process (pinned memory is freed at exit)
+  return rings[device];
+}
+} // namespace
+
+int fcp_concat_outputs_scatter(const void *const *inputs, const int32_t *dims, const int32_t *col_offsets, int32_t n,
+                               int64_t prefix_size, int32_t out_width, void *out, void *stream) {
+  int rc = check_scatter_args(inputs, dims, col_offsets, n, prefix_size, out_width, out);
+  if (rc || n == 0 || prefix_size == 0) return rc;
+  const int e = fcp_launch_concat_outputs(inputs, dims, col_offsets, n, prefix_size, out_width, 0, out,
+                                          static_cast<hipStream_t>(stream));
+  if (e) return hip_fail("concat-outputs launch", (hipError_t)e);
+  return FCP_OK;
+}
+
+int fcp_concat_outputs_host(const void *const *host_inputs, const int32_t *dims, const int32_t *col_offsets, int32_t n,
+                            int64_t prefix_size, int32_t out_width, void *out, fcp_alloc_fn malloc_temp,
+                            void *malloc_temp_ctx, int32_t device, void *stream_) {
+  int rc = check_scatter_args(host_inputs, dims, col_offsets, n, prefix_size, out_width, out);
+  if (rc || n == 0 || prefix_size == 0) return rc;
+  if (!malloc_temp) return fail(FCP_ERR_INVALID_ARGUMENT, "malloc_temp callback is required");
+  DeviceGuard guard;
+  rc = guard.enter(device);
+  if (rc) return rc;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  size_t total = 0;
+  std::vector<size_t> at(n);
+  for (int32_t k = 0; k < n; ++k) {
+    at[k] = total;
+    total += ((size_t)prefix_size * dims[k] * 4 + 15) / 16 * 16;
+  }
+  char *d_stage = static_cast<char *>(malloc_temp(malloc_temp_ctx, total));
+  if (!d_stage) return fail(FCP_ERR_ALLOC, "malloc_temp returned NULL");
+  HostStageRing *ring = host_stage_ring(device);
+  {
+    // pack (the reference: one memcpy per input into a std::vector, concat_outputs_op_gpu.cu.cc:195-201) and
+    // enqueue the one H2D copy under the ring lock; concurrent callers take different slots
+    std::unique_lock<std::mutex> lock(ring->mu);
+    HostStageSlot &sl = ring->slots[ring->next];
+    ring->next = (ring->next + 1) % 4;
+    if (sl.copied && hipEventQuery(sl.copied) != hipSuccess) HIP_TRY(hipEventSynchronize(sl.copied));
+    if (sl.cap < total) {
+      if (sl.buf) HIP_TRY(hipHostFree(sl.buf));
+      sl.buf = nullptr;
+      sl.cap = 0;
+      const size_t cap = std::max<size_t>(total, 1 << 16);
+      HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&sl.buf), cap, hipHostMallocDefault));
+      sl.cap = cap;
+    }
+    if (!sl.copied) HIP_TRY(hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming));
+    for (int32_t k = 0; k < n; ++k) std::memcpy(sl.buf + at[k], host_inputs[k], (size_t)prefix_size * dims[k] * 4);
+    HIP_TRY(hipMemcpyAsync(d_stage, sl.buf, total, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipEventRecord(sl.copied, stream));
+  }
+  std::vector<const void *> d_in(n);
+  for (int32_t k = 0; k < n; ++k) d_in[k] = d_stage + at[k];
+  const int e = fcp_launch_concat_outputs(d_in.data(), dims, col_offsets, n, prefix_size, out_width, 0, out, stream);
   if (e) return hip_fail("concat-outputs launch", (hipError_t)e);
   return FCP_OK;
 }
@@ -1306,31 +1454,31 @@ int fcp_shard_finalize(fcp_plan_t *p, const fcp_process_args_t *a, int32_t group
   if (p->host_only) return fail(FCP_ERR_NO_DEVICE, "host-only plan cannot run");
   if (group < 0 || group >= p->desc.n_groups || world < 1 || row_begin < 0 || row_count < 0)
     return fail(FCP_ERR_INVALID_ARGUMENT, "bad group / world / rows");
-  if (row_count > 65535) return fail(FCP_ERR_UNSUPPORTED, "row_count > 65535 per finalize call");
   DeviceGuard guard;
   int rc = guard.enter(p->desc.device);
   if (rc) return rc;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   fcp_process_args_t args = *a;
   args.stream = stream_;
-  std::unique_lock<std::mutex> lock(p->mu); // held throughout: finalize is not on the multi-worker hot path
+  // same locking discipline as fcp_process_feature_columns: the plan mutex covers the slot bookkeeping only
   DynSlot *slot = nullptr;
   bool install = false;
   thread_local std::vector<int32_t> key;
   build_key(p, &args, key);
-  while ((rc = find_or_reserve(p, key, &slot, &install)) == kAllSlotsBusy) {
-    lock.unlock();
-    std::this_thread::yield();
-    lock.lock();
+  {
+    std::unique_lock<std::mutex> lock(p->mu);
+    while ((rc = find_or_reserve(p, key, &slot, &install)) == kAllSlotsBusy) {
+      lock.unlock();
+      std::this_thread::yield();
+      lock.lock();
+    }
+    if (rc) return rc;
   }
-  if (rc) return rc;
-  struct Release { // the lock is still held when this runs
-    DynSlot *s;
-    ~Release() { --s->users; }
-  } release{slot};
+  SlotUnpin unpin{p, slot, false};
   if (install) {
     rc = install_slot(p, &args, *slot);
     if (rc) return rc;
+    std::lock_guard<std::mutex> lock(p->mu);
     publish_slot(p, *slot, key, args.stream);
   }
   const DynMeta &m = slot->meta;
@@ -1364,7 +1512,7 @@ int fcp_shard_finalize(fcp_plan_t *p, const fcp_process_args_t *a, int32_t group
   if (e) return hip_fail("shard-finalize launch", (hipError_t)e);
   if (install) { // the descriptors were installed by this call
     HIP_TRY(hipEventRecord(slot->done, stream));
-    slot->done_valid = slot->uses == 1;
+    unpin.recorded = true;
   }
   return FCP_OK;
 }

@@ -63,6 +63,8 @@ struct FcpGroupLaunch {
   int32_t pad_;
 };
 
+// Field order matters: everything a block of a one-group plan reads lies in the first two 64-byte
+// lines of the argument block (the kernels fetch both with one batch of scalar loads and wait once).
 struct FcpLaunch {
   const uint32_t *slot_map;  // slot -> column index
   const uint32_t *span_list; // span indices per (group, kernel kind): hybrid dense / ragged dispatch
@@ -71,12 +73,13 @@ struct FcpLaunch {
   const char *blob;
   char *arena;
   unsigned long long *bad_ids; // nullable
-  unsigned long long *stamps;  // diagnostic builds (-DFCP_STAMPS) only: 4 timestamps per block
   int64_t csr_arena_off;       // byte offset of the CSR scratch inside the arena
-  int32_t shard_rank, shard_world;
   int32_t n_groups;
   int32_t rows_per_wave;
+  int32_t shard_rank, shard_world;
   int32_t seg_search;          // 1: blocks find their rows' ranges in the sorted segment ids themselves (no pre-pass)
+  int32_t pad_;
+  unsigned long long *stamps;  // diagnostic builds (-DFCP_STAMPS) only: 8 timestamps per block
   FcpGroupLaunch groups[FCP_MAX_GROUPS];
 };
 
@@ -97,7 +100,8 @@ int fcp_launch_hybrid(const FcpLaunch &Ldense, int dense_blocks, const FcpLaunch
                       ihipStream_t *s);
 int fcp_launch_upload(const void *host_mapped_src, void *dst, size_t bytes, ihipStream_t *s);
 int fcp_launch_segment_offsets(const FcpSegLaunch &L, int n_seg_cols, int max_nnz, ihipStream_t *s);
-int fcp_launch_concat_outputs(const void *const *inputs, const int32_t *dims, int32_t n,
+// col_offsets: destination column of every input, or NULL = side by side starting at first_off
+int fcp_launch_concat_outputs(const void *const *inputs, const int32_t *dims, const int32_t *col_offsets, int32_t n,
                               int64_t prefix, int32_t width, int32_t first_off, void *out,
                               ihipStream_t *s);
 int fcp_launch_shard_finalize(const FcpLaunch &L, int group, const float *partials, int world,

@@ -50,6 +50,10 @@ template <typename T> __device__ __forceinline__ const FCP_GLOBAL T *as_global(c
   return (const FCP_GLOBAL T *)(p);
 }
 template <typename T> __device__ __forceinline__ FCP_GLOBAL T *as_global(T *p) { return (FCP_GLOBAL T *)(p); }
+// Plan data and the request's descriptors are read-only for the lifetime of a launch: the constant
+// address space lets the compiler use scalar loads for wave-uniform addresses (slot map, span list).
+#define FCP_CONST __attribute__((address_space(4)))
+template <typename T> __device__ __forceinline__ const FCP_CONST T *as_const(const T *p) { return (const FCP_CONST T *)(p); }
 
 template <int V> struct VecType;
 template <> struct VecType<4> { typedef float __attribute__((ext_vector_type(4))) T; };
@@ -71,11 +75,36 @@ template <int V> __device__ __forceinline__ VF<V> vzero() {
 // uniform ids) but costs the reference's models E / F 4.5 us per request — their ~1000
 // bucketize / hash tables of ~100 rows are re-read by every row and belong in L2.
 // -DFCP_NO_NT restores the default policy for stores as well (tuning builds).
+#if defined(FCP_STORE_POLICY) // tuning builds: 2 = sc1 (write-through), 3 = sc0 sc1, 4 = sc1 nt, 5 = sc0 sc1 nt
+#if FCP_STORE_POLICY == 2
+#define FCP_ST_BITS "sc1"
+#elif FCP_STORE_POLICY == 3
+#define FCP_ST_BITS "sc0 sc1"
+#elif FCP_STORE_POLICY == 4
+#define FCP_ST_BITS "sc1 nt"
+#else
+#define FCP_ST_BITS "sc0 sc1 nt"
+#endif
+__device__ __forceinline__ void st_asm(FCP_GLOBAL VecType<4>::T *p, VecType<4>::T t) {
+  // s_nop: a VMEM store of more than 64 bits must not be followed immediately by a VALU write of its data
+  // registers; the hazard recogniser does not look inside inline asm
+  asm volatile("global_store_dwordx4 %0, %1, off " FCP_ST_BITS "\n\ts_nop 1" ::"v"(p), "v"(t) : "memory");
+}
+__device__ __forceinline__ void st_asm(FCP_GLOBAL VecType<2>::T *p, VecType<2>::T t) {
+  asm volatile("global_store_dwordx2 %0, %1, off " FCP_ST_BITS ::"v"(p), "v"(t) : "memory");
+}
+__device__ __forceinline__ void st_asm(FCP_GLOBAL VecType<1>::T *p, VecType<1>::T t) {
+  asm volatile("global_store_dword %0, %1, off " FCP_ST_BITS ::"v"(p), "v"(t) : "memory");
+}
+#endif
+
 template <int V> __device__ __forceinline__ void st_out(float *p, const VF<V> &v) {
   typedef typename VecType<V>::T T;
   T t;
   __builtin_memcpy(&t, &v, sizeof(T));
-#if !defined(FCP_NO_NT)
+#if defined(FCP_STORE_POLICY)
+  st_asm(as_global(reinterpret_cast<T *>(p)), t);
+#elif !defined(FCP_NO_NT)
   __builtin_nontemporal_store(t, as_global(reinterpret_cast<T *>(p)));
 #else
   *as_global(reinterpret_cast<T *>(p)) = t;
@@ -156,7 +185,56 @@ struct alignas(16) LdsCol {   // 80 bytes
   int32_t inner;
 };
 
-__device__ __forceinline__ LdsCol make_lds_col(const FcpLaunch &L, const FcpColStatic &cs, const FcpColDyn &cd) {
+// The scalars of the argument block a body uses, fetched up front in ONE batch of scalar loads and
+// pinned there (the empty asm keeps the compiler from sinking each load next to its first use, which
+// made a string of separate scalar-cache round trips at the head of every block).
+struct Hot {
+  const FCP_CONST uint32_t *slot_map, *span_list;
+  const FCP_CONST FcpColStatic *cols;
+  const FCP_CONST FcpColDyn *dyn;
+  const char *blob;
+  char *arena;
+  unsigned long long *bad_ids;
+  int64_t csr_arena_off;
+  int32_t n_groups, rank, world, seg_search;
+  FcpGroupLaunch g0;
+};
+
+__device__ __forceinline__ Hot load_hot(const FcpLaunch &L) {
+  Hot h;
+  h.slot_map = as_const(L.slot_map);
+  h.span_list = as_const(L.span_list);
+  h.cols = as_const(L.cols);
+  h.dyn = as_const(L.dyn);
+  h.blob = L.blob;
+  h.arena = L.arena;
+  h.bad_ids = L.bad_ids;
+  h.csr_arena_off = L.csr_arena_off;
+  h.n_groups = L.n_groups;
+  h.rank = L.shard_rank;
+  h.world = L.shard_world;
+  h.seg_search = L.seg_search;
+  h.g0 = L.groups[0];
+  asm volatile("" : "+s"(h.slot_map), "+s"(h.span_list), "+s"(h.cols), "+s"(h.dyn), "+s"(h.blob), "+s"(h.arena),
+               "+s"(h.bad_ids), "+s"(h.csr_arena_off));
+  asm volatile("" : "+s"(h.n_groups), "+s"(h.rank), "+s"(h.world), "+s"(h.seg_search), "+s"(h.g0.rows), "+s"(h.g0.nslots),
+               "+s"(h.g0.nsp8), "+s"(h.g0.block_begin), "+s"(h.g0.slot_map_off), "+s"(h.g0.span_list_off), "+s"(h.g0.nlist));
+  return h;
+}
+
+// A 48-byte record as three unconditional 16-byte loads (field-by-field access let the compiler wait
+// for `flags` before it asked for the rest: two or three dependent round trips in phase 0).
+template <typename T> __device__ __forceinline__ T ld_rec48(const FCP_CONST T *p) {
+  static_assert(sizeof(T) == 48, "column records are 48 bytes");
+  typedef uint32_t __attribute__((ext_vector_type(4))) U4;
+  const FCP_CONST U4 *g = reinterpret_cast<const FCP_CONST U4 *>(p);
+  U4 w[3] = {g[0], g[1], g[2]};
+  T r;
+  __builtin_memcpy(&r, w, sizeof(T));
+  return r;
+}
+
+__device__ __forceinline__ LdsCol make_lds_col(const Hot &L, const FcpColStatic &cs, const FcpColDyn &cd) {
   LdsCol c;
   c.ids = L.blob + cd.ids_off;
   c.table = FCP_F_FORM(cs.flags) == FCP_FORM_PASSTHROUGH ? reinterpret_cast<const float *>(c.ids) : cs.table;
@@ -222,18 +300,24 @@ __device__ __forceinline__ uint32_t fetch_slot_offset(const LdsCol &c, int64_t p
 struct BlockPos {
   int rows, nslots, q0, row_blk, ncols;
   uint32_t first_col;
-  const uint32_t *map;
+  const FCP_CONST uint32_t *map;
 };
 
-template <int RB> __device__ __forceinline__ bool locate_block(const FcpLaunch &L, int bid, BlockPos &B) {
-  int g = 0;
-  for (int k = 1; k < L.n_groups; ++k)
-    if (bid >= L.groups[k].block_begin) g = k;
-  B.rows = L.groups[g].rows;
-  B.nslots = L.groups[g].nslots;
-  const int nsp8 = L.groups[g].nsp8;
-  B.map = L.slot_map + L.groups[g].slot_map_off;
-  bid -= L.groups[g].block_begin;
+template <int RB> __device__ __forceinline__ bool locate_block(const FcpLaunch &L, const Hot &H, int bid, BlockPos &B) {
+  // Every scalar a block of a one-group plan needs sits at a FIXED offset of the argument block: the
+  // loads are issued together and waited for once.  (Indexing groups[g] with a searched g made a chain
+  // of five dependent scalar loads, each a scalar-cache miss at launch start: 1.9 us before the first
+  // column record was requested, profiles/r01_s2_block_timeline_stamps.txt "desc".)
+  FcpGroupLaunch G = H.g0;
+  if (H.n_groups > 1) {
+    for (int k = 1; k < H.n_groups; ++k)
+      if (bid >= L.groups[k].block_begin) G = L.groups[k];
+  }
+  B.rows = G.rows;
+  B.nslots = G.nslots;
+  const int nsp8 = G.nsp8;
+  B.map = H.slot_map + G.slot_map_off;
+  bid -= G.block_begin;
   // XCD-aware mapping: blocks with equal (bid & 7) share an XCD under the
   // round-robin dispatch; give them the same spans (same columns / tables).
   int idx, tile; // idx: position in the list of spans this launch covers
@@ -245,9 +329,9 @@ template <int RB> __device__ __forceinline__ bool locate_block(const FcpLaunch &
     idx = bid % (-nsp8);
     tile = bid / (-nsp8);
   }
-  if (idx >= L.groups[g].nlist) return false; // uniform: whole block leaves
-  const int lo = L.groups[g].span_list_off;
-  const int span = lo >= 0 ? (int)L.span_list[lo + idx] : idx;
+  if (idx >= G.nlist) return false; // uniform: whole block leaves
+  const int lo = G.span_list_off;
+  const int span = lo >= 0 ? (int)H.span_list[lo + idx] : idx;
   B.q0 = span * FCP_WAVE;
   B.row_blk = tile * RB;
   if (B.q0 >= B.nslots || B.row_blk >= B.rows) return false;
@@ -301,38 +385,49 @@ __device__ __forceinline__ void dense_body(const FcpLaunch &L, int bid, char *sm
 #if defined(FCP_STAMPS) // diagnostic build: where does a block spend its time (never shipped)
   const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
 #endif
-  if (!locate_block<RB>(L, bid, B)) return;
+  const Hot H = load_hot(L);
+  if (!locate_block<RB>(L, H, bid, B)) return;
   const int tid = threadIdx.x;
   const int lane = tid & (FCP_WAVE - 1);
   const int wave = tid >> 6;
   const int q = B.q0 + lane;
   const uint32_t my_col = B.map[min(q, B.nslots - 1)];
-  const int world = L.shard_world, rank = L.shard_rank;
+  const int world = H.world, rank = H.rank;
 
   // ---- phase 0 ----------------------------------------------------------------------
-  if (tid < B.ncols) s_col[tid] = make_lds_col(L, L.cols[B.first_col + tid], L.dyn[B.first_col + tid]);
+  if (tid < B.ncols) s_col[tid] = make_lds_col(H, ld_rec48(H.cols + B.first_col + tid), ld_rec48(H.dyn + B.first_col + tid));
   __syncthreads();
 #if defined(FCP_STAMPS)
   const unsigned long long t_desc = __builtin_amdgcn_s_memrealtime();
 #endif
 
   // ---- phase 1a: raw id words of this thread's (column, row) pairs ------------------------
-  // issued before the boundary staging so that the two memory round trips overlap
+  // issued before the boundary staging so that the two memory round trips overlap.  The column facts of
+  // all the thread's pairs are read from LDS in one batch (unconditional reads, one wait), then the id
+  // loads are issued back to back: interleaving "LDS read, wait, load" per pair put ~0.3 us of LDS
+  // round trips in front of the last id load.
   constexpr int PT = (FCP_WAVE * RB + FCP_BLOCK_THREADS - 1) / FCP_BLOCK_THREADS; // pairs per thread, at most
-  uint32_t raw_lo[PT], raw_hi[PT];
+  uint32_t raw_lo[PT], raw_hi[PT], pflags[PT];
+  const char *pids[PT];
   const int npairs = B.ncols * RB;
 #pragma unroll
   for (int h = 0; h < PT; ++h) {
     const int p = tid + h * FCP_BLOCK_THREADS;
+    const int j = min(p / RB, B.ncols - 1);
+    pflags[h] = s_col[j].flags;
+    pids[h] = s_col[j].ids;
+  }
+#pragma unroll
+  for (int h = 0; h < PT; ++h) {
+    const int p = tid + h * FCP_BLOCK_THREADS;
+    const int b = B.row_blk + p % RB;
+    const unsigned form = FCP_F_FORM(pflags[h]);
     raw_lo[h] = raw_hi[h] = 0;
-    if (p < npairs) {
-      const int j = p / RB, b = B.row_blk + p % RB;
-      if (b < B.rows && FCP_F_FORM(s_col[j].flags) != FCP_FORM_PASSTHROUGH) {
-        const bool is64 = FCP_F_IDSRC(s_col[j].flags) == FCP_IDS_I64;
-        const char *a = s_col[j].ids + (is64 ? 8 : 4) * (int64_t)b;
-        raw_lo[h] = *as_global(reinterpret_cast<const uint32_t *>(a));
-        raw_hi[h] = *as_global(reinterpret_cast<const uint32_t *>(a + (is64 ? 4 : 0)));
-      }
+    if (p < npairs && b < B.rows && form == FCP_FORM_GATHER) {
+      const bool is64 = FCP_F_IDSRC(pflags[h]) == FCP_IDS_I64;
+      const char *a = pids[h] + (is64 ? 8 : 4) * (int64_t)b;
+      raw_lo[h] = *as_global(reinterpret_cast<const uint32_t *>(a));
+      raw_hi[h] = *as_global(reinterpret_cast<const uint32_t *>(a + (is64 ? 4 : 0)));
     }
   }
 
@@ -389,16 +484,18 @@ __device__ __forceinline__ void dense_body(const FcpLaunch &L, int bid, char *sm
     uint32_t off = kNoRow;
     if (b < B.rows) {
       const LdsCol &c = s_col[j];
-      if (FCP_F_FORM(c.flags) == FCP_FORM_PASSTHROUGH) {
+      const unsigned form = FCP_F_FORM(pflags[h]);
+      if (form == FCP_FORM_PASSTHROUGH) {
         // a tensor of the blob copied into its concat slot; table-free columns
         // belong to shard rank 0
         if (rank == 0) off = (uint32_t)b * (uint32_t)(c.dim / V);
-      } else {
+      } else if (form == FCP_FORM_GATHER) {
         bool bad;
         off = slot_offset_from_raw<V, SHARDED>(c, raw_lo[h], raw_hi[h], c.bnd_off >= 0 ? s_bnd + c.bnd_off : nullptr,
                                                rank, world, bad);
-        if (bad && L.bad_ids) atomicAdd(L.bad_ids, 1ull);
-      }
+        // a column that straddles two spans is staged by two blocks: the one holding its first slot counts
+        if (bad && H.bad_ids && c.out_off >= B.q0 * V) atomicAdd(H.bad_ids, 1ull);
+      } // FCP_FORM_EXTERNAL: nothing to fetch, nothing to write
     }
     s_off[j * IDS + r] = off;
   }
@@ -413,7 +510,8 @@ __device__ __forceinline__ void dense_body(const FcpLaunch &L, int bid, char *sm
   const int e = q * V - s_col[j].out_off;
   const float *tb = s_col[j].table + e;
   const int64_t ostride = s_col[j].out_stride;
-  float *outp = reinterpret_cast<float *>(L.arena + s_col[j].out_base) + e;
+  if (FCP_F_FORM(s_col[j].flags) == FCP_FORM_EXTERNAL) return; // somebody else's slot (ConcatOutputs host input)
+  float *outp = reinterpret_cast<float *>(H.arena + s_col[j].out_base) + e;
   const int r0 = wave * R;
   uint32_t off[R];
 #pragma unroll
@@ -574,23 +672,24 @@ __device__ __forceinline__ void ragged_body(const FcpLaunch &L, int bid, char *s
 #if defined(FCP_STAMPS)
   const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
 #endif
-  if (!locate_block<RB>(L, bid, B)) return;
+  const Hot H = load_hot(L);
+  if (!locate_block<RB>(L, H, bid, B)) return;
   const int tid = threadIdx.x;
   const int lane = tid & (FCP_WAVE - 1);
   const int wave = tid >> 6;
   const int q = B.q0 + lane;
   const uint32_t my_col = B.map[min(q, B.nslots - 1)];
-  const int world = L.shard_world, rank = L.shard_rank;
+  const int world = H.world, rank = H.rank;
 
   // ---- phase 0 ----------------------------------------------------------------------
-  if (tid < B.ncols) s_col[tid] = make_lds_col(L, L.cols[B.first_col + tid], L.dyn[B.first_col + tid]);
+  if (tid < B.ncols) s_col[tid] = make_lds_col(H, ld_rec48(H.cols + B.first_col + tid), ld_rec48(H.dyn + B.first_col + tid));
   __syncthreads();
 #if defined(FCP_STAMPS)
   const unsigned long long t_desc = __builtin_amdgcn_s_memrealtime();
 #endif
 
   // ---- phase 1a': segment-id columns without a pre-pass: RB+1 row offsets per column ---
-  if (L.seg_search) {
+  if (H.seg_search) {
     for (int u = tid; u < B.ncols * (RB + 1); u += FCP_BLOCK_THREADS) {
       const LdsCol &c = s_col[u / (RB + 1)];
       const unsigned sk = FCP_F_SEGKIND(c.flags), f = FCP_F_FORM(c.flags);
@@ -619,7 +718,7 @@ __device__ __forceinline__ void ragged_body(const FcpLaunch &L, int bid, char *s
       } else if (form == FCP_FORM_SEGMENT_REDUCE || form == FCP_FORM_GATHER_SCATTER) {
         const int nnz = s_col[pj].nnz;
         int o0, o1;
-        if (L.seg_search && FCP_F_SEGKIND(s_col[pj].flags) != FCP_SEG_CSR_I32) {
+        if (H.seg_search && FCP_F_SEGKIND(s_col[pj].flags) != FCP_SEG_CSR_I32) {
           o0 = S.bound[pj * (RB + 1) + pr];
           o1 = S.bound[pj * (RB + 1) + pr + 1];
         } else {
@@ -670,7 +769,8 @@ __device__ __forceinline__ void ragged_body(const FcpLaunch &L, int bid, char *s
     if (px >= 0 && px <= k && k < px + s_cnt[p]) { // stale owner entries (unstaged bags) fail this test
       bool bad;
       s_ids[k] = fetch_slot_offset<V, SHARDED>(s_col[p / RB], s_lo[p] + (k - px), nullptr, rank, world, bad);
-      if (bad && L.bad_ids) atomicAdd(L.bad_ids, 1ull);
+      // a column that straddles two spans is staged by two blocks: the one holding its first slot counts
+      if (bad && H.bad_ids && s_col[p / RB].out_off >= B.q0 * V) atomicAdd(H.bad_ids, 1ull);
     }
   }
   __syncthreads();
@@ -690,6 +790,7 @@ __device__ __forceinline__ void ragged_body(const FcpLaunch &L, int bid, char *s
   const int p = j * RB + wave;
   const int plo = s_lo[p], pcnt = s_cnt[p], poff = s_offx[p];
   VF<V> acc = vzero<V>();
+  if (form == FCP_FORM_EXTERNAL) return; // somebody else's slot (ConcatOutputs host input): never written here
 
   if (form == FCP_FORM_PASSTHROUGH) {
     if (rank == 0) acc = ld_blob_f32<V>(C.ids + 4 * ((int64_t)b * dim + e)); // table-free: shard rank 0
@@ -707,7 +808,7 @@ __device__ __forceinline__ void ragged_body(const FcpLaunch &L, int bid, char *s
     for (int i = 0; i < pcnt; ++i) {
       bool bad;
       const uint32_t off = fetch_slot_offset<V, SHARDED>(C, plo + i, nullptr, rank, world, bad);
-      if (bad && e == 0 && L.bad_ids) atomicAdd(L.bad_ids, 1ull);
+      if (bad && e == 0 && H.bad_ids) atomicAdd(H.bad_ids, 1ull);
       if (off != kNoRow) {
         const VF<V> w = ld_slot<V>(tb, off);
         if (form == FCP_FORM_SEGMENT_REDUCE) {
@@ -765,7 +866,7 @@ __device__ __forceinline__ void ragged_body(const FcpLaunch &L, int bid, char *s
 #pragma unroll
     for (int t = 0; t < V; ++t) acc.v[t] = acc.v[t] / fc;
   }
-  st_out<V>(reinterpret_cast<float *>(L.arena + C.out_base) + e + (int64_t)b * C.out_stride, acc);
+  st_out<V>(reinterpret_cast<float *>(H.arena + C.out_base) + e + (int64_t)b * C.out_stride, acc);
 #if defined(FCP_STAMPS)
   if (L.stamps && tid == 0) { // wave 0 = first row of the block
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -900,13 +1001,15 @@ __global__ void __launch_bounds__(FCP_BLOCK_THREADS)
     fcp_shard_finalize_kernel(const FcpLaunch L, int g, const float *__restrict__ partials, int world,
                               int64_t row_begin, int64_t row_count, float *__restrict__ out) {
   const int nslots = L.groups[g].nslots;
-  const int q = blockIdx.x * FCP_BLOCK_THREADS + threadIdx.x;
-  const int64_t bl = blockIdx.y;
+  const int nxb = (nslots + FCP_BLOCK_THREADS - 1) / FCP_BLOCK_THREADS; // blocks per output row (1-D grid: any row count)
+  const int q = (int)(blockIdx.x % nxb) * FCP_BLOCK_THREADS + threadIdx.x;
+  const int64_t bl = blockIdx.x / nxb;
   if (q >= nslots || bl >= row_count) return;
   const int64_t W = (int64_t)nslots * V;
   const uint32_t c = L.slot_map[L.groups[g].slot_map_off + q];
   const FcpColStatic cs = L.cols[c];
   const FcpColDyn cd = L.dyn[c];
+  if (FCP_F_FORM(cs.flags) == FCP_FORM_EXTERNAL) return; // the hole stays for fcp_concat_outputs_host
   VF<V> acc = vzero<V>();
   for (int w = 0; w < world; ++w) {
     const VF<V> x = *reinterpret_cast<const VF<V> *>(partials + ((int64_t)w * row_count + bl) * W + (int64_t)q * V);
@@ -1049,7 +1152,7 @@ int fcp_launch_segment_offsets(const FcpSegLaunch &L, int n_seg_cols, int max_nn
   return (int)hipGetLastError();
 }
 
-int fcp_launch_concat_outputs(const void *const *inputs, const int32_t *dims, int32_t n,
+int fcp_launch_concat_outputs(const void *const *inputs, const int32_t *dims, const int32_t *col_offsets, int32_t n,
                               int64_t prefix, int32_t width, int32_t first_off, void *out,
                               ihipStream_t *s) {
   int32_t off = first_off;
@@ -1060,7 +1163,7 @@ int fcp_launch_concat_outputs(const void *const *inputs, const int32_t *dims, in
     for (int32_t k = 0; k < m; ++k) {
       A.in[k] = static_cast<const float *>(inputs[begin + k]);
       A.dim[k] = dims[begin + k];
-      A.off[k] = off;
+      A.off[k] = col_offsets ? col_offsets[begin + k] : off;
       off += dims[begin + k];
       if (dims[begin + k] > max_dim) max_dim = dims[begin + k];
     }
@@ -1083,7 +1186,9 @@ int fcp_launch_shard_finalize(const FcpLaunch &L, int group, const float *partia
                               ihipStream_t *s) {
   if (row_count <= 0) return 0;
   const int nslots = L.groups[group].nslots;
-  dim3 grid((nslots + FCP_BLOCK_THREADS - 1) / FCP_BLOCK_THREADS, (unsigned)row_count);
+  const int64_t nblocks = (int64_t)((nslots + FCP_BLOCK_THREADS - 1) / FCP_BLOCK_THREADS) * row_count;
+  if (nblocks > 0x7fffffff) return (int)hipErrorInvalidValue;
+  dim3 grid((unsigned)nblocks);
   if (vec == 4) {
     hipLaunchKernelGGL((fcp_shard_finalize_kernel<4>), grid, dim3(FCP_BLOCK_THREADS), 0, s, L, group,
                        partials, world, row_begin, row_count, out);

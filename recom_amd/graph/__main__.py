@@ -17,10 +17,13 @@ def main(argv=None) -> int:
     ap.add_argument("--plan", required=True, help="column-plan file to write")
     ap.add_argument("--out", help="rewritten GraphDef to write (.pb or .pbtxt)")
     ap.add_argument("--no-prune", action="store_true", help="keep the replaced subgraphs in the output graph")
+    ap.add_argument("--host-concat", choices=["passthrough", "external"], default="passthrough",
+                    help="non-lookup concat inputs: through ConcatInputs as passthrough columns (default), or as "
+                         "Addons>ConcatOutputs host inputs into reserved slots — the reference's own wiring")
     args = ap.parse_args(argv)
     gd = load_graphdef(args.graph)
     try:
-        built = build_plan(gd)
+        built = build_plan(gd, args.host_concat)
     except Unsupported as why:
         print(f"nothing to fuse: {why}", file=sys.stderr)
         return 1

@@ -30,9 +30,13 @@ What follows the reference, and where:
 * the three ops that replace the subgraphs are wired as ``Rewrite`` ``:2496-2656``
   does (:mod:`recom_amd.graph.rewrite`).
 
-Differences by design: a concat input that is not a lookup (the
-reference's ``host_inputs`` of ConcatOutputs) becomes a ``FORM_PASSTHROUGH`` column
-fed through ConcatInputs, so the concat matrix is written once by the fused kernel;
+A concat input that is not a lookup (the reference's ``host_inputs`` of ConcatOutputs,
+``cuda_emitter.cc:2594-2611``) is handled in one of two ways (``host_concat``):
+``"external"`` keeps the reference's wiring — the plan reserves a ``FORM_EXTERNAL`` slot
+and the rewritten graph feeds the tensor to ``Addons>ConcatOutputs`` as a host input,
+exactly what the reference's own ``Rewrite`` emits; ``"passthrough"`` (default, one H2D
+copy fewer) routes it through ConcatInputs as a ``FORM_PASSTHROUGH`` column so that the
+fused kernel writes the whole concat matrix.  Other differences by design:
 row counts that the reference derives with SymEngine are *symbols* evaluated by
 ordinary TF ops in the rewritten graph (``symbols`` input of
 ``FeatureColumnProcessWithSymbols``, ``cuda_emitter.cc:2446-2458``); there is no
@@ -45,10 +49,10 @@ from typing import Dict, List, Optional, Tuple
 
 import numpy as np
 
-from ..plan import (COMBINER_MEAN, COMBINER_NONE, COMBINER_SUM, FORM_BATCH_COL_REDUCTION, FORM_GATHER,
+from ..plan import (COMBINER_MEAN, COMBINER_NONE, COMBINER_SUM, FORM_BATCH_COL_REDUCTION, FORM_EXTERNAL, FORM_GATHER,
                     FORM_GATHER_SCATTER, FORM_PASSTHROUGH, FORM_SEGMENT_REDUCE, IDS_F32_BUCKETIZE, IDS_I32, IDS_I64,
-                    ROWS_FROM_IDS, ROWS_FROM_INPUT_DIM0, ROWS_FROM_SYMBOL, SEG_IDS_I32, SEG_IDS_I64, SEG_NONE,
-                    ColumnSpec, PlanSpec)
+                    ROWS_FROM_GROUP, ROWS_FROM_IDS, ROWS_FROM_INPUT_DIM0, ROWS_FROM_SYMBOL, SEG_IDS_I32, SEG_IDS_I64,
+                    SEG_NONE, ColumnSpec, PlanSpec)
 from . import tf_proto as P
 from .view import GraphView, tensor_name
 
@@ -104,7 +108,8 @@ class BuiltPlan:
     skipped: List[Tuple[str, str]]                        # (node, reason) — left to TensorFlow
 
     def describe(self) -> str:
-        names = {1: "gather", 2: "segment-reduce", 3: "gather-scatter", 4: "passthrough", 5: "batch-col-reduction"}
+        names = {1: "gather", 2: "segment-reduce", 3: "gather-scatter", 4: "passthrough", 5: "batch-col-reduction",
+                 6: "external (ConcatOutputs host input)"}
         lines = [f"{len(self.groups)} concat group(s), {self.spec.n_columns} column(s), "
                  f"{len(self.host_inputs)} host input(s), {len(self.device_inputs)} table(s), "
                  f"{len(self.symbols)} symbol(s)"]
@@ -121,7 +126,10 @@ class BuiltPlan:
 
 
 class PlanBuilder:
-    def __init__(self, graph_def) -> None:
+    def __init__(self, graph_def, host_concat: str = "passthrough") -> None:
+        if host_concat not in ("passthrough", "external"):
+            raise ValueError("host_concat must be 'passthrough' or 'external'")
+        self.host_concat = host_concat
         self.g = GraphView(graph_def)
         self.tables = self._find_tables()
         self._host: Dict[str, int] = {}
@@ -338,6 +346,17 @@ class PlanBuilder:
         return ColumnSpec(FORM_PASSTHROUGH, int(shape[1]), 0, COMBINER_NONE, IDS_I32, -1, i, -1, SEG_NONE, 1,
                           ROWS_FROM_INPUT_DIM0, i, None, group, slot)
 
+    def _external(self, tensor: str, group: int, slot: int) -> ColumnSpec:
+        """The reference's wiring of a non-FC concat input: it stays a TensorFlow tensor and reaches
+        ``Addons>ConcatOutputs`` as a host input; the plan only reserves its concat slot."""
+        name, port = tensor.partition(":")[0], int(tensor.partition(":")[2] or 0)
+        node = self.g.nodes[name]
+        shape = self.g.static_shape(node, port)
+        if self.g.out_dtype(node, port) != P.DT_FLOAT or shape is None or len(shape) != 2 or shape[1] is None:
+            raise Unsupported(f"{tensor}: not a float32 [rows, dim] tensor with static dim")
+        return ColumnSpec(FORM_EXTERNAL, int(shape[1]), 0, COMBINER_NONE, IDS_I32, -1, -1, -1, SEG_NONE, 1,
+                          ROWS_FROM_GROUP, 0, None, group, slot)
+
     # ---- the walk ------------------------------------------------------------------------
     def build(self) -> BuiltPlan:
         g = self.g
@@ -371,7 +390,7 @@ class PlanBuilder:
                         lookups += 1
                         value = tensor_name(node.name, port)
                     except Unsupported as why:
-                        col = self._passthrough(ins[i], group, i)
+                        col = (self._external if self.host_concat == "external" else self._passthrough)(ins[i], group, i)
                         value = ins[i]
                         if node.name in self.tables or any(t in self.tables for t in self._upstream_tables(node)):
                             skipped.append((node.name, str(why)))
@@ -411,5 +430,5 @@ class PlanBuilder:
         return found
 
 
-def build_plan(graph_def) -> BuiltPlan:
-    return PlanBuilder(graph_def).build()
+def build_plan(graph_def, host_concat: str = "passthrough") -> BuiltPlan:
+    return PlanBuilder(graph_def, host_concat).build()

@@ -9,12 +9,14 @@ Node for node what ``CudaEmitter::Rewrite`` emits (``cuda_emitter.cc:2496-2656``
   symbols), attrs ``input_types`` / ``input_ranks`` / ``output_types`` /
   ``output_ranks`` / ``dlpath`` (``:2501-2512, 2526-2539``) — ``dlpath`` names the plan
   file (``recom_amd.plan_io``) instead of a JIT ``.so``;
-* one ``Addons>ConcatOutputsNoHost`` per concat group that takes over the ConcatV2's
+* one ``Addons>ConcatOutputs[NoHost]`` per concat group that takes over the ConcatV2's
   name, the original being renamed ``<name>_removed`` (``:2645-2646``), with attrs ``T``,
   ``BLOCK_THREADS``, ``prefix_begin`` / ``prefix_end``, ``output_dir``,
-  ``device_concat_indices`` / ``device_input_indices``, ``N`` = 0, ``host_concat_indices``
-  = [], ``embedd_dims``, ``buffer_types`` and the lifetime-extending ``tensor_buffers``
-  inputs blob, tables, arena (``:2547-2643``).
+  ``device_concat_indices`` / ``device_input_indices``, ``N`` / ``host_concat_indices`` /
+  the ``host_inputs`` themselves for the plan's ``FORM_EXTERNAL`` slots (``:2594-2611``;
+  ``NoHost`` when there are none), ``embedd_dims`` over ALL concat positions,
+  ``buffer_types`` and the lifetime-extending ``tensor_buffers`` inputs blob, tables,
+  arena (``:2547-2643``).
 
 Symbols (row counts the reference derives with SymEngine and ships through a
 ``ShapeConstruct`` node, ``:2446-2458``) are computed by plain TF ops here:
@@ -67,7 +69,8 @@ def rewrite_graph(graph_def, built: BuiltPlan, plan_path: str, prune: bool = Tru
         fuse.input.append(tensor)
         fuse.attr["input_types"].list.type.append(dtype)
         fuse.attr["input_ranks"].list.i.append(rank)
-    for _ in built.spec.columns:                       # every column output is [prefix, dim]
+    out_index = {col: i for i, col in enumerate(built.spec.output_columns())}
+    for _ in out_index:                                # every column output is [prefix, dim]
         fuse.attr["output_types"].list.type.append(P.DT_FLOAT)
         fuse.attr["output_ranks"].list.i.append(2)
 
@@ -105,21 +108,26 @@ def rewrite_graph(graph_def, built: BuiltPlan, plan_path: str, prune: bool = Tru
     nodes = {n.name: n for n in gd.node}
     for gi in built.groups:
         orig = nodes[gi.concat_node]
-        new = gd.node.add(op="Addons>ConcatOutputsNoHost")
+        host_pos = [pos for pos, col in enumerate(gi.columns) if col not in out_index]
+        new = gd.node.add(op="Addons>ConcatOutputs" if host_pos else "Addons>ConcatOutputsNoHost")
         a = new.attr
         a["T"].type = gi.dtype
         a["BLOCK_THREADS"].i = BLOCK_THREADS
-        first = gi.columns[0]
+        first = out_index[next(col for col in gi.columns if col in out_index)]
         a["prefix_begin"].i = 2 * first                 # index into output_shapes (rank 2 per output)
         a["prefix_end"].i = 2 * first + 1
         a["output_dir"].s = b""
-        a["N"].i = 0
+        a["N"].i = len(host_pos)
         a["host_concat_indices"].list.SetInParent()
-        for pos, col in enumerate(gi.columns):
-            a["device_concat_indices"].list.i.append(pos)
-            a["device_input_indices"].list.i.append(col)
-            a["embedd_dims"].list.i.append(built.spec.columns[col].dim)
         new.input.extend(["FeatureColumnProcess", "FeatureColumnProcess:1"])
+        for pos, col in enumerate(gi.columns):
+            if col in out_index:
+                a["device_concat_indices"].list.i.append(pos)
+                a["device_input_indices"].list.i.append(out_index[col])
+            else:                                       # the original concat input, untouched (:2597-2602)
+                a["host_concat_indices"].list.i.append(pos)
+                new.input.append(built.columns[col].concat_input)
+            a["embedd_dims"].list.i.append(built.spec.columns[col].dim)
         # tensor_buffers: keep blob, tables and arena alive until the concat output is consumed
         new.input.append("ConcatInputs")
         a["buffer_types"].list.type.append(P.DT_INT8)

@@ -92,8 +92,9 @@ EXPORTS = [
     "fcp_concat_inputs_sizes", "fcp_concat_inputs",
     "fcp_plan_create", "fcp_plan_create_from_file", "fcp_plan_counts", "fcp_plan_destroy", "fcp_plan_group_width",
     "fcp_plan_column_offset",
-    "fcp_plan_arena_bytes", "fcp_plan_read_bad_ids",
-    "fcp_process_feature_columns", "fcp_concat_outputs", "fcp_shard_finalize",
+    "fcp_plan_arena_bytes", "fcp_plan_read_bad_ids", "fcp_plan_output_columns", "fcp_plan_table_bytes",
+    "fcp_process_feature_columns", "fcp_concat_outputs", "fcp_concat_outputs_scatter", "fcp_concat_outputs_host",
+    "fcp_shard_finalize",
     "fcp_stager_create", "fcp_stager_stage", "fcp_stager_stage_narrow", "fcp_stager_destroy",
 ]
 
@@ -108,8 +109,13 @@ def _build_in_tree() -> None:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not (os.path.exists(hipcc) or shutil.which("hipcc")) or not shutil.which("make"):
         return
+    # several ranks of one node may get here at once (torch.distributed.run): one builds, the others wait
+    import fcntl
     try:
-        subprocess.check_call(["make", "-C", os.path.join(_HERE, "csrc")], stdout=subprocess.DEVNULL)
+        with open(os.path.join(_HERE, "csrc", ".build.lock"), "w") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            if not os.path.exists(LIB_PATH):
+                subprocess.check_call(["make", "-C", os.path.join(_HERE, "csrc")], stdout=subprocess.DEVNULL)
     except (subprocess.CalledProcessError, OSError):
         pass
 
@@ -153,6 +159,12 @@ def load() -> C.CDLL:
     L.fcp_process_feature_columns.argtypes = [C.c_void_p, C.POINTER(ProcessArgs), C.POINTER(ProcessResult)]
     L.fcp_concat_outputs.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_int32, C.c_int64, C.c_void_p,
                                      C.c_void_p]
+    L.fcp_plan_output_columns.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_void_p, C.c_int32]
+    L.fcp_plan_table_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.fcp_concat_outputs_scatter.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_int32, C.c_int64,
+                                             C.c_int32, C.c_void_p, C.c_void_p]
+    L.fcp_concat_outputs_host.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_int32, C.c_int64,
+                                          C.c_int32, C.c_void_p, ALLOC_FN, C.c_void_p, C.c_int32, C.c_void_p]
     L.fcp_shard_finalize.argtypes = [C.c_void_p, C.POINTER(ProcessArgs), C.c_int32, C.c_void_p, C.c_int32,
                                      C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
     L.fcp_stager_create.argtypes = [C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,

@@ -325,6 +325,126 @@ def concat_outputs(device_inputs: Sequence, stream: Optional[int] = None):
     return out
 
 
+def _temp_allocator(device):
+    """malloc_temp callback (the op's allocate_temp): torch tensors kept alive by the returned list."""
+    import torch
+    keep = []
+
+    def _alloc(_ctx, nbytes):
+        t = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        keep.append(t)
+        return t.data_ptr()
+
+    return keep, _lib.ALLOC_FN(_alloc)
+
+
+def concat_outputs_scatter(device_inputs: Sequence, col_offsets: Sequence[int], out, stream: Optional[int] = None):
+    """``out[p, col_offsets[k] : +dim_k] = in_k[p, :]`` into an existing row-major matrix ``out``
+    (``ScatterBlock<EmbedDim, Offset>``, ``concat_outputs_op_gpu.cu.cc:85-99``, run-time offsets)."""
+    import torch
+    L = _lib.load()
+    ins = [t.contiguous() for t in device_inputs]
+    if not ins:
+        return out
+    assert out.is_contiguous() and out.element_size() == 4
+    width = int(out.shape[-1])
+    prefix = int(out.numel() // max(width, 1))
+    dims = np.asarray([t.shape[-1] for t in ins], np.int32)
+    offs = np.asarray(col_offsets, np.int32)
+    ptrs = (C.c_void_p * len(ins))(*[t.data_ptr() for t in ins])
+    if stream is None:
+        stream = torch.cuda.current_stream(out.device).cuda_stream
+    _lib.check(L.fcp_concat_outputs_scatter(ptrs, dims.ctypes.data, offs.ctypes.data, len(ins), prefix, width,
+                                            out.data_ptr(), stream), "ConcatOutputs")
+    return out
+
+
+def concat_outputs_host(host_inputs: Sequence[np.ndarray], col_offsets: Sequence[int], out,
+                        stream: Optional[int] = None):
+    """The ``host_inputs`` half of ``Addons>ConcatOutputs`` (``concat_outputs_op_gpu.cu.cc:186-216``):
+    host tensors ``[prefix..., dim_k]`` -> one pinned staging buffer -> one H2D copy -> scattered into
+    columns ``[col_offsets[k], +dim_k)`` of the device matrix ``out`` (the group's matrix inside the
+    FeatureColumnProcess arena when the plan reserves ``FORM_EXTERNAL`` slots for them)."""
+    import torch
+    L = _lib.load()
+    arrs = [np.require(np.asarray(a), requirements="C") for a in host_inputs]
+    if not arrs:
+        return out
+    for a in arrs:
+        if a.dtype.itemsize != 4:
+            raise ValueError("ConcatOutputs supports 4-byte types (float, int)")
+    assert out.is_contiguous() and out.element_size() == 4
+    width = int(out.shape[-1])
+    prefix = int(out.numel() // max(width, 1))
+    for a in arrs:
+        if a.size != prefix * a.shape[-1]:
+            raise ValueError("ConcatOutputs: prefix shapes differ")
+    dims = np.asarray([a.shape[-1] for a in arrs], np.int32)
+    offs = np.asarray(col_offsets, np.int32)
+    ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+    if stream is None:
+        stream = torch.cuda.current_stream(out.device).cuda_stream
+    keep, cb = _temp_allocator(out.device)
+    _lib.check(L.fcp_concat_outputs_host(ptrs, dims.ctypes.data, offs.ctypes.data, len(arrs), prefix, width,
+                                         out.data_ptr(), cb, None, out.device.index or 0, stream), "ConcatOutputs")
+    out._fcp_keep = keep  # the staging scratch must outlive the enqueued copy + scatter
+    return out
+
+
+class ConcatOutputs:
+    """``Addons>ConcatOutputs`` / ``Addons>ConcatOutputsNoHost`` with the reference's attrs
+    (``concat_outputs_op_gpu.cu.cc:39-79, 180-235``; written by ``Rewrite``,
+    ``cuda_emitter.cc:2534-2647``) — what ``tf_shim/fcp_tf_ops.cc::ConcatOutputsOp`` does, in Python.
+
+    With ``FCP_LAYOUT_CONCAT`` the FeatureColumnProcess arena already holds the group's
+    ``[prefix, sum(embedd_dims)]`` matrix: device columns sit at their concat offsets, host columns are
+    ``FORM_EXTERNAL`` holes.  The op checks that (pointer arithmetic on ``device_input_ptrs``), copies the
+    ``host_inputs`` into the holes and returns the matrix as a view of the arena — no second pass over
+    the pooled data, no stream synchronisation."""
+
+    def __init__(self, N: int, embedd_dims: Sequence[int], device_input_indices: Sequence[int],
+                 device_concat_indices: Sequence[int], host_concat_indices: Sequence[int], prefix_begin: int,
+                 prefix_end: int) -> None:
+        if N != len(host_concat_indices):
+            raise ValueError("N != host_concat_indices.size()")
+        if len(device_input_indices) != len(device_concat_indices):
+            raise ValueError("device_input_indices.size() != device_concat_indices.size()")
+        if len(embedd_dims) != len(device_concat_indices) + len(host_concat_indices):
+            raise ValueError("embedd_dims.size() != device_concat_indices.size() + host_concat_indices.size()")
+        if not device_input_indices:
+            raise ValueError("ConcatOutputs without device inputs")
+        self.dims = [int(d) for d in embedd_dims]
+        self.scan = np.concatenate([[0], np.cumsum(self.dims)]).astype(np.int64)   # output_scans, :74-79
+        self.dev_in, self.dev_pos = list(device_input_indices), list(device_concat_indices)
+        self.host_pos = list(host_concat_indices)
+        self.prefix_begin, self.prefix_end = prefix_begin, prefix_end
+
+    def __call__(self, device_input_ptrs: np.ndarray, device_input_shapes: np.ndarray, host_inputs: Sequence[np.ndarray],
+                 arena, stream: Optional[int] = None):
+        import torch
+        prefix_shape = tuple(int(x) for x in device_input_shapes[self.prefix_begin:self.prefix_end])
+        prefix = int(np.prod(prefix_shape)) if prefix_shape else 1
+        width = int(self.scan[-1])
+        base = int(device_input_ptrs[self.dev_in[0]]) - 4 * int(self.scan[self.dev_pos[0]])
+        for i, pos in zip(self.dev_in, self.dev_pos):
+            if int(device_input_ptrs[i]) - base != 4 * int(self.scan[pos]):
+                raise ValueError("ConcatOutputs: the plan's concat layout does not match embedd_dims "
+                                 "(the column plan must reserve FORM_EXTERNAL slots for host concat inputs)")
+        begin = base - arena.data_ptr()
+        nbytes = prefix * width * 4
+        if begin < 0 or begin + nbytes > arena.numel() * arena.element_size():
+            raise ValueError("ConcatOutputs: group outside the arena")
+        out = arena.view(torch.uint8)[begin:begin + nbytes].view(torch.float32).view(prefix_shape + (width,))
+        if len(host_inputs) != len(self.host_pos):
+            raise ValueError("ConcatOutputs: wrong number of host inputs")
+        if host_inputs:
+            for a, pos in zip(host_inputs, self.host_pos):
+                if np.asarray(a).shape[-1] != self.dims[pos]:
+                    raise ValueError("ConcatOutputs: host input width != embedd_dims entry")
+            concat_outputs_host(host_inputs, [int(self.scan[p]) for p in self.host_pos], out, stream)
+        return out
+
+
 # ----------------------------------------------------------------------------
 # request staging: ConcatInputs + H2D in one step (SURVEY.md §8f-2)
 # ----------------------------------------------------------------------------

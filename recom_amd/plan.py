@@ -23,11 +23,12 @@ FORM_SEGMENT_REDUCE = 2    # SparseSegment{Sum,Mean}WithNumSegments  :402-661, :
 FORM_GATHER_SCATTER = 3    # ScatterNd(rows, GatherV2(...))    :296-345
 FORM_PASSTHROUGH = 4       # ConcatOutputs host_inputs         concat_outputs_op_gpu.cu.cc:186-216
 FORM_BATCH_COL_REDUCTION = 5  # Sum(x, axis=1)                 cuda_emitter.cc:1180-1244
+FORM_EXTERNAL = 6          # a concat slot filled by ConcatOutputs `host_inputs` (fcp_concat_outputs_host)
 
 COMBINER_NONE, COMBINER_SUM, COMBINER_MEAN = 0, 1, 2
 IDS_I32, IDS_I64, IDS_F32_BUCKETIZE = 0, 1, 2
 SEG_NONE, SEG_IDS_I32, SEG_IDS_I64, SEG_CSR_I32 = 0, 1, 2, 3
-ROWS_FROM_IDS, ROWS_FROM_SYMBOL, ROWS_FROM_INPUT_DIM0 = 0, 1, 2
+ROWS_FROM_IDS, ROWS_FROM_SYMBOL, ROWS_FROM_INPUT_DIM0, ROWS_FROM_GROUP = 0, 1, 2, 3
 LAYOUT_CONCAT, LAYOUT_PER_COLUMN = 0, 1
 FLAG_COUNT_BAD_IDS = 1
 
@@ -56,10 +57,12 @@ class ColumnSpec:
     concat_slot: int = 0
 
     def validate(self) -> None:
-        if self.form not in (1, 2, 3, 4, 5):
+        if self.form not in (1, 2, 3, 4, 5, 6):
             raise ValueError(f"bad form {self.form}")
         if self.dim <= 0:
             raise ValueError("dim must be positive")
+        if (self.form == FORM_EXTERNAL) != (self.rows_source == ROWS_FROM_GROUP):
+            raise ValueError("external slots (and only they) take their row count from their concat group")
         if self.form in (FORM_GATHER, FORM_SEGMENT_REDUCE, FORM_GATHER_SCATTER):
             if self.vocab <= 0 or self.table_input < 0 or self.ids_input < 0:
                 raise ValueError("lookup column needs vocab, table_input, ids_input")
@@ -125,6 +128,10 @@ class PlanSpec:
     @property
     def n_host_inputs(self) -> int:
         return len(self.host_input_ranks)
+
+    def output_columns(self) -> List[int]:
+        """Plan columns that are outputs of ``Addons>FeatureColumnProcess`` (all but external slots)."""
+        return [k for k, c in enumerate(self.columns) if c.form != FORM_EXTERNAL]
 
     def group_width(self, group: int) -> int:
         return sum(c.dim for c in self.columns if c.concat_group == group)
@@ -236,6 +243,8 @@ class PlanSpec:
 
         rows_b = ids_b = seg_b = bnd_b = out_b = 0
         for c in self.columns:
+            if c.form == FORM_EXTERNAL:      # written by fcp_concat_outputs_host, not by the fused kernel
+                continue
             rows = self.column_rows(c, shapes, symbols)
             out_b += rows * c.dim * 4
             if c.form == FORM_PASSTHROUGH:
@@ -259,6 +268,8 @@ class PlanSpec:
                 "out": out_b, "read": read, "total": read + out_b}
 
     def column_rows(self, c: ColumnSpec, shapes: Sequence[int], symbols: Optional[Sequence[int]]) -> int:
+        if c.rows_source == ROWS_FROM_GROUP:
+            return self.group_rows(c.concat_group, shapes, symbols)
         so = self.shape_offsets()
         if c.rows_source == ROWS_FROM_IDS:
             n = 1
@@ -274,7 +285,7 @@ class PlanSpec:
     def group_rows(self, group: int, shapes: Sequence[int], symbols: Optional[Sequence[int]] = None) -> int:
         rows = None
         for c in self.columns:
-            if c.concat_group != group:
+            if c.concat_group != group or c.rows_source == ROWS_FROM_GROUP:
                 continue
             r = self.column_rows(c, shapes, symbols)
             if rows is not None and r != rows:

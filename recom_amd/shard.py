@@ -27,6 +27,20 @@ from typing import Callable, List, Optional, Sequence, Tuple
 import numpy as np
 
 
+def _all_to_all(recv, send, out_splits, in_splits, group) -> None:
+    """``all_to_all_single`` on the process group's backend.  RCCL (``nccl``) moves device
+    tensors directly over xGMI.  Under ``gloo`` — only used to exercise the N > 1 control
+    flow where every rank shares one GPU — device tensors are staged through the host."""
+    import torch.distributed as dist
+    if send.is_cuda and dist.get_backend(group) == "gloo":
+        r = recv.cpu()
+        dist.all_to_all_single(r, send.cpu(), output_split_sizes=out_splits, input_split_sizes=in_splits,
+                               group=group)
+        recv.copy_(r)
+        return
+    dist.all_to_all_single(recv, send, output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
+
+
 def batch_slices(rows: int, world: int) -> List[Tuple[int, int]]:
     """Contiguous split of the batch: (begin, count) per rank; the first
     ``rows % world`` ranks get one extra row."""
@@ -61,8 +75,7 @@ class RowShardedPath:
         if self.world == 1:
             return partial.reshape(1, rows, width), begin, count
         recv = torch.empty((self.world * count, width), dtype=partial.dtype, device=partial.device)
-        dist.all_to_all_single(recv, partial.contiguous(), output_split_sizes=[count] * self.world,
-                               input_split_sizes=[c for _, c in sl], group=self.group)
+        _all_to_all(recv, partial.contiguous(), [count] * self.world, [c for _, c in sl], self.group)
         return recv.view(self.world, count, width), begin, count
 
     def run(self, partial_fn: Callable, finalize_fn: Callable):
@@ -133,9 +146,8 @@ class ColumnShardedPath:
         if self.world == 1:
             return [block], begin, count
         recv = torch.empty(count * int(sum(widths)), dtype=block.dtype, device=block.device)
-        dist.all_to_all_single(recv, block.contiguous().view(-1),
-                               output_split_sizes=[count * int(w) for w in widths],
-                               input_split_sizes=[c * width for _, c in sl], group=self.group)
+        _all_to_all(recv, block.contiguous().view(-1), [count * int(w) for w in widths],
+                    [c * width for _, c in sl], self.group)
         parts, pos = [], 0
         for w in widths:
             parts.append(recv[pos:pos + count * int(w)].view(count, int(w)))

@@ -50,6 +50,12 @@ void *GpuStream(OpKernelContext *c) {
   return *reinterpret_cast<void **>(c->op_device_context()->stream()->implementation()->GpuStreamMemberHack());
 }
 
+// HIP ordinal of the device the kernel was placed on (DeviceBase::GpuDeviceInfo::gpu_id); 0 when TF does not say.
+template <typename Ctx> int GpuOrdinal(Ctx *c) {
+  const auto *info = c->device()->tensorflow_gpu_device_info();
+  return info ? info->gpu_id : 0;
+}
+
 } // namespace
 
 // ---- Addons>ConcatInputs (CPU) ---------------------------------------------------------------
@@ -99,11 +105,15 @@ public:
     std::string dlpath;
     OP_REQUIRES_OK(c, c->GetAttr("dlpath", &dlpath));
     // was: dlopen(dlpath) + dlsym + CreateConstBuffers (feature_column_process_op_gpu.cu.cc:49-62)
-    OP_REQUIRES_OK(c, FcpStatus(fcp_plan_create_from_file(dlpath.c_str(), /*device=*/0, /*flags=*/0, &plan_),
+    OP_REQUIRES_OK(c, FcpStatus(fcp_plan_create_from_file(dlpath.c_str(), GpuOrdinal(c), /*flags=*/0, &plan_),
                                 "fcp_plan_create_from_file"));
-    int32_t n_columns = 0, n_tables = 0;
-    OP_REQUIRES_OK(c, FcpStatus(fcp_plan_counts(plan_, &n_columns, nullptr, nullptr, &n_tables, nullptr), "fcp_plan_counts"));
-    OP_REQUIRES(c, static_cast<size_t>(n_columns) == output_types_.size(), errors::InvalidArgument("plan columns != output_types"));
+    int32_t n_tables = 0, n_out = 0;
+    OP_REQUIRES_OK(c, FcpStatus(fcp_plan_counts(plan_, &n_columns_, nullptr, nullptr, &n_tables, nullptr), "fcp_plan_counts"));
+    // the op's outputs are the plan's columns minus the slots reserved for ConcatOutputs host inputs
+    out_cols_.resize(n_columns_);
+    OP_REQUIRES_OK(c, FcpStatus(fcp_plan_output_columns(plan_, &n_out, out_cols_.data(), n_columns_), "fcp_plan_output_columns"));
+    out_cols_.resize(n_out);
+    OP_REQUIRES(c, static_cast<size_t>(n_out) == output_types_.size(), errors::InvalidArgument("plan output columns != output_types"));
     OP_REQUIRES(c, static_cast<size_t>(n_tables) == input_types_.size(), errors::InvalidArgument("plan tables != input_types"));
   }
   ~FeatureColumnProcessOp() override { fcp_plan_destroy(plan_); } // the reference frees const_buff here
@@ -141,7 +151,8 @@ public:
       x->temps.emplace_back();
       return x->c->allocate_temp(DT_INT8, {static_cast<int64>(n)}, &x->temps.back()).ok() ? x->temps.back().data() : nullptr;
     };
-    std::vector<void *> out_ptrs(n_out);
+    std::vector<void *> out_ptrs(n_columns_);
+    std::vector<int32_t> out_shapes(2 * n_columns_);
     const int rank_sum = std::accumulate(output_ranks_.begin(), output_ranks_.end(), 0);
     Tensor *shapes_t, *ptrs_t;
     OP_REQUIRES_OK(c, c->allocate_output(1, {rank_sum}, &shapes_t));
@@ -149,25 +160,36 @@ public:
     OP_REQUIRES(c, rank_sum == 2 * n_out, errors::Unimplemented("outputs are rank-2 [prefix, dim]"));
     fcp_process_result_t r{};
     r.output_ptrs = out_ptrs.data();
-    r.output_shapes = shapes_t->flat<int32>().data();
+    r.output_shapes = out_shapes.data();
     OP_REQUIRES_OK(c, FcpStatus(fcp_process_feature_columns(plan_, &a, &r), "FeatureColumnProcess"));
+    auto shapes = shapes_t->flat<int32>();
+    for (int i = 0; i < n_out; ++i) {
+      shapes(2 * i) = out_shapes[2 * out_cols_[i]];
+      shapes(2 * i + 1) = out_shapes[2 * out_cols_[i] + 1];
+    }
     // output 0: in this shim `output_ptrs` is a HOST tensor (kernel registration below; the op
     // signature is unchanged), so publishing the pointers is a plain store — the reference's H2D
     // copy + cudaStreamSynchronize (feature_column_process_op_gpu.cu.cc:119-123) are not needed.
     // ConcatOutputs only uses them to find its group's matrix inside the arena.
     auto ptrs = ptrs_t->flat<int64>();
-    for (int i = 0; i < n_out; ++i) ptrs(i) = reinterpret_cast<int64>(out_ptrs[i]);
+    for (int i = 0; i < n_out; ++i) ptrs(i) = reinterpret_cast<int64>(out_ptrs[out_cols_[i]]);
   }
 
 private:
   std::vector<DataType> input_types_, output_types_;
   std::vector<int> input_ranks_, output_ranks_;
+  std::vector<int32_t> out_cols_; // plan column of every op output
+  int32_t n_columns_ = 0;
   fcp_plan_t *plan_ = nullptr;
 };
 
 // ---- Addons>ConcatOutputs[NoHost] (GPU) ----------------------------------------------------------
-// With FCP_LAYOUT_CONCAT the arena already IS the concatenated matrix: the op forwards the
-// `buffer` input (tensor_buffers[...]) as its output, bit-cast to T with shape [prefix..., sum(dim)].
+// With FCP_LAYOUT_CONCAT the arena already IS the concatenated matrix: device columns sit at their concat
+// offsets and the plan reserves FCP_FORM_EXTERNAL slots for the op's `host_inputs` (the non-FC inputs of the
+// original ConcatV2, cuda_emitter.cc:2594-2611).  The op checks that layout against its own attrs, copies the
+// host inputs into their slots (fcp_concat_outputs_host: pinned staging, one H2D copy, one scatter — was
+// concat_outputs_op_gpu.cu.cc:186-216 + ConcatOutputsKnl over ALL columns + cudaStreamSynchronize) and
+// forwards the arena slice as its output, bit-cast to T with shape [prefix..., sum(embedd_dims)].
 template <typename T> class ConcatOutputsOp : public OpKernel {
 public:
   explicit ConcatOutputsOp(OpKernelConstruction *c) : OpKernel(c) {
@@ -175,32 +197,68 @@ public:
     OP_REQUIRES_OK(c, c->GetAttr("embedd_dims", &embedd_dims_));
     OP_REQUIRES_OK(c, c->GetAttr("prefix_begin", &prefix_begin_));
     OP_REQUIRES_OK(c, c->GetAttr("prefix_end", &prefix_end_));
-    OP_REQUIRES(c, n_host_ == 0, errors::Unimplemented("route host concat inputs through ConcatInputs as PASSTHROUGH columns"));
-    width_ = std::accumulate(embedd_dims_.begin(), embedd_dims_.end(), 0);
-    std::vector<int> input_idx, concat_idx;
-    OP_REQUIRES_OK(c, c->GetAttr("device_input_indices", &input_idx));
-    OP_REQUIRES_OK(c, c->GetAttr("device_concat_indices", &concat_idx));
-    OP_REQUIRES(c, !input_idx.empty() && input_idx.size() == concat_idx.size(), errors::InvalidArgument("device indices"));
-    first_input_ = input_idx[std::min_element(concat_idx.begin(), concat_idx.end()) - concat_idx.begin()];
+    OP_REQUIRES_OK(c, c->GetAttr("device_input_indices", &device_input_indices_));
+    OP_REQUIRES_OK(c, c->GetAttr("device_concat_indices", &device_concat_indices_));
+    OP_REQUIRES_OK(c, c->GetAttr("host_concat_indices", &host_concat_indices_));
+    // the reference's own attr checks (concat_outputs_op_gpu.cu.cc:51-62)
+    OP_REQUIRES(c, static_cast<size_t>(n_host_) == host_concat_indices_.size(), errors::InvalidArgument("N != host_concat_indices.size()"));
+    OP_REQUIRES(c, device_input_indices_.size() == device_concat_indices_.size(),
+                errors::InvalidArgument("device_input_indices.size() != device_concat_indices.size()"));
+    OP_REQUIRES(c, embedd_dims_.size() == device_concat_indices_.size() + host_concat_indices_.size(),
+                errors::InvalidArgument("embedd_dims.size() != device_concat_indices.size() + host_concat_indices.size()"));
+    OP_REQUIRES(c, !device_input_indices_.empty(), errors::InvalidArgument("ConcatOutputs without device inputs"));
+    scan_.assign(embedd_dims_.size() + 1, 0); // output_scans (:74-79)
+    for (size_t i = 0; i < embedd_dims_.size(); ++i) scan_[i + 1] = scan_[i] + embedd_dims_[i];
+    width_ = scan_.back();
+    device_ = GpuOrdinal(c);
   }
   void Compute(OpKernelContext *c) override {
     const int32 *shapes = c->input(1).flat<int32>().data();
     TensorShape out_shape;
-    for (int i = prefix_begin_; i < prefix_end_; ++i) out_shape.AddDim(shapes[i]);
+    int64 prefix = 1;
+    for (int i = prefix_begin_; i < prefix_end_; ++i) {
+      out_shape.AddDim(shapes[i]);
+      prefix *= shapes[i];
+    }
     out_shape.AddDim(width_);
     const Tensor &arena = c->input(c->num_inputs() - 1); // FeatureColumnProcess:2 is wired last (cuda_emitter.cc:2632-2643)
-    // the group's matrix starts where the column at concat position 0 starts (host `output_ptrs`)
-    const int64 base = c->input(0).flat<int64>()(first_input_);
+    // every device column must already sit at its concat offset inside ONE matrix of the arena (host `output_ptrs`)
+    const auto ptrs = c->input(0).flat<int64>();
+    const int64 base = ptrs(device_input_indices_[0]) - static_cast<int64>(sizeof(T)) * scan_[device_concat_indices_[0]];
+    for (size_t i = 0; i < device_input_indices_.size(); ++i)
+      OP_REQUIRES(c, ptrs(device_input_indices_[i]) - base == static_cast<int64>(sizeof(T)) * scan_[device_concat_indices_[i]],
+                  errors::InvalidArgument("the column plan's concat layout does not match embedd_dims (host concat inputs need "
+                                          "FCP_FORM_EXTERNAL slots: build the plan with --host-concat external)"));
     const int64 begin = base - reinterpret_cast<int64>(arena.data());
     const int64 bytes = out_shape.num_elements() * static_cast<int64>(sizeof(T));
     OP_REQUIRES(c, begin >= 0 && begin + bytes <= arena.NumElements(), errors::Internal("group outside the arena"));
     Tensor out;
     OP_REQUIRES_OK(c, out.BitcastFrom(arena.Slice(begin, begin + bytes), DataTypeToEnum<T>::value, out_shape));
+    if (n_host_ > 0) {
+      std::vector<const void *> host(n_host_);
+      std::vector<int32_t> dims(n_host_), offs(n_host_);
+      for (int i = 0; i < n_host_; ++i) {
+        const Tensor &t = c->input(i + 2); // HostMemory("host_inputs")
+        dims[i] = embedd_dims_[host_concat_indices_[i]];
+        offs[i] = scan_[host_concat_indices_[i]];
+        OP_REQUIRES(c, t.NumElements() == prefix * dims[i], errors::InvalidArgument("host concat input has the wrong size"));
+        host[i] = t.data();
+      }
+      struct Ctx { OpKernelContext *c; std::vector<Tensor> temps; } ctx{c, {}};
+      auto malloc_temp = [](void *p, size_t n) -> void * { // allocate_temp, as the reference (:189-193)
+        auto *x = static_cast<Ctx *>(p);
+        x->temps.emplace_back();
+        return x->c->allocate_temp(DT_INT8, {static_cast<int64>(n)}, &x->temps.back()).ok() ? x->temps.back().data() : nullptr;
+      };
+      OP_REQUIRES_OK(c, FcpStatus(fcp_concat_outputs_host(host.data(), dims.data(), offs.data(), n_host_, prefix, width_, out.data(),
+                                                          malloc_temp, &ctx, device_, GpuStream(c)),
+                                  "ConcatOutputs"));
+    }
     c->set_output(0, out);
   }
 private:
-  int n_host_, prefix_begin_, prefix_end_, width_, first_input_ = 0;
-  std::vector<int> embedd_dims_;
+  int n_host_, prefix_begin_, prefix_end_, width_ = 0, device_ = 0;
+  std::vector<int> embedd_dims_, device_input_indices_, device_concat_indices_, host_concat_indices_, scan_;
 };
 
 // ---- registrations: identical to the reference ---------------------------------------------------

@@ -43,8 +43,8 @@ public:
 };
 
 template <typename T> struct Flat {
-  T *data();
-  T &operator()(int64);
+  T *data() const;
+  T &operator()(int64) const;
 };
 
 class Tensor {
@@ -67,11 +67,16 @@ struct Stream { StreamInterface *implementation(); };
 } // namespace stream_executor
 namespace se = stream_executor;
 struct DeviceContext { se::Stream *stream(); };
+struct DeviceBase {
+  struct GpuDeviceInfo { int gpu_id; };
+  const GpuDeviceInfo *tensorflow_gpu_device_info() const;
+};
 
 class OpKernelConstruction {
 public:
   template <typename T> Status GetAttr(const char *, T *);
   void CtxFailure(const Status &);
+  DeviceBase *device() const;
 };
 class OpKernelContext {
 public:
@@ -81,6 +86,7 @@ public:
   Status allocate_temp(DataType, const TensorShape &, Tensor *);
   void set_output(int, const Tensor &);
   DeviceContext *op_device_context();
+  DeviceBase *device() const;
   void CtxFailure(const Status &);
 };
 class OpKernel {

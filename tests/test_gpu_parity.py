@@ -329,18 +329,19 @@ def test_column_sharded_blocks_concat(torch_cuda, oracle):
         assert np.array_equal(got.cpu().numpy(), ref[begin:begin + count])
 
 
-def _graph_through_hip(torch, gd, feeds, variables, fetches, tmp_path):
+def _graph_through_hip(torch, gd, feeds, variables, fetches, tmp_path, host_concat="passthrough"):
     """original graph in NumPy vs rewritten graph with the HIP path behind the Addons> ops"""
     from tf_graph_eval import GraphEvaluator
     from recom_amd.graph import build_plan, parse_graphdef, rewrite_graph
-    from recom_amd.ops import FeatureColumnProcess, concat_inputs
+    from recom_amd.ops import ConcatOutputs, FeatureColumnProcess, concat_inputs
     from recom_amd.plan_io import load_plan, save_plan
     expected = GraphEvaluator(gd, variables).run(fetches, feeds)
-    built = build_plan(gd)
+    built = build_plan(gd, host_concat)
     path = str(tmp_path / "model.fcp")
     save_plan(built.spec, path)
     out_gd = parse_graphdef(rewrite_graph(gd, built, path).SerializeToString())
     ops = {}
+    out_cols = built.spec.output_columns()
 
     def process(node, x):
         if node.name not in ops:                # what the shim does with the `dlpath` attr
@@ -352,40 +353,129 @@ def _graph_through_hip(torch, gd, feeds, variables, fetches, tmp_path):
         assert symbols is None or symbols.dtype == np.int32
         res = op(torch.from_numpy(x[0]).cuda(), x[1], x[2], tables, symbols)
         torch.cuda.synchronize()
-        return [res.output_ptrs, res.output_shapes, res]
+        # the op's outputs: one pointer / shape pair per OUTPUT column (external slots are not outputs)
+        assert len(out_cols) == len(node.attr["output_types"].list.type)
+        ptrs = res.output_ptrs[out_cols]
+        shapes = res.output_shapes.reshape(-1, 2)[out_cols].reshape(-1)
+        return [ptrs, shapes, res.buffer]
 
     def concat_outputs(node, x):
-        res = x[-1]
-        group = built.spec.columns[int(node.attr["device_input_indices"].list.i[0])].concat_group
-        assert int(x[1][int(node.attr["prefix_begin"].i)]) == res.groups[group].shape[0]
-        return [res.groups[group].cpu().numpy()]
+        a = node.attr
+        n = int(a["N"].i)
+        op = ConcatOutputs(n, list(a["embedd_dims"].list.i), list(a["device_input_indices"].list.i),
+                           list(a["device_concat_indices"].list.i), list(a["host_concat_indices"].list.i),
+                           int(a["prefix_begin"].i), int(a["prefix_end"].i))
+        out = op(x[0], x[1], x[2:2 + n], x[-1])          # tensor_buffers[-1] = FeatureColumnProcess:2, the arena
+        torch.cuda.synchronize()
+        return [out.cpu().numpy()]
 
     custom = {"Addons>ConcatInputs": lambda node, x: list(concat_inputs(x)),
               "Addons>FeatureColumnProcess": process, "Addons>FeatureColumnProcessWithSymbols": process,
-              "Addons>ConcatOutputsNoHost": concat_outputs}
+              "Addons>ConcatOutputsNoHost": concat_outputs, "Addons>ConcatOutputs": concat_outputs}
     got = GraphEvaluator(out_gd, variables, custom).run(fetches, feeds)
     for e, o in zip(expected, got):
         assert e.shape == o.shape and np.array_equal(e, o)
     return built
 
 
+@pytest.mark.parametrize("host_concat", ["passthrough", "external"])
 @pytest.mark.parametrize("B,seed", [(19, 0), (300, 3)])
-def test_graphdef_to_hip_path(torch_cuda, tmp_path, B, seed):
+def test_graphdef_to_hip_path(torch_cuda, tmp_path, B, seed, host_concat):
     """SURVEY §8f-1 end to end: a GraphDef in the reference's canonical rewritten form →
     plan builder → plan file → rewritten graph whose three Addons> ops run the HIP path;
     the concat outputs equal the original graph evaluated op by op in NumPy (TF-CPU
     semantics, fp32 adds in id order) bit for bit."""
     from graph_fixtures import canonical_model
     gd, feeds, variables, fetches = canonical_model(B=B, seed=seed)
-    built = _graph_through_hip(torch_cuda, gd, feeds, variables, fetches, tmp_path)
+    built = _graph_through_hip(torch_cuda, gd, feeds, variables, fetches, tmp_path, host_concat)
     assert built.spec.n_columns == 11 and built.spec.n_groups == 2
 
 
+@pytest.mark.parametrize("host_concat", ["passthrough", "external"])
 @pytest.mark.parametrize("seed", [0, 3, 7, 10])
-def test_random_graphdefs_to_hip_path(torch_cuda, tmp_path, seed):
+def test_random_graphdefs_to_hip_path(torch_cuda, tmp_path, seed, host_concat):
     from graph_fixtures import random_model
     gd, feeds, variables, fetches, _ = random_model(seed)
-    _graph_through_hip(torch_cuda, gd, feeds, variables, fetches, tmp_path)
+    _graph_through_hip(torch_cuda, gd, feeds, variables, fetches, tmp_path, host_concat)
+
+
+def test_concat_outputs_host_inputs_into_external_slots(torch_cuda, oracle):
+    """Addons>ConcatOutputs with N > 0 (concat_outputs_op_gpu.cu.cc:186-216): the plan reserves
+    FORM_EXTERNAL slots, the fused kernels (dense AND ragged spans) leave them untouched, and
+    fcp_concat_outputs_host copies the host tensors there (one pinned staging buffer, one H2D copy, one
+    scatter).  Checked against the oracle's group matrix with the host tensors at their concat offsets."""
+    import dataclasses
+    from recom_amd import synth
+    from recom_amd.ops import ConcatOutputs, FeatureColumnProcess, concat_inputs
+    from recom_amd.plan import FORM_EXTERNAL, FORM_PASSTHROUGH, ROWS_FROM_GROUP
+    torch = torch_cuda
+    for batch in (5, 67, 300):
+        m = synth.model_mixed(batch=batch, vocab=997, n_groups=1)
+        # every passthrough column becomes an external slot; two more are added at the ends of the row
+        cols = [dataclasses.replace(c, form=FORM_EXTERNAL, ids_input=-1, rows_source=ROWS_FROM_GROUP, rows_arg=0)
+                if c.form == FORM_PASSTHROUGH else c for c in m.spec.columns]
+        top = max(c.concat_slot for c in cols) + 1
+        cols = [dataclasses.replace(c, concat_slot=c.concat_slot + 1) for c in cols]
+        cols.append(dataclasses.replace(cols[0], form=FORM_EXTERNAL, dim=4, vocab=0, table_input=-1, ids_input=-1,
+                                        id_source=0, boundaries=None, rows_source=ROWS_FROM_GROUP, rows_arg=0, concat_slot=0))
+        cols.append(dataclasses.replace(cols[-1], dim=36, concat_slot=top + 1))
+        spec = dataclasses.replace(m.spec, columns=cols)
+        spec.validate()
+        assert any(c.form == FORM_EXTERNAL for c in spec.columns[:-2])
+        req = m.make_request(1)
+        tabs_np = m.numpy_tables()
+        out, packed, op = run_gpu(torch, spec, req.inputs, tabs_np, req.symbols)
+        want, _ = oracle.process_feature_columns(spec.to_dict(), *packed, tabs_np, req.symbols)
+        want = want[0].copy()
+        offs = spec.column_offsets()
+        order = sorted(range(spec.n_columns), key=lambda k: spec.columns[k].concat_slot)
+        rng = np.random.default_rng(batch)
+        host, host_pos = [], []
+        for pos, k in enumerate(order):
+            c = spec.columns[k]
+            if c.form == FORM_EXTERNAL:
+                a = rng.standard_normal((batch, c.dim)).astype(np.float32)
+                host.append(a)
+                host_pos.append(pos)
+                want[:, offs[k]:offs[k] + c.dim] = a
+        out_cols = spec.output_columns()
+        dev_pos = [pos for pos, k in enumerate(order) if spec.columns[k].form != FORM_EXTERNAL]
+        dev_in = [out_cols.index(order[pos]) for pos in dev_pos]
+        co = ConcatOutputs(len(host), [spec.columns[k].dim for k in order], dev_in, dev_pos, host_pos, 0, 1)
+        ptrs = out.output_ptrs[out_cols]
+        shapes = out.output_shapes.reshape(-1, 2)[out_cols].reshape(-1)
+        got = co(ptrs, shapes, host, out.buffer)
+        torch.cuda.synchronize()
+        assert got.data_ptr() == out.groups[0].data_ptr()          # a view of the arena: no second pass
+        assert np.array_equal(got.cpu().numpy(), want)
+        # a plan whose layout does not match the op's embedd_dims is refused, not mis-copied
+        bad = ConcatOutputs(len(host), [spec.columns[k].dim for k in order][::-1], dev_in, dev_pos, host_pos, 0, 1)
+        with pytest.raises(ValueError):
+            bad(ptrs, shapes, host, out.buffer)
+    # an all-one-hot plan (dense kernel only) with external slots inside and between its spans
+    m = synth.model_s2(columns=60, vocab=1000, batch=70)
+    cols = [dataclasses.replace(c, concat_slot=2 * c.concat_slot) for c in m.spec.columns]
+    ext = dataclasses.replace(cols[1], form=FORM_EXTERNAL, vocab=0, table_input=-1, ids_input=-1, id_source=0,
+                              boundaries=None, rows_source=ROWS_FROM_GROUP, rows_arg=0)
+    for slot, dim in ((1, 8), (33, 300), (77, 4), (119, 20)):
+        cols.append(dataclasses.replace(ext, dim=dim, concat_slot=slot))
+    spec = dataclasses.replace(m.spec, columns=cols)
+    req = m.make_request(4)
+    tabs_np = m.numpy_tables()
+    out, packed, op = run_gpu(torch, spec, req.inputs, tabs_np, req.symbols)
+    want = oracle.process_feature_columns(spec.to_dict(), *packed, tabs_np, req.symbols)[0][0].copy()
+    offs = spec.column_offsets()
+    host, host_offs = [], []
+    for k, c in enumerate(spec.columns):
+        if c.form == FORM_EXTERNAL:
+            a = np.full((70, c.dim), float(k), np.float32)
+            host.append(a)
+            host_offs.append(offs[k])
+            want[:, offs[k]:offs[k] + c.dim] = a
+    from recom_amd.ops import concat_outputs_host
+    concat_outputs_host(host, host_offs, out.groups[0])
+    torch.cuda.synchronize()
+    assert np.array_equal(out.groups[0].cpu().numpy(), want)
 
 
 def test_dlrm_scaled_vs_oracle(torch_cuda, oracle):

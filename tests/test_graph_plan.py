@@ -34,21 +34,32 @@ def oracle_ops(oracle, built, variables):
         symbols = x[3 + n_tab] if node.op.endswith("WithSymbols") else None
         groups, bad = oracle.process_feature_columns(spec.to_dict(), x[0], x[1], x[2], tables, symbols)
         assert bad == 0
-        # output_shapes: [prefix, dim] per column output (feature_column_process_op_gpu.cu.cc:113-118)
-        shapes = np.asarray([v for c in spec.columns for v in (groups[c.concat_group].shape[0], c.dim)], np.int32)
-        return [np.zeros(spec.n_columns, np.int64), shapes, groups]
+        # output_shapes: [prefix, dim] per column OUTPUT (feature_column_process_op_gpu.cu.cc:113-118);
+        # external slots (ConcatOutputs host inputs) are not outputs of this op
+        outs = [spec.columns[k] for k in spec.output_columns()]
+        assert len(outs) == len(node.attr["output_types"].list.type)
+        shapes = np.asarray([v for c in outs for v in (groups[c.concat_group].shape[0], c.dim)], np.int32)
+        return [np.zeros(len(outs), np.int64), shapes, groups]
 
     def concat_outputs(node, x):
-        col = int(node.attr["device_input_indices"].list.i[0])
+        out_cols = built.spec.output_columns()
+        col = out_cols[int(node.attr["device_input_indices"].list.i[0])]
         group = built.spec.columns[col].concat_group
         out = x[-1][group]                                    # FeatureColumnProcess:2 is wired last
         shapes = x[1]
+        dims = [int(d) for d in node.attr["embedd_dims"].list.i]
         assert out.shape[0] == shapes[int(node.attr["prefix_begin"].i)]
-        assert out.shape[1] == sum(int(d) for d in node.attr["embedd_dims"].list.i)
+        assert out.shape[1] == sum(dims)
+        n = int(node.attr["N"].i)
+        assert n == len(node.attr["host_concat_indices"].list.i) and (n == 0) == node.op.endswith("NoHost")
+        scan = np.concatenate([[0], np.cumsum(dims)])
+        for a, pos in zip(x[2:2 + n], node.attr["host_concat_indices"].list.i):   # host_inputs (concat_outputs_op_gpu.cu.cc:186-216)
+            out[:, scan[pos]:scan[pos + 1]] = a
         return [out]
 
     return {"Addons>ConcatInputs": concat_inputs, "Addons>FeatureColumnProcess": process,
-            "Addons>FeatureColumnProcessWithSymbols": process, "Addons>ConcatOutputsNoHost": concat_outputs}
+            "Addons>FeatureColumnProcessWithSymbols": process, "Addons>ConcatOutputsNoHost": concat_outputs,
+            "Addons>ConcatOutputs": concat_outputs}
 
 
 def test_graphdef_roundtrip_binary_and_text():
@@ -143,13 +154,46 @@ def test_rewrite_matches_reference_wiring(tmp_path):
         rewrite_graph(out, built, "x")
 
 
+def test_rewrite_external_host_inputs_is_the_reference_wiring(tmp_path):
+    """``host_concat="external"``: what the reference's unchanged Rewrite emits for a ConcatV2 with
+    non-FC inputs (cuda_emitter.cc:2594-2611) — ``Addons>ConcatOutputs`` with N host inputs at
+    ``host_concat_indices``; the plan reserves FORM_EXTERNAL slots and FeatureColumnProcess has one
+    output per remaining column."""
+    gd, feeds, variables, _ = canonical_model()
+    built = build_plan(gd, host_concat="external")
+    spec = built.spec
+    assert [c.form for c in spec.columns] == [1, 1, 1, 2, 2, 3, 6, 5, 1, 2, 1]
+    ext = spec.columns[6]
+    assert ext.rows_source == PL.ROWS_FROM_GROUP and ext.ids_input == -1 and ext.dim == 13
+    assert "dense_features" not in [t for t, _, _ in built.host_inputs]     # no longer shipped through ConcatInputs
+    assert spec.output_columns() == [0, 1, 2, 3, 4, 5, 7, 8, 9, 10] and spec.group_width(0) == 113
+    path = str(tmp_path / "m.fcp")
+    save_plan(spec, path)
+    assert [c.form for c in load_plan(path).columns] == [c.form for c in spec.columns]
+    out = rewrite_graph(gd, built, path)
+    nodes = {n.name: n for n in out.node}
+    assert list(nodes["FeatureColumnProcess"].attr["output_ranks"].list.i) == [2] * 10
+    co = nodes["input_layer/concat"]
+    assert co.op == "Addons>ConcatOutputs" and co.attr["N"].i == 1
+    assert list(co.attr["host_concat_indices"].list.i) == [6]
+    assert list(co.attr["device_concat_indices"].list.i) == [0, 1, 2, 3, 4, 5, 7, 8]
+    assert list(co.attr["device_input_indices"].list.i) == [0, 1, 2, 3, 4, 5, 6, 7]
+    assert list(co.attr["embedd_dims"].list.i) == [c.dim for c in spec.columns[:9]]
+    assert list(co.input[:3]) == ["FeatureColumnProcess", "FeatureColumnProcess:1", "dense_features"]
+    assert co.input[3] == "ConcatInputs" and co.input[-1] == "FeatureColumnProcess:2"
+    co2 = nodes["seq_layer/concat"]
+    assert co2.op == "Addons>ConcatOutputsNoHost" and list(co2.attr["device_input_indices"].list.i) == [8, 9]
+    assert co2.attr["prefix_begin"].i == 16
+
+
+@pytest.mark.parametrize("host_concat", ["passthrough", "external"])
 @pytest.mark.parametrize("B,seed", [(19, 0), (1, 1), (64, 2)])
-def test_rewritten_graph_equals_original(oracle, tmp_path, B, seed):
+def test_rewritten_graph_equals_original(oracle, tmp_path, B, seed, host_concat):
     from tf_graph_eval import GraphEvaluator
     gd, feeds, variables, fetches = canonical_model(B=B, seed=seed)
     expected = GraphEvaluator(gd, variables).run(fetches, feeds)
     assert expected[0].shape == (B, 113) and expected[1].shape == (B + 5, 28)
-    built = build_plan(gd)
+    built = build_plan(gd, host_concat)
     path = str(tmp_path / "m.fcp")
     save_plan(built.spec, path)
     out = parse_graphdef(rewrite_graph(gd, built, path).SerializeToString())
@@ -191,16 +235,18 @@ def test_microbenchmark_graph(oracle, tmp_path):
     assert np.array_equal(expected[0], got[0])
 
 
+@pytest.mark.parametrize("host_concat", ["passthrough", "external"])
 @pytest.mark.parametrize("seed", range(12))
-def test_random_graphs(oracle, tmp_path, seed):
+def test_random_graphs(oracle, tmp_path, seed, host_concat):
     """Random rewritten graphs (kinds, dims, vocabularies, id dtypes, SparseTensor ranks, shared
     tables, 1-3 concat groups): the plan builder never mislabels a column — the rewritten graph
     reproduces the original bit for bit — and every lookup is taken by the fused path."""
     from tf_graph_eval import GraphEvaluator
     gd, feeds, variables, fetches, kinds = random_model(seed)
     expected = GraphEvaluator(gd, variables).run(fetches, feeds)
-    built = build_plan(gd)
-    want_form = {"dense64": 1, "dense32": 1, "bucket": 1, "mean": 2, "sum": 2, "scatter": 3, "pass": 4, "sum3d": 5}
+    built = build_plan(gd, host_concat)
+    want_form = {"dense64": 1, "dense32": 1, "bucket": 1, "mean": 2, "sum": 2, "scatter": 3,
+                 "pass": 6 if host_concat == "external" else 4, "sum3d": 5}
     groups_with_lookup = {c.concat_group for c in built.spec.columns if c.form in (1, 2, 3)}
     assert [c.form for c in built.spec.columns] == [want_form[k] for k in kinds] or len(groups_with_lookup) < len(fetches)
     assert not built.skipped

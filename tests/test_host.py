@@ -370,3 +370,42 @@ def test_fast_and_general_shape_evaluation_agree(monkeypatch):
             with pytest.raises(lib.FcpError) as e:
                 p.arena_bytes(bad, req.symbols)
             assert e.value.status == lib.FCP_ERR_SHAPE_MISMATCH
+
+
+def test_external_slots_host_side(monkeypatch):
+    """FCP_FORM_EXTERNAL (Addons>ConcatOutputs host inputs): reserved in the concat layout, not an output
+    of FeatureColumnProcess, rows from the group; both shape-evaluation routines agree; bad plans refused."""
+    import ctypes as C
+    import dataclasses
+    from recom_amd import lib, synth
+    from recom_amd.ops import Plan, concat_inputs
+    from recom_amd.plan import FORM_EXTERNAL, LAYOUT_PER_COLUMN, ROWS_FROM_GROUP, ROWS_FROM_IDS
+    m = synth.model_mixed(batch=21, vocab=97, n_groups=2)
+    ext = dataclasses.replace(m.spec.columns[0], form=FORM_EXTERNAL, dim=20, vocab=0, table_input=-1, ids_input=-1,
+                              id_source=0, rows_source=ROWS_FROM_GROUP, rows_arg=0, concat_group=1, concat_slot=99)
+    spec = dataclasses.replace(m.spec, columns=m.spec.columns + [ext])
+    spec.validate()
+    p = Plan(spec, host_only=True)
+    L = lib.load()
+    n = C.c_int32()
+    idx = (C.c_int32 * spec.n_columns)()
+    lib.check(L.fcp_plan_output_columns(p.handle, C.byref(n), idx, spec.n_columns), "fcp_plan_output_columns")
+    assert list(idx[:n.value]) == spec.output_columns() == list(range(spec.n_columns - 1))
+    assert p.group_width(1) == m.spec.group_width(1) + 20 and p.column_offset(spec.n_columns - 1) == m.spec.group_width(1)
+    req = m.make_request(0)
+    _, _, shapes = concat_inputs(req.inputs)
+    base = Plan(m.spec, host_only=True).arena_bytes(shapes, req.symbols)
+    monkeypatch.delenv("FCP_DYN_GENERAL", raising=False)
+    fast = p.arena_bytes(shapes, req.symbols)
+    monkeypatch.setenv("FCP_DYN_GENERAL", "1")
+    assert p.arena_bytes(shapes, req.symbols) == fast > base
+    monkeypatch.delenv("FCP_DYN_GENERAL", raising=False)
+    for bad in (dataclasses.replace(ext, rows_source=ROWS_FROM_IDS),):
+        with pytest.raises(ValueError):
+            dataclasses.replace(m.spec, columns=m.spec.columns + [bad]).validate()
+    with pytest.raises(lib.FcpError) as e:                     # the per-column layout has no concat matrix to leave a hole in
+        Plan(dataclasses.replace(spec, layout=LAYOUT_PER_COLUMN), host_only=True)
+    assert e.value.status == lib.FCP_ERR_INVALID_ARGUMENT
+    only_ext = dataclasses.replace(m.spec, columns=[dataclasses.replace(ext, concat_group=0)], n_groups=1)
+    with pytest.raises(lib.FcpError):                          # a group of external slots only has no row count
+        Plan(only_ext, host_only=True).arena_bytes(shapes, req.symbols)
