@@ -267,6 +267,29 @@ int fcp_plan_output_columns(const fcp_plan_t *plan, int32_t *n, int32_t *indices
  * (unsharded) — the inputs of the placement gate, fcp_placement_decide. */
 int fcp_plan_table_bytes(const fcp_plan_t *plan, int64_t *shard_bytes,
                          int64_t *max_table_bytes_unsharded);
+/* ---- placement gate (replaces check_table_size, cuda_emitter.cc:1080-1094) -------- */
+/* The reference keeps a column on the CPU when its table exceeds max_table_size =
+ * 256 MiB (fc_optimize_pass.cc:71, RECOM_CPU_GPU_CO_RUN).  On MI355X the question is
+ * whether the model's tables fit ONE GPU's HBM: if they do, every GPU serves requests
+ * on its own replica and nothing is exchanged; only when the aggregate exceeds one
+ * GPU are the tables sharded over the `world` GPUs of the node, by whole columns
+ * (final blocks exchanged, bit-identical results; needs every table to fit one GPU)
+ * or by rows (partial sums exchanged + fcp_shard_finalize; any table size). */
+enum { FCP_PLACE_REPLICATE = 0, FCP_PLACE_COLUMN_SHARD = 1, FCP_PLACE_ROW_SHARD = 2 };
+typedef struct fcp_placement {
+  int32_t mode;          /* FCP_PLACE_*                                        */
+  int32_t min_world;     /* fewest GPUs on which the tables fit at all          */
+  int64_t bytes_per_gpu; /* table bytes the fullest GPU holds under `mode`      */
+} fcp_placement_t;
+/* table_bytes[n_tables]: bytes of every (unsharded) table; hbm_bytes: one GPU's
+ * memory; reserve_bytes: what must stay free (arenas, request blobs, runtime);
+ * prefer_mode: FCP_PLACE_COLUMN_SHARD or FCP_PLACE_ROW_SHARD, taken when both are
+ * feasible.  FCP_ERR_UNSUPPORTED (with min_world set) when the tables do not fit
+ * `world` GPUs. */
+int fcp_placement_decide(const int64_t *table_bytes, int32_t n_tables,
+                         int64_t hbm_bytes, int64_t reserve_bytes, int32_t world,
+                         int32_t prefer_mode, fcp_placement_t *out);
+
 /* total concat width of a group (sum of dims in slot order)
  * and the element offset of a column inside its group. */
 int fcp_plan_group_width(const fcp_plan_t *plan, int32_t group, int32_t *width);

@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -404,8 +405,11 @@ int finish_geometry(const fcp_plan *p, DynMeta *m) {
     DynMeta::Geo &G2 = m->geo[kind];
     int rpw = 1;
     if (kind == 0) {
-      // 4 rows per wave (16 per block) measured best on S2 at batch 512 and 2048:
-      // ~2 rounds of blocks de-phase the read and write bursts; 8 rows lose to the tail.
+      // 4 rows per wave (16 per block) measured best on S2 at batch 512 and 2048: ~2 rounds of blocks
+      // de-phase the read and write bursts; 8 rows lose to the tail.  Choosing fewer rows per wave for
+      // narrow plans so that the grid reaches 8 blocks per CU (round 2: DLRM 896 -> 3584 blocks) made
+      // them SLOWER (DLRM 5.0 -> 7.0 us, S2 at batch 128 11.0 -> 11.9 us): a block's fixed staging chain
+      // costs more than the idle CUs, see DESIGN.md section 4.
       while (rpw < 4 && max_rows >= 32 * rpw) rpw *= 2; // >= 64 rows -> 4, 32..63 -> 2, < 32 -> 1
       static const int forced = [] { // tuning aid: FCP_ROWS_PER_WAVE=1|2|4
         const char *e = std::getenv("FCP_ROWS_PER_WAVE");
@@ -552,6 +556,42 @@ int compute_dyn(const fcp_plan *p, const int32_t *offsets, const int32_t *shapes
   return compute_dyn_slow(p, offsets, shapes, symbols, blob_bytes, dyn, m);
 }
 
+// Are the boundaries evenly spaced closely enough that floor((x - b0) * inv) + 1 names the right bucket
+// for x at every boundary and just below it (the places where rounding could push the guess over)?  Then
+// the kernels take the guess and verify it with two reads instead of a 7-step binary search.  The guess is
+// only a starting point — a failed verification falls back to the search — so this is a speed decision.
+void uniform_boundaries(const std::vector<float> &b, float *b0, float *inv, float *step_out) {
+  const int n = (int)b.size();
+  if (n < 2 || !(b[n - 1] > b[0])) return;
+  const float lo = b[0];
+  const float scale = (float)((double)(n - 1) / ((double)b[n - 1] - (double)b[0]));
+  if (!(scale > 0.0f) || !std::isfinite(scale)) return;
+  auto guess = [&](float x) {
+    float t = (x - lo) * scale;
+    t = std::fmin(std::fmax(t, -1.0f), (float)n);
+    int g = (int)std::floor(t) + 1;
+    return std::min(std::max(g, 0), n);
+  };
+  auto exact = [&](float x) { return (int)(std::upper_bound(b.begin(), b.end(), x) - b.begin()); };
+  int misses = 0;
+  for (int i = 0; i < n; ++i) {
+    if (i && !(b[i] > b[i - 1])) return; // not strictly increasing
+    const float below = std::nextafter(b[i], -INFINITY);
+    misses += guess(b[i]) != exact(b[i]);
+    misses += guess(below) != exact(below);
+  }
+  if (misses * 8 > n) return; // an occasional miss costs one fallback search; many mean the spacing is not even
+  *b0 = lo;
+  *inv = scale;
+  // Reproducible boundaries: b[i] == fma(i, step, b0) bit for bit (one correctly rounded operation on the host
+  // and on the GPU alike).  Holds for the reference's 0, 5, ..., 495 and for any integer / dyadic grid.
+  const float step = b[1] - b[0];
+  if (!(step > 0.0f) || !std::isfinite(step)) return;
+  for (int i = 0; i < n; ++i)
+    if (std::fmaf((float)i, step, lo) != b[i]) return;
+  *step_out = step;
+}
+
 void destroy_device(fcp_plan *p) {
   if (p->host_only) return;
   for (auto &s : p->slots) {
@@ -626,7 +666,11 @@ int init_device(fcp_plan *p) {
     s.flags = FCP_F_PACK(hc.d.form, hc.d.combiner, hc.d.id_source, hc.d.seg_kind);
     s.n_boundaries = (int32_t)hc.boundaries.size();
     s.seg_stride = hc.d.seg_stride < 1 ? 1 : hc.d.seg_stride;
-    s.group = hc.d.concat_group;
+    s.bnd_b0 = 0.0f;
+    s.bnd_inv = 0.0f;
+    s.bnd_step = 0.0f;
+    s.pad_[0] = s.pad_[1] = 0;
+    uniform_boundaries(hc.boundaries, &s.bnd_b0, &s.bnd_inv, &s.bnd_step);
   }
   HIP_TRY(hipMalloc(&p->d_cols, nc * sizeof(FcpColStatic)));
   HIP_TRY(hipMemcpy(p->d_cols, p->h_cols.data(), nc * sizeof(FcpColStatic), hipMemcpyHostToDevice));
@@ -674,6 +718,16 @@ int init_device(fcp_plan *p) {
     s.done = nullptr; // created per stream on first use (done_event_for)
   }
   p->bound_tables.assign(p->desc.n_device_inputs, nullptr);
+  {
+    // the gate at plan level (the reference's check_table_size, cuda_emitter.cc:1080-1094, decides per table
+    // against 256 MiB): the tables this plan reads on this device must fit the device at all
+    int64_t shard_bytes = 0;
+    (void)fcp_plan_table_bytes(p, &shard_bytes, nullptr);
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b > 0 && (uint64_t)shard_bytes > total_b)
+      return fail(FCP_ERR_UNSUPPORTED, "this plan's tables need " + std::to_string(shard_bytes) + " bytes on a device with " +
+                                           std::to_string(total_b) + ": shard them over more GPUs (fcp_placement_decide)");
+  }
   return FCP_OK;
 }
 
@@ -1158,6 +1212,48 @@ int fcp_plan_table_bytes(const fcp_plan_t *p, int64_t *shard_bytes, int64_t *max
   }
   if (shard_bytes) *shard_bytes = sum;
   if (max_table_bytes_unsharded) *max_table_bytes_unsharded = mx;
+  return FCP_OK;
+}
+
+int fcp_placement_decide(const int64_t *table_bytes, int32_t n_tables, int64_t hbm_bytes, int64_t reserve_bytes,
+                         int32_t world, int32_t prefer_mode, fcp_placement_t *out) {
+  if (!out || n_tables < 0 || (n_tables > 0 && !table_bytes) || hbm_bytes <= 0 || reserve_bytes < 0 || world < 1)
+    return fail(FCP_ERR_INVALID_ARGUMENT, "bad placement arguments");
+  if (prefer_mode != FCP_PLACE_COLUMN_SHARD && prefer_mode != FCP_PLACE_ROW_SHARD)
+    return fail(FCP_ERR_INVALID_ARGUMENT, "prefer_mode must be column or row sharding");
+  const int64_t budget = hbm_bytes - reserve_bytes;
+  if (budget <= 0) return fail(FCP_ERR_INVALID_ARGUMENT, "reserve_bytes leaves no room for tables");
+  int64_t total = 0, largest = 0;
+  for (int32_t t = 0; t < n_tables; ++t) {
+    if (table_bytes[t] < 0) return fail(FCP_ERR_INVALID_ARGUMENT, "negative table size");
+    total += table_bytes[t];
+    largest = std::max(largest, table_bytes[t]);
+  }
+  out->min_world = (int32_t)std::max<int64_t>(1, (total + budget - 1) / budget);
+  out->mode = FCP_PLACE_REPLICATE;
+  out->bytes_per_gpu = total;
+  if (total <= budget) return FCP_OK; // fits one GPU: replicas, no collective
+  // row sharding: every table contributes ceil(rows / world) rows to every GPU (at most one row's worth of
+  // rounding per table, ignored here: tables are >> one row)
+  const int64_t row_share = (total + world - 1) / world;
+  const bool row_ok = world > 1 && row_share <= budget;
+  // column sharding: whole tables per GPU — longest-processing-time packing as the feasibility test
+  int64_t col_share = 0;
+  bool col_ok = world > 1 && largest <= budget;
+  if (col_ok) {
+    std::vector<int64_t> sorted(table_bytes, table_bytes + n_tables), load(world, 0);
+    std::sort(sorted.begin(), sorted.end(), [](int64_t a, int64_t b) { return a > b; });
+    for (int64_t b : sorted) *std::min_element(load.begin(), load.end()) += b;
+    col_share = *std::max_element(load.begin(), load.end());
+    col_ok = col_share <= budget;
+  }
+  if (!row_ok && !col_ok)
+    return fail(FCP_ERR_UNSUPPORTED, "tables of " + std::to_string(total) + " bytes do not fit " + std::to_string(world) +
+                                         " GPU(s) with " + std::to_string(budget) + " bytes each: needs at least " +
+                                         std::to_string(out->min_world));
+  const bool col = col_ok && (prefer_mode == FCP_PLACE_COLUMN_SHARD || !row_ok);
+  out->mode = col ? FCP_PLACE_COLUMN_SHARD : FCP_PLACE_ROW_SHARD;
+  out->bytes_per_gpu = col ? col_share : row_share;
   return FCP_OK;
 }
 

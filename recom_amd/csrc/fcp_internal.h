@@ -28,7 +28,7 @@
 #define FCP_F_PACK(form, comb, idsrc, segkind) \
   ((uint32_t)(form) | ((uint32_t)(comb) << 4) | ((uint32_t)(idsrc) << 8) | ((uint32_t)(segkind) << 12))
 
-struct FcpColStatic {      // 48 bytes
+struct FcpColStatic {      // 64 bytes: one record per cache line
   const float *table;      // device address of the table (bound from input_ptrs)
   const float *boundaries; // device const buffer (CreateConstBuffers, :2260-2301)
   int64_t vocab;           // global vocabulary (rows of the unsharded table)
@@ -37,7 +37,13 @@ struct FcpColStatic {      // 48 bytes
   uint32_t flags;          // FCP_F_PACK(...)
   int32_t n_boundaries;
   int32_t seg_stride;
-  int32_t group;
+  // Evenly spaced boundaries (the reference's bucketized columns: 0, 5, ..., 495, microbenchmark.py:46):
+  // bucket guess = floor((x - bnd_b0) * bnd_inv) + 1, verified against the two neighbouring boundaries
+  // (exact for any array; see bucketize_fast).  bnd_inv == 0: no guess, plain binary search.
+  // bnd_step != 0: every boundary is REPRODUCIBLE as fma(i, bnd_step, bnd_b0) (checked bit for bit at plan
+  // creation), so the kernels never read the array (bucketize_arith).
+  float bnd_b0, bnd_inv, bnd_step;
+  int32_t pad_[2];
 };
 
 struct FcpColDyn {         // 48 bytes

@@ -165,10 +165,47 @@ template <typename P> __device__ __forceinline__ int bucketize(P b, int n, float
   return r + 1;
 }
 
+// The same count for (nearly) evenly spaced boundaries — the reference's bucketized columns use
+// 0, 5, ..., 495 (examples/python/microbenchmark.py:46): guess the bucket from the spacing, read the two
+// boundaries that bracket it (independent reads, one round trip) and accept the guess only if
+// b[g-1] <= value < b[g]; anything else (rounding at a boundary, NaN, uneven spacing) runs the search.
+// Exact for every input by construction; ~2 reads instead of log2(n) dependent ones.
+template <typename P> __device__ __forceinline__ int bucketize_fast(P b, int n, float b0, float inv, float value) {
+  float t = (value - b0) * inv;
+  t = fminf(fmaxf(t, -1.0f), (float)n); // NaN -> -1
+  const int g = min(max((int)floorf(t) + 1, 0), n);
+  const float below = b[max(g - 1, 0)], above = b[min(g, n - 1)];
+  const bool ok = (g == 0 || !(value < below)) && (g == n || value < above);
+  if (ok) return g;
+  return bucketize(b, n, value);
+}
+
+// Boundaries that are REPRODUCIBLE as fma(i, step, b0) (checked bit for bit when the plan is created):
+// the same guess-and-verify, and the fallback search, on computed boundaries — the array is never read.
+// (Reading it made every block of a launch hit the same few cache lines at once: 2.3 us of queueing on
+// one L2 channel at the head of an S2 launch.)
+__device__ __forceinline__ int bucketize_arith(int n, float b0, float inv, float step, float value) {
+  float t = (value - b0) * inv;
+  t = fminf(fmaxf(t, -1.0f), (float)n); // NaN -> -1
+  const int g = min(max((int)floorf(t) + 1, 0), n);
+  const float below = __builtin_fmaf((float)(g - 1), step, b0), above = __builtin_fmaf((float)g, step, b0);
+  if ((g == 0 || !(value < below)) && (g == n || value < above)) return g;
+  int l = 0, r = n - 1;
+  while (l <= r) {
+    const int mid = (l + r) >> 1;
+    if (value < __builtin_fmaf((float)mid, step, b0)) {
+      r = mid - 1;
+    } else {
+      l = mid + 1;
+    }
+  }
+  return r + 1;
+}
+
 constexpr uint32_t kNoRow = 0xFFFFFFFFu; // "this id contributes nothing"
 
 // One column of the span, staged in LDS by the block.
-struct alignas(16) LdsCol {   // 80 bytes
+struct alignas(16) LdsCol {   // 96 bytes
   const float *table;         // table base, or the passthrough payload
   const char *ids;            // id / value stream of this request
   const float *boundaries;
@@ -183,6 +220,9 @@ struct alignas(16) LdsCol {   // 80 bytes
   int32_t bnd_off;            // offset of the staged boundaries in LDS, or -1
   int32_t nnz;
   int32_t inner;
+  float bnd_b0, bnd_inv;      // evenly spaced boundaries: bucket guess (bnd_inv == 0: none)
+  float bnd_step;             // != 0: boundaries reproducible as fma(i, bnd_step, bnd_b0), never read
+  int32_t pad_;
 };
 
 // The scalars of the argument block a body uses, fetched up front in ONE batch of scalar loads and
@@ -222,13 +262,15 @@ __device__ __forceinline__ Hot load_hot(const FcpLaunch &L) {
   return h;
 }
 
-// A 48-byte record as three unconditional 16-byte loads (field-by-field access let the compiler wait
+// A column record as unconditional 16-byte loads (field-by-field access let the compiler wait
 // for `flags` before it asked for the rest: two or three dependent round trips in phase 0).
-template <typename T> __device__ __forceinline__ T ld_rec48(const FCP_CONST T *p) {
-  static_assert(sizeof(T) == 48, "column records are 48 bytes");
+template <typename T> __device__ __forceinline__ T ld_rec(const FCP_CONST T *p) {
+  static_assert(sizeof(T) % 16 == 0, "column records are whole 16-byte words");
   typedef uint32_t __attribute__((ext_vector_type(4))) U4;
   const FCP_CONST U4 *g = reinterpret_cast<const FCP_CONST U4 *>(p);
-  U4 w[3] = {g[0], g[1], g[2]};
+  U4 w[sizeof(T) / 16];
+#pragma unroll
+  for (unsigned i = 0; i < sizeof(T) / 16; ++i) w[i] = g[i];
   T r;
   __builtin_memcpy(&r, w, sizeof(T));
   return r;
@@ -254,6 +296,10 @@ __device__ __forceinline__ LdsCol make_lds_col(const Hot &L, const FcpColStatic 
   c.bnd_off = -1;
   c.nnz = cd.nnz;
   c.inner = cd.inner;
+  c.bnd_b0 = cs.bnd_b0;
+  c.bnd_inv = cs.bnd_inv;
+  c.bnd_step = cs.bnd_step;
+  c.pad_ = 0;
   return c;
 }
 
@@ -270,8 +316,15 @@ __device__ __forceinline__ uint32_t slot_offset_from_raw(const LdsCol &c, uint32
   const unsigned idsrc = FCP_F_IDSRC(c.flags);
   int64_t id;
   if (idsrc == FCP_IDS_F32_BUCKETIZE) {
-    id = lds_bnd ? bucketize(lds_bnd, c.n_boundaries, __uint_as_float(lo))
-                 : bucketize(as_global(c.boundaries), c.n_boundaries, __uint_as_float(lo));
+    const float x = __uint_as_float(lo);
+    if (c.bnd_step != 0.0f) // reproducible boundaries: no reads at all
+      id = bucketize_arith(c.n_boundaries, c.bnd_b0, c.bnd_inv, c.bnd_step, x);
+    else if (lds_bnd)       // staged in LDS by the block; evenly spaced ones start from the guess
+      id = c.bnd_inv != 0.0f ? bucketize_fast(lds_bnd, c.n_boundaries, c.bnd_b0, c.bnd_inv, x)
+                             : bucketize(lds_bnd, c.n_boundaries, x);
+    else
+      id = c.bnd_inv != 0.0f ? bucketize_fast(as_global(c.boundaries), c.n_boundaries, c.bnd_b0, c.bnd_inv, x)
+                             : bucketize(as_global(c.boundaries), c.n_boundaries, x);
   } else {
     id = idsrc == FCP_IDS_I64 ? (int64_t)(((uint64_t)hi << 32) | lo) : (int64_t)(int32_t)lo;
   }
@@ -395,7 +448,7 @@ __device__ __forceinline__ void dense_body(const FcpLaunch &L, int bid, char *sm
   const int world = H.world, rank = H.rank;
 
   // ---- phase 0 ----------------------------------------------------------------------
-  if (tid < B.ncols) s_col[tid] = make_lds_col(H, ld_rec48(H.cols + B.first_col + tid), ld_rec48(H.dyn + B.first_col + tid));
+  if (tid < B.ncols) s_col[tid] = make_lds_col(H, ld_rec(H.cols + B.first_col + tid), ld_rec(H.dyn + B.first_col + tid));
   __syncthreads();
 #if defined(FCP_STAMPS)
   const unsigned long long t_desc = __builtin_amdgcn_s_memrealtime();
@@ -437,8 +490,9 @@ __device__ __forceinline__ void dense_body(const FcpLaunch &L, int bid, char *sm
   // array (deduplicated at plan creation), and where each run's copy goes (wave-shuffle prefix
   // sum).  No block-wide vote, no per-column LDS round trips: the leaders' (pointer, length,
   // offset) triples travel by lane broadcast, all 256 threads copy, one barrier publishes.
+  // (arrays reproducible as fma(i, step, b0) are not staged: their boundaries are computed, never read)
   const bool my_bkt = lane < B.ncols && FCP_F_IDSRC(s_col[lane].flags) == FCP_IDS_F32_BUCKETIZE &&
-                      FCP_F_FORM(s_col[lane].flags) != FCP_FORM_PASSTHROUGH;
+                      FCP_F_FORM(s_col[lane].flags) == FCP_FORM_GATHER && s_col[lane].bnd_step == 0.0f;
   const unsigned long long any_bkt = __ballot(my_bkt);
 #if defined(FCP_STAMPS)
   const unsigned long long t_or = __builtin_amdgcn_s_memrealtime();
@@ -556,10 +610,207 @@ __device__ __forceinline__ void dense_body(const FcpLaunch &L, int bid, char *sm
 #endif
 }
 
+// ---------------------------------------------------------------------------
+// Dense kernel, wave-autonomous form (round 2).  Same decomposition — a block owns one span for
+// 4*R rows, wave w the rows w*R .. w*R+R-1 — but the four waves never meet: no LDS allocation, no
+// barrier.  Inside a wave the lanes play two roles in turn:
+//   owners     lane l < ncols holds column first_col + l: it loads the column's record (static +
+//              dynamic, 112 bytes), the R ids of the wave's rows (R * 8 contiguous bytes), turns them
+//              into table slot offsets (Bucketize on computed boundaries, range check, row shard) and
+//              keeps them in its registers;
+//   consumers  lane q owns output slot q0 + q of the wave's R rows: it fetches its column's table
+//              base, output base and the R slot offsets from the owner lane with cross-lane reads
+//              (ds_bpermute: the LDS crossbar, no LDS memory), issues R 16-byte table reads back to
+//              back, then R non-temporal stores — 1 KiB contiguous per wave instruction.
+// What the block form paid for sharing one staging among four waves — three barriers, every wave
+// waiting for the slowest, 13.5 KB of LDS per block, a serial LDS round trip per phase — bought
+// nothing the caches do not give for free: the records and ids a span's four waves read are the same
+// cache lines.  Dependent round trips per wave: slot map -> records -> ids -> rows.
+// ---------------------------------------------------------------------------
+template <int V, int R, bool SHARDED>
+__device__ __forceinline__ void dense_wave_body(const FcpLaunch &L, int bid) {
+  constexpr int RB = FCP_WAVES_PER_BLOCK * R;
+#if defined(FCP_STAMPS)
+  const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
+#endif
+  const Hot H = load_hot(L);
+  BlockPos B;
+  if (!locate_block<RB>(L, H, bid, B)) return;
+  const int lane = threadIdx.x & (FCP_WAVE - 1);
+  const int wave = threadIdx.x >> 6;
+  const int row0 = B.row_blk + wave * R;
+  if (row0 >= B.rows) return; // wave-uniform: this wave's rows are beyond the batch
+  const int q = B.q0 + lane;
+  const uint32_t my_col = B.map[min(q, B.nslots - 1)];
+  const int world = H.world, rank = H.rank;
+
+  // ---- owner role ---------------------------------------------------------------------------
+  const bool owner = lane < B.ncols;
+  typedef uint32_t __attribute__((ext_vector_type(4))) U4;
+  U4 s0 = {0, 0, 0, 0}, s1 = s0, s2 = s0, s3 = s0, d0 = s0, d1 = s0;
+  if (owner) { // the record's words as independent loads, issued back to back
+    const FCP_CONST U4 *gs = reinterpret_cast<const FCP_CONST U4 *>(H.cols + B.first_col + lane);
+    const FCP_CONST U4 *gd = reinterpret_cast<const FCP_CONST U4 *>(H.dyn + B.first_col + lane);
+    s0 = gs[0];
+    s1 = gs[1];
+    s2 = gs[2];
+    s3 = gs[3];
+    d0 = gd[0];
+    d1 = gd[1];
+  }
+  FcpColStatic cs;
+  FcpColDyn cd;
+  {
+    U4 ws[4] = {s0, s1, s2, s3}, wd[3] = {d0, d1, {0, 0, 0, 0}};
+    __builtin_memcpy(&cs, ws, sizeof(cs));
+    __builtin_memcpy(&cd, wd, sizeof(cd));
+  }
+#if defined(FCP_STAMPS)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const unsigned long long t_desc = __builtin_amdgcn_s_memrealtime();
+#endif
+  const unsigned form = FCP_F_FORM(cs.flags);
+  const unsigned idsrc = FCP_F_IDSRC(cs.flags);
+  const char *ids = H.blob + cd.ids_off;
+  const uint32_t mult = (uint32_t)(cs.dim / V);
+  const bool is64 = idsrc == FCP_IDS_I64;
+  uint32_t off[R], raw_lo[R], raw_hi[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) raw_lo[r] = raw_hi[r] = 0;
+  if (owner && form == FCP_FORM_GATHER) { // the R ids of the wave's rows: unconditional, back to back (row clamped)
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const char *a = ids + (is64 ? 8 : 4) * (int64_t)min(row0 + r, B.rows - 1);
+      raw_lo[r] = *as_global(reinterpret_cast<const uint32_t *>(a));
+      raw_hi[r] = *as_global(reinterpret_cast<const uint32_t *>(a + (is64 ? 4 : 0)));
+    }
+  }
+  // One copy of the conversion code for the R rows (the arrays rotate through element 0): only the owner
+  // lanes run it, so its latency matters and its issue slots do not; unrolled it was 4x the instructions.
+#pragma unroll 1
+  for (int it = 0; it < R; ++it) {
+    const int b = row0 + it;
+    uint32_t o = kNoRow;
+    if (owner && b < B.rows) {
+      if (form == FCP_FORM_PASSTHROUGH) {
+        // a tensor of the blob copied into its concat slot; table-free columns belong to shard rank 0
+        if (rank == 0) o = (uint32_t)b * mult;
+      } else if (form == FCP_FORM_GATHER) {
+        int64_t id;
+        if (idsrc == FCP_IDS_F32_BUCKETIZE) {
+          const float x = __uint_as_float(raw_lo[0]);
+          if (cs.bnd_step != 0.0f) // boundaries reproducible as fma(i, step, b0): never read
+            id = bucketize_arith(cs.n_boundaries, cs.bnd_b0, cs.bnd_inv, cs.bnd_step, x);
+          else if (cs.bnd_inv != 0.0f)
+            id = bucketize_fast(as_global(cs.boundaries), cs.n_boundaries, cs.bnd_b0, cs.bnd_inv, x);
+          else
+            id = bucketize(as_global(cs.boundaries), cs.n_boundaries, x);
+        } else {
+          id = is64 ? (int64_t)(((uint64_t)raw_hi[0] << 32) | raw_lo[0]) : (int64_t)(int32_t)raw_lo[0];
+        }
+        if ((uint64_t)id >= (uint64_t)cs.vocab) {
+          // a column that straddles two spans has two owners: the one holding its first slot counts
+          if (H.bad_ids && cs.out_off >= B.q0 * V) atomicAdd(H.bad_ids, 1ull);
+        } else {
+          bool mine = true;
+          if (SHARDED) {
+            const int64_t qq = id < 0x7fffffffLL ? (int64_t)((uint32_t)id / (uint32_t)world) : id / world;
+            mine = id - qq * world == rank;
+            id = qq;
+          }
+          if (mine) o = (uint32_t)id * mult;
+        }
+      } // FCP_FORM_EXTERNAL: nothing to fetch, nothing to write
+    }
+#pragma unroll
+    for (int r = 0; r + 1 < R; ++r) { // rotate: the next row's raw words move to element 0, results queue up at the end
+      raw_lo[r] = raw_lo[r + 1];
+      raw_hi[r] = raw_hi[r + 1];
+      off[r] = off[r + 1];
+    }
+    off[R - 1] = o;
+  }
+  // what a consumer needs of its column, as lane-relative bases: slot q of row b reads
+  // tb_base[q*V + off*V ..] and writes out_base[b*stride + q*V ..]
+  const float *src = form == FCP_FORM_PASSTHROUGH ? reinterpret_cast<const float *>(ids) : cs.table;
+  const uint64_t tb_base = (uint64_t)reinterpret_cast<uintptr_t>(src) - 4ull * (uint64_t)(int64_t)cs.out_off;
+  const uint64_t out_base = (uint64_t)reinterpret_cast<uintptr_t>(H.arena) + (uint64_t)cd.out_base - 4ull * (uint64_t)(int64_t)cs.out_off;
+#if defined(FCP_STAMPS)
+  const unsigned long long t_ids = __builtin_amdgcn_s_memrealtime();
+#endif
+
+  // ---- consumer role: cross-lane reads from the owner of my column ----------------------------------
+  const int j = (int)(my_col - B.first_col);
+  const uint64_t c_tb = ((uint64_t)(uint32_t)__shfl((int)(tb_base >> 32), j) << 32) | (uint32_t)__shfl((int)(uint32_t)tb_base, j);
+  const uint64_t c_out = ((uint64_t)(uint32_t)__shfl((int)(out_base >> 32), j) << 32) | (uint32_t)__shfl((int)(uint32_t)out_base, j);
+  const int64_t ostride = __shfl(cd.out_stride, j);
+  const unsigned c_form = (unsigned)__shfl((int)form, j);
+  uint32_t o[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) o[r] = (uint32_t)__shfl((int)off[r], j);
+  if (q >= B.nslots || c_form == FCP_FORM_EXTERNAL) return; // past the row, or somebody else's slot (ConcatOutputs host input)
+
+  const float *tb = reinterpret_cast<const float *>((uintptr_t)c_tb) + (int64_t)q * V;
+  float *outp = reinterpret_cast<float *>((uintptr_t)c_out) + (int64_t)q * V;
+  VF<V> v[R];
+#if !defined(FCP_ABLATE)
+  if (!SHARDED && row0 + R <= B.rows) {
+    // the common case, straight-line: R reads back to back (an id that contributes nothing reads slot 0
+    // and is zeroed by a select: no branch between the reads), then R stores
+#pragma unroll
+    for (int r = 0; r < R; ++r) v[r] = ld_slot<V>(tb, o[r] == kNoRow ? 0u : o[r]);
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      if (o[r] == kNoRow) v[r] = vzero<V>();
+#pragma unroll
+    for (int r = 0; r < R; ++r) st_out<V>(outp + (int64_t)(row0 + r) * ostride, v[r]);
+  } else
+#endif
+  {
+    // last row tile of the batch, or a row shard (most ids belong to other ranks: skipping their reads pays)
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      v[r] = vzero<V>();
+#if !(defined(FCP_ABLATE) && FCP_ABLATE == 1) // timing-only build 1: no table reads
+      if (o[r] != kNoRow) v[r] = ld_slot<V>(tb, o[r]);
+#else
+      v[r].v[0] = (float)o[r];
+#endif
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int b = row0 + r;
+#if defined(FCP_ABLATE) && FCP_ABLATE == 2 // timing-only build 2: no output stores
+      asm volatile("" ::"v"(v[r].v[0]), "v"(v[r].v[V - 1]));
+      if (b < B.rows && v[r].v[0] == 1234.5f) st_out<V>(outp + (int64_t)b * ostride, v[r]);
+#else
+      if (b < B.rows) st_out<V>(outp + (int64_t)b * ostride, v[r]);
+#endif
+    }
+  }
+#if defined(FCP_STAMPS)
+  if (L.stamps && threadIdx.x == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's row reads have landed, its stores are acknowledged
+    unsigned long long *o8 = L.stamps + 8ull * bid;
+    o8[0] = t_begin;
+    o8[1] = t_desc;
+    o8[4] = t_desc;
+    o8[5] = t_desc;
+    o8[6] = t_desc;
+    o8[2] = t_ids;
+    o8[3] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
+}
+
 template <int V, int R, bool SHARDED>
 __global__ void __launch_bounds__(FCP_BLOCK_THREADS) fcp_dense_kernel(const FcpLaunch L) {
+#if !defined(FCP_DENSE_WAVE) // the block-cooperative form (LDS staging, two barriers); -DFCP_DENSE_WAVE: A/B build of the wave-autonomous form
   __shared__ __attribute__((aligned(16))) char smem[sizeof(DenseLds<R>)];
   dense_body<V, R, SHARDED>(L, blockIdx.x, smem);
+#else
+  dense_wave_body<V, R, SHARDED>(L, blockIdx.x);
+#endif
 }
 
 // Table reads a lane of the ragged kernel keeps in flight while it walks a bag (tuning builds:
@@ -682,7 +933,7 @@ __device__ __forceinline__ void ragged_body(const FcpLaunch &L, int bid, char *s
   const int world = H.world, rank = H.rank;
 
   // ---- phase 0 ----------------------------------------------------------------------
-  if (tid < B.ncols) s_col[tid] = make_lds_col(H, ld_rec48(H.cols + B.first_col + tid), ld_rec48(H.dyn + B.first_col + tid));
+  if (tid < B.ncols) s_col[tid] = make_lds_col(H, ld_rec(H.cols + B.first_col + tid), ld_rec(H.dyn + B.first_col + tid));
   __syncthreads();
 #if defined(FCP_STAMPS)
   const unsigned long long t_desc = __builtin_amdgcn_s_memrealtime();
@@ -904,13 +1155,21 @@ struct FcpHybridLaunch {
 
 template <int V, int R, bool SHARDED>
 __global__ void __launch_bounds__(FCP_BLOCK_THREADS) fcp_hybrid_kernel(const FcpHybridLaunch H) {
+#if !defined(FCP_DENSE_WAVE)
   constexpr size_t kSmem = sizeof(RaggedLds) > sizeof(DenseLds<R>) ? sizeof(RaggedLds) : sizeof(DenseLds<R>);
+#else
+  constexpr size_t kSmem = sizeof(RaggedLds);
+#endif
   __shared__ __attribute__((aligned(16))) char smem[kSmem];
   const int bid = blockIdx.x;
   if (bid < H.ragged_blocks) {
     ragged_body<V, SHARDED>(H.ragged, bid, smem); // the longer-running blocks are dispatched first
   } else {
+#if !defined(FCP_DENSE_WAVE)
     dense_body<V, R, SHARDED>(H.dense, bid - H.ragged_blocks, smem);
+#else
+    dense_wave_body<V, R, SHARDED>(H.dense, bid - H.ragged_blocks);
+#endif
   }
 }
 

@@ -81,6 +81,10 @@ class ProcessResult(C.Structure):
     ]
 
 
+class Placement(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("min_world", C.c_int32), ("bytes_per_gpu", C.c_int64)]
+
+
 class HostTensor(C.Structure):
     _fields_ = [("data", C.c_void_p), ("elem_size", C.c_int32), ("rank", C.c_int32),
                 ("dims", C.POINTER(C.c_int64))]
@@ -93,6 +97,7 @@ EXPORTS = [
     "fcp_plan_create", "fcp_plan_create_from_file", "fcp_plan_counts", "fcp_plan_destroy", "fcp_plan_group_width",
     "fcp_plan_column_offset",
     "fcp_plan_arena_bytes", "fcp_plan_read_bad_ids", "fcp_plan_output_columns", "fcp_plan_table_bytes",
+    "fcp_placement_decide",
     "fcp_process_feature_columns", "fcp_concat_outputs", "fcp_concat_outputs_scatter", "fcp_concat_outputs_host",
     "fcp_shard_finalize",
     "fcp_stager_create", "fcp_stager_stage", "fcp_stager_stage_narrow", "fcp_stager_destroy",
@@ -161,6 +166,8 @@ def load() -> C.CDLL:
                                      C.c_void_p]
     L.fcp_plan_output_columns.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_void_p, C.c_int32]
     L.fcp_plan_table_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.fcp_placement_decide.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
+                                       C.POINTER(Placement)]
     L.fcp_concat_outputs_scatter.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_int32, C.c_int64,
                                              C.c_int32, C.c_void_p, C.c_void_p]
     L.fcp_concat_outputs_host.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_int32, C.c_int64,

@@ -727,6 +727,62 @@ def test_wide_columns_and_large_boundary_lists(torch_cuda, oracle):
     assert_equal_oracle(oracle, mixed, packed, tables, sym, out)
 
 
+def test_bucketize_tiers_are_exact(torch_cuda, oracle):
+    """Bucketize (cuda_emitter.cc:233-247, integer result: bit-exact) through the three ways the kernels
+    find a bucket: boundaries reproducible as fma(i, step, b0) are never read (bucketize_arith); evenly
+    spaced but not reproducible ones are guessed and verified (bucketize_fast); anything else is searched.
+    Values: every boundary, its float neighbours, the midpoints, NaN, +-inf, +-0 — in the dense kernel and
+    (same columns next to a pooled one) in the ragged kernel."""
+    from recom_amd.plan import (COMBINER_NONE, COMBINER_SUM, FORM_GATHER, FORM_SEGMENT_REDUCE, IDS_F32_BUCKETIZE, IDS_I64,
+                                ROWS_FROM_IDS, ROWS_FROM_SYMBOL, SEG_CSR_I32, SEG_NONE, ColumnSpec, PlanSpec)
+    rng = np.random.default_rng(11)
+    arrays = {
+        "reference 0,5,...,495": np.arange(0, 500, 5, dtype=np.float32),
+        "dyadic grid": (np.arange(37, dtype=np.float32) * np.float32(0.375) - np.float32(3.0)),
+        "two boundaries": np.asarray([-1.0, 2.0], np.float32),
+        "tenths (evenly spaced, not reproducible)": (np.arange(200) * 0.1).astype(np.float32),
+        "thirds": (np.arange(1, 90) / 3.0).astype(np.float32),
+        "log spaced": np.logspace(-3, 4, 150).astype(np.float32),
+        "random": np.unique(rng.uniform(-50, 50, 300).astype(np.float32)),
+        "single": np.asarray([7.5], np.float32),
+        "huge step": np.asarray([-3e38, 0.0, 3e38], np.float32),
+    }
+    cols, ranks, esz, tables, inputs = [], [], [], [], []
+    for slot, (name, b) in enumerate(arrays.items()):
+        assert np.all(np.diff(b) > 0), name
+        x = np.concatenate([b, np.nextafter(b, -np.inf), np.nextafter(b, np.inf), (b[:-1] + b[1:]) / 2,
+                            [np.nan, np.inf, -np.inf, 0.0, -0.0, b[0] - 1, b[-1] + 1, 3.4e38, -3.4e38],
+                            rng.uniform(b[0] - 3, b[-1] + 3, 200)]).astype(np.float32)
+        inputs.append(x)
+        ranks.append(1)
+        esz.append(4)
+        tables.append(rng.standard_normal((len(b) + 1, 8)).astype(np.float32))
+        cols.append(ColumnSpec(FORM_GATHER, 8, len(b) + 1, COMBINER_NONE, IDS_F32_BUCKETIZE, slot, slot, -1, SEG_NONE, 1,
+                               ROWS_FROM_IDS, 0, b, 0, slot))
+    n = max(len(x) for x in inputs)
+    inputs = [np.concatenate([x, np.full(n - len(x), x[0], np.float32)]) for x in inputs]
+    dense = PlanSpec(cols, ranks, esz, len(tables))
+    out, packed, _ = run_gpu(torch_cuda, dense, inputs, tables, None)
+    assert_equal_oracle(oracle, dense, packed, tables, None, out)
+    # every column: the ids the oracle's plain binary search finds (a wrong bucket would read another row)
+    import fcp_oracle as O
+    got = out.groups[0].cpu().numpy()
+    for k, (name, b) in enumerate(arrays.items()):
+        assert np.array_equal(got[:, 8 * k:8 * k + 8], tables[k][O.np_bucketize(b, inputs[k])]), name
+    # behind the ragged kernel (a pooled column makes every span ragged); ids of the pooled column use the
+    # evenly spaced boundaries too
+    lens = rng.integers(0, 4, n)
+    vals = rng.uniform(-5, 505, int(lens.sum())).astype(np.float32)
+    csr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    tables.append(rng.standard_normal((101, 16)).astype(np.float32))
+    pooled = ColumnSpec(FORM_SEGMENT_REDUCE, 16, 101, COMBINER_SUM, IDS_F32_BUCKETIZE, len(tables) - 1, len(inputs),
+                        len(inputs) + 1, SEG_CSR_I32, 1, ROWS_FROM_SYMBOL, 0, arrays["reference 0,5,...,495"], 0, len(cols))
+    mixed = PlanSpec(cols + [pooled], ranks + [1, 1], esz + [4, 4], len(tables), n_symbols=1)
+    sym = np.asarray([n], np.int32)
+    out, packed, _ = run_gpu(torch_cuda, mixed, inputs + [vals, csr], tables, sym)
+    assert_equal_oracle(oracle, mixed, packed, tables, sym, out)
+
+
 @pytest.mark.parametrize("columns,batch,vocab", [(40, 100_000, 5000), (5000, 8, 300), (1, 1, 7), (3, 70_001, 50)])
 def test_extreme_shapes_dense(torch_cuda, oracle, columns, batch, vocab):
     """Very tall, very wide and degenerate one-hot requests (grid / span / slot-map limits)."""

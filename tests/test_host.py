@@ -409,3 +409,37 @@ def test_external_slots_host_side(monkeypatch):
     only_ext = dataclasses.replace(m.spec, columns=[dataclasses.replace(ext, concat_group=0)], n_groups=1)
     with pytest.raises(lib.FcpError):                          # a group of external slots only has no row count
         Plan(only_ext, host_only=True).arena_bytes(shapes, req.symbols)
+
+
+def test_placement_gate():
+    """a13: replicas while the tables fit one GPU's 288 GB, sharding only beyond (north star); the
+    reference's counterpart is the 256 MiB per-table gate, cuda_emitter.cc:1080-1094."""
+    from recom_amd import lib, synth
+    from recom_amd.placement import COLUMN_SHARD, REPLICATE, ROW_SHARD, decide_placement, table_bytes
+    s2 = synth.model_s2().spec
+    assert int(table_bytes(s2).sum()) == 120_000_000_000
+    for world in (1, 2, 8):
+        p = decide_placement(s2, world)
+        assert p.mode == REPLICATE and p.bytes_per_gpu == 120_000_000_000 and p.min_world == 1
+    shard = synth.model_shard().spec                        # BASELINE config 5: 480 GB
+    for world, per_gpu in ((2, 240_000_000_000), (4, 120_000_000_000), (8, 60_000_000_000)):
+        p = decide_placement(shard, world)
+        assert p.mode == ROW_SHARD and p.bytes_per_gpu == per_gpu and p.min_world == 2
+        q = decide_placement(shard, world, prefer="column")
+        assert q.mode == COLUMN_SHARD and q.bytes_per_gpu >= per_gpu
+    with pytest.raises(lib.FcpError) as e:                  # 480 GB on one GPU: refused, says how many it needs
+        decide_placement(shard, 1)
+    assert e.value.status == lib.FCP_ERR_UNSUPPORTED and "at least 2" in str(e.value)
+    # one table larger than a GPU: only row sharding can hold it
+    big = [400 * 10**9, 10**9]
+    assert decide_placement(big, 2, prefer="column").mode == ROW_SHARD
+    with pytest.raises(lib.FcpError):
+        decide_placement(big, 1)
+    # column sharding infeasible although the total would fit by rows: 3 tables of 200 GB on 2 GPUs
+    three = [200 * 10**9] * 3
+    with pytest.raises(lib.FcpError):
+        decide_placement(three, 2, prefer="column", reserve_bytes=0, hbm_bytes=250 * 10**9)
+    assert decide_placement(three, 3, prefer="column", reserve_bytes=0, hbm_bytes=250 * 10**9).mode == COLUMN_SHARD
+    # a shared table counts once
+    m = synth.model_mixed()
+    assert len(table_bytes(m.spec)) == m.spec.n_device_inputs
