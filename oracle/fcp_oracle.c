@@ -214,6 +214,101 @@ void orc_sparse_segment_reduce_ref8x8(const float *table, int32_t dim,
   free(part);
 }
 
+/* a7 in the reference's OWN summation order for dim <= 20: tiles of 64 ids, a segmented
+ * inclusive scan with cub::BlockScan<..., 64, BLOCK_SCAN_WARP_SCANS> (CUB 1.8.0, WORKSPACE:5-14) over
+ * (row-vector, head-flag) pairs, cuda_emitter.cc:348-501 (Sum) / :504-661 (Mean), driven tile by tile
+ * by EmitSparseSegmentReduce :1542-1618:
+ *   - head flag of element i = row[i] - row[i-1] (row[-1] = 0, `last_row_id`, :1576), tail flag =
+ *     row[i+1] - row[i] (INT_MAX after the end, :1589-1590);
+ *   - ScanVecScanOp (:381-400): op(a, b) = b if b opens a segment, else a + b;
+ *   - CUB 1.8 WarpScanShfl::InclusiveScan on each 32-lane warp: for d = 1, 2, 4, 8, 16:
+ *     x[i] = op(x[i-d], x[i]) for i >= d (Kogge-Stone); BLOCK_SCAN_WARP_SCANS then folds the first
+ *     warp's aggregate into every item of the second: x[i] = op(aggregate0, x[i]);
+ *   - a tail lane writes op(last_aggregate, x[i]) (:470-479); the tile's last lane keeps the carry
+ *     (:482-490).
+ * The slabs of SCAN_DIM = 8 floats (:1609-1618) only partition the row: every float sees the same
+ * order, so whole rows are scanned here.  Used only to bound the fp32 reordering error of the HIP path
+ * (sequential id order) against what the reference's kernel computes; rows without ids stay zero. */
+typedef struct { int32_t key; int32_t cnt; } orc_scan_head_t;
+
+static void refscan_op(const float *av, const orc_scan_head_t *ah, const float *bv, const orc_scan_head_t *bh,
+                       float *rv, orc_scan_head_t *rh, int32_t dim) {
+  /* may be called with rv == bv (in-place on the right operand) or rv == av */
+  orc_scan_head_t h;
+  h.key = (int32_t)((uint32_t)ah->key + (uint32_t)bh->key);
+  if (bh->key) {
+    h.cnt = bh->cnt;
+    for (int32_t e = 0; e < dim; ++e) rv[e] = bv[e];
+  } else {
+    h.cnt = ah->cnt + bh->cnt;
+    for (int32_t e = 0; e < dim; ++e) rv[e] = av[e] + bv[e];
+  }
+  *rh = h;
+}
+
+void orc_sparse_segment_reduce_refscan(const float *table, int32_t dim, const int64_t *ids,
+                                       const int64_t *row_ids, int64_t nnz, int64_t num_segments,
+                                       int32_t mean, float *out, int64_t out_stride) {
+  enum { BT = 64, WARP = 32 };
+  float *x = (float *)malloc(sizeof(float) * BT * (size_t)dim);
+  float *t = (float *)malloc(sizeof(float) * BT * (size_t)dim);
+  float *carry = (float *)calloc((size_t)dim, sizeof(float));
+  float *tmp = (float *)malloc(sizeof(float) * (size_t)dim);
+  orc_scan_head_t h[BT], th[BT], carry_h = {0, 0};
+  for (int64_t s = 0; s < num_segments; ++s)
+    for (int32_t e = 0; e < dim; ++e) out[s * out_stride + e] = 0.0f; /* the arena is pre-zeroed, :1460-1475 */
+  int64_t last_row = 0;
+  for (int64_t base = 0; base < nnz; base += BT) {
+    int64_t row[BT + 2];
+    row[0] = last_row;
+    for (int i = 0; i < BT; ++i) row[i + 1] = base + i < nnz ? row_ids[base + i] : INT32_MAX;
+    row[BT + 1] = base + BT < nnz ? row_ids[base + BT] : INT32_MAX;
+    last_row = row[BT];
+    for (int i = 0; i < BT; ++i) {
+      h[i].key = (int32_t)(row[i + 1] - row[i]);
+      h[i].cnt = 1;
+      for (int32_t e = 0; e < dim; ++e)
+        x[i * dim + e] = base + i < nnz ? table[ids[base + i] * dim + e] : 0.0f; /* lanes past the end: not read */
+    }
+    for (int w = 0; w < BT / WARP; ++w) /* Kogge-Stone inside each warp */
+      for (int d = 1; d < WARP; d <<= 1) {
+        memcpy(t, x, sizeof(float) * BT * (size_t)dim);
+        memcpy(th, h, sizeof(h));
+        for (int i = w * WARP + d; i < (w + 1) * WARP; ++i)
+          refscan_op(t + (i - d) * dim, &th[i - d], t + i * dim, &th[i], x + i * dim, &h[i], dim);
+      }
+    for (int w = 1; w < BT / WARP; ++w) { /* warp prefixes: aggregates of the earlier warps, in order */
+      memcpy(tmp, x + (w * WARP - 1) * dim, sizeof(float) * (size_t)dim);
+      const orc_scan_head_t agg = h[w * WARP - 1];
+      for (int i = w * WARP; i < (w + 1) * WARP; ++i) {
+        memcpy(t, x + i * dim, sizeof(float) * (size_t)dim);
+        const orc_scan_head_t hi = h[i];
+        refscan_op(tmp, &agg, t, &hi, x + i * dim, &h[i], dim);
+      }
+    }
+    for (int i = 0; i < BT; ++i) {
+      const int tail = row[i + 2] != row[i + 1];
+      if (base + i >= nnz) break;
+      if (tail || i == BT - 1) {
+        orc_scan_head_t rh;
+        refscan_op(carry, &carry_h, x + i * dim, &h[i], tmp, &rh, dim);
+        if (tail && row[i + 1] >= 0 && row[i + 1] < num_segments) {
+          float *o = out + row[i + 1] * out_stride;
+          for (int32_t e = 0; e < dim; ++e) o[e] = mean ? tmp[e] / (float)rh.cnt : tmp[e]; /* sum / counter, :625 */
+        }
+        if (i == BT - 1) { /* :482-490: the pair itself if its segment ended here, else carry (+) pair — the same value */
+          memcpy(carry, tmp, sizeof(float) * (size_t)dim);
+          carry_h = rh;
+        }
+      }
+    }
+  }
+  free(x);
+  free(t);
+  free(carry);
+  free(tmp);
+}
+
 /* --------------------------------------------------------------------------
  * a11 — BatchColReduction.  cuda_emitter.cc:1216-1241 (Sum(x, axis=1) on a
  * rank-3 input): out[b,c] = sum_r x[b,r,c], r ascending (:1231-1236).

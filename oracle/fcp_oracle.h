@@ -98,6 +98,13 @@ void orc_sparse_segment_reduce_ref8x8(const float *table, int32_t dim,
                                       int64_t num_segments, int32_t mean,
                                       float *out, int64_t out_stride);
 
+/* a7 in the reference's own summation order for dim <= 20 (64-id tiles, CUB 1.8 BlockScan with
+ * BLOCK_SCAN_WARP_SCANS over (row vector, head flag) pairs, carry across tiles; cuda_emitter.cc:348-661,
+ * :1542-1618).  row_ids[nnz] sorted ascending.  Used only to bound the fp32 reordering error. */
+void orc_sparse_segment_reduce_refscan(const float *table, int32_t dim, const int64_t *ids,
+                                       const int64_t *row_ids, int64_t nnz, int64_t num_segments,
+                                       int32_t mean, float *out, int64_t out_stride);
+
 /* a11 cuda_emitter.cc:1216-1241 */
 void orc_batch_col_reduction(const float *x, int64_t batch, int64_t rows,
                              int64_t cols, float *out, int64_t out_stride);

@@ -91,6 +91,8 @@ class COracle:
                                                 C.c_int64, C.c_int32, C.c_void_p, C.c_int64]
         L.orc_sparse_segment_reduce_ref8x8.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                                        C.c_int64, C.c_int32, C.c_void_p, C.c_int64]
+        L.orc_sparse_segment_reduce_refscan.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64,
+                                                        C.c_int64, C.c_int32, C.c_void_p, C.c_int64]
         L.orc_batch_col_reduction.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p,
                                               C.c_int64]
         L.orc_concat_outputs.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p]
@@ -157,6 +159,17 @@ class COracle:
                                                  o.ctypes.data, S, int(mean), out.ctypes.data,
                                                  t.shape[1])
         return out, bad
+
+    def sparse_segment_reduce_refscan(self, table, ids, row_ids, num_segments: int, mean: bool) -> np.ndarray:
+        """Form 2 in the reference GPU kernel's own order for dim <= 20 (CUB block scan over 64-id tiles)."""
+        t = np.ascontiguousarray(table, np.float32)
+        i = np.ascontiguousarray(ids, np.int64).ravel()
+        r = np.ascontiguousarray(row_ids, np.int64).ravel()
+        assert i.size == r.size
+        out = np.empty((num_segments, t.shape[1]), np.float32)
+        self.lib.orc_sparse_segment_reduce_refscan(t.ctypes.data, t.shape[1], i.ctypes.data, r.ctypes.data, i.size,
+                                                   num_segments, int(mean), out.ctypes.data, t.shape[1])
+        return out
 
     def batch_col_reduction(self, x) -> np.ndarray:
         x = np.ascontiguousarray(x, np.float32)

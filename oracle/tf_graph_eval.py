@@ -166,6 +166,20 @@ class GraphEvaluator:
             out = np.zeros(shape, x[1].dtype)
             np.add.at(out, x[0].astype(np.int64).reshape(-1), x[1])
             return [out]
+        if op == "Prod":
+            axis = tuple(int(v) for v in np.asarray(x[1]).ravel())
+            return [np.prod(x[0], axis=axis, keepdims=bool("keep_dims" in a and a["keep_dims"].b)).astype(x[0].dtype)]
+        if op == "SparseReshape":
+            # tf.sparse.reshape: row-major flat position of every index, re-expressed in the new shape
+            shape = [int(d) for d in x[1].ravel()]
+            new = [int(d) for d in x[2].ravel()]
+            if -1 in new:
+                new[new.index(-1)] = int(np.prod(shape)) // max(1, -int(np.prod(new)))
+            assert int(np.prod(new)) == int(np.prod(shape)), "SparseReshape: element counts differ"
+            idx = x[0].astype(np.int64).reshape(-1, len(shape))
+            flat = np.ravel_multi_index(tuple(idx.T), shape) if idx.size else np.zeros(0, np.int64)
+            out = np.stack(np.unravel_index(flat, new), axis=1).astype(np.int64) if idx.size else np.zeros((0, len(new)), np.int64)
+            return [out, np.asarray(new, np.int64)]
         if op.startswith("SparseSegmentSum") or op.startswith("SparseSegmentMean"):
             n = int(np.asarray(x[3]).ravel()[0]) if op.endswith("WithNumSegments") else None
             return [_sparse_segment(x[0], x[1], x[2], n, "Mean" in op)]

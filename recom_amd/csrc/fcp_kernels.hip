@@ -610,207 +610,10 @@ __device__ __forceinline__ void dense_body(const FcpLaunch &L, int bid, char *sm
 #endif
 }
 
-// ---------------------------------------------------------------------------
-// Dense kernel, wave-autonomous form (round 2).  Same decomposition — a block owns one span for
-// 4*R rows, wave w the rows w*R .. w*R+R-1 — but the four waves never meet: no LDS allocation, no
-// barrier.  Inside a wave the lanes play two roles in turn:
-//   owners     lane l < ncols holds column first_col + l: it loads the column's record (static +
-//              dynamic, 112 bytes), the R ids of the wave's rows (R * 8 contiguous bytes), turns them
-//              into table slot offsets (Bucketize on computed boundaries, range check, row shard) and
-//              keeps them in its registers;
-//   consumers  lane q owns output slot q0 + q of the wave's R rows: it fetches its column's table
-//              base, output base and the R slot offsets from the owner lane with cross-lane reads
-//              (ds_bpermute: the LDS crossbar, no LDS memory), issues R 16-byte table reads back to
-//              back, then R non-temporal stores — 1 KiB contiguous per wave instruction.
-// What the block form paid for sharing one staging among four waves — three barriers, every wave
-// waiting for the slowest, 13.5 KB of LDS per block, a serial LDS round trip per phase — bought
-// nothing the caches do not give for free: the records and ids a span's four waves read are the same
-// cache lines.  Dependent round trips per wave: slot map -> records -> ids -> rows.
-// ---------------------------------------------------------------------------
-template <int V, int R, bool SHARDED>
-__device__ __forceinline__ void dense_wave_body(const FcpLaunch &L, int bid) {
-  constexpr int RB = FCP_WAVES_PER_BLOCK * R;
-#if defined(FCP_STAMPS)
-  const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
-#endif
-  const Hot H = load_hot(L);
-  BlockPos B;
-  if (!locate_block<RB>(L, H, bid, B)) return;
-  const int lane = threadIdx.x & (FCP_WAVE - 1);
-  const int wave = threadIdx.x >> 6;
-  const int row0 = B.row_blk + wave * R;
-  if (row0 >= B.rows) return; // wave-uniform: this wave's rows are beyond the batch
-  const int q = B.q0 + lane;
-  const uint32_t my_col = B.map[min(q, B.nslots - 1)];
-  const int world = H.world, rank = H.rank;
-
-  // ---- owner role ---------------------------------------------------------------------------
-  const bool owner = lane < B.ncols;
-  typedef uint32_t __attribute__((ext_vector_type(4))) U4;
-  U4 s0 = {0, 0, 0, 0}, s1 = s0, s2 = s0, s3 = s0, d0 = s0, d1 = s0;
-  if (owner) { // the record's words as independent loads, issued back to back
-    const FCP_CONST U4 *gs = reinterpret_cast<const FCP_CONST U4 *>(H.cols + B.first_col + lane);
-    const FCP_CONST U4 *gd = reinterpret_cast<const FCP_CONST U4 *>(H.dyn + B.first_col + lane);
-    s0 = gs[0];
-    s1 = gs[1];
-    s2 = gs[2];
-    s3 = gs[3];
-    d0 = gd[0];
-    d1 = gd[1];
-  }
-  FcpColStatic cs;
-  FcpColDyn cd;
-  {
-    U4 ws[4] = {s0, s1, s2, s3}, wd[3] = {d0, d1, {0, 0, 0, 0}};
-    __builtin_memcpy(&cs, ws, sizeof(cs));
-    __builtin_memcpy(&cd, wd, sizeof(cd));
-  }
-#if defined(FCP_STAMPS)
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  const unsigned long long t_desc = __builtin_amdgcn_s_memrealtime();
-#endif
-  const unsigned form = FCP_F_FORM(cs.flags);
-  const unsigned idsrc = FCP_F_IDSRC(cs.flags);
-  const char *ids = H.blob + cd.ids_off;
-  const uint32_t mult = (uint32_t)(cs.dim / V);
-  const bool is64 = idsrc == FCP_IDS_I64;
-  uint32_t off[R], raw_lo[R], raw_hi[R];
-#pragma unroll
-  for (int r = 0; r < R; ++r) raw_lo[r] = raw_hi[r] = 0;
-  if (owner && form == FCP_FORM_GATHER) { // the R ids of the wave's rows: unconditional, back to back (row clamped)
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const char *a = ids + (is64 ? 8 : 4) * (int64_t)min(row0 + r, B.rows - 1);
-      raw_lo[r] = *as_global(reinterpret_cast<const uint32_t *>(a));
-      raw_hi[r] = *as_global(reinterpret_cast<const uint32_t *>(a + (is64 ? 4 : 0)));
-    }
-  }
-  // One copy of the conversion code for the R rows (the arrays rotate through element 0): only the owner
-  // lanes run it, so its latency matters and its issue slots do not; unrolled it was 4x the instructions.
-#pragma unroll 1
-  for (int it = 0; it < R; ++it) {
-    const int b = row0 + it;
-    uint32_t o = kNoRow;
-    if (owner && b < B.rows) {
-      if (form == FCP_FORM_PASSTHROUGH) {
-        // a tensor of the blob copied into its concat slot; table-free columns belong to shard rank 0
-        if (rank == 0) o = (uint32_t)b * mult;
-      } else if (form == FCP_FORM_GATHER) {
-        int64_t id;
-        if (idsrc == FCP_IDS_F32_BUCKETIZE) {
-          const float x = __uint_as_float(raw_lo[0]);
-          if (cs.bnd_step != 0.0f) // boundaries reproducible as fma(i, step, b0): never read
-            id = bucketize_arith(cs.n_boundaries, cs.bnd_b0, cs.bnd_inv, cs.bnd_step, x);
-          else if (cs.bnd_inv != 0.0f)
-            id = bucketize_fast(as_global(cs.boundaries), cs.n_boundaries, cs.bnd_b0, cs.bnd_inv, x);
-          else
-            id = bucketize(as_global(cs.boundaries), cs.n_boundaries, x);
-        } else {
-          id = is64 ? (int64_t)(((uint64_t)raw_hi[0] << 32) | raw_lo[0]) : (int64_t)(int32_t)raw_lo[0];
-        }
-        if ((uint64_t)id >= (uint64_t)cs.vocab) {
-          // a column that straddles two spans has two owners: the one holding its first slot counts
-          if (H.bad_ids && cs.out_off >= B.q0 * V) atomicAdd(H.bad_ids, 1ull);
-        } else {
-          bool mine = true;
-          if (SHARDED) {
-            const int64_t qq = id < 0x7fffffffLL ? (int64_t)((uint32_t)id / (uint32_t)world) : id / world;
-            mine = id - qq * world == rank;
-            id = qq;
-          }
-          if (mine) o = (uint32_t)id * mult;
-        }
-      } // FCP_FORM_EXTERNAL: nothing to fetch, nothing to write
-    }
-#pragma unroll
-    for (int r = 0; r + 1 < R; ++r) { // rotate: the next row's raw words move to element 0, results queue up at the end
-      raw_lo[r] = raw_lo[r + 1];
-      raw_hi[r] = raw_hi[r + 1];
-      off[r] = off[r + 1];
-    }
-    off[R - 1] = o;
-  }
-  // what a consumer needs of its column, as lane-relative bases: slot q of row b reads
-  // tb_base[q*V + off*V ..] and writes out_base[b*stride + q*V ..]
-  const float *src = form == FCP_FORM_PASSTHROUGH ? reinterpret_cast<const float *>(ids) : cs.table;
-  const uint64_t tb_base = (uint64_t)reinterpret_cast<uintptr_t>(src) - 4ull * (uint64_t)(int64_t)cs.out_off;
-  const uint64_t out_base = (uint64_t)reinterpret_cast<uintptr_t>(H.arena) + (uint64_t)cd.out_base - 4ull * (uint64_t)(int64_t)cs.out_off;
-#if defined(FCP_STAMPS)
-  const unsigned long long t_ids = __builtin_amdgcn_s_memrealtime();
-#endif
-
-  // ---- consumer role: cross-lane reads from the owner of my column ----------------------------------
-  const int j = (int)(my_col - B.first_col);
-  const uint64_t c_tb = ((uint64_t)(uint32_t)__shfl((int)(tb_base >> 32), j) << 32) | (uint32_t)__shfl((int)(uint32_t)tb_base, j);
-  const uint64_t c_out = ((uint64_t)(uint32_t)__shfl((int)(out_base >> 32), j) << 32) | (uint32_t)__shfl((int)(uint32_t)out_base, j);
-  const int64_t ostride = __shfl(cd.out_stride, j);
-  const unsigned c_form = (unsigned)__shfl((int)form, j);
-  uint32_t o[R];
-#pragma unroll
-  for (int r = 0; r < R; ++r) o[r] = (uint32_t)__shfl((int)off[r], j);
-  if (q >= B.nslots || c_form == FCP_FORM_EXTERNAL) return; // past the row, or somebody else's slot (ConcatOutputs host input)
-
-  const float *tb = reinterpret_cast<const float *>((uintptr_t)c_tb) + (int64_t)q * V;
-  float *outp = reinterpret_cast<float *>((uintptr_t)c_out) + (int64_t)q * V;
-  VF<V> v[R];
-#if !defined(FCP_ABLATE)
-  if (!SHARDED && row0 + R <= B.rows) {
-    // the common case, straight-line: R reads back to back (an id that contributes nothing reads slot 0
-    // and is zeroed by a select: no branch between the reads), then R stores
-#pragma unroll
-    for (int r = 0; r < R; ++r) v[r] = ld_slot<V>(tb, o[r] == kNoRow ? 0u : o[r]);
-#pragma unroll
-    for (int r = 0; r < R; ++r)
-      if (o[r] == kNoRow) v[r] = vzero<V>();
-#pragma unroll
-    for (int r = 0; r < R; ++r) st_out<V>(outp + (int64_t)(row0 + r) * ostride, v[r]);
-  } else
-#endif
-  {
-    // last row tile of the batch, or a row shard (most ids belong to other ranks: skipping their reads pays)
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      v[r] = vzero<V>();
-#if !(defined(FCP_ABLATE) && FCP_ABLATE == 1) // timing-only build 1: no table reads
-      if (o[r] != kNoRow) v[r] = ld_slot<V>(tb, o[r]);
-#else
-      v[r].v[0] = (float)o[r];
-#endif
-    }
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int b = row0 + r;
-#if defined(FCP_ABLATE) && FCP_ABLATE == 2 // timing-only build 2: no output stores
-      asm volatile("" ::"v"(v[r].v[0]), "v"(v[r].v[V - 1]));
-      if (b < B.rows && v[r].v[0] == 1234.5f) st_out<V>(outp + (int64_t)b * ostride, v[r]);
-#else
-      if (b < B.rows) st_out<V>(outp + (int64_t)b * ostride, v[r]);
-#endif
-    }
-  }
-#if defined(FCP_STAMPS)
-  if (L.stamps && threadIdx.x == 0) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's row reads have landed, its stores are acknowledged
-    unsigned long long *o8 = L.stamps + 8ull * bid;
-    o8[0] = t_begin;
-    o8[1] = t_desc;
-    o8[4] = t_desc;
-    o8[5] = t_desc;
-    o8[6] = t_desc;
-    o8[2] = t_ids;
-    o8[3] = __builtin_amdgcn_s_memrealtime();
-  }
-#endif
-}
-
 template <int V, int R, bool SHARDED>
 __global__ void __launch_bounds__(FCP_BLOCK_THREADS) fcp_dense_kernel(const FcpLaunch L) {
-#if !defined(FCP_DENSE_WAVE) // the block-cooperative form (LDS staging, two barriers); -DFCP_DENSE_WAVE: A/B build of the wave-autonomous form
   __shared__ __attribute__((aligned(16))) char smem[sizeof(DenseLds<R>)];
   dense_body<V, R, SHARDED>(L, blockIdx.x, smem);
-#else
-  dense_wave_body<V, R, SHARDED>(L, blockIdx.x);
-#endif
 }
 
 // Table reads a lane of the ragged kernel keeps in flight while it walks a bag (tuning builds:
@@ -824,22 +627,30 @@ __global__ void __launch_bounds__(FCP_BLOCK_THREADS) fcp_dense_kernel(const FcpL
 // variable length, scatter columns, passthrough, Sum(axis=1)).
 //
 // Same block shape as the dense kernel, one output row per wave (RB = 4).
-//   phase 0  column records -> LDS;
-//   phase 1  one thread per (column, row) pair reads the pair's CSR range
-//            [lo, lo+cnt) — the LDS-staged row-offset buffer — and a block-wide
-//            scan of the counts (wave shuffle scan + per-wave totals) assigns
-//            every bag a slice of the LDS offset tile; then one thread per *id*
-//            (its bag looked up in an LDS owner table the bags fill) fetches it
-//            and stores the table slot offset (Bucketize, range check, row shard:
-//            once per id instead of once per lane, all ids of the block in one
-//            memory round trip);
-//   phase 2  every lane walks its bag in LDS: 8 (then 4) slot offsets -> as many
+//   phase 0  (block) the span's column records -> LDS; the only barrier
+//            (plans whose few segment-id columns are searched in the blocks add a
+//            second one around the search);
+//   phase 1  (wave) a wave owns ONE output row, so it stages its own row's bags:
+//            lane j < ncols reads the CSR range [lo, lo+cnt) of (column j, row) —
+//            the row-offset buffer — a wave prefix sum (shuffles) assigns the bag a
+//            slice of the wave's LDS offset tile and the lane marks the slice in the
+//            wave's owner table; then one lane per *id* (owner table -> column,
+//            position) fetches it and stores the table slot offset (Bucketize, range
+//            check, row shard: once per id instead of once per lane, all ids of the
+//            row in one memory round trip);
+//   phase 2  (wave) lane q walks its column's bag — range and slice come from the
+//            owner lane by cross-lane reads: 8 (then 4) slot offsets -> as many
 //            independent 16-byte table reads in flight -> adds in id order
 //            (sequential fp32 order: deterministic, equal to TF-CPU's and the
 //            oracle's), divides for mean (sum / count, cuda_emitter.cc:625,
 //            :903); the wave stores 1 KiB contiguous of the concat row.
-// Bags longer than 64 ids, or bags that do not fit the 1536-entry tile, are
+// Bags longer than 64 ids, or bags that do not fit the wave's 384-entry tile, are
 // walked from global memory by the lanes themselves (same arithmetic order).
+// Round 1 staged at block scope (ranges, a block-wide scan and the ids of all four
+// rows behind four barriers, 19.7 KB of LDS); measured against this form on RAGGED,
+// E and F the two are equal within noise (30.3-30.7 us RAGGED): a launch is bounded
+// by its ramp, tail and the ~2.4 us kernel boundary, not by the barriers
+// (DESIGN.md section 4).  The wave-scope form stays: 15.1 KB of LDS, one barrier.
 // The kernel is instruction-issue bound rather than HBM bound (rocprofv3: ~490
 // VALU per wave before this layout), hence the pre-scaled 32-bit slot offsets:
 // a table read costs one LDS read, one compare, one 64-bit shift-add, one load.
@@ -896,150 +707,16 @@ __device__ __forceinline__ int seg_lower_bound(const char *seg, bool is64, int s
   return a;
 }
 
-struct RaggedLds {
-  static constexpr int RB = FCP_WAVES_PER_BLOCK; // rows per block, one per wave
-  static constexpr int NP = FCP_WAVE * RB;       // (column, row) pairs per block, at most (= 256 threads)
-  static constexpr int CAP = 1536;               // staged slot offsets per block
-  LdsCol col[FCP_WAVE];
-  int32_t lo[NP], cnt[NP];
-  int32_t offx[NP];                              // exclusive scan of the staged counts
-  uint32_t ids[CAP];
-  uint16_t owner[CAP];                           // staged id slot -> its (column, row) pair
-  int32_t wsum[FCP_WAVES_PER_BLOCK];
-  int32_t bound[FCP_WAVE * (FCP_WAVES_PER_BLOCK + 1)]; // seg_search: row offsets r0..r0+RB of every column
-};
-
+// Phase 2 of the ragged bodies for one output slot: walk the bag of (column C, row b) — its staged table
+// slot offsets sit at s_ids[poff .. poff+pcnt), or poff < 0: fetch the ids from the blob — with 8 (then 4)
+// table reads in flight, add in id order, divide for mean, store.
 template <int V, bool SHARDED>
-__device__ __forceinline__ void ragged_body(const FcpLaunch &L, int bid, char *smem) {
-  constexpr int RB = RaggedLds::RB, NP = RaggedLds::NP, CAP = RaggedLds::CAP;
-  constexpr int LONG_BAG = 64;
-  RaggedLds &S = *reinterpret_cast<RaggedLds *>(smem);
-  LdsCol *s_col = S.col;
-  int32_t *s_lo = S.lo, *s_cnt = S.cnt, *s_offx = S.offx, *s_wsum = S.wsum;
-  uint32_t *s_ids = S.ids;
-  uint16_t *s_owner = S.owner;
-
-  BlockPos B;
-#if defined(FCP_STAMPS)
-  const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
-#endif
-  const Hot H = load_hot(L);
-  if (!locate_block<RB>(L, H, bid, B)) return;
-  const int tid = threadIdx.x;
-  const int lane = tid & (FCP_WAVE - 1);
-  const int wave = tid >> 6;
-  const int q = B.q0 + lane;
-  const uint32_t my_col = B.map[min(q, B.nslots - 1)];
-  const int world = H.world, rank = H.rank;
-
-  // ---- phase 0 ----------------------------------------------------------------------
-  if (tid < B.ncols) s_col[tid] = make_lds_col(H, ld_rec(H.cols + B.first_col + tid), ld_rec(H.dyn + B.first_col + tid));
-  __syncthreads();
-#if defined(FCP_STAMPS)
-  const unsigned long long t_desc = __builtin_amdgcn_s_memrealtime();
-#endif
-
-  // ---- phase 1a': segment-id columns without a pre-pass: RB+1 row offsets per column ---
-  if (H.seg_search) {
-    for (int u = tid; u < B.ncols * (RB + 1); u += FCP_BLOCK_THREADS) {
-      const LdsCol &c = s_col[u / (RB + 1)];
-      const unsigned sk = FCP_F_SEGKIND(c.flags), f = FCP_F_FORM(c.flags);
-      int v = 0;
-      if ((sk == FCP_SEG_IDS_I32 || sk == FCP_SEG_IDS_I64) && (f == FCP_FORM_SEGMENT_REDUCE || f == FCP_FORM_GATHER_SCATTER))
-        v = seg_lower_bound(reinterpret_cast<const char *>(c.csr), sk == FCP_SEG_IDS_I64, (int)(c.flags >> 16), c.nnz,
-                            min(B.row_blk + u % (RB + 1), B.rows), B.rows);
-      S.bound[u] = v;
-    }
-    __syncthreads();
-  }
-
-#if defined(FCP_STAMPS)
-  const unsigned long long t_seg = __builtin_amdgcn_s_memrealtime();
-#endif
-  // ---- phase 1a: row ranges of the block's (column, row) pairs + scan ----------------
-  int lo = 0, cnt = 0;
-  if (tid < B.ncols * RB) {
-    const int pj = tid / RB, pr = tid % RB;
-    const int b = B.row_blk + pr;
-    if (b < B.rows) {
-      const unsigned form = FCP_F_FORM(s_col[pj].flags);
-      if (form == FCP_FORM_GATHER) {
-        lo = b;
-        cnt = 1;
-      } else if (form == FCP_FORM_SEGMENT_REDUCE || form == FCP_FORM_GATHER_SCATTER) {
-        const int nnz = s_col[pj].nnz;
-        int o0, o1;
-        if (H.seg_search && FCP_F_SEGKIND(s_col[pj].flags) != FCP_SEG_CSR_I32) {
-          o0 = S.bound[pj * (RB + 1) + pr];
-          o1 = S.bound[pj * (RB + 1) + pr + 1];
-        } else {
-          const FCP_GLOBAL int32_t *csr = as_global(s_col[pj].csr);
-          o0 = csr[b];
-          o1 = csr[b + 1];
-        }
-        lo = min(max(o0, 0), nnz);
-        const int hi = min(max(o1, lo), nnz);
-        cnt = hi - lo;
-        if (form == FCP_FORM_GATHER_SCATTER && cnt > 0) { // the last id of the row wins
-          lo = hi - 1;
-          cnt = 1;
-        }
-      }
-    }
-  }
-  s_lo[tid] = lo;
-  s_cnt[tid] = cnt;
-  const int want = cnt <= LONG_BAG ? cnt : 0;
-  int incl = want;
-#pragma unroll
-  for (int d = 1; d < FCP_WAVE; d <<= 1) {
-    const int up = __shfl_up(incl, d);
-    if (lane >= d) incl += up;
-  }
-  if (lane == FCP_WAVE - 1) s_wsum[wave] = incl;
-  __syncthreads();
-  int offx = incl - want, total = 0;
-#pragma unroll
-  for (int w = 0; w < FCP_WAVES_PER_BLOCK; ++w) {
-    if (w < wave) offx += s_wsum[w];
-    total += s_wsum[w];
-  }
-  const bool staged = want > 0 && offx + want <= CAP;
-  s_offx[tid] = staged ? offx : -1;
-  if (staged)
-    for (int i = 0; i < want; ++i) s_owner[offx + i] = (uint16_t)tid; // fire-and-forget LDS writes
-  __syncthreads();
-
-#if defined(FCP_STAMPS)
-  const unsigned long long t_scan = __builtin_amdgcn_s_memrealtime();
-#endif
-  // ---- phase 1b: one thread per staged id -> table slot offset in LDS ------------------
-  for (int k = tid; k < min(total, CAP); k += FCP_BLOCK_THREADS) {
-    const int p = s_owner[k];
-    const int px = p < NP ? s_offx[p] : -1;
-    if (px >= 0 && px <= k && k < px + s_cnt[p]) { // stale owner entries (unstaged bags) fail this test
-      bool bad;
-      s_ids[k] = fetch_slot_offset<V, SHARDED>(s_col[p / RB], s_lo[p] + (k - px), nullptr, rank, world, bad);
-      // a column that straddles two spans is staged by two blocks: the one holding its first slot counts
-      if (bad && H.bad_ids && s_col[p / RB].out_off >= B.q0 * V) atomicAdd(H.bad_ids, 1ull);
-    }
-  }
-  __syncthreads();
-#if defined(FCP_STAMPS)
-  const unsigned long long t_ids = __builtin_amdgcn_s_memrealtime();
-#endif
-  const int b = B.row_blk + wave;
-  if (q >= B.nslots || b >= B.rows) return;
-
-  // ---- phase 2 ------------------------------------------------------------------------
-  const int j = (int)(my_col - B.first_col);
-  const LdsCol &C = s_col[j];
+__device__ __forceinline__ void ragged_emit(const Hot &H, const LdsCol &C, int q, int b, int plo, int pcnt, int poff,
+                                            const uint32_t *s_ids, int rank, int world) {
   const unsigned form = FCP_F_FORM(C.flags);
   const int dim = C.dim;
   const int e = q * V - C.out_off;
   const float *tb = C.table + e;
-  const int p = j * RB + wave;
-  const int plo = s_lo[p], pcnt = s_cnt[p], poff = s_offx[p];
   VF<V> acc = vzero<V>();
   if (form == FCP_FORM_EXTERNAL) return; // somebody else's slot (ConcatOutputs host input): never written here
 
@@ -1118,6 +795,140 @@ __device__ __forceinline__ void ragged_body(const FcpLaunch &L, int bid, char *s
     for (int t = 0; t < V; ++t) acc.v[t] = acc.v[t] / fc;
   }
   st_out<V>(reinterpret_cast<float *>(H.arena + C.out_base) + e + (int64_t)b * C.out_stride, acc);
+}
+
+struct RaggedLds {
+  static constexpr int RB = FCP_WAVES_PER_BLOCK; // rows per block, one per wave
+  static constexpr int CAPW = 384;               // staged slot offsets per wave (row)
+  LdsCol col[FCP_WAVE];
+  uint32_t ids[RB][CAPW];
+  uint8_t owner[RB][CAPW];                       // staged id slot -> owner lane (= column within the span)
+  int32_t bound[FCP_WAVE * (FCP_WAVES_PER_BLOCK + 1)]; // seg_search: row offsets r0..r0+RB of every column
+};
+
+// LDS accesses of ONE wave execute in program order; the compiler only has to keep that order.
+__device__ __forceinline__ void wave_lds_order() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int V, bool SHARDED>
+__device__ __forceinline__ void ragged_body(const FcpLaunch &L, int bid, char *smem) {
+  constexpr int RB = RaggedLds::RB, CAPW = RaggedLds::CAPW;
+  constexpr int LONG_BAG = 64;
+  RaggedLds &S = *reinterpret_cast<RaggedLds *>(smem);
+  LdsCol *s_col = S.col;
+
+  BlockPos B;
+#if defined(FCP_STAMPS)
+  const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
+#endif
+  const Hot H = load_hot(L);
+  if (!locate_block<RB>(L, H, bid, B)) return;
+  const int tid = threadIdx.x;
+  const int lane = tid & (FCP_WAVE - 1);
+  const int wave = tid >> 6;
+  const int q = B.q0 + lane;
+  const uint32_t my_col = B.map[min(q, B.nslots - 1)];
+  const int world = H.world, rank = H.rank;
+
+  // ---- phase 0 (block) --------------------------------------------------------------------
+  if (tid < B.ncols) s_col[tid] = make_lds_col(H, ld_rec(H.cols + B.first_col + tid), ld_rec(H.dyn + B.first_col + tid));
+  __syncthreads();
+#if defined(FCP_STAMPS)
+  const unsigned long long t_desc = __builtin_amdgcn_s_memrealtime();
+#endif
+
+  // ---- phase 1a' (block): segment-id columns without a pre-pass: RB+1 row offsets per column ---
+  if (H.seg_search) {
+    for (int u = tid; u < B.ncols * (RB + 1); u += FCP_BLOCK_THREADS) {
+      const LdsCol &c = s_col[u / (RB + 1)];
+      const unsigned sk = FCP_F_SEGKIND(c.flags), f = FCP_F_FORM(c.flags);
+      int v = 0;
+      if ((sk == FCP_SEG_IDS_I32 || sk == FCP_SEG_IDS_I64) && (f == FCP_FORM_SEGMENT_REDUCE || f == FCP_FORM_GATHER_SCATTER))
+        v = seg_lower_bound(reinterpret_cast<const char *>(c.csr), sk == FCP_SEG_IDS_I64, (int)(c.flags >> 16), c.nnz,
+                            min(B.row_blk + u % (RB + 1), B.rows), B.rows);
+      S.bound[u] = v;
+    }
+    __syncthreads();
+  }
+#if defined(FCP_STAMPS)
+  const unsigned long long t_seg = __builtin_amdgcn_s_memrealtime();
+#endif
+  const int b = B.row_blk + wave;
+  if (b >= B.rows) return; // wave-uniform; no block barrier follows
+
+  // ---- phase 1a (wave): range of (column lane, row b), slices of the wave's offset tile ---------------
+  int lo = 0, cnt = 0;
+  if (lane < B.ncols) {
+    const unsigned form = FCP_F_FORM(s_col[lane].flags);
+    if (form == FCP_FORM_GATHER) {
+      lo = b;
+      cnt = 1;
+    } else if (form == FCP_FORM_SEGMENT_REDUCE || form == FCP_FORM_GATHER_SCATTER) {
+      const int nnz = s_col[lane].nnz;
+      int o0, o1;
+      if (H.seg_search && FCP_F_SEGKIND(s_col[lane].flags) != FCP_SEG_CSR_I32) {
+        o0 = S.bound[lane * (RB + 1) + wave];
+        o1 = S.bound[lane * (RB + 1) + wave + 1];
+      } else {
+        const FCP_GLOBAL int32_t *csr = as_global(s_col[lane].csr);
+        o0 = csr[b];
+        o1 = csr[b + 1];
+      }
+      lo = min(max(o0, 0), nnz);
+      const int hi = min(max(o1, lo), nnz);
+      cnt = hi - lo;
+      if (form == FCP_FORM_GATHER_SCATTER && cnt > 0) { // the last id of the row wins
+        lo = hi - 1;
+        cnt = 1;
+      }
+    }
+  }
+  const int want = cnt <= LONG_BAG ? cnt : 0;
+  int incl = want;
+#pragma unroll
+  for (int d = 1; d < FCP_WAVE; d <<= 1) {
+    const int up = __shfl_up(incl, d);
+    if (lane >= d) incl += up;
+  }
+  const int total = __shfl(incl, FCP_WAVE - 1);
+  const int offx = incl - want;
+  const bool staged = want > 0 && offx + want <= CAPW;
+  const int sx = staged ? offx : -1;
+  uint8_t *ow = S.owner[wave];
+  uint32_t *wi = S.ids[wave];
+  if (staged)
+    for (int i = 0; i < want; ++i) ow[offx + i] = (uint8_t)lane; // fire-and-forget LDS writes
+  wave_lds_order();
+#if defined(FCP_STAMPS)
+  const unsigned long long t_scan = __builtin_amdgcn_s_memrealtime();
+#endif
+
+  // ---- phase 1b (wave): one lane per staged id -> table slot offset in the wave's tile -----------------
+  const int limit = min(total, CAPW);
+  for (int base = 0; base < limit; base += FCP_WAVE) { // uniform trip count: the cross-lane reads need every lane
+    const int k = base + lane;
+    const int p = k < limit ? (int)ow[k] : 0;
+    const int px = __shfl(sx, p), pc = __shfl(cnt, p), pl = __shfl(lo, p);
+    if (k < limit && px >= 0 && px <= k && k < px + pc) { // entries of unstaged bags fail this test
+      bool bad;
+      wi[k] = fetch_slot_offset<V, SHARDED>(s_col[p], pl + (k - px), nullptr, rank, world, bad);
+      // a column that straddles two spans is staged by two blocks: the one holding its first slot counts
+      if (bad && H.bad_ids && s_col[p].out_off >= B.q0 * V) atomicAdd(H.bad_ids, 1ull);
+    }
+  }
+  wave_lds_order();
+#if defined(FCP_STAMPS)
+  const unsigned long long t_ids = __builtin_amdgcn_s_memrealtime();
+#endif
+
+  // ---- phase 2 (wave): range and slice of my column come from its owner lane ----------------------------
+  const int j = (int)(my_col - B.first_col);
+  const int plo = __shfl(lo, j), pcnt = __shfl(cnt, j), poff = __shfl(sx, j);
+  if (q >= B.nslots) return;
+  ragged_emit<V, SHARDED>(H, s_col[j], q, b, plo, pcnt, poff, wi, rank, world);
 #if defined(FCP_STAMPS)
   if (L.stamps && tid == 0) { // wave 0 = first row of the block
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1155,21 +966,13 @@ struct FcpHybridLaunch {
 
 template <int V, int R, bool SHARDED>
 __global__ void __launch_bounds__(FCP_BLOCK_THREADS) fcp_hybrid_kernel(const FcpHybridLaunch H) {
-#if !defined(FCP_DENSE_WAVE)
   constexpr size_t kSmem = sizeof(RaggedLds) > sizeof(DenseLds<R>) ? sizeof(RaggedLds) : sizeof(DenseLds<R>);
-#else
-  constexpr size_t kSmem = sizeof(RaggedLds);
-#endif
   __shared__ __attribute__((aligned(16))) char smem[kSmem];
   const int bid = blockIdx.x;
   if (bid < H.ragged_blocks) {
     ragged_body<V, SHARDED>(H.ragged, bid, smem); // the longer-running blocks are dispatched first
   } else {
-#if !defined(FCP_DENSE_WAVE)
     dense_body<V, R, SHARDED>(H.dense, bid - H.ragged_blocks, smem);
-#else
-    dense_wave_body<V, R, SHARDED>(H.dense, bid - H.ragged_blocks);
-#endif
   }
 }
 

@@ -22,8 +22,9 @@ What follows the reference, and where:
 * the value node of a concat input is found through trailing ``Reshape`` /
   ``ExpandDims`` / ``Squeeze`` nodes — ``FindFCOutputs`` ``cuda_emitter.cc:1060-1069``;
 * dispatch on the value node's op — ``EmitSubgraphCode`` ``:1096-1152``;
-* index inputs are followed through ``Reshape``-likes, ``Cast``, ``Bucketize`` and the
-  ``[:, 0:1]`` ``StridedSlice`` of a 2-D index matrix, and end at the first other node,
+* index inputs are followed through ``Reshape``-likes, ``Cast``, ``Bucketize``, the
+  ``[:, 0:1]`` ``StridedSlice`` of a 2-D index matrix and a ``SparseReshape`` that provably
+  keeps ``[rows, k]`` (``:1874-1916`` restricted to that case), and end at the first other node,
   whose tensor becomes a ConcatInputs input — ``EmitInputInline`` ``:1769-1949``;
 * tables become FeatureColumnProcess device inputs, deduplicated by tensor name —
   ``:1262-1279``;
@@ -213,6 +214,13 @@ class PlanBuilder:
         g = self.g
         if port != 0:
             raise Unsupported("not an inlinable op")
+        if node.op == "SparseReshape":
+            # output_indices of a reshape that provably keeps [rows, k]: read the input indices in place.
+            # Anything else (rank change, unprovable shapes) ends the walk: TensorFlow computes the op and
+            # its output tensor is shipped, as for any op the reference does not inline (:1924-1933).
+            if not self._sparse_reshape_is_identity(node):
+                raise Unsupported("SparseReshape is not provably the identity on [rows, k] indices")
+            return self.trace_index(*g.input(node, 0))
         if node.op in RESHAPE_LIKE or node.op == "Identity":
             return self.trace_index(*g.input(node, 0))          # flat element index unchanged
         if node.op == "Cast":
@@ -255,6 +263,21 @@ class PlanBuilder:
             src.stride *= int(in_shape[1])
             return src
         raise Unsupported("not an inlinable op")
+
+    def _sparse_reshape_is_identity(self, node) -> bool:
+        """``SparseReshape(indices [nnz, 2], shape [2], new_shape [2])`` with ``new_shape[1]`` provably the
+        same number as ``shape[1]``: then ``row' = (row * shape[1] + col) / new_shape[1] = row`` and
+        ``col' = col`` for every element (``0 <= col < shape[1]``), so the op changes nothing — the case the
+        reference's flat-index algebra (``cuda_emitter.cc:1874-1916``) reduces to for the 2-D SparseTensors
+        ``safe_embedding_lookup_sparse`` produces."""
+        g = self.g
+        shape, new = g.input(node, 1), g.input(node, 2)
+        if g.static_shape(*shape) != [2] or g.static_shape(*new) != [2]:
+            return False
+        a, b = g.elem_source(*shape, 1), g.elem_source(*new, 1)
+        if a is None or a != b:
+            return False
+        return not (a[0] == "const" and a[1] <= 0)          # a literal -1 would be inferred at run time
 
     def _ids_operand(self, node, port: int) -> Tuple[int, int, Optional[np.ndarray]]:
         src = self.trace_index(node, port)

@@ -114,6 +114,8 @@ class GraphView:
             return a[key].type
         if op == "Bucketize":
             return P.DT_INT32
+        if op == "SparseReshape":
+            return P.DT_INT64
         if op in ("Unique",):
             return a["T"].type if port == 0 else a["out_idx"].type
         if "T" in a:
@@ -198,7 +200,97 @@ class GraphView:
             p = self.static_shape(*self.input(node, 0), _depth + 1)
             i = self.static_shape(*self.input(node, 1), _depth + 1)
             return None if p is None or i is None else i + p[1:]
+        if op == "SparseReshape":
+            # (output_indices [nnz, rank(new_shape)], output_shape [rank(new_shape)])
+            idx = self.static_shape(*self.input(node, 0), _depth + 1)
+            new = self.static_shape(*self.input(node, 2), _depth + 1)
+            if new is None or len(new) != 1 or new[0] is None:
+                return None
+            return [idx[0] if idx else None, new[0]] if port == 0 else [new[0]]
+        if op == "Pack":
+            n = len(self.data_inputs(node))
+            first = self.static_shape(*self.input(node, 0), _depth + 1)
+            axis = int(node.attr["axis"].i) if "axis" in node.attr else 0
+            return None if first is None or axis != 0 else [n] + first
+        if op in ("Prod", "Sum", "Max", "Min"):
+            src = self.static_shape(*self.input(node, 0), _depth + 1)
+            ax = self.const_array(*self.input(node, 1))
+            if src is None or ax is None or ("keep_dims" in node.attr and node.attr["keep_dims"].b):
+                return None
+            axes = {int(a) + len(src) if int(a) < 0 else int(a) for a in ax.reshape(-1)}
+            return [d for k, d in enumerate(src) if k not in axes]
         return None
+
+    # ---- where does one element of a small integer tensor come from? ----------------
+    def elem_source(self, node, port: int, k: int, _depth: int = 0):
+        """Element ``k`` (flat index) of a shape-like tensor, traced to ``("const", value)`` or
+        ``("elem", tensor, index)`` — a plain copy of one element of another tensor — or None when
+        it is computed.  Lets the plan builder prove two shape entries equal without a symbolic
+        engine (the reference asks SymEngine, ``symbolic_shape/``)."""
+        if _depth > 32:
+            return None
+        op = node.op
+        if op == "Const" and port == 0:
+            v = tensor_to_numpy(node.attr["value"].tensor).reshape(-1)
+            return ("const", int(v[k])) if k < v.size else None
+        if op in ("Identity", "StopGradient", "Reshape", "Squeeze", "ExpandDims") and port == 0:
+            return self.elem_source(*self.input(node, 0), k, _depth + 1)       # flat order unchanged
+        if op == "Cast" and port == 0:
+            ints = (P.DT_INT32, P.DT_INT64)
+            if node.attr["SrcT"].type in ints and node.attr["DstT"].type in ints:
+                return self.elem_source(*self.input(node, 0), k, _depth + 1)
+            return None
+        if op == "Pack" and port == 0:
+            if ("axis" in node.attr and node.attr["axis"].i != 0) or k >= len(self.data_inputs(node)):
+                return None
+            src, sp = self.input(node, k)
+            return self.elem_source(src, sp, 0, _depth + 1) if self.static_shape(src, sp) == [] else None
+        if op == "ConcatV2" and port == 0:
+            ins = self.data_inputs(node)
+            for i in range(len(ins) - 1):
+                src, sp = self.input(node, i)
+                shape = self.static_shape(src, sp)
+                if shape is None or len(shape) != 1 or shape[0] is None:
+                    return None
+                if k < shape[0]:
+                    return self.elem_source(src, sp, k, _depth + 1)
+                k -= shape[0]
+            return None
+        if op == "StridedSlice" and port == 0:
+            spec = self.strided_slice_spec(node)
+            src, sp = self.input(node, 0)
+            shape = self.static_shape(src, sp)
+            if spec is None or shape is None or len(shape) != 1 or len(spec["begin"]) != 1 or spec["strides"] != [1]:
+                return None
+            if spec["ellipsis_mask"] or spec["new_axis_mask"]:
+                return None
+            b = 0 if spec["begin_mask"] & 1 else spec["begin"][0]
+            if b < 0:
+                if shape[0] is None:
+                    return None
+                b += shape[0]
+            return self.elem_source(src, sp, b + k, _depth + 1)
+        if op == "GatherV2" and port == 0:
+            idx = self.const_array(*self.input(node, 1))
+            ax = self.const_array(*self.input(node, 2))
+            src, sp = self.input(node, 0)
+            shape = self.static_shape(src, sp)
+            if idx is None or ax is None or int(ax.reshape(-1)[0]) != 0 or shape is None or len(shape) != 1:
+                return None
+            i = int(idx.reshape(-1)[k]) if k < idx.size else None
+            if i is None or (i < 0 and shape[0] is None):
+                return None
+            return self.elem_source(src, sp, i + shape[0] if i < 0 else i, _depth + 1)
+        if op in ("Prod", "Sum", "Max", "Min") and port == 0:
+            src, sp = self.input(node, 0)
+            if self.static_shape(src, sp) == [1] and k == 0:                   # a reduction of one element is that element
+                return self.elem_source(src, sp, 0, _depth + 1)
+            return None
+        if op == "SparseReshape" and port == 1:                                # output_shape = new_shape (no -1 handled)
+            return self.elem_source(*self.input(node, 2), k, _depth + 1)
+        if op in ("Placeholder", "PlaceholderWithDefault") or port != 0 or not self.data_inputs(node):
+            return ("elem", tensor_name(node.name, port), k)
+        return ("elem", tensor_name(node.name, port), k) if op in ("Shape",) else None
 
     def strided_slice_spec(self, node) -> Optional[dict]:
         vals = [self.const_array(*self.input(node, k)) for k in (1, 2, 3)]

@@ -336,3 +336,63 @@ def random_model(seed):
                    Tidx=("type", P.DT_INT32))
         fetches.append(g.node(f"output_{grp}", "Identity", [c], T=("type", P.DT_FLOAT)))
     return g.gd, feeds, variables, fetches, kinds
+
+
+def sparse_reshape_model(B=23, seed=0):
+    """Two pooled columns whose SparseTensor indices pass through ``SparseReshape`` before ``[:, 0]``, the
+    way ``safe_embedding_lookup_sparse`` flattens its ids (``tf.sparse.reshape(ids, [prod(shape[:-1]),
+    shape[-1]])``): column ``p`` reshapes [B, L] -> [B, L] (provably the identity: the plan builder reads the
+    input indices in place), column ``q`` reshapes [B, 2L] -> [2B, L] (not the identity: the op stays in
+    TensorFlow and its output is shipped); each feeds its own ConcatV2 next to a one-hot column.
+    Returns (graph_def, feeds, variables, fetches)."""
+    rng = np.random.default_rng(seed)
+    g = GB()
+    feeds, variables = {}, {}
+    ins = []
+    for name, vocab, dim, identity in (("p", 131, 16, True), ("q", 89, 8, False)):
+        rows, L = B, 6
+        lens = rng.integers(0, L + 1, size=rows)
+        nnz = int(lens.sum())
+        width = L if identity else 2 * L
+        cols = np.concatenate([np.sort(rng.choice(width, size=l, replace=False)) for l in lens]) if nnz else np.zeros(0, np.int64)
+        idx = np.stack([np.repeat(np.arange(rows), lens), cols], 1).astype(np.int64).reshape(nnz, 2)
+        t = g.variable(f"input_layer/{name}_embedding/embedding_weights", vocab, dim)
+        variables[t] = rng.standard_normal((vocab, dim)).astype(np.float32)
+        g.placeholder(f"{name}/values", np.int64, [-1])
+        g.placeholder(f"{name}/indices", np.int64, [-1, 2])
+        g.placeholder(f"{name}/dense_shape", np.int64, [2])
+        feeds[f"{name}/values"] = rng.integers(0, vocab, size=nnz).astype(np.int64)
+        feeds[f"{name}/indices"] = idx
+        feeds[f"{name}/dense_shape"] = np.asarray([rows, width], np.int64)
+        one = lambda s, v: g.const(f"{name}/{s}", np.asarray([v], np.int32))
+        # new_shape = [prod(shape[:-1]) (x2 for q), shape[-1] (/2 for q)]
+        g.node(f"{name}/lead", "StridedSlice", [f"{name}/dense_shape", one("lb", 0), one("le", 1), one("ls", 1)],
+               T=("type", P.DT_INT64), Index=("type", P.DT_INT32))
+        g.const(f"{name}/axis0", np.asarray([0], np.int32))
+        g.node(f"{name}/rows", "Prod", [f"{name}/lead", f"{name}/axis0"], T=("type", P.DT_INT64), Tidx=("type", P.DT_INT32))
+        g.node(f"{name}/last", "StridedSlice", [f"{name}/dense_shape", one("tb", 1), one("te", 2), one("ts", 1)],
+               T=("type", P.DT_INT64), Index=("type", P.DT_INT32), shrink_axis_mask=1)
+        if identity:
+            g.node(f"{name}/new_shape", "Pack", [f"{name}/rows", f"{name}/last"], N=2, T=("type", P.DT_INT64), axis=0)
+        else:
+            g.const(f"{name}/new_shape", np.asarray([2 * rows, L], np.int64))
+        g.node(f"{name}/SparseReshape", "SparseReshape", [f"{name}/indices", f"{name}/dense_shape", f"{name}/new_shape"])
+        seg = g.slice_col0(f"{name}/added_strided_slice", f"{name}/SparseReshape", shrink=True)
+        # num_segments = output_shape[0] of the reshape
+        g.node(f"{name}/num_segments", "StridedSlice", [f"{name}/SparseReshape:1", one("nb", 0), one("ne", 1), one("ns", 1)],
+               T=("type", P.DT_INT64), Index=("type", P.DT_INT32), shrink_axis_mask=1)
+        pooled = g.node(f"{name}/SparseSegmentSum_with_num_segments", "SparseSegmentSumWithNumSegments",
+                        [t, f"{name}/values", seg, f"{name}/num_segments"], T=("type", P.DT_FLOAT), Tidx=("type", P.DT_INT64),
+                        Tsegmentids=("type", P.DT_INT64), Tnumsegments=("type", P.DT_INT64))
+        # a dense companion per concat (a ConcatV2 of one input is not a converging point)
+        d = g.variable(f"input_layer/{name}_dense_embedding/embedding_weights", 40, 4)
+        variables[d] = rng.standard_normal((40, 4)).astype(np.float32)
+        n_rows = rows if identity else 2 * rows             # q's reshape doubles the rows
+        g.placeholder(f"{name}/dense_ids", np.int64, [-1])
+        feeds[f"{name}/dense_ids"] = rng.integers(0, 40, size=n_rows).astype(np.int64)
+        dense = g.gather(f"input_layer/{name}_dense_embedding/GatherDense", d, f"{name}/dense_ids", np.int64)
+        g.const(f"{name}/concat/axis", np.asarray(1, np.int32))
+        g.node(f"{name}_layer/concat", "ConcatV2", [pooled, dense, f"{name}/concat/axis"], N=2, T=("type", P.DT_FLOAT),
+               Tidx=("type", P.DT_INT32))
+        ins.append(g.node(f"output_{name}", "Identity", [f"{name}_layer/concat"], T=("type", P.DT_FLOAT)))
+    return g.gd, feeds, variables, ins

@@ -399,6 +399,15 @@ def test_random_graphdefs_to_hip_path(torch_cuda, tmp_path, seed, host_concat):
     _graph_through_hip(torch_cuda, gd, feeds, variables, fetches, tmp_path, host_concat)
 
 
+def test_sparse_reshape_graph_to_hip_path(torch_cuda, tmp_path):
+    """a12 on the GPU: segment ids read through an identity SparseReshape (inlined) and from the output of
+    one that is not (shipped), two concat groups with different row counts."""
+    from graph_fixtures import sparse_reshape_model
+    gd, feeds, variables, fetches = sparse_reshape_model(B=45, seed=4)
+    built = _graph_through_hip(torch_cuda, gd, feeds, variables, fetches, tmp_path)
+    assert built.spec.n_groups == 2 and [c.form for c in built.spec.columns] == [2, 1, 2, 1]
+
+
 def test_concat_outputs_host_inputs_into_external_slots(torch_cuda, oracle):
     """Addons>ConcatOutputs with N > 0 (concat_outputs_op_gpu.cu.cc:186-216): the plan reserves
     FORM_EXTERNAL slots, the fused kernels (dense AND ragged spans) leave them untouched, and
@@ -725,6 +734,36 @@ def test_wide_columns_and_large_boundary_lists(torch_cuda, oracle):
     sym = np.asarray([B], np.int32)
     out, packed, _ = run_gpu(torch_cuda, mixed, inputs + [ids, csr], tables, sym)
     assert_equal_oracle(oracle, mixed, packed, tables, sym, out)
+
+
+def test_pooled_vectors_vs_the_reference_kernels_own_orders(torch_cuda, oracle):
+    """North star: pooled vectors within 1e-5 of the reference.  The HIP path adds in id order (= TF-CPU);
+    the reference's GPU kernels add in block-scan order for dim <= 20 (cuda_emitter.cc:348-661) and in 8
+    strided partials + an LDS tree for dim > 20 (:820-962).  Both orders are restated in the oracle
+    (orc_sparse_segment_reduce_refscan / _ref8x8): the HIP result must sit within 1e-5 of either."""
+    from recom_amd import synth
+    torch = torch_cuda
+    m = synth.model_ragged(columns=48, vocab=3000, batch=120, dims=(4, 8, 12, 16, 20, 32, 64), max_len=10)
+    tabs_np = m.numpy_tables()
+    req = m.make_request(9)
+    out, packed, _ = run_gpu(torch, m.spec, req.inputs, tabs_np, req.symbols)
+    got = out.groups[0].cpu().numpy()
+    offs = m.spec.column_offsets()
+    small = large = 0
+    for k, c in enumerate(m.spec.columns):
+        ids, csr = req.inputs[c.ids_input], req.inputs[c.seg_input]
+        mean = c.combiner == 2
+        if c.dim <= 20:
+            rows = np.repeat(np.arange(120), np.diff(csr))
+            ref = oracle.sparse_segment_reduce_refscan(tabs_np[c.table_input], ids, rows, 120, mean)
+            small += 1
+        else:
+            ref, _ = oracle.sparse_segment_reduce(tabs_np[c.table_input], ids, csr, mean, ref_order=True)
+            empty = np.diff(csr) == 0
+            ref[empty] = 0.0                   # the reference's dim > 20 template divides 0 / 0 on empty rows; TF gives zeros
+            large += 1
+        assert np.abs(got[:, offs[k]:offs[k] + c.dim] - ref).max() < 1e-5, f"column {k} (dim {c.dim})"
+    assert small and large
 
 
 def test_bucketize_tiers_are_exact(torch_cuda, oracle):

@@ -11,7 +11,7 @@ import sys
 import numpy as np
 import pytest
 
-from graph_fixtures import MICRO_BOUNDARIES, canonical_model, microbenchmark_model, random_model
+from graph_fixtures import MICRO_BOUNDARIES, canonical_model, microbenchmark_model, random_model, sparse_reshape_model
 from recom_amd import plan as PL
 from recom_amd.graph import Unsupported, build_plan, parse_graphdef, rewrite_graph
 from recom_amd.graph import tf_proto as P
@@ -256,6 +256,47 @@ def test_random_graphs(oracle, tmp_path, seed, host_concat):
     got = GraphEvaluator(out, variables, oracle_ops(oracle, built, variables)).run(fetches, feeds)
     for e, o in zip(expected, got):
         assert e.shape == o.shape and np.array_equal(e, o)
+
+
+@pytest.mark.parametrize("B,seed", [(23, 0), (1, 1), (70, 2)])
+def test_sparse_reshape_inlined_when_it_is_the_identity(oracle, tmp_path, B, seed):
+    """a12, SparseReshape (cuda_emitter.cc:1874-1916): a reshape that provably keeps [rows, k] is read
+    through (the kernel takes row ids from the ORIGINAL indices, stride 2); one that is not stays in
+    TensorFlow and its output tensor is what ConcatInputs ships.  Either way the rewritten graph equals
+    the original bit for bit."""
+    from tf_graph_eval import GraphEvaluator
+    gd, feeds, variables, fetches = sparse_reshape_model(B=B, seed=seed)
+    expected = GraphEvaluator(gd, variables).run(fetches, feeds)
+    assert expected[0].shape == (B, 20) and expected[1].shape == (2 * B, 12)
+    built = build_plan(gd)
+    c = built.spec.columns
+    assert [x.form for x in c] == [2, 1, 2, 1] and not built.skipped
+    assert built.host_inputs[c[0].seg_input] == ("p/indices", P.DT_INT64, 2) and c[0].seg_stride == 2      # inlined
+    assert built.host_inputs[c[2].seg_input] == ("q/SparseReshape", P.DT_INT64, 2) and c[2].seg_stride == 2  # computed by TF
+    assert [s.tensor for s in built.symbols] == ["p/num_segments", "q/num_segments"]
+    path = str(tmp_path / "m.fcp")
+    save_plan(built.spec, path)
+    out = parse_graphdef(rewrite_graph(gd, built, path).SerializeToString())
+    names = {n.name for n in out.node}
+    assert "q/SparseReshape" in names                       # still needed: its indices are shipped
+    assert "p/SparseReshape" in names                       # kept for num_segments (output 1) only ...
+    assert "p/added_strided_slice" not in names             # ... its indices output is no longer read
+    got = GraphEvaluator(out, variables, oracle_ops(oracle, built, variables)).run(fetches, feeds)
+    for e, o in zip(expected, got):
+        assert np.array_equal(e, o)
+
+
+def test_elem_source_proofs():
+    """GraphView.elem_source: which shape entries are provably the same number."""
+    from recom_amd.graph.view import GraphView
+    gd, *_ = sparse_reshape_model()
+    g = GraphView(gd)
+    n = g.nodes
+    assert g.elem_source(n["p/new_shape"], 0, 1) == ("elem", "p/dense_shape", 1) == g.elem_source(n["p/dense_shape"], 0, 1)
+    assert g.elem_source(n["p/new_shape"], 0, 0) == ("elem", "p/dense_shape", 0)        # Prod over one element
+    assert g.elem_source(n["q/new_shape"], 0, 1) == ("const", 6)
+    assert g.elem_source(n["p/SparseReshape"], 1, 0) == ("elem", "p/dense_shape", 0)
+    assert g.static_shape(n["p/SparseReshape"], 0) == [None, 2] and g.static_shape(n["p/SparseReshape"], 1) == [2]
 
 
 def test_nothing_to_fuse():

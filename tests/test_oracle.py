@@ -106,6 +106,38 @@ def test_segment_reduce_vs_embedding_bag(oracle, mean, dim):
         assert np.array_equal(out[1], W[ids[0]]) and np.array_equal(ref[1], W[ids[0]])
 
 
+@pytest.mark.parametrize("mean", [False, True])
+@pytest.mark.parametrize("dim", [4, 8, 12, 16, 20])
+def test_reference_block_scan_order_dim_le_20(oracle, mean, dim):
+    """The reference's dim <= 20 template adds in CUB block-scan order (64-id tiles, Kogge-Stone inside each
+    32-lane warp, warp aggregate, carry across tiles: cuda_emitter.cc:348-661, :1542-1618), restated in
+    orc_sparse_segment_reduce_refscan.  Against the sequential id order of the oracle (= the HIP path, =
+    TF-CPU) it differs by fp32 reassociation only; segments of one or two ids are identical in any order;
+    the restatement's own tile logic (segments crossing tiles, empty rows, leading empty rows, nnz a
+    multiple of 64) is checked against float64."""
+    rng = np.random.default_rng(100 * dim + mean)
+    W = rng.standard_normal((400, dim)).astype(np.float32)
+    for lens in (rng.integers(0, 12, 90), np.asarray([0, 0, 1, 2, 63, 64, 65, 130, 0, 1, 0]), np.full(32, 2), np.asarray([0, 128]),
+                 np.asarray([3]), np.zeros(5, np.int64)):
+        ids = rng.integers(0, 400, int(lens.sum()))
+        rows = np.repeat(np.arange(len(lens)), lens)
+        off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        seq, _ = oracle.sparse_segment_reduce(W, ids, off, mean)
+        ref = oracle.sparse_segment_reduce_refscan(W, ids, rows, len(lens), mean)
+        truth = O.np_sparse_segment_reduce(W, ids, off, mean)
+        tol = 1e-5 if mean else 5e-5                       # |sum| of 130 N(0,1) rows reaches ~30: one ulp there is 2e-6
+        assert np.abs(ref - truth).max(initial=0) < tol and np.abs(ref - seq).max(initial=0) < tol
+        short = lens <= 2
+        assert np.array_equal(ref[short], seq[short])      # a + b in either order; empty rows are zeros
+        assert not ref[lens == 0].any()
+    # the order really is the tree, not the sequence: a long bag of badly conditioned values differs in the last bits
+    W2 = (rng.standard_normal((400, dim)) * 10.0 ** rng.integers(-3, 4, (400, 1))).astype(np.float32)
+    ids = rng.integers(0, 400, 64)
+    seq, _ = oracle.sparse_segment_reduce(W2, ids, np.asarray([0, 64], np.int32), False)
+    ref = oracle.sparse_segment_reduce_refscan(W2, ids, np.zeros(64, np.int64), 1, False)
+    assert not np.array_equal(seq, ref) and np.allclose(seq, ref, rtol=1e-4, atol=1e-2)
+
+
 def test_gather_scatter(oracle):
     W = np.arange(40, dtype=np.float32).reshape(10, 4)
     out, bad = oracle.gather_scatter_rows(W, [1, 2, 3, 9], [0, 2, 2, 5], 7)
