@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define FCP_ABI_VERSION 1
+#define FCP_ABI_VERSION 2 /* 2: id transforms (fcp_column_desc_t::xform_*), external slots, placement gate */
 
 /* ---- status codes (reference: void returns + CubDebugExit/exit(1)) ------ */
 enum {
@@ -97,6 +97,27 @@ enum {
   FCP_IDS_I32 = 0,           /* int32 ids                                    */
   FCP_IDS_I64 = 1,           /* int64 ids (reference truncates to int, :270) */
   FCP_IDS_F32_BUCKETIZE = 2  /* float32 values -> Bucketize(boundaries), :233-247, :1798-1835 */
+};
+
+/* Id transform, applied to every id after it has been decoded (raw integer or
+ * Bucketize result) and before the lookup: what the CPU ops the
+ * reference's PreLookupOptimizer puts in front of the lookup compute
+ * (graph_optimizers/pre_lookup_optimizer.cc:596-654).  The interval set is a list of
+ * CLOSED integer intervals [lo_i, hi_i] — the ops' left_boundaries / right_boundaries
+ * attrs.  An id is "in" when lo_i <= id && id <= hi_i for some i.  (The reference's
+ * kernels test `x >= l || x <= r`, select_value_ops.cc:35-41 — true for every x, so
+ * they filter nothing; this is the intended test, SURVEY.md App. A.) */
+enum {
+  FCP_XFORM_NONE = 0,
+  /* Addons>SelectValue (custom_ops/select_value/select_value_ops.cc:33-56):
+   * id' = in ? id : substitute */
+  FCP_XFORM_SELECT = 1,
+  /* Addons>GatherIndiceValue / Addons>GatherValueGenIndice
+   * (gather_indice_value_ops.cc:33-78, gather_value_gen_indice_ops.cc:33-67): ids that
+   * are not "in" are DROPPED: they add nothing to their row and do not count in a
+   * mean; a row left without ids is zeros.  Not available with row sharding together
+   * with FCP_COMBINER_MEAN (fcp_shard_finalize divides by the unfiltered row length). */
+  FCP_XFORM_FILTER = 2
 };
 
 /* How segment membership of the id stream is given. */
@@ -157,6 +178,11 @@ typedef struct fcp_column_desc {
   int32_t concat_group; /* which ConcatV2 this column feeds, 0..n_groups-1    */
   int32_t concat_slot;  /* position inside the group (ConcatOutputs
                            device_concat_indices / host_concat_indices)       */
+  int32_t xform_mode;   /* FCP_XFORM_* (lookup forms only)                    */
+  int32_t xform_n;      /* number of closed intervals                         */
+  const int64_t *xform_lo; /* host int64[xform_n], copied at plan creation    */
+  const int64_t *xform_hi;
+  int64_t xform_substitute; /* FCP_XFORM_SELECT                               */
 } fcp_column_desc_t;
 
 typedef struct fcp_plan_desc {
@@ -246,7 +272,9 @@ int fcp_plan_create(const fcp_plan_desc_t *desc, fcp_plan_t **plan);
  *   fcp_plan 1 / layout L / groups G symbols S device_inputs D / host_inputs N,
  *   N lines "rank elem_size" / columns C, C lines "form combiner dim id_source
  *   vocab table_input ids_input seg_input seg_kind seg_stride rows_source
- *   rows_arg concat_group concat_slot n_boundaries b0 b1 ...".
+ *   rows_arg concat_group concat_slot n_boundaries b0 b1 ..." — version 2 files
+ *   ("fcp_plan 2") append "xform_mode xform_n substitute lo0 hi0 lo1 hi1 ..." to
+ *   every column line.
  * `flags`: fcp_plan_desc_t::flags.  FCP_ERR_INVALID_ARGUMENT for a missing or
  * malformed file. */
 int fcp_plan_create_from_file(const char *path, int32_t device, uint32_t flags,

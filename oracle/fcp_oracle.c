@@ -421,6 +421,13 @@ static void load_ids(const orc_column_t *c, const int8_t *src, int64_t n, int64_
   }
 }
 
+/* The interval test of the id-filter ops (select_value_ops.cc:35-41 and siblings), as intended. */
+static int xform_in(const orc_column_t *c, int64_t x) {
+  for (int32_t i = 0; i < c->xform_n; ++i)
+    if (x >= c->xform_lo[i] && x <= c->xform_hi[i]) return 1;
+  return 0;
+}
+
 static void load_seg(const orc_column_t *c, const int8_t *src, int64_t n, int64_t *seg) {
   for (int64_t i = 0; i < n; ++i) {
     if (c->seg_kind == ORC_SEG_IDS_I32) {
@@ -487,9 +494,20 @@ static int64_t process_column(const orc_plan_t *p, int32_t k, const int8_t *blob
     return 0;
   }
 
-  const int64_t nnz = input_numel(p, c->ids_input, shapes);
+  int64_t nnz = input_numel(p, c->ids_input, shapes);
   int64_t *ids = (int64_t *)malloc(sizeof(int64_t) * (size_t)(nnz + 1));
   load_ids(c, blob + offsets[c->ids_input], nnz, ids);
+  /* the CPU id ops that sit in front of the lookup, applied here as they are in the graph.
+   * SelectValue: elementwise.  GatherIndiceValue / GatherValueGenIndice: the (index, value) pairs that fail
+   * the test are removed — `keep` marks the survivors; the segment structure is compacted below. */
+  uint8_t *keep = NULL;
+  if (c->xform_mode == ORC_XFORM_SELECT) {
+    for (int64_t i = 0; i < nnz; ++i)
+      if (!xform_in(c, ids[i])) ids[i] = c->xform_substitute;
+  } else if (c->xform_mode == ORC_XFORM_FILTER) {
+    keep = (uint8_t *)malloc((size_t)nnz + 1);
+    for (int64_t i = 0; i < nnz; ++i) keep[i] = (uint8_t)xform_in(c, ids[i]);
+  }
   /* count globally-bad ids once, then map to the local shard */
   if (sharded) {
     for (int64_t i = 0; i < nnz; ++i)
@@ -499,8 +517,16 @@ static int64_t process_column(const orc_plan_t *p, int32_t k, const int8_t *blob
   const float *table = tables[c->table_input];
 
   if (c->form == ORC_FORM_GATHER) {
+    /* GatherValueGenIndice emits index [i] for every surviving value i and the lookup scatters the rows
+     * back (form 3); with one value per row that is: a dropped value leaves a zero row */
     int64_t b = orc_gather_rows(table, vocab_local, c->dim, ids, nnz, out, width);
     if (!sharded) bad += b;
+    if (keep)
+      for (int64_t i = 0; i < nnz; ++i)
+        if (!keep[i]) {
+          memset(out + i * width, 0, 4 * (size_t)c->dim);
+          if (!sharded && (ids[i] < 0 || ids[i] >= vocab_local)) --bad; /* never reached the lookup */
+        }
   } else {
     int64_t *seg = NULL;
     int32_t *offs = (int32_t *)malloc(sizeof(int32_t) * (size_t)(rows + 1));
@@ -510,6 +536,23 @@ static int64_t process_column(const orc_plan_t *p, int32_t k, const int8_t *blob
       seg = (int64_t *)malloc(sizeof(int64_t) * (size_t)(nnz + 1));
       load_seg(c, blob + offsets[c->seg_input], nnz, seg);
       orc_segment_offsets(seg, nnz, rows, offs);
+    }
+    if (keep) { /* compact ids (and row ids) in place; the row offsets follow the survivors */
+      int64_t w = 0, src = 0;
+      for (int64_t r = 0; r < rows; ++r) {
+        int64_t lo = offs[r] < 0 ? 0 : offs[r], hi = offs[r + 1] > nnz ? nnz : offs[r + 1];
+        if (lo < src) lo = src;
+        offs[r] = (int32_t)w;
+        for (int64_t i = lo; i < hi; ++i)
+          if (keep[i]) {
+            ids[w] = ids[i];
+            if (seg) seg[w] = seg[i];
+            ++w;
+          }
+        if (hi > src) src = hi;
+      }
+      offs[rows] = (int32_t)w;
+      nnz = w;
     }
     if (c->form == ORC_FORM_SEGMENT_REDUCE) {
       const int32_t mean = (c->combiner == ORC_COMBINER_MEAN) && !sharded;
@@ -539,6 +582,7 @@ static int64_t process_column(const orc_plan_t *p, int32_t k, const int8_t *blob
     free(seg);
     free(offs);
   }
+  free(keep);
   free(ids);
   return bad;
 }

@@ -33,6 +33,7 @@ enum { ORC_FORM_GATHER = 1, ORC_FORM_SEGMENT_REDUCE = 2, ORC_FORM_GATHER_SCATTER
        ORC_FORM_EXTERNAL = 6 };
 enum { ORC_COMBINER_NONE = 0, ORC_COMBINER_SUM = 1, ORC_COMBINER_MEAN = 2 };
 enum { ORC_IDS_I32 = 0, ORC_IDS_I64 = 1, ORC_IDS_F32_BUCKETIZE = 2 };
+enum { ORC_XFORM_NONE = 0, ORC_XFORM_SELECT = 1, ORC_XFORM_FILTER = 2 };
 enum { ORC_SEG_NONE = 0, ORC_SEG_IDS_I32 = 1, ORC_SEG_IDS_I64 = 2, ORC_SEG_CSR_I32 = 3 };
 enum { ORC_ROWS_FROM_IDS = 0, ORC_ROWS_FROM_SYMBOL = 1, ORC_ROWS_FROM_INPUT_DIM0 = 2,
        ORC_ROWS_FROM_GROUP = 3 /* external slots: the row count of the other columns of the group */ };
@@ -45,6 +46,15 @@ typedef struct orc_column {
   int32_t n_boundaries;
   const float *boundaries;
   int32_t concat_group, concat_slot;
+  /* id transform in front of the lookup: the reference's CPU ops Addons>SelectValue (mode 1,
+   * custom_ops/select_value/select_value_ops.cc:33-56) and Addons>GatherIndiceValue /
+   * Addons>GatherValueGenIndice (mode 2, gather_indice_value_ops.cc:33-78,
+   * gather_value_gen_indice_ops.cc:33-67) over closed intervals [lo_i, hi_i] =
+   * left_boundaries / right_boundaries.  Restated with the INTENDED test lo <= x && x <= hi: the
+   * reference's `x >= l || x <= r` is true for every x. */
+  int32_t xform_mode, xform_n;
+  const int64_t *xform_lo, *xform_hi;
+  int64_t xform_substitute;
 } orc_column_t;
 
 typedef struct orc_plan {

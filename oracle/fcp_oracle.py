@@ -52,6 +52,9 @@ class _Column(C.Structure):
         ("n_boundaries", C.c_int32),
         ("boundaries", C.POINTER(C.c_float)),
         ("concat_group", C.c_int32), ("concat_slot", C.c_int32),
+        ("xform_mode", C.c_int32), ("xform_n", C.c_int32),
+        ("xform_lo", C.POINTER(C.c_int64)), ("xform_hi", C.POINTER(C.c_int64)),
+        ("xform_substitute", C.c_int64),
     ]
 
 
@@ -213,12 +216,17 @@ class COracle:
             if b is not None:
                 b = np.ascontiguousarray(b, np.float32)
                 keep.append(b)
+            xlo = np.ascontiguousarray(c.get("xform_lo", ()), np.int64)
+            xhi = np.ascontiguousarray(c.get("xform_hi", ()), np.int64)
+            keep += [xlo, xhi]
             arr[k] = _Column(
                 c["form"], c["combiner"], c["dim"], c["id_source"], c["vocab"], c["table_input"],
                 c["ids_input"], c["seg_input"], c["seg_kind"], max(1, c["seg_stride"]),
                 c["rows_source"], c["rows_arg"], 0 if b is None else len(b),
                 None if b is None else b.ctypes.data_as(C.POINTER(C.c_float)),
-                c["concat_group"], c["concat_slot"])
+                c["concat_group"], c["concat_slot"], c.get("xform_mode", 0), len(xlo),
+                xlo.ctypes.data_as(C.POINTER(C.c_int64)) if len(xlo) else None,
+                xhi.ctypes.data_as(C.POINTER(C.c_int64)) if len(xhi) else None, int(c.get("xform_substitute", 0)))
         ranks = _i32(plan["host_input_ranks"])
         esz = _i32(plan["host_input_elem_sizes"])
         keep += [ranks, esz]
@@ -357,7 +365,17 @@ def np_process_feature_columns(plan: dict, blob: np.ndarray, offsets, shapes, ta
             ids = np_bucketize(c["boundaries"], tensor(c["ids_input"], np.float32).ravel()).astype(np.int64)
         else:
             ids = tensor(c["ids_input"], np.int32 if c["id_source"] == 0 else np.int64).ravel().astype(np.int64)
-        ok = (ids >= 0) & (ids < c["vocab"])
+        mode = c.get("xform_mode", 0)
+        kept = np.ones(ids.size, bool)
+        if mode:
+            inside = np.zeros(ids.size, bool)
+            for lo_, hi_ in zip(c.get("xform_lo", ()), c.get("xform_hi", ())):
+                inside |= (ids >= lo_) & (ids <= hi_)
+            if mode == 1:
+                ids = np.where(inside, ids, c.get("xform_substitute", 0))
+            else:
+                kept = inside
+        ok = (ids >= 0) & (ids < c["vocab"]) & kept
         if c["form"] == 1:
             dst[:] = np.where(ok[:, None], table[np.where(ok, ids, 0)], 0.0)
             continue
@@ -373,7 +391,8 @@ def np_process_feature_columns(plan: dict, blob: np.ndarray, offsets, shapes, ta
                 lo, hi = int(offs[s]), int(offs[s + 1])
                 sel = ids[lo:hi][ok[lo:hi]]
                 acc = table[sel].sum(axis=0) if sel.size else 0.0
-                dst[s] = acc / (hi - lo) if (mean and hi > lo) else acc
+                n_kept = int(kept[lo:hi].sum())                     # dropped ids do not count in a mean
+                dst[s] = acc / n_kept if (mean and n_kept > 0) else acc
         else:  # form 3: last id of the row wins
             for s in range(rows):
                 lo, hi = int(offs[s]), int(offs[s + 1])

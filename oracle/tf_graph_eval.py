@@ -166,6 +166,21 @@ class GraphEvaluator:
             out = np.zeros(shape, x[1].dtype)
             np.add.at(out, x[0].astype(np.int64).reshape(-1), x[1])
             return [out]
+        if op in ("Addons>SelectValue", "Addons>GatherIndiceValue", "Addons>GatherValueGenIndice"):
+            # the reference's CPU id ops (custom_ops/select_value, gather_indice_value, gather_value_gen_indice) with the
+            # INTENDED interval test lo <= x && x <= hi (their `x >= l || x <= r` accepts everything)
+            lo = [int(v) for v in a["left_boundaries"].list.i]
+            hi = [int(v) for v in a["right_boundaries"].list.i]
+            values = x[-1]
+            inside = np.zeros(values.shape, bool)
+            for l, h in zip(lo, hi):
+                inside |= (values >= l) & (values <= h)
+            if op == "Addons>SelectValue":
+                return [np.where(inside, values, values.dtype.type(int(a["substitute"].i)))]
+            keep = inside.ravel()
+            if op == "Addons>GatherIndiceValue":
+                return [x[0].reshape(keep.size, -1)[keep], values.ravel()[keep]]
+            return [np.nonzero(keep)[0].astype(values.dtype).reshape(-1, 1), values.ravel()[keep]]
         if op == "Prod":
             axis = tuple(int(v) for v in np.asarray(x[1]).ravel())
             return [np.prod(x[0], axis=axis, keepdims=bool("keep_dims" in a and a["keep_dims"].b)).astype(x[0].dtype)]

@@ -62,6 +62,8 @@ constexpr uint32_t kFlagHostOnly = 1u << 31; // undocumented: plan without devic
 struct HostColumn {
   fcp_column_desc_t d;
   std::vector<float> boundaries;
+  std::vector<int64_t> xf_lo, xf_hi; // id transform intervals (closed)
+  int64_t xf_const_off = -1;         // byte offset in the const buffer of intervals 1.. as (lo, hi) pairs
   int32_t out_off = 0;
   int64_t const_off = -1; // byte offset of the boundaries in the const buffer
 };
@@ -139,6 +141,7 @@ struct fcp_plan {
 
   uint32_t *d_slot_map = nullptr;
   FcpColStatic *d_cols = nullptr;
+  FcpXform *d_xforms = nullptr; // per column, only for plans with id transforms
   std::vector<FcpColStatic> h_cols;
   char *d_const = nullptr;
   int32_t *d_seg_cols = nullptr;
@@ -230,6 +233,18 @@ int validate_desc(const fcp_plan_desc_t *d) {
         return fail(FCP_ERR_INVALID_ARGUMENT, where + "ids element size does not match id_source");
     } else if (d->host_input_elem_sizes[c.ids_input] != 4) {
       return fail(FCP_ERR_INVALID_ARGUMENT, where + "payload must be a 4-byte type");
+    }
+    if (c.xform_mode != FCP_XFORM_NONE) {
+      if (!lookup) return fail(FCP_ERR_INVALID_ARGUMENT, where + "id transforms apply to lookup columns only");
+      if (c.xform_mode != FCP_XFORM_SELECT && c.xform_mode != FCP_XFORM_FILTER)
+        return fail(FCP_ERR_INVALID_ARGUMENT, where + "bad xform_mode");
+      if (c.xform_n < 0 || c.xform_n > (1 << 20) || (c.xform_n > 0 && (!c.xform_lo || !c.xform_hi)))
+        return fail(FCP_ERR_INVALID_ARGUMENT, where + "bad id transform intervals");
+      for (int i = 0; i < c.xform_n; ++i)
+        if (c.xform_lo[i] > c.xform_hi[i]) return fail(FCP_ERR_INVALID_ARGUMENT, where + "empty id transform interval");
+      if (c.xform_mode == FCP_XFORM_FILTER && c.form == FCP_FORM_SEGMENT_REDUCE && c.combiner == FCP_COMBINER_MEAN &&
+          d->shard_world > 1)
+        return fail(FCP_ERR_UNSUPPORTED, where + "an id filter on a mean column cannot be row-sharded");
     }
     if (c.form == FCP_FORM_SEGMENT_REDUCE || c.form == FCP_FORM_GATHER_SCATTER) {
       if (c.seg_kind < FCP_SEG_IDS_I32 || c.seg_kind > FCP_SEG_CSR_I32)
@@ -603,6 +618,7 @@ void destroy_device(fcp_plan *p) {
   if (p->d_slot_map) (void)hipFree(p->d_slot_map);
   if (p->d_span_list) (void)hipFree(p->d_span_list);
   if (p->d_cols) (void)hipFree(p->d_cols);
+  if (p->d_xforms) (void)hipFree(p->d_xforms);
   if (p->d_const) (void)hipFree(p->d_const);
   if (p->d_seg_cols) (void)hipFree(p->d_seg_cols);
   if (p->d_bad) (void)hipFree(p->d_bad);
@@ -647,13 +663,28 @@ int init_device(fcp_plan *p) {
       owners.push_back((int)k);
     }
   }
+  for (HostColumn &hc : p->cols) { // id transform intervals beyond the first (the first one travels in the record)
+    if (hc.xf_lo.size() <= 1) continue;
+    hc.xf_const_off = const_bytes;
+    const_bytes += align128((int64_t)(hc.xf_lo.size() - 1) * 16);
+  }
   if (const_bytes) {
     HIP_TRY(hipMalloc(&p->d_const, const_bytes));
+    for (const HostColumn &hc : p->cols) {
+      if (hc.xf_const_off < 0) continue;
+      std::vector<int64_t> pairs;
+      for (size_t i = 1; i < hc.xf_lo.size(); ++i) {
+        pairs.push_back(hc.xf_lo[i]);
+        pairs.push_back(hc.xf_hi[i]);
+      }
+      HIP_TRY(hipMemcpy(p->d_const + hc.xf_const_off, pairs.data(), pairs.size() * 8, hipMemcpyHostToDevice));
+    }
     for (int o : owners)
       HIP_TRY(hipMemcpy(p->d_const + p->cols[o].const_off, p->cols[o].boundaries.data(),
                         p->cols[o].boundaries.size() * 4, hipMemcpyHostToDevice));
   }
   // static column records (tables are bound on the first request)
+  std::vector<FcpXform> h_xforms; // filled only if some column has an id transform
   p->h_cols.resize(nc);
   for (int pos = 0; pos < nc; ++pos) {
     const HostColumn &hc = p->cols[p->order[pos]];
@@ -669,11 +700,36 @@ int init_device(fcp_plan *p) {
     s.bnd_b0 = 0.0f;
     s.bnd_inv = 0.0f;
     s.bnd_step = 0.0f;
-    s.pad_[0] = s.pad_[1] = 0;
     uniform_boundaries(hc.boundaries, &s.bnd_b0, &s.bnd_inv, &s.bnd_step);
+    // id transform: an empty interval set (nothing is "in") is encoded as one impossible interval
+    s.bnd_off = -1;
+    s.xform = 0;
+    if (hc.d.xform_mode != FCP_XFORM_NONE) {
+      if (h_xforms.empty()) {
+        FcpXform none;
+        none.lo0 = 1;
+        none.hi0 = 0;
+        none.sub = 0;
+        none.extra = nullptr;
+        h_xforms.assign(nc, none);
+      }
+      FcpXform &x = h_xforms[pos];
+      const uint32_t n = (uint32_t)std::max<size_t>(hc.xf_lo.size(), 1);
+      s.xform = (n << 2) | (uint32_t)hc.d.xform_mode;
+      x.sub = hc.d.xform_substitute;
+      if (!hc.xf_lo.empty()) {
+        x.lo0 = hc.xf_lo[0];
+        x.hi0 = hc.xf_hi[0];
+      }
+      if (hc.xf_const_off >= 0) x.extra = reinterpret_cast<const int64_t *>(p->d_const + hc.xf_const_off);
+    }
   }
   HIP_TRY(hipMalloc(&p->d_cols, nc * sizeof(FcpColStatic)));
   HIP_TRY(hipMemcpy(p->d_cols, p->h_cols.data(), nc * sizeof(FcpColStatic), hipMemcpyHostToDevice));
+  if (!h_xforms.empty()) {
+    HIP_TRY(hipMalloc(&p->d_xforms, nc * sizeof(FcpXform)));
+    HIP_TRY(hipMemcpy(p->d_xforms, h_xforms.data(), nc * sizeof(FcpXform), hipMemcpyHostToDevice));
+  }
   if (!p->seg_cols.empty()) {
     std::vector<int32_t> seg_pos;
     for (int k : p->seg_cols) seg_pos.push_back(p->pos_of[k]);
@@ -876,6 +932,7 @@ void fill_launch(const fcp_plan *p, const DynSlot &s, int kind, const void *blob
   L->slot_map = p->d_slot_map;
   L->span_list = p->d_span_list;
   L->cols = p->d_cols;
+  L->xforms = p->d_xforms;
   L->dyn = s.d_dyn;
   L->blob = static_cast<const char *>(blob);
   L->arena = static_cast<char *>(arena);
@@ -997,6 +1054,11 @@ int fcp_plan_create(const fcp_plan_desc_t *desc, fcp_plan_t **out) {
         hc.d.form != FCP_FORM_PASSTHROUGH && hc.d.form != FCP_FORM_BATCH_COL_REDUCTION && hc.d.form != FCP_FORM_EXTERNAL)
       hc.boundaries.assign(hc.d.boundaries, hc.d.boundaries + hc.d.n_boundaries);
     hc.d.boundaries = nullptr;
+    if (hc.d.xform_mode != FCP_XFORM_NONE && hc.d.xform_n > 0) {
+      hc.xf_lo.assign(hc.d.xform_lo, hc.d.xform_lo + hc.d.xform_n);
+      hc.xf_hi.assign(hc.d.xform_hi, hc.d.xform_hi + hc.d.xform_n);
+    }
+    hc.d.xform_lo = hc.d.xform_hi = nullptr;
     if (hc.d.dim % 4) gcd4 = (hc.d.dim % 2) ? 1 : std::min(gcd4, 2);
     const int f = hc.d.form;
     if ((f == FCP_FORM_SEGMENT_REDUCE || f == FCP_FORM_GATHER_SCATTER) && hc.d.seg_kind != FCP_SEG_CSR_I32)
@@ -1126,7 +1188,7 @@ int fcp_plan_create_from_file(const char *path, int32_t device, uint32_t flags, 
   int version = 0, n_host = 0, n_cols = 0;
   fcp_plan_desc_t d;
   std::memset(&d, 0, sizeof(d));
-  if (std::fscanf(f, "%31s %d", tag, &version) != 2 || std::strcmp(tag, "fcp_plan") || version != 1)
+  if (std::fscanf(f, "%31s %d", tag, &version) != 2 || std::strcmp(tag, "fcp_plan") || (version != 1 && version != 2))
     return fail(FCP_ERR_INVALID_ARGUMENT, where + "bad header");
   if (std::fscanf(f, "%31s %d", tag, &d.layout) != 2 || std::strcmp(tag, "layout"))
     return fail(FCP_ERR_INVALID_ARGUMENT, where + "expected 'layout'");
@@ -1142,6 +1204,7 @@ int fcp_plan_create_from_file(const char *path, int32_t device, uint32_t flags, 
     return fail(FCP_ERR_INVALID_ARGUMENT, where + "expected 'columns C'");
   std::vector<fcp_column_desc_t> cols(n_cols);
   std::vector<std::vector<float>> bnd(n_cols);
+  std::vector<std::vector<int64_t>> xlo(n_cols), xhi(n_cols);
   for (int k = 0; k < n_cols; ++k) {
     fcp_column_desc_t &c = cols[k];
     std::memset(&c, 0, sizeof(c));
@@ -1156,6 +1219,22 @@ int fcp_plan_create_from_file(const char *path, int32_t device, uint32_t flags, 
     for (int b = 0; b < c.n_boundaries; ++b)
       if (std::fscanf(f, "%f", &bnd[k][b]) != 1) return fail(FCP_ERR_INVALID_ARGUMENT, where + "truncated boundary list");
     c.boundaries = c.n_boundaries ? bnd[k].data() : nullptr;
+    if (version >= 2) { // id transform: mode, number of intervals, substitute, (lo, hi) pairs
+      long long sub = 0;
+      if (std::fscanf(f, "%d %d %lld", &c.xform_mode, &c.xform_n, &sub) != 3 || c.xform_n < 0 || c.xform_n > (1 << 20))
+        return fail(FCP_ERR_INVALID_ARGUMENT, where + "truncated or malformed id transform of column " + std::to_string(k));
+      c.xform_substitute = sub;
+      xlo[k].resize(c.xform_n);
+      xhi[k].resize(c.xform_n);
+      for (int i = 0; i < c.xform_n; ++i) {
+        long long lo = 0, hi = 0;
+        if (std::fscanf(f, "%lld %lld", &lo, &hi) != 2) return fail(FCP_ERR_INVALID_ARGUMENT, where + "truncated interval list");
+        xlo[k][i] = lo;
+        xhi[k][i] = hi;
+      }
+      c.xform_lo = c.xform_n ? xlo[k].data() : nullptr;
+      c.xform_hi = c.xform_n ? xhi[k].data() : nullptr;
+    }
   }
   d.abi_version = FCP_ABI_VERSION;
   d.n_columns = n_cols;

@@ -43,7 +43,16 @@ struct FcpColStatic {      // 64 bytes: one record per cache line
   // bnd_step != 0: every boundary is REPRODUCIBLE as fma(i, bnd_step, bnd_b0) (checked bit for bit at plan
   // creation), so the kernels never read the array (bucketize_arith).
   float bnd_b0, bnd_inv, bnd_step;
-  int32_t pad_[2];
+  // id transform (FCP_XFORM_*): mode in the low 2 bits, number of closed intervals above, 0 = none; the
+  // intervals live in FcpLaunch::xforms[column] and are only read by columns that have one
+  uint32_t xform;
+  int32_t bnd_off;         // always -1 in memory; in the LDS copy: where a block staged the boundaries (or -1)
+};
+
+struct FcpXform {          // 32 bytes per column (allocated only for plans with id transforms)
+  int64_t lo0, hi0;        // first closed interval
+  int64_t sub;             // FCP_XFORM_SELECT: what an id outside the intervals becomes
+  const int64_t *extra;    // intervals 1.. as (lo, hi) pairs in the const buffer
 };
 
 struct FcpColDyn {         // 48 bytes
@@ -87,6 +96,7 @@ struct FcpLaunch {
   int32_t pad_;
   unsigned long long *stamps;  // diagnostic builds (-DFCP_STAMPS) only: 8 timestamps per block
   FcpGroupLaunch groups[FCP_MAX_GROUPS];
+  const FcpXform *xforms;      // per column (concat order), or null: no column has an id transform
 };
 
 // Segment-offset pre-pass (ComputeSegmentOffsets, cuda_emitter.cc:768-818)

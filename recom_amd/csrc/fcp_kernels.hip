@@ -202,28 +202,24 @@ __device__ __forceinline__ int bucketize_arith(int n, float b0, float inv, float
   return r + 1;
 }
 
-constexpr uint32_t kNoRow = 0xFFFFFFFFu; // "this id contributes nothing"
+constexpr uint32_t kNoRow = 0xFFFFFFFFu;    // "this id contributes nothing" (out of range, or another rank's row)
+constexpr uint32_t kFiltered = 0xFFFFFFFEu; // dropped by the column's id filter: contributes nothing AND does not count in a mean
+__device__ __forceinline__ bool is_row(uint32_t off) { return off < kFiltered; }
 
-// One column of the span, staged in LDS by the block.
-struct alignas(16) LdsCol {   // 96 bytes
-  const float *table;         // table base, or the passthrough payload
+// One column of the span, staged in LDS by the block: the static record VERBATIM (its six 16-byte words go
+// from the load straight to LDS: nothing is re-packed, few registers live) plus what the request's dynamic
+// record turns into.
+struct alignas(16) LdsCol : FcpColStatic { // 64 + 32 = 96 bytes
   const char *ids;            // id / value stream of this request
-  const float *boundaries;
   const int32_t *csr;         // CSR offsets of this request (blob or arena scratch), or — L.seg_search — the segment ids
-  int64_t vocab;
   int64_t out_base;           // byte offset in the arena of element (0,0)
-  int32_t dim;
-  int32_t out_off;
   int32_t out_stride;
-  uint32_t flags;
-  int32_t n_boundaries;
-  int32_t bnd_off;            // offset of the staged boundaries in LDS, or -1
-  int32_t nnz;
-  int32_t inner;
-  float bnd_b0, bnd_inv;      // evenly spaced boundaries: bucket guess (bnd_inv == 0: none)
-  float bnd_step;             // != 0: boundaries reproducible as fma(i, bnd_step, bnd_b0), never read
-  int32_t pad_;
+  union {
+    int32_t nnz;              // lookup forms: number of ids
+    int32_t inner;            // BatchColReduction: rows reduced per output row
+  };
 };
+static_assert(sizeof(LdsCol) == 96 && sizeof(FcpColStatic) == 64, "column records: 64 static + 32 derived bytes");
 
 // The scalars of the argument block a body uses, fetched up front in ONE batch of scalar loads and
 // pinned there (the empty asm keeps the compiler from sinking each load next to its first use, which
@@ -276,31 +272,61 @@ template <typename T> __device__ __forceinline__ T ld_rec(const FCP_CONST T *p) 
   return r;
 }
 
-__device__ __forceinline__ LdsCol make_lds_col(const Hot &L, const FcpColStatic &cs, const FcpColDyn &cd) {
-  LdsCol c;
-  c.ids = L.blob + cd.ids_off;
-  c.table = FCP_F_FORM(cs.flags) == FCP_FORM_PASSTHROUGH ? reinterpret_cast<const float *>(c.ids) : cs.table;
-  c.boundaries = cs.boundaries;
-  const unsigned segkind = FCP_F_SEGKIND(cs.flags);
-  c.csr = (segkind == FCP_SEG_CSR_I32 || (segkind != FCP_SEG_NONE && L.seg_search))
-              ? reinterpret_cast<const int32_t *>(L.blob + cd.seg_off)
-          : segkind != FCP_SEG_NONE ? reinterpret_cast<const int32_t *>(L.arena + L.csr_arena_off) + cd.csr_base
-                                    : nullptr;
-  c.vocab = cs.vocab;
-  c.out_base = cd.out_base;
-  c.dim = cs.dim;
-  c.out_off = cs.out_off;
-  c.out_stride = cd.out_stride;
-  c.flags = cs.flags | ((uint32_t)cs.seg_stride << 16); // FCP_F_PACK uses the low 16 bits; stride < 2^16 is checked at plan creation
-  c.n_boundaries = cs.n_boundaries;
-  c.bnd_off = -1;
-  c.nnz = cd.nnz;
-  c.inner = cd.inner;
-  c.bnd_b0 = cs.bnd_b0;
-  c.bnd_inv = cs.bnd_inv;
-  c.bnd_step = cs.bnd_step;
-  c.pad_ = 0;
-  return c;
+// Phase 0 of both bodies for one column: static record -> LDS word by word, then the derived part.
+// (For a PASSTHROUGH column the "table" is its payload in the blob.)
+__device__ __forceinline__ void stage_col(const Hot &L, LdsCol *dst, const FCP_CONST FcpColStatic *gs,
+                                          const FCP_CONST FcpColDyn *gd) {
+  typedef uint32_t __attribute__((ext_vector_type(4))) U4;
+  const FCP_CONST U4 *ws = reinterpret_cast<const FCP_CONST U4 *>(gs);
+  const FCP_CONST U4 *wd = reinterpret_cast<const FCP_CONST U4 *>(gd);
+  U4 s0 = ws[0], s1 = ws[1], s2 = ws[2], s3 = ws[3];
+  const U4 d0 = wd[0], d1 = wd[1], d2 = wd[2];
+  FcpColDyn cd;
+  {
+    U4 w[3] = {d0, d1, d2};
+    __builtin_memcpy(&cd, w, sizeof(cd));
+  }
+  const uint32_t flags = s2.x; // word 2: flags, n_boundaries, seg_stride, bnd_b0 (offset 32)
+  const char *ids = L.blob + cd.ids_off;
+  if (FCP_F_FORM(flags) == FCP_FORM_PASSTHROUGH) { // word 0: table, boundaries
+    const uint64_t t = (uint64_t)reinterpret_cast<uintptr_t>(ids);
+    s0.x = (uint32_t)t;
+    s0.y = (uint32_t)(t >> 32);
+  }
+  U4 *out = reinterpret_cast<U4 *>(dst);
+  out[0] = s0;
+  out[1] = s1;
+  out[2] = s2;
+  out[3] = s3;
+  const unsigned segkind = FCP_F_SEGKIND(flags);
+  dst->ids = ids;
+  dst->csr = (segkind == FCP_SEG_CSR_I32 || (segkind != FCP_SEG_NONE && L.seg_search))
+                 ? reinterpret_cast<const int32_t *>(L.blob + cd.seg_off)
+             : segkind != FCP_SEG_NONE ? reinterpret_cast<const int32_t *>(L.arena + L.csr_arena_off) + cd.csr_base
+                                       : nullptr;
+  dst->out_base = cd.out_base;
+  dst->out_stride = cd.out_stride;
+  dst->nnz = FCP_F_FORM(flags) == FCP_FORM_BATCH_COL_REDUCTION ? cd.inner : cd.nnz;
+}
+static_assert(offsetof(FcpColStatic, flags) == 32 && offsetof(FcpColStatic, table) == 0, "stage_col reads the record by word");
+
+// the interval test of Addons>SelectValue / Addons>GatherIndiceValue /
+// Addons>GatherValueGenIndice (select_value_ops.cc:33-56 and siblings), fused: closed intervals,
+// `lo <= id && id <= hi` (the reference's `||` accepts everything).  Returns the id the
+// lookup sees, or kDroppedId: the filter removed it.  Out of line and fed from the per-column side table
+// (FcpLaunch::xforms) on purpose: columns without a transform — nearly all — pay one compare, no registers
+// and no record bytes for it (inlined with the intervals in the column record it cost S2 2 us of 29: 76 VGPRs).
+constexpr int64_t kDroppedId = INT64_MIN;
+__device__ __attribute__((noinline)) int64_t apply_xform(uint32_t xform, const FcpXform *xf, int64_t id) {
+  const FCP_GLOBAL FcpXform *x = as_global(xf);
+  bool in = id >= x->lo0 && id <= x->hi0;
+  const int n = (int)(xform >> 2);
+  for (int i = 1; i < n && !in; ++i) {
+    const FCP_GLOBAL int64_t *e = as_global(x->extra) + 2 * (i - 1);
+    in = id >= e[0] && id <= e[1];
+  }
+  if (in) return id;
+  return (xform & 3u) == FCP_XFORM_FILTER ? kDroppedId : x->sub;
 }
 
 // The index expression the reference inlines per column (EmitInputInline,
@@ -311,8 +337,8 @@ __device__ __forceinline__ LdsCol make_lds_col(const Hot &L, const FcpColStatic 
 // reference reads out of bounds, TF-GPU GatherV2 returns zeros); under row
 // sharding an id owned by another rank contributes nothing here.
 template <int V, bool SHARDED>
-__device__ __forceinline__ uint32_t slot_offset_from_raw(const LdsCol &c, uint32_t lo, uint32_t hi, const float *lds_bnd,
-                                                         int rank, int world, bool &bad) {
+__device__ __forceinline__ uint32_t slot_offset_from_raw(const LdsCol &c, const FcpXform *xf, uint32_t lo, uint32_t hi,
+                                                         const float *lds_bnd, int rank, int world, bool &bad) {
   const unsigned idsrc = FCP_F_IDSRC(c.flags);
   int64_t id;
   if (idsrc == FCP_IDS_F32_BUCKETIZE) {
@@ -328,6 +354,11 @@ __device__ __forceinline__ uint32_t slot_offset_from_raw(const LdsCol &c, uint32
   } else {
     id = idsrc == FCP_IDS_I64 ? (int64_t)(((uint64_t)hi << 32) | lo) : (int64_t)(int32_t)lo;
   }
+  bad = false;
+  if (c.xform) { // rare
+    id = apply_xform(c.xform, xf, id);
+    if (id == kDroppedId) return kFiltered;
+  }
   bad = (uint64_t)id >= (uint64_t)c.vocab;
   if (bad) return kNoRow;
   if (SHARDED) {
@@ -339,14 +370,14 @@ __device__ __forceinline__ uint32_t slot_offset_from_raw(const LdsCol &c, uint32
 }
 
 template <int V, bool SHARDED>
-__device__ __forceinline__ uint32_t fetch_slot_offset(const LdsCol &c, int64_t pos, const float *lds_bnd, int rank,
-                                                      int world, bool &bad) {
+__device__ __forceinline__ uint32_t fetch_slot_offset(const LdsCol &c, const FcpXform *xf, int64_t pos, const float *lds_bnd,
+                                                      int rank, int world, bool &bad) {
   const bool is64 = FCP_F_IDSRC(c.flags) == FCP_IDS_I64;
   // branch-free fetch: one code path for every id source
   const char *a = c.ids + (is64 ? 8 : 4) * pos;
   const uint32_t lo = *as_global(reinterpret_cast<const uint32_t *>(a));
   const uint32_t hi = *as_global(reinterpret_cast<const uint32_t *>(a + (is64 ? 4 : 0)));
-  return slot_offset_from_raw<V, SHARDED>(c, lo, hi, lds_bnd, rank, world, bad);
+  return slot_offset_from_raw<V, SHARDED>(c, xf, lo, hi, lds_bnd, rank, world, bad);
 }
 
 // Common block header: which group / span / row tile this block owns.
@@ -448,7 +479,7 @@ __device__ __forceinline__ void dense_body(const FcpLaunch &L, int bid, char *sm
   const int world = H.world, rank = H.rank;
 
   // ---- phase 0 ----------------------------------------------------------------------
-  if (tid < B.ncols) s_col[tid] = make_lds_col(H, ld_rec(H.cols + B.first_col + tid), ld_rec(H.dyn + B.first_col + tid));
+  if (tid < B.ncols) stage_col(H, &s_col[tid], H.cols + B.first_col + tid, H.dyn + B.first_col + tid);
   __syncthreads();
 #if defined(FCP_STAMPS)
   const unsigned long long t_desc = __builtin_amdgcn_s_memrealtime();
@@ -545,7 +576,8 @@ __device__ __forceinline__ void dense_body(const FcpLaunch &L, int bid, char *sm
         if (rank == 0) off = (uint32_t)b * (uint32_t)(c.dim / V);
       } else if (form == FCP_FORM_GATHER) {
         bool bad;
-        off = slot_offset_from_raw<V, SHARDED>(c, raw_lo[h], raw_hi[h], c.bnd_off >= 0 ? s_bnd + c.bnd_off : nullptr,
+        off = slot_offset_from_raw<V, SHARDED>(c, L.xforms + B.first_col + j, raw_lo[h], raw_hi[h],
+                                               c.bnd_off >= 0 ? s_bnd + c.bnd_off : nullptr,
                                                rank, world, bad);
         // a column that straddles two spans is staged by two blocks: the one holding its first slot counts
         if (bad && H.bad_ids && c.out_off >= B.q0 * V) atomicAdd(H.bad_ids, 1ull);
@@ -580,7 +612,7 @@ __device__ __forceinline__ void dense_body(const FcpLaunch &L, int bid, char *sm
   for (int r = 0; r < R; ++r) {
     v[r] = vzero<V>();
 #if !(defined(FCP_ABLATE) && FCP_ABLATE == 1) // timing-only build 1: no table reads
-    if (off[r] != kNoRow) v[r] = ld_slot<V>(tb, off[r]);
+    if (is_row(off[r])) v[r] = ld_slot<V>(tb, off[r]);
 #else
     v[r].v[0] = (float)off[r];
 #endif
@@ -711,13 +743,14 @@ __device__ __forceinline__ int seg_lower_bound(const char *seg, bool is64, int s
 // slot offsets sit at s_ids[poff .. poff+pcnt), or poff < 0: fetch the ids from the blob — with 8 (then 4)
 // table reads in flight, add in id order, divide for mean, store.
 template <int V, bool SHARDED>
-__device__ __forceinline__ void ragged_emit(const Hot &H, const LdsCol &C, int q, int b, int plo, int pcnt, int poff,
+__device__ __forceinline__ void ragged_emit(const Hot &H, const LdsCol &C, const FcpXform *xf, int q, int b, int plo, int pcnt, int poff,
                                             const uint32_t *s_ids, int rank, int world) {
   const unsigned form = FCP_F_FORM(C.flags);
   const int dim = C.dim;
   const int e = q * V - C.out_off;
   const float *tb = C.table + e;
   VF<V> acc = vzero<V>();
+  int dropped = 0; // ids the column's filter removed: they do not count in a mean
   if (form == FCP_FORM_EXTERNAL) return; // somebody else's slot (ConcatOutputs host input): never written here
 
   if (form == FCP_FORM_PASSTHROUGH) {
@@ -735,9 +768,10 @@ __device__ __forceinline__ void ragged_emit(const Hot &H, const LdsCol &C, int q
 #pragma unroll 1
     for (int i = 0; i < pcnt; ++i) {
       bool bad;
-      const uint32_t off = fetch_slot_offset<V, SHARDED>(C, plo + i, nullptr, rank, world, bad);
+      const uint32_t off = fetch_slot_offset<V, SHARDED>(C, xf, plo + i, nullptr, rank, world, bad);
       if (bad && e == 0 && H.bad_ids) atomicAdd(H.bad_ids, 1ull);
-      if (off != kNoRow) {
+      dropped += off == kFiltered;
+      if (is_row(off)) {
         const VF<V> w = ld_slot<V>(tb, off);
         if (form == FCP_FORM_SEGMENT_REDUCE) {
 #pragma unroll
@@ -751,11 +785,17 @@ __device__ __forceinline__ void ragged_emit(const Hot &H, const LdsCol &C, int q
     // GATHER / GATHER_SCATTER: a pure copy of one row (rows without ids stay zero)
     if (pcnt > 0) {
       const uint32_t off = s_ids[poff];
-      if (off != kNoRow) acc = ld_slot<V>(tb, off);
+      if (is_row(off)) acc = ld_slot<V>(tb, off);
     }
   } else {
     // Adding the zero vector of a skipped id is exact (acc is never -0.0: it
     // starts at +0.0), so the adds need no predicate.
+    if ((C.xform & 3u) == FCP_XFORM_FILTER && FCP_F_COMBINER(C.flags) == FCP_COMBINER_MEAN) {
+      // ids the filter dropped do not count in the mean: a separate pass over the staged offsets, only for
+      // such columns (counting inside the walk cost every column 12 registers)
+#pragma unroll 1
+      for (int k = 0; k < pcnt; ++k) dropped += s_ids[poff + k] == kFiltered;
+    }
     int i = 0;
     while (pcnt - i > 4) {
       uint32_t off[FCP_WALK];
@@ -765,7 +805,7 @@ __device__ __forceinline__ void ragged_emit(const Hot &H, const LdsCol &C, int q
 #pragma unroll
       for (int k = 0; k < FCP_WALK; ++k) {
         w[k] = vzero<V>();
-        if (off[k] != kNoRow) w[k] = ld_slot<V>(tb, off[k]);
+        if (is_row(off[k])) w[k] = ld_slot<V>(tb, off[k]);
       }
 #pragma unroll
       for (int k = 0; k < FCP_WALK; ++k)
@@ -781,7 +821,7 @@ __device__ __forceinline__ void ragged_emit(const Hot &H, const LdsCol &C, int q
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         w[k] = vzero<V>();
-        if (off[k] != kNoRow) w[k] = ld_slot<V>(tb, off[k]);
+        if (is_row(off[k])) w[k] = ld_slot<V>(tb, off[k]);
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k)
@@ -789,8 +829,8 @@ __device__ __forceinline__ void ragged_emit(const Hot &H, const LdsCol &C, int q
         for (int t = 0; t < V; ++t) acc.v[t] = acc.v[t] + w[k].v[t];
     }
   }
-  if (form == FCP_FORM_SEGMENT_REDUCE && !SHARDED && FCP_F_COMBINER(C.flags) == FCP_COMBINER_MEAN && pcnt > 0) {
-    const float fc = (float)pcnt; // sum / count
+  if (form == FCP_FORM_SEGMENT_REDUCE && !SHARDED && FCP_F_COMBINER(C.flags) == FCP_COMBINER_MEAN && pcnt > dropped) {
+    const float fc = (float)(pcnt - dropped); // sum / count of the ids that reached the lookup
 #pragma unroll
     for (int t = 0; t < V; ++t) acc.v[t] = acc.v[t] / fc;
   }
@@ -834,7 +874,7 @@ __device__ __forceinline__ void ragged_body(const FcpLaunch &L, int bid, char *s
   const int world = H.world, rank = H.rank;
 
   // ---- phase 0 (block) --------------------------------------------------------------------
-  if (tid < B.ncols) s_col[tid] = make_lds_col(H, ld_rec(H.cols + B.first_col + tid), ld_rec(H.dyn + B.first_col + tid));
+  if (tid < B.ncols) stage_col(H, &s_col[tid], H.cols + B.first_col + tid, H.dyn + B.first_col + tid);
   __syncthreads();
 #if defined(FCP_STAMPS)
   const unsigned long long t_desc = __builtin_amdgcn_s_memrealtime();
@@ -847,7 +887,7 @@ __device__ __forceinline__ void ragged_body(const FcpLaunch &L, int bid, char *s
       const unsigned sk = FCP_F_SEGKIND(c.flags), f = FCP_F_FORM(c.flags);
       int v = 0;
       if ((sk == FCP_SEG_IDS_I32 || sk == FCP_SEG_IDS_I64) && (f == FCP_FORM_SEGMENT_REDUCE || f == FCP_FORM_GATHER_SCATTER))
-        v = seg_lower_bound(reinterpret_cast<const char *>(c.csr), sk == FCP_SEG_IDS_I64, (int)(c.flags >> 16), c.nnz,
+        v = seg_lower_bound(reinterpret_cast<const char *>(c.csr), sk == FCP_SEG_IDS_I64, c.seg_stride, c.nnz,
                             min(B.row_blk + u % (RB + 1), B.rows), B.rows);
       S.bound[u] = v;
     }
@@ -914,7 +954,7 @@ __device__ __forceinline__ void ragged_body(const FcpLaunch &L, int bid, char *s
     const int px = __shfl(sx, p), pc = __shfl(cnt, p), pl = __shfl(lo, p);
     if (k < limit && px >= 0 && px <= k && k < px + pc) { // entries of unstaged bags fail this test
       bool bad;
-      wi[k] = fetch_slot_offset<V, SHARDED>(s_col[p], pl + (k - px), nullptr, rank, world, bad);
+      wi[k] = fetch_slot_offset<V, SHARDED>(s_col[p], L.xforms + B.first_col + p, pl + (k - px), nullptr, rank, world, bad);
       // a column that straddles two spans is staged by two blocks: the one holding its first slot counts
       if (bad && H.bad_ids && s_col[p].out_off >= B.q0 * V) atomicAdd(H.bad_ids, 1ull);
     }
@@ -928,7 +968,7 @@ __device__ __forceinline__ void ragged_body(const FcpLaunch &L, int bid, char *s
   const int j = (int)(my_col - B.first_col);
   const int plo = __shfl(lo, j), pcnt = __shfl(cnt, j), poff = __shfl(sx, j);
   if (q >= B.nslots) return;
-  ragged_emit<V, SHARDED>(H, s_col[j], q, b, plo, pcnt, poff, wi, rank, world);
+  ragged_emit<V, SHARDED>(H, s_col[j], L.xforms + B.first_col + j, q, b, plo, pcnt, poff, wi, rank, world);
 #if defined(FCP_STAMPS)
   if (L.stamps && tid == 0) { // wave 0 = first row of the block
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -50,7 +50,8 @@ from typing import Dict, List, Optional, Tuple
 
 import numpy as np
 
-from ..plan import (COMBINER_MEAN, COMBINER_NONE, COMBINER_SUM, FORM_BATCH_COL_REDUCTION, FORM_EXTERNAL, FORM_GATHER,
+from ..plan import (XFORM_FILTER, XFORM_NONE, XFORM_SELECT,
+                    COMBINER_MEAN, COMBINER_NONE, COMBINER_SUM, FORM_BATCH_COL_REDUCTION, FORM_EXTERNAL, FORM_GATHER,
                     FORM_GATHER_SCATTER, FORM_PASSTHROUGH, FORM_SEGMENT_REDUCE, IDS_F32_BUCKETIZE, IDS_I32, IDS_I64,
                     ROWS_FROM_GROUP, ROWS_FROM_IDS, ROWS_FROM_INPUT_DIM0, ROWS_FROM_SYMBOL, SEG_IDS_I32, SEG_IDS_I64,
                     SEG_NONE, ColumnSpec, PlanSpec)
@@ -74,6 +75,13 @@ class IndexSource:
     rank: int
     stride: int = 1             # element stride into `tensor` (StridedSlice [:, 0:1] of [n, k] → k)
     boundaries: Optional[np.ndarray] = None
+    # id transform absorbed on the way (Addons>SelectValue / GatherIndiceValue / GatherValueGenIndice)
+    xform_mode: int = XFORM_NONE
+    xform_lo: Tuple[int, ...] = ()
+    xform_hi: Tuple[int, ...] = ()
+    xform_substitute: int = 0
+    filter_node: Optional[str] = None    # the Gather* node whose (indices, values) pair this operand belongs to
+    generated_rows: bool = False         # indices output of GatherValueGenIndice: row i of the values tensor
 
 
 @dataclass
@@ -212,6 +220,8 @@ class PlanBuilder:
 
     def _trace_inline(self, node, port: int) -> IndexSource:
         g = self.g
+        if node.op.startswith("Addons>"):
+            return self._trace_id_filter(node, port)
         if port != 0:
             raise Unsupported("not an inlinable op")
         if node.op == "SparseReshape":
@@ -264,6 +274,51 @@ class PlanBuilder:
             return src
         raise Unsupported("not an inlinable op")
 
+    def _trace_id_filter(self, node, port: int) -> IndexSource:
+        """the CPU id ops PreLookupOptimizer leaves in front of a lookup
+        (``pre_lookup_optimizer.cc:596-654``) become the column's id transform, evaluated on the device next
+        to Bucketize; the walk continues at the op's input.  One transform per column."""
+        g = self.g
+        lo = tuple(int(v) for v in node.attr["left_boundaries"].list.i)
+        hi = tuple(int(v) for v in node.attr["right_boundaries"].list.i)
+        if len(lo) != len(hi) or any(a > b for a, b in zip(lo, hi)):
+            raise Unsupported("malformed interval attrs")
+
+        def absorb(k: int, mode: int, sub: int = 0) -> IndexSource:
+            """the values operand (input k) with this op's transform on top; an operand that already carries a
+            transform (two id ops in a row) is not walked further: the inner op stays in TensorFlow"""
+            in_node, in_port = g.input(node, k)
+            src = self.trace_index(in_node, in_port)
+            if src.xform_mode != XFORM_NONE or src.stride != 1 or src.generated_rows or src.filter_node is not None:
+                src = self._terminal(in_node, in_port)
+            src.xform_mode, src.xform_lo, src.xform_hi, src.xform_substitute = mode, lo, hi, sub
+            return src
+
+        if node.op == "Addons>SelectValue" and port == 0:
+            return absorb(0, XFORM_SELECT, int(node.attr["substitute"].i))
+        if node.op == "Addons>GatherIndiceValue":
+            if port == 1:                                    # the surviving values: filter the original ones
+                src = absorb(1, XFORM_FILTER)
+            elif port == 0:                                  # their indices: the original indices, same filter
+                src = self.trace_index(*g.input(node, 0))
+                if src.filter_node is not None or src.xform_mode != XFORM_NONE:
+                    src = self._terminal(*g.input(node, 0))
+            else:
+                raise Unsupported("not an inlinable op")
+            src.filter_node = node.name
+            return src
+        if node.op == "Addons>GatherValueGenIndice":
+            if port == 1:
+                src = absorb(0, XFORM_FILTER)
+            elif port == 0:                                  # index [i] of every surviving value i
+                src = self._terminal(*g.input(node, 0))
+                src.generated_rows = True
+            else:
+                raise Unsupported("not an inlinable op")
+            src.filter_node = node.name
+            return src
+        raise Unsupported("not an inlinable op")
+
     def _sparse_reshape_is_identity(self, node) -> bool:
         """``SparseReshape(indices [nnz, 2], shape [2], new_shape [2])`` with ``new_shape[1]`` provably the
         same number as ``shape[1]``: then ``row' = (row * shape[1] + col) / new_shape[1] = row`` and
@@ -279,9 +334,10 @@ class PlanBuilder:
             return False
         return not (a[0] == "const" and a[1] <= 0)          # a literal -1 would be inferred at run time
 
-    def _ids_operand(self, node, port: int) -> Tuple[int, int, Optional[np.ndarray]]:
+    def _ids_operand(self, node, port: int):
+        """-> (host input, id_source, boundaries, transform kwargs for ColumnSpec, filter node)"""
         src = self.trace_index(node, port)
-        if src.stride != 1:                       # no strided id source in the column record
+        if src.stride != 1 or src.generated_rows:  # no strided id source in the column record
             src = self._terminal(node, port)
         if src.boundaries is not None:
             id_source = IDS_F32_BUCKETIZE
@@ -291,11 +347,18 @@ class PlanBuilder:
             id_source = IDS_I64
         else:
             raise Unsupported(f"ids tensor {src.tensor} has dtype {src.dtype}")
-        return self._host_input(src.tensor, src.dtype, src.rank), id_source, src.boundaries
+        xf = dict(xform_mode=src.xform_mode, xform_lo=src.xform_lo, xform_hi=src.xform_hi,
+                  xform_substitute=src.xform_substitute)
+        return self._host_input(src.tensor, src.dtype, src.rank), id_source, src.boundaries, xf, src.filter_node
 
-    def _seg_operand(self, node, port: int) -> Tuple[int, int, int]:
+    def _seg_operand(self, node, port: int, filter_node: Optional[str] = None) -> Tuple[int, int, int]:
+        """``filter_node``: the Gather* op the column's ids went through; its indices output may be read
+        through (the kernel drops the same pairs), any other filtered index stream may not."""
         src = self.trace_index(node, port)
-        if src.boundaries is not None:
+        if src.boundaries is not None or src.xform_mode != XFORM_NONE or src.generated_rows or \
+                src.filter_node != filter_node:
+            if filter_node is not None:
+                raise Unsupported("segment ids do not come from the id filter's indices output")
             src = self._terminal(node, port)
         kind = {P.DT_INT32: SEG_IDS_I32, P.DT_INT64: SEG_IDS_I64}.get(src.dtype)
         if kind is None:
@@ -303,47 +366,55 @@ class PlanBuilder:
         return self._host_input(src.tensor, src.dtype, src.rank), kind, src.stride
 
     # ---- EmitSubgraphCode dispatch (cuda_emitter.cc:1096-1152) --------------------------
-    def _match_gather(self, node) -> Tuple[str, int, int, int, int, Optional[np.ndarray]]:
+    def _match_gather(self, node):
         axis = self.g.const_array(*self.g.input(node, 2))
         if axis is None or int(axis.reshape(-1)[0]) != 0:
             raise Unsupported("GatherV2 axis is not 0")
         if "batch_dims" in node.attr and node.attr["batch_dims"].i != 0:
             raise Unsupported("GatherV2 batch_dims")
         table, vocab, dim = self._table_of(*self.g.input(node, 0))
-        ids_in, id_source, boundaries = self._ids_operand(*self.g.input(node, 1))
-        return table, vocab, dim, ids_in, id_source, boundaries
+        ids_in, id_source, boundaries, xf, fnode = self._ids_operand(*self.g.input(node, 1))
+        return table, vocab, dim, ids_in, id_source, boundaries, xf, fnode
 
     def match_column(self, node, port: int, group: int, slot: int) -> ColumnSpec:
         g = self.g
         if port != 0:
             raise Unsupported("value is not output 0")
         if node.op == "GatherV2":                                                   # EmitGatherRows :1246-1330
-            table, vocab, dim, ids_in, id_source, bnd = self._match_gather(node)
+            table, vocab, dim, ids_in, id_source, bnd, xf, fnode = self._match_gather(node)
+            if fnode is not None:                         # compacted values without their indices: rows are lost
+                raise Unsupported("GatherV2 over filtered values")
             return ColumnSpec(FORM_GATHER, dim, vocab, COMBINER_NONE, id_source, self._device_input(table), ids_in,
-                              -1, SEG_NONE, 1, ROWS_FROM_IDS, 0, bnd, group, slot)
+                              -1, SEG_NONE, 1, ROWS_FROM_IDS, 0, bnd, group, slot, **xf)
         if node.op in SEGMENT_OPS:                                                  # EmitSparseSegmentReduce* :1444-1760
             table, vocab, dim = self._table_of(*g.input(node, 0))
-            ids_in, id_source, bnd = self._ids_operand(*g.input(node, 1))
-            seg_in, seg_kind, stride = self._seg_operand(*g.input(node, 2))
+            ids_in, id_source, bnd, xf, fnode = self._ids_operand(*g.input(node, 1))
+            seg_in, seg_kind, stride = self._seg_operand(*g.input(node, 2), fnode)
             n_node, n_port = g.input(node, 3)
             while n_node.op in RESHAPE_LIKE and n_port == 0:                        # Squeeze(num_segments) lookup_optimizer.cc:248-254
                 n_node, n_port = g.input(n_node, 0)
             sym = self._symbol(tensor_name(n_node.name, n_port), 0)
             return ColumnSpec(FORM_SEGMENT_REDUCE, dim, vocab, SEGMENT_OPS[node.op], id_source,
                               self._device_input(table), ids_in, seg_in, seg_kind, stride, ROWS_FROM_SYMBOL, sym, bnd,
-                              group, slot)
+                              group, slot, **xf)
         if node.op in ("SparseSegmentSum", "SparseSegmentMean"):
             raise Unsupported("row count is data dependent without num_segments")
         if node.op == "ScatterNd":                                                  # EmitGatherScatterRows :1332-1442
             upd, upd_port = g.input(node, 1)
             if upd.op != "GatherV2" or upd_port != 0:
                 raise Unsupported("ScatterNd updates are not a GatherV2")
-            table, vocab, dim, ids_in, id_source, bnd = self._match_gather(upd)
-            seg_in, seg_kind, stride = self._seg_operand(*g.input(node, 0))
+            table, vocab, dim, ids_in, id_source, bnd, xf, fnode = self._match_gather(upd)
+            rows = self.trace_index(*g.input(node, 0))
+            if fnode is not None and rows.generated_rows and rows.filter_node == fnode:
+                # ScatterNd(GatherValueGenIndice:0, GatherV2(table, GatherValueGenIndice:1)): surviving value i
+                # goes to row i — a one-hot gather over the ORIGINAL values whose dropped ids leave zero rows
+                return ColumnSpec(FORM_GATHER, dim, vocab, COMBINER_NONE, id_source, self._device_input(table), ids_in,
+                                  -1, SEG_NONE, 1, ROWS_FROM_IDS, 0, bnd, group, slot, **xf)
+            seg_in, seg_kind, stride = self._seg_operand(*g.input(node, 0), fnode)
             shp, shp_port = g.input(node, 2)
             sym = self._symbol(tensor_name(shp.name, shp_port), 0)
             return ColumnSpec(FORM_GATHER_SCATTER, dim, vocab, COMBINER_NONE, id_source, self._device_input(table),
-                              ids_in, seg_in, seg_kind, stride, ROWS_FROM_SYMBOL, sym, bnd, group, slot)
+                              ids_in, seg_in, seg_kind, stride, ROWS_FROM_SYMBOL, sym, bnd, group, slot, **xf)
         if node.op == "Sum":                                                        # EmitBatchColReduction :1180-1244
             axis = g.const_array(*g.input(node, 1))
             if axis is None or axis.size != 1 or int(axis.reshape(-1)[0]) != 1:

@@ -200,6 +200,13 @@ class GraphView:
             p = self.static_shape(*self.input(node, 0), _depth + 1)
             i = self.static_shape(*self.input(node, 1), _depth + 1)
             return None if p is None or i is None else i + p[1:]
+        if op == "Addons>SelectValue":
+            return self.static_shape(*self.input(node, 0), _depth + 1)
+        if op == "Addons>GatherIndiceValue":                     # (surviving indices [n, k], surviving values [n])
+            idx = self.static_shape(*self.input(node, 0), _depth + 1)
+            return [None, idx[1] if idx and len(idx) == 2 else None] if port == 0 else [None]
+        if op == "Addons>GatherValueGenIndice":                  # (indices [n, 1], surviving values [n])
+            return [None, 1] if port == 0 else [None]
         if op == "SparseReshape":
             # (output_indices [nnz, rank(new_shape)], output_shape [rank(new_shape)])
             idx = self.static_shape(*self.input(node, 0), _depth + 1)

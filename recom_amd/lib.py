@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # FCP_LIB_DIR: tuning aid, loads an alternative build (e.g. build/abl4) of the same sources
 LIB_PATH = os.path.join(os.environ.get("FCP_LIB_DIR", _HERE), "libfcp_hip.so")
 
-FCP_ABI_VERSION = 1
+FCP_ABI_VERSION = 2
 FCP_OK = 0
 FCP_ERR_INVALID_ARGUMENT = 1
 FCP_ERR_SHAPE_MISMATCH = 2
@@ -40,6 +40,9 @@ class ColumnDesc(C.Structure):
         ("n_boundaries", C.c_int32),
         ("boundaries", C.POINTER(C.c_float)),
         ("concat_group", C.c_int32), ("concat_slot", C.c_int32),
+        ("xform_mode", C.c_int32), ("xform_n", C.c_int32),
+        ("xform_lo", C.POINTER(C.c_int64)), ("xform_hi", C.POINTER(C.c_int64)),
+        ("xform_substitute", C.c_int64),
     ]
 
 

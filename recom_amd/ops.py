@@ -72,10 +72,15 @@ class Plan:
                     c.form not in (FORM_PASSTHROUGH, FORM_BATCH_COL_REDUCTION):
                 b = np.ascontiguousarray(c.boundaries, np.float32)
                 self._keep.append(b)
+            xlo = np.ascontiguousarray(c.xform_lo, np.int64)
+            xhi = np.ascontiguousarray(c.xform_hi, np.int64)
+            self._keep += [xlo, xhi]
             cols[k] = _lib.ColumnDesc(
                 c.form, c.combiner, c.dim, c.id_source, c.vocab, c.table_input, c.ids_input, c.seg_input,
                 c.seg_kind, c.seg_stride, c.rows_source, c.rows_arg, 0 if b is None else len(b),
-                None if b is None else b.ctypes.data_as(C.POINTER(C.c_float)), c.concat_group, c.concat_slot)
+                None if b is None else b.ctypes.data_as(C.POINTER(C.c_float)), c.concat_group, c.concat_slot,
+                c.xform_mode, len(xlo), xlo.ctypes.data_as(C.POINTER(C.c_int64)) if len(xlo) else None,
+                xhi.ctypes.data_as(C.POINTER(C.c_int64)) if len(xhi) else None, int(c.xform_substitute))
         ranks = np.asarray(spec.host_input_ranks, np.int32)
         esz = np.asarray(spec.host_input_elem_sizes, np.int32)
         self._keep += [ranks, esz]

@@ -29,6 +29,7 @@ COMBINER_NONE, COMBINER_SUM, COMBINER_MEAN = 0, 1, 2
 IDS_I32, IDS_I64, IDS_F32_BUCKETIZE = 0, 1, 2
 SEG_NONE, SEG_IDS_I32, SEG_IDS_I64, SEG_CSR_I32 = 0, 1, 2, 3
 ROWS_FROM_IDS, ROWS_FROM_SYMBOL, ROWS_FROM_INPUT_DIM0, ROWS_FROM_GROUP = 0, 1, 2, 3
+XFORM_NONE, XFORM_SELECT, XFORM_FILTER = 0, 1, 2   # id transforms (SelectValue / GatherIndiceValue family)
 LAYOUT_CONCAT, LAYOUT_PER_COLUMN = 0, 1
 FLAG_COUNT_BAD_IDS = 1
 
@@ -55,6 +56,12 @@ class ColumnSpec:
     boundaries: Optional[np.ndarray] = None
     concat_group: int = 0
     concat_slot: int = 0
+    # id transform: closed integer intervals; SELECT substitutes ids outside them,
+    # FILTER drops them (custom_ops/select_value, gather_indice_value, gather_value_gen_indice)
+    xform_mode: int = XFORM_NONE
+    xform_lo: Sequence[int] = ()
+    xform_hi: Sequence[int] = ()
+    xform_substitute: int = 0
 
     def validate(self) -> None:
         if self.form not in (1, 2, 3, 4, 5, 6):
@@ -76,6 +83,13 @@ class ColumnSpec:
                 raise ValueError("pooled/scatter column needs an explicit row count source")
         if self.form == FORM_SEGMENT_REDUCE and self.combiner not in (COMBINER_SUM, COMBINER_MEAN):
             raise ValueError("segment-reduce column needs sum or mean")
+        if self.xform_mode != XFORM_NONE:
+            if self.form not in (FORM_GATHER, FORM_SEGMENT_REDUCE, FORM_GATHER_SCATTER):
+                raise ValueError("id transforms apply to lookup columns only")
+            if self.xform_mode not in (XFORM_SELECT, XFORM_FILTER) or len(self.xform_lo) != len(self.xform_hi):
+                raise ValueError("bad id transform")
+            if any(lo > hi for lo, hi in zip(self.xform_lo, self.xform_hi)):
+                raise ValueError("empty id transform interval")
 
 
 @dataclass
@@ -161,6 +175,8 @@ class PlanSpec:
         d = dataclasses.asdict(self)
         for c, src in zip(d["columns"], self.columns):
             c["boundaries"] = None if src.boundaries is None else np.asarray(src.boundaries, np.float32)
+            c["xform_lo"] = [int(v) for v in src.xform_lo]
+            c["xform_hi"] = [int(v) for v in src.xform_hi]
         return d
 
     def with_shard(self, rank: int, world: int) -> "PlanSpec":

@@ -13,7 +13,7 @@ from .plan import ColumnSpec, PlanSpec
 def save_plan(spec: PlanSpec, path: str) -> None:
     spec.validate()
     with open(path, "w") as f:
-        f.write("fcp_plan 1\n")
+        f.write("fcp_plan 2\n")
         f.write(f"layout {spec.layout}\n")
         f.write(f"groups {spec.n_groups} symbols {spec.n_symbols} device_inputs {spec.n_device_inputs}\n")
         f.write(f"host_inputs {spec.n_host_inputs}\n")
@@ -25,7 +25,10 @@ def save_plan(spec: PlanSpec, path: str) -> None:
             f.write(" ".join(str(x) for x in (
                 c.form, c.combiner, c.dim, c.id_source, c.vocab, c.table_input, c.ids_input, c.seg_input,
                 c.seg_kind, c.seg_stride, c.rows_source, c.rows_arg, c.concat_group, c.concat_slot, len(b))))
-            f.write((" " + " ".join(b) if b else "") + "\n")
+            f.write(" " + " ".join(b) if b else "")
+            # version 2: the id transform — mode, number of intervals, substitute, (lo, hi) pairs
+            x = [c.xform_mode, len(c.xform_lo), c.xform_substitute] + [v for p in zip(c.xform_lo, c.xform_hi) for v in p]
+            f.write(" " + " ".join(str(int(v)) for v in x) + "\n")
 
 
 def load_plan(path: str) -> PlanSpec:
@@ -38,7 +41,10 @@ def load_plan(path: str) -> PlanSpec:
         except StopIteration:
             raise ValueError(f"truncated column plan {path}") from None
 
-    if nxt() != "fcp_plan" or int(nxt()) != 1:
+    if nxt() != "fcp_plan":
+        raise ValueError("bad plan header")
+    version = int(nxt())
+    if version not in (1, 2):
         raise ValueError("bad plan header")
     assert nxt() == "layout"
     layout = int(nxt())
@@ -59,9 +65,16 @@ def load_plan(path: str) -> PlanSpec:
     for _ in range(int(nxt())):
         v = [int(nxt()) for _ in range(15)]
         b = np.asarray([float(nxt()) for _ in range(v[14])], np.float32) if v[14] else None
+        mode, lo, hi, sub = 0, [], [], 0
+        if version >= 2:
+            mode, n, sub = int(nxt()), int(nxt()), int(nxt())
+            for _ in range(n):
+                lo.append(int(nxt()))
+                hi.append(int(nxt()))
         cols.append(ColumnSpec(form=v[0], combiner=v[1], dim=v[2], id_source=v[3], vocab=v[4], table_input=v[5],
                                ids_input=v[6], seg_input=v[7], seg_kind=v[8], seg_stride=v[9], rows_source=v[10],
-                               rows_arg=v[11], concat_group=v[12], concat_slot=v[13], boundaries=b))
+                               rows_arg=v[11], concat_group=v[12], concat_slot=v[13], boundaries=b,
+                               xform_mode=mode, xform_lo=tuple(lo), xform_hi=tuple(hi), xform_substitute=sub))
     spec = PlanSpec(cols, ranks, esz, n_dev, n_groups=n_groups, n_symbols=n_symbols, layout=layout)
     spec.validate()
     return spec

@@ -396,3 +396,84 @@ def sparse_reshape_model(B=23, seed=0):
                Tidx=("type", P.DT_INT32))
         ins.append(g.node(f"output_{name}", "Identity", [f"{name}_layer/concat"], T=("type", P.DT_FLOAT)))
     return g.gd, feeds, variables, ins
+
+
+def id_filter_model(B=29, seed=0):
+    """Columns whose ids pass through the CPU id ops PreLookupOptimizer leaves in front of a lookup
+    (pre_lookup_optimizer.cc:596-654): SelectValue on a one-hot column; GatherIndiceValue (indices + values)
+    in front of a pooled mean and a pooled sum (the sum after Bucketize + Cast); GatherValueGenIndice +
+    ScatterNd (the dense-input form); and a column with TWO transforms in a row (only the outer one can be
+    fused: the inner op stays in TensorFlow).  Returns (graph_def, feeds, variables, fetches)."""
+    rng = np.random.default_rng(seed)
+    g = GB()
+    feeds, variables, ins = {}, {}, []
+
+    def table(name, vocab, dim):
+        t = g.variable(f"input_layer/{name}_embedding/embedding_weights", vocab, dim)
+        variables[t] = rng.standard_normal((vocab, dim)).astype(np.float32)
+        return t
+
+    def ivals(lo, hi):
+        return dict(left_boundaries=("ints", lo), right_boundaries=("ints", hi), T=("type", P.DT_INT64))
+
+    def sparse(prefix, vocab, max_len, dtype=np.int64):
+        lens = rng.integers(0, max_len + 1, size=B)
+        nnz = int(lens.sum())
+        idx = np.stack([np.repeat(np.arange(B), lens),
+                        np.concatenate([np.arange(l) for l in lens]) if nnz else np.zeros(0, np.int64)], 1)
+        g.placeholder(prefix + "/values", dtype, [-1])
+        g.placeholder(prefix + "/indices", np.int64, [-1, 2])
+        g.placeholder(prefix + "/rows", np.int64, [])
+        feeds[prefix + "/values"] = (rng.integers(0, vocab, size=nnz).astype(dtype) if dtype != np.float32
+                                     else rng.uniform(-10, 510, size=nnz).astype(np.float32))
+        feeds[prefix + "/indices"] = idx.astype(np.int64).reshape(nnz, 2)
+        feeds[prefix + "/rows"] = np.asarray(B, np.int64)
+
+    # a: one-hot, SelectValue (ids outside [10, 60] u [80, 90] become 3)
+    t = table("a", 97, 8)
+    g.placeholder("a_ids", np.int64, [-1])
+    feeds["a_ids"] = rng.integers(0, 97, size=B).astype(np.int64)
+    g.node("a/SelectValue", "Addons>SelectValue", ["a_ids"], substitute=3, **ivals([10, 80], [60, 90]))
+    ins.append(g.gather("input_layer/a_embedding/GatherDense", t, "a/SelectValue", np.int64))
+    # b: pooled mean, GatherIndiceValue keeps ids in [20, 150]
+    t = table("b", 211, 16)
+    sparse("b", 211, 6)
+    g.node("b/GatherIndiceValue", "Addons>GatherIndiceValue", ["b/indices", "b/values"], **ivals([20], [150]))
+    seg = g.slice_col0("b/added_strided_slice", "b/GatherIndiceValue", shrink=True)
+    ins.append(g.node("b/SparseSegmentMean_with_num_segments", "SparseSegmentMeanWithNumSegments",
+                      [t, "b/GatherIndiceValue:1", seg, "b/rows"], T=("type", P.DT_FLOAT), Tidx=("type", P.DT_INT64),
+                      Tsegmentids=("type", P.DT_INT64), Tnumsegments=("type", P.DT_INT64)))
+    # c: pooled sum over Bucketize(float) -> Cast -> GatherIndiceValue (buckets 5..95 survive)
+    t = table("c", 101, 8)
+    sparse("c", 101, 5, np.float32)
+    g.node("c/Bucketize", "Bucketize", ["c/values"], T=("type", P.DT_FLOAT), boundaries=("floats", MICRO_BOUNDARIES))
+    g.node("c/Cast", "Cast", ["c/Bucketize"], SrcT=("type", P.DT_INT32), DstT=("type", P.DT_INT64))
+    g.node("c/GatherIndiceValue", "Addons>GatherIndiceValue", ["c/indices", "c/Cast"], **ivals([5], [95]))
+    seg = g.slice_col0("c/added_strided_slice", "c/GatherIndiceValue", shrink=True)
+    ins.append(g.node("c/SparseSegmentSum_with_num_segments", "SparseSegmentSumWithNumSegments",
+                      [t, "c/GatherIndiceValue:1", seg, "c/rows"], T=("type", P.DT_FLOAT), Tidx=("type", P.DT_INT64),
+                      Tsegmentids=("type", P.DT_INT64), Tnumsegments=("type", P.DT_INT64)))
+    # d: dense input, GatherValueGenIndice + ScatterNd (a value outside [1, 40] leaves a zero row)
+    t = table("d", 64, 4)
+    g.placeholder("d_ids", np.int64, [-1])
+    feeds["d_ids"] = rng.integers(0, 64, size=B).astype(np.int64)
+    g.node("d/GatherValueGenIndice", "Addons>GatherValueGenIndice", ["d_ids"], **ivals([1], [40]))
+    g.gather("input_layer/d_embedding/GatherScatter/Gather", t, "d/GatherValueGenIndice:1", np.int64)
+    g.placeholder("d/rows", np.int64, [])
+    feeds["d/rows"] = np.asarray(B, np.int64)
+    g.const("d/dim", np.asarray(4, np.int64))
+    g.node("d/Scatter_shape", "Pack", ["d/rows", "d/dim"], N=2, T=("type", P.DT_INT64), axis=0)
+    ins.append(g.node("input_layer/d_embedding/GatherScatter/Scatter", "ScatterNd",
+                      ["d/GatherValueGenIndice", "input_layer/d_embedding/GatherScatter/Gather", "d/Scatter_shape"],
+                      T=("type", P.DT_FLOAT), Tindices=("type", P.DT_INT64)))
+    # e: two transforms in a row: SelectValue(SelectValue(ids)) — the outer one is fused, the inner one stays
+    t = table("e", 53, 12)
+    g.placeholder("e_ids", np.int64, [-1])
+    feeds["e_ids"] = rng.integers(0, 53, size=B).astype(np.int64)
+    g.node("e/inner", "Addons>SelectValue", ["e_ids"], substitute=1, **ivals([0], [30]))
+    g.node("e/outer", "Addons>SelectValue", ["e/inner"], substitute=2, **ivals([5], [52]))
+    ins.append(g.gather("input_layer/e_embedding/GatherDense", t, "e/outer", np.int64))
+    g.const("concat/axis", np.asarray(1, np.int32))
+    g.node("input_layer/concat", "ConcatV2", ins + ["concat/axis"], N=len(ins), T=("type", P.DT_FLOAT), Tidx=("type", P.DT_INT32))
+    g.node("output", "Identity", ["input_layer/concat"], T=("type", P.DT_FLOAT))
+    return g.gd, feeds, variables, ["output"]

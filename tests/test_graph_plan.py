@@ -11,7 +11,8 @@ import sys
 import numpy as np
 import pytest
 
-from graph_fixtures import MICRO_BOUNDARIES, canonical_model, microbenchmark_model, random_model, sparse_reshape_model
+from graph_fixtures import (MICRO_BOUNDARIES, canonical_model, id_filter_model, microbenchmark_model, random_model,
+                            sparse_reshape_model)
 from recom_amd import plan as PL
 from recom_amd.graph import Unsupported, build_plan, parse_graphdef, rewrite_graph
 from recom_amd.graph import tf_proto as P
@@ -284,6 +285,41 @@ def test_sparse_reshape_inlined_when_it_is_the_identity(oracle, tmp_path, B, see
     got = GraphEvaluator(out, variables, oracle_ops(oracle, built, variables)).run(fetches, feeds)
     for e, o in zip(expected, got):
         assert np.array_equal(e, o)
+
+
+@pytest.mark.parametrize("B,seed", [(29, 0), (1, 1), (90, 2)])
+def test_id_filter_ops_become_column_transforms(oracle, tmp_path, B, seed):
+    """Addons>SelectValue / GatherIndiceValue / GatherValueGenIndice in front of a lookup are
+    absorbed into the column plan (evaluated on the device next to Bucketize) and disappear from the
+    rewritten graph; the rewritten graph equals the original bit for bit."""
+    from tf_graph_eval import GraphEvaluator
+    gd, feeds, variables, fetches = id_filter_model(B=B, seed=seed)
+    expected = GraphEvaluator(gd, variables).run(fetches, feeds)
+    assert expected[0].shape == (B, 8 + 16 + 8 + 4 + 12)
+    built = build_plan(gd)
+    c = built.spec.columns
+    assert [x.form for x in c] == [1, 2, 2, 1, 1] and not built.skipped
+    assert (c[0].xform_mode, c[0].xform_lo, c[0].xform_hi, c[0].xform_substitute) == (PL.XFORM_SELECT, (10, 80), (60, 90), 3)
+    assert built.host_inputs[c[0].ids_input][0] == "a_ids"
+    assert (c[1].xform_mode, c[1].xform_lo, c[1].xform_hi) == (PL.XFORM_FILTER, (20,), (150,))
+    assert built.host_inputs[c[1].ids_input][0] == "b/values" and built.host_inputs[c[1].seg_input][0] == "b/indices"
+    assert c[1].seg_stride == 2 and c[1].combiner == PL.COMBINER_MEAN
+    assert c[2].id_source == PL.IDS_F32_BUCKETIZE and c[2].xform_mode == PL.XFORM_FILTER and c[2].xform_lo == (5,)
+    assert built.host_inputs[c[2].ids_input][0] == "c/values" and built.host_inputs[c[2].seg_input][0] == "c/indices"
+    # GatherValueGenIndice + ScatterNd: a one-hot gather over the original values with a filter
+    assert c[3].form == PL.FORM_GATHER and c[3].xform_mode == PL.XFORM_FILTER and built.host_inputs[c[3].ids_input][0] == "d_ids"
+    # two transforms: the outer one is fused, the inner op keeps running in TensorFlow
+    assert c[4].xform_mode == PL.XFORM_SELECT and c[4].xform_substitute == 2 and built.host_inputs[c[4].ids_input][0] == "e/inner"
+    path = str(tmp_path / "m.fcp")
+    save_plan(built.spec, path)
+    again = load_plan(path)
+    assert [(x.xform_mode, x.xform_lo, x.xform_hi, x.xform_substitute) for x in again.columns] == \
+           [(x.xform_mode, x.xform_lo, x.xform_hi, x.xform_substitute) for x in c]
+    out = parse_graphdef(rewrite_graph(gd, built, path).SerializeToString())
+    ops = [n.op for n in out.node]
+    assert ops.count("Addons>SelectValue") == 1 and "Addons>GatherIndiceValue" not in ops and "Addons>GatherValueGenIndice" not in ops
+    got = GraphEvaluator(out, variables, oracle_ops(oracle, built, variables)).run(fetches, feeds)
+    assert np.array_equal(expected[0], got[0])
 
 
 def test_elem_source_proofs():

@@ -443,3 +443,37 @@ def test_placement_gate():
     # a shared table counts once
     m = synth.model_mixed()
     assert len(table_bytes(m.spec)) == m.spec.n_device_inputs
+
+
+def test_hot_kernels_keep_full_occupancy(tmp_path):
+    """The fused kernels must stay at <= 64 VGPRs (8 waves per SIMD, MI355X_MICROARCH.md register table) and
+    use no scratch: round 2 lost 2 us of 29 on S2 when a rarely-taken branch (the id transform) pushed the
+    dense kernel to 76 VGPRs.  Read from the code object metadata hipcc emits for gfx950 (no GPU needed)."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not (os.path.exists(hipcc) or shutil.which("hipcc")):
+        pytest.skip("no hipcc")
+    asm = tmp_path / "k.s"
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-std=c++17", "-O3", "--offload-device-only", "-S",
+                        os.path.join(ROOT, "recom_amd", "csrc", "fcp_kernels.hip"), "-o", str(asm)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    text = asm.read_text()
+    seen = 0
+    for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", text, re.S):
+        name, body = m.group(1), m.group(2)
+        if not any(k in name for k in ("fcp_dense_kernel", "fcp_ragged_kernel", "fcp_hybrid_kernel")):
+            continue
+        seen += 1
+        vgpr = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", body).group(1))
+        scratch = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", body).group(1))
+        lds = int(re.search(r"\.amdhsa_group_segment_fixed_size (\d+)", body).group(1))
+        # the instantiations every full-size workload runs (4 rows per wave, or the ragged kernel) keep 8 waves per
+        # SIMD; the small-batch ones (< 64 rows: 1 or 2 rows per wave, the chip is not full anyway) may take 72
+        headline = "ELi4ELb" in name or "fcp_ragged_kernel" in name
+        assert vgpr <= (64 if headline else 72), f"{name}: {vgpr} VGPRs (> 64 costs a wave per SIMD)"
+        assert scratch == 0, f"{name}: uses scratch"
+        assert 8 * lds <= 160 * 1024, f"{name}: {lds} bytes of LDS leave fewer than 8 blocks per CU"
+    assert seen >= 12

@@ -138,6 +138,76 @@ def test_reference_block_scan_order_dim_le_20(oracle, mean, dim):
     assert not np.array_equal(seq, ref) and np.allclose(seq, ref, rtol=1e-4, atol=1e-2)
 
 
+def _xform_spec(m, transforms):
+    import dataclasses
+    cols = list(m.spec.columns)
+    for k, (mode, ivals, sub) in transforms.items():
+        cols[k] = dataclasses.replace(cols[k], xform_mode=mode, xform_lo=tuple(a for a, _ in ivals),
+                                      xform_hi=tuple(b for _, b in ivals), xform_substitute=sub)
+    spec = dataclasses.replace(m.spec, columns=cols)
+    spec.validate()
+    return spec
+
+
+XFORMS = {0: (2, [(100, 500)], 0), 1: (1, [(10, 60), (80, 90)], 3), 2: (1, [], 7), 3: (2, [(0, 300), (600, 996)], 0),
+          4: (2, [(200, 800)], 0), 5: (2, [(0, 498)], 0), 6: (1, [(0, 500)], -5), 7: (2, [(0, 700)], 0)}
+
+
+@pytest.mark.parametrize("batch,seed", [(33, 0), (1, 1), (120, 2)])
+def test_id_transforms_equal_the_cpu_ops_followed_by_the_lookup(oracle, batch, seed):
+    """a column with a fused id transform == the reference's CPU op applied to the request
+    (SelectValue: elementwise; GatherIndiceValue / GatherValueGenIndice: compaction of the (index, value)
+    pairs; select_value_ops.cc:33-56, gather_indice_value_ops.cc:33-78, gather_value_gen_indice_ops.cc:33-67,
+    with the intended `lo <= x && x <= hi`) followed by the untransformed column.  Also pinned against the
+    float64 NumPy restatement."""
+    from recom_amd import synth
+    from recom_amd.ops import concat_inputs
+    from recom_amd.plan import FORM_GATHER, SEG_CSR_I32
+    m = synth.model_mixed(batch=batch, vocab=997, n_groups=1)
+    spec = _xform_spec(m, XFORMS)
+    tabs = m.numpy_tables()
+    req = m.make_request(seed)
+    packed = concat_inputs(req.inputs)
+    got, bad = oracle.process_feature_columns(spec.to_dict(), *packed, tabs, req.symbols)
+    # the same request after the CPU ops, through the plain plan
+    inputs = [np.array(a) for a in req.inputs]
+    zero_rows = {}
+    for k, (mode, ivals, sub) in XFORMS.items():
+        c = m.spec.columns[k]
+        raw = inputs[c.ids_input]
+        ids = O.np_bucketize(c.boundaries, raw).astype(np.int64) if c.id_source == 2 else raw.astype(np.int64)
+        inside = np.zeros(ids.size, bool)
+        for lo, hi in ivals:
+            inside |= (ids >= lo) & (ids <= hi)
+        if c.id_source == 2:
+            continue                                          # checked through the NumPy restatement below
+        if mode == 1:                                         # Addons>SelectValue
+            inputs[c.ids_input] = np.where(inside, ids, sub).astype(raw.dtype)
+        elif c.form == FORM_GATHER:                           # Addons>GatherValueGenIndice: dropped values leave zero rows
+            zero_rows[k] = ~inside
+        else:                                                 # Addons>GatherIndiceValue
+            inputs[c.ids_input] = raw[inside]
+            seg = inputs[c.seg_input]
+            if c.seg_kind == SEG_CSR_I32:
+                rows = np.repeat(np.arange(seg.size - 1), np.diff(seg))[inside]
+                inputs[c.seg_input] = np.concatenate([[0], np.cumsum(np.bincount(rows, minlength=seg.size - 1))]).astype(np.int32)
+            else:
+                inputs[c.seg_input] = seg[inside]                  # rows of the [nnz, k] (or [nnz]) index tensor
+    plain_cols = {k: v for k, v in XFORMS.items() if m.spec.columns[k].id_source == 2}
+    want, bad2 = oracle.process_feature_columns(_xform_spec(m, plain_cols).to_dict(), *concat_inputs(inputs), tabs, req.symbols)
+    want = want[0].copy()
+    offs = m.spec.column_offsets()
+    for k, z in zero_rows.items():
+        want[z, offs[k]:offs[k] + m.spec.columns[k].dim] = 0.0
+    assert np.array_equal(got[0], want)
+    truth = O.np_process_feature_columns(spec.to_dict(), *packed, tabs, req.symbols)
+    assert np.abs(got[0] - truth[0]).max() < 1e-5
+    # substituted id -5 is out of range (counted), dropped ids are not lookups at all
+    c6 = m.spec.columns[6]
+    n_sub = int((~((req.inputs[c6.ids_input] >= 0) & (req.inputs[c6.ids_input] <= 500))).sum())
+    assert bad == n_sub
+
+
 def test_gather_scatter(oracle):
     W = np.arange(40, dtype=np.float32).reshape(10, 4)
     out, bad = oracle.gather_scatter_rows(W, [1, 2, 3, 9], [0, 2, 2, 5], 7)
