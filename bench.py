@@ -227,15 +227,9 @@ def main():
             dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
 
     if args.workload in ("shard", "shard-col"):
-        from recom_amd.shard import bench_sharded
-        rec = bench_sharded(args, rank, world, local_rank, dist, mode="row" if args.workload == "shard" else "col")
-        if rank == 0:
-            print(json.dumps(rec))
-        if dist:
-            dist.destroy_process_group()
-        return
-
-    if args.workload == "s2":
+        # BASELINE.json config 5: 4000 S2-shaped columns (480 GB); the flag names the model and the preferred sharding
+        model = synth.model_shard(columns=args.columns or 4000)
+    elif args.workload == "s2":
         model = synth.model_s2(columns=args.columns or 1000, dist=args.ids, **({'batch': args.batch} if args.batch else {}))
     elif args.workload == "dlrm":
         model = synth.model_dlrm()
@@ -244,6 +238,31 @@ def main():
     else:
         model = synth.model_ragged(columns=args.columns or 512, **({'batch': args.batch} if args.batch else {}),
                                    **({'vocab': args.vocab} if args.vocab else {}))
+
+    # The placement gate (a13): tables that fit this GPU's HBM are served from replicas — every rank its own
+    # requests, no collective; only beyond that are they sharded over the node's GPUs with one RCCL exchange per
+    # request.  The branch below is the gate's decision, not the flag's.  Tables that fit no placement on
+    # `world` GPUs are refused (FcpError names the smallest world that would do).
+    from recom_amd.lib import FcpError
+    from recom_amd.placement import REPLICATE, decide_placement, device_hbm_bytes
+    try:
+        placement = decide_placement(model.spec, world, hbm_bytes=device_hbm_bytes(local_rank),
+                                     prefer="column" if args.workload == "shard-col" else "row")
+    except FcpError as e:                            # the tables fit no placement on this many GPUs
+        if rank == 0:
+            print(f"bench.py: {model.name} ({model.table_bytes() / 1e9:.0f} GB of tables) cannot be placed on {world} GPU(s): {e}",
+                  file=sys.stderr)
+        if dist:
+            dist.destroy_process_group()
+        sys.exit(2)
+    if placement.mode != REPLICATE:
+        from recom_amd.shard import bench_sharded
+        rec = bench_sharded(args, model, placement, rank, world, local_rank, dist)
+        if rank == 0:
+            print(json.dumps(rec))
+        if dist:
+            dist.destroy_process_group()
+        return
 
     h = ServingHarness(model, device=local_rank, n_requests=args.requests, arena_ring=6, n_threads=args.threads,
                        seed0=1000 * rank)
@@ -294,7 +313,8 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{model.name}: {model.description}", "batch": batch,
                    "columns": model.spec.n_columns, "table_bytes": model.table_bytes(),
-                   "parallelism": f"{world} replica(s), requests sharded across ranks, no collective",
+                   "parallelism": f"{world} replica(s), requests sharded across ranks, no collective (placement gate: "
+                                  f"{model.table_bytes() / 1e9:.0f} GB of tables fit one GPU)",
                    "serve_workers": args.threads},
         "requests_per_s": value / batch,
         "p50_latency_ms": float(np.percentile(it, 50)), "p95_latency_ms": float(np.percentile(it, 95)),

@@ -70,7 +70,13 @@ enum {
    * cuda_emitter.cc:402-501, :564-661 (dim<=20) and :768-962 (dim>20) */
   FCP_FORM_SEGMENT_REDUCE = 2,
   /* ScatterNd(rows, GatherV2(table, ids), [B,dim]): zero-fill, then
-   * out[rows[i],:] = W[ids[i],:]   cuda_emitter.cc:296-345, :1332-1442 */
+   * out[rows[i],:] = W[ids[i],:]   cuda_emitter.cc:296-345, :1332-1442
+   * PRECONDITION: the row ids are ascending (the canonical order of SparseTensor
+   * indices, which is where LookupOptimizer::RewriteGatherScatter takes them from,
+   * lookup_optimizer.cc:324-440) with at most one id per row — the kernels find a
+   * row's id by position, like a segment; the reference's kernel scatters in any
+   * order.  With FCP_FLAG_COUNT_BAD_IDS, positions whose row id is smaller than its
+   * predecessor's are counted as bad ids when the segment-offset pre-pass runs. */
   FCP_FORM_GATHER_SCATTER = 3,
   /* A tensor of the ConcatInputs blob copied straight into its concat slot
    * (ConcatOutputs `host_inputs`, concat_outputs_op_gpu.cu.cc:186-216) */
@@ -331,6 +337,14 @@ int fcp_plan_arena_bytes(fcp_plan_t *plan, const int32_t *concated_shapes,
 int fcp_plan_read_bad_ids(fcp_plan_t *plan, void *stream, int64_t *count);
 
 /* ---- ProcessFeatureColumns (cuda_emitter.cc:2303-2494) ------------------- */
+/* HIP graphs: a request whose shapes are resident (it ran once on this stream) only
+ * enqueues kernels, so the call may be made while `stream` is being captured.  The
+ * recorded launch reads the request's descriptor slot whenever the graph is replayed:
+ * the slot is then kept until fcp_plan_release_captures (call it once the graphs are
+ * destroyed).  Capturing a request whose shapes are NOT resident returns
+ * FCP_ERR_UNSUPPORTED (descriptors cannot be installed inside a capture), as does a
+ * request with new shapes once all 8 slots belong to captured graphs. */
+int fcp_plan_release_captures(fcp_plan_t *plan);
 int fcp_process_feature_columns(fcp_plan_t *plan,
                                 const fcp_process_args_t *args,
                                 fcp_process_result_t *result);
@@ -395,6 +409,56 @@ int fcp_stager_stage_narrow(fcp_stager_t *stager, const fcp_host_tensor_t *input
                             const void **device_blob, int64_t *blob_bytes,
                             const int32_t **offsets, const int32_t **shapes);
 int fcp_stager_destroy(fcp_stager_t *stager);
+
+/* ---- multi-GPU exchange (no reference counterpart) ---------- */
+/* The ONE collective of the sharded path: an all-to-all partitioned along the batch,
+ * issued as grouped ncclSend / ncclRecv (RCCL) to every peer at once so that all
+ * xGMI links of the GPU carry traffic concurrently, on the request's stream, between
+ * the partial kernel and fcp_shard_finalize / fcp_concat_outputs.  RCCL is bound at
+ * run time (librccl.so.1); FCP_ERR_UNSUPPORTED where it is missing.
+ *
+ * A communicator belongs to one GPU of one process (one process per GPU).  Rank 0
+ * calls fcp_comm_unique_id and ships the 128 bytes to the other ranks by any
+ * host-side channel; every rank then calls fcp_comm_create (collective). */
+#define FCP_COMM_ID_BYTES 128
+#define FCP_MAX_GROUPS_ABI 16 /* fcp_plan_desc_t::n_groups is at most this */
+typedef struct fcp_comm fcp_comm_t;
+int fcp_comm_unique_id(uint8_t *id /* [FCP_COMM_ID_BYTES] */);
+int fcp_comm_create(const uint8_t *id, int32_t rank, int32_t world, int32_t device,
+                    fcp_comm_t **comm);
+int fcp_comm_destroy(fcp_comm_t *comm);
+int fcp_comm_rank(const fcp_comm_t *comm, int32_t *rank, int32_t *world);
+/* The batch split every exchange uses: contiguous, the first rows % world ranks get
+ * one row more. */
+int fcp_shard_batch_slice(int64_t rows, int32_t world, int32_t rank, int64_t *begin,
+                          int64_t *count);
+/* Row sharding: `partial` = this rank's [rows, width] partial sums (a row-sharded
+ * plan's group matrix); on return (enqueued) `slices` holds [world, row_count, width]:
+ * rows [row_begin, row_begin + row_count) of every rank's partial, in rank order —
+ * the input of fcp_shard_finalize. */
+int fcp_shard_exchange(fcp_comm_t *comm, const void *partial, int64_t rows,
+                       int64_t width, void *slices, int64_t *row_begin,
+                       int64_t *row_count, void *stream);
+/* Column sharding: `block` = this rank's [rows, widths[rank]] final column block;
+ * `recv` receives, back to back, the [row_count, widths[g]] blocks of g = 0..world-1
+ * (fcp_concat_outputs[_scatter] puts them side by side). */
+int fcp_shard_exchange_columns(fcp_comm_t *comm, const void *block, int64_t rows,
+                               const int32_t *widths, void *recv, int64_t *row_begin,
+                               int64_t *row_count, void *stream);
+/* One native call per sharded request: partial kernel -> exchange -> finalize (row
+ * mode, FCP_PLACE_ROW_SHARD) or concat (FCP_PLACE_COLUMN_SHARD) of concat group
+ * `group`, all enqueued on args->stream, from buffers the object owns (a ring of 3;
+ * args' allocator callbacks are ignored).  max_rows / max_arena_bytes bound the
+ * requests it will see (fcp_plan_arena_bytes); col_widths[world]: column mode only.
+ * *out: device [row_count, width] of this rank's batch slice, valid for the next two
+ * calls. */
+typedef struct fcp_shard_step fcp_shard_step_t;
+int fcp_shard_step_create(fcp_plan_t *plan, fcp_comm_t *comm, int32_t mode,
+                          int32_t group, int64_t max_rows, int64_t max_arena_bytes,
+                          const int32_t *col_widths, fcp_shard_step_t **step);
+int fcp_shard_step_run(fcp_shard_step_t *step, const fcp_process_args_t *args,
+                       void **out, int64_t *row_begin, int64_t *row_count);
+int fcp_shard_step_destroy(fcp_shard_step_t *step);
 
 /* ---- multi-GPU finalize (no reference counterpart) --------- */
 /* After the all-to-all of per-rank partial sums: out = sum over `world`

@@ -70,6 +70,7 @@ struct HostColumn {
 
 constexpr int64_t kSegSearchMaxPairs = 32768;
 constexpr int kAllSlotsBusy = -2; // find_or_reserve: every slot is pinned by a concurrent request
+constexpr int kNeedsInstall = -3; // find_or_reserve during stream capture: these shapes are not resident
 
 struct DynMeta {
   std::vector<int32_t> group_rows;
@@ -104,11 +105,16 @@ struct DynSlot {
   uint64_t tick = 0;
   int users = 0;                 // requests between "slot chosen" and "kernels enqueued": not evictable
   int uses = 0;                  // requests that have used this content since it was installed
+  bool captured = false;         // a stream capture recorded a launch that reads this slot: a graph replay will read
+                                 // it at any later time, so it is never evicted (fcp_plan_release_captures)
   bool was_valid = false;        // reserved for installation: the previous content had readers to wait for
   DynMeta meta;
 };
 
 } // namespace
+
+// failure reporting for the library's other translation units (fcp_shard.hip)
+int fcp_internal_fail(int code, const std::string &msg) { return fail(code, msg); }
 
 struct fcp_plan {
   fcp_plan_desc_t desc;
@@ -849,18 +855,29 @@ void build_key(const fcp_plan *p, const fcp_process_args_t *a, std::vector<int32
   key[key_len - 1] = (int32_t)(uint32_t)(stream_bits >> 32);
 }
 
-int find_or_reserve(fcp_plan *p, const std::vector<int32_t> &key, DynSlot **out, bool *install) {
+// `capturing`: the request's stream is being captured into a HIP graph.  The launch that gets recorded bakes
+// in the slot's device address, geometry and arena pointer and may be replayed at any later time: its slot
+// is marked `captured` and never evicted again; shapes that are not resident cannot be installed while
+// capturing (the installation synchronises and writes descriptors NOW, a replay would read whatever the
+// slot holds THEN): kNeedsInstall.
+int find_or_reserve(fcp_plan *p, const std::vector<int32_t> &key, DynSlot **out, bool *install, bool capturing) {
   ++p->tick;
   DynSlot *victim = nullptr;
+  int pinned = 0;
   for (auto &s : p->slots) {
     if (s.valid && s.key == key) {
       s.tick = p->tick;
       ++s.users;
       ++s.uses;
       s.done_valid = false; // one more reader that `done` (recorded by the installer) does not cover
+      if (capturing) s.captured = true;
       *out = &s;
       *install = false;
       return FCP_OK;
+    }
+    if (s.captured) {
+      ++pinned;
+      continue;
     }
     if (s.users > 0) continue; // being filled, or its kernels are being enqueued right now
     // preference: an empty slot; then the least recently used slot whose `done` event covers all of its
@@ -868,7 +885,10 @@ int find_or_reserve(fcp_plan *p, const std::vector<int32_t> &key, DynSlot **out,
     auto rank = [](const DynSlot &x) { return !x.valid ? 0 : (x.done_valid ? 1 : 2); };
     if (!victim || rank(s) < rank(*victim) || (rank(s) == rank(*victim) && s.tick < victim->tick)) victim = &s;
   }
-  if (!victim) return kAllSlotsBusy; // more concurrent requests than slots: the caller retries
+  if (capturing) return kNeedsInstall;
+  if (!victim)
+    return pinned == kSlots ? fail(FCP_ERR_UNSUPPORTED, "every descriptor slot belongs to a captured graph: fcp_plan_release_captures")
+                            : kAllSlotsBusy; // more concurrent requests than slots: the caller retries
   victim->was_valid = victim->valid;
   victim->valid = false;
   victim->users = 1;
@@ -1336,6 +1356,17 @@ int fcp_placement_decide(const int64_t *table_bytes, int32_t n_tables, int64_t h
   return FCP_OK;
 }
 
+int fcp_plan_release_captures(fcp_plan_t *p) {
+  if (!p) return fail(FCP_ERR_INVALID_ARGUMENT, "null plan");
+  std::lock_guard<std::mutex> lock(p->mu);
+  for (auto &s : p->slots) {
+    if (!s.captured) continue;
+    s.captured = false;
+    s.done_valid = false; // its readers were graph replays: the next installation drains the stream / device
+  }
+  return FCP_OK;
+}
+
 int fcp_plan_destroy(fcp_plan_t *p) {
   if (!p) return FCP_OK;
   if (!p->host_only) {
@@ -1425,17 +1456,26 @@ int fcp_process_feature_columns(fcp_plan_t *p, const fcp_process_args_t *a, fcp_
   bool install = false;
   thread_local std::vector<int32_t> key;
   build_key(p, a, key);
+  bool capturing = false;
+  {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (stream && hipStreamIsCapturing(stream, &st) == hipSuccess) capturing = st == hipStreamCaptureStatusActive;
+    else (void)hipGetLastError();
+  }
   {
     std::unique_lock<std::mutex> lock(p->mu);
     if (p->desc.n_device_inputs > 0) {
       rc = bind_tables(p, a->input_ptrs);
       if (rc) return rc;
     }
-    while ((rc = find_or_reserve(p, key, &slot, &install)) == kAllSlotsBusy) {
+    while ((rc = find_or_reserve(p, key, &slot, &install, capturing)) == kAllSlotsBusy) {
       lock.unlock();
       std::this_thread::yield();
       lock.lock();
     }
+    if (rc == kNeedsInstall)
+      return fail(FCP_ERR_UNSUPPORTED, "stream capture of a request whose shapes are not resident: run it once on this stream "
+                                       "before capturing (descriptors cannot be installed inside a capture)");
     if (rc) return rc;
   }
   SlotUnpin unpin{p, slot, false};
@@ -1463,6 +1503,7 @@ int fcp_process_feature_columns(fcp_plan_t *p, const fcp_process_args_t *a, fcp_
     S.dyn = slot->d_dyn;
     S.blob = L.blob;
     S.arena = L.arena;
+    S.bad_ids = p->d_bad;
     S.csr_arena_off = m.csr_arena_off;
     const int e = fcp_launch_segment_offsets(S, (int)p->seg_cols.size(), m.max_seg_nnz, stream);
     if (e) return hip_fail("segment-offsets launch", (hipError_t)e);
@@ -1642,7 +1683,7 @@ int fcp_shard_finalize(fcp_plan_t *p, const fcp_process_args_t *a, int32_t group
   build_key(p, &args, key);
   {
     std::unique_lock<std::mutex> lock(p->mu);
-    while ((rc = find_or_reserve(p, key, &slot, &install)) == kAllSlotsBusy) {
+    while ((rc = find_or_reserve(p, key, &slot, &install, false)) == kAllSlotsBusy) {
       lock.unlock();
       std::this_thread::yield();
       lock.lock();
@@ -1678,6 +1719,7 @@ int fcp_shard_finalize(fcp_plan_t *p, const fcp_process_args_t *a, int32_t group
     S.dyn = slot->d_dyn;
     S.blob = L.blob;
     S.arena = static_cast<char *>(scratch);
+    S.bad_ids = nullptr; // the partial pass has counted already
     S.csr_arena_off = 0;
     const int e = fcp_launch_segment_offsets(S, (int)p->seg_cols.size(), m.max_seg_nnz, stream);
     if (e) return hip_fail("segment-offsets launch", (hipError_t)e);

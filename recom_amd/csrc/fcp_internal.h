@@ -107,6 +107,7 @@ struct FcpSegLaunch {
   const char *blob;
   char *arena;
   int64_t csr_arena_off;     // byte offset of the CSR scratch in the arena
+  unsigned long long *bad_ids; // nullable: FCP_FLAG_COUNT_BAD_IDS also counts unsorted segment ids here
 };
 
 // ---- launchers implemented in fcp_kernels.hip --------------------------------

@@ -1057,6 +1057,9 @@ __global__ void __launch_bounds__(FCP_BLOCK_THREADS) fcp_segment_offsets_kernel(
     }
   }
   const bool boundary = active && cur > prev;
+  // sorted-ascending is the caller's contract (TF SparseSegment*, SparseTensor indices); a descending step is
+  // reported through the bad-id counter when the plan asks for it
+  if (L.bad_ids && active && i < nnz && cur < prev) atomicAdd(L.bad_ids, 1ull);
   if (__ballot(boundary) == 0ull) return;
   if (!boundary) return;
   int32_t *csr = reinterpret_cast<int32_t *>(L.arena + L.csr_arena_off) + cd.csr_base;
@@ -1118,7 +1121,8 @@ __global__ void __launch_bounds__(FCP_BLOCK_THREADS)
 #pragma unroll
     for (int t = 0; t < V; ++t) acc.v[t] = acc.v[t] + x.v[t];
   }
-  if (FCP_F_FORM(cs.flags) == FCP_FORM_SEGMENT_REDUCE && FCP_F_COMBINER(cs.flags) == FCP_COMBINER_MEAN) {
+  // (a plan with shard_world == 1 is not sharded: its kernels have already divided)
+  if (L.shard_world > 1 && FCP_F_FORM(cs.flags) == FCP_FORM_SEGMENT_REDUCE && FCP_F_COMBINER(cs.flags) == FCP_COMBINER_MEAN) {
     const unsigned segkind = FCP_F_SEGKIND(cs.flags);
     const int32_t *csr = segkind == FCP_SEG_CSR_I32
                              ? reinterpret_cast<const int32_t *>(L.blob + cd.seg_off)

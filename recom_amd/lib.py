@@ -100,9 +100,11 @@ EXPORTS = [
     "fcp_plan_create", "fcp_plan_create_from_file", "fcp_plan_counts", "fcp_plan_destroy", "fcp_plan_group_width",
     "fcp_plan_column_offset",
     "fcp_plan_arena_bytes", "fcp_plan_read_bad_ids", "fcp_plan_output_columns", "fcp_plan_table_bytes",
-    "fcp_placement_decide",
+    "fcp_placement_decide", "fcp_plan_release_captures",
     "fcp_process_feature_columns", "fcp_concat_outputs", "fcp_concat_outputs_scatter", "fcp_concat_outputs_host",
-    "fcp_shard_finalize",
+    "fcp_shard_finalize", "fcp_comm_unique_id", "fcp_comm_create", "fcp_comm_destroy", "fcp_comm_rank",
+    "fcp_shard_batch_slice", "fcp_shard_exchange", "fcp_shard_exchange_columns",
+    "fcp_shard_step_create", "fcp_shard_step_run", "fcp_shard_step_destroy",
     "fcp_stager_create", "fcp_stager_stage", "fcp_stager_stage_narrow", "fcp_stager_destroy",
 ]
 
@@ -169,6 +171,7 @@ def load() -> C.CDLL:
                                      C.c_void_p]
     L.fcp_plan_output_columns.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_void_p, C.c_int32]
     L.fcp_plan_table_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.fcp_plan_release_captures.argtypes = [C.c_void_p]
     L.fcp_placement_decide.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
                                        C.POINTER(Placement)]
     L.fcp_concat_outputs_scatter.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_int32, C.c_int64,
@@ -177,6 +180,20 @@ def load() -> C.CDLL:
                                           C.c_int32, C.c_void_p, ALLOC_FN, C.c_void_p, C.c_int32, C.c_void_p]
     L.fcp_shard_finalize.argtypes = [C.c_void_p, C.POINTER(ProcessArgs), C.c_int32, C.c_void_p, C.c_int32,
                                      C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
+    L.fcp_comm_unique_id.argtypes = [C.c_void_p]
+    L.fcp_comm_create.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
+    L.fcp_comm_destroy.argtypes = [C.c_void_p]
+    L.fcp_comm_rank.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L.fcp_shard_batch_slice.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.fcp_shard_exchange.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.POINTER(C.c_int64),
+                                     C.POINTER(C.c_int64), C.c_void_p]
+    L.fcp_shard_exchange_columns.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                             C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p]
+    L.fcp_shard_step_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_void_p,
+                                        C.POINTER(C.c_void_p)]
+    L.fcp_shard_step_run.argtypes = [C.c_void_p, C.POINTER(ProcessArgs), C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
+                                     C.POINTER(C.c_int64)]
+    L.fcp_shard_step_destroy.argtypes = [C.c_void_p]
     L.fcp_stager_create.argtypes = [C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                     C.POINTER(C.c_void_p)]
     L.fcp_stager_stage.argtypes = [C.c_void_p, C.POINTER(HostTensor), C.c_int32, C.c_void_p, C.POINTER(C.c_void_p),

@@ -225,34 +225,140 @@ class ShardedFeatureColumns:
         return self.path.run(partial, finalize)
 
 
-def bench_sharded(args, rank: int, world: int, local_rank: int, dist, mode: str = "row") -> dict:
-    """`bench.py --workload shard` (mode "row") / `--workload shard-col` (mode "col"):
-    S2-shaped model with 500 columns per GPU (60 GB of table rows per GPU; 4000 columns
-    / 480 GB at 8 GPUs).  "row": tables row-sharded, one all-to-all of partial sums per
-    request + finalize.  "col": whole columns per GPU, one all-to-all of final column
-    blocks per request + concat."""
+class Communicator:
+    """One RCCL communicator of this process' GPU, owned by ``libfcp_hip.so`` (``fcp_comm_*``).  The
+    128-byte id is created on rank 0 and shipped with ``torch.distributed`` (any backend; a host-side
+    channel, not the data path)."""
+
+    def __init__(self, rank: int, world: int, device: int, dist=None) -> None:
+        import ctypes as C
+        import torch
+        from . import lib as _lib
+        self._L = _lib.load()
+        ident = (C.c_uint8 * 128)()
+        if rank == 0:
+            _lib.check(self._L.fcp_comm_unique_id(ident), "fcp_comm_unique_id")
+        if world > 1:
+            t = torch.tensor(list(ident), dtype=torch.uint8)
+            if dist.get_backend() == "nccl":
+                t = t.cuda(device)
+            dist.broadcast(t, src=0)
+            ident = (C.c_uint8 * 128)(*t.cpu().tolist())
+        h = C.c_void_p()
+        _lib.check(self._L.fcp_comm_create(ident, rank, world, device, C.byref(h)), "fcp_comm_create")
+        self.handle, self.rank, self.world, self.device = h, rank, world, device
+
+    def close(self) -> None:
+        if getattr(self, "handle", None):
+            self._L.fcp_comm_destroy(self.handle)
+            self.handle = None
+
+
+class NativeShardedStep:
+    """The sharded serving step as ONE native call per request (``fcp_shard_step_run``): partial kernel ->
+    grouped ncclSend / ncclRecv over xGMI -> ``fcp_shard_finalize`` (row mode) or concat (column mode), on
+    one stream, from buffers the library owns.  Python prepares the request records once."""
+
+    def __init__(self, model, comm: Communicator, mode: str = "row", group: int = 0) -> None:
+        import ctypes as C
+        import torch
+        from . import lib as _lib
+        from .ops import Plan
+        from .placement import COLUMN_SHARD, ROW_SHARD
+        self.torch, self._lib, self._L, self.comm, self.mode = torch, _lib, _lib.load(), comm, mode
+        self.dev = torch.device("cuda", comm.device)
+        rank, world = comm.rank, comm.world
+        if mode == "row":
+            self.spec = model.spec.with_shard(rank, world)
+            self.tables = model.torch_tables(self.dev, rank, world)
+            self.host_inputs = list(range(model.spec.n_host_inputs))
+            widths = None
+        else:
+            from .synth import hash_table_torch
+            assignment = assign_columns(model.spec, world)
+            sub = model.spec.column_subset(assignment[rank])
+            self.spec, self.host_inputs = sub.spec, sub.host_inputs
+            self.tables = [hash_table_torch(model.tables[i].seed, model.tables[i].vocab, model.tables[i].dim, self.dev)
+                           for i in sub.device_inputs]
+            widths = np.asarray([sum(model.spec.columns[k].dim for k in cols if model.spec.columns[k].concat_group == group)
+                                 for cols in assignment], np.int32)
+        self.width = int(model.spec.group_width(group)) if mode == "row" else int(widths.sum())
+        self.plan = Plan(self.spec, comm.device)
+        self._tptrs = (C.c_void_p * max(1, len(self.tables)))(*[t.data_ptr() for t in self.tables])
+        self._widths = widths
+        self._step = None
+        self._keep = []
+        self._group = group
+
+    def prepare(self, inputs, symbols):
+        """Pack one request (this rank's share of its host tensors), put it in HBM and build the argument
+        record ``run`` replays.  Returns an opaque request."""
+        import ctypes as C
+        from .ops import concat_inputs
+        blob, offsets, shapes = concat_inputs([inputs[i] for i in self.host_inputs])
+        d_blob = self.torch.from_numpy(blob).to(self.dev)
+        sym = None if symbols is None else np.ascontiguousarray(symbols, np.int32)
+        a = self._lib.ProcessArgs(
+            d_blob.data_ptr() if blob.size else None, blob.nbytes, offsets.ctypes.data_as(C.POINTER(C.c_int32)),
+            shapes.ctypes.data_as(C.POINTER(C.c_int32)), self._tptrs, None,
+            None if sym is None else sym.ctypes.data_as(C.POINTER(C.c_int32)), None,
+            self._lib.ALLOC_FN(), None, self._lib.ALLOC_FN(), None)
+        if self._step is None:
+            rows = self.spec.group_rows(self._group, shapes, sym)
+            arena = self.plan.arena_bytes(shapes, sym)
+            from .placement import COLUMN_SHARD, ROW_SHARD
+            h = C.c_void_p()
+            self._lib.check(self._L.fcp_shard_step_create(
+                self.plan.handle, self.comm.handle, ROW_SHARD if self.mode == "row" else COLUMN_SHARD, self._group,
+                2 * rows, 2 * arena + (1 << 20), None if self._widths is None else self._widths.ctypes.data, C.byref(h)),
+                "fcp_shard_step_create")
+            self._step = h
+        self._keep.append((d_blob, offsets, shapes, sym))
+        return a
+
+    def run(self, request, stream=None):
+        """Enqueue one request; returns (torch view [count, width] of this rank's batch slice, begin, count)."""
+        import ctypes as C
+        torch = self.torch
+        request.stream = torch.cuda.current_stream(self.dev).cuda_stream if stream is None else stream
+        out, begin, count = C.c_void_p(), C.c_int64(), C.c_int64()
+        self._lib.check(self._L.fcp_shard_step_run(self._step, C.byref(request), C.byref(out), C.byref(begin), C.byref(count)),
+                        "fcp_shard_step_run")
+        return out.value, begin.value, count.value
+
+    def result(self, ptr: int, count: int):
+        """Copy of the slice `run` produced (the library's buffer is recycled after two more calls)."""
+        torch = self.torch
+        if not count:
+            return torch.empty((0, self.width), dtype=torch.float32, device=self.dev)
+        return _device_view(torch, ptr, count * self.width, self.dev).view(count, self.width).clone()
+
+    def close(self) -> None:
+        if self._step is not None:
+            self._L.fcp_shard_step_destroy(self._step)
+            self._step = None
+        self.plan.close()
+
+
+def _device_view(torch, ptr: int, numel: int, device):
+    """float32 torch view of `numel` elements of device memory at `ptr` (no ownership)."""
+    class _Holder:
+        __cuda_array_interface__ = {"shape": (numel,), "typestr": "<f4", "data": (ptr, False), "version": 2}
+    return torch.as_tensor(_Holder(), device=device)
+
+
+def bench_sharded(args, model, placement, rank: int, world: int, local_rank: int, dist) -> dict:
+    """`bench.py --workload shard[-col]` once the placement gate has decided to shard (BASELINE.json config 5:
+    4000 S2-shaped columns, 480 GB of tables): every rank holds its shard, every request runs partial
+    kernel -> RCCL all-to-all over xGMI -> finalize / concat as one native call (NativeShardedStep)."""
     import torch
-    from . import synth
-    from .ops import concat_inputs
-
-    columns = args.columns or 500 * world
-    model = synth.model_s2(columns=columns)
-    model.name = "SHARD" if mode == "row" else "SHARD-COL"
-    reqs = [model.make_request(s) for s in range(8)]  # identical on every rank (ids replicated)
-    if mode == "row":
-        sfc = ShardedFeatureColumns(model, rank, world, local_rank)
-        packed = [concat_inputs(r.inputs) for r in reqs]
-    else:
-        sfc = ColumnShardedFeatureColumns(model, rank, world, local_rank)
-        packed = [concat_inputs(sfc.request_inputs(r.inputs)) for r in reqs]
-    blobs = [torch.from_numpy(p[0]).to(sfc.dev) for p in packed]
-
-    def step(i):
-        k = i % len(reqs)
-        return sfc(blobs[k], packed[k][1], packed[k][2], reqs[k].symbols)
-
+    from .placement import ROW_SHARD
+    mode = "row" if placement.mode == ROW_SHARD else "col"
+    comm = Communicator(rank, world, local_rank, dist)
+    step = NativeShardedStep(model, comm, mode)
+    reqs = [step.prepare(r.inputs, r.symbols) for r in (model.make_request(s) for s in range(8))]  # ids replicated on every rank
     for i in range(max(args.warmup, 1)):
-        step(i)
+        step.run(reqs[i % len(reqs)])
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -260,7 +366,7 @@ def bench_sharded(args, rank: int, world: int, local_rank: int, dist, mode: str 
     t0 = time.perf_counter()
     e0.record()
     for i in range(args.steps):
-        step(i)
+        step.run(reqs[i % len(reqs)])
     e1.record()
     torch.cuda.synchronize()
     if dist:
@@ -272,32 +378,35 @@ def bench_sharded(args, rank: int, world: int, local_rank: int, dist, mode: str 
         elapsed = float(t.item())
     batch = model.batch
     width = model.spec.group_width(0)
-    full_req = concat_inputs(reqs[0].inputs)
-    bytes_alg = model.spec.algorithmic_bytes(full_req[2], reqs[0].symbols)
+    from .ops import concat_inputs
+    r0 = model.make_request(0)
+    bytes_alg = model.spec.algorithmic_bytes(concat_inputs(r0.inputs)[2], r0.symbols)
     if mode == "row":
         # per-GPU algorithmic bytes: 1/world of the table rows, all ids, the partial
         # [rows, width] written once, its slices sent / received, the final slice written
         per_gpu = bytes_alg["rows"] / world + bytes_alg["ids"] + bytes_alg["boundaries"] + batch * width * 4 * (
             1 + 2.0 * (world - 1) / world + 1.0 / world)
-        par = f"row-sharded x{world}, all_to_all_single of partial sums (RCCL)"
+        par = f"row-sharded x{world}: grouped ncclSend/ncclRecv of partial sums (RCCL over xGMI) + fcp_shard_finalize"
     else:
         # 1/world of the rows, ids and output; the block's remote slices sent / received,
         # and (world > 1) the final [count, width] slice read + written by the concat
         per_gpu = bytes_alg["total"] / world + batch * width * 4 / world * (
             2.0 * (world - 1) / world + (2.0 if world > 1 else 0.0))
-        par = f"column-sharded x{world}, all_to_all_single of final column blocks (RCCL)"
+        par = f"column-sharded x{world}: grouped ncclSend/ncclRecv of final column blocks (RCCL over xGMI) + concat"
     dev_s = e0.elapsed_time(e1) * 1e-3 / args.steps
+    step.close()
+    comm.close()
     return {
         "metric": f"inference QPS, {'row' if mode == 'row' else 'column'}-sharded tables (SHARD config)",
         "value": batch * args.steps / elapsed,
         "unit": "inferences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{model.name}: {model.description}; {columns} columns, tables "
-                               f"{'row' if mode == 'row' else 'column'}-sharded over {world} GPU(s)",
-                   "batch": batch, "columns": columns, "table_bytes": model.table_bytes(),
+        "config": {"workload": f"{model.name}: {model.description}; tables {placement.name} over {world} GPU(s) by the "
+                               f"placement gate ({placement.total_bytes / 1e9:.0f} GB of tables, {placement.bytes_per_gpu / 1e9:.0f} GB per GPU)",
+                   "batch": batch, "columns": model.spec.n_columns, "table_bytes": model.table_bytes(),
                    "parallelism": par},
         "roofline": {"bound": "hbm", "achieved": per_gpu / dev_s / 1e9, "peak": 8000.0, "unit": "GB/s",
                      "frac": per_gpu / dev_s / 1e9 / 8000.0, "traffic": None,
-                     "note": "per GPU, whole step (kernel + exchange + finalize/concat), torch events on the compute stream"},
+                     "note": "per GPU, whole step (partial kernel + exchange + finalize / concat), events on the compute stream"},
     }

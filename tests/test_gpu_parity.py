@@ -682,6 +682,59 @@ def test_process_call_is_hip_graph_capturable(torch_cuda, oracle):
         torch.cuda.synchronize()
         want, _ = oracle.process_feature_columns(m.spec.to_dict(), blob2, offsets, shapes, tabs_np, req.symbols)
         assert np.array_equal(out.groups[0].cpu().numpy(), want[0])
+    # The captured launch reads its descriptor slot at every replay: 12 requests with other shapes (more than
+    # the 8 slots) on the same stream must not evict it ...
+    import ctypes as C
+    from recom_amd import lib
+    others = [m.make_request(100 + k, B=40 + k) for k in range(12)]
+    with torch.cuda.stream(s):
+        for r in others:
+            b, o, sh = concat_inputs(r.inputs)
+            res = op(torch.from_numpy(b).cuda(), o, sh, tabs, r.symbols)
+            torch.cuda.synchronize()
+            w, _ = oracle.process_feature_columns(m.spec.to_dict(), b, o, sh, tabs_np, r.symbols)
+            assert np.array_equal(res.groups[0].cpu().numpy(), w[0])
+    g.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(out.groups[0].cpu().numpy(), want[0])
+    # ... and a request whose shapes are NOT resident cannot be captured (its descriptors would have to be
+    # installed inside the capture): refused, loudly
+    fresh = m.make_request(999, B=77)
+    fb, fo, fs = concat_inputs(fresh.inputs)
+    d_fresh = torch.from_numpy(fb).cuda()
+    g2 = torch.cuda.CUDAGraph()
+    with pytest.raises(lib.FcpError) as e:
+        with torch.cuda.graph(g2, stream=s):
+            op(d_fresh, fo, fs, tabs, fresh.symbols)
+    assert e.value.status == lib.FCP_ERR_UNSUPPORTED and "capture" in str(e.value)
+    torch.cuda.synchronize()
+    lib.check(lib.load().fcp_plan_release_captures(op.plan.handle), "fcp_plan_release_captures")
+    with torch.cuda.stream(s):                                 # the plan serves on after the release
+        res = op(d_fresh, fo, fs, tabs, fresh.symbols)
+    torch.cuda.synchronize()
+    w, _ = oracle.process_feature_columns(m.spec.to_dict(), fb, fo, fs, tabs_np, fresh.symbols)
+    assert np.array_equal(res.groups[0].cpu().numpy(), w[0])
+
+
+def test_unsorted_scatter_rows_are_reported(torch_cuda, oracle, monkeypatch):
+    """Form 3 (and form 2) take row ids in ascending order — the contract of SparseTensor indices.  A request
+    that breaks it is not silently accepted: with FCP_FLAG_COUNT_BAD_IDS every descending step is counted
+    (segment-offset pre-pass)."""
+    import dataclasses
+    from recom_amd import synth
+    from recom_amd.plan import FLAG_COUNT_BAD_IDS, FORM_GATHER_SCATTER
+    monkeypatch.setenv("FCP_SEG_PREPASS", "1")
+    m = synth.model_mixed(batch=40, vocab=997, n_groups=1)
+    spec = dataclasses.replace(m.spec, flags=FLAG_COUNT_BAD_IDS)
+    k = next(i for i, c in enumerate(spec.columns) if c.form == FORM_GATHER_SCATTER)
+    req = m.make_request(3)
+    _, _, op = run_gpu(torch_cuda, spec, req.inputs, m.numpy_tables(), req.symbols)
+    assert op.plan.read_bad_ids() == 0
+    idx = req.inputs[spec.columns[k].seg_input]
+    assert idx.shape[0] >= 3
+    idx[[0, 2]] = idx[[2, 0]]                                  # two rows swapped: one or two descending steps
+    run_gpu(torch_cuda, spec, req.inputs, m.numpy_tables(), req.symbols, op)
+    assert op.plan.read_bad_ids() in (1, 2)
 
 
 def test_empty_batch(torch_cuda, oracle):

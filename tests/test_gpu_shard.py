@@ -144,3 +144,49 @@ def test_shard_config_column_sharded_rank_share(torch_cuda, rank):
     assert np.array_equal(full.cpu().numpy(), want)
     del tabs, op, block, parts
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("mode", ["row", "col"])
+def test_native_exchange_and_step_world_1(torch_cuda, mode):
+    """fcp_comm_* / fcp_shard_exchange* / fcp_shard_step_* through RCCL on the one GPU a test box has: a
+    communicator of world 1 (send / receive to self inside one group), so what is checked is the binding,
+    the buffer arithmetic and the stream ordering of partial kernel -> exchange -> finalize / concat — the
+    8-GPU exchange itself is the driver's to run.  The step's result must equal the plain op's."""
+    import ctypes as C
+    import fcp_oracle as O
+    from recom_amd import lib, synth
+    from recom_amd.ops import concat_inputs
+    from recom_amd.shard import Communicator, NativeShardedStep
+    torch = torch_cuda
+    L = lib.load()
+    comm = Communicator(0, 1, 0)
+    r, w = C.c_int32(-1), C.c_int32(-1)
+    lib.check(L.fcp_comm_rank(comm.handle, C.byref(r), C.byref(w)), "fcp_comm_rank")
+    assert (r.value, w.value) == (0, 1)
+    # raw exchanges: to self
+    x = torch.arange(37 * 20, dtype=torch.float32, device="cuda").view(37, 20)
+    y = torch.zeros_like(x)
+    b, c = C.c_int64(), C.c_int64()
+    s = torch.cuda.current_stream().cuda_stream
+    lib.check(L.fcp_shard_exchange(comm.handle, x.data_ptr(), 37, 20, y.data_ptr(), C.byref(b), C.byref(c), s), "exchange")
+    torch.cuda.synchronize()
+    assert (b.value, c.value) == (0, 37) and torch.equal(x, y)
+    y.zero_()
+    widths = np.asarray([20], np.int32)
+    lib.check(L.fcp_shard_exchange_columns(comm.handle, x.data_ptr(), 37, widths.ctypes.data, y.data_ptr(), C.byref(b),
+                                           C.byref(c), s), "exchange_columns")
+    torch.cuda.synchronize()
+    assert torch.equal(x, y)
+    # the whole step, every column form (mean columns: a world-1 "shard" is already divided by its kernel)
+    orc = O.COracle()
+    for m in (synth.model_mixed(batch=50, vocab=997, n_groups=1), synth.model_s2(columns=64, vocab=5000, batch=96)):
+        step = NativeShardedStep(m, comm, mode)
+        tabs_np = m.numpy_tables()
+        for seed in range(5):                         # more requests than the step's ring of buffers
+            req = m.make_request(seed)
+            want, _ = orc.process_feature_columns(m.spec.to_dict(), *concat_inputs(req.inputs), tabs_np, req.symbols)
+            ptr, begin, count = step.run(step.prepare(req.inputs, req.symbols))
+            got = step.result(ptr, count).cpu().numpy()
+            assert (begin, count) == (0, want[0].shape[0]) and np.array_equal(got, want[0]), (m.name, seed)
+        step.close()
+    comm.close()

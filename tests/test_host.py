@@ -477,3 +477,23 @@ def test_hot_kernels_keep_full_occupancy(tmp_path):
         assert scratch == 0, f"{name}: uses scratch"
         assert 8 * lds <= 160 * 1024, f"{name}: {lds} bytes of LDS leave fewer than 8 blocks per CU"
     assert seen >= 12
+
+
+def test_shard_exchange_entry_points_without_a_gpu():
+    """The exchange under the C ABI (fcp_shard.hip): the batch split equals recom_amd.shard.batch_slices; bad
+    arguments are refused before RCCL or a device is touched."""
+    import ctypes as C
+    from recom_amd import lib
+    from recom_amd.shard import batch_slices
+    L = lib.load()
+    for rows, world in ((33, 2), (512, 8), (3, 4), (0, 3), (100, 7)):
+        for rank, want in enumerate(batch_slices(rows, world)):
+            b, c = C.c_int64(), C.c_int64()
+            lib.check(L.fcp_shard_batch_slice(rows, world, rank, C.byref(b), C.byref(c)), "fcp_shard_batch_slice")
+            assert (b.value, c.value) == want
+    b, c = C.c_int64(), C.c_int64()
+    assert L.fcp_shard_batch_slice(10, 2, 2, C.byref(b), C.byref(c)) == lib.FCP_ERR_INVALID_ARGUMENT
+    assert L.fcp_comm_create(None, 0, 1, 0, C.byref(C.c_void_p())) == lib.FCP_ERR_INVALID_ARGUMENT
+    assert L.fcp_shard_exchange(None, None, 4, 4, None, None, None, None) == lib.FCP_ERR_INVALID_ARGUMENT
+    assert L.fcp_shard_step_run(None, None, None, None, None) == lib.FCP_ERR_INVALID_ARGUMENT
+    assert L.fcp_comm_destroy(None) == lib.FCP_OK and L.fcp_shard_step_destroy(None) == lib.FCP_OK
