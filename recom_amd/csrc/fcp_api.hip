@@ -799,19 +799,22 @@ int bind_tables(fcp_plan *p, const void *const *input_ptrs) {
   const int nt = p->desc.n_device_inputs;
   if (p->tables_bound && std::memcmp(p->bound_tables.data(), input_ptrs, nt * sizeof(void *)) == 0)
     return FCP_OK;
-  if (p->tables_bound) HIP_TRY(hipDeviceSynchronize()); // in-flight requests still read the old table
-  for (int t = 0; t < nt; ++t) p->bound_tables[t] = input_ptrs[t];
+  // validate first and build the new records aside: a failure leaves the plan exactly as it was
+  std::vector<FcpColStatic> cols = p->h_cols;
   for (size_t k = 0; k < p->cols.size(); ++k) {
     const int t = p->cols[k].d.table_input;
     const bool lookup = p->cols[k].d.form == FCP_FORM_GATHER || p->cols[k].d.form == FCP_FORM_SEGMENT_REDUCE ||
                         p->cols[k].d.form == FCP_FORM_GATHER_SCATTER;
     if (lookup) {
       if (!input_ptrs[t]) return fail(FCP_ERR_INVALID_ARGUMENT, "null table pointer");
-      p->h_cols[p->pos_of[k]].table = static_cast<const float *>(input_ptrs[t]);
+      cols[p->pos_of[k]].table = static_cast<const float *>(input_ptrs[t]);
     }
   }
-  HIP_TRY(hipMemcpy(p->d_cols, p->h_cols.data(), p->h_cols.size() * sizeof(FcpColStatic),
-                    hipMemcpyHostToDevice));
+  if (p->tables_bound) HIP_TRY(hipDeviceSynchronize()); // in-flight requests still read the old tables
+  p->tables_bound = false;                               // until the upload below has succeeded
+  HIP_TRY(hipMemcpy(p->d_cols, cols.data(), cols.size() * sizeof(FcpColStatic), hipMemcpyHostToDevice));
+  p->h_cols.swap(cols);
+  for (int t = 0; t < nt; ++t) p->bound_tables[t] = input_ptrs[t];
   p->tables_bound = true;
   return FCP_OK;
 }

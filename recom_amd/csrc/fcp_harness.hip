@@ -133,16 +133,18 @@ int fcp_harness_run(fcp_harness *h, int steps, double *wall_ms, float *dev_ms, f
   H_TRY(hipEventRecord(h->e0, h->streams[0]));
   std::vector<std::thread> workers;
   for (int t = 1; t < n_threads; ++t) workers.emplace_back([h, t, begin, steps] { h->issue(t, begin, steps); });
+  hipError_t worker0 = hipSuccess; // no early return while the other workers run: a joinable std::thread must be joined
   if (iter_ms) {
-    for (int k = 0; k < steps; ++k) {
-      H_TRY(hipEventRecord(ev[2 * k], h->streams[0]));
+    for (int k = 0; k < steps && worker0 == hipSuccess; ++k) {
+      worker0 = hipEventRecord(ev[2 * k], h->streams[0]);
       h->issue(0, begin + k, 1);
-      H_TRY(hipEventRecord(ev[2 * k + 1], h->streams[0]));
+      if (worker0 == hipSuccess) worker0 = hipEventRecord(ev[2 * k + 1], h->streams[0]);
     }
   } else {
     h->issue(0, begin, steps);
   }
   for (auto &w : workers) w.join();
+  H_TRY(worker0);
   H_TRY(hipEventRecord(h->e1, h->streams[0]));
   for (int t = 0; t < n_threads; ++t) H_TRY(hipStreamSynchronize(h->streams[t]));
   const auto t1 = std::chrono::steady_clock::now();
