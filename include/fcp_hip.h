@@ -189,6 +189,13 @@ typedef struct fcp_column_desc {
   const int64_t *xform_lo; /* host int64[xform_n], copied at plan creation    */
   const int64_t *xform_hi;
   int64_t xform_substitute; /* FCP_XFORM_SELECT                               */
+  /* > 0: categorical_column_with_hash_bucket over INTEGER ids, on the device:
+   * id' = Fingerprint64(decimal string of id) % hash_buckets — what TensorFlow's
+   * AsString -> StringToHashBucketFast pair computes (TF 2.6.2
+   * core/kernels/string_to_hash_bucket_fast_op.h: Fingerprint64 = FarmHash
+   * farmhashna::Hash64, third_party farmhash commit 816a4ae6).  Applied FIRST,
+   * before the interval transform.  String features are hashed on the CPU. */
+  int64_t hash_buckets;
 } fcp_column_desc_t;
 
 typedef struct fcp_plan_desc {
@@ -279,8 +286,8 @@ int fcp_plan_create(const fcp_plan_desc_t *desc, fcp_plan_t **plan);
  *   N lines "rank elem_size" / columns C, C lines "form combiner dim id_source
  *   vocab table_input ids_input seg_input seg_kind seg_stride rows_source
  *   rows_arg concat_group concat_slot n_boundaries b0 b1 ..." — version 2 files
- *   ("fcp_plan 2") append "xform_mode xform_n substitute lo0 hi0 lo1 hi1 ..." to
- *   every column line.
+ *   ("fcp_plan 2") append "xform_mode xform_n substitute hash_buckets lo0 hi0 lo1
+ *   hi1 ..." to every column line.
  * `flags`: fcp_plan_desc_t::flags.  FCP_ERR_INVALID_ARGUMENT for a missing or
  * malformed file. */
 int fcp_plan_create_from_file(const char *path, int32_t device, uint32_t flags,

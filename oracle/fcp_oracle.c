@@ -18,6 +18,7 @@
  */
 #include "fcp_oracle.h"
 
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -421,6 +422,51 @@ static void load_ids(const orc_column_t *c, const int8_t *src, int64_t n, int64_
   }
 }
 
+/* ---- Fingerprint64 (FarmHash farmhashna::Hash64) for len <= 32 ------------------------------------- */
+static uint64_t fp_fetch64(const char *p) { uint64_t v; memcpy(&v, p, 8); return v; }   /* little endian hosts */
+static uint32_t fp_fetch32(const char *p) { uint32_t v; memcpy(&v, p, 4); return v; }
+static uint64_t fp_rot(uint64_t v, int s) { return s ? (v >> s) | (v << (64 - s)) : v; }
+static uint64_t fp_len16(uint64_t u, uint64_t v, uint64_t mul) {
+  uint64_t a = (u ^ v) * mul;
+  a ^= a >> 47;
+  uint64_t b = (v ^ a) * mul;
+  b ^= b >> 47;
+  return b * mul;
+}
+uint64_t orc_fingerprint64(const char *s, size_t len) {
+  const uint64_t k0 = 0xc3a5c85c97cb3127ULL, k1 = 0xb492b66fbe98f273ULL, k2 = 0x9ae16a3b2f90404fULL;
+  if (len <= 16) { /* HashLen0to16 */
+    if (len >= 8) {
+      uint64_t mul = k2 + len * 2, a = fp_fetch64(s) + k2, b = fp_fetch64(s + len - 8);
+      return fp_len16(fp_rot(b, 37) * mul + a, (fp_rot(a, 25) + b) * mul, mul);
+    }
+    if (len >= 4) {
+      uint64_t mul = k2 + len * 2, a = fp_fetch32(s);
+      return fp_len16(len + (a << 3), fp_fetch32(s + len - 4), mul);
+    }
+    if (len > 0) {
+      uint8_t a = (uint8_t)s[0], b = (uint8_t)s[len >> 1], c = (uint8_t)s[len - 1];
+      uint32_t y = (uint32_t)a + ((uint32_t)b << 8), z = (uint32_t)len + ((uint32_t)c << 2);
+      uint64_t h = (uint64_t)y * k2 ^ (uint64_t)z * k0;
+      h ^= h >> 47;
+      return h * k2;
+    }
+    return k2;
+  }
+  if (len <= 32) { /* HashLen17to32 */
+    uint64_t mul = k2 + len * 2, a = fp_fetch64(s) * k1, b = fp_fetch64(s + 8), c = fp_fetch64(s + len - 8) * mul,
+             d = fp_fetch64(s + len - 16) * k2;
+    return fp_len16(fp_rot(a + b, 43) + fp_rot(c, 30) + d, a + fp_rot(b + k2, 18) + c, mul);
+  }
+  return 0; /* longer strings are not on this path (decimal int64: at most 20 bytes) */
+}
+
+int64_t orc_hash_bucket_int64(int64_t value, int64_t num_buckets) {
+  char buf[32];
+  int n = snprintf(buf, sizeof buf, "%lld", (long long)value); /* AsString: plain decimal */
+  return (int64_t)(orc_fingerprint64(buf, (size_t)n) % (uint64_t)num_buckets);
+}
+
 /* The interval test of the id-filter ops (select_value_ops.cc:35-41 and siblings), as intended. */
 static int xform_in(const orc_column_t *c, int64_t x) {
   for (int32_t i = 0; i < c->xform_n; ++i)
@@ -500,6 +546,8 @@ static int64_t process_column(const orc_plan_t *p, int32_t k, const int8_t *blob
   /* the CPU id ops that sit in front of the lookup, applied here as they are in the graph.
    * SelectValue: elementwise.  GatherIndiceValue / GatherValueGenIndice: the (index, value) pairs that fail
    * the test are removed — `keep` marks the survivors; the segment structure is compacted below. */
+  if (c->hash_buckets > 0)
+    for (int64_t i = 0; i < nnz; ++i) ids[i] = orc_hash_bucket_int64(ids[i], c->hash_buckets);
   uint8_t *keep = NULL;
   if (c->xform_mode == ORC_XFORM_SELECT) {
     for (int64_t i = 0; i < nnz; ++i)

@@ -19,6 +19,7 @@
 #ifndef FCP_ORACLE_H_
 #define FCP_ORACLE_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -55,7 +56,20 @@ typedef struct orc_column {
   int32_t xform_mode, xform_n;
   const int64_t *xform_lo, *xform_hi;
   int64_t xform_substitute;
+  /* > 0: id = Fingerprint64(AsString(id)) % hash_buckets first (TensorFlow AsString ->
+   * StringToHashBucketFast, the graph of categorical_column_with_hash_bucket over integer features;
+   * reference models: examples/python/dlrm.py "hash-int" columns) */
+  int64_t hash_buckets;
 } orc_column_t;
+
+/* TensorFlow 2.6.2's Fingerprint64 (core/platform/fingerprint.h -> FarmHash farmhashna::Hash64, third_party
+ * farmhash 816a4ae6; un-vendored here) for strings of at most 32 bytes, restated from the published
+ * algorithm.  Known answers it is pinned to (tests/test_oracle.py): "" -> k2; "abc" -> 0x24a5b3a074e7f369
+ * (the CityHash64 v1.1 / FarmHash na test value for short strings, the same code path);
+ * tf.strings.to_hash_bucket_fast(["Hello", "TensorFlow", "2.x"], 3) == [0, 2, 2] (TensorFlow API docs). */
+uint64_t orc_fingerprint64(const char *s, size_t len);
+/* StringToHashBucketFast(AsString(value), num_buckets) */
+int64_t orc_hash_bucket_int64(int64_t value, int64_t num_buckets);
 
 typedef struct orc_plan {
   int32_t n_columns;

@@ -54,7 +54,7 @@ class _Column(C.Structure):
         ("concat_group", C.c_int32), ("concat_slot", C.c_int32),
         ("xform_mode", C.c_int32), ("xform_n", C.c_int32),
         ("xform_lo", C.POINTER(C.c_int64)), ("xform_hi", C.POINTER(C.c_int64)),
-        ("xform_substitute", C.c_int64),
+        ("xform_substitute", C.c_int64), ("hash_buckets", C.c_int64),
     ]
 
 
@@ -96,6 +96,10 @@ class COracle:
                                                        C.c_int64, C.c_int32, C.c_void_p, C.c_int64]
         L.orc_sparse_segment_reduce_refscan.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64,
                                                         C.c_int64, C.c_int32, C.c_void_p, C.c_int64]
+        L.orc_fingerprint64.restype = C.c_uint64
+        L.orc_fingerprint64.argtypes = [C.c_char_p, C.c_size_t]
+        L.orc_hash_bucket_int64.restype = C.c_int64
+        L.orc_hash_bucket_int64.argtypes = [C.c_int64, C.c_int64]
         L.orc_batch_col_reduction.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p,
                                               C.c_int64]
         L.orc_concat_outputs.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p]
@@ -226,7 +230,8 @@ class COracle:
                 None if b is None else b.ctypes.data_as(C.POINTER(C.c_float)),
                 c["concat_group"], c["concat_slot"], c.get("xform_mode", 0), len(xlo),
                 xlo.ctypes.data_as(C.POINTER(C.c_int64)) if len(xlo) else None,
-                xhi.ctypes.data_as(C.POINTER(C.c_int64)) if len(xhi) else None, int(c.get("xform_substitute", 0)))
+                xhi.ctypes.data_as(C.POINTER(C.c_int64)) if len(xhi) else None, int(c.get("xform_substitute", 0)),
+                int(c.get("hash_buckets", 0)))
         ranks = _i32(plan["host_input_ranks"])
         esz = _i32(plan["host_input_elem_sizes"])
         keep += [ranks, esz]
@@ -287,6 +292,46 @@ class COracle:
 # =============================================================================
 # NumPy restatement (float64 accumulation) — the independent pin for the C oracle
 # =============================================================================
+
+def np_fingerprint64(s: bytes) -> int:
+    """TensorFlow's Fingerprint64 (FarmHash farmhashna::Hash64) for len(s) <= 32, in Python integers —
+    an independent restatement of the published algorithm next to the C one (orc_fingerprint64)."""
+    M = (1 << 64) - 1
+    k0, k1, k2 = 0xc3a5c85c97cb3127, 0xb492b66fbe98f273, 0x9ae16a3b2f90404f
+
+    def rot(v, sh):
+        return ((v >> sh) | (v << (64 - sh))) & M if sh else v
+
+    def f(i, n):
+        return int.from_bytes(s[i:i + n], "little")
+
+    def len16(u, v, mul):
+        a = ((u ^ v) * mul) & M
+        a ^= a >> 47
+        b = ((v ^ a) * mul) & M
+        b ^= b >> 47
+        return (b * mul) & M
+
+    n = len(s)
+    if n <= 16:
+        if n >= 8:
+            mul, a, b = (k2 + 2 * n) & M, (f(0, 8) + k2) & M, f(n - 8, 8)
+            return len16((rot(b, 37) * mul + a) & M, ((rot(a, 25) + b) * mul) & M, mul)
+        if n >= 4:
+            mul = (k2 + 2 * n) & M
+            return len16((n + (f(0, 4) << 3)) & M, f(n - 4, 4), mul)
+        if n > 0:
+            y, z = (s[0] + (s[n >> 1] << 8)) & 0xFFFFFFFF, (n + (s[n - 1] << 2)) & 0xFFFFFFFF
+            h = (y * k2 ^ z * k0) & M
+            h ^= h >> 47
+            return (h * k2) & M
+        return k2
+    if n > 32:
+        raise NotImplementedError("Fingerprint64 of strings longer than 32 bytes is not on this path")
+    mul = (k2 + 2 * n) & M
+    a, b, c, d = (f(0, 8) * k1) & M, f(8, 8), (f(n - 8, 8) * mul) & M, (f(n - 16, 8) * k2) & M
+    return len16((rot((a + b) & M, 43) + rot(c, 30) + d) & M, (a + rot((b + k2) & M, 18) + c) & M, mul)
+
 
 def np_bucketize(boundaries, values) -> np.ndarray:
     """TF Bucketize == number of boundaries <= value (cuda_emitter.cc:233-247)."""
@@ -365,6 +410,8 @@ def np_process_feature_columns(plan: dict, blob: np.ndarray, offsets, shapes, ta
             ids = np_bucketize(c["boundaries"], tensor(c["ids_input"], np.float32).ravel()).astype(np.int64)
         else:
             ids = tensor(c["ids_input"], np.int32 if c["id_source"] == 0 else np.int64).ravel().astype(np.int64)
+        if c.get("hash_buckets", 0):
+            ids = np.asarray([np_fingerprint64(str(int(v)).encode()) % c["hash_buckets"] for v in ids], np.int64)
         mode = c.get("xform_mode", 0)
         kept = np.ones(ids.size, bool)
         if mode:

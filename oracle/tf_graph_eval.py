@@ -181,6 +181,19 @@ class GraphEvaluator:
             if op == "Addons>GatherIndiceValue":
                 return [x[0].reshape(keep.size, -1)[keep], values.ravel()[keep]]
             return [np.nonzero(keep)[0].astype(values.dtype).reshape(-1, 1), values.ravel()[keep]]
+        if op == "AsString":
+            # integers only (what categorical_column_with_hash_bucket(dtype=int64) feeds): plain decimal
+            assert x[0].dtype.kind in "iu", "AsString: integer tensors only"
+            out = np.empty(x[0].shape, object)
+            out.ravel()[:] = [str(int(v)).encode() for v in x[0].ravel()]
+            return [out]
+        if op == "StringToHashBucketFast":
+            # Fingerprint64(s) % num_buckets (TF core/kernels/string_to_hash_bucket_fast_op.h)
+            from fcp_oracle import np_fingerprint64
+            nb = int(a["num_buckets"].i)
+            out = np.empty(x[0].shape, np.int64)
+            out.ravel()[:] = [np_fingerprint64(bytes(v)) % nb for v in x[0].ravel()]
+            return [out]
         if op == "Prod":
             axis = tuple(int(v) for v in np.asarray(x[1]).ravel())
             return [np.prod(x[0], axis=axis, keepdims=bool("keep_dims" in a and a["keep_dims"].b)).astype(x[0].dtype)]

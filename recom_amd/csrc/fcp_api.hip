@@ -240,6 +240,11 @@ int validate_desc(const fcp_plan_desc_t *d) {
     } else if (d->host_input_elem_sizes[c.ids_input] != 4) {
       return fail(FCP_ERR_INVALID_ARGUMENT, where + "payload must be a 4-byte type");
     }
+    if (c.hash_buckets != 0) {
+      if (!lookup) return fail(FCP_ERR_INVALID_ARGUMENT, where + "id transforms apply to lookup columns only");
+      if (c.hash_buckets < 0) return fail(FCP_ERR_INVALID_ARGUMENT, where + "hash_buckets must be positive");
+      if (c.id_source == FCP_IDS_F32_BUCKETIZE) return fail(FCP_ERR_INVALID_ARGUMENT, where + "hash_buckets applies to integer ids");
+    }
     if (c.xform_mode != FCP_XFORM_NONE) {
       if (!lookup) return fail(FCP_ERR_INVALID_ARGUMENT, where + "id transforms apply to lookup columns only");
       if (c.xform_mode != FCP_XFORM_SELECT && c.xform_mode != FCP_XFORM_FILTER)
@@ -710,24 +715,32 @@ int init_device(fcp_plan *p) {
     // id transform: an empty interval set (nothing is "in") is encoded as one impossible interval
     s.bnd_off = -1;
     s.xform = 0;
-    if (hc.d.xform_mode != FCP_XFORM_NONE) {
+    if (hc.d.xform_mode != FCP_XFORM_NONE || hc.d.hash_buckets > 0) {
       if (h_xforms.empty()) {
         FcpXform none;
         none.lo0 = 1;
         none.hi0 = 0;
         none.sub = 0;
         none.extra = nullptr;
+        none.hash_buckets = 0;
+        none.pad_ = 0;
         h_xforms.assign(nc, none);
       }
       FcpXform &x = h_xforms[pos];
-      const uint32_t n = (uint32_t)std::max<size_t>(hc.xf_lo.size(), 1);
-      s.xform = (n << 2) | (uint32_t)hc.d.xform_mode;
-      x.sub = hc.d.xform_substitute;
-      if (!hc.xf_lo.empty()) {
-        x.lo0 = hc.xf_lo[0];
-        x.hi0 = hc.xf_hi[0];
+      if (hc.d.hash_buckets > 0) {
+        s.xform |= FCP_XFORM_HASH_BIT;
+        x.hash_buckets = hc.d.hash_buckets;
       }
-      if (hc.xf_const_off >= 0) x.extra = reinterpret_cast<const int64_t *>(p->d_const + hc.xf_const_off);
+      if (hc.d.xform_mode != FCP_XFORM_NONE) {
+        const uint32_t n = (uint32_t)std::max<size_t>(hc.xf_lo.size(), 1);
+        s.xform |= (n << 2) | (uint32_t)hc.d.xform_mode;
+        x.sub = hc.d.xform_substitute;
+        if (!hc.xf_lo.empty()) {
+          x.lo0 = hc.xf_lo[0];
+          x.hi0 = hc.xf_hi[0];
+        }
+        if (hc.xf_const_off >= 0) x.extra = reinterpret_cast<const int64_t *>(p->d_const + hc.xf_const_off);
+      }
     }
   }
   HIP_TRY(hipMalloc(&p->d_cols, nc * sizeof(FcpColStatic)));
@@ -1243,10 +1256,11 @@ int fcp_plan_create_from_file(const char *path, int32_t device, uint32_t flags, 
       if (std::fscanf(f, "%f", &bnd[k][b]) != 1) return fail(FCP_ERR_INVALID_ARGUMENT, where + "truncated boundary list");
     c.boundaries = c.n_boundaries ? bnd[k].data() : nullptr;
     if (version >= 2) { // id transform: mode, number of intervals, substitute, (lo, hi) pairs
-      long long sub = 0;
-      if (std::fscanf(f, "%d %d %lld", &c.xform_mode, &c.xform_n, &sub) != 3 || c.xform_n < 0 || c.xform_n > (1 << 20))
+      long long sub = 0, hb = 0;
+      if (std::fscanf(f, "%d %d %lld %lld", &c.xform_mode, &c.xform_n, &sub, &hb) != 4 || c.xform_n < 0 || c.xform_n > (1 << 20))
         return fail(FCP_ERR_INVALID_ARGUMENT, where + "truncated or malformed id transform of column " + std::to_string(k));
       c.xform_substitute = sub;
+      c.hash_buckets = hb;
       xlo[k].resize(c.xform_n);
       xhi[k].resize(c.xform_n);
       for (int i = 0; i < c.xform_n; ++i) {

@@ -43,17 +43,21 @@ struct FcpColStatic {      // 64 bytes: one record per cache line
   // bnd_step != 0: every boundary is REPRODUCIBLE as fma(i, bnd_step, bnd_b0) (checked bit for bit at plan
   // creation), so the kernels never read the array (bucketize_arith).
   float bnd_b0, bnd_inv, bnd_step;
-  // id transform (FCP_XFORM_*): mode in the low 2 bits, number of closed intervals above, 0 = none; the
-  // intervals live in FcpLaunch::xforms[column] and are only read by columns that have one
+  // id transform, 0 = none: FCP_XFORM_* in the low 2 bits, number of closed intervals in bits 2..30, bit 31 =
+  // hash the id into buckets first; the parameters live in FcpLaunch::xforms[column] and are only read by
+  // columns that have a transform
   uint32_t xform;
   int32_t bnd_off;         // always -1 in memory; in the LDS copy: where a block staged the boundaries (or -1)
 };
 
-struct FcpXform {          // 32 bytes per column (allocated only for plans with id transforms)
+struct FcpXform {          // 48 bytes per column (allocated only for plans with id transforms)
   int64_t lo0, hi0;        // first closed interval
   int64_t sub;             // FCP_XFORM_SELECT: what an id outside the intervals becomes
   const int64_t *extra;    // intervals 1.. as (lo, hi) pairs in the const buffer
+  int64_t hash_buckets;    // bit 31 of xform: id = Fingerprint64(decimal(id)) % hash_buckets
+  int64_t pad_;
 };
+#define FCP_XFORM_HASH_BIT 0x80000000u
 
 struct FcpColDyn {         // 48 bytes
   int64_t ids_off;         // byte offset of the id / value / payload stream in the blob

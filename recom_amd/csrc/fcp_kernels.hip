@@ -317,16 +317,79 @@ static_assert(offsetof(FcpColStatic, flags) == 32 && offsetof(FcpColStatic, tabl
 // (FcpLaunch::xforms) on purpose: columns without a transform — nearly all — pay one compare, no registers
 // and no record bytes for it (inlined with the intervals in the column record it cost S2 2 us of 29: 76 VGPRs).
 constexpr int64_t kDroppedId = INT64_MIN;
+
+// ---- Fingerprint64 of a short byte string (FarmHash farmhashna::Hash64, lengths 1..32; TensorFlow's
+// StringToHashBucketFast, core/kernels/string_to_hash_bucket_fast_op.h) -----------------------------------
+// The string is the decimal form of an int64 (at most 20 bytes), kept in three little-endian 64-bit words
+// held in registers (no arrays: nothing may end up in scratch memory).
+struct Str24 {
+  uint64_t w0, w1, w2;
+};
+__device__ __forceinline__ uint64_t fetch64(const Str24 &s, int o) { // unaligned little-endian read at byte o (o <= 15)
+  const int i = o >> 3, sh = (o & 7) * 8;
+  const uint64_t lo = (i == 0 ? s.w0 : s.w1) >> sh;
+  return sh ? lo | ((i == 0 ? s.w1 : s.w2) << (64 - sh)) : lo;
+}
+__device__ __forceinline__ uint64_t rot64(uint64_t v, int sh) { return sh ? (v >> sh) | (v << (64 - sh)) : v; }
+__device__ __forceinline__ uint64_t hash_len16(uint64_t u, uint64_t v, uint64_t mul) {
+  uint64_t a = (u ^ v) * mul;
+  a ^= a >> 47;
+  uint64_t b = (v ^ a) * mul;
+  b ^= b >> 47;
+  return b * mul;
+}
+__device__ uint64_t fingerprint64_decimal(int64_t value) {
+  constexpr uint64_t k0 = 0xc3a5c85c97cb3127ull, k1 = 0xb492b66fbe98f273ull, k2 = 0x9ae16a3b2f90404full;
+  // AsString of an integer: decimal digits, most significant first, '-' for negatives, no padding
+  const uint64_t mag = value < 0 ? 0ull - (uint64_t)value : (uint64_t)value;
+  int n = 1;
+  for (uint64_t p = 10; n < 20 && mag >= p; p *= 10) ++n; // 10^19 < 2^64: p never overflows before n reaches 20
+  const int neg = value < 0 ? 1 : 0;
+  Str24 s = {neg ? (uint64_t)'-' : 0ull, 0ull, 0ull};
+  uint64_t m = mag;
+  for (int k = 0; k < n; ++k) { // least significant digit first, written at its final position
+    const int pos = neg + n - 1 - k;
+    const uint64_t v = (uint64_t)('0' + (int)(m % 10)) << ((pos & 7) * 8);
+    m /= 10;
+    if (pos < 8) s.w0 |= v;
+    else if (pos < 16) s.w1 |= v;
+    else s.w2 |= v;
+  }
+  n += neg;
+  const uint64_t len = (uint64_t)n;
+  if (n <= 16) {
+    if (n >= 8) {
+      const uint64_t mul = k2 + len * 2, a = fetch64(s, 0) + k2, b = fetch64(s, n - 8);
+      return hash_len16(rot64(b, 37) * mul + a, (rot64(a, 25) + b) * mul, mul);
+    }
+    if (n >= 4) {
+      const uint64_t mul = k2 + len * 2, a = (uint32_t)s.w0;
+      return hash_len16(len + (a << 3), (uint32_t)(s.w0 >> ((n - 4) * 8)), mul);
+    }
+    const uint8_t a = (uint8_t)s.w0, b = (uint8_t)(s.w0 >> ((n >> 1) * 8)), c = (uint8_t)(s.w0 >> ((n - 1) * 8));
+    const uint32_t y = (uint32_t)a + ((uint32_t)b << 8), z = (uint32_t)n + ((uint32_t)c << 2);
+    uint64_t h = (uint64_t)y * k2 ^ (uint64_t)z * k0;
+    h ^= h >> 47;
+    return h * k2;
+  }
+  const uint64_t mul = k2 + len * 2, a = fetch64(s, 0) * k1, b = fetch64(s, 8), c = fetch64(s, n - 8) * mul,
+                 e = fetch64(s, n - 16) * k2;
+  return hash_len16(rot64(a + b, 43) + rot64(c, 30) + e, a + rot64(b + k2, 18) + c, mul);
+}
+
 __device__ __attribute__((noinline)) int64_t apply_xform(uint32_t xform, const FcpXform *xf, int64_t id) {
   const FCP_GLOBAL FcpXform *x = as_global(xf);
+  if (xform & FCP_XFORM_HASH_BIT) id = (int64_t)(fingerprint64_decimal(id) % (uint64_t)x->hash_buckets);
+  const unsigned mode = xform & 3u;
+  if (mode == FCP_XFORM_NONE) return id;
   bool in = id >= x->lo0 && id <= x->hi0;
-  const int n = (int)(xform >> 2);
+  const int n = (int)((xform & ~FCP_XFORM_HASH_BIT) >> 2);
   for (int i = 1; i < n && !in; ++i) {
     const FCP_GLOBAL int64_t *e = as_global(x->extra) + 2 * (i - 1);
     in = id >= e[0] && id <= e[1];
   }
   if (in) return id;
-  return (xform & 3u) == FCP_XFORM_FILTER ? kDroppedId : x->sub;
+  return mode == FCP_XFORM_FILTER ? kDroppedId : x->sub;
 }
 
 // The index expression the reference inlines per column (EmitInputInline,

@@ -80,6 +80,7 @@ class IndexSource:
     xform_lo: Tuple[int, ...] = ()
     xform_hi: Tuple[int, ...] = ()
     xform_substitute: int = 0
+    hash_buckets: int = 0                # StringToHashBucketFast(AsString(int ids)) absorbed: hash on the device
     filter_node: Optional[str] = None    # the Gather* node whose (indices, values) pair this operand belongs to
     generated_rows: bool = False         # indices output of GatherValueGenIndice: row i of the values tensor
 
@@ -224,6 +225,24 @@ class PlanBuilder:
             return self._trace_id_filter(node, port)
         if port != 0:
             raise Unsupported("not an inlinable op")
+        if node.op == "StringToHashBucketFast":
+            # categorical_column_with_hash_bucket over an INTEGER feature: AsString(ids) -> StringToHashBucketFast.
+            # The pair is evaluated on the device (Fingerprint64 of the decimal string); a string feature, or an
+            # AsString with formatting attrs, ends the walk here and stays on the CPU.
+            a_node, a_port = g.input(node, 0)
+            if a_node.op != "AsString" or a_port != 0:
+                raise Unsupported("StringToHashBucketFast over a string tensor")
+            at = a_node.attr
+            if at["T"].type not in (P.DT_INT32, P.DT_INT64) or ("width" in at and at["width"].i not in (-1, 0)) or \
+                    ("fill" in at and at["fill"].s not in (b"",)) or ("scientific" in at and at["scientific"].b) or \
+                    ("shortest" in at and at["shortest"].b):
+                raise Unsupported("AsString with formatting")
+            src = self.trace_index(*g.input(a_node, 0))
+            if src.boundaries is not None or src.xform_mode != XFORM_NONE or src.hash_buckets or src.stride != 1 or \
+                    src.filter_node is not None or src.dtype not in (P.DT_INT32, P.DT_INT64):
+                raise Unsupported("hash of a transformed id stream")
+            src.hash_buckets = int(node.attr["num_buckets"].i)
+            return src
         if node.op == "SparseReshape":
             # output_indices of a reshape that provably keeps [rows, k]: read the input indices in place.
             # Anything else (rank change, unprovable shapes) ends the walk: TensorFlow computes the op and
@@ -348,7 +367,7 @@ class PlanBuilder:
         else:
             raise Unsupported(f"ids tensor {src.tensor} has dtype {src.dtype}")
         xf = dict(xform_mode=src.xform_mode, xform_lo=src.xform_lo, xform_hi=src.xform_hi,
-                  xform_substitute=src.xform_substitute)
+                  xform_substitute=src.xform_substitute, hash_buckets=src.hash_buckets)
         return self._host_input(src.tensor, src.dtype, src.rank), id_source, src.boundaries, xf, src.filter_node
 
     def _seg_operand(self, node, port: int, filter_node: Optional[str] = None) -> Tuple[int, int, int]:

@@ -114,8 +114,10 @@ class GraphView:
             return a[key].type
         if op == "Bucketize":
             return P.DT_INT32
-        if op == "SparseReshape":
+        if op in ("SparseReshape", "StringToHashBucketFast"):
             return P.DT_INT64
+        if op == "AsString":
+            return P.DT_STRING
         if op in ("Unique",):
             return a["T"].type if port == 0 else a["out_idx"].type
         if "T" in a:
@@ -139,7 +141,7 @@ class GraphView:
             return None if s.unknown_rank else [int(d.size) if d.size >= 0 else None for d in s.dim]
         if op == "Const":
             return [int(d.size) for d in node.attr["value"].tensor.tensor_shape.dim]
-        if op in ("Identity", "Cast", "Bucketize", "StopGradient", "ZerosLike"):
+        if op in ("Identity", "Cast", "Bucketize", "StopGradient", "ZerosLike", "AsString", "StringToHashBucketFast"):
             return self.static_shape(*self.input(node, 0), _depth + 1)
         if op == "Reshape":
             tgt = self.const_array(*self.input(node, 1))

@@ -42,7 +42,7 @@ class ColumnDesc(C.Structure):
         ("concat_group", C.c_int32), ("concat_slot", C.c_int32),
         ("xform_mode", C.c_int32), ("xform_n", C.c_int32),
         ("xform_lo", C.POINTER(C.c_int64)), ("xform_hi", C.POINTER(C.c_int64)),
-        ("xform_substitute", C.c_int64),
+        ("xform_substitute", C.c_int64), ("hash_buckets", C.c_int64),
     ]
 
 

@@ -80,7 +80,8 @@ class Plan:
                 c.seg_kind, c.seg_stride, c.rows_source, c.rows_arg, 0 if b is None else len(b),
                 None if b is None else b.ctypes.data_as(C.POINTER(C.c_float)), c.concat_group, c.concat_slot,
                 c.xform_mode, len(xlo), xlo.ctypes.data_as(C.POINTER(C.c_int64)) if len(xlo) else None,
-                xhi.ctypes.data_as(C.POINTER(C.c_int64)) if len(xhi) else None, int(c.xform_substitute))
+                xhi.ctypes.data_as(C.POINTER(C.c_int64)) if len(xhi) else None, int(c.xform_substitute),
+                int(c.hash_buckets))
         ranks = np.asarray(spec.host_input_ranks, np.int32)
         esz = np.asarray(spec.host_input_elem_sizes, np.int32)
         self._keep += [ranks, esz]

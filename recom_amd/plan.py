@@ -62,6 +62,9 @@ class ColumnSpec:
     xform_lo: Sequence[int] = ()
     xform_hi: Sequence[int] = ()
     xform_substitute: int = 0
+    # > 0: integer ids are hashed into buckets first — Fingerprint64(decimal string) % hash_buckets, TensorFlow's
+    # AsString -> StringToHashBucketFast (categorical_column_with_hash_bucket over integer features)
+    hash_buckets: int = 0
 
     def validate(self) -> None:
         if self.form not in (1, 2, 3, 4, 5, 6):
@@ -83,6 +86,10 @@ class ColumnSpec:
                 raise ValueError("pooled/scatter column needs an explicit row count source")
         if self.form == FORM_SEGMENT_REDUCE and self.combiner not in (COMBINER_SUM, COMBINER_MEAN):
             raise ValueError("segment-reduce column needs sum or mean")
+        if self.hash_buckets:
+            if self.form not in (FORM_GATHER, FORM_SEGMENT_REDUCE, FORM_GATHER_SCATTER) or self.hash_buckets < 0 or \
+                    self.id_source == IDS_F32_BUCKETIZE:
+                raise ValueError("hash_buckets applies to the integer ids of lookup columns")
         if self.xform_mode != XFORM_NONE:
             if self.form not in (FORM_GATHER, FORM_SEGMENT_REDUCE, FORM_GATHER_SCATTER):
                 raise ValueError("id transforms apply to lookup columns only")

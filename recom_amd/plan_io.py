@@ -26,8 +26,9 @@ def save_plan(spec: PlanSpec, path: str) -> None:
                 c.form, c.combiner, c.dim, c.id_source, c.vocab, c.table_input, c.ids_input, c.seg_input,
                 c.seg_kind, c.seg_stride, c.rows_source, c.rows_arg, c.concat_group, c.concat_slot, len(b))))
             f.write(" " + " ".join(b) if b else "")
-            # version 2: the id transform — mode, number of intervals, substitute, (lo, hi) pairs
-            x = [c.xform_mode, len(c.xform_lo), c.xform_substitute] + [v for p in zip(c.xform_lo, c.xform_hi) for v in p]
+            # version 2: the id transform — mode, number of intervals, substitute, hash buckets, (lo, hi) pairs
+            x = [c.xform_mode, len(c.xform_lo), c.xform_substitute, c.hash_buckets] + \
+                [v for p in zip(c.xform_lo, c.xform_hi) for v in p]
             f.write(" " + " ".join(str(int(v)) for v in x) + "\n")
 
 
@@ -65,16 +66,17 @@ def load_plan(path: str) -> PlanSpec:
     for _ in range(int(nxt())):
         v = [int(nxt()) for _ in range(15)]
         b = np.asarray([float(nxt()) for _ in range(v[14])], np.float32) if v[14] else None
-        mode, lo, hi, sub = 0, [], [], 0
+        mode, lo, hi, sub, hb = 0, [], [], 0, 0
         if version >= 2:
-            mode, n, sub = int(nxt()), int(nxt()), int(nxt())
+            mode, n, sub, hb = int(nxt()), int(nxt()), int(nxt()), int(nxt())
             for _ in range(n):
                 lo.append(int(nxt()))
                 hi.append(int(nxt()))
         cols.append(ColumnSpec(form=v[0], combiner=v[1], dim=v[2], id_source=v[3], vocab=v[4], table_input=v[5],
                                ids_input=v[6], seg_input=v[7], seg_kind=v[8], seg_stride=v[9], rows_source=v[10],
                                rows_arg=v[11], concat_group=v[12], concat_slot=v[13], boundaries=b,
-                               xform_mode=mode, xform_lo=tuple(lo), xform_hi=tuple(hi), xform_substitute=sub))
+                               xform_mode=mode, xform_lo=tuple(lo), xform_hi=tuple(hi), xform_substitute=sub,
+                               hash_buckets=hb))
     spec = PlanSpec(cols, ranks, esz, n_dev, n_groups=n_groups, n_symbols=n_symbols, layout=layout)
     spec.validate()
     return spec

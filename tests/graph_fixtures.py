@@ -473,6 +473,25 @@ def id_filter_model(B=29, seed=0):
     g.node("e/inner", "Addons>SelectValue", ["e_ids"], substitute=1, **ivals([0], [30]))
     g.node("e/outer", "Addons>SelectValue", ["e/inner"], substitute=2, **ivals([5], [52]))
     ins.append(g.gather("input_layer/e_embedding/GatherDense", t, "e/outer", np.int64))
+    # f: categorical_column_with_hash_bucket over an int64 feature (dlrm.py "hash-int" columns):
+    #    AsString -> StringToHashBucketFast(100) -> lookup, pooled mean over SparseTensor indices
+    t = table("f", 100, 8)
+    sparse("f", 10**12, 4)
+    feeds["f/values"][::3] *= -1                            # negative ids hash too ("-123")
+    g.node("f/AsString", "AsString", ["f/values"], T=("type", P.DT_INT64))
+    g.node("f/hash", "StringToHashBucketFast", ["f/AsString"], num_buckets=100)
+    seg = g.slice_col0("f/added_strided_slice", "f/indices", shrink=True)
+    ins.append(g.node("f/SparseSegmentMean_with_num_segments", "SparseSegmentMeanWithNumSegments",
+                      [t, "f/hash", seg, "f/rows"], T=("type", P.DT_FLOAT), Tidx=("type", P.DT_INT64),
+                      Tsegmentids=("type", P.DT_INT64), Tnumsegments=("type", P.DT_INT64)))
+    # h: the same over a one-hot int32 feature, followed by SelectValue (hash first, then the interval test)
+    t = table("h", 1000, 4)
+    g.placeholder("h_ids", np.int32, [-1])
+    feeds["h_ids"] = rng.integers(0, 2**31 - 1, size=B).astype(np.int32)
+    g.node("h/AsString", "AsString", ["h_ids"], T=("type", P.DT_INT32))
+    g.node("h/hash", "StringToHashBucketFast", ["h/AsString"], num_buckets=1000)
+    g.node("h/SelectValue", "Addons>SelectValue", ["h/hash"], substitute=0, **ivals([100], [899]))
+    ins.append(g.gather("input_layer/h_embedding/GatherDense", t, "h/SelectValue", np.int64))
     g.const("concat/axis", np.asarray(1, np.int32))
     g.node("input_layer/concat", "ConcatV2", ins + ["concat/axis"], N=len(ins), T=("type", P.DT_FLOAT), Tidx=("type", P.DT_INT32))
     g.node("output", "Identity", ["input_layer/concat"], T=("type", P.DT_FLOAT))

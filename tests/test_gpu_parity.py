@@ -415,7 +415,8 @@ def test_id_filter_graph_to_hip_path(torch_cuda, tmp_path):
     for B, seed in ((29, 0), (300, 3)):
         gd, feeds, variables, fetches = id_filter_model(B=B, seed=seed)
         built = _graph_through_hip(torch_cuda, gd, feeds, variables, fetches, tmp_path)
-        assert [c.xform_mode for c in built.spec.columns] == [1, 2, 2, 2, 1]
+        assert [c.xform_mode for c in built.spec.columns] == [1, 2, 2, 2, 1, 0, 1]
+        assert [c.hash_buckets for c in built.spec.columns] == [0, 0, 0, 0, 0, 100, 1000]
 
 
 def test_concat_outputs_host_inputs_into_external_slots(torch_cuda, oracle):

@@ -295,10 +295,14 @@ def test_id_filter_ops_become_column_transforms(oracle, tmp_path, B, seed):
     from tf_graph_eval import GraphEvaluator
     gd, feeds, variables, fetches = id_filter_model(B=B, seed=seed)
     expected = GraphEvaluator(gd, variables).run(fetches, feeds)
-    assert expected[0].shape == (B, 8 + 16 + 8 + 4 + 12)
+    assert expected[0].shape == (B, 8 + 16 + 8 + 4 + 12 + 8 + 4)
     built = build_plan(gd)
     c = built.spec.columns
-    assert [x.form for x in c] == [1, 2, 2, 1, 1] and not built.skipped
+    assert [x.form for x in c] == [1, 2, 2, 1, 1, 2, 1] and not built.skipped
+    # AsString -> StringToHashBucketFast over integer ids: hashed on the device, the raw ids are shipped
+    assert c[5].hash_buckets == 100 and built.host_inputs[c[5].ids_input] == ("f/values", P.DT_INT64, 1) and c[5].xform_mode == 0
+    assert c[6].hash_buckets == 1000 and built.host_inputs[c[6].ids_input] == ("h_ids", P.DT_INT32, 1)
+    assert (c[6].xform_mode, c[6].xform_lo, c[6].xform_hi, c[6].id_source) == (PL.XFORM_SELECT, (100,), (899,), PL.IDS_I32)
     assert (c[0].xform_mode, c[0].xform_lo, c[0].xform_hi, c[0].xform_substitute) == (PL.XFORM_SELECT, (10, 80), (60, 90), 3)
     assert built.host_inputs[c[0].ids_input][0] == "a_ids"
     assert (c[1].xform_mode, c[1].xform_lo, c[1].xform_hi) == (PL.XFORM_FILTER, (20,), (150,))
@@ -313,11 +317,12 @@ def test_id_filter_ops_become_column_transforms(oracle, tmp_path, B, seed):
     path = str(tmp_path / "m.fcp")
     save_plan(built.spec, path)
     again = load_plan(path)
-    assert [(x.xform_mode, x.xform_lo, x.xform_hi, x.xform_substitute) for x in again.columns] == \
-           [(x.xform_mode, x.xform_lo, x.xform_hi, x.xform_substitute) for x in c]
+    assert [(x.xform_mode, x.xform_lo, x.xform_hi, x.xform_substitute, x.hash_buckets) for x in again.columns] == \
+           [(x.xform_mode, x.xform_lo, x.xform_hi, x.xform_substitute, x.hash_buckets) for x in c]
     out = parse_graphdef(rewrite_graph(gd, built, path).SerializeToString())
     ops = [n.op for n in out.node]
     assert ops.count("Addons>SelectValue") == 1 and "Addons>GatherIndiceValue" not in ops and "Addons>GatherValueGenIndice" not in ops
+    assert "AsString" not in ops and "StringToHashBucketFast" not in ops
     got = GraphEvaluator(out, variables, oracle_ops(oracle, built, variables)).run(fetches, feeds)
     assert np.array_equal(expected[0], got[0])
 

@@ -141,16 +141,20 @@ def test_reference_block_scan_order_dim_le_20(oracle, mean, dim):
 def _xform_spec(m, transforms):
     import dataclasses
     cols = list(m.spec.columns)
-    for k, (mode, ivals, sub) in transforms.items():
+    for k, t in transforms.items():
+        mode, ivals, sub = t[:3]
         cols[k] = dataclasses.replace(cols[k], xform_mode=mode, xform_lo=tuple(a for a, _ in ivals),
-                                      xform_hi=tuple(b for _, b in ivals), xform_substitute=sub)
+                                      xform_hi=tuple(b for _, b in ivals), xform_substitute=sub,
+                                      hash_buckets=t[3] if len(t) > 3 else 0)
     spec = dataclasses.replace(m.spec, columns=cols)
     spec.validate()
     return spec
 
 
-XFORMS = {0: (2, [(100, 500)], 0), 1: (1, [(10, 60), (80, 90)], 3), 2: (1, [], 7), 3: (2, [(0, 300), (600, 996)], 0),
-          4: (2, [(200, 800)], 0), 5: (2, [(0, 498)], 0), 6: (1, [(0, 500)], -5), 7: (2, [(0, 700)], 0)}
+# column -> (xform_mode, closed intervals, substitute[, hash_buckets]); columns 0, 4 and 7 hash their ids first
+# (Fingerprint64 of the decimal string, TensorFlow's AsString -> StringToHashBucketFast)
+XFORMS = {0: (2, [(100, 500)], 0, 997), 1: (1, [(10, 60), (80, 90)], 3), 2: (1, [], 7), 3: (2, [(0, 300), (600, 996)], 0),
+          4: (2, [(200, 800)], 0, 900), 5: (2, [(0, 498)], 0), 6: (1, [(0, 500)], -5), 7: (0, [], 0, 640)}
 
 
 @pytest.mark.parametrize("batch,seed", [(33, 0), (1, 1), (120, 2)])
@@ -172,15 +176,22 @@ def test_id_transforms_equal_the_cpu_ops_followed_by_the_lookup(oracle, batch, s
     # the same request after the CPU ops, through the plain plan
     inputs = [np.array(a) for a in req.inputs]
     zero_rows = {}
-    for k, (mode, ivals, sub) in XFORMS.items():
+    for k, t in XFORMS.items():
+        mode, ivals, sub = t[:3]
         c = m.spec.columns[k]
         raw = inputs[c.ids_input]
         ids = O.np_bucketize(c.boundaries, raw).astype(np.int64) if c.id_source == 2 else raw.astype(np.int64)
+        if len(t) > 3:                                        # AsString -> StringToHashBucketFast in front of everything
+            ids = np.asarray([O.np_fingerprint64(str(int(v)).encode()) % t[3] for v in ids], np.int64)
+            raw = ids.astype(raw.dtype)
+            inputs[c.ids_input] = raw
         inside = np.zeros(ids.size, bool)
         for lo, hi in ivals:
             inside |= (ids >= lo) & (ids <= hi)
         if c.id_source == 2:
             continue                                          # checked through the NumPy restatement below
+        if mode == 0:
+            continue
         if mode == 1:                                         # Addons>SelectValue
             inputs[c.ids_input] = np.where(inside, ids, sub).astype(raw.dtype)
         elif c.form == FORM_GATHER:                           # Addons>GatherValueGenIndice: dropped values leave zero rows
@@ -274,3 +285,26 @@ def test_sharded_partials_sum_to_unsharded(oracle, golden):
             sl /= np.where(cnt > 0, cnt, 1.0)[:, None]
     for a, f in zip(acc, full):
         assert np.abs(a - f).max() < 1e-5
+
+
+def test_fingerprint64_known_answers(oracle):
+    """TensorFlow's Fingerprint64 (FarmHash farmhashna::Hash64; TF 2.6.2 pins farmhash 816a4ae6, un-vendored in
+    the reference) restated in C (orc_fingerprint64) and independently in Python integers (np_fingerprint64).
+    Published known answers: the empty string hashes to k2 (HashLen0to16's `return k2`); "abc" ->
+    0x24a5b3a074e7f369 (the CityHash64 v1.1 / FarmHash short-string value); the TensorFlow API docs'
+    tf.strings.to_hash_bucket_fast(["Hello", "TensorFlow", "2.x"], 3) == [0, 2, 2] — one string per branch of
+    HashLen0to16 (len >= 8, >= 4, > 0), the code every decimal id of up to 16 digits goes through."""
+    L = oracle.lib
+    fp = lambda s: int(L.orc_fingerprint64(s, len(s)))
+    assert fp(b"") == 0x9ae16a3b2f90404f == O.np_fingerprint64(b"")
+    assert fp(b"abc") == 0x24a5b3a074e7f369 == O.np_fingerprint64(b"abc")
+    assert [fp(s) % 3 for s in (b"Hello", b"TensorFlow", b"2.x")] == [0, 2, 2]
+    rng = np.random.default_rng(0)
+    vals = np.concatenate([rng.integers(-2**63, 2**63 - 1, 400, dtype=np.int64, endpoint=True),
+                           rng.integers(-1000, 1000, 200), [0, -1, 9, 10, 99999999, 10**15, 10**16, -10**16, 2**63 - 1, -2**63],
+                           10 ** np.arange(0, 19, dtype=np.int64), 10 ** np.arange(1, 19, dtype=np.int64) - 1])
+    for v in vals:                                             # C and Python restatements agree on every length 1..20
+        s = str(int(v)).encode()
+        assert fp(s) == O.np_fingerprint64(s), s
+        for buckets in (1, 7, 100, 10_000, 2**31 - 1):
+            assert L.orc_hash_bucket_int64(int(v), buckets) == O.np_fingerprint64(s) % buckets
