@@ -127,6 +127,12 @@ class GraphEvaluator:
             return [tensor_value(a["value"].tensor)]
         if op == "VariableV2":
             return [np.asarray(self.variables[node.name])]
+        if op == "VarHandleOp":                        # a resource handle: stands for the variable's name
+            return [node.name]
+        if op == "ReadVariableOp":
+            return [np.asarray(self.variables[x[0]])]
+        if op == "ResourceGather":
+            return [np.take(np.asarray(self.variables[x[0]]), x[1].astype(np.int64), axis=0)]
         if op in ("Identity", "StopGradient"):
             return [x[0]]
         if op == "GatherV2":

@@ -151,21 +151,29 @@ class PlanBuilder:
 
     # ---- tables (graph_info.cc:209-259) ----------------------------------------
     def _find_tables(self) -> Dict[str, Tuple[int, int]]:
+        """A table is a VariableV2 / Const — or, in TF2 SavedModels, a VarHandleOp (resource variable; the
+        reference registers shape functions for it, symbolic_shape/op_infer_fn/) — whose consumers, through
+        Identity / ReadVariableOp, are only lookups."""
         out: Dict[str, Tuple[int, int]] = {}
         for n in self.g.gd.node:
-            if n.op not in ("VariableV2", "Const"):
+            if n.op not in ("VariableV2", "Const", "VarHandleOp"):
                 continue
-            if self.g.out_dtype(n) != P.DT_FLOAT:
-                continue
-            shape = self.g.static_shape(n)
+            if n.op == "VarHandleOp":
+                if n.attr["dtype"].type != P.DT_FLOAT or n.attr["shape"].shape.unknown_rank:
+                    continue
+                shape = [int(d.size) if d.size >= 0 else None for d in n.attr["shape"].shape.dim]
+            else:
+                if self.g.out_dtype(n) != P.DT_FLOAT:
+                    continue
+                shape = self.g.static_shape(n)
             if shape is None or len(shape) != 2 or None in shape or min(shape) <= 0:
                 continue
             stack, lookups, ok = [n.name], 0, True
             while stack and ok:
                 for c, i in self.g.data_consumers(stack.pop()):
-                    if c.op == "Identity":
+                    if c.op in ("Identity", "ReadVariableOp"):
                         stack.append(c.name)
-                    elif c.op in ("Assign", "SaveV2"):
+                    elif c.op in ("Assign", "SaveV2", "AssignVariableOp", "VarIsInitializedOp"):
                         pass
                     elif ("Gather" in c.op or "SparseSegment" in c.op) and i == 0:
                         lookups += 1
@@ -177,7 +185,7 @@ class PlanBuilder:
         return out
 
     def _table_of(self, node, port: int) -> Tuple[str, int, int]:
-        while node.op == "Identity" and port == 0:
+        while node.op in ("Identity", "ReadVariableOp") and port == 0:
             node, port = self.g.input(node, 0)
         if node.name not in self.tables or port != 0:
             raise Unsupported(f"{node.name} ({node.op}) is not an embedding table")
@@ -191,9 +199,17 @@ class PlanBuilder:
         return self._host[tensor]
 
     def _device_input(self, tensor: str) -> int:
+        """Tables become FeatureColumnProcess `inputs`.  A resource variable's handle is not its data: its
+        device input is the output of a ReadVariableOp (an existing one, or `<var>/fcp_read`, which
+        rewrite_graph adds)."""
         if tensor not in self._dev:
+            name = tensor
+            node = self.g.nodes.get(tensor)
+            if node is not None and node.op == "VarHandleOp":
+                reads = [c.name for c, i in self.g.data_consumers(tensor) if c.op == "ReadVariableOp" and i == 0]
+                name = reads[0] if reads else tensor + "/fcp_read"
             self._dev[tensor] = len(self._dev_list)
-            self._dev_list.append((tensor, P.DT_FLOAT, 2))
+            self._dev_list.append((name, P.DT_FLOAT, 2))
         return self._dev[tensor]
 
     def _symbol(self, tensor: str, index: int) -> int:
@@ -399,6 +415,15 @@ class PlanBuilder:
         g = self.g
         if port != 0:
             raise Unsupported("value is not output 0")
+        if node.op == "ResourceGather":                                             # GatherV2 over a resource variable (TF2)
+            if "batch_dims" in node.attr and node.attr["batch_dims"].i != 0:
+                raise Unsupported("ResourceGather batch_dims")
+            table, vocab, dim = self._table_of(*g.input(node, 0))
+            ids_in, id_source, bnd, xf, fnode = self._ids_operand(*g.input(node, 1))
+            if fnode is not None:
+                raise Unsupported("ResourceGather over filtered values")
+            return ColumnSpec(FORM_GATHER, dim, vocab, COMBINER_NONE, id_source, self._device_input(table), ids_in,
+                              -1, SEG_NONE, 1, ROWS_FROM_IDS, 0, bnd, group, slot, **xf)
         if node.op == "GatherV2":                                                   # EmitGatherRows :1246-1330
             table, vocab, dim, ids_in, id_source, bnd, xf, fnode = self._match_gather(node)
             if fnode is not None:                         # compacted values without their indices: rows are lost

@@ -66,6 +66,10 @@ def rewrite_graph(graph_def, built: BuiltPlan, plan_path: str, prune: bool = Tru
     fuse.attr["input_types"].list.SetInParent()
     fuse.attr["input_ranks"].list.SetInParent()
     for tensor, dtype, rank in built.device_inputs:
+        if tensor.endswith("/fcp_read") and tensor not in view.nodes:   # a resource variable nobody reads as a tensor yet
+            rd = gd.node.add(name=tensor, op="ReadVariableOp")
+            rd.input.append(tensor[:-len("/fcp_read")])
+            rd.attr["dtype"].type = dtype
         fuse.input.append(tensor)
         fuse.attr["input_types"].list.type.append(dtype)
         fuse.attr["input_ranks"].list.i.append(rank)

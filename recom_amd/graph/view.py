@@ -109,7 +109,8 @@ class GraphView:
         a = node.attr
         op = node.op
         key = {"Placeholder": "dtype", "Const": "dtype", "VariableV2": "dtype", "GatherV2": "Tparams",
-               "ResourceGather": "dtype", "Cast": "DstT", "Shape": "out_type", "Size": "out_type"}.get(op)
+               "ResourceGather": "dtype", "ReadVariableOp": "dtype", "Cast": "DstT", "Shape": "out_type",
+               "Size": "out_type"}.get(op)
         if key:
             return a[key].type
         if op == "Bucketize":
@@ -198,7 +199,12 @@ class GraphView:
                     hi = d if em else (e + d if e < 0 else e)
                     out.append(max(0, min(hi, d if d is not None else hi) - lo))
             return out
-        if op == "GatherV2":
+        if op in ("VarHandleOp", "ReadVariableOp"):                 # the variable's shape (attr of the handle op)
+            h = node if op == "VarHandleOp" else self.input(node, 0)[0]
+            if h.op != "VarHandleOp" or h.attr["shape"].shape.unknown_rank:
+                return None
+            return [int(d.size) if d.size >= 0 else None for d in h.attr["shape"].shape.dim]
+        if op in ("GatherV2", "ResourceGather"):
             p = self.static_shape(*self.input(node, 0), _depth + 1)
             i = self.static_shape(*self.input(node, 1), _depth + 1)
             return None if p is None or i is None else i + p[1:]

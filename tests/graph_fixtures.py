@@ -496,3 +496,51 @@ def id_filter_model(B=29, seed=0):
     g.node("input_layer/concat", "ConcatV2", ins + ["concat/axis"], N=len(ins), T=("type", P.DT_FLOAT), Tidx=("type", P.DT_INT32))
     g.node("output", "Identity", ["input_layer/concat"], T=("type", P.DT_FLOAT))
     return g.gd, feeds, variables, ["output"]
+
+
+def resource_variable_model(B=21, seed=0):
+    """A TF2-SavedModel-shaped graph: tables are resource variables (VarHandleOp), read through
+    ResourceGather (one-hot column), ReadVariableOp -> SparseSegmentSum (pooled column, the variable already
+    has a reader) and a table shared by a ResourceGather and a second pooled column through its own
+    ReadVariableOp.  Returns (graph_def, feeds, variables, fetches)."""
+    rng = np.random.default_rng(seed)
+    g = GB()
+    feeds, variables, ins = {}, {}, []
+
+    def var(name, vocab, dim):
+        n = g.node(f"input_layer/{name}_embedding/embedding_weights", "VarHandleOp", dtype=("type", P.DT_FLOAT),
+                   shape=("shape", [vocab, dim]))
+        variables[n] = rng.standard_normal((vocab, dim)).astype(np.float32)
+        return n
+
+    def pooled(prefix, table_value, vocab, op):
+        lens = rng.integers(0, 5, size=B)
+        nnz = int(lens.sum())
+        g.placeholder(prefix + "/values", np.int64, [-1])
+        g.placeholder(prefix + "/indices", np.int64, [-1, 2])
+        g.placeholder(prefix + "/rows", np.int64, [])
+        feeds[prefix + "/values"] = rng.integers(0, vocab, size=nnz).astype(np.int64)
+        feeds[prefix + "/indices"] = np.stack([np.repeat(np.arange(B), lens), np.zeros(nnz, np.int64)], 1).astype(np.int64)
+        feeds[prefix + "/rows"] = np.asarray(B, np.int64)
+        seg = g.slice_col0(prefix + "/added_strided_slice", prefix + "/indices", shrink=True)
+        return g.node(prefix + "/" + op, op, [table_value, prefix + "/values", seg, prefix + "/rows"], T=("type", P.DT_FLOAT),
+                      Tidx=("type", P.DT_INT64), Tsegmentids=("type", P.DT_INT64), Tnumsegments=("type", P.DT_INT64))
+
+    ta = var("a", 77, 8)
+    g.placeholder("a_ids", np.int64, [-1])
+    feeds["a_ids"] = rng.integers(0, 77, size=B).astype(np.int64)
+    ins.append(g.node("input_layer/a_embedding/ResourceGather", "ResourceGather", [ta, "a_ids"], dtype=("type", P.DT_FLOAT),
+                      Tindices=("type", P.DT_INT64), batch_dims=0))
+    tb = var("b", 140, 16)
+    g.node("b/Read", "ReadVariableOp", [tb], dtype=("type", P.DT_FLOAT))
+    ins.append(pooled("b", "b/Read", 140, "SparseSegmentSumWithNumSegments"))
+    g.placeholder("c_ids", np.int32, [-1])
+    feeds["c_ids"] = rng.integers(0, 77, size=B).astype(np.int32)
+    ins.append(g.node("input_layer/c_embedding/ResourceGather", "ResourceGather", [ta, "c_ids"], dtype=("type", P.DT_FLOAT),
+                      Tindices=("type", P.DT_INT32), batch_dims=0))                 # shares table a
+    g.node("d/Read", "ReadVariableOp", [ta], dtype=("type", P.DT_FLOAT))
+    ins.append(pooled("d", "d/Read", 77, "SparseSegmentMeanWithNumSegments"))       # table a again, through a reader
+    g.const("concat/axis", np.asarray(1, np.int32))
+    g.node("input_layer/concat", "ConcatV2", ins + ["concat/axis"], N=len(ins), T=("type", P.DT_FLOAT), Tidx=("type", P.DT_INT32))
+    g.node("output", "Identity", ["input_layer/concat"], T=("type", P.DT_FLOAT))
+    return g.gd, feeds, variables, ["output"]

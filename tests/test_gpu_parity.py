@@ -419,6 +419,14 @@ def test_id_filter_graph_to_hip_path(torch_cuda, tmp_path):
         assert [c.hash_buckets for c in built.spec.columns] == [0, 0, 0, 0, 0, 100, 1000]
 
 
+def test_resource_variable_graph_to_hip_path(torch_cuda, tmp_path):
+    """TF2-style graph (VarHandleOp / ReadVariableOp / ResourceGather tables) end to end on the GPU."""
+    from graph_fixtures import resource_variable_model
+    gd, feeds, variables, fetches = resource_variable_model(B=64, seed=2)
+    built = _graph_through_hip(torch_cuda, gd, feeds, variables, fetches, tmp_path)
+    assert [c.form for c in built.spec.columns] == [1, 2, 1, 2]
+
+
 def test_concat_outputs_host_inputs_into_external_slots(torch_cuda, oracle):
     """Addons>ConcatOutputs with N > 0 (concat_outputs_op_gpu.cu.cc:186-216): the plan reserves
     FORM_EXTERNAL slots, the fused kernels (dense AND ragged spans) leave them untouched, and

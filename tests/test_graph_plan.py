@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 from graph_fixtures import (MICRO_BOUNDARIES, canonical_model, id_filter_model, microbenchmark_model, random_model,
-                            sparse_reshape_model)
+                            resource_variable_model, sparse_reshape_model)
 from recom_amd import plan as PL
 from recom_amd.graph import Unsupported, build_plan, parse_graphdef, rewrite_graph
 from recom_amd.graph import tf_proto as P
@@ -323,6 +323,46 @@ def test_id_filter_ops_become_column_transforms(oracle, tmp_path, B, seed):
     ops = [n.op for n in out.node]
     assert ops.count("Addons>SelectValue") == 1 and "Addons>GatherIndiceValue" not in ops and "Addons>GatherValueGenIndice" not in ops
     assert "AsString" not in ops and "StringToHashBucketFast" not in ops
+    got = GraphEvaluator(out, variables, oracle_ops(oracle, built, variables)).run(fetches, feeds)
+    assert np.array_equal(expected[0], got[0])
+
+
+def test_resource_variable_tables(oracle, tmp_path):
+    """TF2 SavedModels keep embedding tables in resource variables: VarHandleOp + ResourceGather /
+    ReadVariableOp.  The plan builder takes them like VariableV2 tables; FeatureColumnProcess receives the
+    table VALUES (a ReadVariableOp output: an existing reader, or one the rewrite adds)."""
+    from tf_graph_eval import GraphEvaluator
+    gd, feeds, variables, fetches = resource_variable_model()
+    expected = GraphEvaluator(gd, variables).run(fetches, feeds)
+    built = build_plan(gd)
+    c = built.spec.columns
+    assert [x.form for x in c] == [1, 2, 1, 2] and not built.skipped
+    assert c[0].table_input == c[2].table_input == c[3].table_input != c[1].table_input     # table a bound once
+    assert [t for t, _, _ in built.device_inputs] == ["d/Read", "b/Read"]                  # values, not handles
+    path = str(tmp_path / "m.fcp")
+    save_plan(built.spec, path)
+    out = parse_graphdef(rewrite_graph(gd, built, path).SerializeToString())
+    nodes = {n.name: n for n in out.node}
+    assert list(nodes["FeatureColumnProcess"].input[3:5]) == ["d/Read", "b/Read"]
+    assert not any(n.op in ("ResourceGather",) or n.op.startswith("SparseSegment") for n in out.node)
+    got = GraphEvaluator(out, variables, oracle_ops(oracle, built, variables)).run(fetches, feeds)
+    assert np.array_equal(expected[0], got[0])
+    # a variable nobody reads as a tensor yet: the rewrite adds the reader
+    for n in gd.node:
+        if n.name == "d/SparseSegmentMeanWithNumSegments":
+            n.input[0] = "b/Read"                              # (column d now pools table b; table a is gather-only)
+    for i, n in enumerate(gd.node):
+        if n.name == "d/Read":
+            del gd.node[i]
+            break
+    feeds["d/values"] = feeds["d/values"] % 140
+    expected = GraphEvaluator(gd, variables).run(fetches, feeds)
+    built = build_plan(gd)
+    assert [t for t, _, _ in built.device_inputs][0] == "input_layer/a_embedding/embedding_weights/fcp_read"
+    out = parse_graphdef(rewrite_graph(gd, built, path).SerializeToString())
+    rd = {n.name: n for n in out.node}["input_layer/a_embedding/embedding_weights/fcp_read"]
+    assert rd.op == "ReadVariableOp" and list(rd.input) == ["input_layer/a_embedding/embedding_weights"]
+    save_plan(built.spec, path)
     got = GraphEvaluator(out, variables, oracle_ops(oracle, built, variables)).run(fetches, feeds)
     assert np.array_equal(expected[0], got[0])
 
