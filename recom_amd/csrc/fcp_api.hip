@@ -980,6 +980,12 @@ void fill_launch(const fcp_plan *p, const DynSlot &s, int kind, const void *blob
   L->n_groups = p->desc.n_groups;
   L->rows_per_wave = s.meta.geo[kind].rows_per_wave;
   L->seg_search = s.meta.seg_search ? 1 : 0;
+  // write-through output stores once the outputs exceed what the eight 4-MiB L2s can hold (see st_through)
+  static const int64_t through_bytes = [] {
+    const char *e = std::getenv("FCP_STORE_THROUGH_BYTES"); // tuning aid
+    return e ? std::atoll(e) : (int64_t)32 << 20;
+  }();
+  L->store_through = s.meta.csr_arena_off >= through_bytes ? 1 : 0;
   for (int g = 0; g < p->desc.n_groups; ++g) L->groups[g] = s.meta.geo[kind].groups[g];
 }
 

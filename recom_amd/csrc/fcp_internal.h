@@ -97,7 +97,7 @@ struct FcpLaunch {
   int32_t rows_per_wave;
   int32_t shard_rank, shard_world;
   int32_t seg_search;          // 1: blocks find their rows' ranges in the sorted segment ids themselves (no pre-pass)
-  int32_t pad_;
+  int32_t store_through;       // 1: output stores are write-through (`sc1 nt`): outputs larger than the L2s (host decides)
   unsigned long long *stamps;  // diagnostic builds (-DFCP_STAMPS) only: 8 timestamps per block
   FcpGroupLaunch groups[FCP_MAX_GROUPS];
   const FcpXform *xforms;      // per column (concat order), or null: no column has an id transform

@@ -75,36 +75,31 @@ template <int V> __device__ __forceinline__ VF<V> vzero() {
 // uniform ids) but costs the reference's models E / F 4.5 us per request — their ~1000
 // bucketize / hash tables of ~100 rows are re-read by every row and belong in L2.
 // -DFCP_NO_NT restores the default policy for stores as well (tuning builds).
-#if defined(FCP_STORE_POLICY) // tuning builds: 2 = sc1 (write-through), 3 = sc0 sc1, 4 = sc1 nt, 5 = sc0 sc1 nt
-#if FCP_STORE_POLICY == 2
-#define FCP_ST_BITS "sc1"
-#elif FCP_STORE_POLICY == 3
-#define FCP_ST_BITS "sc0 sc1"
-#elif FCP_STORE_POLICY == 4
-#define FCP_ST_BITS "sc1 nt"
-#else
-#define FCP_ST_BITS "sc0 sc1 nt"
-#endif
-__device__ __forceinline__ void st_asm(FCP_GLOBAL VecType<4>::T *p, VecType<4>::T t) {
-  // s_nop: a VMEM store of more than 64 bits must not be followed immediately by a VALU write of its data
-  // registers; the hazard recogniser does not look inside inline asm
-  asm volatile("global_store_dwordx4 %0, %1, off " FCP_ST_BITS "\n\ts_nop 1" ::"v"(p), "v"(t) : "memory");
+// Write-through form (`sc1 nt`: the line leaves the XCD's L2 at once instead of at the kernel boundary) for
+// outputs larger than the L2s can hold — S2's 61 MB: 28.4 vs 29.0 us per request; outputs that FIT the
+// caches (DLRM 3.5 MB, models E / F 16 MB) lose with it (DLRM 4.7 -> 5.9 us, F 14.7 -> 17.7 us): the host
+// picks per launch (FcpLaunch::store_through, profiles/r02_store_policy.txt).  Inline asm: the compiler has
+// no builtin for the sc1 bit; the s_nop covers the hazard "VMEM store of more than 64 bits followed by a
+// VALU write of its data registers", which the hazard recogniser cannot see inside asm.
+__device__ __forceinline__ void st_through(FCP_GLOBAL VecType<4>::T *p, VecType<4>::T t) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" ::"v"(p), "v"(t) : "memory");
 }
-__device__ __forceinline__ void st_asm(FCP_GLOBAL VecType<2>::T *p, VecType<2>::T t) {
-  asm volatile("global_store_dwordx2 %0, %1, off " FCP_ST_BITS ::"v"(p), "v"(t) : "memory");
+__device__ __forceinline__ void st_through(FCP_GLOBAL VecType<2>::T *p, VecType<2>::T t) {
+  asm volatile("global_store_dwordx2 %0, %1, off sc1 nt" ::"v"(p), "v"(t) : "memory");
 }
-__device__ __forceinline__ void st_asm(FCP_GLOBAL VecType<1>::T *p, VecType<1>::T t) {
-  asm volatile("global_store_dword %0, %1, off " FCP_ST_BITS ::"v"(p), "v"(t) : "memory");
+__device__ __forceinline__ void st_through(FCP_GLOBAL VecType<1>::T *p, VecType<1>::T t) {
+  asm volatile("global_store_dword %0, %1, off sc1 nt" ::"v"(p), "v"(t) : "memory");
 }
-#endif
 
-template <int V> __device__ __forceinline__ void st_out(float *p, const VF<V> &v) {
+template <int V> __device__ __forceinline__ void st_out(float *p, const VF<V> &v, bool through = false) {
   typedef typename VecType<V>::T T;
   T t;
   __builtin_memcpy(&t, &v, sizeof(T));
-#if defined(FCP_STORE_POLICY)
-  st_asm(as_global(reinterpret_cast<T *>(p)), t);
-#elif !defined(FCP_NO_NT)
+  if (through) {
+    st_through(as_global(reinterpret_cast<T *>(p)), t);
+    return;
+  }
+#if !defined(FCP_NO_NT)
   __builtin_nontemporal_store(t, as_global(reinterpret_cast<T *>(p)));
 #else
   *as_global(reinterpret_cast<T *>(p)) = t;
@@ -232,7 +227,7 @@ struct Hot {
   char *arena;
   unsigned long long *bad_ids;
   int64_t csr_arena_off;
-  int32_t n_groups, rank, world, seg_search;
+  int32_t n_groups, rank, world, seg_search, store_through;
   FcpGroupLaunch g0;
 };
 
@@ -250,10 +245,11 @@ __device__ __forceinline__ Hot load_hot(const FcpLaunch &L) {
   h.rank = L.shard_rank;
   h.world = L.shard_world;
   h.seg_search = L.seg_search;
+  h.store_through = L.store_through;
   h.g0 = L.groups[0];
   asm volatile("" : "+s"(h.slot_map), "+s"(h.span_list), "+s"(h.cols), "+s"(h.dyn), "+s"(h.blob), "+s"(h.arena),
                "+s"(h.bad_ids), "+s"(h.csr_arena_off));
-  asm volatile("" : "+s"(h.n_groups), "+s"(h.rank), "+s"(h.world), "+s"(h.seg_search), "+s"(h.g0.rows), "+s"(h.g0.nslots),
+  asm volatile("" : "+s"(h.n_groups), "+s"(h.rank), "+s"(h.world), "+s"(h.seg_search), "+s"(h.store_through), "+s"(h.g0.rows), "+s"(h.g0.nslots),
                "+s"(h.g0.nsp8), "+s"(h.g0.block_begin), "+s"(h.g0.slot_map_off), "+s"(h.g0.span_list_off), "+s"(h.g0.nlist));
   return h;
 }
@@ -687,7 +683,7 @@ __device__ __forceinline__ void dense_body(const FcpLaunch &L, int bid, char *sm
     asm volatile("" ::"v"(v[r].v[0]), "v"(v[r].v[V - 1]));
     if (b < B.rows && v[r].v[0] == 1234.5f) st_out<V>(outp + (int64_t)b * ostride, v[r]);
 #else
-    if (b < B.rows) st_out<V>(outp + (int64_t)b * ostride, v[r]);
+    if (b < B.rows) st_out<V>(outp + (int64_t)b * ostride, v[r], H.store_through != 0);
 #endif
   }
 #if defined(FCP_STAMPS)
@@ -897,7 +893,7 @@ __device__ __forceinline__ void ragged_emit(const Hot &H, const LdsCol &C, const
 #pragma unroll
     for (int t = 0; t < V; ++t) acc.v[t] = acc.v[t] / fc;
   }
-  st_out<V>(reinterpret_cast<float *>(H.arena + C.out_base) + e + (int64_t)b * C.out_stride, acc);
+  st_out<V>(reinterpret_cast<float *>(H.arena + C.out_base) + e + (int64_t)b * C.out_stride, acc, H.store_through != 0);
 }
 
 struct RaggedLds {
