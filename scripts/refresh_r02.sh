@@ -3,6 +3,12 @@
 cd $GRAFT_REPO_ROOT
 O=$GRAFT_REPO_ROOT/gpurun_out/refresh2
 rm -rf $O; mkdir -p $O
+# PMC passes first (their own runs: --pmc with --kernel-trace only): the bench lines below report
+# roofline.traffic from profiles/traffic.json, which must describe the kernels of this build
+bash scripts/pmc.sh refresh2 > $O/r02_s2_pmc_fcp_bench.txt 2>&1
+bash scripts/pmc_py.sh refresh2_ragged --workload ragged > $O/r02_ragged_pmc.txt 2>&1
+bash scripts/pmc_py.sh refresh2_e --workload e > $O/r02_ae_model_e_pmc.txt 2>&1
+python3 scripts/traffic_from_pmc.py $O > /dev/null && cp profiles/traffic.json $O/traffic.json
 # the driver's invocation (few steps) and the default one
 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/r02_bench_s2_driver_steps20.json 2> $O/bench_s2_driver.err
 python bench.py > $O/r02_bench_s2.json 2> $O/bench_s2.err
@@ -14,6 +20,7 @@ python bench.py --workload f > $O/r02_bench_ae_model_f.json 2>/dev/null
 ./build/stamps/fcp_bench --steps 200 | tail -24 > $O/stamps_s2.txt
 ./build/stamps/fcp_bench --columns 980 --vocab 101 --bucketize-every 1 --dim 8 --steps 200 | tail -12 > $O/stamps_elike.txt
 ./build/ramp_probe 3776 300 > $O/ramp_probe.txt 2>&1
+bash scripts/r02_suite.sh recom_amd > $O/r02_other_workloads.txt 2>&1
 # kernel traces (single stream: --no-overlap keeps every traced kernel alone on its stream)
 bash scripts/profile_s2.sh refresh2 > $O/profile_s2.log 2>&1
 cp gpurun_out/prof_refresh2/summary.txt $O/r02_s2_kernel_trace_stats.txt 2>/dev/null
@@ -21,10 +28,6 @@ cp gpurun_out/prof_refresh2/summary.txt $O/r02_s2_kernel_trace_stats.txt 2>/dev/
 python3 scripts/summarize_prof.py $O/r > $O/r02_ragged_kernel_trace_stats.txt 2>&1
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/e/trace -- python3 $GRAFT_REPO_ROOT/bench.py --workload e --steps 300 --warmup 50 --no-cpu-baseline --no-overlap > $O/trace_e.log 2>&1 )
 python3 scripts/summarize_prof.py $O/e > $O/r02_ae_model_e_kernel_trace_stats.txt 2>&1
-# PMC passes (their own runs: --pmc with --kernel-trace only)
-bash scripts/pmc.sh refresh2 > $O/r02_s2_pmc_fcp_bench.txt 2>&1
-bash scripts/pmc_py.sh refresh2_ragged --workload ragged > $O/r02_ragged_pmc.txt 2>&1
-bash scripts/pmc_py.sh refresh2_e --workload e > $O/r02_ae_model_e_pmc.txt 2>&1
 find $O -name "*.csv" -size +2M -delete
 rm -rf $O/r $O/e
 ls -la $O
