@@ -346,6 +346,12 @@ def main():
             overlap["inferences_per_s"] = batch / (overlap["us_per_request"] * 1e-6)
             overlap["aggregate_frac_of_peak"] = bytes_alg["total"] / (overlap["us_per_request"] * 1e-6) / 1e9 / HBM_PEAK_GBS
             rec["overlapped_serving"] = overlap
+            rec["qps_definition"] = ("`value` = one serve worker issuing exactly --steps requests back to back (the bench contract's timed "
+                                     "region; roofline.frac is this single-stream kernel); the serving QPS under the reference's own "
+                                     "protocol - benchmark_multi_thread: serve_workers threads x num_iterations requests, "
+                                     "examples/cc/recom_examples.patch:193-225 - is overlapped_serving.inferences_per_s "
+                                     f"({overlap['inferences_per_s'] / 1e6:.1f} M with {overlap['serve_workers']} workers), next to the single-request "
+                                     "p50 above")
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
             rec["cpu_baseline"] = cpu_baseline(model)
         print(json.dumps(rec))
