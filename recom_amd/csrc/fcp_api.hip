@@ -819,7 +819,9 @@ int bind_tables(fcp_plan *p, const void *const *input_ptrs) {
     const bool lookup = p->cols[k].d.form == FCP_FORM_GATHER || p->cols[k].d.form == FCP_FORM_SEGMENT_REDUCE ||
                         p->cols[k].d.form == FCP_FORM_GATHER_SCATTER;
     if (lookup) {
-      if (!input_ptrs[t]) return fail(FCP_ERR_INVALID_ARGUMENT, "null table pointer");
+      // (a row shard of a table with fewer rows than ranks may be empty: no id maps to it, nothing is read)
+      const bool empty_shard = p->desc.shard_world > 1 && p->cols[k].d.vocab <= p->desc.shard_rank;
+      if (!input_ptrs[t] && !empty_shard) return fail(FCP_ERR_INVALID_ARGUMENT, "null table pointer");
       cols[p->pos_of[k]].table = static_cast<const float *>(input_ptrs[t]);
     }
   }

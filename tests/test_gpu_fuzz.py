@@ -1,7 +1,9 @@
 """Randomised parity: random column plans (forms, dims, id sources, segment
-encodings, concat groups, batch sizes, bag lengths) through the C ABI against the
-oracle — bit-exact, including pooled columns (same sequential fp32 order).  Also
-host threads sharing one plan on their own streams with ever-changing shapes."""
+encodings, concat groups, batch sizes, bag lengths; bucketize boundary arrays of every tier —
+arithmetic, nearly uniform, duplicated, random — with boundary-exact / NaN / inf values; id transforms
+and integer hashing; ids outside the vocabulary) through the C ABI against the oracle — bit-exact,
+including pooled columns (same sequential fp32 order); the same for row-sharded plans (per-rank
+partials).  Also host threads sharing one plan on their own streams with ever-changing shapes."""
 import os
 import threading
 
@@ -13,10 +15,38 @@ pytestmark = pytest.mark.gpu
 from recom_amd.plan import (COMBINER_MEAN, COMBINER_NONE, COMBINER_SUM, FORM_BATCH_COL_REDUCTION, FORM_GATHER,  # noqa: E402
                             FORM_GATHER_SCATTER, FORM_PASSTHROUGH, FORM_SEGMENT_REDUCE, IDS_F32_BUCKETIZE, IDS_I32,
                             IDS_I64, ROWS_FROM_IDS, ROWS_FROM_INPUT_DIM0, ROWS_FROM_SYMBOL, SEG_CSR_I32, SEG_IDS_I32,
-                            SEG_IDS_I64, SEG_NONE, ColumnSpec, PlanSpec)
+                            SEG_IDS_I64, SEG_NONE, XFORM_FILTER, XFORM_NONE, XFORM_SELECT, ColumnSpec, PlanSpec)
 
 
-def random_model(rng, dense_only=False):
+def random_boundaries(rng, nb):
+    """One boundary array per bucketize tier of the kernels (computed / guess + verify / binary search)."""
+    kind = str(rng.choice(["random", "arith", "arith", "linspace", "jitter", "dups"]))
+    if kind == "arith":                               # exactly fma(i, step, b0) in fp32 for most (b0, step)
+        b0, step = np.float32(rng.choice([-10.0, -3.5, 0.0, 0.25])), np.float32(rng.choice([0.5, 1.0, 0.37, 2.0, 0.001]))
+        b = b0 + np.arange(nb, dtype=np.float32) * step
+    elif kind == "linspace":
+        b = np.linspace(-10, 10, nb, dtype=np.float32)
+    elif kind == "jitter":
+        b = np.linspace(-10, 10, nb) + rng.uniform(-0.4, 0.4, nb) * (20.0 / max(nb, 1))
+    elif kind == "dups":
+        b = np.round(rng.uniform(-10, 10, nb) * 2) / 2
+    else:
+        b = rng.uniform(-10, 10, nb)
+    return np.sort(np.asarray(b, np.float32))
+
+
+def random_values(rng, n, bnd):
+    """float32 features for a bucketize column: mostly uniform, some exactly on a boundary, a few NaN / inf / huge."""
+    v = rng.uniform(-12, 12, n).astype(np.float32)
+    if n:
+        on = rng.random(n) < 0.15
+        v[on] = bnd[rng.integers(0, len(bnd), int(on.sum()))]
+        odd = rng.random(n) < 0.03
+        v[odd] = rng.choice(np.asarray([np.nan, np.inf, -np.inf, 3e38, -3e38, 0.0, -0.0], np.float32), int(odd.sum()))
+    return v
+
+
+def random_model(rng, dense_only=False, extended=True):
     """Returns (spec, tables, make_inputs(batch per group) -> (inputs, symbols))."""
     vec = int(rng.choice([4, 4, 4, 2, 1]))
     n_groups = int(rng.integers(1, 4))
@@ -57,21 +87,38 @@ def random_model(rng, dense_only=False):
         src = int(rng.choice([IDS_I32, IDS_I64, IDS_I64, IDS_F32_BUCKETIZE]))
         bnd = None
         if src == IDS_F32_BUCKETIZE:
-            nb = vocab - 1 if vocab > 1 else 1
-            bnd = np.sort(rng.uniform(-10, 10, nb)).astype(np.float32)
-            if vocab == 1:  # buckets 0..1 would overflow a 1-row table: bad ids are part of the test
-                pass
+            nb = vocab - 1 if vocab > 1 else 1        # vocab 1: bucket 1 overflows the 1-row table: bad ids are part of the test
+            bnd = random_boundaries(rng, nb)
         id_esz = 8 if src == IDS_I64 else 4
+        # integer hashing in front (raw ids of any magnitude), interval select / filter, ids outside the vocabulary
+        hashb = int(rng.integers(1, vocab + 1)) if extended and src != IDS_F32_BUCKETIZE and rng.random() < 0.25 else 0
+        xf = dict(xform_mode=XFORM_NONE)
+        if extended and rng.random() < 0.3:
+            n_iv = int(rng.integers(0, 4))
+            los = rng.integers(-2, vocab + 2, n_iv)
+            his = los + rng.integers(0, max(vocab // 2, 1) + 1, n_iv)
+            xf = dict(xform_mode=int(rng.choice([XFORM_SELECT, XFORM_FILTER])), xform_lo=tuple(int(v) for v in los),
+                      xform_hi=tuple(int(v) for v in his), xform_substitute=int(rng.integers(-1, vocab + 1)))
+        oob = extended and not hashb and rng.random() < 0.25
+        xf["hash_buckets"] = hashb
 
-        def draw_ids(r, n, src=src, vocab=vocab, bnd=bnd):
+        def draw_ids(r, n, src=src, vocab=vocab, bnd=bnd, hashb=hashb, oob=oob):
             if src == IDS_F32_BUCKETIZE:
-                return r.uniform(-12, 12, n).astype(np.float32)
-            return r.integers(0, vocab, n).astype(np.int64 if src == IDS_I64 else np.int32)
+                return random_values(r, n, bnd) if extended else r.uniform(-12, 12, n).astype(np.float32)
+            dt = np.int64 if src == IDS_I64 else np.int32
+            if hashb:
+                info = np.iinfo(dt)
+                return r.integers(info.min, info.max, n, dtype=dt, endpoint=True)
+            ids = r.integers(0, vocab, n).astype(dt)
+            if oob and n:
+                bad = r.random(n) < 0.05
+                ids[bad] = r.choice(np.asarray([-1, -7, vocab, vocab + 3, np.iinfo(dt).max, np.iinfo(dt).min], dt), int(bad.sum()))
+            return ids
 
         if form == FORM_GATHER:
             i = host(1, id_esz)
             gens.append((g, lambda r, B, d=draw_ids: [d(r, B)]))
-            cols.append(ColumnSpec(form, dim, vocab, COMBINER_NONE, src, t, i, -1, SEG_NONE, 1, ROWS_FROM_IDS, 0, bnd, g, slot))
+            cols.append(ColumnSpec(form, dim, vocab, COMBINER_NONE, src, t, i, -1, SEG_NONE, 1, ROWS_FROM_IDS, 0, bnd, g, slot, **xf))
             continue
         seg = str(rng.choice(["csr", "indices", "rowids32"]))
         max_len = 1 if form == FORM_GATHER_SCATTER else int(rng.choice([0, 1, 3, 10, 10, 70, 200]))
@@ -97,7 +144,7 @@ def random_model(rng, dense_only=False):
 
         gens.append((g, gen))
         comb = int(rng.choice([COMBINER_SUM, COMBINER_MEAN])) if form == FORM_SEGMENT_REDUCE else COMBINER_NONE
-        cols.append(ColumnSpec(form, dim, vocab, comb, src, t, i, si, kind, stride, ROWS_FROM_SYMBOL, g, bnd, g, slot))
+        cols.append(ColumnSpec(form, dim, vocab, comb, src, t, i, si, kind, stride, ROWS_FROM_SYMBOL, g, bnd, g, slot, **xf))
     # every group needs a column
     for g in range(n_groups):
         if slots[g] == 0:
@@ -140,6 +187,95 @@ def test_random_plans_match_oracle(oracle, seed):
             got = out.groups[g].cpu().numpy()
             assert got.shape == w.shape, (seed, trial, g)
             assert np.array_equal(got, w), (seed, trial, g, float(np.abs(got - w).max()))
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FCP_FUZZ_SHARD_SEEDS", "8"))))
+def test_random_plans_row_sharded_match_oracle(oracle, seed):
+    """The same random plans as one rank of a row-sharded world (rows id % world == rank of every table): the
+    rank's partial sums equal the sharded oracle bit for bit — transforms and hashing run before the ownership
+    test, table-free columns belong to rank 0."""
+    import torch
+    from recom_amd.ops import FeatureColumnProcess, concat_inputs
+    rng = np.random.default_rng(5000 + seed)
+    spec, tables, make = random_model(rng, dense_only=(seed % 4 == 3))
+    # a filtered MEAN column cannot be row-sharded (the kept count of a bag is not known to one rank; refused at
+    # plan creation, test_host.py): such columns pool by sum here
+    import dataclasses
+    spec = dataclasses.replace(spec, columns=[dataclasses.replace(c, combiner=COMBINER_SUM)
+                                              if c.xform_mode == XFORM_FILTER and c.combiner == COMBINER_MEAN else c
+                                              for c in spec.columns])
+    world = int(rng.choice([2, 3, 8]))
+    dev = torch.device("cuda", 0)
+    for rank in sorted({0, int(rng.integers(0, world)), world - 1}):
+        sspec = spec.with_shard(rank, world)
+        shard = [np.ascontiguousarray(t[rank::world]) for t in tables]
+        d_tabs = [torch.from_numpy(t).to(dev) for t in shard]
+        op = FeatureColumnProcess(sspec, 0)
+        for trial in range(2):
+            batches = [int(rng.choice([1, 5, 64, 130])) for _ in range(spec.n_groups)]
+            inputs, symbols = make(rng, batches)
+            blob, offsets, shapes = concat_inputs(inputs)
+            d_blob = torch.from_numpy(blob).to(dev) if blob.size else torch.empty(0, dtype=torch.int8, device=dev)
+            out = op(d_blob, offsets, shapes, d_tabs, symbols)
+            torch.cuda.synchronize()
+            want, _bad = oracle.process_feature_columns(sspec.to_dict(), blob, offsets, shapes, shard, symbols)
+            for g, w in enumerate(want):
+                got = out.groups[g].cpu().numpy()
+                assert got.shape == w.shape and np.array_equal(got, w), (seed, rank, world, trial, g)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FCP_FUZZ_FINALIZE_SEEDS", "6"))))
+def test_random_plans_sharded_then_finalized_equal_the_unsharded_result(oracle, seed):
+    """All ranks' partial sums of a random plan, a random batch slice of each, fcp_shard_finalize: equal to the
+    unsharded oracle — exactly for columns with one owner per row (gathers, scatters, table-free columns),
+    within 1e-5 of the bag's absolute sum for pooled ones (the adds are regrouped by owner)."""
+    import dataclasses
+    import torch
+    from recom_amd.ops import FeatureColumnProcess, concat_inputs
+    rng = np.random.default_rng(9000 + seed)
+    spec, tables, make = random_model(rng, dense_only=(seed % 4 == 3))
+    spec = dataclasses.replace(spec, columns=[dataclasses.replace(c, combiner=COMBINER_SUM)
+                                              if c.xform_mode == XFORM_FILTER and c.combiner == COMBINER_MEAN else c
+                                              for c in spec.columns])
+    world = int(rng.choice([2, 3, 8]))
+    dev = torch.device("cuda", 0)
+    batches = [int(rng.choice([3, 64, 130])) for _ in range(spec.n_groups)]
+    inputs, symbols = make(rng, batches)
+    blob, offsets, shapes = concat_inputs(inputs)
+    d_blob = torch.from_numpy(blob).to(dev) if blob.size else torch.empty(0, dtype=torch.int8, device=dev)
+    full, _ = oracle.process_feature_columns(spec.to_dict(), blob, offsets, shapes, tables, symbols)
+    # an upper bound of what reassociation can move: the same plan over |tables|, pooled by sum
+    abs_spec = dataclasses.replace(spec, columns=[dataclasses.replace(c, combiner=COMBINER_SUM) if c.form == FORM_SEGMENT_REDUCE else c
+                                                  for c in spec.columns])
+    mag, _ = oracle.process_feature_columns(abs_spec.to_dict(), blob, offsets, shapes, [np.abs(t) for t in tables], symbols)
+    ops, tabs, parts = [], [], []
+    for rank in range(world):
+        sspec = spec.with_shard(rank, world)
+        d_tabs = [torch.from_numpy(np.ascontiguousarray(t[rank::world])).to(dev) for t in tables]
+        op = FeatureColumnProcess(sspec, 0)
+        out = op(d_blob, offsets, shapes, d_tabs, symbols)
+        torch.cuda.synchronize()
+        parts.append([g.clone() for g in out.groups])
+        ops.append(op)
+        tabs.append(d_tabs)
+    offs = spec.column_offsets()
+    for g in range(spec.n_groups):
+        rows = batches[g]
+        lo = int(rng.integers(0, rows))
+        cnt = int(rng.integers(1, rows - lo + 1))
+        sl = torch.stack([parts[r][g][lo:lo + cnt] for r in range(world)]).contiguous()
+        r = int(rng.integers(0, world))
+        fin = ops[r].shard_finalize(d_blob, offsets, shapes, tabs[r], symbols, g, sl, world, lo, cnt)
+        torch.cuda.synchronize()
+        got, ref, m = fin.cpu().numpy(), full[g][lo:lo + cnt], mag[g][lo:lo + cnt]
+        for k, c in enumerate(spec.columns):
+            if c.concat_group != g:
+                continue
+            a, b = got[:, offs[k]:offs[k] + c.dim], ref[:, offs[k]:offs[k] + c.dim]
+            if c.form != FORM_SEGMENT_REDUCE:
+                assert np.array_equal(a, b), (seed, g, k, c.form)
+            else:
+                assert np.all(np.abs(a - b) <= 1e-5 * np.maximum(np.abs(m[:, offs[k]:offs[k] + c.dim]), 1.0)), (seed, g, k)
 
 
 def test_host_threads_share_a_plan_with_changing_shapes(oracle):
