@@ -203,10 +203,12 @@ class PlanSpec:
                     flags[c.ids_input] = True
                 if c.seg_kind == SEG_IDS_I64:
                     flags[c.seg_input] = True
-        # an input stays 8-byte unless every column reading it agrees
+        # an input stays 8-byte unless every column reading it agrees; raw ids that are hashed or run through an
+        # interval transform on the device keep their full width (the stager maps ids outside [0, 2^31) to -1,
+        # which only the plain vocabulary check treats the same way)
         for c in self.columns:
             if c.form in (FORM_GATHER, FORM_SEGMENT_REDUCE, FORM_GATHER_SCATTER):
-                if c.id_source != IDS_I64 or c.vocab > 0x7fffffff:
+                if c.id_source != IDS_I64 or c.vocab > 0x7fffffff or c.hash_buckets or c.xform_mode != XFORM_NONE:
                     if c.ids_input >= 0 and self.host_input_elem_sizes[c.ids_input] == 8:
                         flags[c.ids_input] = False
         cols = []

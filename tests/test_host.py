@@ -273,6 +273,15 @@ def test_narrowed_plan_and_column_subset():
     big = synth.model_s2(columns=4, vocab=1 << 33)
     nb, fb = big.spec.narrowed()
     assert not any(fb) and nb.host_input_elem_sizes == big.spec.host_input_elem_sizes
+    # ids that are hashed or interval-transformed on the device keep their 8 bytes (raw ids of any magnitude)
+    import dataclasses
+    k64 = [k for k, c in enumerate(m.spec.columns) if c.form in (1, 2, 3) and c.id_source == PL.IDS_I64][:2]
+    cols = list(m.spec.columns)
+    cols[k64[0]] = dataclasses.replace(cols[k64[0]], hash_buckets=97)
+    cols[k64[1]] = dataclasses.replace(cols[k64[1]], xform_mode=PL.XFORM_SELECT, xform_lo=(-5,), xform_hi=(1 << 40,), xform_substitute=0)
+    hx, fx = dataclasses.replace(m.spec, columns=cols).narrowed()
+    for k in k64:
+        assert hx.columns[k].id_source == PL.IDS_I64 and not fx[cols[k].ids_input] and hx.host_input_elem_sizes[cols[k].ids_input] == 8
     # column subset: renumbered operands, same concat slots
     keep = [k for k, c in enumerate(m.spec.columns) if c.concat_group == 0][2:6]
     sub = m.spec.column_subset(keep)
