@@ -50,7 +50,7 @@ def random_model(rng, dense_only=False, extended=True):
     """Returns (spec, tables, make_inputs(batch per group) -> (inputs, symbols))."""
     vec = int(rng.choice([4, 4, 4, 2, 1]))
     n_groups = int(rng.integers(1, 4))
-    n_cols = int(rng.integers(1, 40))
+    n_cols = int(rng.integers(1, 40)) if rng.random() > 0.12 else int(rng.integers(100, 400))   # some plans span dozens of 64-slot spans
     cols, ranks, esz, tables, gens = [], [], [], [], []
     slots = [0] * n_groups
 
@@ -168,15 +168,19 @@ def random_model(rng, dense_only=False, extended=True):
 # FCP_FUZZ_SEEDS=<n>: longer soak runs (the suite keeps 24)
 @pytest.mark.parametrize("seed", range(int(os.environ.get("FCP_FUZZ_SEEDS", "24"))))
 def test_random_plans_match_oracle(oracle, seed):
+    import dataclasses
     import torch
+    from recom_amd.plan import FLAG_COUNT_BAD_IDS
     from recom_amd.ops import FeatureColumnProcess, concat_inputs
     rng = np.random.default_rng(1000 + seed)
     spec, tables, make = random_model(rng, dense_only=(seed % 4 == 3))
+    spec = dataclasses.replace(spec, flags=FLAG_COUNT_BAD_IDS)
+    bad_total = 0
     dev = torch.device("cuda", 0)
     d_tabs = [torch.from_numpy(t).to(dev) for t in tables]
     op = FeatureColumnProcess(spec, 0)
     for trial in range(4):
-        batches = [int(rng.choice([1, 2, 5, 33, 64, 130, 257])) for _ in range(spec.n_groups)]
+        batches = [int(rng.choice([1, 2, 5, 33, 64, 130, 257, 700])) for _ in range(spec.n_groups)]
         inputs, symbols = make(rng, batches)
         blob, offsets, shapes = concat_inputs(inputs)
         d_blob = torch.from_numpy(blob).to(dev) if blob.size else torch.empty(0, dtype=torch.int8, device=dev)
@@ -187,6 +191,8 @@ def test_random_plans_match_oracle(oracle, seed):
             got = out.groups[g].cpu().numpy()
             assert got.shape == w.shape, (seed, trial, g)
             assert np.array_equal(got, w), (seed, trial, g, float(np.abs(got - w).max()))
+        bad_total += int(_bad)                          # ids outside the vocabulary: zeros in the output, counted once each
+        assert op.plan.read_bad_ids() == bad_total, (seed, trial)
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("FCP_FUZZ_SHARD_SEEDS", "8"))))
