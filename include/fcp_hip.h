@@ -164,6 +164,10 @@ enum {
    * reads out of bounds. */
   FCP_FLAG_COUNT_BAD_IDS = 1u << 0
 };
+/* A plan without device resources: layout / arena / table-byte queries and plan-file checks on a machine
+ * without a GPU (offline graph tooling).  Anything that computes returns FCP_ERR_NO_DEVICE — there is no
+ * CPU fallback.  (A macro: the value does not fit an int enumerator.) */
+#define FCP_FLAG_HOST_ONLY 0x80000000u
 
 typedef struct fcp_column_desc {
   int32_t form;         /* FCP_FORM_*                                         */

@@ -57,7 +57,7 @@ int fail(int code, const std::string &msg) {
 inline int64_t align128(int64_t x) { return (x + 127) / 128 * 128; } // alignmem, cuda_emitter.cc:967-969
 
 constexpr int kSlots = 8;
-constexpr uint32_t kFlagHostOnly = 1u << 31; // undocumented: plan without device resources (layout queries)
+constexpr uint32_t kFlagHostOnly = FCP_FLAG_HOST_ONLY; // plan without device resources (layout queries)
 
 struct HostColumn {
   fcp_column_desc_t d;

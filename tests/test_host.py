@@ -342,6 +342,27 @@ def test_plan_file_loaded_by_the_library(tmp_path):
         Plan.from_file(str(tmp_path / "missing.fcp"), host_only=True)
 
 
+def test_header_is_plain_c_and_a_c_client_drives_the_boundary(tmp_path):
+    """include/fcp_hip.h compiled as strict C99 (-pedantic -Werror) into a client that drives the boundary the
+    way a cgo / JNI / dlsym binding would: host-only plan, ConcatInputs packing, layout / arena / table-byte
+    queries, the placement gate, and the loud failure of a compute call without a device
+    (tests/native/abi_c_client.c)."""
+    import shutil
+    import subprocess
+    from recom_amd import lib
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    lib.load()                                        # builds libfcp_hip.so when it is missing
+    exe = str(tmp_path / "abi_c_client")
+    libdir = os.path.join(ROOT, "recom_amd")
+    build = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+                            os.path.join(ROOT, "tests", "native", "abi_c_client.c"), "-L", libdir, "-lfcp_hip",
+                            "-Wl,-rpath," + libdir, "-o", exe], capture_output=True, text=True)
+    assert build.returncode == 0, build.stderr
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0 and "abi_c_client ok" in run.stdout, run.stdout + run.stderr
+
+
 def test_tf_shim_parses_against_a_mock_of_the_tf_api():
     """recom_amd/tf_shim/fcp_tf_ops.cc cannot be built here (no TensorFlow); at least it must
     parse and type-check against include/fcp_hip.h and a minimal mock of the TF op-kernel API."""
