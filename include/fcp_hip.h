@@ -121,8 +121,8 @@ enum {
   /* Addons>GatherIndiceValue / Addons>GatherValueGenIndice
    * (gather_indice_value_ops.cc:33-78, gather_value_gen_indice_ops.cc:33-67): ids that
    * are not "in" are DROPPED: they add nothing to their row and do not count in a
-   * mean; a row left without ids is zeros.  Not available with row sharding together
-   * with FCP_COMBINER_MEAN (fcp_shard_finalize divides by the unfiltered row length). */
+   * mean; a row left without ids is zeros.  (Row-sharded plans: fcp_shard_finalize
+   * re-reads the row's ids and divides a mean by the kept count.) */
   FCP_XFORM_FILTER = 2
 };
 

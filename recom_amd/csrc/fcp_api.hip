@@ -253,9 +253,6 @@ int validate_desc(const fcp_plan_desc_t *d) {
         return fail(FCP_ERR_INVALID_ARGUMENT, where + "bad id transform intervals");
       for (int i = 0; i < c.xform_n; ++i)
         if (c.xform_lo[i] > c.xform_hi[i]) return fail(FCP_ERR_INVALID_ARGUMENT, where + "empty id transform interval");
-      if (c.xform_mode == FCP_XFORM_FILTER && c.form == FCP_FORM_SEGMENT_REDUCE && c.combiner == FCP_COMBINER_MEAN &&
-          d->shard_world > 1)
-        return fail(FCP_ERR_UNSUPPORTED, where + "an id filter on a mean column cannot be row-sharded");
     }
     if (c.form == FCP_FORM_SEGMENT_REDUCE || c.form == FCP_FORM_GATHER_SCATTER) {
       if (c.seg_kind < FCP_SEG_IDS_I32 || c.seg_kind > FCP_SEG_CSR_I32)

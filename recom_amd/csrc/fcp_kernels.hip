@@ -1190,8 +1190,27 @@ __global__ void __launch_bounds__(FCP_BLOCK_THREADS)
     int lo = csr[b], hi = csr[b + 1];
     lo = min(max(lo, 0), cd.nnz);
     hi = min(max(hi, lo), cd.nnz);
-    if (hi > lo) {
-      const float fc = (float)(hi - lo);
+    int kept = hi - lo;
+    if ((cs.xform & 3u) == FCP_XFORM_FILTER) {
+      // ids the column's filter drops do not count in the mean; which ones they are does not depend on the
+      // rank (hash and intervals are applied to the raw id, before the ownership test), so the finalizing
+      // rank re-reads the row's ids and counts the kept ones
+      LdsCol lc;
+      static_cast<FcpColStatic &>(lc) = cs;
+      lc.ids = L.blob + cd.ids_off;
+      lc.csr = nullptr;
+      lc.out_base = 0;
+      lc.out_stride = 0;
+      lc.nnz = cd.nnz;
+      lc.bnd_off = -1; // boundaries, if any, are read from global memory
+      kept = 0;
+      for (int i = lo; i < hi; ++i) {
+        bool bad;
+        kept += fetch_slot_offset<V, false>(lc, L.xforms + c, i, nullptr, 0, 1, bad) != kFiltered ? 1 : 0;
+      }
+    }
+    if (kept > 0) {
+      const float fc = (float)kept;
 #pragma unroll
       for (int t = 0; t < V; ++t) acc.v[t] = acc.v[t] / fc;
     }

@@ -204,12 +204,6 @@ def test_random_plans_row_sharded_match_oracle(oracle, seed):
     from recom_amd.ops import FeatureColumnProcess, concat_inputs
     rng = np.random.default_rng(5000 + seed)
     spec, tables, make = random_model(rng, dense_only=(seed % 4 == 3))
-    # a filtered MEAN column cannot be row-sharded (the kept count of a bag is not known to one rank; refused at
-    # plan creation, test_host.py): such columns pool by sum here
-    import dataclasses
-    spec = dataclasses.replace(spec, columns=[dataclasses.replace(c, combiner=COMBINER_SUM)
-                                              if c.xform_mode == XFORM_FILTER and c.combiner == COMBINER_MEAN else c
-                                              for c in spec.columns])
     world = int(rng.choice([2, 3, 8]))
     dev = torch.device("cuda", 0)
     for rank in sorted({0, int(rng.integers(0, world)), world - 1}):
@@ -234,15 +228,13 @@ def test_random_plans_row_sharded_match_oracle(oracle, seed):
 def test_random_plans_sharded_then_finalized_equal_the_unsharded_result(oracle, seed):
     """All ranks' partial sums of a random plan, a random batch slice of each, fcp_shard_finalize: equal to the
     unsharded oracle — exactly for columns with one owner per row (gathers, scatters, table-free columns),
-    within 1e-5 of the bag's absolute sum for pooled ones (the adds are regrouped by owner)."""
+    within 1e-5 of the bag's absolute sum for pooled ones (the adds are regrouped by owner); a filtered mean
+    divides by the kept count, which the finalizing rank recounts from the row's ids."""
     import dataclasses
     import torch
     from recom_amd.ops import FeatureColumnProcess, concat_inputs
     rng = np.random.default_rng(9000 + seed)
     spec, tables, make = random_model(rng, dense_only=(seed % 4 == 3))
-    spec = dataclasses.replace(spec, columns=[dataclasses.replace(c, combiner=COMBINER_SUM)
-                                              if c.xform_mode == XFORM_FILTER and c.combiner == COMBINER_MEAN else c
-                                              for c in spec.columns])
     world = int(rng.choice([2, 3, 8]))
     dev = torch.device("cuda", 0)
     batches = [int(rng.choice([3, 64, 130])) for _ in range(spec.n_groups)]

@@ -868,12 +868,6 @@ def test_id_transforms_on_device(torch_cuda, oracle, batch, seed):
     out, packed, dop = run_gpu(torch, dspec, req.inputs, dt, req.symbols)
     _, dbad = assert_equal_oracle(oracle, dspec, packed, dt, req.symbols, out)
     assert dbad > 0 and dop.plan.read_bad_ids() == dbad
-    # a filter on a mean column cannot be row-sharded (finalize divides by the unfiltered row length)
-    from recom_amd import lib
-    from recom_amd.ops import Plan
-    with pytest.raises(lib.FcpError) as e:
-        Plan(spec.with_shard(0, 2), 0)
-    assert e.value.status == lib.FCP_ERR_UNSUPPORTED
 
 
 def test_bucketize_tiers_are_exact(torch_cuda, oracle):
