@@ -1127,8 +1127,13 @@ __global__ void __launch_bounds__(FCP_BLOCK_THREADS) fcp_segment_offsets_kernel(
 
 // ---------------------------------------------------------------------------
 // ConcatOutputs (reference layout pass, concat_outputs_op_gpu.cu.cc:85-131):
-// out[p, off_k + e] = in_k[p*dim_k + e].  Only used with FCP_LAYOUT_PER_COLUMN;
-// the fused kernel above writes the concat layout directly.
+// out[p, off_k + e] = in_k[p*dim_k + e].  Used with FCP_LAYOUT_PER_COLUMN (hundreds of narrow inputs), by
+// the host half of Addons>ConcatOutputs (a few payloads scattered into the EXTERNAL slots) and by the
+// column-sharded step (8 wide blocks side by side: there it is half of a rank's work per request).
+// One thread per VEC floats; a block is a tile of TY rows x TX vectors of one input, TX = the widest
+// input of the launch rounded up to a power of two (at most 256), so that narrow inputs still fill
+// their waves with rows.  No integer division per element, no grid cap (round 1: scalar copies behind a
+// 64-block grid-stride loop: 2.35 TB/s on the 8 x [64, 15000] blocks of BASELINE configs[4]).
 // ---------------------------------------------------------------------------
 #define FCP_CONCAT_CHUNK 192
 struct FcpConcatArgs {
@@ -1139,20 +1144,23 @@ struct FcpConcatArgs {
   int64_t prefix;
   int32_t width;
   int32_t n;
+  int32_t tx_log2; // threads along a row
+  int32_t cpr;     // column chunks per row: ceil(max_dim / VEC / TX)
 };
 
-__global__ void __launch_bounds__(FCP_BLOCK_THREADS) fcp_concat_outputs_kernel(const FcpConcatArgs A) {
+template <int VEC> __global__ void __launch_bounds__(FCP_BLOCK_THREADS) fcp_concat_outputs_kernel(const FcpConcatArgs A) {
   const int k = blockIdx.y;
-  const int dim = A.dim[k];
-  const int off = A.off[k];
-  const float *__restrict__ in = A.in[k];
-  const int64_t total = A.prefix * dim;
-  for (int64_t i = (int64_t)blockIdx.x * FCP_BLOCK_THREADS + threadIdx.x; i < total;
-       i += (int64_t)gridDim.x * FCP_BLOCK_THREADS) {
-    const int64_t p = i / dim;
-    const int e = (int)(i - p * dim);
-    A.out[p * A.width + off + e] = in[i];
-  }
+  const int dimv = A.dim[k] / VEC;
+  const int tx = 1 << A.tx_log2;
+  const int lx = threadIdx.x & (tx - 1), ly = threadIdx.x >> A.tx_log2;
+  const int64_t tile = blockIdx.x / A.cpr;
+  const int chunk = (int)(blockIdx.x - tile * A.cpr);
+  const int64_t p = tile * (FCP_BLOCK_THREADS >> A.tx_log2) + ly;
+  const int e = chunk * tx + lx;
+  if (p >= A.prefix || e >= dimv) return;
+  typedef typename VecType<VEC>::T T;
+  const T v = *as_global(reinterpret_cast<const T *>(A.in[k]) + (p * dimv + e));
+  __builtin_nontemporal_store(v, as_global(reinterpret_cast<T *>(A.out + (p * A.width + A.off[k])) + e));
 }
 
 // ---------------------------------------------------------------------------
@@ -1355,10 +1363,28 @@ int fcp_launch_concat_outputs(const void *const *inputs, const int32_t *dims, co
     A.prefix = prefix;
     A.width = width;
     A.n = m;
-    int64_t gx = (prefix * max_dim + FCP_BLOCK_THREADS - 1) / FCP_BLOCK_THREADS;
-    if (gx < 1) gx = 1;
-    if (gx > 64) gx = 64;
-    hipLaunchKernelGGL(fcp_concat_outputs_kernel, dim3((unsigned)gx, m), dim3(FCP_BLOCK_THREADS), 0, s, A);
+    // widest vector every address of the launch is aligned for
+    int vec = 4;
+    uintptr_t bits = reinterpret_cast<uintptr_t>(out) | (uintptr_t)(4u * (uint32_t)width);
+    for (int32_t k = 0; k < m; ++k)
+      bits |= reinterpret_cast<uintptr_t>(A.in[k]) | (uintptr_t)(4u * (uint32_t)A.dim[k]) | (uintptr_t)(4u * (uint32_t)A.off[k]);
+    while (vec > 1 && (bits & (uintptr_t)(4 * vec - 1))) vec >>= 1;
+    const int max_dimv = (max_dim + vec - 1) / vec;
+    int tx_log2 = 0;
+    while ((1 << tx_log2) < max_dimv && (1 << tx_log2) < FCP_BLOCK_THREADS) ++tx_log2;
+    A.tx_log2 = tx_log2;
+    A.cpr = (max_dimv + (1 << tx_log2) - 1) >> tx_log2;
+    const int ty = FCP_BLOCK_THREADS >> tx_log2;
+    const int64_t gx = (prefix + ty - 1) / ty * A.cpr;
+    if (gx <= 0) continue;
+    if (gx > 0x7fffffff) return (int)hipErrorInvalidValue;
+    const dim3 grid((unsigned)gx, (unsigned)m), block(FCP_BLOCK_THREADS);
+    if (vec == 4)
+      hipLaunchKernelGGL(fcp_concat_outputs_kernel<4>, grid, block, 0, s, A);
+    else if (vec == 2)
+      hipLaunchKernelGGL(fcp_concat_outputs_kernel<2>, grid, block, 0, s, A);
+    else
+      hipLaunchKernelGGL(fcp_concat_outputs_kernel<1>, grid, block, 0, s, A);
     const int err = (int)hipGetLastError();
     if (err) return err;
   }
