@@ -192,6 +192,9 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--workload", default="s2", choices=["s2", "dlrm", "ragged", "shard", "shard-col", "e", "f"])
+    ap.add_argument("--seg", default="indices", choices=["indices", "csr", "rowids32"],
+                    help="ragged: how row membership arrives - SparseTensor indices [nnz, 2] int64 (what BASELINE configs[3] "
+                         "names and TF graphs deliver; default), CSR offsets or int32 row ids")
     ap.add_argument("--ids", default="uniform", choices=["uniform", "zipf"])
     ap.add_argument("--threads", type=int, default=1, help="serve_workers per GPU (reference harness flag)")
     ap.add_argument("--columns", type=int, default=0, help="override the column count (debug only)")
@@ -236,7 +239,7 @@ def main():
     elif args.workload in ("e", "f"):
         model = synth.model_ae(args.workload, **({'batch': args.batch} if args.batch else {}))
     else:
-        model = synth.model_ragged(columns=args.columns or 512, **({'batch': args.batch} if args.batch else {}),
+        model = synth.model_ragged(columns=args.columns or 512, seg=args.seg, **({'batch': args.batch} if args.batch else {}),
                                    **({'vocab': args.vocab} if args.vocab else {}))
 
     # The placement gate (a13): tables that fit this GPU's HBM are served from replicas — every rank its own

@@ -68,7 +68,10 @@ struct HostColumn {
   int64_t const_off = -1; // byte offset of the boundaries in the const buffer
 };
 
-constexpr int64_t kSegSearchMaxPairs = 32768;
+const int64_t kSegSearchMaxPairs = [] { // tuning aid: FCP_SEG_SEARCH_MAX_PAIRS
+  const char *e = std::getenv("FCP_SEG_SEARCH_MAX_PAIRS");
+  return e ? std::atoll(e) : (int64_t)32768;
+}();
 constexpr int kAllSlotsBusy = -2; // find_or_reserve: every slot is pinned by a concurrent request
 constexpr int kNeedsInstall = -3; // find_or_reserve during stream capture: these shapes are not resident
 
