@@ -21,11 +21,13 @@ TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
 TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_LATENCY_sum
 LIST
 python3 - <<PY
-import csv, glob, collections
+import csv, glob, collections, re
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in sorted(glob.glob("$OUT/p*/**/*counter_collection.csv", recursive=True)):
     for row in csv.DictReader(open(f)):
-        acc[row["Kernel_Name"].split("(")[0][-60:]][row["Counter_Name"]].append(float(row["Counter_Value"]))
+        name = row["Kernel_Name"]
+        m = re.search(r"fcp_\w+(<[^>]*>)?", name)
+        acc[m.group(0) if m else name[:60]][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for kern, d in acc.items():
     print(kern)
     for k, v in d.items():

@@ -17,11 +17,13 @@ FETCH_SIZE
 WRITE_SIZE
 LIST
 python3 - <<PY
-import csv, glob, collections
+import csv, glob, collections, re
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in sorted(glob.glob("$OUT/p*/**/*counter_collection.csv", recursive=True)):
     for row in csv.DictReader(open(f)):
-        acc[row["Kernel_Name"].split("(")[0][-60:]][row["Counter_Name"]].append(float(row["Counter_Value"]))
+        name = row["Kernel_Name"]
+        m = re.search(r"fcp_\w+(<[^>]*>)?", name)
+        acc[m.group(0) if m else name[:60]][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for kern, d in acc.items():
     print(kern)
     for k, v in d.items():

@@ -14,13 +14,16 @@ python bench.py --gpus 1 --steps 20 --warmup 5 > $O/r02_bench_s2_driver_steps20.
 python bench.py > $O/r02_bench_s2.json 2> $O/bench_s2.err
 python bench.py --ids zipf --no-cpu-baseline > $O/r02_bench_s2_zipf.json 2>/dev/null
 python bench.py --workload ragged > $O/r02_bench_ragged.json 2>/dev/null
+python bench.py --workload ragged --seg csr --no-cpu-baseline > $O/r02_bench_ragged_csr.json 2>/dev/null
 python bench.py --workload dlrm > $O/r02_bench_dlrm.json 2>/dev/null
 python bench.py --workload e > $O/r02_bench_ae_model_e.json 2>/dev/null
 python bench.py --workload f > $O/r02_bench_ae_model_f.json 2>/dev/null
 ./build/stamps/fcp_bench --steps 200 | tail -24 > $O/stamps_s2.txt
 ./build/stamps/fcp_bench --columns 980 --vocab 101 --bucketize-every 1 --dim 8 --steps 200 | tail -12 > $O/stamps_elike.txt
 ./build/ramp_probe 3776 300 > $O/ramp_probe.txt 2>&1
-bash scripts/r02_suite.sh recom_amd > $O/r02_other_workloads.txt 2>&1
+bash scripts/r02_suite.sh product > $O/r02_other_workloads.txt 2>&1
+bash scripts/r02_ragged_indices.sh > $O/r02_ragged_segment_encodings.txt 2>&1
+python3 scripts/shard_rank_share.py 300 2>&1 | grep -v amdgpu.ids > $O/r02_shard_rank_share.txt
 # kernel traces (single stream: --no-overlap keeps every traced kernel alone on its stream)
 bash scripts/profile_s2.sh refresh2 > $O/profile_s2.log 2>&1
 cp gpurun_out/prof_refresh2/summary.txt $O/r02_s2_kernel_trace_stats.txt 2>/dev/null

@@ -12,15 +12,29 @@ FILES = {"s2": ("r02_s2_pmc_fcp_bench.txt", "fcp_dense_kernel<4,4,false>"),
          "e": ("r02_ae_model_e_pmc.txt", "fcp_hybrid_kernel<4,4,false>")}
 
 
-def first_block(path):
-    vals, started = {}, False
+def kernel_block(path, kernel):
+    """Counters of the block headed by `kernel` (a prefix of the header line); the request's other kernels (the
+    segment-offset pre-pass of RAGGED with SparseTensor indices) are added: traffic is per request."""
+    blocks, cur = {}, None
     for line in open(path):
         m = re.match(r"\s+(\w+)\s+n=\s*(\d+)\s+mean=([0-9.e+]+)", line)
-        if m:
-            started = True
-            vals.setdefault(m.group(1), float(m.group(3)))
-        elif started:
-            break
+        if m and cur is not None:
+            blocks[cur].setdefault(m.group(1), (int(m.group(2)), float(m.group(3))))
+        elif not m and line.strip():
+            cur = line.strip()
+            blocks.setdefault(cur, {})
+    main = [k for k in blocks if k.startswith(kernel.split("<")[0])]
+    if not main:
+        raise SystemExit(f"{path}: no block for {kernel}: {list(blocks)}")
+    n_main = blocks[main[0]]["FETCH_SIZE"][0]
+    vals = {}
+    for name, b in blocks.items():
+        if not name.startswith("fcp_") or "probe" in name or "FETCH_SIZE" not in b:
+            continue
+        if name != main[0] and b["FETCH_SIZE"][0] != n_main:
+            continue                                  # not launched once per request
+        for c in ("FETCH_SIZE", "WRITE_SIZE"):
+            vals[c] = vals.get(c, 0.0) + b[c][1]
     return vals
 
 
@@ -33,7 +47,7 @@ def main(d):
                        "at 64 bytes, so the read side is doubled (an upper bound here: requests for 32/64-byte rows are not wide).",
            "kernels_sha16": sha}
     for key, (name, kernel) in FILES.items():
-        v = first_block(os.path.join(d, name))
+        v = kernel_block(os.path.join(d, name), kernel)
         fetch, write = v["FETCH_SIZE"], v["WRITE_SIZE"]
         rec[key] = {"source": f"profiles/{name}", "kernel": kernel, "FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write,
                     "traffic_bytes": int(round((2 * fetch + write) * 1024))}
