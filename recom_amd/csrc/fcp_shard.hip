@@ -287,6 +287,11 @@ struct fcp_shard_step {
   int64_t arena_bytes = 0;
   std::vector<void *> arenas, recvs, outs, temps;
   int64_t temp_bytes = 0;
+  // a ring entry is reused `depth` calls later: on the same stream that is ordered by itself, on another stream the
+  // new call waits for the entry's previous use (event recorded at the end of every run)
+  std::vector<hipEvent_t> used;
+  std::vector<void *> used_on;
+  std::mutex mu; // the ring cursor (callers on several host threads)
 };
 
 namespace {
@@ -360,6 +365,13 @@ int fcp_shard_step_create(fcp_plan_t *plan, fcp_comm_t *comm, int32_t mode, int3
     s->recvs.push_back(rv);
     s->outs.push_back(o);
     s->temps.push_back(t);
+    hipEvent_t ev = nullptr;
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+      fcp_shard_step_destroy(s);
+      return fcp_internal_fail(FCP_ERR_HIP, "shard step event");
+    }
+    s->used.push_back(ev);
+    s->used_on.push_back(nullptr);
   }
   *out = s;
   return FCP_OK;
@@ -372,6 +384,7 @@ int fcp_shard_step_destroy(fcp_shard_step_t *s) {
   (void)hipDeviceSynchronize();
   for (auto *v : {&s->arenas, &s->recvs, &s->outs, &s->temps})
     for (void *p : *v) (void)hipFree(p);
+  for (hipEvent_t ev : s->used) (void)hipEventDestroy(ev);
   delete s;
   return FCP_OK;
 }
@@ -380,8 +393,19 @@ int fcp_shard_step_destroy(fcp_shard_step_t *s) {
 // *out: device [row_count, width] of this rank's batch slice, valid until `depth` further calls.
 int fcp_shard_step_run(fcp_shard_step_t *s, const fcp_process_args_t *args, void **out, int64_t *row_begin, int64_t *row_count) {
   if (!s || !args || !out) return fcp_internal_fail(FCP_ERR_INVALID_ARGUMENT, "null argument");
-  const size_t k = s->next;
-  s->next = (s->next + 1) % (size_t)s->depth;
+  size_t k;
+  {
+    std::lock_guard<std::mutex> lock(s->mu);
+    k = s->next;
+    s->next = (s->next + 1) % (size_t)s->depth;
+  }
+  DeviceScope scope;
+  int rc = scope.enter(s->device);
+  if (rc) return rc;
+  void *const stream_key = args->stream ? args->stream : reinterpret_cast<void *>(1); // the null stream is a stream too
+  if (s->used_on[k] && s->used_on[k] != stream_key &&
+      hipStreamWaitEvent(static_cast<hipStream_t>(args->stream), s->used[k], 0) != hipSuccess)
+    return fcp_internal_fail(FCP_ERR_HIP, "hipStreamWaitEvent (shard step ring)");
   OneShot arena{s->arenas[k], (size_t)s->arena_bytes}, temp{s->temps[k], (size_t)s->temp_bytes};
   fcp_process_args_t a = *args;
   a.malloc_buff = oneshot_alloc;
@@ -394,7 +418,7 @@ int fcp_shard_step_run(fcp_shard_step_t *s, const fcp_process_args_t *args, void
   std::memset(&res, 0, sizeof(res));
   res.group_ptrs = group_ptr;
   res.group_shapes = group_shape;
-  int rc = fcp_process_feature_columns(s->plan, &a, &res);
+  rc = fcp_process_feature_columns(s->plan, &a, &res);
   if (rc) return rc;
   const int64_t rows = group_shape[2 * s->group];
   if (rows > s->max_rows) return fcp_internal_fail(FCP_ERR_SHAPE_MISMATCH, "more rows than the shard step was created for");
@@ -417,6 +441,9 @@ int fcp_shard_step_run(fcp_shard_step_t *s, const fcp_process_args_t *args, void
                                     s->outs[k], a.stream);
     if (rc) return rc;
   }
+  if (hipEventRecord(s->used[k], static_cast<hipStream_t>(a.stream)) != hipSuccess)
+    return fcp_internal_fail(FCP_ERR_HIP, "hipEventRecord (shard step ring)");
+  s->used_on[k] = stream_key;
   *out = s->outs[k];
   if (row_begin) *row_begin = begin;
   if (row_count) *row_count = count;
