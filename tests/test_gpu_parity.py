@@ -52,6 +52,53 @@ def assert_equal_oracle(oracle, spec, packed, tables_np, symbols, out, exact=Tru
     return want, bad
 
 
+def test_tensorflow_documented_examples_through_the_hip_path(torch_cuda):
+    """The worked examples of the TensorFlow API documentation (tests/golden/tf_doc_examples.py; vectors neither
+    this repository nor the reference produced) as one-column plans through the C ABI: Bucketize, GatherV2,
+    SparseSegmentSum / Mean with and without missing segments, ScatterNd(GatherV2), ConcatV2 — the documented
+    outputs, exactly.  No oracle involved."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import tf_doc_examples as T
+    from recom_amd.plan import (COMBINER_MEAN, COMBINER_NONE, COMBINER_SUM, FORM_GATHER, FORM_GATHER_SCATTER, FORM_PASSTHROUGH,
+                                FORM_SEGMENT_REDUCE, IDS_F32_BUCKETIZE, IDS_I64, ROWS_FROM_IDS, ROWS_FROM_INPUT_DIM0,
+                                ROWS_FROM_SYMBOL, SEG_IDS_I64, SEG_NONE, ColumnSpec, PlanSpec)
+    torch = torch_cuda
+
+    def run(cols, ranks, esz, inputs, tables, symbols=None, n_symbols=0):
+        spec = PlanSpec(cols, ranks, esz, len(tables), n_groups=1, n_symbols=n_symbols)
+        spec.validate()
+        out, _, _ = run_gpu(torch, spec, inputs, tables, None if symbols is None else np.asarray(symbols, np.int32))
+        return out.groups[0].cpu().numpy()
+
+    b = T.BUCKETIZE                                            # bucket index read back through a table whose row r is [r]
+    ident = np.arange(4, dtype=np.float32).reshape(4, 1)
+    got = run([ColumnSpec(FORM_GATHER, 1, 4, COMBINER_NONE, IDS_F32_BUCKETIZE, 0, 0, -1, SEG_NONE, 1, ROWS_FROM_IDS, 0,
+                          b["boundaries"], 0, 0)], [1], [4], [b["values"].ravel()], [ident])
+    assert np.array_equal(got.ravel().astype(np.int32), b["expected"].ravel())
+    g = T.GATHER
+    got = run([ColumnSpec(FORM_GATHER, 3, 4, COMBINER_NONE, IDS_I64, 0, 0, -1, SEG_NONE, 1, ROWS_FROM_IDS, 0, None, 0, 0)],
+              [1], [8], [g["indices"]], [g["params"]])
+    assert np.array_equal(got, g["expected"])
+    for case in T.SPARSE_SEGMENT_SUM + [dict(T.SPARSE_SEGMENT_MEAN, mean=True)]:
+        comb = COMBINER_MEAN if case.get("mean") else COMBINER_SUM
+        got = run([ColumnSpec(FORM_SEGMENT_REDUCE, 4, 3, comb, IDS_I64, 0, 0, 1, SEG_IDS_I64, 1, ROWS_FROM_SYMBOL, 0, None, 0, 0)],
+                  [1, 1], [8, 8], [np.asarray(case["indices"], np.int64), np.asarray(case["segment_ids"], np.int64)],
+                  [case["data"]], [case["num_segments"]], 1)
+        assert np.array_equal(got, np.asarray(case["expected"], np.float32)), case
+    sc = T.SCATTER_ND
+    order = np.argsort(sc["indices"])
+    got = run([ColumnSpec(FORM_GATHER_SCATTER, 1, 4, COMBINER_NONE, IDS_I64, 0, 0, 1, SEG_IDS_I64, 1, ROWS_FROM_SYMBOL, 0, None, 0, 0)],
+              [1, 1], [8, 8], [order.astype(np.int64), np.asarray(sc["indices"], np.int64)[order]],
+              [np.asarray(sc["updates"], np.float32).reshape(-1, 1)], [sc["size"]], 1)
+    assert np.array_equal(got.ravel(), np.asarray(sc["expected"], np.float32))
+    c = T.CONCAT
+    got = run([ColumnSpec(FORM_PASSTHROUGH, 3, 0, COMBINER_NONE, 0, -1, k, -1, SEG_NONE, 1, ROWS_FROM_INPUT_DIM0, k, None, 0, k)
+               for k in range(2)], [2, 2], [4, 4], c["inputs"], [])
+    assert np.array_equal(got, c["expected"])
+
+
 @pytest.mark.parametrize("name", GOLDEN_NAMES)
 def test_golden_through_c_abi(torch_cuda, oracle, golden, name):
     case = golden[0][name]

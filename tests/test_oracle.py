@@ -287,6 +287,42 @@ def test_sharded_partials_sum_to_unsharded(oracle, golden):
         assert np.abs(a - f).max() < 1e-5
 
 
+def test_tensorflow_documented_examples(oracle):
+    """The worked examples of the TensorFlow API documentation for the ops the path fuses
+    (tests/golden/tf_doc_examples.py): vectors that neither this repository nor the reference produced.  The C
+    oracle and the NumPy restatement must reproduce every documented output exactly."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import tf_doc_examples as T
+    b = T.BUCKETIZE
+    assert np.array_equal(oracle.bucketize(b["boundaries"], b["values"]), b["expected"])
+    assert np.array_equal(O.np_bucketize(b["boundaries"], b["values"].ravel()).reshape(b["expected"].shape), b["expected"])
+    g = T.GATHER
+    out, bad = oracle.gather_rows(g["params"], g["indices"])
+    assert bad == 0 and np.array_equal(out, g["expected"])
+    for case in T.SPARSE_SEGMENT_SUM + [dict(T.SPARSE_SEGMENT_MEAN, mean=True)]:
+        offs = oracle.segment_offsets(case["segment_ids"], case["num_segments"])
+        assert np.array_equal(offs, O.np_segment_offsets(np.asarray(case["segment_ids"]), case["num_segments"]))
+        mean = case.get("mean", False)
+        out, bad = oracle.sparse_segment_reduce(case["data"], case["indices"], offs, mean)
+        want = np.asarray(case["expected"], np.float32)
+        assert bad == 0 and np.array_equal(out, want), case
+        assert np.array_equal(O.np_sparse_segment_reduce(case["data"], np.asarray(case["indices"]), offs, mean), want)
+        # the reference GPU kernels' own addition orders give the same on these exact values
+        assert np.array_equal(oracle.sparse_segment_reduce(case["data"], case["indices"], offs, mean, ref_order=True)[0], want)
+        assert np.array_equal(oracle.sparse_segment_reduce_refscan(case["data"], case["indices"], case["segment_ids"],
+                                                                  case["num_segments"], mean), want)
+    sc = T.SCATTER_ND
+    order = np.argsort(sc["indices"])                           # form 3 takes its (id, row) pairs in row order
+    table = np.asarray(sc["updates"], np.float32).reshape(-1, 1)
+    out, bad = oracle.gather_scatter_rows(table, order, np.asarray(sc["indices"])[order], sc["size"])
+    assert bad == 0 and np.array_equal(out.ravel(), np.asarray(sc["expected"], np.float32))
+    assert np.array_equal(oracle.concat_outputs(T.CONCAT["inputs"]), T.CONCAT["expected"])
+    h = T.TO_HASH_BUCKET_FAST
+    assert [int(oracle.lib.orc_fingerprint64(s, len(s))) % h["num_buckets"] for s in h["strings"]] == h["expected"]
+
+
 def test_fingerprint64_known_answers(oracle):
     """TensorFlow's Fingerprint64 (FarmHash farmhashna::Hash64; TF 2.6.2 pins farmhash 816a4ae6, un-vendored in
     the reference) restated in C (orc_fingerprint64) and independently in Python integers (np_fingerprint64).
