@@ -399,3 +399,47 @@ def test_cli(tmp_path):
     assert load_plan(str(tmp_path / "m.fcp")).n_columns == 11
     out = parse_graphdef((tmp_path / "out.pbtxt").read_bytes())
     assert any(n.op == "Addons>FeatureColumnProcessWithSymbols" for n in out.node)
+
+
+def test_graph_evaluator_reproduces_the_tensorflow_documented_examples():
+    """oracle/tf_graph_eval.py (the stand-in for TF-CPU that the rewritten graphs are diffed against) evaluated on
+    one-op GraphDefs of the TensorFlow API documentation's worked examples (tests/golden/tf_doc_examples.py):
+    vectors it did not produce itself."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import tf_doc_examples as T
+    from graph_fixtures import GB
+    from recom_amd.graph import tf_proto as P
+    from tf_graph_eval import GraphEvaluator
+
+    def run(build, fetch="out"):
+        g = GB()
+        build(g)
+        return GraphEvaluator(g.gd, {}).run([fetch], {})[0]
+
+    b = T.BUCKETIZE
+    got = run(lambda g: g.node("out", "Bucketize", [g.const("x", b["values"])], T=("type", P.DT_FLOAT),
+                               boundaries=("floats", [float(v) for v in b["boundaries"]])))
+    assert np.array_equal(got, b["expected"])
+    ga = T.GATHER
+    got = run(lambda g: g.gather("out", g.const("p", ga["params"]), g.const("i", ga["indices"]), np.int64))
+    assert np.array_equal(got, ga["expected"])
+    for case in T.SPARSE_SEGMENT_SUM + [dict(T.SPARSE_SEGMENT_MEAN, mean=True)]:
+        op = "SparseSegmentMeanWithNumSegments" if case.get("mean") else "SparseSegmentSumWithNumSegments"
+        got = run(lambda g: g.node("out", op, [g.const("d", case["data"]), g.const("i", np.asarray(case["indices"], np.int64)),
+                                               g.const("s", np.asarray(case["segment_ids"], np.int64)),
+                                               g.const("n", np.asarray(case["num_segments"], np.int32))],
+                                   T=("type", P.DT_FLOAT), Tidx=("type", P.DT_INT64), Tnumsegments=("type", P.DT_INT32),
+                                   Tsegmentids=("type", P.DT_INT64)))
+        assert np.array_equal(got, np.asarray(case["expected"], np.float32)), case
+    sc = T.SCATTER_ND
+    got = run(lambda g: g.node("out", "ScatterNd", [g.const("i", np.asarray(sc["indices"], np.int64).reshape(-1, 1)),
+                                                    g.const("u", np.asarray(sc["updates"], np.float32)),
+                                                    g.const("s", np.asarray([sc["size"]], np.int64))],
+                               T=("type", P.DT_FLOAT), Tindices=("type", P.DT_INT64)))
+    assert np.array_equal(got, np.asarray(sc["expected"], np.float32))
+    c = T.CONCAT
+    got = run(lambda g: g.node("out", "ConcatV2", [g.const("a", c["inputs"][0]), g.const("b", c["inputs"][1]),
+                                                   g.const("axis", np.asarray(1, np.int32))], T=("type", P.DT_FLOAT), N=2))
+    assert np.array_equal(got, c["expected"])
