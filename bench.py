@@ -2,6 +2,7 @@
 """bench.py — BASELINE.json's metric on BASELINE.json's config.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--workload s2|dlrm|ragged|shard|shard-col|e|f]
+                  [--seg indices|csr|rowids32]   (ragged: how row membership arrives; default SparseTensor indices)
 
 A *step* is one request: one pass of the fused feature-column path (ids resident
 in HBM -> [batch, sum(dim)] concat output resident in HBM) over one batch of
@@ -14,8 +15,12 @@ no data-path collective ("weak" scaling).  Only `--workload shard` / `shard-col`
 (tables larger than one GPU's HBM) shard the tables — by rows (partial sums) or by
 columns (final column blocks) — and exchange with one RCCL all-to-all.
 
+Whether tables are replicated or sharded is decided by the placement gate
+(recom_amd/placement.py) from the workload's table bytes and the GPU's HBM.
+
 The timed loop is native (recom_amd/csrc/fcp_harness.hip); rank 0 prints ONE JSON
-line.  `roofline.achieved` = algorithmic bytes per request (SURVEY.md §8d formula,
+line: `value` = exactly --steps requests from one serve worker; `overlapped_serving` =
+the reference's multi-worker protocol (best of 2 / 3 / 4 workers, >= 400 requests each).  `roofline.achieved` = algorithmic bytes per request (SURVEY.md §8d formula,
 DESIGN.md §5) / average device time per request from HIP events recorded on the
 launch stream around the timed region.  `cpu_baseline` times the CPU oracle
 (oracle/, a port of the reference's TF-CPU semantics; TensorFlow is absent) on
