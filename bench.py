@@ -70,6 +70,26 @@ def measured_traffic(workload):
     return entry["traffic_bytes"], "profiles/traffic.json: separate rocprofv3 --pmc passes (scripts/pmc.sh), per launch"
 
 
+def pcie_inclusive():
+    """The same workload with the request on the HOST when the clock starts: host id tensors -> fcp_stager (pinned ring,
+    pack threads, int64 ids shipped as int32) -> one H2D -> kernel, from the torch-free native binary in its own process
+    (never part of `value`: the bench contract times inputs resident in HBM).  Pipelined rate and the
+    latency of a lone request, host clock."""
+    import subprocess
+    exe = os.path.join(os.environ.get("FCP_LIB_DIR", os.path.join(ROOT, "recom_amd")), "fcp_bench")
+    cmd = [exe, "--h2d", "1", "--narrow", "1", "--steps", "300", "--warmup", "50", "--verify", "0"]
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+        line = [ln for ln in out.stdout.splitlines() if ln.startswith("{") and "pcie_inclusive" in ln][-1]
+        r = json.loads(line)
+        r.pop("pcie_inclusive", None)
+        r["what"] = ("host int64 id tensors -> fcp_stager_stage_narrow (pinned ring, ids packed as int32) -> one H2D on the stager's "
+                     "stream -> fused kernel; host clock; `recom_amd/fcp_bench --h2d 1 --narrow 1`")
+        return r
+    except Exception as e:  # the bench line must not depend on this extra
+        return {"error": f"{type(e).__name__}: {e}"[:300]}
+
+
 def cpu_baseline(model, budget_s: float = 12.0, sample_columns: int = 40):
     """Time the CPU oracle (OpenMP over columns, all host cores) on a bounded
     sample: the first `sample_columns` columns of the workload at full batch.
@@ -204,6 +224,7 @@ def main():
     ap.add_argument("--threads", type=int, default=1, help="serve_workers per GPU (reference harness flag)")
     ap.add_argument("--columns", type=int, default=0, help="override the column count (debug only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive pass (host tensors -> pinned ring -> H2D -> kernel)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="skip the extra overlapped-serving pass (3 streams): keeps a kernel trace of this run single-stream")
     ap.add_argument("--vocab", type=int, default=0, help="override the vocabulary size (debug only)")
@@ -364,8 +385,13 @@ def main():
                                      "p50 above")
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
             rec["cpu_baseline"] = cpu_baseline(model)
-        print(json.dumps(rec))
     h.close()
+    if rank == 0:
+        if args.workload == "s2" and world == 1 and args.ids == "uniform" and not args.no_pcie and not args.no_cpu_baseline and not args.batch and not args.columns:
+            del h
+            torch.cuda.empty_cache()
+            rec["pcie_inclusive"] = pcie_inclusive()
+        print(json.dumps(rec))
     if dist:
         dist.destroy_process_group()
 
