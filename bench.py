@@ -77,17 +77,19 @@ def pcie_inclusive():
     latency of a lone request, host clock."""
     import subprocess
     exe = os.path.join(os.environ.get("FCP_LIB_DIR", os.path.join(ROOT, "recom_amd")), "fcp_bench")
-    cmd = [exe, "--h2d", "1", "--narrow", "1", "--steps", "300", "--warmup", "50", "--verify", "0"]
-    try:
-        out = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
-        line = [ln for ln in out.stdout.splitlines() if ln.startswith("{") and "pcie_inclusive" in ln][-1]
-        r = json.loads(line)
-        r.pop("pcie_inclusive", None)
-        r["what"] = ("host int64 id tensors -> fcp_stager_stage_narrow (pinned ring, ids packed as int32) -> one H2D on the stager's "
-                     "stream -> fused kernel; host clock; `recom_amd/fcp_bench --h2d 1 --narrow 1`")
-        return r
-    except Exception as e:  # the bench line must not depend on this extra
-        return {"error": f"{type(e).__name__}: {e}"[:300]}
+    out = {"what": "host int64 id tensors -> fcp_stager_stage_narrow (pinned ring, ids packed as int32) -> fused kernel, host clock, "
+                   "`recom_amd/fcp_bench --h2d 1 --narrow 1 [--zero-copy 1]`; h2d_copy: one hipMemcpyAsync on the stager's stream; "
+                   "zero_copy: the kernel reads the pinned ring over PCIe itself (FCP_STAGER_ZERO_COPY)"}
+    for key, extra in (("h2d_copy", []), ("zero_copy", ["--zero-copy", "1"])):
+        cmd = [exe, "--h2d", "1", "--narrow", "1", "--steps", "300", "--warmup", "50", "--verify", "0"] + extra
+        try:
+            res = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+            line = [ln for ln in res.stdout.splitlines() if ln.startswith("{") and "pcie_inclusive" in ln][-1]
+            r = json.loads(line)
+            out[key] = {k: r[k] for k in ("pack_threads", "blob_MB", "us_per_request_pipelined", "us_latency_single", "inferences_per_s")}
+        except Exception as e:  # the bench line must not depend on this extra
+            out[key] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    return out
 
 
 def cpu_baseline(model, budget_s: float = 12.0, sample_columns: int = 40):

@@ -406,11 +406,24 @@ int fcp_concat_outputs_host(const void *const *host_inputs, const int32_t *dims,
  * `narrow_int64[n_inputs]` to int32 while packing (values outside [0, 2^31) become
  * -1, an invalid id / row either way): half the PCIe bytes for id and index tensors.
  * The plan consuming such a blob declares those inputs as 4-byte (FCP_IDS_I32 /
- * FCP_SEG_IDS_I32); results are unchanged. */
+ * FCP_SEG_IDS_I32); results are unchanged.
+ *
+ * FCP_STAGER_ZERO_COPY (fcp_stager_create_ex): no copy at all — the ring is pinned
+ * memory mapped into the device's address space and the returned "device blob" is
+ * that mapping: the kernels fetch the ids over PCIe themselves.  Fewer runtime calls
+ * per request and no copy engine in the path (S2: 65 us per request steadily, where
+ * the copying form swings between 63 and 150 us with the host's load; lone-request
+ * latency 100-117 vs 121-137 us), at the price of a kernel that holds its CUs for the
+ * duration of the transfer.  A slot is repacked only after the work that read it has
+ * finished (the call waits on the host if it must). */
 typedef struct fcp_stager fcp_stager_t;
+enum { FCP_STAGER_DEFAULT = 0, FCP_STAGER_ZERO_COPY = 1 };
 int fcp_stager_create(int32_t device, int64_t capacity_bytes, int32_t max_inputs,
                       int32_t max_rank_sum, int32_t depth, int32_t n_threads,
                       fcp_stager_t **stager);
+int fcp_stager_create_ex(int32_t device, int64_t capacity_bytes, int32_t max_inputs,
+                         int32_t max_rank_sum, int32_t depth, int32_t n_threads,
+                         uint32_t flags, fcp_stager_t **stager);
 int fcp_stager_stage(fcp_stager_t *stager, const fcp_host_tensor_t *inputs,
                      int32_t n_inputs, void *stream, const void **device_blob,
                      int64_t *blob_bytes, const int32_t **offsets,

@@ -1791,12 +1791,21 @@ struct fcp_stager {
   int n_threads = 1;
   std::mutex mu;
   std::vector<int64_t> byte_off; // scratch
+  bool zero_copy = false;        // the kernels read the pinned ring over PCIe themselves (no H2D copy)
 };
 
 extern "C" {
 
 int fcp_stager_create(int32_t device, int64_t capacity_bytes, int32_t max_inputs, int32_t max_rank_sum,
                       int32_t depth, int32_t n_threads, fcp_stager_t **out) {
+  static const bool zero_copy_env = std::getenv("FCP_STAGER_ZERO_COPY") != nullptr; // tuning aid
+  return fcp_stager_create_ex(device, capacity_bytes, max_inputs, max_rank_sum, depth, n_threads,
+                              zero_copy_env ? FCP_STAGER_ZERO_COPY : FCP_STAGER_DEFAULT, out);
+}
+
+int fcp_stager_create_ex(int32_t device, int64_t capacity_bytes, int32_t max_inputs, int32_t max_rank_sum,
+                         int32_t depth, int32_t n_threads, uint32_t flags, fcp_stager_t **out) {
+  if (flags & ~(uint32_t)FCP_STAGER_ZERO_COPY) return fail(FCP_ERR_INVALID_ARGUMENT, "unknown stager flags");
   if (!out || capacity_bytes <= 0 || capacity_bytes > 0x7fffffff || max_inputs <= 0 || max_rank_sum < 0 ||
       depth < 1 || n_threads < 1)
     return fail(FCP_ERR_INVALID_ARGUMENT, "bad stager parameters (capacity is limited to 2^31 bytes: int32 offsets)");
@@ -1811,10 +1820,12 @@ int fcp_stager_create(int32_t device, int64_t capacity_bytes, int32_t max_inputs
   s->max_inputs = max_inputs;
   s->max_rank_sum = max_rank_sum;
   s->n_threads = n_threads;
+  s->zero_copy = (flags & FCP_STAGER_ZERO_COPY) != 0;
   s->slots.resize(depth);
   for (auto &sl : s->slots) {
-    if (hipHostMalloc(reinterpret_cast<void **>(&sl.h_blob), capacity_bytes, hipHostMallocDefault) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void **>(&sl.d_blob), capacity_bytes) != hipSuccess ||
+    if (hipHostMalloc(reinterpret_cast<void **>(&sl.h_blob), capacity_bytes, hipHostMallocMapped) != hipSuccess ||
+        (s->zero_copy ? hipHostGetDevicePointer(reinterpret_cast<void **>(&sl.d_blob), sl.h_blob, 0)
+                      : hipMalloc(reinterpret_cast<void **>(&sl.d_blob), capacity_bytes)) != hipSuccess ||
         hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&sl.consumed, hipEventDisableTiming) != hipSuccess) {
       fcp_stager_destroy(s);
@@ -1858,8 +1869,12 @@ int fcp_stager_stage_narrow(fcp_stager_t *s, const fcp_host_tensor_t *inputs, in
   const int slot_idx = (int)s->next;
   StageSlot &sl = s->slots[s->next];
   s->next = (s->next + 1) % s->slots.size();
-  // the slot's previous copy must have left the pinned buffer
-  if (hipEventQuery(sl.copied) != hipSuccess) HIP_TRY(hipEventSynchronize(sl.copied));
+  // the slot's previous copy must have left the pinned buffer (zero copy: the kernels that read it must have run)
+  if (s->zero_copy) {
+    if (sl.consumed_valid && hipEventQuery(sl.consumed) != hipSuccess) HIP_TRY(hipEventSynchronize(sl.consumed));
+  } else if (hipEventQuery(sl.copied) != hipSuccess) {
+    HIP_TRY(hipEventSynchronize(sl.copied));
+  }
   // sizes / offsets / shapes: exactly ConcatInputsOp::Compute (concat_inputs_ops.cc:52-66),
   // except that a narrowed int64 input occupies 4 bytes per element
   int64_t size = 0;
@@ -1907,11 +1922,15 @@ int fcp_stager_stage_narrow(fcp_stager_t *s, const fcp_host_tensor_t *inputs, in
       }
     }
   });
-  // the device twin is free once the work that read its previous contents has run
-  if (sl.consumed_valid) HIP_TRY(hipStreamWaitEvent(s->copy_stream, sl.consumed, 0));
-  if (size) HIP_TRY(hipMemcpyAsync(sl.d_blob, sl.h_blob, (size_t)size, hipMemcpyHostToDevice, s->copy_stream));
-  HIP_TRY(hipEventRecord(sl.copied, s->copy_stream));
-  HIP_TRY(hipStreamWaitEvent(user, sl.copied, 0));
+  if (!s->zero_copy) {
+    // the device twin is free once the work that read its previous contents has run
+    if (sl.consumed_valid) HIP_TRY(hipStreamWaitEvent(s->copy_stream, sl.consumed, 0));
+    if (size) HIP_TRY(hipMemcpyAsync(sl.d_blob, sl.h_blob, (size_t)size, hipMemcpyHostToDevice, s->copy_stream));
+    HIP_TRY(hipEventRecord(sl.copied, s->copy_stream));
+    HIP_TRY(hipStreamWaitEvent(user, sl.copied, 0));
+  } else {
+    __atomic_thread_fence(__ATOMIC_SEQ_CST); // the packed bytes are in memory before the launch that reads them is queued
+  }
   s->last = slot_idx;
   if (device_blob) *device_blob = sl.d_blob;
   if (blob_bytes) *blob_bytes = size;
@@ -1941,8 +1960,8 @@ int fcp_stager_destroy(fcp_stager_t *s) {
       (void)hipEventDestroy(sl.copied);
     }
     if (sl.consumed) (void)hipEventDestroy(sl.consumed);
+    if (sl.d_blob && !s->zero_copy) (void)hipFree(sl.d_blob);
     if (sl.h_blob) (void)hipHostFree(sl.h_blob);
-    if (sl.d_blob) (void)hipFree(sl.d_blob);
     delete[] sl.offsets;
     delete[] sl.shapes;
   }

@@ -101,6 +101,7 @@ int main(int argc, char **argv) {
   int slab = 0;             // 1: all tables carved from ONE hipMalloc (as under TF's BFC allocator)
   int h2d = 0;              // 1: PCIe-inclusive loop: stage (pack + H2D) every request, then process
   int narrow = 0;           // with --h2d: ship int64 ids as int32 (fcp_stager_stage_narrow)
+  int zero_copy = std::getenv("FCP_STAGER_ZERO_COPY") ? 1 : 0; // with --h2d: no copy, the kernel reads the pinned ring over PCIe
   int fixed_dim = 0;        // 0: dims cycle 8/16/32/64 (S2); D: every column has dim D (E/F-like models: --dim 8)
   int pack_threads = 8;
   long vocab = 1000000;
@@ -120,6 +121,7 @@ int main(int argc, char **argv) {
     else if (k == "--slab") slab = (int)v;
     else if (k == "--h2d") h2d = (int)v;
     else if (k == "--narrow") narrow = (int)v;
+    else if (k == "--zero-copy") zero_copy = (int)v;
     else if (k == "--dim") fixed_dim = (int)v;
     else if (k == "--pack-threads") pack_threads = (int)v;
     else if (k == "--bw-probe") {
@@ -363,7 +365,8 @@ int main(int argc, char **argv) {
       if (!std::getenv("FCP_STAGER_NO_PIN") && fcp::cpus_near_device(0, &near)) (void)sched_setaffinity(0, sizeof(near), &near);
     }
     fcp_stager_t *st = nullptr;
-    CHECK_FCP(fcp_stager_create(0, (int64_t)blobs[0].size() + 4096, columns, columns, 4, pack_threads, &st));
+    CHECK_FCP(fcp_stager_create_ex(0, (int64_t)blobs[0].size() + 4096, columns, columns, 4, pack_threads,
+                                   zero_copy ? FCP_STAGER_ZERO_COPY : FCP_STAGER_DEFAULT, &st));
     std::vector<uint8_t> nflags(columns, 0);
     size_t shipped = blobs[0].size();
     if (narrow) {
@@ -421,9 +424,9 @@ int main(int argc, char **argv) {
       CHECK_HIP(hipStreamSynchronize(stream));
       lat += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - a0).count();
     }
-    std::printf("{\"pcie_inclusive\": true, \"pack_threads\": %d, \"blob_MB\": %.2f, \"us_per_request_pipelined\": %.2f, "
+    std::printf("{\"pcie_inclusive\": true, \"zero_copy\": %d, \"pack_threads\": %d, \"blob_MB\": %.2f, \"us_per_request_pipelined\": %.2f, "
                 "\"us_latency_single\": %.2f, \"inferences_per_s\": %.0f}\n",
-                pack_threads, shipped / 1e6, us, lat / 50, batch / (us * 1e-6));
+                zero_copy, pack_threads, shipped / 1e6, us, lat / 50, batch / (us * 1e-6));
     CHECK_FCP(fcp_stager_destroy(st));
     CHECK_FCP(fcp_plan_destroy(plan));
     return 0;

@@ -459,14 +459,15 @@ class RequestStager:
     tensors exactly like :func:`concat_inputs` (multi-threaded, straight into pinned
     memory) and enqueues one async H2D copy on the stager's copy stream (``stream`` waits
     for it).  Returns ``(device_blob_ptr, nbytes, offsets, shapes)``; the device blob
-    stays valid for the next ``depth - 1`` calls."""
+    stays valid for the next ``depth - 1`` calls.  ``zero_copy``: no copy — the "device blob" is the pinned
+    ring itself, mapped into the device's address space (``FCP_STAGER_ZERO_COPY``)."""
 
     def __init__(self, capacity_bytes: int, max_inputs: int, max_rank_sum: int, device: int = 0, depth: int = 4,
-                 n_threads: int = 8) -> None:
+                 n_threads: int = 8, zero_copy: bool = False) -> None:
         self._L = _lib.load()
         h = C.c_void_p()
-        _lib.check(self._L.fcp_stager_create(device, capacity_bytes, max_inputs, max_rank_sum, depth, n_threads,
-                                             C.byref(h)), "fcp_stager_create")
+        _lib.check(self._L.fcp_stager_create_ex(device, capacity_bytes, max_inputs, max_rank_sum, depth, n_threads,
+                                                1 if zero_copy else 0, C.byref(h)), "fcp_stager_create_ex")
         self.handle = h
 
     def stage(self, inputs: Sequence[np.ndarray], stream: Optional[int] = None,

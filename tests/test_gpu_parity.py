@@ -643,10 +643,28 @@ def test_ragged_full_size_closed_form(torch_cuda):
     torch.cuda.empty_cache()
 
 
-def test_request_stager_matches_concat_inputs_and_feeds_the_kernel(torch_cuda, oracle):
+class _RawBlob:
+    """A device address handed to the op wrapper in place of a torch tensor (the stager's blob)."""
+
+    def __init__(self, ptr, nbytes):
+        self._p, self._n = ptr, nbytes
+
+    def data_ptr(self):
+        return self._p
+
+    def numel(self):
+        return self._n
+
+    def element_size(self):
+        return 1
+
+
+@pytest.mark.parametrize("zero_copy", [False, True])
+def test_request_stager_matches_concat_inputs_and_feeds_the_kernel(torch_cuda, oracle, zero_copy):
     """ConcatInputs + H2D as one step.  The staged device blob is
     byte-identical to ConcatInputs' output; offsets / shapes are the same arrays; the
-    kernel result through it equals the oracle."""
+    kernel result through it equals the oracle — with the H2D copy and with
+    FCP_STAGER_ZERO_COPY (the kernel reads the pinned ring through its device mapping)."""
     import ctypes as C
     from recom_amd import lib, synth
     from recom_amd.ops import FeatureColumnProcess, RequestStager, concat_inputs
@@ -655,7 +673,7 @@ def test_request_stager_matches_concat_inputs_and_feeds_the_kernel(torch_cuda, o
     tabs_np = m.numpy_tables()
     tabs = [torch.from_numpy(t).cuda() for t in tabs_np]
     op = FeatureColumnProcess(m.spec, 0)
-    st = RequestStager(1 << 20, m.spec.n_host_inputs, sum(m.spec.host_input_ranks), depth=3, n_threads=4)
+    st = RequestStager(1 << 20, m.spec.n_host_inputs, sum(m.spec.host_input_ranks), depth=3, n_threads=4, zero_copy=zero_copy)
     for seed in range(7):  # more requests than ring slots
         req = m.make_request(seed)
         blob, offsets, shapes = concat_inputs(req.inputs)
@@ -670,6 +688,9 @@ def test_request_stager_matches_concat_inputs_and_feeds_the_kernel(torch_cuda, o
         torch.cuda.synchronize()
         want, _ = oracle.process_feature_columns(m.spec.to_dict(), blob, offsets, shapes, tabs_np, req.symbols)
         assert np.array_equal(out.groups[0].cpu().numpy(), want[0])
+        out2 = op(_RawBlob(d_ptr, nbytes), off2, shp2, tabs, req.symbols)       # the kernel on the staged blob itself
+        torch.cuda.synchronize()
+        assert np.array_equal(out2.groups[0].cpu().numpy(), want[0])
     st.close()
 
 
