@@ -1950,6 +1950,7 @@ int fcp_stager_destroy(fcp_stager_t *s) {
   DeviceGuard guard;
   (void)guard.enter(s->device);
   delete s->pool;
+  if (s->zero_copy) (void)hipDeviceSynchronize(); // kernels may still be reading the pinned ring
   if (s->copy_stream) {
     (void)hipStreamSynchronize(s->copy_stream);
     (void)hipStreamDestroy(s->copy_stream);
