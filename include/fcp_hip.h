@@ -432,6 +432,17 @@ int fcp_stager_stage_narrow(fcp_stager_t *stager, const fcp_host_tensor_t *input
                             int32_t n_inputs, const uint8_t *narrow_int64, void *stream,
                             const void **device_blob, int64_t *blob_bytes,
                             const int32_t **offsets, const int32_t **shapes);
+/* The general form: modes[n_inputs] (NULL: all FCP_STAGE_COPY) says what happens to each input while it is packed.
+ * FCP_STAGE_SEG_TO_CSR turns the sorted row ids of a multi-hot feature — an int32 / int64 tensor [nnz], or the
+ * SparseTensor indices [nnz, k] whose column 0 they are — into the int32 row offsets[rows + 1] the kernels want
+ * (mode_args[i] = rows; the plan declares that input FCP_SEG_CSR_I32, rank 1): the host reads those bytes anyway to
+ * pack them, the device then needs neither the segment-offset pre-pass nor the in-block search, and 16 bytes per id
+ * shrink to 4 bytes per ROW on the wire (RAGGED, BASELINE configs[3]: 15.7 MB of blob -> 3.1 MB with narrowed ids). */
+enum { FCP_STAGE_COPY = 0, FCP_STAGE_NARROW_I64 = 1, FCP_STAGE_SEG_TO_CSR = 2 };
+int fcp_stager_stage_ex(fcp_stager_t *stager, const fcp_host_tensor_t *inputs, int32_t n_inputs,
+                        const uint8_t *modes, const int64_t *mode_args, void *stream,
+                        const void **device_blob, int64_t *blob_bytes, const int32_t **offsets,
+                        const int32_t **shapes);
 int fcp_stager_destroy(fcp_stager_t *stager);
 
 /* ---- multi-GPU exchange (no reference counterpart) ---------- */

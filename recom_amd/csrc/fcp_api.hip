@@ -1853,7 +1853,35 @@ int fcp_stager_create_ex(int32_t device, int64_t capacity_bytes, int32_t max_inp
 int fcp_stager_stage_narrow(fcp_stager_t *s, const fcp_host_tensor_t *inputs, int32_t n, const uint8_t *narrow,
                             void *stream, const void **device_blob, int64_t *blob_bytes, const int32_t **offsets,
                             const int32_t **shapes) {
+  return fcp_stager_stage_ex(s, inputs, n, narrow, nullptr, stream, device_blob, blob_bytes, offsets, shapes);
+}
+
+namespace {
+// Sorted segment / row ids (element i at index i * stride, int32 or int64) -> CSR offsets[0..rows]: offsets[r] = number of ids
+// below r — what the device pre-pass (fcp_segment_offsets_kernel) and ComputeSegmentOffsets (cuda_emitter.cc:768-818) produce.
+void seg_to_csr(const void *seg, int elem_size, int64_t stride, int64_t nnz, int64_t rows, int32_t *out) {
+  int64_t i = 0;
+  if (elem_size == 8) {
+    const int64_t *p = static_cast<const int64_t *>(seg);
+    for (int64_t r = 0; r <= rows; ++r) {
+      while (i < nnz && p[i * stride] < r) ++i;
+      out[r] = (int32_t)i;
+    }
+  } else {
+    const int32_t *p = static_cast<const int32_t *>(seg);
+    for (int64_t r = 0; r <= rows; ++r) {
+      while (i < nnz && p[i * stride] < r) ++i;
+      out[r] = (int32_t)i;
+    }
+  }
+}
+} // namespace
+
+int fcp_stager_stage_ex(fcp_stager_t *s, const fcp_host_tensor_t *inputs, int32_t n, const uint8_t *modes,
+                        const int64_t *mode_args, void *stream, const void **device_blob, int64_t *blob_bytes,
+                        const int32_t **offsets, const int32_t **shapes) {
   if (!s || n < 0 || (n > 0 && !inputs)) return fail(FCP_ERR_INVALID_ARGUMENT, "null argument");
+  const uint8_t *narrow = modes; // FCP_STAGE_NARROW_I64 == 1: the flags of fcp_stager_stage_narrow are modes
   if (n > s->max_inputs) return fail(FCP_ERR_INVALID_ARGUMENT, "more inputs than the stager was created for");
   DeviceGuard guard;
   int rc = guard.enter(s->device);
@@ -1882,17 +1910,28 @@ int fcp_stager_stage_narrow(fcp_stager_t *s, const fcp_host_tensor_t *inputs, in
   for (int32_t i = 0; i < n; ++i) {
     const fcp_host_tensor_t &t = inputs[i];
     if (t.rank < 0 || t.elem_size <= 0 || (t.rank > 0 && !t.dims)) return fail(FCP_ERR_INVALID_ARGUMENT, "bad host tensor");
-    if (narrow && narrow[i] && t.elem_size != 8) return fail(FCP_ERR_INVALID_ARGUMENT, "only 8-byte inputs can be narrowed");
+    const int mode = modes ? modes[i] : FCP_STAGE_COPY;
+    if (mode > FCP_STAGE_SEG_TO_CSR) return fail(FCP_ERR_INVALID_ARGUMENT, "unknown staging mode");
+    if (mode == FCP_STAGE_NARROW_I64 && t.elem_size != 8) return fail(FCP_ERR_INVALID_ARGUMENT, "only 8-byte inputs can be narrowed");
     if (rank_sum + t.rank > s->max_rank_sum) return fail(FCP_ERR_INVALID_ARGUMENT, "more dims than the stager was created for");
     int64_t ne = 1;
     for (int32_t j = 0; j < t.rank; ++j) {
       if (t.dims[j] < 0) return fail(FCP_ERR_INVALID_ARGUMENT, "negative dimension");
       ne *= t.dims[j];
-      sl.shapes[rank_sum++] = (int32_t)t.dims[j];
     }
     s->byte_off[i] = size;
     sl.offsets[i] = (int32_t)size;
-    size += ne * ((narrow && narrow[i]) ? 4 : t.elem_size);
+    if (mode == FCP_STAGE_SEG_TO_CSR) {
+      // sorted row ids [nnz] or SparseTensor indices [nnz, k] -> int32 offsets[rows + 1]: one dim in the shapes
+      if ((t.elem_size != 4 && t.elem_size != 8) || t.rank < 1 || t.rank > 2 || !mode_args || mode_args[i] < 0 ||
+          mode_args[i] >= 0x7fffffff || (t.rank == 2 && t.dims[1] < 1))
+        return fail(FCP_ERR_INVALID_ARGUMENT, "segment-id input to convert: int32 / int64 [nnz] or [nnz, k], with its number of rows");
+      sl.shapes[rank_sum++] = (int32_t)(mode_args[i] + 1);
+      size += (mode_args[i] + 1) * 4;
+    } else {
+      for (int32_t j = 0; j < t.rank; ++j) sl.shapes[rank_sum++] = (int32_t)t.dims[j];
+      size += ne * (mode == FCP_STAGE_NARROW_I64 ? 4 : t.elem_size);
+    }
     if (size > s->capacity) return fail(FCP_ERR_INVALID_ARGUMENT, "request larger than the stager capacity");
     if (ne && !t.data) return fail(FCP_ERR_INVALID_ARGUMENT, "null tensor data");
   }
@@ -1908,7 +1947,11 @@ int fcp_stager_stage_narrow(fcp_stager_t *s, const fcp_host_tensor_t *inputs, in
     const int hi = (int)(std::lower_bound(bo, bo + n, b1) - bo);
     for (; lo < hi; ++lo) {
       if (bo[lo + 1] <= bo[lo]) continue;
-      if (narrow && narrow[lo]) {
+      if (modes && modes[lo] == FCP_STAGE_SEG_TO_CSR) {
+        const fcp_host_tensor_t &t = inputs[lo];
+        seg_to_csr(t.data, t.elem_size, t.rank == 2 ? t.dims[1] : 1, t.dims[0], mode_args[lo],
+                   reinterpret_cast<int32_t *>(dst + bo[lo]));
+      } else if (narrow && narrow[lo] == FCP_STAGE_NARROW_I64) {
         // int64 -> int32; values that do not fit are not valid ids / rows anyway: -1 (reads as zeros)
         const int64_t *src = static_cast<const int64_t *>(inputs[lo].data);
         int32_t *d32 = reinterpret_cast<int32_t *>(dst + bo[lo]);

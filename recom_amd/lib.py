@@ -105,7 +105,7 @@ EXPORTS = [
     "fcp_shard_finalize", "fcp_comm_unique_id", "fcp_comm_create", "fcp_comm_destroy", "fcp_comm_rank",
     "fcp_shard_batch_slice", "fcp_shard_exchange", "fcp_shard_exchange_columns",
     "fcp_shard_step_create", "fcp_shard_step_run", "fcp_shard_step_destroy",
-    "fcp_stager_create", "fcp_stager_create_ex", "fcp_stager_stage", "fcp_stager_stage_narrow", "fcp_stager_destroy",
+    "fcp_stager_create", "fcp_stager_create_ex", "fcp_stager_stage", "fcp_stager_stage_ex", "fcp_stager_stage_narrow", "fcp_stager_destroy",
 ]
 
 _lib = None
@@ -194,6 +194,9 @@ def load() -> C.CDLL:
     L.fcp_shard_step_run.argtypes = [C.c_void_p, C.POINTER(ProcessArgs), C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
                                      C.POINTER(C.c_int64)]
     L.fcp_shard_step_destroy.argtypes = [C.c_void_p]
+    L.fcp_stager_stage_ex.argtypes = [C.c_void_p, C.POINTER(HostTensor), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.POINTER(C.c_int32)),
+                                      C.POINTER(C.POINTER(C.c_int32))]
     L.fcp_stager_create_ex.argtypes = [C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_uint32,
                                        C.POINTER(C.c_void_p)]
     L.fcp_stager_create.argtypes = [C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,

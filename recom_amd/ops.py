@@ -470,6 +470,30 @@ class RequestStager:
                                                 1 if zero_copy else 0, C.byref(h)), "fcp_stager_create_ex")
         self.handle = h
 
+    def stage_ex(self, inputs: Sequence[np.ndarray], modes: Sequence[int], mode_args: Sequence[int],
+                 stream: Optional[int] = None):
+        """``fcp_stager_stage_ex``: ``modes[i]`` in ``plan.STAGE_*`` (``PlanSpec.staged()`` gives them and the matching
+        plan); ``mode_args[i]`` = number of rows for ``STAGE_SEG_TO_CSR`` inputs."""
+        import torch
+        arrs = [np.require(np.asarray(a), requirements="C") for a in inputs]
+        n = len(arrs)
+        dims_keep = [np.asarray(a.shape, np.int64) for a in arrs]
+        tens = (_lib.HostTensor * max(n, 1))()
+        for i, a in enumerate(arrs):
+            tens[i] = _lib.HostTensor(a.ctypes.data, a.dtype.itemsize, a.ndim, dims_keep[i].ctypes.data_as(C.POINTER(C.c_int64)))
+        if stream is None:
+            stream = torch.cuda.current_stream().cuda_stream
+        blob, nbytes = C.c_void_p(), C.c_int64()
+        offs, shps = C.POINTER(C.c_int32)(), C.POINTER(C.c_int32)()
+        m = np.asarray(list(modes), np.uint8)
+        a64 = np.asarray(list(mode_args), np.int64)
+        _lib.check(self._L.fcp_stager_stage_ex(self.handle, tens, n, m.ctypes.data, a64.ctypes.data, stream, C.byref(blob),
+                                               C.byref(nbytes), C.byref(offs), C.byref(shps)), "fcp_stager_stage_ex")
+        rank_sum = sum(1 if mm == 2 else a.ndim for mm, a in zip(m, arrs))
+        offsets = np.ctypeslib.as_array(offs, shape=(n,)).copy() if n else np.zeros(0, np.int32)
+        shapes = np.ctypeslib.as_array(shps, shape=(rank_sum,)).copy() if rank_sum else np.zeros(0, np.int32)
+        return blob.value, nbytes.value, offsets, shapes
+
     def stage(self, inputs: Sequence[np.ndarray], stream: Optional[int] = None,
               narrow: Optional[Sequence[bool]] = None):
         """``narrow[i]``: ship int64 input ``i`` as int32 (``PlanSpec.narrowed()`` gives the

@@ -29,6 +29,7 @@ COMBINER_NONE, COMBINER_SUM, COMBINER_MEAN = 0, 1, 2
 IDS_I32, IDS_I64, IDS_F32_BUCKETIZE = 0, 1, 2
 SEG_NONE, SEG_IDS_I32, SEG_IDS_I64, SEG_CSR_I32 = 0, 1, 2, 3
 ROWS_FROM_IDS, ROWS_FROM_SYMBOL, ROWS_FROM_INPUT_DIM0, ROWS_FROM_GROUP = 0, 1, 2, 3
+STAGE_COPY, STAGE_NARROW_I64, STAGE_SEG_TO_CSR = 0, 1, 2  # fcp_stager_stage_ex modes
 XFORM_NONE, XFORM_SELECT, XFORM_FILTER = 0, 1, 2   # id transforms (SelectValue / GatherIndiceValue family)
 LAYOUT_CONCAT, LAYOUT_PER_COLUMN = 0, 1
 FLAG_COUNT_BAD_IDS = 1
@@ -221,6 +222,40 @@ class PlanSpec:
             cols.append(dataclasses.replace(c, **r) if r else c)
         sizes = [4 if f else e for f, e in zip(flags, self.host_input_elem_sizes)]
         return dataclasses.replace(self, columns=cols, host_input_elem_sizes=sizes), flags
+
+    def staged(self, narrow: bool = True, csr: bool = True) -> "tuple[PlanSpec, List[int], List[int]]":
+        """Plan for requests that go through ``fcp_stager_stage_ex``: int64 ids shipped as int32 (``narrowed()``) and the
+        sorted row ids / SparseTensor indices of multi-hot columns turned into int32 CSR offsets by the host while it packs
+        (``STAGE_SEG_TO_CSR``) — the device then needs neither the segment-offset pre-pass nor the in-block search, and the
+        blob carries 4 bytes per ROW instead of 8-16 bytes per id for them.  Returns ``(plan, modes, rows_source)``:
+        ``modes[i]`` is the stager mode of host input ``i``; ``rows_source[i]`` is, for converted inputs, the index of the
+        column whose row count the stager needs (``rows_of_inputs`` evaluates it for a request), else -1."""
+        spec, flags = self.narrowed() if narrow else (self, [False] * self.n_host_inputs)
+        modes = [STAGE_NARROW_I64 if f else STAGE_COPY for f in flags]
+        rows_col = [-1] * self.n_host_inputs
+        if csr:
+            users: dict = {}
+            for k, c in enumerate(spec.columns):
+                if c.form in (FORM_SEGMENT_REDUCE, FORM_GATHER_SCATTER) and c.seg_kind in (SEG_IDS_I32, SEG_IDS_I64):
+                    users.setdefault(c.seg_input, []).append(k)
+            for i, ks in users.items():
+                # an input is converted only if every reader is such a column with the same stride and the same row count
+                # source, and nothing reads it as ids or as a passthrough payload
+                c0 = self.columns[ks[0]]
+                same = all((self.columns[k].seg_stride, self.columns[k].rows_source, self.columns[k].rows_arg) ==
+                           (c0.seg_stride, c0.rows_source, c0.rows_arg) for k in ks)
+                other = any(c.ids_input == i or (c.rows_source == ROWS_FROM_INPUT_DIM0 and c.rows_arg == i) for c in self.columns)
+                readers = sum(1 for c in self.columns if c.seg_input == i)
+                if same and not other and readers == len(ks) and c0.rows_source == ROWS_FROM_SYMBOL:
+                    modes[i] = STAGE_SEG_TO_CSR
+                    rows_col[i] = ks[0]
+            cols = [dataclasses.replace(c, seg_kind=SEG_CSR_I32, seg_stride=1)
+                    if c.seg_input >= 0 and modes[c.seg_input] == STAGE_SEG_TO_CSR else c for c in spec.columns]
+            ranks = [1 if m == STAGE_SEG_TO_CSR else r for m, r in zip(modes, spec.host_input_ranks)]
+            sizes = [4 if m == STAGE_SEG_TO_CSR else e for m, e in zip(modes, spec.host_input_elem_sizes)]
+            spec = dataclasses.replace(spec, columns=cols, host_input_ranks=ranks, host_input_elem_sizes=sizes)
+        spec.validate()
+        return spec, modes, rows_col
 
     def column_subset(self, keep: Sequence[int]) -> "SubPlan":
         """Plan over the columns ``keep`` only (column-sharded serving: one such plan

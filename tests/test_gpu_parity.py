@@ -694,6 +694,52 @@ def test_request_stager_matches_concat_inputs_and_feeds_the_kernel(torch_cuda, o
     st.close()
 
 
+@pytest.mark.parametrize("zero_copy", [False, True])
+def test_request_stager_turns_sparse_indices_into_row_offsets(torch_cuda, oracle, zero_copy):
+    """fcp_stager_stage_ex / FCP_STAGE_SEG_TO_CSR: the sorted row ids of multi-hot features (SparseTensor indices [nnz, 2],
+    int32 / int64 row ids) become int32 CSR offsets while the host packs them, ids are narrowed; the staged plan
+    (PlanSpec.staged(): those columns read CSR, no pre-pass, no in-block search) gives the same bits as the original
+    request through the oracle.  The staged blob is exactly ConcatInputs of the converted tensors."""
+    import fcp_oracle as O
+    from recom_amd import synth
+    from recom_amd.ops import FeatureColumnProcess, RequestStager, concat_inputs
+    from recom_amd.plan import STAGE_NARROW_I64, STAGE_SEG_TO_CSR
+    torch = torch_cuda
+    for m in (synth.model_mixed(batch=70, vocab=997, n_groups=1), synth.model_ragged(columns=40, vocab=3000, batch=130, seg="indices"),
+              synth.model_ragged(columns=12, vocab=500, batch=33, seg="rowids32")):
+        sspec, modes, rows_col = m.spec.staged()
+        assert STAGE_SEG_TO_CSR in modes
+        tabs_np = m.numpy_tables()
+        tabs = [torch.from_numpy(t).cuda() for t in tabs_np]
+        op = FeatureColumnProcess(sspec, 0)
+        st = RequestStager(4 << 20, m.spec.n_host_inputs, sum(m.spec.host_input_ranks), depth=3, n_threads=4, zero_copy=zero_copy)
+        for seed in range(5):
+            req = m.make_request(seed)
+            rows = [int(req.symbols[m.spec.columns[k].rows_arg]) if k >= 0 else 0 for k in rows_col]
+            d_ptr, nbytes, offs, shps = st.stage_ex(req.inputs, modes, rows)
+            conv = []
+            for i, a in enumerate(req.inputs):                  # what the stager must have packed
+                if modes[i] == STAGE_SEG_TO_CSR:
+                    conv.append(O.np_segment_offsets(np.asarray(a).reshape(a.shape[0], -1)[:, 0], rows[i]).astype(np.int32))
+                elif modes[i] == STAGE_NARROW_I64:
+                    conv.append(np.where((a >= 0) & (a <= 0x7fffffff), a, -1).astype(np.int32))
+                else:
+                    conv.append(a)
+            blob2, offs2, shps2 = concat_inputs(conv)
+            assert nbytes == blob2.nbytes and np.array_equal(offs, offs2) and np.array_equal(shps, shps2)
+            out = op(_RawBlob(d_ptr, nbytes), offs, shps, tabs, req.symbols)
+            torch.cuda.synchronize()
+            staged = np.empty(nbytes, np.int8)
+            import ctypes as C
+            hip = C.CDLL("libamdhip64.so")
+            assert hip.hipMemcpy(C.c_void_p(staged.ctypes.data), C.c_void_p(d_ptr), C.c_size_t(nbytes), 2) == 0
+            assert np.array_equal(staged, blob2)
+            want, _ = oracle.process_feature_columns(m.spec.to_dict(), *concat_inputs(req.inputs), tabs_np, req.symbols)
+            for g, w in enumerate(want):
+                assert np.array_equal(out.groups[g].cpu().numpy(), w), (m.name, seed, g)
+        st.close()
+
+
 def test_request_stager_narrows_int64_ids(torch_cuda, oracle):
     """fcp_stager_stage_narrow: int64 ids / SparseTensor indices cross PCIe as int32; the
     narrowed plan gives the same bits as the int64 request through the oracle —

@@ -282,6 +282,16 @@ def test_narrowed_plan_and_column_subset():
     hx, fx = dataclasses.replace(m.spec, columns=cols).narrowed()
     for k in k64:
         assert hx.columns[k].id_source == PL.IDS_I64 and not fx[cols[k].ids_input] and hx.host_input_elem_sizes[cols[k].ids_input] == 8
+    # staged(): narrowing + sorted row ids -> CSR offsets on the host (fcp_stager_stage_ex)
+    sp, modes, rows_col = m.spec.staged()
+    for c0, c1 in zip(m.spec.columns, sp.columns):
+        if c0.form in (2, 3) and c0.seg_kind in (PL.SEG_IDS_I32, PL.SEG_IDS_I64) and c0.rows_source == PL.ROWS_FROM_SYMBOL:
+            assert modes[c0.seg_input] == PL.STAGE_SEG_TO_CSR and c1.seg_kind == PL.SEG_CSR_I32 and c1.seg_stride == 1
+            assert sp.host_input_ranks[c0.seg_input] == 1 and sp.host_input_elem_sizes[c0.seg_input] == 4
+            assert m.spec.columns[rows_col[c0.seg_input]].rows_arg == c0.rows_arg
+        if c0.seg_kind == PL.SEG_CSR_I32:
+            assert modes[c0.seg_input] == PL.STAGE_COPY and c1.seg_kind == PL.SEG_CSR_I32
+    assert PL.STAGE_SEG_TO_CSR in modes and all((r >= 0) == (mo == PL.STAGE_SEG_TO_CSR) for r, mo in zip(rows_col, modes))
     # column subset: renumbered operands, same concat slots
     keep = [k for k, c in enumerate(m.spec.columns) if c.concat_group == 0][2:6]
     sub = m.spec.column_subset(keep)
