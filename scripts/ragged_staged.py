@@ -46,7 +46,7 @@ def alloc(_ctx, nbytes):
 for name, (spec, modes) in VARIANTS.items():
     op = FeatureColumnProcess(spec, 0)
     for zero_copy in (False, True):
-        st = RequestStager(32 << 20, m.spec.n_host_inputs, sum(m.spec.host_input_ranks), depth=4, n_threads=8, zero_copy=zero_copy)
+        st = RequestStager(32 << 20, m.spec.n_host_inputs, sum(m.spec.host_input_ranks), depth=4, n_threads=int(os.environ.get("PACK_THREADS", "8")), zero_copy=zero_copy)
         pre = []
         for r in reqs:                                         # marshal once
             arrs = [np.require(np.asarray(a), requirements="C") for a in r.inputs]
