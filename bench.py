@@ -230,6 +230,9 @@ def main():
     ap.add_argument("--ids", default="uniform", choices=["uniform", "zipf"])
     ap.add_argument("--threads", type=int, default=1, help="serve_workers per GPU (reference harness flag)")
     ap.add_argument("--columns", type=int, default=0, help="override the column count (debug only)")
+    ap.add_argument("--staged", action="store_true",
+                    help="requests resident in HBM in the form the staging step (fcp_stager_stage_ex, PlanSpec.staged()) leaves "
+                         "them: ids int32, sorted row ids / SparseTensor indices already CSR offsets (no pre-pass, no search)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive pass (host tensors -> pinned ring -> H2D -> kernel)")
     ap.add_argument("--no-overlap", action="store_true",
@@ -274,6 +277,9 @@ def main():
     else:
         model = synth.model_ragged(columns=args.columns or 512, seg=args.seg, **({'batch': args.batch} if args.batch else {}),
                                    **({'vocab': args.vocab} if args.vocab else {}))
+
+    if args.staged:
+        model = synth.staged_model(model)
 
     # The placement gate (a13): tables that fit this GPU's HBM are served from replicas — every rank its own
     # requests, no collective; only beyond that are they sharded over the node's GPUs with one RCCL exchange per

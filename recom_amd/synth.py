@@ -133,6 +133,32 @@ def submodel(model: SynthModel, keep: Sequence[int], name: Optional[str] = None)
                       f"{len(sub.columns)} of {model.spec.n_columns} columns of: {model.description}")
 
 
+def staged_model(model: SynthModel) -> SynthModel:
+    """The model as its requests look AFTER the staging step (``fcp_stager_stage_ex`` with the modes of
+    ``PlanSpec.staged()``): int64 ids narrowed to int32, sorted row ids / SparseTensor indices turned into int32 CSR
+    offsets.  The conversion here is NumPy's (the stager's is tested against it bit for bit); used to time the kernels
+    on inputs resident in HBM in the form the staging step leaves there."""
+    from .plan import STAGE_NARROW_I64, STAGE_SEG_TO_CSR
+    spec, modes, rows_col = model.spec.staged()
+
+    def make_request(seed: int, B: int = model.batch) -> Request:
+        r = model.make_request(seed, B)
+        out = []
+        for i, a in enumerate(r.inputs):
+            if modes[i] == STAGE_SEG_TO_CSR:
+                rows = int(r.symbols[model.spec.columns[rows_col[i]].rows_arg])
+                seg = np.asarray(a).reshape(a.shape[0], -1)[:, 0]
+                out.append(np.searchsorted(seg, np.arange(rows + 1), side="left").astype(np.int32))
+            elif modes[i] == STAGE_NARROW_I64:
+                out.append(np.where((a >= 0) & (a <= 0x7FFFFFFF), a, -1).astype(np.int32))
+            else:
+                out.append(a)
+        return Request(out, r.symbols)
+
+    return SynthModel(model.name, spec, model.tables, model.batch, make_request,
+                      model.description + "; requests as staged (ids int32, row ids -> CSR offsets on the host)")
+
+
 class _Builder:
     """Assigns host-input / table slots while columns are added."""
 
