@@ -613,6 +613,36 @@ def test_s2_full_size_closed_form(torch_cuda):
     torch.cuda.empty_cache()
 
 
+def test_output_arena_beyond_4_gib(torch_cuda):
+    """64-bit offsets end to end (the reference's generated code indexes with 32-bit ints): S2 at batch 40 000
+    writes a 4.8 GB concat matrix; rows that lie wholly beyond byte 2^32 of the arena, the row that straddles it and the
+    first rows must all equal the closed-form table rows."""
+    from recom_amd import synth
+    import fcp_oracle as O
+    torch = torch_cuda
+    B = 40_000
+    m = synth.model_s2(batch=B)
+    free, _total = torch.cuda.mem_get_info()
+    if free < m.table_bytes() + (16 << 30):
+        pytest.skip(f"needs {(m.table_bytes() + (16 << 30)) / 2**30:.0f} GiB of HBM, {free / 2**30:.0f} GiB free")
+    tabs = m.torch_tables(torch.device("cuda", 0))
+    req = m.make_request(11)
+    out, _, _ = run_gpu(torch, m.spec, req.inputs, None, req.symbols, tables_dev=tabs)
+    g = out.groups[0]
+    assert g.shape == (B, 30000) and g.numel() * 4 > (1 << 32)
+    straddle = (1 << 32) // (30000 * 4)                         # the row that contains byte 2^32
+    offs = m.spec.column_offsets()
+    for lo, hi in ((0, 64), (straddle - 8, straddle + 8), (B - 512, B)):
+        got = g[lo:hi].cpu().numpy()
+        for k, c in enumerate(m.spec.columns):
+            raw = req.inputs[c.ids_input][lo:hi]
+            ids = O.np_bucketize(c.boundaries, raw) if c.id_source == 2 else raw
+            want = synth.hash_rows(m.tables[c.table_input].seed, ids, c.dim)
+            assert np.array_equal(got[:, offs[k]:offs[k] + c.dim], want), (lo, k)
+    del tabs, out, g
+    torch.cuda.empty_cache()
+
+
 def test_ragged_full_size_closed_form(torch_cuda):
     """BASELINE.json configs[3] at full size: 512 multi-hot columns, vocab 100k (6 GB of
     tables), batch 256, 0..10 ids per row, CSR offsets, sum / mean alternating.  Every pooled
