@@ -276,6 +276,49 @@ def test_random_plans_sharded_then_finalized_equal_the_unsharded_result(oracle, 
                 assert np.all(np.abs(a - b) <= 1e-5 * np.maximum(np.abs(m[:, offs[k]:offs[k] + c.dim]), 1.0)), (seed, g, k)
 
 
+class _RawBlob:
+    def __init__(self, ptr, nbytes):
+        self._p, self._n = ptr, nbytes
+
+    def data_ptr(self):
+        return self._p
+
+    def numel(self):
+        return self._n
+
+    def element_size(self):
+        return 1
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FCP_FUZZ_STAGER_SEEDS", "6"))))
+def test_random_plans_through_the_stager(oracle, seed):
+    """Random plans, requests staged from host tensors with PlanSpec.staged() / fcp_stager_stage_ex (ids narrowed where the
+    plan allows, sorted row ids -> CSR offsets on the host), copy and zero-copy rings: the staged plan on the staged blob
+    equals the oracle on the original request."""
+    import torch
+    from recom_amd.ops import FeatureColumnProcess, RequestStager, concat_inputs
+    rng = np.random.default_rng(7000 + seed)
+    spec, tables, make = random_model(rng, dense_only=False)
+    sspec, modes, rows_col = spec.staged()
+    dev = torch.device("cuda", 0)
+    d_tabs = [torch.from_numpy(t).to(dev) for t in tables]
+    op = FeatureColumnProcess(sspec, 0)
+    st = RequestStager(64 << 20, max(spec.n_host_inputs, 1), max(sum(spec.host_input_ranks), 1), depth=3, n_threads=4,
+                       zero_copy=bool(seed % 2))
+    for trial in range(4):
+        batches = [int(rng.choice([1, 5, 64, 130, 257])) for _ in range(spec.n_groups)]
+        inputs, symbols = make(rng, batches)
+        rows = [int(symbols[spec.columns[k].rows_arg]) if k >= 0 else 0 for k in rows_col]
+        d_ptr, nbytes, offs, shps = st.stage_ex(inputs, modes, rows)
+        out = op(_RawBlob(d_ptr, nbytes), offs, shps, d_tabs, symbols)
+        torch.cuda.synchronize()
+        want, _ = oracle.process_feature_columns(spec.to_dict(), *concat_inputs(inputs), tables, symbols)
+        for g, w in enumerate(want):
+            got = out.groups[g].cpu().numpy()
+            assert got.shape == w.shape and np.array_equal(got, w), (seed, trial, g)
+    st.close()
+
+
 def test_host_threads_share_a_plan_with_changing_shapes(oracle):
     """serve_workers: ten host threads (more than descriptor slots), one plan, one stream each; half of
     them bring a new shape on every request, the other half share three requests (slots hit from
