@@ -276,6 +276,66 @@ def test_random_plans_sharded_then_finalized_equal_the_unsharded_result(oracle, 
                 assert np.all(np.abs(a - b) <= 1e-5 * np.maximum(np.abs(m[:, offs[k]:offs[k] + c.dim]), 1.0)), (seed, g, k)
 
 
+def test_sixteen_concat_groups_with_their_own_batches(oracle):
+    """The most concat groups a plan may have (FCP_MAX_GROUPS_ABI = 16), every group with its own batch size and a mix of
+    one-hot, pooled and passthrough columns: the block -> group search of the kernels and the per-group geometry."""
+    import torch
+    from recom_amd.ops import FeatureColumnProcess, concat_inputs
+    rng = np.random.default_rng(99)
+    cols, ranks, esz, tables, gens = [], [], [], [], []
+
+    def host(rank, e):
+        ranks.append(rank)
+        esz.append(e)
+        return len(ranks) - 1
+
+    for g in range(16):
+        for slot in range(int(rng.integers(1, 5))):
+            dim = 4 * int(rng.integers(1, 20))
+            vocab = int(rng.integers(5, 300))
+            kind = int(rng.integers(0, 3))
+            if kind == 2:
+                i = host(2, 4)
+                gens.append((g, lambda r, B, dim=dim: [r.standard_normal((B, dim)).astype(np.float32)]))
+                cols.append(ColumnSpec(FORM_PASSTHROUGH, dim, 0, COMBINER_NONE, IDS_I32, -1, i, -1, SEG_NONE, 1, ROWS_FROM_INPUT_DIM0, i, None, g, slot))
+                continue
+            tables.append(rng.standard_normal((vocab, dim)).astype(np.float32))
+            t = len(tables) - 1
+            if kind == 0:
+                i = host(1, 8)
+                gens.append((g, lambda r, B, vocab=vocab: [r.integers(0, vocab, B).astype(np.int64)]))
+                cols.append(ColumnSpec(FORM_GATHER, dim, vocab, COMBINER_NONE, IDS_I64, t, i, -1, SEG_NONE, 1, ROWS_FROM_IDS, 0, None, g, slot))
+            else:
+                i, si = host(1, 8), host(2, 8)
+
+                def gen(r, B, vocab=vocab):
+                    lens = r.integers(0, 6, B)
+                    rows = np.repeat(np.arange(B, dtype=np.int64), lens)
+                    return [r.integers(0, vocab, int(lens.sum())).astype(np.int64), np.stack([rows, np.zeros_like(rows)], axis=1)]
+
+                gens.append((g, gen))
+                cols.append(ColumnSpec(FORM_SEGMENT_REDUCE, dim, vocab, COMBINER_MEAN, IDS_I64, t, i, si, SEG_IDS_I64, 2, ROWS_FROM_SYMBOL, g, None, g, slot))
+    spec = PlanSpec(cols, ranks, esz, len(tables), n_groups=16, n_symbols=16)
+    spec.validate()
+    dev = torch.device("cuda", 0)
+    d_tabs = [torch.from_numpy(t).to(dev) for t in tables]
+    op = FeatureColumnProcess(spec, 0)
+    for trial in range(3):
+        batches = [int(rng.choice([1, 3, 17, 64, 200])) for _ in range(16)]
+        inputs = []
+        for g, gen in gens:
+            inputs.extend(gen(rng, batches[g]))
+        symbols = np.asarray(batches, np.int32)
+        blob, offsets, shapes = concat_inputs(inputs)
+        out = op(torch.from_numpy(blob).to(dev), offsets, shapes, d_tabs, symbols)
+        torch.cuda.synchronize()
+        want, _ = oracle.process_feature_columns(spec.to_dict(), blob, offsets, shapes, tables, symbols)
+        assert len(out.groups) == 16
+        for g, w in enumerate(want):
+            got = out.groups[g].cpu().numpy()
+            assert got.shape == w.shape and np.array_equal(got, w), (trial, g)
+
+
 class _RawBlob:
     def __init__(self, ptr, nbytes):
         self._p, self._n = ptr, nbytes
