@@ -378,10 +378,12 @@ int fcp_concat_outputs_scatter(const void *const *inputs, const int32_t *dims,
                                void *stream);
 /* Addons>ConcatOutputs `host_inputs` (concat_outputs_op_gpu.cu.cc:186-216): the n
  * HOST tensors ([prefix, dims[k]], 4-byte elements) are packed into one pinned
- * staging buffer (library-owned, per device), copied H2D with ONE asynchronous
- * copy on `stream` into scratch obtained from `malloc_temp` (the reference's
- * allocate_temp, :189-193) and scattered into columns [col_offsets[k], +dims[k])
- * of `out` [prefix, out_width] — with FCP_LAYOUT_CONCAT `out` is the group's
+ * staging buffer (library-owned, per device) and scattered into columns
+ * [col_offsets[k], +dims[k]) of `out` [prefix, out_width] by one kernel on `stream`
+ * — reading the pinned buffer through its device mapping when the payload is at
+ * most 1 MiB (no copy at all), otherwise after ONE asynchronous H2D copy into
+ * scratch obtained from `malloc_temp` (the reference's allocate_temp, :189-193;
+ * called only then).  With FCP_LAYOUT_CONCAT `out` is the group's
  * matrix inside the FeatureColumnProcess arena, whose FCP_FORM_EXTERNAL slots are
  * exactly these columns.  No stream synchronisation (the reference blocks, :234);
  * the host tensors may be reused when the call returns. */

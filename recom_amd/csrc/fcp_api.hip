@@ -1614,6 +1614,7 @@ int check_scatter_args(const void *const *inputs, const int32_t *dims, const int
 // steady state and never hands pageable memory to an asynchronous copy.
 struct HostStageSlot {
   char *buf = nullptr;
+  char *buf_dev = nullptr; // device mapping of buf
   size_t cap = 0;
   hipEvent_t copied = nullptr;
 };
@@ -1658,8 +1659,6 @@ int fcp_concat_outputs_host(const void *const *host_inputs, const int32_t *dims,
     at[k] = total;
     total += ((size_t)prefix_size * dims[k] * 4 + 15) / 16 * 16;
   }
-  char *d_stage = static_cast<char *>(malloc_temp(malloc_temp_ctx, total));
-  if (!d_stage) return fail(FCP_ERR_ALLOC, "malloc_temp returned NULL");
   HostStageRing *ring = host_stage_ring(device);
   {
     // pack (the reference: one memcpy per input into a std::vector, concat_outputs_op_gpu.cu.cc:195-201) and
@@ -1671,20 +1670,38 @@ int fcp_concat_outputs_host(const void *const *host_inputs, const int32_t *dims,
     if (sl.cap < total) {
       if (sl.buf) HIP_TRY(hipHostFree(sl.buf));
       sl.buf = nullptr;
+      sl.buf_dev = nullptr;
       sl.cap = 0;
       const size_t cap = std::max<size_t>(total, 1 << 16);
-      HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&sl.buf), cap, hipHostMallocDefault));
+      HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&sl.buf), cap, hipHostMallocMapped));
+      HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&sl.buf_dev), sl.buf, 0));
       sl.cap = cap;
     }
     if (!sl.copied) HIP_TRY(hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming));
     for (int32_t k = 0; k < n; ++k) std::memcpy(sl.buf + at[k], host_inputs[k], (size_t)prefix_size * dims[k] * 4);
-    HIP_TRY(hipMemcpyAsync(d_stage, sl.buf, total, hipMemcpyHostToDevice, stream));
-    HIP_TRY(hipEventRecord(sl.copied, stream));
+    // Small payloads (the reference's models E / F: 32 dense features, 64 KB per request): the scatter kernel reads the
+    // pinned slot through its device mapping — no copy, no device staging buffer, one runtime call less per request.
+    // Large ones keep the H2D copy (the scatter would hold its CUs for the length of the PCIe transfer).
+    static const size_t direct_max = [] { // tuning aid: FCP_CONCAT_HOST_DIRECT_MAX=<bytes> (0: always copy)
+      const char *e = std::getenv("FCP_CONCAT_HOST_DIRECT_MAX");
+      return e ? (size_t)std::atoll(e) : (size_t)1 << 20;
+    }();
+    const bool direct = total <= direct_max;
+    const char *src = sl.buf_dev;
+    if (!direct) {
+      char *d_stage = static_cast<char *>(malloc_temp(malloc_temp_ctx, total));
+      if (!d_stage) return fail(FCP_ERR_ALLOC, "malloc_temp returned NULL");
+      HIP_TRY(hipMemcpyAsync(d_stage, sl.buf, total, hipMemcpyHostToDevice, stream));
+      src = d_stage;
+    } else {
+      __atomic_thread_fence(__ATOMIC_SEQ_CST); // the packed bytes are in memory before the launch that reads them is queued
+    }
+    std::vector<const void *> d_in(n);
+    for (int32_t k = 0; k < n; ++k) d_in[k] = src + at[k];
+    const int e = fcp_launch_concat_outputs(d_in.data(), dims, col_offsets, n, prefix_size, out_width, 0, out, stream);
+    if (e) return hip_fail("concat-outputs launch", (hipError_t)e);
+    HIP_TRY(hipEventRecord(sl.copied, stream)); // the slot is free once its last reader (copy or scatter) has run
   }
-  std::vector<const void *> d_in(n);
-  for (int32_t k = 0; k < n; ++k) d_in[k] = d_stage + at[k];
-  const int e = fcp_launch_concat_outputs(d_in.data(), dims, col_offsets, n, prefix_size, out_width, 0, out, stream);
-  if (e) return hip_fail("concat-outputs launch", (hipError_t)e);
   return FCP_OK;
 }
 
