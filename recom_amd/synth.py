@@ -395,8 +395,8 @@ def model_ae(which: str = "E", batch: int = 512, large_rows: int = 1 << 23) -> S
      hash-int (100 rows, dim 8, mean), hash-str (10 000 rows, dim 8, mean),
      sparse hash-str (10 000 rows, dim 8, sum, 1-10 ids/row),
      large sparse hash-str (2^23 rows, dim 32, sum, 1-10 ids/row)}.
-    Hashing / string splitting is CPU id preprocessing upstream of the path
-    (SURVEY.md §8f-3): ids arrive already hashed.  On MI355X the 1 GiB tables the
+    String hashing / splitting is CPU id preprocessing upstream of the path: those ids arrive
+    already hashed; the integer hash columns bring their raw integers and are hashed on the device.  On MI355X the 1 GiB tables the
     reference leaves on the CPU (256 MiB gate, ``fc_optimize_pass.cc:71``) stay on the GPU."""
     counts = {"E": (880, 50, 50, 15, 5), "F": (1000, 90, 100, 7, 3)}[which.upper()]
     b = _Builder()
@@ -408,10 +408,18 @@ def model_ae(which: str = "E", batch: int = 512, large_rows: int = 1 << 23) -> S
         b.columns.append(ColumnSpec(FORM_GATHER, 8, 101, COMBINER_NONE, IDS_F32_BUCKETIZE, t, i, -1, SEG_NONE, 1,
                                     ROWS_FROM_IDS, 0, MICROBENCH_BOUNDARIES, 0, slot))
         slot += 1
-    for rows, n in ((100, counts[1]), (10_000, counts[2])):
-        for _ in range(n):
-            _add_dense(b, rows, 8, slot)
-            slot += 1
+    for _ in range(counts[1]):
+        # categorical_column_with_hash_bucket over an int32 feature (make_categ_hashbucket_int, dlrm.py:55-69): the raw
+        # integers arrive, AsString -> StringToHashBucketFast runs on the device (hash_buckets)
+        t = b.table(100, 8)
+        i = b.host_input(1, 4)
+        b.gens.append(lambda rng, B: [rng.integers(0, 100, size=B).astype(np.int32)])       # make_num_input
+        b.columns.append(ColumnSpec(FORM_GATHER, 8, 100, COMBINER_NONE, IDS_I32, t, i, -1, SEG_NONE, 1, ROWS_FROM_IDS, 0, None, 0,
+                                    slot, hash_buckets=100))
+        slot += 1
+    for _ in range(counts[2]):
+        _add_dense(b, 10_000, 8, slot)                          # string features: hashed on the CPU, bucket ids arrive
+        slot += 1
     for rows, dim, n in ((10_000, 8, counts[3]), (large_rows, 32, counts[4])):
         for _ in range(n):
             t = b.table(rows, dim)
