@@ -24,6 +24,7 @@ python bench.py --workload f > $O/r02_bench_ae_model_f.json 2>/dev/null
 bash scripts/r02_suite.sh product > $O/r02_other_workloads.txt 2>&1
 bash scripts/r02_ragged_indices.sh > $O/r02_ragged_segment_encodings.txt 2>&1
 python3 scripts/shard_rank_share.py 300 2>&1 | grep -v amdgpu.ids > $O/r02_shard_rank_share.txt
+bash scripts/r02_staged.sh > $O/r02_delivered_vs_staged.txt 2>&1
 # kernel traces (single stream: --no-overlap keeps every traced kernel alone on its stream)
 bash scripts/profile_s2.sh refresh2 > $O/profile_s2.log 2>&1
 cp gpurun_out/prof_refresh2/summary.txt $O/r02_s2_kernel_trace_stats.txt 2>/dev/null
