@@ -3,6 +3,7 @@
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--workload s2|dlrm|ragged|shard|shard-col|e|f]
                   [--seg indices|csr|rowids32]   (ragged: how row membership arrives; default SparseTensor indices)
+                  [--max-len N] [--ids uniform|zipf]   (ragged: bag lengths U{0..N}; id distribution)
 
 A *step* is one request: one pass of the fused feature-column path (ids resident
 in HBM -> [batch, sum(dim)] concat output resident in HBM) over one batch of
@@ -228,6 +229,8 @@ def main():
                     help="ragged: how row membership arrives - SparseTensor indices [nnz, 2] int64 (what BASELINE configs[3] "
                          "names and TF graphs deliver; default), CSR offsets or int32 row ids")
     ap.add_argument("--ids", default="uniform", choices=["uniform", "zipf"])
+    ap.add_argument("--max-len", type=int, default=0,
+                    help="ragged: ids per row drawn from U{0..max-len} (default 10); hundreds = multi-hot history features")
     ap.add_argument("--threads", type=int, default=1, help="serve_workers per GPU (reference harness flag)")
     ap.add_argument("--columns", type=int, default=0, help="override the column count (debug only)")
     ap.add_argument("--staged", action="store_true",
@@ -275,8 +278,10 @@ def main():
     elif args.workload in ("e", "f"):
         model = synth.model_ae(args.workload, **({'batch': args.batch} if args.batch else {}))
     else:
-        model = synth.model_ragged(columns=args.columns or 512, seg=args.seg, **({'batch': args.batch} if args.batch else {}),
-                                   **({'vocab': args.vocab} if args.vocab else {}))
+        model = synth.model_ragged(columns=args.columns or 512, seg=args.seg, dist=args.ids,
+                                   **({'batch': args.batch} if args.batch else {}),
+                                   **({'vocab': args.vocab} if args.vocab else {}),
+                                   **({'max_len': args.max_len} if args.max_len else {}))
 
     if args.staged:
         model = synth.staged_model(model)

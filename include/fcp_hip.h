@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define FCP_ABI_VERSION 2 /* 2: id transforms (fcp_column_desc_t::xform_*), external slots, placement gate */
+#define FCP_ABI_VERSION 2 /* 2: id transforms (fcp_column_desc_t::xform_*), external slots, placement gate; additions since keep every v2 struct as it was */
 
 /* ---- status codes (reference: void returns + CubDebugExit/exit(1)) ------ */
 enum {
@@ -71,12 +71,14 @@ enum {
   FCP_FORM_SEGMENT_REDUCE = 2,
   /* ScatterNd(rows, GatherV2(table, ids), [B,dim]): zero-fill, then
    * out[rows[i],:] = W[ids[i],:]   cuda_emitter.cc:296-345, :1332-1442
-   * PRECONDITION: the row ids are ascending (the canonical order of SparseTensor
-   * indices, which is where LookupOptimizer::RewriteGatherScatter takes them from,
-   * lookup_optimizer.cc:324-440) with at most one id per row — the kernels find a
-   * row's id by position, like a segment; the reference's kernel scatters in any
-   * order.  With FCP_FLAG_COUNT_BAD_IDS, positions whose row id is smaller than its
-   * predecessor's are counted as bad ids when the segment-offset pre-pass runs. */
+   * The row ids (seg_kind FCP_SEG_IDS_*) arrive in ANY order, as the reference's
+   * kernel takes them; of several writes to one row the LAST one stays (the order
+   * of a sequential scatter; the reference races inside a 64-id tile), rows
+   * outside [0, B) are dropped (TF's ScatterNd on a GPU) and, with
+   * FCP_FLAG_COUNT_BAD_IDS, counted.  The segment-offset pre-pass builds the
+   * row -> position map for such columns.  With seg_kind FCP_SEG_CSR_I32 the ids
+   * are grouped by row and the last id of a row's range wins.  An id filter
+   * (xform) drops ids before the scatter: the last id it KEEPS wins. */
   FCP_FORM_GATHER_SCATTER = 3,
   /* A tensor of the ConcatInputs blob copied straight into its concat slot
    * (ConcatOutputs `host_inputs`, concat_outputs_op_gpu.cu.cc:186-216) */
@@ -291,7 +293,8 @@ int fcp_plan_create(const fcp_plan_desc_t *desc, fcp_plan_t **plan);
  *   vocab table_input ids_input seg_input seg_kind seg_stride rows_source
  *   rows_arg concat_group concat_slot n_boundaries b0 b1 ..." — version 2 files
  *   ("fcp_plan 2") append "xform_mode xform_n substitute hash_buckets lo0 hi0 lo1
- *   hi1 ..." to every column line.
+ *   hi1 ..." to every column line; version 3 files may end with a stage section
+ *   (fcp_plan_file_stage_info) that tells Addons>ConcatInputs how to pack.
  * `flags`: fcp_plan_desc_t::flags.  FCP_ERR_INVALID_ARGUMENT for a missing or
  * malformed file. */
 int fcp_plan_create_from_file(const char *path, int32_t device, uint32_t flags,
@@ -446,6 +449,30 @@ int fcp_stager_stage_ex(fcp_stager_t *stager, const fcp_host_tensor_t *inputs, i
                         const void **device_blob, int64_t *blob_bytes, const int32_t **offsets,
                         const int32_t **shapes);
 int fcp_stager_destroy(fcp_stager_t *stager);
+
+/* ---- Addons>ConcatInputs in its staged form (host only; replaces concat_inputs_ops.cc:42-77) ---- */
+/* The same packing as fcp_stager_stage_ex — modes[n_inputs] / mode_args[n_inputs] as there, NULL = plain
+ * fcp_concat_inputs — into a caller-owned blob, on the calling thread, without a stager or a device: what the TF
+ * shim's ConcatInputsOp runs (its output 0 is the blob; TensorFlow copies it to the GPU).  The reference's op copies
+ * every input byte for byte (RAGGED, BASELINE configs[3]: 15.7 MB per request); with the modes of the plan file's
+ * stage section the blob carries int32 ids and int32 row offsets (3.1 MB) and the device runs neither the
+ * segment-offset pre-pass nor the in-block search.  The consuming plan is the STAGED plan (PlanSpec.staged()):
+ * narrowed inputs declared 4-byte, converted ones FCP_SEG_CSR_I32 of rank 1. */
+int fcp_concat_inputs_ex_sizes(const fcp_host_tensor_t *inputs, int32_t n_inputs,
+                               const uint8_t *modes, const int64_t *mode_args,
+                               int64_t *blob_bytes, int32_t *rank_sum);
+int fcp_concat_inputs_ex(const fcp_host_tensor_t *inputs, int32_t n_inputs,
+                         const uint8_t *modes, const int64_t *mode_args, void *blob,
+                         int64_t blob_capacity, int32_t *offsets, int32_t *shapes);
+/* The stage section of a column-plan file (version 3, written by `python -m recom_amd.graph --staged`):
+ *   stage N symbols_input K / N lines "mode rows_symbol"
+ * N = number of Addons>ConcatInputs inputs of the rewritten graph (= the plan's host inputs); modes[i] = FCP_STAGE_*
+ * of input i; rows_symbol[i] = for FCP_STAGE_SEG_TO_CSR inputs the index into the `symbols` vector of the row count
+ * (mode_args[i] = symbols[rows_symbol[i]]), else -1; *symbols_input = which ConcatInputs input IS that symbols
+ * vector (int32[n_symbols]; the rewritten graph wires it in as the op's last input), or -1 when nothing is
+ * converted.  *n_inputs = 0: the file has no stage section (a plain plan).  Up to `capacity` entries are written. */
+int fcp_plan_file_stage_info(const char *path, int32_t *n_inputs, uint8_t *modes,
+                             int32_t *rows_symbol, int32_t capacity, int32_t *symbols_input);
 
 /* ---- multi-GPU exchange (no reference counterpart) ---------- */
 /* The ONE collective of the sharded path: an all-to-all partitioned along the batch,

@@ -556,10 +556,20 @@ static int64_t process_column(const orc_plan_t *p, int32_t k, const int8_t *blob
     keep = (uint8_t *)malloc((size_t)nnz + 1);
     for (int64_t i = 0; i < nnz; ++i) keep[i] = (uint8_t)xform_in(c, ids[i]);
   }
+  /* ScatterNd columns (form 3) count differently: of the ids written to one row only the one that stays (the last) is
+   * "an id that reached the output", so only winners outside the vocabulary are counted, plus the row ids outside
+   * [0, rows) that ScatterNd drops — `gbad` remembers which ids are globally bad before the shard mapping. */
+  const int scatter = c->form == ORC_FORM_GATHER_SCATTER;
+  uint8_t *gbad = NULL;
+  if (scatter) {
+    gbad = (uint8_t *)malloc((size_t)nnz + 1);
+    for (int64_t i = 0; i < nnz; ++i) gbad[i] = (uint8_t)(ids[i] < 0 || ids[i] >= c->vocab);
+  }
   /* count globally-bad ids once, then map to the local shard */
   if (sharded) {
-    for (int64_t i = 0; i < nnz; ++i)
-      if (ids[i] < 0 || ids[i] >= c->vocab) ++bad;
+    if (!scatter)
+      for (int64_t i = 0; i < nnz; ++i)
+        if (ids[i] < 0 || ids[i] >= c->vocab) ++bad;
     shard_ids(p, ids, nnz, c->vocab);
   }
   const float *table = tables[c->table_input];
@@ -585,7 +595,19 @@ static int64_t process_column(const orc_plan_t *p, int32_t k, const int8_t *blob
       load_seg(c, blob + offsets[c->seg_input], nnz, seg);
       orc_segment_offsets(seg, nnz, rows, offs);
     }
-    if (keep) { /* compact ids (and row ids) in place; the row offsets follow the survivors */
+    if (keep && scatter && seg) {
+      /* ScatterNd takes its row ids in any order (GatherScatterRows, cuda_emitter.cc:296-345): the filter op in front
+       * of it removes (row id, id) pairs by position, nothing is assumed sorted */
+      int64_t w = 0;
+      for (int64_t i = 0; i < nnz; ++i)
+        if (keep[i]) {
+          ids[w] = ids[i];
+          seg[w] = seg[i];
+          gbad[w] = gbad[i];
+          ++w;
+        }
+      nnz = w;
+    } else if (keep) { /* compact ids (and row ids) in place; the row offsets follow the survivors */
       int64_t w = 0, src = 0;
       for (int64_t r = 0; r < rows; ++r) {
         int64_t lo = offs[r] < 0 ? 0 : offs[r], hi = offs[r + 1] > nnz ? nnz : offs[r + 1];
@@ -595,6 +617,7 @@ static int64_t process_column(const orc_plan_t *p, int32_t k, const int8_t *blob
           if (keep[i]) {
             ids[w] = ids[i];
             if (seg) seg[w] = seg[i];
+            if (gbad) gbad[w] = gbad[i];
             ++w;
           }
         if (hi > src) src = hi;
@@ -609,9 +632,17 @@ static int64_t process_column(const orc_plan_t *p, int32_t k, const int8_t *blob
       if (!sharded) bad += b;
     } else { /* ORC_FORM_GATHER_SCATTER */
       if (seg) {
-        int64_t b = orc_gather_scatter_rows(table, vocab_local, c->dim, ids, seg, nnz, rows, out,
-                                            width);
-        if (!sharded) bad += b;
+        (void)orc_gather_scatter_rows(table, vocab_local, c->dim, ids, seg, nnz, rows, out, width);
+        /* the counter: rows ScatterNd drops, and winners (the last write to a row) outside the vocabulary */
+        int64_t *winner = (int64_t *)malloc(sizeof(int64_t) * (size_t)(rows + 1));
+        for (int64_t r = 0; r < rows; ++r) winner[r] = -1;
+        for (int64_t i = 0; i < nnz; ++i) {
+          if (seg[i] < 0 || seg[i] >= rows) ++bad;
+          else winner[seg[i]] = i;
+        }
+        for (int64_t r = 0; r < rows; ++r)
+          if (winner[r] >= 0 && gbad[winner[r]]) ++bad;
+        free(winner);
       } else {
         /* CSR form of "at most one id per row": last id of the row wins */
         for (int64_t r = 0; r < rows; ++r) {
@@ -619,10 +650,8 @@ static int64_t process_column(const orc_plan_t *p, int32_t k, const int8_t *blob
           memset(o, 0, 4 * (size_t)c->dim);
           if (offs[r + 1] > offs[r]) {
             int64_t id = ids[offs[r + 1] - 1];
-            if (id >= 0 && id < vocab_local)
-              memcpy(o, table + id * c->dim, 4 * (size_t)c->dim);
-            else if (!sharded)
-              ++bad;
+            if (id >= 0 && id < vocab_local) memcpy(o, table + id * c->dim, 4 * (size_t)c->dim);
+            if (gbad[offs[r + 1] - 1]) ++bad;
           }
         }
       }
@@ -631,6 +660,7 @@ static int64_t process_column(const orc_plan_t *p, int32_t k, const int8_t *blob
     free(offs);
   }
   free(keep);
+  free(gbad);
   free(ids);
   return bad;
 }

@@ -431,6 +431,13 @@ def np_process_feature_columns(plan: dict, blob: np.ndarray, offsets, shapes, ta
         else:
             raw = tensor(c["seg_input"], np.int32 if c["seg_kind"] == 1 else np.int64).ravel()
             seg = raw[::max(1, c["seg_stride"])][:ids.size]
+            if c["form"] == 3:
+                # ScatterNd with row ids as delivered, in any order (GatherScatterRows, cuda_emitter.cc:296-345): a
+                # sequential scatter of the ids the filter kept; rows outside [0, rows) are dropped
+                for i in range(ids.size):
+                    if kept[i] and 0 <= seg[i] < rows:
+                        dst[int(seg[i])] = table[ids[i]] if ok[i] else 0.0
+                continue
             offs = np_segment_offsets(seg, rows)
         if c["form"] == 2:
             mean = c["combiner"] == 2
@@ -440,9 +447,10 @@ def np_process_feature_columns(plan: dict, blob: np.ndarray, offsets, shapes, ta
                 acc = table[sel].sum(axis=0) if sel.size else 0.0
                 n_kept = int(kept[lo:hi].sum())                     # dropped ids do not count in a mean
                 dst[s] = acc / n_kept if (mean and n_kept > 0) else acc
-        else:  # form 3: last id of the row wins
+        else:  # form 3 with row offsets: the last id of the row that the filter kept wins
             for s in range(rows):
                 lo, hi = int(offs[s]), int(offs[s + 1])
-                if hi > lo and ok[hi - 1]:
-                    dst[s] = table[ids[hi - 1]]
+                live = np.nonzero(kept[lo:hi])[0]
+                if live.size and ok[lo + live[-1]]:
+                    dst[s] = table[ids[lo + live[-1]]]
     return outs

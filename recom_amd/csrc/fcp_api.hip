@@ -126,6 +126,7 @@ struct fcp_plan {
   std::vector<int32_t> group_width, group_nslots, group_map_off;
   std::vector<int32_t> seg_cols;
   bool seg_search = false;  // blocks search the segment ids themselves; no segment-offset pre-pass
+  bool has_inverse = false; // some ScatterNd column brings its row ids as delivered (any order): inverse map in the pre-pass
   // device arrays are kept in concat order (group-major, ascending concat offset)
   // so that the columns of one output span are contiguous: order[pos] = column,
   // pos_of[column] = pos.
@@ -155,6 +156,7 @@ struct fcp_plan {
   char *d_const = nullptr;
   int32_t *d_seg_cols = nullptr;
   unsigned long long *d_bad = nullptr;
+  float *d_zeros = nullptr;     // 256 zero bytes: the row a skipped id of a bag reads (ld_slot_or_zero)
   unsigned long long *d_stamps = nullptr; // diagnostic builds only (-DFCP_STAMPS)
   std::vector<const void *> bound_tables;
   bool tables_bound = false;
@@ -369,7 +371,7 @@ int compute_dyn_slow(const fcp_plan *p, const int32_t *offsets, const int32_t *s
       d.nnz = 0;
     } else if (c.form == FCP_FORM_PASSTHROUGH) {
       if (n_ids != rows * c.dim) return fail(FCP_ERR_SHAPE_MISMATCH, "passthrough tensor size != rows*dim");
-      if (n_ids / p->vec >= 0xFFFFFFFFLL) return fail(FCP_ERR_UNSUPPORTED, "passthrough tensor exceeds 2^32 slots");
+      if (n_ids / p->vec >= 0xFFFFFFFDLL) return fail(FCP_ERR_UNSUPPORTED, "passthrough tensor exceeds 2^32 slots");
       d.nnz = (int32_t)rows;
     } else if (c.form == FCP_FORM_BATCH_COL_REDUCTION) {
       const int32_t *s = shapes + p->shape_off[c.ids_input];
@@ -536,7 +538,7 @@ int compute_dyn_fast(const fcp_plan *p, const int32_t *offsets, const int32_t *s
     } else if (external) {
       d.nnz = 0;
     } else if (c.form == FCP_FORM_PASSTHROUGH) {
-      if (n_ids != rows * c.dim || n_ids / p->vec >= 0xFFFFFFFFLL) return -1;
+      if (n_ids != rows * c.dim || n_ids / p->vec >= 0xFFFFFFFDLL) return -1;
       d.nnz = (int32_t)rows;
     } else if (c.form == FCP_FORM_BATCH_COL_REDUCTION) {
       const int32_t *sh = shapes + p->shape_off[c.ids_input];
@@ -633,6 +635,7 @@ void destroy_device(fcp_plan *p) {
   if (p->d_const) (void)hipFree(p->d_const);
   if (p->d_seg_cols) (void)hipFree(p->d_seg_cols);
   if (p->d_bad) (void)hipFree(p->d_bad);
+  if (p->d_zeros) (void)hipFree(p->d_zeros);
   if (p->d_stamps) (void)hipFree(p->d_stamps);
 }
 
@@ -755,6 +758,8 @@ int init_device(fcp_plan *p) {
     HIP_TRY(hipMalloc(&p->d_seg_cols, seg_pos.size() * sizeof(int32_t)));
     HIP_TRY(hipMemcpy(p->d_seg_cols, seg_pos.data(), seg_pos.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   }
+  HIP_TRY(hipMalloc(&p->d_zeros, 256));
+  HIP_TRY(hipMemset(p->d_zeros, 0, 256));
   if (p->desc.flags & FCP_FLAG_COUNT_BAD_IDS) {
     HIP_TRY(hipMalloc(&p->d_bad, sizeof(unsigned long long)));
     HIP_TRY(hipMemset(p->d_bad, 0, sizeof(unsigned long long)));
@@ -971,6 +976,7 @@ void fill_launch(const fcp_plan *p, const DynSlot &s, int kind, const void *blob
   L->span_list = p->d_span_list;
   L->cols = p->d_cols;
   L->xforms = p->d_xforms;
+  L->zeros = p->d_zeros;
   L->dyn = s.d_dyn;
   L->blob = static_cast<const char *>(blob);
   L->arena = static_cast<char *>(arena);
@@ -1114,8 +1120,15 @@ int fcp_plan_create(const fcp_plan_desc_t *desc, fcp_plan_t **out) {
   // ComputeSegmentOffsets pre-pass as a second, dependent launch.  Row-sharded plans keep the
   // pre-pass: fcp_shard_finalize needs the row lengths as CSR.  FCP_SEG_PREPASS=1: tuning aid.
   p->seg_search = desc->shard_world <= 1 && std::getenv("FCP_SEG_PREPASS") == nullptr;
-  for (const HostColumn &hc : p->cols)
+  for (const HostColumn &hc : p->cols) {
     if (hc.d.seg_kind != FCP_SEG_NONE && hc.d.seg_stride > 0xffff) p->seg_search = false; // stride rides in 16 flag bits
+    // ScatterNd columns take their row ids in any order (cuda_emitter.cc:296-345): nothing to search, the pre-pass
+    // builds the row -> position map
+    if (hc.d.form == FCP_FORM_GATHER_SCATTER && hc.d.seg_kind != FCP_SEG_CSR_I32) {
+      p->has_inverse = true;
+      p->seg_search = false;
+    }
+  }
   // The kernels address table rows by a 32-bit slot offset (row * dim / vec): one
   // table (or one shard of it) may hold up to 2^32 slots = 64 GB at vec 4.  (The
   // reference's int arithmetic stops at 2^31 elements = 8 GB, cuda_emitter.cc:270-271.)
@@ -1123,7 +1136,7 @@ int fcp_plan_create(const fcp_plan_desc_t *desc, fcp_plan_t **out) {
     const fcp_column_desc_t &c = p->cols[k].d;
     if (c.form == FCP_FORM_PASSTHROUGH || c.form == FCP_FORM_BATCH_COL_REDUCTION || c.form == FCP_FORM_EXTERNAL) continue;
     const int64_t local_vocab = (c.vocab - desc->shard_rank + desc->shard_world - 1) / desc->shard_world;
-    if (local_vocab * (c.dim / p->vec) >= 0xFFFFFFFFLL) {
+    if (local_vocab * (c.dim / p->vec) >= 0xFFFFFFFDLL) { // (the three largest values are the kernels' sentinels)
       delete p;
       return fail(FCP_ERR_UNSUPPORTED, "column " + std::to_string(k) + ": table shard exceeds 2^32 slots");
     }
@@ -1218,9 +1231,22 @@ int fcp_plan_create(const fcp_plan_desc_t *desc, fcp_plan_t **out) {
   return FCP_OK;
 }
 
-int fcp_plan_create_from_file(const char *path, int32_t device, uint32_t flags, fcp_plan_t **out) {
-  if (!path || !out) return fail(FCP_ERR_INVALID_ARGUMENT, "null argument");
-  *out = nullptr;
+namespace {
+// A column-plan file in memory (see include/fcp_hip.h for the format).
+struct ParsedPlanFile {
+  fcp_plan_desc_t d;
+  std::vector<int32_t> ranks, esz;
+  std::vector<fcp_column_desc_t> cols;
+  std::vector<std::vector<float>> bnd;
+  std::vector<std::vector<int64_t>> xlo, xhi;
+  // "stage" section (version 3): what Addons>ConcatInputs does to each of ITS inputs while packing
+  std::vector<uint8_t> stage_modes;
+  std::vector<int32_t> stage_rows_symbol;
+  int32_t stage_symbols_input = -1;
+  bool has_stage = false;
+};
+
+int parse_plan_file(const char *path, ParsedPlanFile &P) {
   std::FILE *f = std::fopen(path, "r");
   if (!f) return fail(FCP_ERR_INVALID_ARGUMENT, std::string("cannot open column plan ") + path);
   struct Closer {
@@ -1230,9 +1256,9 @@ int fcp_plan_create_from_file(const char *path, int32_t device, uint32_t flags, 
   const std::string where = std::string("column plan ") + path + ": ";
   char tag[32], t2[32], t3[32];
   int version = 0, n_host = 0, n_cols = 0;
-  fcp_plan_desc_t d;
+  fcp_plan_desc_t &d = P.d;
   std::memset(&d, 0, sizeof(d));
-  if (std::fscanf(f, "%31s %d", tag, &version) != 2 || std::strcmp(tag, "fcp_plan") || (version != 1 && version != 2))
+  if (std::fscanf(f, "%31s %d", tag, &version) != 2 || std::strcmp(tag, "fcp_plan") || version < 1 || version > 3)
     return fail(FCP_ERR_INVALID_ARGUMENT, where + "bad header");
   if (std::fscanf(f, "%31s %d", tag, &d.layout) != 2 || std::strcmp(tag, "layout"))
     return fail(FCP_ERR_INVALID_ARGUMENT, where + "expected 'layout'");
@@ -1241,16 +1267,18 @@ int fcp_plan_create_from_file(const char *path, int32_t device, uint32_t flags, 
     return fail(FCP_ERR_INVALID_ARGUMENT, where + "expected 'groups G symbols S device_inputs D'");
   if (std::fscanf(f, "%31s %d", tag, &n_host) != 2 || std::strcmp(tag, "host_inputs") || n_host < 0 || n_host > (1 << 24))
     return fail(FCP_ERR_INVALID_ARGUMENT, where + "expected 'host_inputs N'");
-  std::vector<int32_t> ranks(n_host), esz(n_host);
+  P.ranks.resize(n_host);
+  P.esz.resize(n_host);
   for (int i = 0; i < n_host; ++i)
-    if (std::fscanf(f, "%d %d", &ranks[i], &esz[i]) != 2) return fail(FCP_ERR_INVALID_ARGUMENT, where + "truncated host input list");
+    if (std::fscanf(f, "%d %d", &P.ranks[i], &P.esz[i]) != 2) return fail(FCP_ERR_INVALID_ARGUMENT, where + "truncated host input list");
   if (std::fscanf(f, "%31s %d", tag, &n_cols) != 2 || std::strcmp(tag, "columns") || n_cols < 0 || n_cols > (1 << 24))
     return fail(FCP_ERR_INVALID_ARGUMENT, where + "expected 'columns C'");
-  std::vector<fcp_column_desc_t> cols(n_cols);
-  std::vector<std::vector<float>> bnd(n_cols);
-  std::vector<std::vector<int64_t>> xlo(n_cols), xhi(n_cols);
+  P.cols.resize(n_cols);
+  P.bnd.resize(n_cols);
+  P.xlo.resize(n_cols);
+  P.xhi.resize(n_cols);
   for (int k = 0; k < n_cols; ++k) {
-    fcp_column_desc_t &c = cols[k];
+    fcp_column_desc_t &c = P.cols[k];
     std::memset(&c, 0, sizeof(c));
     long long vocab = 0;
     if (std::fscanf(f, "%d %d %d %d %lld %d %d %d %d %d %d %d %d %d %d", &c.form, &c.combiner, &c.dim, &c.id_source, &vocab,
@@ -1259,39 +1287,91 @@ int fcp_plan_create_from_file(const char *path, int32_t device, uint32_t flags, 
         c.n_boundaries < 0 || c.n_boundaries > (1 << 24))
       return fail(FCP_ERR_INVALID_ARGUMENT, where + "truncated or malformed column " + std::to_string(k));
     c.vocab = vocab;
-    bnd[k].resize(c.n_boundaries);
+    P.bnd[k].resize(c.n_boundaries);
     for (int b = 0; b < c.n_boundaries; ++b)
-      if (std::fscanf(f, "%f", &bnd[k][b]) != 1) return fail(FCP_ERR_INVALID_ARGUMENT, where + "truncated boundary list");
-    c.boundaries = c.n_boundaries ? bnd[k].data() : nullptr;
+      if (std::fscanf(f, "%f", &P.bnd[k][b]) != 1) return fail(FCP_ERR_INVALID_ARGUMENT, where + "truncated boundary list");
+    c.boundaries = c.n_boundaries ? P.bnd[k].data() : nullptr;
     if (version >= 2) { // id transform: mode, number of intervals, substitute, (lo, hi) pairs
       long long sub = 0, hb = 0;
       if (std::fscanf(f, "%d %d %lld %lld", &c.xform_mode, &c.xform_n, &sub, &hb) != 4 || c.xform_n < 0 || c.xform_n > (1 << 20))
         return fail(FCP_ERR_INVALID_ARGUMENT, where + "truncated or malformed id transform of column " + std::to_string(k));
       c.xform_substitute = sub;
       c.hash_buckets = hb;
-      xlo[k].resize(c.xform_n);
-      xhi[k].resize(c.xform_n);
+      P.xlo[k].resize(c.xform_n);
+      P.xhi[k].resize(c.xform_n);
       for (int i = 0; i < c.xform_n; ++i) {
         long long lo = 0, hi = 0;
         if (std::fscanf(f, "%lld %lld", &lo, &hi) != 2) return fail(FCP_ERR_INVALID_ARGUMENT, where + "truncated interval list");
-        xlo[k][i] = lo;
-        xhi[k][i] = hi;
+        P.xlo[k][i] = lo;
+        P.xhi[k][i] = hi;
       }
-      c.xform_lo = c.xform_n ? xlo[k].data() : nullptr;
-      c.xform_hi = c.xform_n ? xhi[k].data() : nullptr;
+      c.xform_lo = c.xform_n ? P.xlo[k].data() : nullptr;
+      c.xform_hi = c.xform_n ? P.xhi[k].data() : nullptr;
+    }
+  }
+  if (version >= 3) { // optional: "stage N symbols_input K" + N x "mode rows_symbol"
+    int n_stage = 0, sym_in = -1;
+    const int got = std::fscanf(f, "%31s %d %31s %d", tag, &n_stage, t2, &sym_in);
+    if (got == 4) {
+      if (std::strcmp(tag, "stage") || std::strcmp(t2, "symbols_input") || n_stage < 0 || n_stage > (1 << 24) || sym_in < -1 || sym_in >= n_stage)
+        return fail(FCP_ERR_INVALID_ARGUMENT, where + "expected 'stage N symbols_input K'");
+      P.stage_modes.resize(n_stage);
+      P.stage_rows_symbol.resize(n_stage);
+      for (int i = 0; i < n_stage; ++i) {
+        int mode = 0, sym = -1;
+        if (std::fscanf(f, "%d %d", &mode, &sym) != 2 || mode < FCP_STAGE_COPY || mode > FCP_STAGE_SEG_TO_CSR || sym < -1 ||
+            sym >= d.n_symbols || (mode == FCP_STAGE_SEG_TO_CSR && (sym < 0 || sym_in < 0)))
+          return fail(FCP_ERR_INVALID_ARGUMENT, where + "malformed stage entry " + std::to_string(i));
+        P.stage_modes[i] = (uint8_t)mode;
+        P.stage_rows_symbol[i] = sym;
+      }
+      P.stage_symbols_input = sym_in;
+      P.has_stage = true;
+    } else if (got != EOF && got != 0) {
+      return fail(FCP_ERR_INVALID_ARGUMENT, where + "malformed stage section");
     }
   }
   d.abi_version = FCP_ABI_VERSION;
   d.n_columns = n_cols;
-  d.columns = cols.data();
+  d.columns = P.cols.data();
   d.n_host_inputs = n_host;
-  d.host_input_ranks = ranks.data();
-  d.host_input_elem_sizes = esz.data();
-  d.device = device;
+  d.host_input_ranks = P.ranks.data();
+  d.host_input_elem_sizes = P.esz.data();
   d.shard_rank = 0;
   d.shard_world = 1;
-  d.flags = flags;
-  return fcp_plan_create(&d, out);
+  return FCP_OK;
+}
+} // namespace
+
+int fcp_plan_create_from_file(const char *path, int32_t device, uint32_t flags, fcp_plan_t **out) {
+  if (!path || !out) return fail(FCP_ERR_INVALID_ARGUMENT, "null argument");
+  *out = nullptr;
+  ParsedPlanFile P;
+  const int rc = parse_plan_file(path, P);
+  if (rc) return rc;
+  if (P.has_stage && (int32_t)P.stage_modes.size() != P.d.n_host_inputs)
+    return fail(FCP_ERR_INVALID_ARGUMENT, std::string("column plan ") + path + ": the stage section lists " +
+                                              std::to_string(P.stage_modes.size()) + " inputs, the plan has " +
+                                              std::to_string(P.d.n_host_inputs) + " host inputs");
+  P.d.device = device;
+  P.d.flags = flags;
+  return fcp_plan_create(&P.d, out);
+}
+
+int fcp_plan_file_stage_info(const char *path, int32_t *n_inputs, uint8_t *modes, int32_t *rows_symbol, int32_t capacity,
+                             int32_t *symbols_input) {
+  if (!path) return fail(FCP_ERR_INVALID_ARGUMENT, "null argument");
+  ParsedPlanFile P;
+  const int rc = parse_plan_file(path, P);
+  if (rc) return rc;
+  const int32_t n = P.has_stage ? (int32_t)P.stage_modes.size() : 0;
+  if (n_inputs) *n_inputs = n;
+  if (symbols_input) *symbols_input = P.has_stage ? P.stage_symbols_input : -1;
+  for (int32_t i = 0; i < n && i < capacity; ++i) {
+    if (modes) modes[i] = P.stage_modes[i];
+    if (rows_symbol) rows_symbol[i] = P.stage_rows_symbol[i];
+  }
+  return FCP_OK;
 }
 
 int fcp_plan_counts(const fcp_plan_t *p, int32_t *n_columns, int32_t *n_groups, int32_t *n_host_inputs,
@@ -1529,7 +1609,12 @@ int fcp_process_feature_columns(fcp_plan_t *p, const fcp_process_args_t *a, fcp_
     S.blob = L.blob;
     S.arena = L.arena;
     S.bad_ids = p->d_bad;
+    S.xforms = p->d_xforms;
+    S.skip_inverse = 0;
     S.csr_arena_off = m.csr_arena_off;
+    // any-order scatter columns build their inverse map with atomic max: their scratch starts from zero
+    if (p->has_inverse && m.arena_bytes > m.csr_arena_off)
+      HIP_TRY(hipMemsetAsync(static_cast<char *>(arena) + m.csr_arena_off, 0, (size_t)(m.arena_bytes - m.csr_arena_off), stream));
     const int e = fcp_launch_segment_offsets(S, (int)p->seg_cols.size(), m.max_seg_nnz, stream);
     if (e) return hip_fail("segment-offsets launch", (hipError_t)e);
   }
@@ -1762,6 +1847,8 @@ int fcp_shard_finalize(fcp_plan_t *p, const fcp_process_args_t *a, int32_t group
     S.blob = L.blob;
     S.arena = static_cast<char *>(scratch);
     S.bad_ids = nullptr; // the partial pass has counted already
+    S.xforms = p->d_xforms;
+    S.skip_inverse = 1;  // only the row lengths of mean columns are wanted here
     S.csr_arena_off = 0;
     const int e = fcp_launch_segment_offsets(S, (int)p->seg_cols.size(), m.max_seg_nnz, stream);
     if (e) return hip_fail("segment-offsets launch", (hipError_t)e);
@@ -1870,7 +1957,14 @@ int fcp_stager_create_ex(int32_t device, int64_t capacity_bytes, int32_t max_inp
 int fcp_stager_stage_narrow(fcp_stager_t *s, const fcp_host_tensor_t *inputs, int32_t n, const uint8_t *narrow,
                             void *stream, const void **device_blob, int64_t *blob_bytes, const int32_t **offsets,
                             const int32_t **shapes) {
-  return fcp_stager_stage_ex(s, inputs, n, narrow, nullptr, stream, device_blob, blob_bytes, offsets, shapes);
+  // the flags are booleans: anything non-zero means "narrow" (FCP_STAGE_NARROW_I64), never another mode
+  std::vector<uint8_t> modes;
+  if (narrow && n > 0) {
+    modes.resize(n);
+    for (int32_t i = 0; i < n; ++i) modes[i] = narrow[i] ? FCP_STAGE_NARROW_I64 : FCP_STAGE_COPY;
+  }
+  return fcp_stager_stage_ex(s, inputs, n, modes.empty() ? nullptr : modes.data(), nullptr, stream, device_blob, blob_bytes, offsets,
+                             shapes);
 }
 
 namespace {
@@ -1892,13 +1986,76 @@ void seg_to_csr(const void *seg, int elem_size, int64_t stride, int64_t nnz, int
     }
   }
 }
+
+// Layout of the staged blob: byte offsets (byte_off[0..n]), the op's `offsets` and `shapes` outputs — exactly
+// ConcatInputsOp::Compute (concat_inputs_ops.cc:52-66), except that a narrowed int64 input occupies 4 bytes per element
+// and a converted row-id input is int32[rows + 1] (one dim).  max_rank_sum < 0: no limit.
+int stage_layout(const fcp_host_tensor_t *inputs, int32_t n, const uint8_t *modes, const int64_t *mode_args, int64_t capacity,
+                 int32_t max_rank_sum, int64_t *byte_off, int32_t *offsets, int32_t *shapes, int32_t *rank_sum_out) {
+  int64_t size = 0;
+  int32_t rank_sum = 0;
+  for (int32_t i = 0; i < n; ++i) {
+    const fcp_host_tensor_t &t = inputs[i];
+    if (t.rank < 0 || t.elem_size <= 0 || (t.rank > 0 && !t.dims)) return fail(FCP_ERR_INVALID_ARGUMENT, "bad host tensor");
+    const int mode = modes ? modes[i] : FCP_STAGE_COPY;
+    if (mode > FCP_STAGE_SEG_TO_CSR) return fail(FCP_ERR_INVALID_ARGUMENT, "unknown staging mode");
+    if (mode == FCP_STAGE_NARROW_I64 && t.elem_size != 8) return fail(FCP_ERR_INVALID_ARGUMENT, "only 8-byte inputs can be narrowed");
+    if (max_rank_sum >= 0 && rank_sum + t.rank > max_rank_sum) return fail(FCP_ERR_INVALID_ARGUMENT, "more dims than the stager was created for");
+    int64_t ne = 1;
+    for (int32_t j = 0; j < t.rank; ++j) {
+      if (t.dims[j] < 0) return fail(FCP_ERR_INVALID_ARGUMENT, "negative dimension");
+      ne *= t.dims[j];
+    }
+    byte_off[i] = size;
+    if (offsets) offsets[i] = (int32_t)size;
+    if (mode == FCP_STAGE_SEG_TO_CSR) {
+      // sorted row ids [nnz] or SparseTensor indices [nnz, k] -> int32 offsets[rows + 1]: one dim in the shapes
+      if ((t.elem_size != 4 && t.elem_size != 8) || t.rank < 1 || t.rank > 2 || !mode_args || mode_args[i] < 0 ||
+          mode_args[i] >= 0x7fffffff || (t.rank == 2 && t.dims[1] < 1))
+        return fail(FCP_ERR_INVALID_ARGUMENT, "segment-id input to convert: int32 / int64 [nnz] or [nnz, k], with its number of rows");
+      if (shapes) shapes[rank_sum] = (int32_t)(mode_args[i] + 1);
+      rank_sum += 1;
+      size += (mode_args[i] + 1) * 4;
+    } else {
+      for (int32_t j = 0; j < t.rank; ++j)
+        if (shapes) shapes[rank_sum + j] = (int32_t)t.dims[j];
+      rank_sum += t.rank;
+      size += ne * (mode == FCP_STAGE_NARROW_I64 ? 4 : t.elem_size);
+    }
+    if (capacity >= 0 && size > capacity) return fail(FCP_ERR_INVALID_ARGUMENT, "request larger than the blob / stager capacity");
+    // The reference keeps offsets in int32 (:52-60); refuse what it would overflow.
+    if (size > 0x7fffffff) return fail(FCP_ERR_UNSUPPORTED, "blob larger than 2^31 bytes (int32 offsets)");
+    if (ne && !t.data) return fail(FCP_ERR_INVALID_ARGUMENT, "null tensor data");
+  }
+  byte_off[n] = size;
+  if (rank_sum_out) *rank_sum_out = rank_sum;
+  return FCP_OK;
+}
+
+// One input into its place in the staged blob (`nbytes` = its bytes there).
+void stage_pack_one(const fcp_host_tensor_t &t, int mode, int64_t mode_arg, char *dst, int64_t nbytes) {
+  if (nbytes <= 0) return;
+  if (mode == FCP_STAGE_SEG_TO_CSR) {
+    seg_to_csr(t.data, t.elem_size, t.rank == 2 ? t.dims[1] : 1, t.dims[0], mode_arg, reinterpret_cast<int32_t *>(dst));
+  } else if (mode == FCP_STAGE_NARROW_I64) {
+    // int64 -> int32; values that do not fit are not valid ids / rows anyway: -1 (reads as zeros)
+    const int64_t *src = static_cast<const int64_t *>(t.data);
+    int32_t *d32 = reinterpret_cast<int32_t *>(dst);
+    const int64_t ne = nbytes / 4;
+    for (int64_t k = 0; k < ne; ++k) {
+      const int64_t v = src[k];
+      d32[k] = (v >= 0 && v <= 0x7fffffff) ? (int32_t)v : -1;
+    }
+  } else {
+    std::memcpy(dst, t.data, (size_t)nbytes);
+  }
+}
 } // namespace
 
 int fcp_stager_stage_ex(fcp_stager_t *s, const fcp_host_tensor_t *inputs, int32_t n, const uint8_t *modes,
                         const int64_t *mode_args, void *stream, const void **device_blob, int64_t *blob_bytes,
                         const int32_t **offsets, const int32_t **shapes) {
   if (!s || n < 0 || (n > 0 && !inputs)) return fail(FCP_ERR_INVALID_ARGUMENT, "null argument");
-  const uint8_t *narrow = modes; // FCP_STAGE_NARROW_I64 == 1: the flags of fcp_stager_stage_narrow are modes
   if (n > s->max_inputs) return fail(FCP_ERR_INVALID_ARGUMENT, "more inputs than the stager was created for");
   DeviceGuard guard;
   int rc = guard.enter(s->device);
@@ -1920,40 +2077,10 @@ int fcp_stager_stage_ex(fcp_stager_t *s, const fcp_host_tensor_t *inputs, int32_
   } else if (hipEventQuery(sl.copied) != hipSuccess) {
     HIP_TRY(hipEventSynchronize(sl.copied));
   }
-  // sizes / offsets / shapes: exactly ConcatInputsOp::Compute (concat_inputs_ops.cc:52-66),
-  // except that a narrowed int64 input occupies 4 bytes per element
-  int64_t size = 0;
-  int32_t rank_sum = 0;
-  for (int32_t i = 0; i < n; ++i) {
-    const fcp_host_tensor_t &t = inputs[i];
-    if (t.rank < 0 || t.elem_size <= 0 || (t.rank > 0 && !t.dims)) return fail(FCP_ERR_INVALID_ARGUMENT, "bad host tensor");
-    const int mode = modes ? modes[i] : FCP_STAGE_COPY;
-    if (mode > FCP_STAGE_SEG_TO_CSR) return fail(FCP_ERR_INVALID_ARGUMENT, "unknown staging mode");
-    if (mode == FCP_STAGE_NARROW_I64 && t.elem_size != 8) return fail(FCP_ERR_INVALID_ARGUMENT, "only 8-byte inputs can be narrowed");
-    if (rank_sum + t.rank > s->max_rank_sum) return fail(FCP_ERR_INVALID_ARGUMENT, "more dims than the stager was created for");
-    int64_t ne = 1;
-    for (int32_t j = 0; j < t.rank; ++j) {
-      if (t.dims[j] < 0) return fail(FCP_ERR_INVALID_ARGUMENT, "negative dimension");
-      ne *= t.dims[j];
-    }
-    s->byte_off[i] = size;
-    sl.offsets[i] = (int32_t)size;
-    if (mode == FCP_STAGE_SEG_TO_CSR) {
-      // sorted row ids [nnz] or SparseTensor indices [nnz, k] -> int32 offsets[rows + 1]: one dim in the shapes
-      if ((t.elem_size != 4 && t.elem_size != 8) || t.rank < 1 || t.rank > 2 || !mode_args || mode_args[i] < 0 ||
-          mode_args[i] >= 0x7fffffff || (t.rank == 2 && t.dims[1] < 1))
-        return fail(FCP_ERR_INVALID_ARGUMENT, "segment-id input to convert: int32 / int64 [nnz] or [nnz, k], with its number of rows");
-      sl.shapes[rank_sum++] = (int32_t)(mode_args[i] + 1);
-      size += (mode_args[i] + 1) * 4;
-    } else {
-      for (int32_t j = 0; j < t.rank; ++j) sl.shapes[rank_sum++] = (int32_t)t.dims[j];
-      size += ne * (mode == FCP_STAGE_NARROW_I64 ? 4 : t.elem_size);
-    }
-    if (size > s->capacity) return fail(FCP_ERR_INVALID_ARGUMENT, "request larger than the stager capacity");
-    if (ne && !t.data) return fail(FCP_ERR_INVALID_ARGUMENT, "null tensor data");
-  }
-  s->byte_off[n] = size;
-  // pack: contiguous ranges of inputs per chunk, ~equal bytes
+  // sizes / offsets / shapes (stage_layout), then the pack: contiguous ranges of inputs per chunk, ~equal bytes
+  int rc2 = stage_layout(inputs, n, modes, mode_args, s->capacity, s->max_rank_sum, s->byte_off.data(), sl.offsets, sl.shapes, nullptr);
+  if (rc2) return rc2;
+  const int64_t size = s->byte_off[n];
   const int chunks = (int)std::min<int64_t>(std::max<int64_t>(1, size / (64 << 10)), 4 * s->n_threads);
   const int64_t *bo = s->byte_off.data();
   char *dst = sl.h_blob;
@@ -1962,25 +2089,8 @@ int fcp_stager_stage_ex(fcp_stager_t *s, const fcp_host_tensor_t *inputs, int32_
     // inputs whose start offset falls in [b0, b1)
     int lo = (int)(std::lower_bound(bo, bo + n, b0) - bo);
     const int hi = (int)(std::lower_bound(bo, bo + n, b1) - bo);
-    for (; lo < hi; ++lo) {
-      if (bo[lo + 1] <= bo[lo]) continue;
-      if (modes && modes[lo] == FCP_STAGE_SEG_TO_CSR) {
-        const fcp_host_tensor_t &t = inputs[lo];
-        seg_to_csr(t.data, t.elem_size, t.rank == 2 ? t.dims[1] : 1, t.dims[0], mode_args[lo],
-                   reinterpret_cast<int32_t *>(dst + bo[lo]));
-      } else if (narrow && narrow[lo] == FCP_STAGE_NARROW_I64) {
-        // int64 -> int32; values that do not fit are not valid ids / rows anyway: -1 (reads as zeros)
-        const int64_t *src = static_cast<const int64_t *>(inputs[lo].data);
-        int32_t *d32 = reinterpret_cast<int32_t *>(dst + bo[lo]);
-        const int64_t ne = (bo[lo + 1] - bo[lo]) / 4;
-        for (int64_t k = 0; k < ne; ++k) {
-          const int64_t v = src[k];
-          d32[k] = (v >= 0 && v <= 0x7fffffff) ? (int32_t)v : -1;
-        }
-      } else {
-        std::memcpy(dst + bo[lo], inputs[lo].data, (size_t)(bo[lo + 1] - bo[lo]));
-      }
-    }
+    for (; lo < hi; ++lo)
+      stage_pack_one(inputs[lo], modes ? modes[lo] : FCP_STAGE_COPY, mode_args ? mode_args[lo] : 0, dst + bo[lo], bo[lo + 1] - bo[lo]);
   });
   if (!s->zero_copy) {
     // the device twin is free once the work that read its previous contents has run
@@ -1996,6 +2106,32 @@ int fcp_stager_stage_ex(fcp_stager_t *s, const fcp_host_tensor_t *inputs, int32_
   if (blob_bytes) *blob_bytes = size;
   if (offsets) *offsets = sl.offsets;
   if (shapes) *shapes = sl.shapes;
+  return FCP_OK;
+}
+
+// ---- Addons>ConcatInputs, staged form (host only; no stager, no device) --------------------------------
+int fcp_concat_inputs_ex_sizes(const fcp_host_tensor_t *inputs, int32_t n, const uint8_t *modes, const int64_t *mode_args,
+                               int64_t *blob_bytes, int32_t *rank_sum) {
+  if (n < 0 || (n > 0 && !inputs)) return fail(FCP_ERR_INVALID_ARGUMENT, "null inputs");
+  std::vector<int64_t> bo((size_t)n + 1);
+  int32_t ranks = 0;
+  const int rc = stage_layout(inputs, n, modes, mode_args, -1, -1, bo.data(), nullptr, nullptr, &ranks);
+  if (rc) return rc;
+  if (blob_bytes) *blob_bytes = bo[n];
+  if (rank_sum) *rank_sum = ranks;
+  return FCP_OK;
+}
+
+int fcp_concat_inputs_ex(const fcp_host_tensor_t *inputs, int32_t n, const uint8_t *modes, const int64_t *mode_args, void *blob,
+                         int64_t blob_capacity, int32_t *offsets, int32_t *shapes) {
+  if (n < 0 || (n > 0 && (!inputs || !offsets || !shapes))) return fail(FCP_ERR_INVALID_ARGUMENT, "null argument");
+  std::vector<int64_t> bo((size_t)n + 1);
+  const int rc = stage_layout(inputs, n, modes, mode_args, blob_capacity, -1, bo.data(), offsets, shapes, nullptr);
+  if (rc) return rc;
+  if (bo[n] > 0 && !blob) return fail(FCP_ERR_INVALID_ARGUMENT, "blob too small");
+  for (int32_t i = 0; i < n; ++i)
+    stage_pack_one(inputs[i], modes ? modes[i] : FCP_STAGE_COPY, mode_args ? mode_args[i] : 0, static_cast<char *>(blob) + bo[i],
+                   bo[i + 1] - bo[i]);
   return FCP_OK;
 }
 

@@ -101,6 +101,7 @@ struct FcpLaunch {
   unsigned long long *stamps;  // diagnostic builds (-DFCP_STAMPS) only: 8 timestamps per block
   FcpGroupLaunch groups[FCP_MAX_GROUPS];
   const FcpXform *xforms;      // per column (concat order), or null: no column has an id transform
+  const float *zeros;          // 256 zero bytes (plan-owned): what a skipped id of a bag reads
 };
 
 // Segment-offset pre-pass (ComputeSegmentOffsets, cuda_emitter.cc:768-818)
@@ -112,6 +113,8 @@ struct FcpSegLaunch {
   char *arena;
   int64_t csr_arena_off;     // byte offset of the CSR scratch in the arena
   unsigned long long *bad_ids; // nullable: FCP_FLAG_COUNT_BAD_IDS also counts unsorted segment ids here
+  const FcpXform *xforms;    // per column, or null (id filter of any-order scatter columns)
+  int32_t skip_inverse;      // 1: leave the any-order scatter columns alone (fcp_shard_finalize only wants row lengths)
 };
 
 // ---- launchers implemented in fcp_kernels.hip --------------------------------

@@ -36,6 +36,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "../../include/fcp_hip.h"
 #include "fcp_internal.h"
 
@@ -197,9 +199,10 @@ __device__ __forceinline__ int bucketize_arith(int n, float b0, float inv, float
   return r + 1;
 }
 
-constexpr uint32_t kNoRow = 0xFFFFFFFFu;    // "this id contributes nothing" (out of range, or another rank's row)
+constexpr uint32_t kNoRow = 0xFFFFFFFFu;    // "this id contributes nothing" (another rank's row, or past the end of a bag)
 constexpr uint32_t kFiltered = 0xFFFFFFFEu; // dropped by the column's id filter: contributes nothing AND does not count in a mean
-__device__ __forceinline__ bool is_row(uint32_t off) { return off < kFiltered; }
+constexpr uint32_t kBadRow = 0xFFFFFFFDu;   // an id outside [0, vocab): reads as zeros (and can be told from kNoRow when it is counted late)
+__device__ __forceinline__ bool is_row(uint32_t off) { return off < kBadRow; }
 
 // One column of the span, staged in LDS by the block: the static record VERBATIM (its six 16-byte words go
 // from the load straight to LDS: nothing is re-packed, few registers live) plus what the request's dynamic
@@ -226,6 +229,7 @@ struct Hot {
   const char *blob;
   char *arena;
   unsigned long long *bad_ids;
+  const float *zeros;
   int64_t csr_arena_off;
   int32_t n_groups, rank, world, seg_search, store_through;
   FcpGroupLaunch g0;
@@ -240,6 +244,7 @@ __device__ __forceinline__ Hot load_hot(const FcpLaunch &L) {
   h.blob = L.blob;
   h.arena = L.arena;
   h.bad_ids = L.bad_ids;
+  h.zeros = L.zeros;
   h.csr_arena_off = L.csr_arena_off;
   h.n_groups = L.n_groups;
   h.rank = L.shard_rank;
@@ -248,7 +253,7 @@ __device__ __forceinline__ Hot load_hot(const FcpLaunch &L) {
   h.store_through = L.store_through;
   h.g0 = L.groups[0];
   asm volatile("" : "+s"(h.slot_map), "+s"(h.span_list), "+s"(h.cols), "+s"(h.dyn), "+s"(h.blob), "+s"(h.arena),
-               "+s"(h.bad_ids), "+s"(h.csr_arena_off));
+               "+s"(h.bad_ids), "+s"(h.csr_arena_off), "+s"(h.zeros));
   asm volatile("" : "+s"(h.n_groups), "+s"(h.rank), "+s"(h.world), "+s"(h.seg_search), "+s"(h.store_through), "+s"(h.g0.rows), "+s"(h.g0.nslots),
                "+s"(h.g0.nsp8), "+s"(h.g0.block_begin), "+s"(h.g0.slot_map_off), "+s"(h.g0.span_list_off), "+s"(h.g0.nlist));
   return h;
@@ -419,7 +424,7 @@ __device__ __forceinline__ uint32_t slot_offset_from_raw(const LdsCol &c, const 
     if (id == kDroppedId) return kFiltered;
   }
   bad = (uint64_t)id >= (uint64_t)c.vocab;
-  if (bad) return kNoRow;
+  if (bad) return kBadRow;
   if (SHARDED) {
     const int64_t q = id < 0x7fffffffLL ? (int64_t)((uint32_t)id / (uint32_t)world) : id / world;
     if (id - q * world != rank) return kNoRow;
@@ -712,6 +717,9 @@ __global__ void __launch_bounds__(FCP_BLOCK_THREADS) fcp_dense_kernel(const FcpL
 #if !defined(FCP_WALK)
 #define FCP_WALK 8
 #endif
+#if !defined(FCP_WALK_LONG) // the same in the rounds after the first (rows whose bags exceed the wave's tile)
+#define FCP_WALK_LONG 6 // (8 would need 66 VGPRs in the loop around the rounds)
+#endif
 
 // ---------------------------------------------------------------------------
 // Ragged kernel: any mix of column forms (dynamic shapes: multi-hot bags of
@@ -798,113 +806,6 @@ __device__ __forceinline__ int seg_lower_bound(const char *seg, bool is64, int s
   return a;
 }
 
-// Phase 2 of the ragged bodies for one output slot: walk the bag of (column C, row b) — its staged table
-// slot offsets sit at s_ids[poff .. poff+pcnt), or poff < 0: fetch the ids from the blob — with 8 (then 4)
-// table reads in flight, add in id order, divide for mean, store.
-template <int V, bool SHARDED>
-__device__ __forceinline__ void ragged_emit(const Hot &H, const LdsCol &C, const FcpXform *xf, int q, int b, int plo, int pcnt, int poff,
-                                            const uint32_t *s_ids, int rank, int world) {
-  const unsigned form = FCP_F_FORM(C.flags);
-  const int dim = C.dim;
-  const int e = q * V - C.out_off;
-  const float *tb = C.table + e;
-  VF<V> acc = vzero<V>();
-  int dropped = 0; // ids the column's filter removed: they do not count in a mean
-  if (form == FCP_FORM_EXTERNAL) return; // somebody else's slot (ConcatOutputs host input): never written here
-
-  if (form == FCP_FORM_PASSTHROUGH) {
-    if (rank == 0) acc = ld_blob_f32<V>(C.ids + 4 * ((int64_t)b * dim + e)); // table-free: shard rank 0
-  } else if (form == FCP_FORM_BATCH_COL_REDUCTION) {
-    // cuda_emitter.cc:1231-1236: r ascending, sequential fp32 adds
-    const int inner = rank == 0 ? C.inner : 0;
-    for (int rr = 0; rr < inner; ++rr) {
-      const VF<V> x = ld_blob_f32<V>(C.ids + 4 * (((int64_t)b * inner + rr) * dim + e));
-#pragma unroll
-      for (int t = 0; t < V; ++t) acc.v[t] = acc.v[t] + x.v[t];
-    }
-  } else if (poff < 0) {
-    // slow path (long or unstaged bags): one id at a time from global memory
-#pragma unroll 1
-    for (int i = 0; i < pcnt; ++i) {
-      bool bad;
-      const uint32_t off = fetch_slot_offset<V, SHARDED>(C, xf, plo + i, nullptr, rank, world, bad);
-      if (bad && e == 0 && H.bad_ids) atomicAdd(H.bad_ids, 1ull);
-      dropped += off == kFiltered;
-      if (is_row(off)) {
-        const VF<V> w = ld_slot<V>(tb, off);
-        if (form == FCP_FORM_SEGMENT_REDUCE) {
-#pragma unroll
-          for (int t = 0; t < V; ++t) acc.v[t] = acc.v[t] + w.v[t];
-        } else {
-          acc = w;
-        }
-      }
-    }
-  } else if (form != FCP_FORM_SEGMENT_REDUCE) {
-    // GATHER / GATHER_SCATTER: a pure copy of one row (rows without ids stay zero)
-    if (pcnt > 0) {
-      const uint32_t off = s_ids[poff];
-      if (is_row(off)) acc = ld_slot<V>(tb, off);
-    }
-  } else {
-    // Adding the zero vector of a skipped id is exact (acc is never -0.0: it
-    // starts at +0.0), so the adds need no predicate.
-    if ((C.xform & 3u) == FCP_XFORM_FILTER && FCP_F_COMBINER(C.flags) == FCP_COMBINER_MEAN) {
-      // ids the filter dropped do not count in the mean: a separate pass over the staged offsets, only for
-      // such columns (counting inside the walk cost every column 12 registers)
-#pragma unroll 1
-      for (int k = 0; k < pcnt; ++k) dropped += s_ids[poff + k] == kFiltered;
-    }
-    int i = 0;
-    while (pcnt - i > 4) {
-      uint32_t off[FCP_WALK];
-      VF<V> w[FCP_WALK];
-#pragma unroll
-      for (int k = 0; k < FCP_WALK; ++k) off[k] = (i + k < pcnt) ? s_ids[poff + i + k] : kNoRow;
-#pragma unroll
-      for (int k = 0; k < FCP_WALK; ++k) {
-        w[k] = vzero<V>();
-        if (is_row(off[k])) w[k] = ld_slot<V>(tb, off[k]);
-      }
-#pragma unroll
-      for (int k = 0; k < FCP_WALK; ++k)
-#pragma unroll
-        for (int t = 0; t < V; ++t) acc.v[t] = acc.v[t] + w[k].v[t]; // id order
-      i += FCP_WALK;
-    }
-    if (pcnt - i > 0) {
-      uint32_t off[4];
-      VF<V> w[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) off[k] = (i + k < pcnt) ? s_ids[poff + i + k] : kNoRow;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        w[k] = vzero<V>();
-        if (is_row(off[k])) w[k] = ld_slot<V>(tb, off[k]);
-      }
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-#pragma unroll
-        for (int t = 0; t < V; ++t) acc.v[t] = acc.v[t] + w[k].v[t];
-    }
-  }
-  if (form == FCP_FORM_SEGMENT_REDUCE && !SHARDED && FCP_F_COMBINER(C.flags) == FCP_COMBINER_MEAN && pcnt > dropped) {
-    const float fc = (float)(pcnt - dropped); // sum / count of the ids that reached the lookup
-#pragma unroll
-    for (int t = 0; t < V; ++t) acc.v[t] = acc.v[t] / fc;
-  }
-  st_out<V>(reinterpret_cast<float *>(H.arena + C.out_base) + e + (int64_t)b * C.out_stride, acc, H.store_through != 0);
-}
-
-struct RaggedLds {
-  static constexpr int RB = FCP_WAVES_PER_BLOCK; // rows per block, one per wave
-  static constexpr int CAPW = 384;               // staged slot offsets per wave (row)
-  LdsCol col[FCP_WAVE];
-  uint32_t ids[RB][CAPW];
-  uint8_t owner[RB][CAPW];                       // staged id slot -> owner lane (= column within the span)
-  int32_t bound[FCP_WAVE * (FCP_WAVES_PER_BLOCK + 1)]; // seg_search: row offsets r0..r0+RB of every column
-};
-
 // LDS accesses of ONE wave execute in program order; the compiler only has to keep that order.
 __device__ __forceinline__ void wave_lds_order() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -912,10 +813,80 @@ __device__ __forceinline__ void wave_lds_order() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Where slot offset `off` of a bag is read from: the table row, or — an id that contributes nothing (out of
+// range, another rank's row, dropped by the filter, past the end of the bag) — the plan's zero line: one hot
+// cache line instead of a predicated read, so the walk is branch-free (no exec-mask bookkeeping around every
+// read); adding its +0.0 is exact (acc is never -0.0: it starts at +0.0).
+template <int V> __device__ __forceinline__ VF<V> ld_slot_or_zero(const float *tb, const float *zeros, uint32_t off) {
+  typedef typename VecType<V>::T T;
+  const FCP_GLOBAL T *g = is_row(off) ? as_global(reinterpret_cast<const T *>(tb)) + off : as_global(reinterpret_cast<const T *>(zeros));
+#if defined(FCP_ABLATE) && FCP_ABLATE == 4 // timing-only build 4: no table reads at all
+  g = as_global(reinterpret_cast<const T *>(zeros));
+#endif
+  const T t = *g;
+  VF<V> r;
+  __builtin_memcpy(&r, &t, sizeof(T));
+  return r;
+}
+
+// The walk of one bag slice for one output slot: the n table slot offsets staged at s[0..n) are added to `acc`
+// in id order (sequential fp32 adds: the order of TF-CPU and of the oracle), FCP_WALK table reads in flight
+// per lane.  EVERY lane issues its first FCP_WALK reads at once, whatever its bag length; further batches
+// only while some bag of the wave goes on.  (Round 2 walked "8, then 4" behind per-lane conditions: lanes with
+// up to 4 ids sat out the first pass and issued their reads only after it.)
+template <int V, int N>
+__device__ __forceinline__ void bag_walk_batch(const float *tb, const float *zeros, const uint32_t *s, int base, int n, VF<V> &acc) {
+  uint32_t off[N];
+  VF<V> w[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k) off[k] = base + k < n ? s[base + k] : kNoRow;
+#pragma unroll
+  for (int k = 0; k < N; ++k) w[k] = ld_slot_or_zero<V>(tb, zeros, off[k]);
+#pragma unroll
+  for (int k = 0; k < N; ++k)
+#pragma unroll
+    for (int t = 0; t < V; ++t) acc.v[t] = acc.v[t] + w[k].v[t]; // id order
+}
+
+template <int V, int WALK>
+__device__ __forceinline__ void bag_walk_sum(const float *tb, const float *zeros, const uint32_t *s, int n, VF<V> &acc) {
+  bag_walk_batch<V, WALK>(tb, zeros, s, 0, n, acc);
+  for (int base = WALK; __any(n > base);) { // wave-uniform trip count
+    if (WALK > 4 && !__any(n > base + 4)) { // a short tail (bags of 9..12 ids): half a batch
+      bag_walk_batch<V, 4>(tb, zeros, s, base, n, acc);
+      base += 4;
+    } else {
+      bag_walk_batch<V, WALK>(tb, zeros, s, base, n, acc);
+      base += WALK;
+    }
+  }
+}
+
+// Inclusive prefix sum over the 64 lanes of a wave with data-parallel-primitive moves: four shifts inside the rows of
+// 16 lanes, then the row totals broadcast to the rows after them (row_bcast:15 / row_bcast:31) — six VALU instructions
+// and no LDS traffic, where six __shfl_up steps cost six ds_bpermute round trips plus their index arithmetic.
+__device__ __forceinline__ int wave_inclusive_sum(int x) {
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true); // row_shr:1 (lanes without a source read 0)
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true); // row_shr:2
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true); // row_shr:4
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true); // row_shr:8
+  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false); // row_bcast:15 -> rows 1 and 3
+  x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false); // row_bcast:31 -> rows 2 and 3
+  return x;
+}
+
+struct RaggedLds {
+  static constexpr int RB = FCP_WAVES_PER_BLOCK; // rows per block, one per wave
+  static constexpr int CAPW = 384;               // staged slot offsets per wave (row) and round
+  LdsCol col[FCP_WAVE];
+  uint32_t ids[RB][CAPW];
+  uint8_t owner[RB][CAPW];                       // staged id slot -> owner lane (= column within the span)
+  int32_t bound[FCP_WAVE * (FCP_WAVES_PER_BLOCK + 1)]; // seg_search: row offsets r0..r0+RB of every column
+};
+
 template <int V, bool SHARDED>
 __device__ __forceinline__ void ragged_body(const FcpLaunch &L, int bid, char *smem) {
   constexpr int RB = RaggedLds::RB, CAPW = RaggedLds::CAPW;
-  constexpr int LONG_BAG = 64;
   RaggedLds &S = *reinterpret_cast<RaggedLds *>(smem);
   LdsCol *s_col = S.col;
 
@@ -958,7 +929,7 @@ __device__ __forceinline__ void ragged_body(const FcpLaunch &L, int bid, char *s
   const int b = B.row_blk + wave;
   if (b >= B.rows) return; // wave-uniform; no block barrier follows
 
-  // ---- phase 1a (wave): range of (column lane, row b), slices of the wave's offset tile ---------------
+  // ---- phase 1a (wave): range [lo, lo + cnt) of (column lane, row b) ------------------------------------
   int lo = 0, cnt = 0;
   if (lane < B.ncols) {
     const unsigned form = FCP_F_FORM(s_col[lane].flags);
@@ -968,7 +939,14 @@ __device__ __forceinline__ void ragged_body(const FcpLaunch &L, int bid, char *s
     } else if (form == FCP_FORM_SEGMENT_REDUCE || form == FCP_FORM_GATHER_SCATTER) {
       const int nnz = s_col[lane].nnz;
       int o0, o1;
-      if (H.seg_search && FCP_F_SEGKIND(s_col[lane].flags) != FCP_SEG_CSR_I32) {
+      const unsigned sk = FCP_F_SEGKIND(s_col[lane].flags);
+      if (form == FCP_FORM_GATHER_SCATTER && sk != FCP_SEG_CSR_I32) {
+        // ScatterNd with its row ids as delivered, in ANY order (GatherScatterRows, cuda_emitter.cc:296-345):
+        // the pre-pass left "1 + position of the last id written to row b" (0: none) in the column's scratch
+        const int t = as_global(s_col[lane].csr)[b];
+        o0 = t - 1;
+        o1 = t > 0 ? t : -1;
+      } else if (H.seg_search && sk != FCP_SEG_CSR_I32) {
         o0 = S.bound[lane * (RB + 1) + wave];
         o1 = S.bound[lane * (RB + 1) + wave + 1];
       } else {
@@ -979,43 +957,55 @@ __device__ __forceinline__ void ragged_body(const FcpLaunch &L, int bid, char *s
       lo = min(max(o0, 0), nnz);
       const int hi = min(max(o1, lo), nnz);
       cnt = hi - lo;
-      if (form == FCP_FORM_GATHER_SCATTER && cnt > 0) { // the last id of the row wins
+      // GATHER_SCATTER: the last id of the row wins; a row with several ids (duplicate row ids) is walked
+      // whole only when an id filter may drop its last ones
+      if (form == FCP_FORM_GATHER_SCATTER && cnt > 1 && (s_col[lane].xform & 3u) != FCP_XFORM_FILTER) {
         lo = hi - 1;
         cnt = 1;
       }
     }
   }
-  const int want = cnt <= LONG_BAG ? cnt : 0;
-  int incl = want;
-#pragma unroll
-  for (int d = 1; d < FCP_WAVE; d <<= 1) {
-    const int up = __shfl_up(incl, d);
-    if (lane >= d) incl += up;
-  }
-  const int total = __shfl(incl, FCP_WAVE - 1);
-  const int offx = incl - want;
-  const bool staged = want > 0 && offx + want <= CAPW;
-  const int sx = staged ? offx : -1;
+
+  // my slot: which column (its facts are re-read from LDS where they are used: few registers live across the staging)
+  const int j = (int)(my_col - B.first_col);
+  const bool live = q < B.nslots;
+  VF<V> acc = vzero<V>();
+  int dropped = 0; // ids the column's filter removed: they do not count in a mean
+
   uint8_t *ow = S.owner[wave];
   uint32_t *wi = S.ids[wave];
-  if (staged)
-    for (int i = 0; i < want; ++i) ow[offx + i] = (uint8_t)lane; // fire-and-forget LDS writes
+  // ---- phase 1b (wave): slices of the wave's offset tile — a prefix sum over the lanes' bag lengths; a bag gets
+  // what is left of the tile after the bags of the lanes before it (`take` of its `cnt` ids; all of them unless the
+  // row holds more than CAPW ids, see "long bags" below)
+  const int want = min(cnt, CAPW);
+  const int incl = wave_inclusive_sum(want);
+  const int offx = incl - want;
+  const int take = max(min(want, CAPW - offx), 0);
+  const int limit = min(__shfl(incl, FCP_WAVE - 1), CAPW);
+  if (take <= 16)
+    for (int i = 0; i < take; ++i) ow[offx + i] = (uint8_t)lane; // fire-and-forget LDS writes
+  for (unsigned long long big = __ballot(take > 16); big; big &= big - 1) { // long slices are marked by the whole wave
+    const int p = __ffsll((long long)big) - 1;
+    const int po = __shfl(offx, p), pt = __shfl(take, p);
+    for (int i = lane; i < pt; i += FCP_WAVE) ow[po + i] = (uint8_t)p;
+  }
   wave_lds_order();
 #if defined(FCP_STAMPS)
   const unsigned long long t_scan = __builtin_amdgcn_s_memrealtime();
 #endif
 
-  // ---- phase 1b (wave): one lane per staged id -> table slot offset in the wave's tile -----------------
-  const int limit = min(total, CAPW);
+  // ---- one lane per staged id -> table slot offset in the wave's tile ---------------------------------------
   for (int base = 0; base < limit; base += FCP_WAVE) { // uniform trip count: the cross-lane reads need every lane
     const int k = base + lane;
     const int p = k < limit ? (int)ow[k] : 0;
-    const int px = __shfl(sx, p), pc = __shfl(cnt, p), pl = __shfl(lo, p);
-    if (k < limit && px >= 0 && px <= k && k < px + pc) { // entries of unstaged bags fail this test
+    const int px = __shfl(offx, p), pl = __shfl(lo, p);
+    if (k < limit) {
       bool bad;
       wi[k] = fetch_slot_offset<V, SHARDED>(s_col[p], L.xforms + B.first_col + p, pl + (k - px), nullptr, rank, world, bad);
-      // a column that straddles two spans is staged by two blocks: the one holding its first slot counts
-      if (bad && H.bad_ids && s_col[p].out_off >= B.q0 * V) atomicAdd(H.bad_ids, 1ull);
+      // a column that straddles two spans is staged by two blocks: the one holding its first slot counts.  (ScatterNd
+      // columns count where the row's winner is known: an id that a later write replaces never reached the output.)
+      if (bad && H.bad_ids && s_col[p].out_off >= B.q0 * V && FCP_F_FORM(s_col[p].flags) != FCP_FORM_GATHER_SCATTER)
+        atomicAdd(H.bad_ids, 1ull);
     }
   }
   wave_lds_order();
@@ -1023,11 +1013,99 @@ __device__ __forceinline__ void ragged_body(const FcpLaunch &L, int bid, char *s
   const unsigned long long t_ids = __builtin_amdgcn_s_memrealtime();
 #endif
 
-  // ---- phase 2 (wave): range and slice of my column come from its owner lane ----------------------------
-  const int j = (int)(my_col - B.first_col);
-  const int plo = __shfl(lo, j), pcnt = __shfl(cnt, j), poff = __shfl(sx, j);
-  if (q >= B.nslots) return;
-  ragged_emit<V, SHARDED>(H, s_col[j], L.xforms + B.first_col + j, q, b, plo, pcnt, poff, wi, rank, world);
+  // ---- phase 2 (wave): the owning lanes consume their column's slice ------------------------------------------
+  // (a slot's column facts are re-read from LDS where they are used: few registers live across the staging)
+  auto consume = [&](auto walk_width, const uint32_t *s, int n) __attribute__((always_inline)) {
+    constexpr int WALK = decltype(walk_width)::value;
+    const unsigned form = FCP_F_FORM(s_col[j].flags);
+    const float *tb = s_col[j].table + (q * V - s_col[j].out_off);
+    if (form == FCP_FORM_SEGMENT_REDUCE) {
+      if ((s_col[j].xform & 3u) == FCP_XFORM_FILTER && FCP_F_COMBINER(s_col[j].flags) == FCP_COMBINER_MEAN) {
+        // ids the filter dropped do not count in the mean: a separate pass over the staged offsets, only for
+        // such columns (counting inside the walk cost every column 12 registers)
+#pragma unroll 1
+        for (int k = 0; k < n; ++k) dropped += s[k] == kFiltered;
+      }
+      bag_walk_sum<V, WALK>(tb, H.zeros, s, n, acc);
+    } else if (form == FCP_FORM_GATHER || form == FCP_FORM_GATHER_SCATTER) {
+      // a pure copy of one row (rows without ids stay zero); of several ids the last one the filter kept wins
+      // (TF: ScatterNd after the filter op; the oracle compacts first)
+      int k = n - 1;
+      while (k > 0 && s[k] == kFiltered) --k;
+      const uint32_t off = s[k];
+      if (off != kFiltered) {
+        acc = vzero<V>();
+        if (is_row(off)) acc = ld_slot<V>(tb, off);
+        // the winner of a ScatterNd row is out of the vocabulary: counted once, by the lane of the column's first slot
+        if (form == FCP_FORM_GATHER_SCATTER && off == kBadRow && H.bad_ids && q * V == s_col[j].out_off) atomicAdd(H.bad_ids, 1ull);
+      }
+    }
+  };
+  {
+    const int ptake = __shfl(take, j), poff = __shfl(offx, j);
+    if (live && ptake > 0) consume(std::integral_constant<int, FCP_WALK>(), wi + poff, ptake);
+  }
+
+  // ---- long bags (rare: a row whose bags hold more than CAPW ids, e.g. multi-hot history features of hundreds
+  // of ids): what the tile could not take in goes through it in further rounds.  Every bag that has ids left gets
+  // an EQUAL share of the tile per round (a power of two: position -> (bag, index) is a shift and a mask; no
+  // prefix sum), so all the wave's lanes keep walking their own bags at once, and the owning lanes go on adding
+  // to their running sums — the order of the adds is the order of the ids, however they are chunked.  (Round 2
+  // walked such bags from global memory, one dependent id read -> row read pair at a time.)
+  for (int done = take;;) {
+    const int rem = cnt - done;
+    const unsigned long long act = __ballot(rem > 0);
+    if (!act) break; // wave-uniform
+    const int nact = __popcll(act);
+    const int sh_log2 = 31 - __clz(CAPW / nact); // nact <= 64: at least 4 ids per bag and round
+    const int share = 1 << sh_log2;
+    const int my_rank = __popcll(act & ((1ull << lane) - 1ull));
+    const int tk = rem > 0 ? min(rem, share) : 0;
+    wave_lds_order(); // the tile's previous contents have been consumed
+    if (rem > 0) ow[my_rank] = (uint8_t)lane;
+    wave_lds_order();
+    const int limit = nact << sh_log2;
+    const int from = lo + done;
+    for (int base = 0; base < limit; base += FCP_WAVE) { // uniform trip count
+      const int k = base + lane;
+      const int p = k < limit ? (int)ow[k >> sh_log2] : 0;
+      const int i = k & (share - 1);
+      const int ptk = __shfl(tk, p), pf = __shfl(from, p);
+      if (k < limit && i < ptk) {
+        bool bad;
+        wi[k] = fetch_slot_offset<V, SHARDED>(s_col[p], L.xforms + B.first_col + p, pf + i, nullptr, rank, world, bad);
+        if (bad && H.bad_ids && s_col[p].out_off >= B.q0 * V && FCP_F_FORM(s_col[p].flags) != FCP_FORM_GATHER_SCATTER)
+          atomicAdd(H.bad_ids, 1ull);
+      }
+    }
+    wave_lds_order();
+    const int ptake = __shfl(tk, j), prank = __shfl(my_rank, j);
+    if (live && ptake > 0) consume(std::integral_constant<int, FCP_WALK_LONG>(), wi + (prank << sh_log2), ptake);
+    done += tk;
+  }
+  const int pcnt = __shfl(cnt, j);
+  const LdsCol &C = s_col[j];
+  const unsigned form = FCP_F_FORM(C.flags);
+  if (!live || form == FCP_FORM_EXTERNAL) return; // EXTERNAL: somebody else's slot (ConcatOutputs host input), never written here
+
+  const int dim = C.dim;
+  const int e = q * V - C.out_off;
+  if (form == FCP_FORM_PASSTHROUGH) {
+    if (rank == 0) acc = ld_blob_f32<V>(C.ids + 4 * ((int64_t)b * dim + e)); // table-free: shard rank 0
+  } else if (form == FCP_FORM_BATCH_COL_REDUCTION) {
+    // cuda_emitter.cc:1231-1236: r ascending, sequential fp32 adds
+    const int inner = rank == 0 ? C.inner : 0;
+    for (int rr = 0; rr < inner; ++rr) {
+      const VF<V> x = ld_blob_f32<V>(C.ids + 4 * (((int64_t)b * inner + rr) * dim + e));
+#pragma unroll
+      for (int t = 0; t < V; ++t) acc.v[t] = acc.v[t] + x.v[t];
+    }
+  } else if (form == FCP_FORM_SEGMENT_REDUCE && !SHARDED && FCP_F_COMBINER(C.flags) == FCP_COMBINER_MEAN && pcnt > dropped) {
+    const float fc = (float)(pcnt - dropped); // sum / count of the ids that reached the lookup
+#pragma unroll
+    for (int t = 0; t < V; ++t) acc.v[t] = acc.v[t] / fc;
+  }
+  st_out<V>(reinterpret_cast<float *>(H.arena + C.out_base) + e + (int64_t)b * C.out_stride, acc, H.store_through != 0);
 #if defined(FCP_STAMPS)
   if (L.stamps && tid == 0) { // wave 0 = first row of the block
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1044,7 +1122,7 @@ __device__ __forceinline__ void ragged_body(const FcpLaunch &L, int bid, char *s
 }
 
 template <int V, bool SHARDED>
-__global__ void __launch_bounds__(FCP_BLOCK_THREADS) fcp_ragged_kernel(const FcpLaunch L) {
+__global__ void __launch_bounds__(FCP_BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) fcp_ragged_kernel(const FcpLaunch L) {
   __shared__ __attribute__((aligned(16))) char smem[sizeof(RaggedLds)];
   ragged_body<V, SHARDED>(L, blockIdx.x, smem);
 }
@@ -1064,7 +1142,7 @@ struct FcpHybridLaunch {
 };
 
 template <int V, int R, bool SHARDED>
-__global__ void __launch_bounds__(FCP_BLOCK_THREADS) fcp_hybrid_kernel(const FcpHybridLaunch H) {
+__global__ void __launch_bounds__(FCP_BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) fcp_hybrid_kernel(const FcpHybridLaunch H) {
   constexpr size_t kSmem = sizeof(RaggedLds) > sizeof(DenseLds<R>) ? sizeof(RaggedLds) : sizeof(DenseLds<R>);
   __shared__ __attribute__((aligned(16))) char smem[kSmem];
   const int bid = blockIdx.x;
@@ -1111,6 +1189,40 @@ __global__ void __launch_bounds__(FCP_BLOCK_THREADS) fcp_segment_offsets_kernel(
   const char *seg = L.blob + cd.seg_off;
   const int lane = threadIdx.x & (FCP_WAVE - 1);
   int32_t *csr = reinterpret_cast<int32_t *>(L.arena + L.csr_arena_off) + cd.csr_base;
+  if (FCP_F_FORM(cs.flags) == FCP_FORM_GATHER_SCATTER) {
+    // ScatterNd row ids arrive in ANY order (GatherScatterRows, cuda_emitter.cc:296-345, scatters whatever it is
+    // given): instead of row offsets the column's scratch (zeroed before this launch) receives the inverse map
+    // inv[row] = 1 + the LAST position whose row id is `row` (atomic max: "the last write wins", the order of a
+    // sequential scatter and of the oracle); ids the column's filter drops never reach the scatter.
+    if (L.skip_inverse) return;
+    const bool filtered = (cs.xform & 3u) == FCP_XFORM_FILTER;
+    LdsCol lc;
+    if (filtered) {
+      static_cast<FcpColStatic &>(lc) = cs;
+      lc.ids = L.blob + cd.ids_off;
+      lc.csr = nullptr;
+      lc.out_base = 0;
+      lc.out_stride = 0;
+      lc.nnz = nnz;
+      lc.bnd_off = -1; // boundaries, if any, are read from global memory
+    }
+#pragma unroll 1
+    for (int r = 0; r < FCP_SEG_ROUNDS; ++r) {
+      const int64_t i = base + r * FCP_BLOCK_THREADS + threadIdx.x;
+      if (i >= nnz) break;
+      if (filtered) { // the filter op sits in front of the scatter: what it drops never gets there
+        bool bad;
+        if (fetch_slot_offset<1, false>(lc, L.xforms + c, i, nullptr, 0, 1, bad) == kFiltered) continue;
+      }
+      const int64_t row = load_seg(seg, segkind, stride, i);
+      if (row < 0 || row >= rows) { // TF's ScatterNd on a GPU drops such rows
+        if (L.bad_ids) atomicAdd(L.bad_ids, 1ull);
+        continue;
+      }
+      atomicMax(csr + row, (int32_t)(i + 1));
+    }
+    return;
+  }
   int64_t cur[FCP_SEG_ROUNDS], first_prev[FCP_SEG_ROUNDS];
 #pragma unroll
   for (int r = 0; r < FCP_SEG_ROUNDS; ++r) {

@@ -29,26 +29,67 @@ from .plan import (FORM_BATCH_COL_REDUCTION, FORM_PASSTHROUGH, IDS_F32_BUCKETIZE
 # ----------------------------------------------------------------------------
 # Addons>ConcatInputs (CPU op)
 # ----------------------------------------------------------------------------
-def concat_inputs(inputs: Sequence[np.ndarray]):
-    """Pack N host tensors into ``(output:int8[sum bytes], offsets:int32[N],
-    shapes:int32[sum rank])`` — bit-exact with ``ConcatInputsOp::Compute``."""
-    L = _lib.load()
+def _host_tensors(inputs):
     arrs = [np.require(np.asarray(a), requirements="C") for a in inputs]  # keeps rank-0
-    n = len(arrs)
     dims_keep = [np.asarray(a.shape, np.int64) for a in arrs]
-    tens = (_lib.HostTensor * max(n, 1))()
+    tens = (_lib.HostTensor * max(len(arrs), 1))()
     for i, a in enumerate(arrs):
         tens[i] = _lib.HostTensor(a.ctypes.data, a.dtype.itemsize, a.ndim,
                                   dims_keep[i].ctypes.data_as(C.POINTER(C.c_int64)))
+    return arrs, dims_keep, tens
+
+
+def concat_inputs(inputs: Sequence[np.ndarray], stage=None):
+    """Pack N host tensors into ``(output:int8[sum bytes], offsets:int32[N],
+    shapes:int32[sum rank])`` — bit-exact with ``ConcatInputsOp::Compute``.
+
+    ``stage`` (a :class:`recom_amd.plan.StageInfo`, the stage section of the plan file): the staged form —
+    int64 ids packed as int32, the sorted row ids / SparseTensor indices of pooled columns as int32 row offsets
+    (``fcp_concat_inputs_ex``); the consuming plan is the staged plan."""
+    L = _lib.load()
+    arrs, dims_keep, tens = _host_tensors(inputs)
+    n = len(arrs)
     nbytes = C.c_int64(0)
     rank_sum = C.c_int32(0)
-    _lib.check(L.fcp_concat_inputs_sizes(tens, n, C.byref(nbytes), C.byref(rank_sum)), "ConcatInputs")
+    if stage is None:
+        _lib.check(L.fcp_concat_inputs_sizes(tens, n, C.byref(nbytes), C.byref(rank_sum)), "ConcatInputs")
+    else:
+        if len(stage.modes) != n:
+            raise ValueError(f"ConcatInputs: the plan's stage section lists {len(stage.modes)} inputs, the op got {n}")
+        modes = np.asarray(stage.modes, np.uint8)
+        args = np.asarray(stage.mode_args(arrs), np.int64)
+        _lib.check(L.fcp_concat_inputs_ex_sizes(tens, n, modes.ctypes.data, args.ctypes.data, C.byref(nbytes),
+                                                C.byref(rank_sum)), "ConcatInputs")
     blob = np.empty(nbytes.value, np.int8)
     offsets = np.empty(n, np.int32)
     shapes = np.empty(rank_sum.value, np.int32)
-    _lib.check(L.fcp_concat_inputs(tens, n, blob.ctypes.data, blob.nbytes, offsets.ctypes.data,
-                                   shapes.ctypes.data), "ConcatInputs")
+    if stage is None:
+        _lib.check(L.fcp_concat_inputs(tens, n, blob.ctypes.data, blob.nbytes, offsets.ctypes.data,
+                                       shapes.ctypes.data), "ConcatInputs")
+    else:
+        _lib.check(L.fcp_concat_inputs_ex(tens, n, modes.ctypes.data, args.ctypes.data, blob.ctypes.data, blob.nbytes,
+                                          offsets.ctypes.data, shapes.ctypes.data), "ConcatInputs")
     return blob, offsets, shapes
+
+
+class ConcatInputs:
+    """``Addons>ConcatInputs`` as the shim builds it from a node of the rewritten graph: attrs ``T`` / ``ranks``
+    (``concat_inputs_ops.cc:33-40``) and, when the graph was rewritten for a staged plan, the node's ``_fcp_plan``
+    attr — the plan file whose stage section says how to pack (``tf_shim/fcp_tf_ops.cc``)."""
+
+    def __init__(self, ranks: Sequence[int], plan_path: Optional[str] = None) -> None:
+        self.ranks = [int(r) for r in ranks]
+        self.stage = None
+        if plan_path:
+            from .plan_io import load_stage
+            self.stage = load_stage(plan_path)
+            if self.stage is not None and len(self.stage.modes) != len(self.ranks):
+                raise ValueError("ConcatInputs: the plan's stage section does not match the op's inputs")
+
+    def __call__(self, inputs: Sequence[np.ndarray]):
+        if [np.asarray(a).ndim for a in inputs] != self.ranks:
+            raise ValueError("ConcatInputs: input ranks differ from attr `ranks`")
+        return concat_inputs(inputs, self.stage)
 
 
 # ----------------------------------------------------------------------------

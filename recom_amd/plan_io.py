@@ -7,13 +7,17 @@ from __future__ import annotations
 
 import numpy as np
 
-from .plan import ColumnSpec, PlanSpec
+from .plan import ColumnSpec, PlanSpec, StageInfo
 
 
-def save_plan(spec: PlanSpec, path: str) -> None:
+def save_plan(spec: PlanSpec, path: str, stage: "StageInfo | None" = None) -> None:
+    """``stage``: the stage section (version 3 files) — how ``Addons>ConcatInputs`` packs each of its inputs for this
+    (staged) plan; one entry per host input of ``spec``."""
     spec.validate()
+    if stage is not None and len(stage.modes) != spec.n_host_inputs:
+        raise ValueError("the stage section lists one entry per host input of the plan")
     with open(path, "w") as f:
-        f.write("fcp_plan 2\n")
+        f.write(f"fcp_plan {3 if stage is not None else 2}\n")
         f.write(f"layout {spec.layout}\n")
         f.write(f"groups {spec.n_groups} symbols {spec.n_symbols} device_inputs {spec.n_device_inputs}\n")
         f.write(f"host_inputs {spec.n_host_inputs}\n")
@@ -30,6 +34,10 @@ def save_plan(spec: PlanSpec, path: str) -> None:
             x = [c.xform_mode, len(c.xform_lo), c.xform_substitute, c.hash_buckets] + \
                 [v for p in zip(c.xform_lo, c.xform_hi) for v in p]
             f.write(" " + " ".join(str(int(v)) for v in x) + "\n")
+        if stage is not None:
+            f.write(f"stage {len(stage.modes)} symbols_input {stage.symbols_input}\n")
+            for m, k in zip(stage.modes, stage.rows_symbol):
+                f.write(f"{int(m)} {int(k)}\n")
 
 
 def load_plan(path: str) -> PlanSpec:
@@ -45,7 +53,7 @@ def load_plan(path: str) -> PlanSpec:
     if nxt() != "fcp_plan":
         raise ValueError("bad plan header")
     version = int(nxt())
-    if version not in (1, 2):
+    if version not in (1, 2, 3):
         raise ValueError("bad plan header")
     assert nxt() == "layout"
     layout = int(nxt())
@@ -80,3 +88,20 @@ def load_plan(path: str) -> PlanSpec:
     spec = PlanSpec(cols, ranks, esz, n_dev, n_groups=n_groups, n_symbols=n_symbols, layout=layout)
     spec.validate()
     return spec
+
+
+def load_stage(path: str) -> "StageInfo | None":
+    """The stage section of a plan file as the LIBRARY parses it (``fcp_plan_file_stage_info`` — what the shim's
+    ConcatInputsOp calls with the node's ``_fcp_plan`` attr), or None: a plain plan."""
+    import ctypes as C
+    from . import lib as _lib
+    L = _lib.load()
+    n, sym_in = C.c_int32(0), C.c_int32(-1)
+    _lib.check(L.fcp_plan_file_stage_info(path.encode(), C.byref(n), None, None, 0, C.byref(sym_in)), "fcp_plan_file_stage_info")
+    if n.value == 0:
+        return None
+    modes = np.zeros(n.value, np.uint8)
+    rows = np.zeros(n.value, np.int32)
+    _lib.check(L.fcp_plan_file_stage_info(path.encode(), C.byref(n), modes.ctypes.data, rows.ctypes.data, n.value,
+                                          C.byref(sym_in)), "fcp_plan_file_stage_info")
+    return StageInfo([int(m) for m in modes], [int(r) for r in rows], int(sym_in.value))

@@ -14,6 +14,8 @@ from recom_amd.harness import ServingHarness  # noqa: E402
 which = sys.argv[1] if len(sys.argv) > 1 else "ragged"
 if which == "ragged":
     m = synth.model_ragged()
+elif which == "ragged-staged":
+    m = synth.staged_model(synth.model_ragged(seg="indices"))
 elif which == "ragged-indices":
     m = synth.model_ragged(seg="indices")
 else:

@@ -121,7 +121,10 @@ def random_model(rng, dense_only=False, extended=True):
             cols.append(ColumnSpec(form, dim, vocab, COMBINER_NONE, src, t, i, -1, SEG_NONE, 1, ROWS_FROM_IDS, 0, bnd, g, slot, **xf))
             continue
         seg = str(rng.choice(["csr", "indices", "rowids32"]))
-        max_len = 1 if form == FORM_GATHER_SCATTER else int(rng.choice([0, 1, 3, 10, 10, 70, 200]))
+        # ScatterNd columns: mostly at most one id per row, sometimes rows hit several times (the last write wins); with
+        # row ids (not offsets) the pairs arrive in any order and some rows lie outside the output
+        max_len = int(rng.choice([1, 1, 3])) if form == FORM_GATHER_SCATTER else int(rng.choice([0, 1, 3, 10, 10, 70, 200, 500]))
+        shuffle = form == FORM_GATHER_SCATTER and seg != "csr" and rng.random() < 0.7
         i = host(1, id_esz)
         if seg == "csr":
             si, kind, stride = host(1, 4), SEG_CSR_I32, 1
@@ -130,10 +133,14 @@ def random_model(rng, dense_only=False, extended=True):
         else:
             si, kind, stride = host(1, 4), SEG_IDS_I32, 1
 
-        def gen(r, B, d=draw_ids, seg=seg, max_len=max_len):
+        def gen(r, B, d=draw_ids, seg=seg, max_len=max_len, shuffle=shuffle):
             lens = r.integers(0, max_len + 1, B)
             nnz = int(lens.sum())
             rows = np.repeat(np.arange(B, dtype=np.int64), lens)
+            if shuffle and nnz:
+                rows = rows[r.permutation(nnz)]
+                stray = r.random(nnz) < 0.03
+                rows[stray] = r.choice(np.asarray([-1, B, B + 5, -B - 1], np.int64), int(stray.sum()))
             if seg == "csr":
                 s = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
             elif seg == "indices":

@@ -87,10 +87,9 @@ def test_tensorflow_documented_examples_through_the_hip_path(torch_cuda):
                   [1, 1], [8, 8], [np.asarray(case["indices"], np.int64), np.asarray(case["segment_ids"], np.int64)],
                   [case["data"]], [case["num_segments"]], 1)
         assert np.array_equal(got, np.asarray(case["expected"], np.float32)), case
-    sc = T.SCATTER_ND
-    order = np.argsort(sc["indices"])
+    sc = T.SCATTER_ND                                          # indices as documented: [4, 3, 1, 7], not sorted
     got = run([ColumnSpec(FORM_GATHER_SCATTER, 1, 4, COMBINER_NONE, IDS_I64, 0, 0, 1, SEG_IDS_I64, 1, ROWS_FROM_SYMBOL, 0, None, 0, 0)],
-              [1, 1], [8, 8], [order.astype(np.int64), np.asarray(sc["indices"], np.int64)[order]],
+              [1, 1], [8, 8], [np.arange(len(sc["indices"]), dtype=np.int64), np.asarray(sc["indices"], np.int64)],
               [np.asarray(sc["updates"], np.float32).reshape(-1, 1)], [sc["size"]], 1)
     assert np.array_equal(got.ravel(), np.asarray(sc["expected"], np.float32))
     c = T.CONCAT
@@ -163,8 +162,9 @@ def test_ragged_dynamic_shapes(torch_cuda, oracle, monkeypatch, seg, prepass):
 
 @pytest.mark.parametrize("columns", [16, 900])
 def test_zipf_and_long_bags(torch_cuda, oracle, columns):
-    """Bags of up to 300 ids (walked from global memory); 900 columns x 40 rows exceeds the
-    in-block search threshold, so that plan takes the pre-pass by itself."""
+    """Bags of up to 300 ids: what the wave's 384-entry tile cannot take in is staged bag by bag in further
+    chunks (same order of adds: bit-exact); 900 columns x 40 rows exceeds the in-block search threshold, so that
+    plan takes the pre-pass by itself."""
     from recom_amd import synth
     m = synth.model_ragged(columns=columns, vocab=3000, batch=40, seg="indices", max_len=300, dist="zipf")
     tabs = m.numpy_tables()
@@ -869,25 +869,84 @@ def test_process_call_is_hip_graph_capturable(torch_cuda, oracle):
     assert np.array_equal(res.groups[0].cpu().numpy(), w[0])
 
 
-def test_unsorted_scatter_rows_are_reported(torch_cuda, oracle, monkeypatch):
-    """Form 3 (and form 2) take row ids in ascending order — the contract of SparseTensor indices.  A request
-    that breaks it is not silently accepted: with FCP_FLAG_COUNT_BAD_IDS every descending step is counted
-    (segment-offset pre-pass)."""
+@pytest.mark.parametrize("seg", ["indices", "rowids32"])
+def test_scatter_rows_arrive_in_any_order(torch_cuda, oracle, seg):
+    """Form 3 = ScatterNd(rows, GatherV2(table, ids)): the reference scatters whatever order the row ids come in
+    (GatherScatterRows, cuda_emitter.cc:296-345), and so does the HIP path (inverse map built by the pre-pass, last
+    write wins).  Shuffled rows, rows hit twice, rows outside [0, B): the RESULT equals the oracle's sequential scatter."""
     import dataclasses
     from recom_amd import synth
-    from recom_amd.plan import FLAG_COUNT_BAD_IDS, FORM_GATHER_SCATTER
-    monkeypatch.setenv("FCP_SEG_PREPASS", "1")
-    m = synth.model_mixed(batch=40, vocab=997, n_groups=1)
-    spec = dataclasses.replace(m.spec, flags=FLAG_COUNT_BAD_IDS)
-    k = next(i for i, c in enumerate(spec.columns) if c.form == FORM_GATHER_SCATTER)
-    req = m.make_request(3)
-    _, _, op = run_gpu(torch_cuda, spec, req.inputs, m.numpy_tables(), req.symbols)
-    assert op.plan.read_bad_ids() == 0
-    idx = req.inputs[spec.columns[k].seg_input]
-    assert idx.shape[0] >= 3
-    idx[[0, 2]] = idx[[2, 0]]                                  # two rows swapped: one or two descending steps
-    run_gpu(torch_cuda, spec, req.inputs, m.numpy_tables(), req.symbols, op)
-    assert op.plan.read_bad_ids() in (1, 2)
+    from recom_amd.plan import (COMBINER_NONE, FLAG_COUNT_BAD_IDS, FORM_GATHER_SCATTER, IDS_I64, ROWS_FROM_SYMBOL,
+                                SEG_IDS_I32, SEG_IDS_I64, ColumnSpec, PlanSpec)
+    rng = np.random.default_rng(11)
+    B, vocab = 300, 991
+    cols, ranks, esz, tables, inputs = [], [], [], [], []
+    for c, dim in enumerate((8, 16, 4, 64, 32)):
+        n = [B, B // 2, 0, 2 * B, 1][c]                            # all rows / half of them / none / every row hit about twice / one
+        rows = rng.integers(0, B, n).astype(np.int64) if n > B else rng.permutation(B)[:n].astype(np.int64)
+        if c == 1:
+            rows[:5] = [-1, B, B + 7, -(2 ** 40), 2 ** 40]          # ScatterNd on a GPU drops rows outside the output
+        ids = rng.integers(0, vocab, n).astype(np.int64)
+        if c == 0:
+            ids[:3] = [-1, vocab, 2 ** 35]                         # out-of-vocabulary ids scatter zeros
+        tables.append(synth.hash_table_numpy(50 + c, vocab, dim))
+        inputs.append(ids)
+        if seg == "indices":
+            inputs.append(np.stack([rows, np.zeros(n, np.int64)], axis=1).reshape(n, 2))
+            kind, stride, r, e = SEG_IDS_I64, 2, 2, 8
+        else:
+            inputs.append(np.where(np.abs(rows) < 2 ** 31, rows, -1).astype(np.int32))
+            kind, stride, r, e = SEG_IDS_I32, 1, 1, 4
+        ranks += [1, r]
+        esz += [8, e]
+        cols.append(ColumnSpec(FORM_GATHER_SCATTER, dim, vocab, COMBINER_NONE, IDS_I64, c, 2 * c, 2 * c + 1, kind, stride,
+                               ROWS_FROM_SYMBOL, 0, None, 0, c))
+    spec = PlanSpec(cols, ranks, esz, len(tables), n_groups=1, n_symbols=1, flags=FLAG_COUNT_BAD_IDS)
+    sym = np.array([B], np.int32)
+    out, packed, op = run_gpu(torch_cuda, spec, inputs, tables, sym)
+    assert_equal_oracle(oracle, spec, packed, tables, sym, out)
+    assert op.plan.read_bad_ids() >= 3 + 5                         # the bad ids and the dropped rows are counted
+
+
+def test_scatter_rows_with_several_ids_and_a_filter(torch_cuda, oracle):
+    """A ScatterNd column behind an id filter (plan_builder: ScatterNd(GatherIndiceValue:0, GatherV2(table,
+    GatherIndiceValue:1))): of a row's ids the last one the filter KEEPS wins — the oracle compacts first, TF scatters the
+    survivors — in all three row encodings (sorted CSR: walked backwards; row ids: filtered before the inverse map)."""
+    from recom_amd import synth
+    from recom_amd.plan import (COMBINER_NONE, FORM_GATHER_SCATTER, IDS_I64, ROWS_FROM_SYMBOL, SEG_CSR_I32, SEG_IDS_I32,
+                                SEG_IDS_I64, XFORM_FILTER, ColumnSpec, PlanSpec)
+    rng = np.random.default_rng(12)
+    B, vocab = 70, 500
+    cols, ranks, esz, tables, inputs = [], [], [], [], []
+    for c, (seg, dim) in enumerate((("csr", 8), ("indices", 16), ("rowids32", 32), ("csr", 4))):
+        lens = rng.integers(0, 5, B)                               # up to 4 ids per row
+        if c == 3:
+            lens[7] = 450                                          # one row longer than the wave's tile
+        nnz = int(lens.sum())
+        rows = np.repeat(np.arange(B, dtype=np.int64), lens)
+        ids = rng.integers(0, vocab, nnz).astype(np.int64)
+        tables.append(synth.hash_table_numpy(70 + c, vocab, dim))
+        inputs.append(ids)
+        if seg == "csr":
+            inputs.append(np.concatenate([[0], np.cumsum(lens)]).astype(np.int32))
+            kind, stride, r, e = SEG_CSR_I32, 1, 1, 4
+        elif seg == "indices":
+            inputs.append(np.stack([rows, np.zeros(nnz, np.int64)], axis=1).reshape(nnz, 2))
+            kind, stride, r, e = SEG_IDS_I64, 2, 2, 8
+        else:
+            perm = rng.permutation(nnz)                            # any order: the LAST kept id of a row in this order wins
+            inputs[-1] = ids[perm]
+            inputs.append(rows[perm].astype(np.int32))
+            kind, stride, r, e = SEG_IDS_I32, 1, 1, 4
+        ranks += [1, r]
+        esz += [8, e]
+        cols.append(ColumnSpec(FORM_GATHER_SCATTER, dim, vocab, COMBINER_NONE, IDS_I64, c, 2 * c, 2 * c + 1, kind, stride,
+                               ROWS_FROM_SYMBOL, 0, None, 0, c, xform_mode=XFORM_FILTER,
+                               xform_lo=[0, 300], xform_hi=[99, 420]))
+    spec = PlanSpec(cols, ranks, esz, len(tables), n_groups=1, n_symbols=1)
+    sym = np.array([B], np.int32)
+    out, packed, _ = run_gpu(torch_cuda, spec, inputs, tables, sym)
+    assert_equal_oracle(oracle, spec, packed, tables, sym, out)
 
 
 def test_empty_batch(torch_cuda, oracle):

@@ -285,7 +285,10 @@ def test_narrowed_plan_and_column_subset():
     # staged(): narrowing + sorted row ids -> CSR offsets on the host (fcp_stager_stage_ex)
     sp, modes, rows_col = m.spec.staged()
     for c0, c1 in zip(m.spec.columns, sp.columns):
-        if c0.form in (2, 3) and c0.seg_kind in (PL.SEG_IDS_I32, PL.SEG_IDS_I64) and c0.rows_source == PL.ROWS_FROM_SYMBOL:
+        if c0.form == 3 and c0.seg_kind in (PL.SEG_IDS_I32, PL.SEG_IDS_I64):
+            # ScatterNd row ids come in any order: narrowed at most, never turned into offsets
+            assert modes[c0.seg_input] != PL.STAGE_SEG_TO_CSR and c1.seg_kind in (PL.SEG_IDS_I32, PL.SEG_IDS_I64)
+        if c0.form == 2 and c0.seg_kind in (PL.SEG_IDS_I32, PL.SEG_IDS_I64) and c0.rows_source == PL.ROWS_FROM_SYMBOL:
             assert modes[c0.seg_input] == PL.STAGE_SEG_TO_CSR and c1.seg_kind == PL.SEG_CSR_I32 and c1.seg_stride == 1
             assert sp.host_input_ranks[c0.seg_input] == 1 and sp.host_input_elem_sizes[c0.seg_input] == 4
             assert m.spec.columns[rows_col[c0.seg_input]].rows_arg == c0.rows_arg

@@ -314,9 +314,8 @@ def test_tensorflow_documented_examples(oracle):
         assert np.array_equal(oracle.sparse_segment_reduce_refscan(case["data"], case["indices"], case["segment_ids"],
                                                                   case["num_segments"], mean), want)
     sc = T.SCATTER_ND
-    order = np.argsort(sc["indices"])                           # form 3 takes its (id, row) pairs in row order
-    table = np.asarray(sc["updates"], np.float32).reshape(-1, 1)
-    out, bad = oracle.gather_scatter_rows(table, order, np.asarray(sc["indices"])[order], sc["size"])
+    table = np.asarray(sc["updates"], np.float32).reshape(-1, 1)  # indices as documented ([4, 3, 1, 7]: any order)
+    out, bad = oracle.gather_scatter_rows(table, np.arange(len(sc["indices"])), np.asarray(sc["indices"]), sc["size"])
     assert bad == 0 and np.array_equal(out.ravel(), np.asarray(sc["expected"], np.float32))
     assert np.array_equal(oracle.concat_outputs(T.CONCAT["inputs"]), T.CONCAT["expected"])
     h = T.TO_HASH_BUCKET_FAST
