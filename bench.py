@@ -4,6 +4,8 @@
   python bench.py [--gpus N] [--steps K] [--warmup W] [--workload s2|dlrm|ragged|shard|shard-col|e|f]
                   [--seg indices|csr|rowids32]   (ragged: how row membership arrives; default SparseTensor indices)
                   [--max-len N] [--ids uniform|zipf]   (ragged: bag lengths U{0..N}; id distribution)
+                  [--as-delivered]   (ragged: int64 ids + SparseTensor indices resident on the device, pre-pass there;
+                                      default: as the staged Addons>ConcatInputs leaves the request, host cost stated)
 
 A *step* is one request: one pass of the fused feature-column path (ids resident
 in HBM -> [batch, sum(dim)] concat output resident in HBM) over one batch of
@@ -96,6 +98,50 @@ def pcie_inclusive():
         except Exception as e:  # the bench line must not depend on this extra
             out[key] = {"error": f"{type(e).__name__}: {e}"[:300]}
     return out
+
+
+def host_staging_cost(raw_model, n_requests: int = 8):
+    """What the staged request form costs the HOST, stated beside the device figure: Addons>ConcatInputs packing the
+    graph's tensors with the plan's stage section (fcp_concat_inputs_ex: int64 ids -> int32, sorted row ids /
+    SparseTensor indices -> row offsets; one thread, like the TF op) next to the reference's byte-for-byte pack of the same
+    tensors (fcp_concat_inputs = concat_inputs_ops.cc:42-77).  The C calls alone are timed (tensor views prepared
+    beforehand).  Host time only; never part of `value`."""
+    import ctypes as C
+    from recom_amd import lib as _lib
+    from recom_amd.ops import _host_tensors
+    L = _lib.load()
+    spec, stage = raw_model.spec.staged_for_concat_inputs()
+    reqs = [raw_model.make_request(777 + i) for i in range(n_requests)]
+    raws = [list(r.inputs) + ([r.symbols] if stage.symbols_input >= 0 else []) for r in reqs]
+    n = len(raws[0])
+    modes = np.asarray(stage.modes, np.uint8)
+    prepared = []
+    for x in raws:
+        arrs, keep, tens = _host_tensors(x)
+        args = np.asarray(stage.mode_args(arrs), np.int64)
+        prepared.append((arrs, keep, tens, args))
+    cap = sum(a.nbytes for a in raws[0]) * 2 + 4096
+    blob, offsets, shapes = np.empty(cap, np.int8), np.empty(n, np.int32), np.empty(4 * n, np.int32)
+
+    def timed(call):
+        best = float("inf")
+        for _ in range(4):
+            t0 = time.perf_counter()
+            for pr in prepared:
+                _lib.check(call(pr), "ConcatInputs")
+            best = min(best, (time.perf_counter() - t0) / len(prepared))
+        return best * 1e6
+    plain_us = timed(lambda pr: L.fcp_concat_inputs(pr[2], n, blob.ctypes.data, blob.nbytes, offsets.ctypes.data, shapes.ctypes.data))
+    staged_us = timed(lambda pr: L.fcp_concat_inputs_ex(pr[2], n, modes.ctypes.data, pr[3].ctypes.data, blob.ctypes.data, blob.nbytes,
+                                                        offsets.ctypes.data, shapes.ctypes.data))
+    nb = C.c_int64(0)
+    _lib.check(L.fcp_concat_inputs_ex_sizes(prepared[0][2], n, modes.ctypes.data, prepared[0][3].ctypes.data, C.byref(nb), None), "sizes")
+    return {"what": "host cost of the request form timed above: Addons>ConcatInputs with the plan file's stage section "
+                    "(fcp_concat_inputs_ex, one thread, like the TF op) vs the reference's byte copy of the same tensors "
+                    "(fcp_concat_inputs = concat_inputs_ops.cc:42-77); the C calls alone; never part of `value`",
+            "concat_inputs_staged_us": staged_us, "concat_inputs_byte_copy_us": plain_us,
+            "blob_bytes_staged": int(nb.value), "blob_bytes_byte_copy": int(sum(a.nbytes for a in raws[0])),
+            "inputs": n}
 
 
 def cpu_baseline(model, budget_s: float = 12.0, sample_columns: int = 40):
@@ -234,8 +280,13 @@ def main():
     ap.add_argument("--threads", type=int, default=1, help="serve_workers per GPU (reference harness flag)")
     ap.add_argument("--columns", type=int, default=0, help="override the column count (debug only)")
     ap.add_argument("--staged", action="store_true",
-                    help="requests resident in HBM in the form the staging step (fcp_stager_stage_ex, PlanSpec.staged()) leaves "
-                         "them: ids int32, sorted row ids / SparseTensor indices already CSR offsets (no pre-pass, no search)")
+                    help="requests resident in HBM in the form the staging step (Addons>ConcatInputs with the plan's stage section / "
+                         "fcp_stager_stage_ex, PlanSpec.staged()) leaves them: ids int32, sorted row ids / SparseTensor indices "
+                         "already CSR offsets (no pre-pass, no search).  The default for --workload ragged: the reference delivers "
+                         "SparseTensor indices on the HOST (ConcatInputs is a CPU op), so the conversion happens while packing")
+    ap.add_argument("--as-delivered", action="store_true",
+                    help="ragged: time the request as the graph's tensors are (int64 ids, SparseTensor indices resident on the "
+                         "device, segment-offset pre-pass on the device) instead of as the staged ConcatInputs leaves it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive pass (host tensors -> pinned ring -> H2D -> kernel)")
     ap.add_argument("--no-overlap", action="store_true",
@@ -283,6 +334,9 @@ def main():
                                    **({'vocab': args.vocab} if args.vocab else {}),
                                    **({'max_len': args.max_len} if args.max_len else {}))
 
+    raw_model = model
+    if args.workload == "ragged" and args.seg == "indices" and not args.as_delivered:
+        args.staged = True
     if args.staged:
         model = synth.staged_model(model)
 
@@ -402,6 +456,8 @@ def main():
                                      "examples/cc/recom_examples.patch:193-225 - is overlapped_serving.inferences_per_s "
                                      f"({overlap['inferences_per_s'] / 1e6:.1f} M with {overlap['serve_workers']} workers), next to the single-request "
                                      "p50 above")
+        if args.staged:
+            rec["staging"] = host_staging_cost(raw_model)
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
             rec["cpu_baseline"] = cpu_baseline(model)
     h.close()

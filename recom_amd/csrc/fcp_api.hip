@@ -1968,24 +1968,9 @@ int fcp_stager_stage_narrow(fcp_stager_t *s, const fcp_host_tensor_t *inputs, in
 }
 
 namespace {
-// Sorted segment / row ids (element i at index i * stride, int32 or int64) -> CSR offsets[0..rows]: offsets[r] = number of ids
-// below r — what the device pre-pass (fcp_segment_offsets_kernel) and ComputeSegmentOffsets (cuda_emitter.cc:768-818) produce.
-void seg_to_csr(const void *seg, int elem_size, int64_t stride, int64_t nnz, int64_t rows, int32_t *out) {
-  int64_t i = 0;
-  if (elem_size == 8) {
-    const int64_t *p = static_cast<const int64_t *>(seg);
-    for (int64_t r = 0; r <= rows; ++r) {
-      while (i < nnz && p[i * stride] < r) ++i;
-      out[r] = (int32_t)i;
-    }
-  } else {
-    const int32_t *p = static_cast<const int32_t *>(seg);
-    for (int64_t r = 0; r <= rows; ++r) {
-      while (i < nnz && p[i * stride] < r) ++i;
-      out[r] = (int32_t)i;
-    }
-  }
-}
+// the two host loops of the staged pack, built per instruction set (fcp_pack.cc)
+extern "C" void fcp_pack_narrow_i64(const int64_t *src, int32_t *dst, int64_t n);
+extern "C" void fcp_pack_seg_to_csr(const void *seg, int elem_size, int64_t stride, int64_t nnz, int64_t rows, int32_t *out);
 
 // Layout of the staged blob: byte offsets (byte_off[0..n]), the op's `offsets` and `shapes` outputs — exactly
 // ConcatInputsOp::Compute (concat_inputs_ops.cc:52-66), except that a narrowed int64 input occupies 4 bytes per element
@@ -2036,16 +2021,9 @@ int stage_layout(const fcp_host_tensor_t *inputs, int32_t n, const uint8_t *mode
 void stage_pack_one(const fcp_host_tensor_t &t, int mode, int64_t mode_arg, char *dst, int64_t nbytes) {
   if (nbytes <= 0) return;
   if (mode == FCP_STAGE_SEG_TO_CSR) {
-    seg_to_csr(t.data, t.elem_size, t.rank == 2 ? t.dims[1] : 1, t.dims[0], mode_arg, reinterpret_cast<int32_t *>(dst));
+    fcp_pack_seg_to_csr(t.data, t.elem_size, t.rank == 2 ? t.dims[1] : 1, t.dims[0], mode_arg, reinterpret_cast<int32_t *>(dst));
   } else if (mode == FCP_STAGE_NARROW_I64) {
-    // int64 -> int32; values that do not fit are not valid ids / rows anyway: -1 (reads as zeros)
-    const int64_t *src = static_cast<const int64_t *>(t.data);
-    int32_t *d32 = reinterpret_cast<int32_t *>(dst);
-    const int64_t ne = nbytes / 4;
-    for (int64_t k = 0; k < ne; ++k) {
-      const int64_t v = src[k];
-      d32[k] = (v >= 0 && v <= 0x7fffffff) ? (int32_t)v : -1;
-    }
+    fcp_pack_narrow_i64(static_cast<const int64_t *>(t.data), reinterpret_cast<int32_t *>(dst), nbytes / 4);
   } else {
     std::memcpy(dst, t.data, (size_t)nbytes);
   }

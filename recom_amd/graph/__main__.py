@@ -20,6 +20,11 @@ def main(argv=None) -> int:
     ap.add_argument("--host-concat", choices=["passthrough", "external"], default="passthrough",
                     help="non-lookup concat inputs: through ConcatInputs as passthrough columns (default), or as "
                          "Addons>ConcatOutputs host inputs into reserved slots — the reference's own wiring")
+    ap.add_argument("--staged", action="store_true",
+                    help="write the STAGED plan: Addons>ConcatInputs packs int64 ids as int32 and turns the sorted row ids / "
+                         "SparseTensor indices of pooled columns into int32 row offsets (the plan file's stage section tells it "
+                         "how; the rewritten ConcatInputs node names the plan in its `_fcp_plan` attr and receives the symbols "
+                         "vector as one more input) - the device then runs neither the segment-offset pre-pass nor a search")
     args = ap.parse_args(argv)
     gd = load_graphdef(args.graph)
     try:
@@ -27,10 +32,19 @@ def main(argv=None) -> int:
     except Unsupported as why:
         print(f"nothing to fuse: {why}", file=sys.stderr)
         return 1
-    save_plan(built.spec, args.plan)
+    stage = None
+    if args.staged:
+        spec, stage = built.spec.staged_for_concat_inputs()
+        save_plan(spec, args.plan, stage)
+    else:
+        save_plan(built.spec, args.plan)
     print(built.describe())
+    if stage is not None:
+        names = {0: "copied", 1: "int64 -> int32", 2: "row ids -> row offsets"}
+        counts = {v: sum(1 for m in stage.modes if names[m] == v) for v in names.values()}
+        print("  staged ConcatInputs: " + ", ".join(f"{n}x {k}" for k, n in counts.items() if n))
     if args.out:
-        save_graphdef(rewrite_graph(gd, built, args.plan, prune=not args.no_prune), args.out)
+        save_graphdef(rewrite_graph(gd, built, args.plan, prune=not args.no_prune, stage=stage), args.out)
     return 0
 
 

@@ -45,8 +45,13 @@ def _const(gd, name: str, value: np.ndarray):
     return n
 
 
-def rewrite_graph(graph_def, built: BuiltPlan, plan_path: str, prune: bool = True):
-    """Returns a new GraphDef; ``graph_def`` is left untouched."""
+def rewrite_graph(graph_def, built: BuiltPlan, plan_path: str, prune: bool = True, stage=None):
+    """Returns a new GraphDef; ``graph_def`` is left untouched.
+
+    ``stage`` (``PlanSpec.staged_for_concat_inputs()``): the graph is rewritten for the STAGED plan — the ConcatInputs
+    node carries ``_fcp_plan`` = the plan file (an underscore attr: node-private, not part of the op's registered
+    signature, which stays the reference's ``T`` / ``ranks``) and, when row ids are converted to offsets, receives the
+    symbols vector as its last input, because the row counts are not among the tensors it packs."""
     gd = P.GraphDef()
     gd.CopyFrom(graph_def)
     view = GraphView(gd)
@@ -59,6 +64,15 @@ def rewrite_graph(graph_def, built: BuiltPlan, plan_path: str, prune: bool = Tru
         concat_in.input.append(tensor)
         concat_in.attr["T"].list.type.append(dtype)
         concat_in.attr["ranks"].list.i.append(rank)
+
+    if stage is not None:
+        concat_in.attr["_fcp_plan"].s = plan_path.encode()
+        if stage.symbols_input >= 0:
+            if stage.symbols_input != len(built.host_inputs) or not built.symbols:
+                raise ValueError("the stage section expects the symbols vector as the last ConcatInputs input")
+            concat_in.input.append("FeatureColumnProcess/symbols")
+            concat_in.attr["T"].list.type.append(P.DT_INT32)
+            concat_in.attr["ranks"].list.i.append(1)
 
     fuse = gd.node.add(name="FeatureColumnProcess", op="Addons>FeatureColumnProcess")
     fuse.attr["dlpath"].s = plan_path.encode()

@@ -106,6 +106,7 @@ EXPORTS = [
     "fcp_shard_batch_slice", "fcp_shard_exchange", "fcp_shard_exchange_columns",
     "fcp_shard_step_create", "fcp_shard_step_run", "fcp_shard_step_destroy",
     "fcp_stager_create", "fcp_stager_create_ex", "fcp_stager_stage", "fcp_stager_stage_ex", "fcp_stager_stage_narrow", "fcp_stager_destroy",
+    "fcp_concat_inputs_ex_sizes", "fcp_concat_inputs_ex", "fcp_plan_file_stage_info",
 ]
 
 _lib = None

@@ -59,6 +59,11 @@ template <typename Ctx> int GpuOrdinal(Ctx *c) {
 } // namespace
 
 // ---- Addons>ConcatInputs (CPU) ---------------------------------------------------------------
+// Registered exactly as the reference registers it (attrs `T`, `ranks`).  A graph rewritten for a STAGED plan
+// (`python -m recom_amd.graph --staged`) additionally carries the node-private attr `_fcp_plan` (underscore attrs are
+// not part of an op's signature): the plan file whose stage section says how each input is packed — int64 ids as
+// int32, the sorted row ids / SparseTensor indices of pooled columns as int32 row offsets (fcp_concat_inputs_ex) —
+// and the symbols vector (the row counts) arrives as one more input.  Without the attr: the reference's byte copy.
 class ConcatInputsOp : public OpKernel {
 public:
   explicit ConcatInputsOp(OpKernelConstruction *c) : OpKernel(c) {
@@ -68,6 +73,21 @@ public:
     OP_REQUIRES_OK(c, c->GetAttr("ranks", &ranks));
     OP_REQUIRES(c, types.size() == ranks.size(), errors::InvalidArgument("input_types.size() != input_ranks.size()"));
     num_inputs_ = types.size();
+    std::string plan_path;
+    if (c->GetAttr("_fcp_plan", &plan_path).ok() && !plan_path.empty()) {
+      int32_t n = 0;
+      OP_REQUIRES_OK(c, FcpStatus(fcp_plan_file_stage_info(plan_path.c_str(), &n, nullptr, nullptr, 0, &symbols_input_), "stage info"));
+      if (n > 0) {
+        OP_REQUIRES(c, n == num_inputs_, errors::InvalidArgument("the plan's stage section does not match the op's inputs"));
+        modes_.resize(n);
+        rows_symbol_.resize(n);
+        OP_REQUIRES_OK(c, FcpStatus(fcp_plan_file_stage_info(plan_path.c_str(), &n, modes_.data(), rows_symbol_.data(), n,
+                                                             &symbols_input_),
+                                    "stage info"));
+        OP_REQUIRES(c, symbols_input_ < 0 || types[symbols_input_] == DT_INT32,
+                    errors::InvalidArgument("the symbols input of ConcatInputs must be int32"));
+      }
+    }
   }
   void Compute(OpKernelContext *c) override {
     std::vector<fcp_host_tensor_t> ts(num_inputs_);
@@ -77,19 +97,41 @@ public:
       for (int j = 0; j < t.dims(); ++j) dims[i].push_back(t.dim_size(j));
       ts[i] = {t.data(), DataTypeSize(t.dtype()), t.dims(), dims[i].data()};
     }
+    const uint8_t *modes = modes_.empty() ? nullptr : modes_.data();
+    std::vector<int64_t> mode_args;
+    if (modes && symbols_input_ >= 0) { // row counts of the inputs that become row offsets
+      const Tensor &sym = c->input(symbols_input_);
+      const int32 *sv = sym.flat<int32>().data();
+      mode_args.assign(num_inputs_, 0);
+      for (int i = 0; i < num_inputs_; ++i)
+        if (modes_[i] == FCP_STAGE_SEG_TO_CSR) {
+          OP_REQUIRES(c, rows_symbol_[i] >= 0 && rows_symbol_[i] < sym.NumElements(), errors::InvalidArgument("symbol index out of range"));
+          mode_args[i] = sv[rows_symbol_[i]];
+        }
+    }
     int64_t bytes = 0;
     int32_t rank_sum = 0;
-    OP_REQUIRES_OK(c, FcpStatus(fcp_concat_inputs_sizes(ts.data(), num_inputs_, &bytes, &rank_sum), "ConcatInputs"));
+    OP_REQUIRES_OK(c, FcpStatus(fcp_concat_inputs_ex_sizes(ts.data(), num_inputs_, modes, mode_args.empty() ? nullptr : mode_args.data(),
+                                                           &bytes, &rank_sum),
+                                "ConcatInputs"));
     Tensor *blob, *offsets, *shapes;
-    OP_REQUIRES_OK(c, c->allocate_output(0, {bytes}, &blob));
+    // the blob is what TensorFlow copies to the GPU next: allocate it where that copy starts from pinned memory
+    // (the reference's plain allocate_output gives pageable memory, concat_inputs_ops.cc:69)
+    AllocatorAttributes pinned;
+    pinned.set_gpu_compatible(true);
+    OP_REQUIRES_OK(c, c->allocate_output(0, {bytes}, &blob, pinned));
     OP_REQUIRES_OK(c, c->allocate_output(1, {num_inputs_}, &offsets));
     OP_REQUIRES_OK(c, c->allocate_output(2, {rank_sum}, &shapes));
-    OP_REQUIRES_OK(c, FcpStatus(fcp_concat_inputs(ts.data(), num_inputs_, blob->data(), bytes,
-                                                  offsets->flat<int32>().data(), shapes->flat<int32>().data()),
+    OP_REQUIRES_OK(c, FcpStatus(fcp_concat_inputs_ex(ts.data(), num_inputs_, modes, mode_args.empty() ? nullptr : mode_args.data(),
+                                                     blob->data(), bytes, offsets->flat<int32>().data(),
+                                                     shapes->flat<int32>().data()),
                                 "ConcatInputs"));
   }
 private:
   int num_inputs_;
+  std::vector<uint8_t> modes_;        // FCP_STAGE_* per input (empty: plain byte copy)
+  std::vector<int32_t> rows_symbol_;  // which symbol holds the row count of a converted input
+  int32_t symbols_input_ = -1;        // which input is the symbols vector
 };
 
 // ---- Addons>FeatureColumnProcess[WithSymbols] (GPU) --------------------------------------------

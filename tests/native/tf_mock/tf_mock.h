@@ -72,6 +72,10 @@ struct DeviceBase {
   const GpuDeviceInfo *tensorflow_gpu_device_info() const;
 };
 
+struct AllocatorAttributes {
+  void set_gpu_compatible(bool);
+};
+
 class OpKernelConstruction {
 public:
   template <typename T> Status GetAttr(const char *, T *);
@@ -83,6 +87,7 @@ public:
   const Tensor &input(int);
   int num_inputs() const;
   Status allocate_output(int, const TensorShape &, Tensor **);
+  Status allocate_output(int, const TensorShape &, Tensor **, AllocatorAttributes);
   Status allocate_temp(DataType, const TensorShape &, Tensor *);
   void set_output(int, const Tensor &);
   DeviceContext *op_device_context();

@@ -376,18 +376,31 @@ def test_column_sharded_blocks_concat(torch_cuda, oracle):
         assert np.array_equal(got.cpu().numpy(), ref[begin:begin + count])
 
 
-def _graph_through_hip(torch, gd, feeds, variables, fetches, tmp_path, host_concat="passthrough"):
-    """original graph in NumPy vs rewritten graph with the HIP path behind the Addons> ops"""
+def _graph_through_hip(torch, gd, feeds, variables, fetches, tmp_path, host_concat="passthrough", staged=False):
+    """original graph in NumPy vs rewritten graph with the HIP path behind the Addons> ops.  ``staged``: the graph is
+    rewritten for the staged plan (`python -m recom_amd.graph --staged`): ConcatInputs packs as the plan file's stage
+    section says (what the shim does with the node's `_fcp_plan` attr)."""
     from tf_graph_eval import GraphEvaluator
     from recom_amd.graph import build_plan, parse_graphdef, rewrite_graph
-    from recom_amd.ops import ConcatOutputs, FeatureColumnProcess, concat_inputs
+    from recom_amd.ops import ConcatInputs, ConcatOutputs, FeatureColumnProcess
     from recom_amd.plan_io import load_plan, save_plan
     expected = GraphEvaluator(gd, variables).run(fetches, feeds)
     built = build_plan(gd, host_concat)
     path = str(tmp_path / "model.fcp")
-    save_plan(built.spec, path)
-    out_gd = parse_graphdef(rewrite_graph(gd, built, path).SerializeToString())
+    stage = None
+    if staged:
+        spec, stage = built.spec.staged_for_concat_inputs()
+        save_plan(spec, path, stage)
+    else:
+        save_plan(built.spec, path)
+    out_gd = parse_graphdef(rewrite_graph(gd, built, path, stage=stage).SerializeToString())
     ops = {}
+
+    def concat_inputs_node(node, x):
+        plan = node.attr["_fcp_plan"].s.decode() if "_fcp_plan" in node.attr else None
+        assert (plan is not None) == staged
+        return list(ConcatInputs(list(node.attr["ranks"].list.i), plan)(x))
+
     out_cols = built.spec.output_columns()
 
     def process(node, x):
@@ -416,7 +429,7 @@ def _graph_through_hip(torch, gd, feeds, variables, fetches, tmp_path, host_conc
         torch.cuda.synchronize()
         return [out.cpu().numpy()]
 
-    custom = {"Addons>ConcatInputs": lambda node, x: list(concat_inputs(x)),
+    custom = {"Addons>ConcatInputs": concat_inputs_node,
               "Addons>FeatureColumnProcess": process, "Addons>FeatureColumnProcessWithSymbols": process,
               "Addons>ConcatOutputsNoHost": concat_outputs, "Addons>ConcatOutputs": concat_outputs}
     got = GraphEvaluator(out_gd, variables, custom).run(fetches, feeds)
@@ -444,6 +457,26 @@ def test_random_graphdefs_to_hip_path(torch_cuda, tmp_path, seed, host_concat):
     from graph_fixtures import random_model
     gd, feeds, variables, fetches, _ = random_model(seed)
     _graph_through_hip(torch_cuda, gd, feeds, variables, fetches, tmp_path, host_concat)
+
+
+@pytest.mark.parametrize("which", ["canonical", "random3", "random7", "id_filter", "sparse_reshape", "microbenchmark"])
+def test_graphdef_to_hip_path_through_the_staged_concat_inputs(torch_cuda, tmp_path, which):
+    """The RAGGED config's real path: the reference delivers SparseTensor indices on the HOST (ConcatInputs is a CPU op,
+    concat_inputs_ops.cc:42-77), so the staged Addons>ConcatInputs turns them into row offsets (and int64 ids into int32)
+    while it packs, and the device runs neither the pre-pass nor a search.  GraphDef -> staged plan + stage section ->
+    rewritten graph -> HIP path; equal to the original graph (NumPy, TF-CPU semantics) bit for bit."""
+    import graph_fixtures as F
+    if which == "canonical":
+        gd, feeds, variables, fetches = F.canonical_model(B=300, seed=3)
+    elif which.startswith("random"):
+        gd, feeds, variables, fetches, _ = F.random_model(int(which[6:]))
+    elif which == "id_filter":
+        gd, feeds, variables, fetches = F.id_filter_model(B=120, seed=1)
+    elif which == "sparse_reshape":
+        gd, feeds, variables, fetches = F.sparse_reshape_model(B=45, seed=4)
+    else:
+        gd, feeds, variables, fetches = F.microbenchmark_model(columns=30, B=64, seed=2)
+    _graph_through_hip(torch_cuda, gd, feeds, variables, fetches, tmp_path, staged=True)
 
 
 def test_sparse_reshape_graph_to_hip_path(torch_cuda, tmp_path):
@@ -643,24 +676,42 @@ def test_output_arena_beyond_4_gib(torch_cuda):
     torch.cuda.empty_cache()
 
 
-def test_ragged_full_size_closed_form(torch_cuda):
+@pytest.mark.parametrize("how", ["indices", "indices-staged", "csr"])
+def test_ragged_full_size_closed_form(torch_cuda, how):
     """BASELINE.json configs[3] at full size: 512 multi-hot columns, vocab 100k (6 GB of
-    tables), batch 256, 0..10 ids per row, CSR offsets, sum / mean alternating.  Every pooled
-    vector is rebuilt from the closed-form table rows with fp32 adds in id order — bit-exact."""
+    tables), batch 256, 0..10 ids per row, sum / mean alternating.  Every pooled vector is rebuilt from the
+    closed-form table rows with fp32 adds in id order — bit-exact.  `indices`: the config's own encoding, SparseTensor
+    indices [nnz, 2] int64 as delivered (segment-offset pre-pass on the device); `indices-staged`: the same request
+    through the staged Addons>ConcatInputs (int32 ids, row offsets made on the host: fcp_concat_inputs_ex with the
+    modes of the plan's stage section); `csr`: row offsets given."""
     from recom_amd import synth
+    from recom_amd.ops import FeatureColumnProcess, concat_inputs
     from recom_amd.plan import COMBINER_MEAN
     torch = torch_cuda
-    m = synth.model_ragged()
+    m = synth.model_ragged(seg="csr" if how == "csr" else "indices")
     tabs = m.torch_tables(torch.device("cuda", 0))
     op = None
+    staged_spec, stage = m.spec.staged_for_concat_inputs() if how == "indices-staged" else (None, None)
     for seed in (0, 5):                                     # different nnz: new descriptors
         req = m.make_request(seed)
-        out, _, op = run_gpu(torch, m.spec, req.inputs, None, req.symbols, op, tables_dev=tabs)
+        if stage is None:
+            out, _, op = run_gpu(torch, m.spec, req.inputs, None, req.symbols, op, tables_dev=tabs)
+        else:
+            assert stage.symbols_input == m.spec.n_host_inputs and stage.modes.count(2) == 512 and stage.modes.count(1) == 512
+            blob, offsets, shapes = concat_inputs(list(req.inputs) + [req.symbols], stage)
+            assert blob.nbytes < 0.25 * sum(a.nbytes for a in req.inputs)   # 15.7 MB of tensors -> about 3.1 MB on the wire
+            op = op or FeatureColumnProcess(staged_spec, 0)
+            out = op(torch.from_numpy(blob).cuda(), offsets, shapes, tabs, req.symbols)
+            torch.cuda.synchronize()
         got = out.groups[0].cpu().numpy()
         assert got.shape == (256, 15360)
         offs = m.spec.column_offsets()
         for k, c in enumerate(m.spec.columns):
-            ids, csr = req.inputs[c.ids_input], req.inputs[c.seg_input].astype(np.int64)
+            ids = req.inputs[c.ids_input]
+            if how == "csr":
+                csr = req.inputs[c.seg_input].astype(np.int64)
+            else:
+                csr = np.searchsorted(req.inputs[c.seg_input][:, 0], np.arange(257), side="left")
             rows = synth.hash_rows(m.tables[c.table_input].seed, ids, c.dim)
             want = np.zeros((256, c.dim), np.float32)
             seg = np.repeat(np.arange(256), np.diff(csr))

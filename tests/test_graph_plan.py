@@ -25,6 +25,9 @@ def oracle_ops(oracle, built, variables):
     """The three Addons> ops with the C oracle behind them (CPU stand-in for the shim)."""
     def concat_inputs(node, x):
         assert [int(r) for r in node.attr["ranks"].list.i] == [a.ndim for a in x]
+        if "_fcp_plan" in node.attr:                             # graph rewritten for a staged plan: the op packs as the
+            from recom_amd.ops import ConcatInputs               # plan file's stage section says (host-only product code)
+            return list(ConcatInputs(list(node.attr["ranks"].list.i), node.attr["_fcp_plan"].s.decode())(x))
         blob, offsets, shapes = oracle.concat_inputs(x)
         return [blob, offsets, shapes]
 
@@ -443,3 +446,36 @@ def test_graph_evaluator_reproduces_the_tensorflow_documented_examples():
     got = run(lambda g: g.node("out", "ConcatV2", [g.const("a", c["inputs"][0]), g.const("b", c["inputs"][1]),
                                                    g.const("axis", np.asarray(1, np.int32))], T=("type", P.DT_FLOAT), N=2))
     assert np.array_equal(got, c["expected"])
+
+
+@pytest.mark.parametrize("which", ["canonical", "random1", "random5", "id_filter", "sparse_reshape"])
+def test_staged_rewrite_matches_the_original_graph(oracle, tmp_path, which):
+    """`python -m recom_amd.graph --staged`: the staged plan + its stage section + a rewritten graph whose ConcatInputs
+    node carries `_fcp_plan` and receives the symbols vector; evaluated with the staged ConcatInputs and the C oracle on
+    the staged plan it equals the original graph bit for bit, and the blob is smaller than the reference's byte copy."""
+    from tf_graph_eval import GraphEvaluator
+    from recom_amd.graph.__main__ import main
+    from recom_amd.graph import load_graphdef, save_graphdef
+    from recom_amd.plan_io import load_stage
+    if which == "canonical":
+        gd, feeds, variables, fetches = canonical_model(B=41, seed=2)
+    elif which.startswith("random"):
+        gd, feeds, variables, fetches, _ = random_model(int(which[6:]))
+    elif which == "id_filter":
+        gd, feeds, variables, fetches = id_filter_model(B=37, seed=1)
+    else:
+        gd, feeds, variables, fetches = sparse_reshape_model(B=23, seed=0)
+    expected = GraphEvaluator(gd, variables).run(fetches, feeds)
+    src, plan, out = str(tmp_path / "m.pb"), str(tmp_path / "m.fcp"), str(tmp_path / "m_fcp.pb")
+    save_graphdef(gd, src)
+    assert main([src, "--plan", plan, "--out", out, "--staged"]) == 0
+    stage = load_stage(plan)
+    built = build_plan(gd)
+    assert stage is not None and len(stage.modes) == len(built.host_inputs) + (stage.symbols_input >= 0)
+    out_gd = load_graphdef(out)
+    ci = {n.name: n for n in out_gd.node}["ConcatInputs"]
+    assert ci.op == "Addons>ConcatInputs" and ci.attr["_fcp_plan"].s.decode() == plan
+    assert len(ci.input) == len(stage.modes) and (stage.symbols_input < 0 or ci.input[-1] == "FeatureColumnProcess/symbols")
+    got = GraphEvaluator(out_gd, variables, oracle_ops(oracle, built, variables)).run(fetches, feeds)
+    for e, o in zip(expected, got):
+        assert e.shape == o.shape and np.array_equal(e, o)

@@ -540,3 +540,59 @@ def test_shard_exchange_entry_points_without_a_gpu():
     assert L.fcp_shard_exchange(None, None, 4, 4, None, None, None, None) == lib.FCP_ERR_INVALID_ARGUMENT
     assert L.fcp_shard_step_run(None, None, None, None, None) == lib.FCP_ERR_INVALID_ARGUMENT
     assert L.fcp_comm_destroy(None) == lib.FCP_OK and L.fcp_shard_step_destroy(None) == lib.FCP_OK
+
+
+def test_staged_concat_inputs_and_the_stage_section(L, tmp_path):
+    """Addons>ConcatInputs in its staged form (fcp_concat_inputs_ex, host only): with the modes of the plan file's stage
+    section the blob carries int32 ids and int32 row offsets — exactly ConcatInputs of the converted tensors (NumPy
+    conversion) — and the stage section survives the file (fcp_plan_file_stage_info, what the shim's ConcatInputsOp reads
+    through the node's `_fcp_plan` attr)."""
+    import fcp_oracle as O  # noqa: F401  (np_segment_offsets: the checker)
+    from recom_amd import synth
+    from recom_amd import plan as PL
+    from recom_amd.ops import ConcatInputs, concat_inputs
+    from recom_amd.plan_io import load_plan, load_stage, save_plan
+    for m in (synth.model_mixed(batch=70, vocab=997), synth.model_ragged(columns=24, vocab=3000, batch=130, seg="indices"),
+              synth.model_ragged(columns=6, vocab=500, batch=33, seg="rowids32"), synth.model_s2(columns=20, vocab=1000, batch=32)):
+        spec, stage = m.spec.staged_for_concat_inputs()
+        converted = PL.STAGE_SEG_TO_CSR in stage.modes
+        assert (stage.symbols_input == m.spec.n_host_inputs) == converted and spec.n_host_inputs == m.spec.n_host_inputs + converted
+        for k, (c0, c1) in enumerate(zip(m.spec.columns, spec.columns)):
+            if c0.form == 3:                                       # ScatterNd rows come in any order: never offsets
+                assert c1.seg_kind != PL.SEG_CSR_I32 or c0.seg_kind == PL.SEG_CSR_I32
+        path = str(tmp_path / f"{m.name}.fcp")
+        save_plan(spec, path, stage)
+        again = load_stage(path)
+        assert again.modes == list(stage.modes) and again.rows_symbol == list(stage.rows_symbol) and again.symbols_input == stage.symbols_input
+        assert load_plan(path).n_host_inputs == spec.n_host_inputs
+        from recom_amd.ops import Plan
+        Plan.from_file(path, host_only=True).close()              # the library accepts the version-3 file
+        op = ConcatInputs([a.ndim for a in m.make_request(0).inputs] + ([1] if converted else []), path)
+        for seed in range(3):
+            req = m.make_request(seed)
+            raw = list(req.inputs) + ([req.symbols] if converted else [])
+            blob, offsets, shapes = op(raw)
+            conv = []
+            for i, a in enumerate(raw):
+                if stage.modes[i] == PL.STAGE_SEG_TO_CSR:
+                    rows = int(req.symbols[stage.rows_symbol[i]])
+                    conv.append(O.np_segment_offsets(np.asarray(a).reshape(a.shape[0], -1)[:, 0], rows).astype(np.int32))
+                elif stage.modes[i] == PL.STAGE_NARROW_I64:
+                    conv.append(np.where((a >= 0) & (a <= 0x7fffffff), a, -1).astype(np.int32))
+                else:
+                    conv.append(a)
+            b2, o2, s2 = concat_inputs(conv)
+            assert np.array_equal(blob, b2) and np.array_equal(offsets, o2) and np.array_equal(shapes, s2)
+            assert spec.host_input_ranks == [np.asarray(a).ndim for a in conv]
+            assert spec.host_input_elem_sizes == [np.asarray(a).dtype.itemsize for a in conv]
+    # a plain plan file has no stage section; a wrong one is refused
+    plain = str(tmp_path / "plain.fcp")
+    save_plan(m.spec, plain)
+    assert load_stage(plain) is None
+    text = open(path).read().replace("stage ", "stage 9")
+    bad = str(tmp_path / "bad.fcp")
+    open(bad, "w").write(text)
+    with pytest.raises(Exception):
+        load_stage(bad)
+    with pytest.raises(ValueError):
+        ConcatInputs([1, 2], path)                                 # input count differs from the stage section
