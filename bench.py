@@ -12,7 +12,7 @@ in HBM -> [batch, sum(dim)] concat output resident in HBM) over one batch of
 synthetic input.  Default workload = BASELINE.json configs[1] "S2": 1000 columns,
 dims 8/16/32/64, vocab 1M (120 GB of tables), batch 512, on 1 MI355X.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): the path shards by
+N > 1 (one rank per GPU: launched by torch.distributed.run, or by bench.py itself when no launcher did): the path shards by
 requests — every rank serves its own requests on its own replica of the tables,
 no data-path collective ("weak" scaling).  Only `--workload shard` / `shard-col`
 (tables larger than one GPU's HBM) shard the tables — by rows (partial sums) or by
@@ -265,6 +265,25 @@ def access_mix_floor(model, h, bytes_alg, measured_us):
                     "ids/offsets at the sequential read rate; frac = floor / measured device time per request"}
 
 
+def launch_ranks(n: int, argv) -> int:
+    """One process per GPU through torch.distributed.run (what the driver does for N > 1), rendezvous on 127.0.0.1 and
+    a free port.  FCP_BENCH_DRY_LAUNCH=1 prints the command instead of running it (CPU test of the launcher)."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    if os.environ.get("FCP_BENCH_DRY_LAUNCH"):
+        print(json.dumps({"launch": cmd}))
+        return 0
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -297,6 +316,12 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) normally; gloo only to exercise the N>1 control flow on a 1-GPU box")
     args = ap.parse_args()
 
+    # `python bench.py --gpus N` without a launcher: start the N ranks here (one process per GPU, torch.distributed.run
+    # on 127.0.0.1) and leave with their exit code.  Nothing has touched the GPU yet — torch is not even imported — so
+    # this process never initialises HIP; rank 0 of the children prints the JSON line.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+
     import torch
     from recom_amd import synth
     from recom_amd.harness import ServingHarness, copy_probe
@@ -306,8 +331,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if os.environ.get("FCP_BENCH_DEVICE"):  # testing aid: several ranks on one GPU (with --dist-backend gloo)
         local_rank = int(os.environ["FCP_BENCH_DEVICE"])
-    if args.gpus > 1 and world == 1:
-        print("bench.py: --gpus > 1 must be launched with torch.distributed.run", file=sys.stderr)
+    if args.gpus != world:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)", file=sys.stderr)
         sys.exit(2)
     torch.cuda.set_device(local_rank)
     dist = None
@@ -321,9 +347,11 @@ def main():
 
     if args.workload in ("shard", "shard-col"):
         # BASELINE.json config 5: 4000 S2-shaped columns (480 GB); the flag names the model and the preferred sharding
-        model = synth.model_shard(columns=args.columns or 4000)
+        model = synth.model_shard(columns=args.columns or 4000, **({'vocab': args.vocab} if args.vocab else {}),
+                                  **({'batch': args.batch} if args.batch else {}))
     elif args.workload == "s2":
-        model = synth.model_s2(columns=args.columns or 1000, dist=args.ids, **({'batch': args.batch} if args.batch else {}))
+        model = synth.model_s2(columns=args.columns or 1000, dist=args.ids, **({'batch': args.batch} if args.batch else {}),
+                               **({'vocab': args.vocab} if args.vocab else {}))
     elif args.workload == "dlrm":
         model = synth.model_dlrm()
     elif args.workload in ("e", "f"):
@@ -347,8 +375,11 @@ def main():
     from recom_amd.lib import FcpError
     from recom_amd.placement import REPLICATE, decide_placement, device_hbm_bytes
     try:
-        placement = decide_placement(model.spec, world, hbm_bytes=device_hbm_bytes(local_rank),
-                                     prefer="column" if args.workload == "shard-col" else "row")
+        # FCP_BENCH_HBM_BYTES: testing aid — pretend the GPU is this small, so that a toy model takes the sharded branch
+        hbm_override = os.environ.get("FCP_BENCH_HBM_BYTES")
+        placement = decide_placement(model.spec, world, hbm_bytes=int(hbm_override) if hbm_override else device_hbm_bytes(local_rank),
+                                     prefer="column" if args.workload == "shard-col" else "row",
+                                     **({"reserve_bytes": 0} if hbm_override else {}))
     except FcpError as e:                            # the tables fit no placement on this many GPUs
         if rank == 0:
             print(f"bench.py: {model.name} ({model.table_bytes() / 1e9:.0f} GB of tables) cannot be placed on {world} GPU(s): {e}",
@@ -380,7 +411,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -456,7 +487,7 @@ def main():
                                      "examples/cc/recom_examples.patch:193-225 - is overlapped_serving.inferences_per_s "
                                      f"({overlap['inferences_per_s'] / 1e6:.1f} M with {overlap['serve_workers']} workers), next to the single-request "
                                      "p50 above")
-        if args.staged:
+        if args.staged and "FCP_LIB_DIR" not in os.environ:
             rec["staging"] = host_staging_cost(raw_model)
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
             rec["cpu_baseline"] = cpu_baseline(model)

@@ -515,8 +515,10 @@ int fcp_shard_exchange_columns(fcp_comm_t *comm, const void *block, int64_t rows
  * args' allocator callbacks are ignored).  max_rows / max_arena_bytes bound the
  * requests it will see (fcp_plan_arena_bytes); col_widths[world]: column mode only.
  * *out: device [row_count, width] of this rank's batch slice, valid for the next two
- * calls.  Calls may come on different streams and host threads (a ring entry waits for
- * its previous use; RCCL itself wants one collective at a time per communicator). */
+ * calls.  Calls may come on different streams and host threads: they are serialised on
+ * the step object for the duration of the ENQUEUE (a ring entry waits for its previous
+ * use; RCCL wants its collectives issued one at a time and in the same order on every
+ * rank), the enqueued work of different streams still overlaps on the GPU. */
 typedef struct fcp_shard_step fcp_shard_step_t;
 int fcp_shard_step_create(fcp_plan_t *plan, fcp_comm_t *comm, int32_t mode,
                           int32_t group, int64_t max_rows, int64_t max_arena_bytes,

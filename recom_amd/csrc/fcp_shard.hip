@@ -247,6 +247,14 @@ int fcp_shard_exchange_columns(fcp_comm_t *c, const void *block, int64_t rows, c
   const float *src = static_cast<const float *>(block);
   float *dst = static_cast<float *>(recv);
   if (rows * my_width > 0 && !src) return fcp_internal_fail(FCP_ERR_INVALID_ARGUMENT, "null block");
+  // every argument is checked BEFORE the group opens: a rank that left between ncclGroupStart and ncclGroupEnd with
+  // some sends queued would leave its peers waiting for the rest
+  int64_t total_recv = 0;
+  for (int peer = 0; peer < c->world; ++peer) {
+    if (widths[peer] < 0) return fcp_internal_fail(FCP_ERR_INVALID_ARGUMENT, "negative block width");
+    total_recv += my_count * widths[peer];
+  }
+  if (total_recv > 0 && !dst) return fcp_internal_fail(FCP_ERR_INVALID_ARGUMENT, "null receive buffer");
   int e = r->GroupStart();
   if (e != kNcclSuccess) return nccl_fail(r, "ncclGroupStart", e);
   int64_t at = 0;
@@ -255,17 +263,10 @@ int fcp_shard_exchange_columns(fcp_comm_t *c, const void *block, int64_t rows, c
     batch_slice(rows, c->world, peer, &pb, &pc);
     if (pc * my_width > 0) e = r->Send(src + pb * my_width, (size_t)(pc * my_width), kNcclFloat32, peer, c->comm, stream);
     const int64_t n = my_count * widths[peer];
-    if (e == kNcclSuccess && n > 0) {
-      if (!dst) {
-        e = -1;
-        break;
-      }
-      e = r->Recv(dst + at, (size_t)n, kNcclFloat32, peer, c->comm, stream);
-    }
+    if (e == kNcclSuccess && n > 0) e = r->Recv(dst + at, (size_t)n, kNcclFloat32, peer, c->comm, stream);
     at += n;
   }
   const int e2 = r->GroupEnd();
-  if (e == -1) return fcp_internal_fail(FCP_ERR_INVALID_ARGUMENT, "null receive buffer");
   if (e != kNcclSuccess) return nccl_fail(r, "ncclSend / ncclRecv", e);
   if (e2 != kNcclSuccess) return nccl_fail(r, "ncclGroupEnd", e2);
   return FCP_OK;
@@ -291,7 +292,7 @@ struct fcp_shard_step {
   // new call waits for the entry's previous use (event recorded at the end of every run)
   std::vector<hipEvent_t> used;
   std::vector<void *> used_on;
-  std::mutex mu; // the ring cursor (callers on several host threads)
+  std::mutex mu; // held for a whole fcp_shard_step_run: ring cursor, ring entry state, order of the collectives
 };
 
 namespace {
@@ -393,12 +394,12 @@ int fcp_shard_step_destroy(fcp_shard_step_t *s) {
 // *out: device [row_count, width] of this rank's batch slice, valid until `depth` further calls.
 int fcp_shard_step_run(fcp_shard_step_t *s, const fcp_process_args_t *args, void **out, int64_t *row_begin, int64_t *row_count) {
   if (!s || !args || !out) return fcp_internal_fail(FCP_ERR_INVALID_ARGUMENT, "null argument");
-  size_t k;
-  {
-    std::lock_guard<std::mutex> lock(s->mu);
-    k = s->next;
-    s->next = (s->next + 1) % (size_t)s->depth;
-  }
+  // One call at a time per step object: the ring entry's bookkeeping (used / used_on) belongs to the call that holds it,
+  // and the collective inside must be issued in the same order on every rank anyway (RCCL: one operation at a time per
+  // communicator) — host threads that share a step serialise here, their streams still overlap on the GPU.
+  std::lock_guard<std::mutex> lock(s->mu);
+  const size_t k = s->next;
+  s->next = (s->next + 1) % (size_t)s->depth;
   DeviceScope scope;
   int rc = scope.enter(s->device);
   if (rc) return rc;

@@ -209,12 +209,13 @@ def load() -> C.CDLL:
                                           C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
                                           C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.POINTER(C.c_int32))]
     L.fcp_stager_destroy.argtypes = [C.c_void_p]
-    L.fcp_concat_inputs_ex_sizes.argtypes = [C.POINTER(HostTensor), C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64),
-                                             C.POINTER(C.c_int32)]
-    L.fcp_concat_inputs_ex.argtypes = [C.POINTER(HostTensor), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
-                                       C.c_void_p, C.c_void_p]
-    L.fcp_plan_file_stage_info.argtypes = [C.c_char_p, C.POINTER(C.c_int32), C.c_void_p, C.c_void_p, C.c_int32,
-                                           C.POINTER(C.c_int32)]
+    if "FCP_LIB_DIR" not in os.environ or hasattr(L, "fcp_concat_inputs_ex"):  # (an older A/B build may predate these)
+        L.fcp_concat_inputs_ex_sizes.argtypes = [C.POINTER(HostTensor), C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64),
+                                                 C.POINTER(C.c_int32)]
+        L.fcp_concat_inputs_ex.argtypes = [C.POINTER(HostTensor), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                           C.c_void_p, C.c_void_p]
+        L.fcp_plan_file_stage_info.argtypes = [C.c_char_p, C.POINTER(C.c_int32), C.c_void_p, C.c_void_p, C.c_int32,
+                                               C.POINTER(C.c_int32)]
     if L.fcp_abi_version() != FCP_ABI_VERSION:
         raise ImportError("libfcp_hip.so ABI version mismatch; rebuild")
     _lib = L

@@ -347,6 +347,30 @@ def _device_view(torch, ptr: int, numel: int, device):
     return torch.as_tensor(_Holder(), device=device)
 
 
+class _GlooShardedStep:
+    """The sharded step with the exchange staged through the host (``_all_to_all`` under gloo): the interface of
+    :class:`NativeShardedStep`, for ``bench.py --dist-backend gloo`` on a box whose ranks share one GPU."""
+
+    def __init__(self, model, rank: int, world: int, device: int, mode: str) -> None:
+        import torch
+        self.torch = torch
+        self.impl = (ShardedFeatureColumns if mode == "row" else ColumnShardedFeatureColumns)(model, rank, world, device)
+        self.mode = mode
+
+    def prepare(self, inputs, symbols):
+        from .ops import concat_inputs
+        mine = inputs if self.mode == "row" else self.impl.request_inputs(inputs)
+        blob, offsets, shapes = concat_inputs(mine)
+        return (self.torch.from_numpy(blob).to(self.impl.dev), offsets, shapes, symbols)
+
+    def run(self, request):
+        out, begin, count = self.impl(*request)
+        return out, begin, count
+
+    def close(self) -> None:
+        pass
+
+
 def bench_sharded(args, model, placement, rank: int, world: int, local_rank: int, dist) -> dict:
     """`bench.py --workload shard[-col]` once the placement gate has decided to shard (BASELINE.json config 5:
     4000 S2-shaped columns, 480 GB of tables): every rank holds its shard, every request runs partial
@@ -354,8 +378,14 @@ def bench_sharded(args, model, placement, rank: int, world: int, local_rank: int
     import torch
     from .placement import ROW_SHARD
     mode = "row" if placement.mode == ROW_SHARD else "col"
-    comm = Communicator(rank, world, local_rank, dist)
-    step = NativeShardedStep(model, comm, mode)
+    if dist is not None and dist.get_backend() != "nccl":
+        # RCCL refuses two ranks on one device: under gloo (several ranks sharing a GPU, a 1-GPU box exercising the N > 1
+        # control flow) the exchange goes through the host and the step is the Python orchestration of the same kernels
+        step = _GlooShardedStep(model, rank, world, local_rank, mode)
+        comm = None
+    else:
+        comm = Communicator(rank, world, local_rank, dist)
+        step = NativeShardedStep(model, comm, mode)
     reqs = [step.prepare(r.inputs, r.symbols) for r in (model.make_request(s) for s in range(8))]  # ids replicated on every rank
     for i in range(max(args.warmup, 1)):
         step.run(reqs[i % len(reqs)])
@@ -373,7 +403,7 @@ def bench_sharded(args, model, placement, rank: int, world: int, local_rank: int
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     batch = model.batch
@@ -395,7 +425,8 @@ def bench_sharded(args, model, placement, rank: int, world: int, local_rank: int
         par = f"column-sharded x{world}: grouped ncclSend/ncclRecv of final column blocks (RCCL over xGMI) + concat"
     dev_s = e0.elapsed_time(e1) * 1e-3 / args.steps
     step.close()
-    comm.close()
+    if comm is not None:
+        comm.close()
     return {
         "metric": f"inference QPS, {'row' if mode == 'row' else 'column'}-sharded tables (SHARD config)",
         "value": batch * args.steps / elapsed,

@@ -1,7 +1,7 @@
 #!/bin/bash
-# Round 3: interleaved A/B of builds on the ragged path (bench.py, single stream + overlapped): RAGGED as delivered
-# (SparseTensor indices), as staged (CSR offsets + int32 ids), and with long bags (U{0..300}, Zipf ids, 64 columns).
-# Usage: r03_ragged_ab.sh [build dirs...]   (default: build/r02 product)
+# Round 3: interleaved A/B of builds on the ragged path (bench.py, single stream + overlapped): RAGGED as staged (the
+# default: CSR offsets + int32 ids made by ConcatInputs on the host), as delivered (SparseTensor indices on the device),
+# with long bags, and the reference's model E.  Usage: r03_ragged_ab.sh [build dirs...]   (default: build/r02 product)
 cd $GRAFT_REPO_ROOT
 BUILDS=${*:-build/r02 product}
 one() { local d=$1; shift; if [ "$d" != product ]; then export FCP_LIB_DIR=$GRAFT_REPO_ROOT/$d; else unset FCP_LIB_DIR; fi
@@ -11,11 +11,10 @@ r=json.loads(sys.stdin.readline()); o=r.get('overlapped_serving') or {}
 print('%.2f us/request (frac %.3f), p50 %.2f us, overlapped %.2f us' % (r['roofline']['kernel_avg_us'], r['roofline']['frac'], r['p50_latency_ms']*1e3, o.get('us_per_request', float('nan'))))"; }
 for round in 1 2; do
   for d in $BUILDS; do
-    echo -n "round $round $d ragged as delivered: "; one $d --workload ragged
-    echo -n "round $round $d ragged staged      : "; one $d --workload ragged --staged
-    echo -n "round $round $d ragged csr         : "; one $d --workload ragged --seg csr
-    echo -n "round $round $d long bags (64 cols, U{0..300}, zipf, staged): "; one $d --workload ragged --staged --columns 64 --max-len 300 --ids zipf --no-overlap
-    echo -n "round $round $d long bags (512 cols, U{0..100}, staged): "; one $d --workload ragged --staged --max-len 100 --no-overlap
+    echo -n "round $round $d ragged (staged)    : "; one $d --workload ragged
+    echo -n "round $round $d ragged as delivered: "; one $d --workload ragged --as-delivered
+    echo -n "round $round $d long bags (64 cols, U{0..300}, zipf): "; one $d --workload ragged --columns 64 --max-len 300 --ids zipf --no-overlap
+    echo -n "round $round $d long bags (512 cols, U{0..100}): "; one $d --workload ragged --max-len 100 --no-overlap
     echo -n "round $round $d model E: "; one $d --workload e
   done
 done

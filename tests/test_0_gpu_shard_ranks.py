@@ -101,3 +101,94 @@ def test_two_ranks_one_gpu_product_path(mode):
             if p.is_alive():
                 p.kill()
     assert results == {r: "ok" for r in range(world)}, "\n".join(f"rank {r}: {m}" for r, m in results.items())
+
+
+@pytest.mark.parametrize("workload", ["s2", "shard", "shard-col"])
+def test_bench_gpus_2_starts_its_ranks_and_prints_one_line(workload):
+    """`python bench.py --gpus 2` with no launcher: bench.py starts the two ranks itself (torch.distributed.run on
+    127.0.0.1), rank 0 prints ONE JSON line with n_gpus 2 — replicas for a model that fits (S2 reduced), the row- and the
+    column-sharded step for one that does not (the gate is told the GPU is small).  gloo, both ranks on cuda:0: the
+    control flow of the N > 1 run on a 1-GPU box (on a node with N GPUs the backend is RCCL)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["FCP_BENCH_DEVICE"] = "0"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--steps", "20", "--warmup", "5",
+           "--no-cpu-baseline", "--no-pcie", "--no-overlap", "--columns", "48", "--vocab", "5000", "--batch", "64"]
+    if workload != "s2":
+        cmd += ["--workload", workload]
+        env["FCP_BENCH_HBM_BYTES"] = str(24 << 20)              # 48 tables of 160 KB .. 1.3 MB: 29 MB do not fit "one GPU"
+    res = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 20 and rec["value"] > 0 and rec["unit"] == "inferences/s"
+    if workload == "s2":
+        assert rec["scaling"] == "weak" and "replica" in rec["config"]["parallelism"]
+    else:
+        assert ("row-sharded" if workload == "shard" else "column-sharded") in rec["config"]["parallelism"]
+
+
+def _rccl_rank_main(rank, world, port, q):
+    """One rank per GPU, RCCL: the NATIVE sharded step (fcp_shard_step_run: grouped ncclSend / ncclRecv) for both modes
+    against the unsharded oracle."""
+    try:
+        for p in (ROOT, os.path.join(ROOT, "oracle")):
+            if p not in sys.path:
+                sys.path.insert(0, p)
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+        import fcp_oracle as O
+        from recom_amd import synth
+        from recom_amd.ops import concat_inputs
+        from recom_amd.shard import Communicator, NativeShardedStep, batch_slices
+        orc = O.COracle()
+        comm = Communicator(rank, world, rank, dist)
+        for m in (synth.model_mixed(batch=50, vocab=997, n_groups=1), synth.model_s2(columns=64, vocab=5000, batch=96)):
+            tabs_np = m.numpy_tables()
+            for mode in ("row", "col"):
+                step = NativeShardedStep(m, comm, mode)
+                for seed in (0, 1, 2, 3, 4):                      # more requests than ring entries: the ring is reused
+                    req = m.make_request(seed)
+                    want, _ = orc.process_feature_columns(m.spec.to_dict(), *concat_inputs(req.inputs), tabs_np, req.symbols)
+                    ptr, begin, count = step.run(step.prepare(req.inputs, req.symbols))
+                    torch.cuda.synchronize()
+                    assert (begin, count) == batch_slices(want[0].shape[0], world)[rank]
+                    got, ref = step.result(ptr, count).cpu().numpy(), want[0][begin:begin + count]
+                    if mode == "col":
+                        assert np.array_equal(got, ref), (m.name, mode, seed)
+                    else:                                          # partial sums meet in rank order: fp32 reassociation only
+                        assert np.abs(got - ref).max(initial=0) < 1e-5, (m.name, mode, seed)
+                step.close()
+        comm.close()
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception:
+        q.put((rank, traceback.format_exc()))
+
+
+def test_native_sharded_step_over_rccl_two_gpus():
+    """the native RCCL step (grouped send / recv layout, batch-slice order against fcp_shard_finalize, ring
+    reuse) with world = 2 on two GPUs, both modes, against the unsharded oracle.  Needs 2 GPUs (skipped on the 1-GPU
+    boxes of this pool; `torch.cuda.device_count()` does not initialise the GPU in the parent)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    ctx = multiprocessing.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rccl_rank_main, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, status in results:
+        assert status == "ok", f"rank {rank}:\n{status}"

@@ -596,3 +596,24 @@ def test_staged_concat_inputs_and_the_stage_section(L, tmp_path):
         load_stage(bad)
     with pytest.raises(ValueError):
         ConcatInputs([1, 2], path)                                 # input count differs from the stage section
+
+
+def test_bench_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus N` with no launcher around it (WORLD_SIZE unset) starts N ranks itself through
+    torch.distributed.run on 127.0.0.1, before anything touches the GPU; the dry run prints the command."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["FCP_BENCH_DRY_LAUNCH"] = "1"
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "7", "--workload", "shard"],
+                         capture_output=True, text=True, env=env, timeout=120)
+    assert res.returncode == 0, res.stderr
+    cmd = json.loads(res.stdout.strip().splitlines()[-1])["launch"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    tail = cmd[cmd.index(os.path.join(ROOT, "bench.py")) + 1:]
+    assert tail == ["--gpus", "8", "--steps", "7", "--workload", "shard"]
+    # N = 1 never launches anything
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, env=env, timeout=120)
+    assert res.returncode == 0 and "--gpus" in res.stdout
