@@ -732,6 +732,66 @@ int64_t orc_process_feature_columns(const orc_plan_t *p, const int8_t *blob,
  * requests (blob + offsets + shapes; equal row counts, nnz may differ) so that the touched
  * table rows are not cache-resident.
  * Returns the elapsed seconds for n_threads * calls_per_thread requests, or -1. */
+/* The same protocol for a fixed DURATION: every worker serves requests until `seconds` have passed (the clock is read
+ * between requests), so that every worker count of a sweep is measured for the same time.  Returns the number of
+ * requests all workers completed, *elapsed = the wall time from the common start to the last worker's finish, or -1. */
+int64_t orc_serve_for(const orc_plan_t *p, const int8_t *const *blobs, int32_t n_blobs,
+                      const int32_t *const *offsets, const int32_t *const *shapes,
+                      const float *const *tables, const int32_t *symbols, int32_t n_threads,
+                      double seconds, double *elapsed) {
+#ifdef _OPENMP
+  if (n_threads < 1 || !(seconds > 0.0) || n_blobs < 1 || !elapsed) return -1;
+  for (int32_t r = 0; r < n_blobs; ++r)
+    for (int32_t g = 0; g < p->n_groups; ++g)
+      if (orc_group_rows(p, g, shapes[r], symbols) < 0 ||
+          orc_group_rows(p, g, shapes[r], symbols) != orc_group_rows(p, g, shapes[0], symbols))
+        return -1; /* requests may differ in nnz, not in rows */
+  double t0 = 0.0, t1 = 0.0;
+  int64_t total = 0;
+  int failed = 0;
+#pragma omp parallel num_threads(n_threads) reduction(+ : total)
+  {
+    float **out = (float **)malloc(sizeof(float *) * (size_t)p->n_groups);
+    int ok = out != NULL;
+    for (int32_t g = 0; ok && g < p->n_groups; ++g) {
+      const size_t n = (size_t)orc_group_rows(p, g, shapes[0], symbols) * (size_t)orc_group_width(p, g);
+      out[g] = (float *)calloc(n ? n : 1, sizeof(float));
+      if (!out[g]) ok = 0;
+    }
+    int32_t r = (int32_t)(((int64_t)omp_get_thread_num() * 7) % n_blobs);
+    if (ok) (void)orc_process_feature_columns(p, blobs[r], offsets[r], shapes[r], tables, symbols, out, 1); /* warm */
+#pragma omp barrier
+#pragma omp master
+    t0 = omp_get_wtime();
+#pragma omp barrier
+    if (ok) {
+      const double stop = t0 + seconds;
+      do {
+        r = (r + 1) % n_blobs;
+        (void)orc_process_feature_columns(p, blobs[r], offsets[r], shapes[r], tables, symbols, out, 1);
+        ++total;
+      } while (omp_get_wtime() < stop);
+    }
+#pragma omp barrier
+#pragma omp master
+    t1 = omp_get_wtime();
+    if (!ok) {
+#pragma omp atomic write
+      failed = 1;
+    }
+    if (out) {
+      for (int32_t g = 0; g < p->n_groups; ++g) free(out[g]);
+      free(out);
+    }
+  }
+  *elapsed = t1 - t0;
+  return failed ? -1 : total;
+#else
+  (void)p; (void)blobs; (void)n_blobs; (void)offsets; (void)shapes; (void)tables; (void)symbols; (void)n_threads; (void)seconds; (void)elapsed;
+  return -1;
+#endif
+}
+
 double orc_serve_throughput(const orc_plan_t *p, const int8_t *const *blobs, int32_t n_blobs,
                             const int32_t *const *offsets, const int32_t *const *shapes,
                             const float *const *tables, const int32_t *symbols, int32_t n_threads,

@@ -262,6 +262,31 @@ class COracle:
             raise ValueError("oracle: serve_throughput failed")
         return float(el)
 
+    def serve_for(self, plan: dict, requests: Sequence, tables: Sequence[np.ndarray], symbols=None,
+                  n_threads: int = 1, seconds: float = 1.0):
+        """(requests completed, elapsed seconds): `n_threads` independent single-threaded workers serve requests,
+        rotating over `requests`, for `seconds` each (orc_serve_for)."""
+        p, _keep = self._make_plan(plan)
+        bl = [np.ascontiguousarray(r[0]).view(np.int8) for r in requests]
+        of = [_i32(r[1]) for r in requests]
+        sh = [_i32(r[2]) for r in requests]
+        n = len(bl)
+        bptrs = (C.c_void_p * n)(*[b.ctypes.data for b in bl])
+        optrs = (C.c_void_p * n)(*[o.ctypes.data for o in of])
+        sptrs = (C.c_void_p * n)(*[x.ctypes.data for x in sh])
+        sym = None if symbols is None else _i32(symbols)
+        tabs = [np.ascontiguousarray(t, np.float32) for t in tables]
+        tptrs = (C.c_void_p * max(1, len(tabs)))(*[t.ctypes.data for t in tabs])
+        el = C.c_double(0.0)
+        self.lib.orc_serve_for.restype = C.c_int64
+        self.lib.orc_serve_for.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_int32, C.c_double, C.POINTER(C.c_double)]
+        done = self.lib.orc_serve_for(C.byref(p), bptrs, n, optrs, sptrs, tptrs, None if sym is None else sym.ctypes.data,
+                                      n_threads, float(seconds), C.byref(el))
+        if done < 0:
+            raise ValueError("oracle: serve_for failed")
+        return int(done), float(el.value)
+
     def process_feature_columns(self, plan: dict, blob: np.ndarray, offsets, shapes,
                                 tables: Sequence[np.ndarray], symbols=None, n_threads: int = 1,
                                 out: Optional[List[np.ndarray]] = None):
