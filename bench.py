@@ -89,12 +89,13 @@ def pcie_inclusive():
                    "`recom_amd/fcp_bench --h2d 1 --narrow 1 [--zero-copy 1]`; h2d_copy: one hipMemcpyAsync on the stager's stream; "
                    "zero_copy: the kernel reads the pinned ring over PCIe itself (FCP_STAGER_ZERO_COPY)"}
     for key, extra in (("h2d_copy", []), ("zero_copy", ["--zero-copy", "1"])):
-        cmd = [exe, "--h2d", "1", "--narrow", "1", "--steps", "300", "--warmup", "50", "--verify", "0"] + extra
+        cmd = [exe, "--h2d", "1", "--narrow", "1", "--steps", "300", "--warmup", "50", "--verify", "0", "--pack-threads", "16"] + extra
         try:
             res = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
             line = [ln for ln in res.stdout.splitlines() if ln.startswith("{") and "pcie_inclusive" in ln][-1]
             r = json.loads(line)
-            out[key] = {k: r[k] for k in ("pack_threads", "blob_MB", "us_per_request_pipelined", "us_latency_single", "inferences_per_s")}
+            out[key] = {k: r[k] for k in ("pack_threads", "blob_MB", "us_per_request_pipelined", "us_latency_single", "inferences_per_s",
+                                          "host_us_stage_call", "host_us_process_call", "h2d_copy_alone_us", "h2d_GBs") if k in r}
         except Exception as e:  # the bench line must not depend on this extra
             out[key] = {"error": f"{type(e).__name__}: {e}"[:300]}
     return out

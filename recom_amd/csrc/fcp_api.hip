@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -1896,6 +1897,9 @@ struct fcp_stager {
   std::mutex mu;
   std::vector<int64_t> byte_off; // scratch
   bool zero_copy = false;        // the kernels read the pinned ring over PCIe themselves (no H2D copy)
+  // FCP_STAGER_STATS=1: where a call spends its host time (ns per phase, printed when the stager is destroyed)
+  bool stats = false;
+  uint64_t n_calls = 0, ns_wait = 0, ns_layout = 0, ns_pack = 0, ns_enqueue = 0, ns_api[4] = {0, 0, 0, 0};
 };
 
 extern "C" {
@@ -1925,6 +1929,7 @@ int fcp_stager_create_ex(int32_t device, int64_t capacity_bytes, int32_t max_inp
   s->max_rank_sum = max_rank_sum;
   s->n_threads = n_threads;
   s->zero_copy = (flags & FCP_STAGER_ZERO_COPY) != 0;
+  s->stats = std::getenv("FCP_STAGER_STATS") != nullptr;
   s->slots.resize(depth);
   for (auto &sl : s->slots) {
     if (hipHostMalloc(reinterpret_cast<void **>(&sl.h_blob), capacity_bytes, hipHostMallocMapped) != hipSuccess ||
@@ -2040,6 +2045,10 @@ int fcp_stager_stage_ex(fcp_stager_t *s, const fcp_host_tensor_t *inputs, int32_
   if (rc) return rc;
   hipStream_t user = static_cast<hipStream_t>(stream);
   std::lock_guard<std::mutex> lock(s->mu);
+  auto now_ns = [] { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const uint64_t t_begin = s->stats ? now_ns() : 0;
+  static const bool early_wake = std::getenv("FCP_STAGER_NO_EARLY_WAKE") == nullptr; // tuning aid
+  if (early_wake) s->pool->expect(); // the pack workers wake up while this thread waits for the slot and lays the blob out
   // whatever consumes the previous slot has been enqueued on the caller's stream by now
   if (s->last >= 0) {
     StageSlot &prev = s->slots[s->last];
@@ -2055,6 +2064,7 @@ int fcp_stager_stage_ex(fcp_stager_t *s, const fcp_host_tensor_t *inputs, int32_
   } else if (hipEventQuery(sl.copied) != hipSuccess) {
     HIP_TRY(hipEventSynchronize(sl.copied));
   }
+  const uint64_t t_waited = s->stats ? now_ns() : 0;
   // sizes / offsets / shapes (stage_layout), then the pack: contiguous ranges of inputs per chunk, ~equal bytes
   int rc2 = stage_layout(inputs, n, modes, mode_args, s->capacity, s->max_rank_sum, s->byte_off.data(), sl.offsets, sl.shapes, nullptr);
   if (rc2) return rc2;
@@ -2062,6 +2072,7 @@ int fcp_stager_stage_ex(fcp_stager_t *s, const fcp_host_tensor_t *inputs, int32_
   const int chunks = (int)std::min<int64_t>(std::max<int64_t>(1, size / (64 << 10)), 4 * s->n_threads);
   const int64_t *bo = s->byte_off.data();
   char *dst = sl.h_blob;
+  const uint64_t t_layout = s->stats ? now_ns() : 0;
   s->pool->run(chunks, [&](int c) {
     const int64_t b0 = size * c / chunks, b1 = size * (c + 1) / chunks;
     // inputs whose start offset falls in [b0, b1)
@@ -2070,14 +2081,28 @@ int fcp_stager_stage_ex(fcp_stager_t *s, const fcp_host_tensor_t *inputs, int32_
     for (; lo < hi; ++lo)
       stage_pack_one(inputs[lo], modes ? modes[lo] : FCP_STAGE_COPY, mode_args ? mode_args[lo] : 0, dst + bo[lo], bo[lo + 1] - bo[lo]);
   });
+  const uint64_t t_packed = s->stats ? now_ns() : 0;
   if (!s->zero_copy) {
     // the device twin is free once the work that read its previous contents has run
+    uint64_t a0 = s->stats ? now_ns() : 0, a1;
     if (sl.consumed_valid) HIP_TRY(hipStreamWaitEvent(s->copy_stream, sl.consumed, 0));
+    if (s->stats) { a1 = now_ns(); s->ns_api[0] += a1 - a0; a0 = a1; }
     if (size) HIP_TRY(hipMemcpyAsync(sl.d_blob, sl.h_blob, (size_t)size, hipMemcpyHostToDevice, s->copy_stream));
+    if (s->stats) { a1 = now_ns(); s->ns_api[1] += a1 - a0; a0 = a1; }
     HIP_TRY(hipEventRecord(sl.copied, s->copy_stream));
+    if (s->stats) { a1 = now_ns(); s->ns_api[2] += a1 - a0; a0 = a1; }
     HIP_TRY(hipStreamWaitEvent(user, sl.copied, 0));
+    if (s->stats) { a1 = now_ns(); s->ns_api[3] += a1 - a0; }
   } else {
     __atomic_thread_fence(__ATOMIC_SEQ_CST); // the packed bytes are in memory before the launch that reads them is queued
+  }
+  if (s->stats) {
+    const uint64_t t_end = now_ns();
+    ++s->n_calls;
+    s->ns_wait += t_waited - t_begin;
+    s->ns_layout += t_layout - t_waited;
+    s->ns_pack += t_packed - t_layout;
+    s->ns_enqueue += t_end - t_packed;
   }
   s->last = slot_idx;
   if (device_blob) *device_blob = sl.d_blob;
@@ -2121,6 +2146,12 @@ int fcp_stager_stage(fcp_stager_t *s, const fcp_host_tensor_t *inputs, int32_t n
 
 int fcp_stager_destroy(fcp_stager_t *s) {
   if (!s) return FCP_OK;
+  if (s->stats && s->n_calls)
+    std::fprintf(stderr, "fcp_stager: %llu calls, host us per call: wait for the slot %.2f, layout %.2f, pack %.2f (%d threads), enqueue %.2f "
+                         "(wait-event on the copy stream %.2f, hipMemcpyAsync %.2f, event record %.2f, wait-event on the request's stream %.2f)\n",
+                 (unsigned long long)s->n_calls, s->ns_wait / 1e3 / s->n_calls, s->ns_layout / 1e3 / s->n_calls, s->ns_pack / 1e3 / s->n_calls,
+                 s->n_threads, s->ns_enqueue / 1e3 / s->n_calls, s->ns_api[0] / 1e3 / s->n_calls, s->ns_api[1] / 1e3 / s->n_calls,
+                 s->ns_api[2] / 1e3 / s->n_calls, s->ns_api[3] / 1e3 / s->n_calls);
   DeviceGuard guard;
   (void)guard.enter(s->device);
   delete s->pool;

@@ -104,6 +104,7 @@ int main(int argc, char **argv) {
   int zero_copy = std::getenv("FCP_STAGER_ZERO_COPY") ? 1 : 0; // with --h2d: no copy, the kernel reads the pinned ring over PCIe
   int fixed_dim = 0;        // 0: dims cycle 8/16/32/64 (S2); D: every column has dim D (E/F-like models: --dim 8)
   int pack_threads = 8;
+  int stager_depth = 4;     // with --h2d: slots of the stager's pinned ring
   long vocab = 1000000;
   for (int i = 1; i + 1 < argc; i += 2) {
     std::string k = argv[i];
@@ -124,6 +125,7 @@ int main(int argc, char **argv) {
     else if (k == "--zero-copy") zero_copy = (int)v;
     else if (k == "--dim") fixed_dim = (int)v;
     else if (k == "--pack-threads") pack_threads = (int)v;
+    else if (k == "--stager-depth") stager_depth = (int)v;
     else if (k == "--bw-probe") {
       const char *names[4] = {"read", "write", "write-nt", "chunked-write-nt"};
       for (int kind = 0; kind < 4; ++kind) {
@@ -365,7 +367,7 @@ int main(int argc, char **argv) {
       if (!std::getenv("FCP_STAGER_NO_PIN") && fcp::cpus_near_device(0, &near)) (void)sched_setaffinity(0, sizeof(near), &near);
     }
     fcp_stager_t *st = nullptr;
-    CHECK_FCP(fcp_stager_create_ex(0, (int64_t)blobs[0].size() + 4096, columns, columns, 4, pack_threads,
+    CHECK_FCP(fcp_stager_create_ex(0, (int64_t)blobs[0].size() + 4096, columns, columns, stager_depth, pack_threads,
                                    zero_copy ? FCP_STAGER_ZERO_COPY : FCP_STAGER_DEFAULT, &st));
     std::vector<uint8_t> nflags(columns, 0);
     size_t shipped = blobs[0].size();
@@ -397,25 +399,32 @@ int main(int argc, char **argv) {
     struct RingCtx { std::vector<void *> *r; size_t i; } rc{&ring, 0};
     hipStream_t stream;
     CHECK_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    double host_stage_us = 0, host_process_us = 0; // host time inside the two calls (the pipelined loop is host-bound when their sum exceeds the copy)
     auto one = [&](int k) {
       const int v = k % requests;
       fcp_process_args_t a;
       std::memset(&a, 0, sizeof(a));
+      const auto h0 = std::chrono::steady_clock::now();
       CHECK_FCP(fcp_stager_stage_narrow(st, host[v].data(), columns, narrow ? nflags.data() : nullptr, stream,
                                         &a.concated_inputs, &a.concated_bytes, &a.concated_offsets,
                                         &a.concated_shapes));
+      const auto h1 = std::chrono::steady_clock::now();
       a.input_ptrs = tables.data();
       a.stream = stream;
       a.malloc_buff_ctx = &rc;
       a.malloc_buff = [](void *ctx, size_t) -> void * { auto *x = static_cast<RingCtx *>(ctx); return (*x->r)[x->i++ % x->r->size()]; };
       CHECK_FCP(fcp_process_feature_columns(plan, &a, nullptr));
+      host_stage_us += std::chrono::duration<double, std::micro>(h1 - h0).count();
+      host_process_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - h1).count();
     };
     for (int k = 0; k < warmup + 1; ++k) one(k);
     CHECK_HIP(hipStreamSynchronize(stream));
+    host_stage_us = host_process_us = 0;
     const auto t0 = std::chrono::steady_clock::now();
     for (int k = 0; k < steps; ++k) one(k);
     CHECK_HIP(hipStreamSynchronize(stream));
     const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / steps;
+    const double hs = host_stage_us / steps, hp = host_process_us / steps;
     // single-request latency: stage + process + sync, nothing else in flight
     double lat = 0;
     for (int k = 0; k < 50; ++k) {
@@ -424,9 +433,27 @@ int main(int argc, char **argv) {
       CHECK_HIP(hipStreamSynchronize(stream));
       lat += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - a0).count();
     }
+    // the floor of this loop: what the box's host-to-device link does with a blob of this size (pinned memory,
+    // back-to-back hipMemcpyAsync on one stream: the copies of a pipelined run follow each other the same way)
+    double copy_us = 0;
+    {
+      void *hp_buf = nullptr, *dp_buf = nullptr;
+      CHECK_HIP(hipHostMalloc(&hp_buf, shipped, hipHostMallocDefault));
+      CHECK_HIP(hipMalloc(&dp_buf, shipped));
+      std::memset(hp_buf, 1, shipped);
+      for (int k = 0; k < 10; ++k) CHECK_HIP(hipMemcpyAsync(dp_buf, hp_buf, shipped, hipMemcpyHostToDevice, stream));
+      CHECK_HIP(hipStreamSynchronize(stream));
+      const auto c0 = std::chrono::steady_clock::now();
+      for (int k = 0; k < 100; ++k) CHECK_HIP(hipMemcpyAsync(dp_buf, hp_buf, shipped, hipMemcpyHostToDevice, stream));
+      CHECK_HIP(hipStreamSynchronize(stream));
+      copy_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - c0).count() / 100;
+      CHECK_HIP(hipFree(dp_buf));
+      CHECK_HIP(hipHostFree(hp_buf));
+    }
     std::printf("{\"pcie_inclusive\": true, \"zero_copy\": %d, \"pack_threads\": %d, \"blob_MB\": %.2f, \"us_per_request_pipelined\": %.2f, "
-                "\"us_latency_single\": %.2f, \"inferences_per_s\": %.0f}\n",
-                zero_copy, pack_threads, shipped / 1e6, us, lat / 50, batch / (us * 1e-6));
+                "\"us_latency_single\": %.2f, \"inferences_per_s\": %.0f, \"host_us_stage_call\": %.2f, \"host_us_process_call\": %.2f, "
+                "\"h2d_copy_alone_us\": %.2f, \"h2d_GBs\": %.1f}\n",
+                zero_copy, pack_threads, shipped / 1e6, us, lat / 50, batch / (us * 1e-6), hs, hp, copy_us, shipped / copy_us / 1e3);
     CHECK_FCP(fcp_stager_destroy(st));
     CHECK_FCP(fcp_plan_destroy(plan));
     return 0;

@@ -5,6 +5,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <cstdint>
+#include <cstdlib>
 #include <mutex>
 #include <pthread.h>
 #include <sched.h>
@@ -15,11 +16,14 @@
 namespace fcp {
 
 // Persistent worker pool: parallel_for over [0, n_chunks).  Requests arrive every few tens of
-// microseconds, so workers spin for a short while after each job before they go to sleep
-// (a futex wake-up costs more than packing one request).  Chunk claims carry the job's
-// epoch and chunk count together with the next chunk index in one 64-bit word and advance by
-// compare-exchange, so a worker that is late leaving job e can neither run nor skip a chunk
-// of job e+1.
+// microseconds and a futex wake-up costs about as much as packing one request, so the workers
+// are woken EARLY — `expect()` at the top of a staging call, several microseconds before the job
+// is published — and spin only from then until the job arrives (bounded), never between requests:
+// workers that spun through the gaps (round 2: ~1-2 ms after every job) kept the HIP runtime's own
+// threads off their CPUs, and the hipMemcpyAsync that follows the pack blocked for ~50 us
+// (profiles/r03_pcie_staging_api_call_timers.txt).  Chunk claims carry the job's epoch and chunk
+// count together with the next chunk index in one 64-bit word and advance by compare-exchange, so
+// a worker that is late leaving job e can neither run nor skip a chunk of job e+1.
 class PackPool {
 public:
   // `affinity` (optional): CPUs the workers may run on
@@ -41,6 +45,16 @@ public:
     }
     cv_.notify_all();
     for (auto &w : workers_) w.join();
+  }
+  // A job is about to be published: wake the workers now, so that their wake-up latency overlaps whatever
+  // the caller still does before run().  Harmless if no job follows (they spin kSpins and sleep again).
+  void expect() {
+    if (workers_.empty()) return;
+    expected_.fetch_add(1, std::memory_order_release);
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+    }
+    cv_.notify_all();
   }
   template <typename F> void run(int n_chunks, F &&fn) {
     if (workers_.empty() || n_chunks <= 1) {
@@ -85,25 +99,34 @@ private:
     }
   }
   void loop() {
-    uint64_t seen = 0;
+    uint64_t seen = 0, seen_expect = 0;
     for (;;) {
       uint64_t e;
-      int spins = 0;
+      int spins = kSpins; // asleep until a job is announced (expect) or published (run)
       while ((e = epoch_.load(std::memory_order_acquire)) == seen) {
         if (stop_.load(std::memory_order_acquire)) return;
         if (++spins < kSpins) {
           __builtin_ia32_pause();
         } else {
           std::unique_lock<std::mutex> lk(mu_);
-          cv_.wait(lk, [&] { return epoch_.load(std::memory_order_acquire) != seen || stop_.load(std::memory_order_acquire); });
-          spins = 0;
+          cv_.wait(lk, [&] {
+            return epoch_.load(std::memory_order_acquire) != seen || expected_.load(std::memory_order_acquire) != seen_expect ||
+                   stop_.load(std::memory_order_acquire);
+          });
+          seen_expect = expected_.load(std::memory_order_acquire);
+          spins = 0; // announced: spin until the job is there, at most kSpins pauses
         }
       }
       seen = e;
       work(e);
     }
   }
-  static constexpr int kSpins = 1 << 16; // ~1-2 ms of pause instructions: longer than the gap between requests under load
+  // how long a woken worker spins for the announced job: ~20-40 us of pause instructions, a few times the layout phase
+  // that separates expect() from run() (FCP_PACK_SPINS: tuning aid)
+  const int kSpins = [] {
+    const char *e = std::getenv("FCP_PACK_SPINS");
+    return e ? std::atoi(e) : 1 << 10;
+  }();
   cpu_set_t affinity_;
   bool pinned_ = false;
   std::vector<std::thread> workers_;
@@ -111,7 +134,7 @@ private:
   std::condition_variable cv_;
   void (*call_)(void *, int) = nullptr;
   void *ctx_ = nullptr;
-  std::atomic<uint64_t> next_{0}, epoch_{0};
+  std::atomic<uint64_t> next_{0}, epoch_{0}, expected_{0};
   std::atomic<int> pending_{0};
   std::atomic<bool> stop_{false};
 };

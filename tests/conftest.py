@@ -22,6 +22,29 @@ def oracle():
     return fcp_oracle.COracle()
 
 
+@pytest.fixture(scope="session")
+def ref_bucketize():
+    """The REFERENCE's own `Bucketize` (cuda_emitter.cc:233-247), compiled from its source where it lies by the recipe
+    oracle/ref_extract.py into oracle/_ref/libref_bucketize.so (built in the container that has /root/reference; the built
+    library travels to the GPU box).  Returns f(boundaries, values) -> int32 bucket ids."""
+    import ctypes as C
+    import ref_extract
+    if not ref_extract.build():
+        pytest.skip("oracle/_ref/libref_bucketize.so is absent and /root/reference is not here to build it from")
+    lib = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libref_bucketize.so"))
+    lib.ref_bucketize_many.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]
+    lib.ref_bucketize_max_boundaries.restype = C.c_int
+
+    def run(boundaries, values):
+        b = np.ascontiguousarray(boundaries, np.float32)
+        v = np.ascontiguousarray(values, np.float32).ravel()
+        assert 1 <= b.size <= lib.ref_bucketize_max_boundaries()
+        out = np.empty(v.size, np.int32)
+        lib.ref_bucketize_many(b.ctypes.data, int(b.size), v.ctypes.data, int(v.size), out.ctypes.data)
+        return out
+    return run
+
+
 class GoldenCase:
     def __init__(self, z, name):
         self.name = name

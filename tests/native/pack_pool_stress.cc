@@ -3,7 +3,9 @@
 // size, each checked for "every chunk ran exactly once"; jobs are short so that workers
 // are regularly still leaving job e when job e+1 is published.
 #include <cstdio>
+#include <chrono>
 #include <cstdlib>
+#include <thread>
 #include <vector>
 
 #include "pack_pool.h"
@@ -21,6 +23,8 @@ int main(int argc, char **argv) {
     rng ^= rng << 17;
     const int n = 1 + (int)(rng % 200);
     for (int c = 0; c < n; ++c) hits[c].store(0, std::memory_order_relaxed);
+    if (rng & 64) pool.expect();                                       // announced jobs, unannounced jobs ...
+    if ((rng & 0x3f00) == 0) { pool.expect(); std::this_thread::sleep_for(std::chrono::microseconds(150)); } // ... and announcements nothing follows in time
     pool.run(n, [&](int c) {
       hits[c].fetch_add(1, std::memory_order_relaxed);
       if ((c & 7) == 0) {

@@ -8,6 +8,8 @@ star's 1e-5 max-abs-diff of the float64 expectation.
 import copy
 import dataclasses
 
+import sys
+
 import numpy as np
 import pytest
 
@@ -1122,6 +1124,45 @@ def test_id_transforms_on_device(torch_cuda, oracle, batch, seed):
     out, packed, dop = run_gpu(torch, dspec, req.inputs, dt, req.symbols)
     _, dbad = assert_equal_oracle(oracle, dspec, packed, dt, req.symbols, out)
     assert dbad > 0 and dop.plan.read_bad_ids() == dbad
+
+
+def test_bucketize_tiers_against_the_reference_itself(torch_cuda, ref_bucketize):
+    """The HIP kernels' three ways to find a bucket (computed boundaries, guess + verify, binary search; dense and ragged
+    bodies) against the REFERENCE's own `Bucketize`, compiled from its source (oracle/ref_extract.py, cuda_emitter.cc:233-247)
+    — no restatement in between.  Each column reads an identity table (row r = [r, r, r, r]), so the output IS the bucket."""
+    from recom_amd.plan import (COMBINER_NONE, COMBINER_SUM, FORM_GATHER, FORM_SEGMENT_REDUCE, IDS_F32_BUCKETIZE, ROWS_FROM_IDS,
+                                ROWS_FROM_SYMBOL, SEG_CSR_I32, SEG_NONE, ColumnSpec, PlanSpec)
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_oracle import _bucketize_cases
+    rng = np.random.default_rng(5)
+    cases = list(_bucketize_cases(rng))
+    n = max(len(x) for _, _, x in cases)
+    cols, ranks, esz, tables, inputs = [], [], [], [], []
+    for slot, (name, b, x) in enumerate(cases):
+        inputs.append(np.concatenate([x, np.full(n - len(x), x[0], np.float32)]))
+        ranks.append(1)
+        esz.append(4)
+        tables.append(np.repeat(np.arange(len(b) + 1, dtype=np.float32)[:, None], 4, axis=1))
+        cols.append(ColumnSpec(FORM_GATHER, 4, len(b) + 1, COMBINER_NONE, IDS_F32_BUCKETIZE, slot, slot, -1, SEG_NONE, 1,
+                               ROWS_FROM_IDS, 0, b, 0, slot))
+    out, _, _ = run_gpu(torch_cuda, PlanSpec(cols, ranks, esz, len(tables)), inputs, tables, None)
+    got = out.groups[0].cpu().numpy()
+    for k, (name, b, x) in enumerate(cases):
+        assert np.array_equal(got[:, 4 * k].astype(np.int32), ref_bucketize(b, inputs[k])), ("dense", name)
+    # the same columns pooled one value per row (sum of one row = the row), which routes them through the ragged body
+    offs = np.arange(n + 1, dtype=np.int32)
+    rcols, rranks, resz, rinputs = [], [], [], []
+    for slot, (name, b, x) in enumerate(cases):
+        rinputs += [inputs[slot], offs]
+        rranks += [1, 1]
+        resz += [4, 4]
+        rcols.append(ColumnSpec(FORM_SEGMENT_REDUCE, 4, len(b) + 1, COMBINER_SUM, IDS_F32_BUCKETIZE, slot, 2 * slot, 2 * slot + 1,
+                                SEG_CSR_I32, 1, ROWS_FROM_SYMBOL, 0, b, 0, slot))
+    out, _, _ = run_gpu(torch_cuda, PlanSpec(rcols, rranks, resz, len(tables), n_symbols=1), rinputs, tables, np.asarray([n], np.int32))
+    got = out.groups[0].cpu().numpy()
+    for k, (name, b, x) in enumerate(cases):
+        assert np.array_equal(got[:, 4 * k].astype(np.int32), ref_bucketize(b, inputs[k])), ("ragged", name)
 
 
 def test_bucketize_tiers_are_exact(torch_cuda, oracle):

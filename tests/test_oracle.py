@@ -343,3 +343,38 @@ def test_fingerprint64_known_answers(oracle):
         assert fp(s) == O.np_fingerprint64(s), s
         for buckets in (1, 7, 100, 10_000, 2**31 - 1):
             assert L.orc_hash_bucket_int64(int(v), buckets) == O.np_fingerprint64(s) % buckets
+
+
+def _bucketize_cases(rng):
+    arrays = {
+        "reference 0,5,...,495": np.arange(0, 500, 5, dtype=np.float32),
+        "dyadic grid": (np.arange(37, dtype=np.float32) * np.float32(0.375) - np.float32(3.0)),
+        "two boundaries": np.asarray([-1.0, 2.0], np.float32),
+        "tenths": (np.arange(200) * 0.1).astype(np.float32),
+        "thirds": (np.arange(1, 90) / 3.0).astype(np.float32),
+        "log spaced": np.logspace(-3, 4, 150).astype(np.float32),
+        "random": np.unique(rng.uniform(-50, 50, 300).astype(np.float32)),
+        "single": np.asarray([7.5], np.float32),
+        "huge step": np.asarray([-3e38, 0.0, 3e38], np.float32),
+        "1024 random": np.unique(rng.standard_normal(4000).astype(np.float32))[:1024],
+        "with duplicates": np.sort(np.repeat(rng.uniform(0, 10, 40).astype(np.float32), 2)),
+    }
+    for name, b in arrays.items():
+        x = np.concatenate([b, np.nextafter(b, np.float32(-np.inf)), np.nextafter(b, np.float32(np.inf)), (b[:-1] + b[1:]) / 2,
+                            [np.nan, np.inf, -np.inf, 0.0, -0.0, b[0] - 1, b[-1] + 1, 3.4e38, -3.4e38],
+                            rng.uniform(b[0] - 3, b[-1] + 3, 300)]).astype(np.float32)
+        yield name, b, x
+
+
+def test_bucketize_is_pinned_by_the_reference_itself(oracle, ref_bucketize):
+    """a5 is the one function of the path whose reference source is plain C++ inside its string literal: compiled from
+    /root/reference by oracle/ref_extract.py (no copy in the repository), it pins the oracle's restatement and the NumPy
+    twin on boundary-exact values, their float neighbours, NaN, infinities and signed zeros, for evenly spaced, uneven,
+    duplicated and single-element boundary lists."""
+    import fcp_oracle as O
+    rng = np.random.default_rng(5)
+    for name, b, x in _bucketize_cases(rng):
+        want = ref_bucketize(b, x)
+        assert np.array_equal(oracle.bucketize(b, x), want), name
+        ok = ~np.isnan(x)                                   # searchsorted sorts NaN last: the same bucket (n) as the reference
+        assert np.array_equal(O.np_bucketize(b, x)[ok], want[ok]) and np.all(want[~ok] == len(b)), name
