@@ -474,6 +474,27 @@ int fcp_concat_inputs_ex(const fcp_host_tensor_t *inputs, int32_t n_inputs,
 int fcp_plan_file_stage_info(const char *path, int32_t *n_inputs, uint8_t *modes,
                              int32_t *rows_symbol, int32_t capacity, int32_t *symbols_input);
 
+/* ---- plan builder from a GraphDef (replaces CudaEmitter::Optimize, cuda_emitter.cc:80-116) ---- */
+/* The non-codegen half of the reference's CudaEmitter as ONE in-process call for the retained Grappler pass: where
+ * the reference generates CUDA text per feature column (EmitFCCode, cuda_emitter.cc:975-1178), runs nvcc, caches the
+ * .so by md5 and rewrites the graph (Rewrite, :2496-2656), the pass serialises its GraphDef, calls fcp_graph_build and
+ * parses what comes back.  `graphdef`: a serialized tensorflow.GraphDef in the form the reference's emitter sees (after
+ * the lookup optimizers, lookup_optimizer.cc:157-440).  The column plan is WRITTEN to `plan_path` (the file the
+ * rewritten FeatureColumnProcess names in `dlpath`); *rewritten receives the serialized rewritten GraphDef
+ * (malloc'd; fcp_graph_free) unless `rewritten` is NULL; *description a human-readable summary (fcp_graph_free), may
+ * be NULL.  FCP_ERR_UNSUPPORTED: no ConcatV2 of embedding lookups in this graph ("nothing to fuse": the pass leaves
+ * the graph alone).  No TensorFlow, no protobuf library, no Python, no device.  The same walk exists as an offline
+ * tool (`python -m recom_amd.graph`); both write identical plan files (tests/test_graph_plan.py). */
+enum {
+  FCP_GRAPH_HOST_CONCAT_EXTERNAL = 1u << 0, /* non-lookup concat inputs stay Addons>ConcatOutputs host inputs (the
+                                               reference's wiring) instead of passthrough columns                 */
+  FCP_GRAPH_STAGED = 1u << 1,               /* the staged plan + stage section; ConcatInputs gets `_fcp_plan`       */
+  FCP_GRAPH_NO_PRUNE = 1u << 2              /* keep the replaced subgraphs in the output graph                     */
+};
+int fcp_graph_build(const void *graphdef, size_t n_bytes, uint32_t flags, const char *plan_path,
+                    void **rewritten, size_t *rewritten_bytes, char **description);
+void fcp_graph_free(void *p);
+
 /* ---- multi-GPU exchange (no reference counterpart) ---------- */
 /* The ONE collective of the sharded path: an all-to-all partitioned along the batch,
  * issued as grouped ncclSend / ncclRecv (RCCL) to every peer at once so that all

@@ -16,7 +16,7 @@
 #endif
 
 // int64 -> int32; values that do not fit are not valid ids / rows anyway: -1 (reads as zeros on the device)
-extern "C" __attribute__((visibility("hidden"))) FCP_CLONES void fcp_pack_narrow_i64(const int64_t *src, int32_t *dst, int64_t n) {
+extern "C" FCP_CLONES void fcp_pack_narrow_i64(const int64_t *src, int32_t *dst, int64_t n) {
   for (int64_t k = 0; k < n; ++k) {
     const int64_t v = src[k];
     dst[k] = (uint64_t)v <= 0x7fffffffull ? (int32_t)v : -1;
@@ -69,7 +69,7 @@ template <typename T> static inline void seg_to_csr_t(const T *p, int64_t stride
   }
 }
 
-extern "C" __attribute__((visibility("hidden"))) FCP_CLONES void fcp_pack_seg_to_csr(const void *seg, int elem_size, int64_t stride, int64_t nnz, int64_t rows, int32_t *out) {
+extern "C" FCP_CLONES void fcp_pack_seg_to_csr(const void *seg, int elem_size, int64_t stride, int64_t nnz, int64_t rows, int32_t *out) {
   if (elem_size == 8) seg_to_csr_t(static_cast<const int64_t *>(seg), stride, nnz, rows, out);
   else seg_to_csr_t(static_cast<const int32_t *>(seg), stride, nnz, rows, out);
 }

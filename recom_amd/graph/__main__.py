@@ -25,7 +25,23 @@ def main(argv=None) -> int:
                          "SparseTensor indices of pooled columns into int32 row offsets (the plan file's stage section tells it "
                          "how; the rewritten ConcatInputs node names the plan in its `_fcp_plan` attr and receives the symbols "
                          "vector as one more input) - the device then runs neither the segment-offset pre-pass nor a search")
+    ap.add_argument("--native", action="store_true",
+                    help="build through the C ABI (fcp_graph_build, recom_amd/csrc/fcp_graph.cc) - the in-process entry of the "
+                         "retained Grappler pass; binary .pb graphs only; same plan file, same rewritten graph")
     args = ap.parse_args(argv)
+    if args.native:
+        from . import native_build
+        try:
+            graph, text = native_build(open(args.graph, "rb").read(), args.plan, args.host_concat, args.staged,
+                                       prune=not args.no_prune, want_graph=bool(args.out))
+        except Unsupported as why:
+            print(f"{why}", file=sys.stderr)
+            return 1
+        print(text)
+        if args.out:
+            with open(args.out, "wb") as f:
+                f.write(graph)
+        return 0
     gd = load_graphdef(args.graph)
     try:
         built = build_plan(gd, args.host_concat)

@@ -479,3 +479,63 @@ def test_staged_rewrite_matches_the_original_graph(oracle, tmp_path, which):
     got = GraphEvaluator(out_gd, variables, oracle_ops(oracle, built, variables)).run(fetches, feeds)
     for e, o in zip(expected, got):
         assert e.shape == o.shape and np.array_equal(e, o)
+
+
+def _fixture_graphs():
+    yield "canonical", canonical_model(B=41, seed=2)[0]
+    yield "microbenchmark", microbenchmark_model(columns=12, B=32, seed=1)[0]
+    yield "id_filter", id_filter_model(B=37, seed=1)[0]
+    yield "sparse_reshape", sparse_reshape_model(B=23, seed=0)[0]
+    yield "resource_variable", resource_variable_model(B=16, seed=3)[0]
+    yield "unsupported-in-part", canonical_model(B=9, seed=0, unsupported=True)[0]
+    for seed in range(24):
+        yield f"random{seed}", random_model(seed)[0]
+
+
+@pytest.mark.parametrize("host_concat", ["passthrough", "external"])
+@pytest.mark.parametrize("staged", [False, True])
+def test_native_plan_builder_matches_the_python_one(tmp_path, host_concat, staged):
+    """the plan builder behind the C ABI (fcp_graph_build, recom_amd/csrc/fcp_graph.cc: own GraphDef
+    wire reader / writer, no protobuf library, no Python) — what the retained Grappler pass calls in place of
+    CudaEmitter::Optimize (cuda_emitter.cc:80-116).  On every fixture graph both builders write the SAME plan file, byte
+    for byte, and rewritten graphs that are equal as GraphDef messages."""
+    from recom_amd.graph import native_build
+    n = 0
+    for name, gd in _fixture_graphs():
+        data = gd.SerializeToString()
+        py_plan, c_plan = str(tmp_path / f"{name}.py.fcp"), str(tmp_path / f"{name}.c.fcp")
+        built = build_plan(gd, host_concat)
+        stage = None
+        if staged:
+            spec, stage = built.spec.staged_for_concat_inputs()
+            save_plan(spec, py_plan, stage)
+        else:
+            save_plan(built.spec, py_plan)
+        c_graph, desc = native_build(data, c_plan, host_concat, staged)
+        assert open(c_plan).read() == open(py_plan).read(), name
+        # the rewritten graphs name their plan file: give both the same name before comparing
+        want = rewrite_graph(gd, built, c_plan, stage=stage)
+        got = parse_graphdef(c_graph)
+        assert len(got.node) == len(want.node), name
+        for a, b in zip(got.node, want.node):
+            assert a == b, (name, a.name, b.name)
+        assert got == want, name
+        assert desc.splitlines()[0] == built.describe().splitlines()[0], name
+        n += 1
+    assert n >= 30
+
+
+def test_native_plan_builder_errors(tmp_path):
+    from recom_amd.graph import native_build
+    from recom_amd.lib import FcpError
+    g = P.GraphDef()
+    g.node.add(name="x", op="Placeholder").attr["dtype"].type = P.DT_FLOAT
+    with pytest.raises(Unsupported):                               # nothing to fuse: the pass leaves the graph alone
+        native_build(g.SerializeToString(), str(tmp_path / "x.fcp"))
+    with pytest.raises(FcpError):                                  # not a GraphDef
+        native_build(b"\xff\xff\xff\xff\x01", str(tmp_path / "y.fcp"))
+    gd = canonical_model()[0]
+    with pytest.raises(FcpError):                                  # the plan file cannot be written
+        native_build(gd.SerializeToString(), str(tmp_path / "no" / "such" / "dir" / "z.fcp"))
+    graph, _ = native_build(gd.SerializeToString(), str(tmp_path / "k.fcp"), prune=False)
+    assert len(parse_graphdef(graph).node) > len(gd.node)          # nothing pruned: the original nodes + the new ones
