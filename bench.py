@@ -285,7 +285,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--workload", default="s2", choices=["s2", "dlrm", "ragged", "shard", "shard-col", "e", "f"])
+    ap.add_argument("--workload", default="s2", choices=["s2", "dlrm", "ragged", "shard", "shard-row", "shard-col", "e", "f"],
+                    help="shard = BASELINE configs[4] (4000 columns, 480 GB) placed by the gate's mixed preference: whole tables "
+                         "wherever a table fits one GPU, rows only for those that do not (configs[4]: every table fits -> "
+                         "column blocks, 8x fewer bytes on the wire); shard-row / shard-col force one kind")
     ap.add_argument("--seg", default="indices", choices=["indices", "csr", "rowids32"],
                     help="ragged: how row membership arrives - SparseTensor indices [nnz, 2] int64 (what BASELINE configs[3] "
                          "names and TF graphs deliver; default), CSR offsets or int32 row ids")
@@ -341,7 +344,7 @@ def main():
         else:
             dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
 
-    if args.workload in ("shard", "shard-col"):
+    if args.workload in ("shard", "shard-row", "shard-col"):
         # BASELINE.json config 5: 4000 S2-shaped columns (480 GB); the flag names the model and the preferred sharding
         model = synth.model_shard(columns=args.columns or 4000, **({'vocab': args.vocab} if args.vocab else {}),
                                   **({'batch': args.batch} if args.batch else {}))
@@ -374,7 +377,7 @@ def main():
         # FCP_BENCH_HBM_BYTES: testing aid — pretend the GPU is this small, so that a toy model takes the sharded branch
         hbm_override = os.environ.get("FCP_BENCH_HBM_BYTES")
         placement = decide_placement(model.spec, world, hbm_bytes=int(hbm_override) if hbm_override else device_hbm_bytes(local_rank),
-                                     prefer="column" if args.workload == "shard-col" else "row",
+                                     prefer={"shard-col": "column", "shard-row": "row"}.get(args.workload, "mixed" if args.workload == "shard" else "row"),
                                      **({"reserve_bytes": 0} if hbm_override else {}))
     except FcpError as e:                            # the tables fit no placement on this many GPUs
         if rank == 0:

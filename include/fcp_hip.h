@@ -323,7 +323,16 @@ int fcp_plan_table_bytes(const fcp_plan_t *plan, int64_t *shard_bytes,
  * GPU are the tables sharded over the `world` GPUs of the node, by whole columns
  * (final blocks exchanged, bit-identical results; needs every table to fit one GPU)
  * or by rows (partial sums exchanged + fcp_shard_finalize; any table size). */
-enum { FCP_PLACE_REPLICATE = 0, FCP_PLACE_COLUMN_SHARD = 1, FCP_PLACE_ROW_SHARD = 2 };
+enum {
+  FCP_PLACE_REPLICATE = 0,
+  FCP_PLACE_COLUMN_SHARD = 1,
+  FCP_PLACE_ROW_SHARD = 2,
+  /* whole tables wherever a table fits one GPU, rows only for the tables that do not: the fewest bytes on the wire
+   * (a whole column sends its FINAL block, 1/world of a row-sharded column's dense partial sums).  As a preference
+   * (prefer_mode) it resolves to COLUMN_SHARD when every table fits, to MIXED when some do not, and falls back to
+   * ROW_SHARD when whole tables cannot be packed. */
+  FCP_PLACE_MIXED = 3
+};
 typedef struct fcp_placement {
   int32_t mode;          /* FCP_PLACE_*                                        */
   int32_t min_world;     /* fewest GPUs on which the tables fit at all          */
@@ -332,11 +341,18 @@ typedef struct fcp_placement {
 /* table_bytes[n_tables]: bytes of every (unsharded) table; hbm_bytes: one GPU's
  * memory; reserve_bytes: what must stay free (arenas, request blobs, runtime);
  * prefer_mode: FCP_PLACE_COLUMN_SHARD or FCP_PLACE_ROW_SHARD, taken when both are
- * feasible.  FCP_ERR_UNSUPPORTED (with min_world set) when the tables do not fit
- * `world` GPUs. */
+ * feasible, or FCP_PLACE_MIXED.  FCP_ERR_UNSUPPORTED (with min_world set) when the
+ * tables do not fit `world` GPUs. */
 int fcp_placement_decide(const int64_t *table_bytes, int32_t n_tables,
                          int64_t hbm_bytes, int64_t reserve_bytes, int32_t world,
                          int32_t prefer_mode, fcp_placement_t *out);
+/* The same decision with the assignment: owner[t] = the rank that holds table t whole, or -1 = its rows are spread over
+ * all ranks (every table under ROW_SHARD; under MIXED only the tables larger than one GPU's budget), or 0 under
+ * REPLICATE (every rank holds everything).  Whole tables are dealt longest-first onto the least loaded rank, on top of
+ * the row shares every rank holds. */
+int fcp_placement_assign(const int64_t *table_bytes, int32_t n_tables,
+                         int64_t hbm_bytes, int64_t reserve_bytes, int32_t world,
+                         int32_t prefer_mode, int32_t *owner, fcp_placement_t *out);
 
 /* total concat width of a group (sum of dims in slot order)
  * and the element offset of a column inside its group. */
@@ -379,6 +395,13 @@ int fcp_concat_outputs_scatter(const void *const *inputs, const int32_t *dims,
                                const int32_t *col_offsets, int32_t n,
                                int64_t prefix_size, int32_t out_width, void *out,
                                void *stream);
+/* The same for inputs that are column ranges of wider matrices: input k has row stride in_strides[k] floats
+ * (>= dims[k]; NULL: contiguous).  The mixed-placement step assembles its output this way from the row-sharded
+ * part and every rank's whole-column block. */
+int fcp_concat_outputs_scatter_strided(const void *const *inputs, const int32_t *dims,
+                                       const int32_t *in_strides, const int32_t *col_offsets,
+                                       int32_t n, int64_t prefix_size, int32_t out_width,
+                                       void *out, void *stream);
 /* Addons>ConcatOutputs `host_inputs` (concat_outputs_op_gpu.cu.cc:186-216): the n
  * HOST tensors ([prefix, dims[k]], 4-byte elements) are packed into one pinned
  * staging buffer (library-owned, per device) and scattered into columns

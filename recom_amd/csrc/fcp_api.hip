@@ -1420,12 +1420,12 @@ int fcp_plan_table_bytes(const fcp_plan_t *p, int64_t *shard_bytes, int64_t *max
   return FCP_OK;
 }
 
-int fcp_placement_decide(const int64_t *table_bytes, int32_t n_tables, int64_t hbm_bytes, int64_t reserve_bytes,
-                         int32_t world, int32_t prefer_mode, fcp_placement_t *out) {
+int fcp_placement_assign(const int64_t *table_bytes, int32_t n_tables, int64_t hbm_bytes, int64_t reserve_bytes, int32_t world,
+                         int32_t prefer_mode, int32_t *owner, fcp_placement_t *out) {
   if (!out || n_tables < 0 || (n_tables > 0 && !table_bytes) || hbm_bytes <= 0 || reserve_bytes < 0 || world < 1)
     return fail(FCP_ERR_INVALID_ARGUMENT, "bad placement arguments");
-  if (prefer_mode != FCP_PLACE_COLUMN_SHARD && prefer_mode != FCP_PLACE_ROW_SHARD)
-    return fail(FCP_ERR_INVALID_ARGUMENT, "prefer_mode must be column or row sharding");
+  if (prefer_mode != FCP_PLACE_COLUMN_SHARD && prefer_mode != FCP_PLACE_ROW_SHARD && prefer_mode != FCP_PLACE_MIXED)
+    return fail(FCP_ERR_INVALID_ARGUMENT, "prefer_mode must be column sharding, row sharding or mixed");
   const int64_t budget = hbm_bytes - reserve_bytes;
   if (budget <= 0) return fail(FCP_ERR_INVALID_ARGUMENT, "reserve_bytes leaves no room for tables");
   int64_t total = 0, largest = 0;
@@ -1437,29 +1437,71 @@ int fcp_placement_decide(const int64_t *table_bytes, int32_t n_tables, int64_t h
   out->min_world = (int32_t)std::max<int64_t>(1, (total + budget - 1) / budget);
   out->mode = FCP_PLACE_REPLICATE;
   out->bytes_per_gpu = total;
+  if (owner)
+    for (int32_t t = 0; t < n_tables; ++t) owner[t] = 0;
   if (total <= budget) return FCP_OK; // fits one GPU: replicas, no collective
   // row sharding: every table contributes ceil(rows / world) rows to every GPU (at most one row's worth of
   // rounding per table, ignored here: tables are >> one row)
   const int64_t row_share = (total + world - 1) / world;
   const bool row_ok = world > 1 && row_share <= budget;
-  // column sharding: whole tables per GPU — longest-processing-time packing as the feasibility test
-  int64_t col_share = 0;
-  bool col_ok = world > 1 && largest <= budget;
-  if (col_ok) {
-    std::vector<int64_t> sorted(table_bytes, table_bytes + n_tables), load(world, 0);
-    std::sort(sorted.begin(), sorted.end(), [](int64_t a, int64_t b) { return a > b; });
-    for (int64_t b : sorted) *std::min_element(load.begin(), load.end()) += b;
-    col_share = *std::max_element(load.begin(), load.end());
-    col_ok = col_share <= budget;
+  // whole tables, longest first onto the least loaded rank (longest-processing-time packing), on top of the row
+  // share of the tables that are spread: `spread_over` = the threshold above which a table is spread by rows
+  std::vector<int32_t> assign(n_tables, -1);
+  auto pack = [&](int64_t spread_over, int64_t *share) {
+    int64_t spread = 0;
+    std::vector<int32_t> order;
+    for (int32_t t = 0; t < n_tables; ++t) {
+      if (table_bytes[t] > spread_over) {
+        spread += table_bytes[t];
+        assign[t] = -1;
+      } else {
+        order.push_back(t);
+      }
+    }
+    std::vector<int64_t> load(world, (spread + world - 1) / world);
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return table_bytes[a] > table_bytes[b]; });
+    for (int32_t t : order) {
+      const int32_t r = (int32_t)(std::min_element(load.begin(), load.end()) - load.begin());
+      load[r] += table_bytes[t];
+      assign[t] = r;
+    }
+    *share = *std::max_element(load.begin(), load.end());
+    return *share <= budget;
+  };
+  int64_t col_share = 0, mixed_share = 0;
+  const bool col_ok = world > 1 && largest <= budget && pack(INT64_MAX, &col_share);
+  int mode;
+  if (prefer_mode == FCP_PLACE_MIXED) {
+    if (col_ok) mode = FCP_PLACE_COLUMN_SHARD;                                       // every table fits a GPU: no rows spread at all
+    else if (world > 1 && largest > budget && pack(budget, &mixed_share)) mode = FCP_PLACE_MIXED;
+    else if (row_ok) mode = FCP_PLACE_ROW_SHARD;
+    else mode = -1;
+  } else {
+    if (!row_ok && !col_ok) mode = -1;
+    else mode = (col_ok && (prefer_mode == FCP_PLACE_COLUMN_SHARD || !row_ok)) ? FCP_PLACE_COLUMN_SHARD : FCP_PLACE_ROW_SHARD;
   }
-  if (!row_ok && !col_ok)
+  if (mode < 0)
     return fail(FCP_ERR_UNSUPPORTED, "tables of " + std::to_string(total) + " bytes do not fit " + std::to_string(world) +
                                          " GPU(s) with " + std::to_string(budget) + " bytes each: needs at least " +
                                          std::to_string(out->min_world));
-  const bool col = col_ok && (prefer_mode == FCP_PLACE_COLUMN_SHARD || !row_ok);
-  out->mode = col ? FCP_PLACE_COLUMN_SHARD : FCP_PLACE_ROW_SHARD;
-  out->bytes_per_gpu = col ? col_share : row_share;
+  out->mode = mode;
+  if (mode == FCP_PLACE_COLUMN_SHARD) {
+    (void)pack(INT64_MAX, &col_share); // (the mixed attempt may have run after it)
+    out->bytes_per_gpu = col_share;
+  } else if (mode == FCP_PLACE_MIXED) {
+    out->bytes_per_gpu = mixed_share;
+  } else {
+    out->bytes_per_gpu = row_share;
+    std::fill(assign.begin(), assign.end(), -1);
+  }
+  if (owner)
+    for (int32_t t = 0; t < n_tables; ++t) owner[t] = assign[t];
   return FCP_OK;
+}
+
+int fcp_placement_decide(const int64_t *table_bytes, int32_t n_tables, int64_t hbm_bytes, int64_t reserve_bytes,
+                         int32_t world, int32_t prefer_mode, fcp_placement_t *out) {
+  return fcp_placement_assign(table_bytes, n_tables, hbm_bytes, reserve_bytes, world, prefer_mode, nullptr, out);
 }
 
 int fcp_plan_release_captures(fcp_plan_t *p) {
@@ -1675,7 +1717,7 @@ int fcp_concat_outputs(const void *const *inputs, const int32_t *dims, int32_t n
     width += dims[k];
   }
   if (width > 0x7fffffff) return fail(FCP_ERR_UNSUPPORTED, "concat width exceeds 2^31");
-  const int e = fcp_launch_concat_outputs(inputs, dims, nullptr, n, prefix_size, (int32_t)width, 0, out,
+  const int e = fcp_launch_concat_outputs(inputs, dims, nullptr, nullptr, n, prefix_size, (int32_t)width, 0, out,
                                           static_cast<hipStream_t>(stream));
   if (e) return hip_fail("concat-outputs launch", (hipError_t)e);
   return FCP_OK;
@@ -1719,14 +1761,23 @@ HostStageRing *host_stage_ring(int device) {
 }
 } // namespace
 
-int fcp_concat_outputs_scatter(const void *const *inputs, const int32_t *dims, const int32_t *col_offsets, int32_t n,
-                               int64_t prefix_size, int32_t out_width, void *out, void *stream) {
+int fcp_concat_outputs_scatter_strided(const void *const *inputs, const int32_t *dims, const int32_t *in_strides,
+                                       const int32_t *col_offsets, int32_t n, int64_t prefix_size, int32_t out_width, void *out,
+                                       void *stream) {
   int rc = check_scatter_args(inputs, dims, col_offsets, n, prefix_size, out_width, out);
   if (rc || n == 0 || prefix_size == 0) return rc;
-  const int e = fcp_launch_concat_outputs(inputs, dims, col_offsets, n, prefix_size, out_width, 0, out,
+  if (in_strides)
+    for (int32_t k = 0; k < n; ++k)
+      if (in_strides[k] < dims[k]) return fail(FCP_ERR_INVALID_ARGUMENT, "input row stride smaller than its width");
+  const int e = fcp_launch_concat_outputs(inputs, dims, col_offsets, in_strides, n, prefix_size, out_width, 0, out,
                                           static_cast<hipStream_t>(stream));
   if (e) return hip_fail("concat-outputs launch", (hipError_t)e);
   return FCP_OK;
+}
+
+int fcp_concat_outputs_scatter(const void *const *inputs, const int32_t *dims, const int32_t *col_offsets, int32_t n,
+                               int64_t prefix_size, int32_t out_width, void *out, void *stream) {
+  return fcp_concat_outputs_scatter_strided(inputs, dims, nullptr, col_offsets, n, prefix_size, out_width, out, stream);
 }
 
 int fcp_concat_outputs_host(const void *const *host_inputs, const int32_t *dims, const int32_t *col_offsets, int32_t n,
@@ -1784,7 +1835,7 @@ int fcp_concat_outputs_host(const void *const *host_inputs, const int32_t *dims,
     }
     std::vector<const void *> d_in(n);
     for (int32_t k = 0; k < n; ++k) d_in[k] = src + at[k];
-    const int e = fcp_launch_concat_outputs(d_in.data(), dims, col_offsets, n, prefix_size, out_width, 0, out, stream);
+    const int e = fcp_launch_concat_outputs(d_in.data(), dims, col_offsets, nullptr, n, prefix_size, out_width, 0, out, stream);
     if (e) return hip_fail("concat-outputs launch", (hipError_t)e);
     HIP_TRY(hipEventRecord(sl.copied, stream)); // the slot is free once its last reader (copy or scatter) has run
   }

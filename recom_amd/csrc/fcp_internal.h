@@ -124,9 +124,10 @@ int fcp_launch_hybrid(const FcpLaunch &Ldense, int dense_blocks, const FcpLaunch
                       ihipStream_t *s);
 int fcp_launch_upload(const void *host_mapped_src, void *dst, size_t bytes, ihipStream_t *s);
 int fcp_launch_segment_offsets(const FcpSegLaunch &L, int n_seg_cols, int max_nnz, ihipStream_t *s);
-// col_offsets: destination column of every input, or NULL = side by side starting at first_off
-int fcp_launch_concat_outputs(const void *const *inputs, const int32_t *dims, const int32_t *col_offsets, int32_t n,
-                              int64_t prefix, int32_t width, int32_t first_off, void *out,
+// col_offsets: destination column of every input, or NULL = side by side starting at first_off;
+// in_strides: row stride of every input in floats, or NULL = contiguous [prefix, dims[k]] inputs
+int fcp_launch_concat_outputs(const void *const *inputs, const int32_t *dims, const int32_t *col_offsets, const int32_t *in_strides,
+                              int32_t n, int64_t prefix, int32_t width, int32_t first_off, void *out,
                               ihipStream_t *s);
 int fcp_launch_shard_finalize(const FcpLaunch &L, int group, const float *partials, int world,
                               int64_t row_begin, int64_t row_count, float *out, int vec,

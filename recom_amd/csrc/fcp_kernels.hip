@@ -1263,6 +1263,7 @@ struct FcpConcatArgs {
   const float *in[FCP_CONCAT_CHUNK];
   int32_t off[FCP_CONCAT_CHUNK];
   int32_t dim[FCP_CONCAT_CHUNK];
+  int32_t stride[FCP_CONCAT_CHUNK]; // row stride of the input in floats (= dim for a contiguous [prefix, dim] input)
   float *out;
   int64_t prefix;
   int32_t width;
@@ -1282,7 +1283,7 @@ template <int VEC> __global__ void __launch_bounds__(FCP_BLOCK_THREADS) fcp_conc
   const int e = chunk * tx + lx;
   if (p >= A.prefix || e >= dimv) return;
   typedef typename VecType<VEC>::T T;
-  const T v = *as_global(reinterpret_cast<const T *>(A.in[k]) + (p * dimv + e));
+  const T v = *as_global(reinterpret_cast<const T *>(A.in[k]) + (p * (A.stride[k] / VEC) + e));
   __builtin_nontemporal_store(v, as_global(reinterpret_cast<T *>(A.out + (p * A.width + A.off[k])) + e));
 }
 
@@ -1467,8 +1468,8 @@ int fcp_launch_segment_offsets(const FcpSegLaunch &L, int n_seg_cols, int max_nn
   return (int)hipGetLastError();
 }
 
-int fcp_launch_concat_outputs(const void *const *inputs, const int32_t *dims, const int32_t *col_offsets, int32_t n,
-                              int64_t prefix, int32_t width, int32_t first_off, void *out,
+int fcp_launch_concat_outputs(const void *const *inputs, const int32_t *dims, const int32_t *col_offsets, const int32_t *in_strides,
+                              int32_t n, int64_t prefix, int32_t width, int32_t first_off, void *out,
                               ihipStream_t *s) {
   int32_t off = first_off;
   for (int32_t begin = 0; begin < n; begin += FCP_CONCAT_CHUNK) {
@@ -1478,6 +1479,7 @@ int fcp_launch_concat_outputs(const void *const *inputs, const int32_t *dims, co
     for (int32_t k = 0; k < m; ++k) {
       A.in[k] = static_cast<const float *>(inputs[begin + k]);
       A.dim[k] = dims[begin + k];
+      A.stride[k] = in_strides ? in_strides[begin + k] : dims[begin + k];
       A.off[k] = col_offsets ? col_offsets[begin + k] : off;
       off += dims[begin + k];
       if (dims[begin + k] > max_dim) max_dim = dims[begin + k];
@@ -1490,7 +1492,8 @@ int fcp_launch_concat_outputs(const void *const *inputs, const int32_t *dims, co
     int vec = 4;
     uintptr_t bits = reinterpret_cast<uintptr_t>(out) | (uintptr_t)(4u * (uint32_t)width);
     for (int32_t k = 0; k < m; ++k)
-      bits |= reinterpret_cast<uintptr_t>(A.in[k]) | (uintptr_t)(4u * (uint32_t)A.dim[k]) | (uintptr_t)(4u * (uint32_t)A.off[k]);
+      bits |= reinterpret_cast<uintptr_t>(A.in[k]) | (uintptr_t)(4u * (uint32_t)A.dim[k]) | (uintptr_t)(4u * (uint32_t)A.off[k]) |
+              (uintptr_t)(4u * (uint32_t)A.stride[k]);
     while (vec > 1 && (bits & (uintptr_t)(4 * vec - 1))) vec >>= 1;
     const int max_dimv = (max_dim + vec - 1) / vec;
     int tx_log2 = 0;

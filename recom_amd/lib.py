@@ -107,7 +107,7 @@ EXPORTS = [
     "fcp_shard_step_create", "fcp_shard_step_run", "fcp_shard_step_destroy",
     "fcp_stager_create", "fcp_stager_create_ex", "fcp_stager_stage", "fcp_stager_stage_ex", "fcp_stager_stage_narrow", "fcp_stager_destroy",
     "fcp_concat_inputs_ex_sizes", "fcp_concat_inputs_ex", "fcp_plan_file_stage_info",
-    "fcp_graph_build", "fcp_graph_free",
+    "fcp_graph_build", "fcp_graph_free", "fcp_placement_assign", "fcp_concat_outputs_scatter_strided",
 ]
 
 _lib = None
@@ -221,6 +221,10 @@ def load() -> C.CDLL:
                                       C.POINTER(C.c_char_p)]
         L.fcp_graph_free.argtypes = [C.c_void_p]
         L.fcp_graph_free.restype = None
+        L.fcp_placement_assign.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p,
+                                           C.POINTER(Placement)]
+        L.fcp_concat_outputs_scatter_strided.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                                         C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]
     if L.fcp_abi_version() != FCP_ABI_VERSION:
         raise ImportError("libfcp_hip.so ABI version mismatch; rebuild")
     _lib = L

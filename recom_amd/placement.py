@@ -24,8 +24,9 @@ from .plan import FORM_GATHER, FORM_GATHER_SCATTER, FORM_SEGMENT_REDUCE, PlanSpe
 MI355X_HBM_BYTES = 288 * 10**9          # HBM3E per GPU (MI355X_MICROARCH.md)
 DEFAULT_RESERVE_BYTES = 8 << 30         # arenas, request blobs, RCCL buffers, runtime
 
-REPLICATE, COLUMN_SHARD, ROW_SHARD = 0, 1, 2
-MODE_NAMES = {REPLICATE: "replicas", COLUMN_SHARD: "column-sharded", ROW_SHARD: "row-sharded"}
+REPLICATE, COLUMN_SHARD, ROW_SHARD, MIXED = 0, 1, 2, 3
+MODE_NAMES = {REPLICATE: "replicas", COLUMN_SHARD: "column-sharded", ROW_SHARD: "row-sharded",
+              MIXED: "mixed (whole tables where they fit, rows for the rest)"}
 
 
 @dataclass
@@ -34,6 +35,7 @@ class Placement:
     min_world: int
     bytes_per_gpu: int
     total_bytes: int
+    owners: Optional[Sequence[int]] = None      # per table input: the rank that holds it whole, or -1 = spread by rows
 
     @property
     def name(self) -> str:
@@ -51,17 +53,20 @@ def table_bytes(spec: PlanSpec) -> np.ndarray:
 
 def decide_placement(spec_or_bytes, world: int, hbm_bytes: Optional[int] = None,
                      reserve_bytes: int = DEFAULT_RESERVE_BYTES, prefer: str = "row") -> Placement:
-    """``spec_or_bytes``: a :class:`PlanSpec` or the table sizes in bytes.  Raises
+    """``spec_or_bytes``: a :class:`PlanSpec` or the table sizes in bytes; ``prefer``: "row", "column" or "mixed" (whole
+    tables wherever a table fits one GPU, rows only for those that do not: the fewest bytes on the wire).  Raises
     :class:`recom_amd.lib.FcpError` (``FCP_ERR_UNSUPPORTED``) when the tables do not fit ``world``
     GPUs; the message names the smallest world that would do."""
     L = _lib.load()
     tb = table_bytes(spec_or_bytes) if isinstance(spec_or_bytes, PlanSpec) else np.asarray(spec_or_bytes, np.int64)
     tb = np.ascontiguousarray(tb, np.int64)
     out = _lib.Placement()
-    _lib.check(L.fcp_placement_decide(tb.ctypes.data, len(tb), int(hbm_bytes or MI355X_HBM_BYTES), int(reserve_bytes),
-                                      int(world), {"row": ROW_SHARD, "column": COLUMN_SHARD}[prefer], C.byref(out)),
-               "fcp_placement_decide")
-    return Placement(out.mode, out.min_world, out.bytes_per_gpu, int(tb.sum()))
+    owners = np.zeros(len(tb), np.int32)
+    _lib.check(L.fcp_placement_assign(tb.ctypes.data, len(tb), int(hbm_bytes or MI355X_HBM_BYTES), int(reserve_bytes),
+                                      int(world), {"row": ROW_SHARD, "column": COLUMN_SHARD, "mixed": MIXED}[prefer],
+                                      owners.ctypes.data, C.byref(out)),
+               "fcp_placement_assign")
+    return Placement(out.mode, out.min_world, out.bytes_per_gpu, int(tb.sum()), [int(o) for o in owners])
 
 
 def device_hbm_bytes(device: int = 0) -> int:

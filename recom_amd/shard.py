@@ -164,12 +164,12 @@ class ColumnShardedFeatureColumns:
     ``[count, width]`` matrix is assembled by ``fcp_concat_outputs`` from the received
     column blocks."""
 
-    def __init__(self, model, rank: int, world: int, device: int, group=None) -> None:
+    def __init__(self, model, rank: int, world: int, device: int, group=None, assignment=None) -> None:
         import torch
         from .ops import FeatureColumnProcess
         self.torch = torch
         self.model = model
-        self.assignment = assign_columns(model.spec, world)
+        self.assignment = assignment if assignment is not None else assign_columns(model.spec, world)
         self.sub = model.spec.column_subset(self.assignment[rank])
         self.dev = torch.device("cuda", device)
         self.op = FeatureColumnProcess(self.sub.spec, device)
@@ -259,7 +259,9 @@ class NativeShardedStep:
     grouped ncclSend / ncclRecv over xGMI -> ``fcp_shard_finalize`` (row mode) or concat (column mode), on
     one stream, from buffers the library owns.  Python prepares the request records once."""
 
-    def __init__(self, model, comm: Communicator, mode: str = "row", group: int = 0) -> None:
+    def __init__(self, model, comm: Communicator, mode: str = "row", group: int = 0, assignment=None) -> None:
+        """``assignment`` (column mode): the columns every rank owns, as lists of column indices in concat order; default:
+        contiguous ranges of about equal width (:func:`assign_columns`)."""
         import ctypes as C
         import torch
         from . import lib as _lib
@@ -275,7 +277,7 @@ class NativeShardedStep:
             widths = None
         else:
             from .synth import hash_table_torch
-            assignment = assign_columns(model.spec, world)
+            assignment = assignment if assignment is not None else assign_columns(model.spec, world)
             sub = model.spec.column_subset(assignment[rank])
             self.spec, self.host_inputs = sub.spec, sub.host_inputs
             self.tables = [hash_table_torch(model.tables[i].seed, model.tables[i].vocab, model.tables[i].dim, self.dev)
@@ -347,24 +349,177 @@ def _device_view(torch, ptr: int, numel: int, device):
     return torch.as_tensor(_Holder(), device=device)
 
 
+def mixed_assignment(spec, owners: Sequence[int], world: int):
+    """The gate's per-table decision (``Placement.owners``: a rank, or -1 = spread by rows) as column sets:
+    ``(row_cols, per_rank)`` — the columns whose table is spread over all ranks, and per rank the columns it holds
+    whole, both in plan order.  Table-free columns (passthrough, Sum) go with rank 0's whole columns."""
+    row_cols = [k for k, c in enumerate(spec.columns) if c.table_input >= 0 and owners[c.table_input] < 0]
+    per_rank: List[List[int]] = [[] for _ in range(world)]
+    for k, c in enumerate(spec.columns):
+        if c.table_input < 0:
+            per_rank[0].append(k)
+        elif owners[c.table_input] >= 0:
+            per_rank[owners[c.table_input]].append(k)
+    return row_cols, per_rank
+
+
+def _mixed_pieces(spec, row_cols, per_rank, group: int = 0):
+    """How the output row [width of the group] is put together: pieces ``(source, source offset, destination offset,
+    width)`` with source 0 = the row-sharded part's result (its columns side by side in plan order) and source 1 = the
+    whole-column part's result (rank 0's block, rank 1's block, ...); neighbouring pieces are merged."""
+    offs = spec.column_offsets()
+    src_of = {}
+    at = 0
+    for k in row_cols:
+        if spec.columns[k].concat_group == group:
+            src_of[k] = (0, at)
+            at += spec.columns[k].dim
+    w_row = at
+    at = 0
+    for cols in per_rank:
+        for k in cols:
+            if spec.columns[k].concat_group == group:
+                src_of[k] = (1, at)
+                at += spec.columns[k].dim
+    w_col = at
+    pieces = []
+    for k in sorted(src_of, key=lambda k: offs[k]):
+        src, so = src_of[k]
+        d = spec.columns[k].dim
+        if pieces and pieces[-1][0] == src and pieces[-1][1] + pieces[-1][3] == so and pieces[-1][2] + pieces[-1][3] == offs[k]:
+            pieces[-1] = (src, pieces[-1][1], pieces[-1][2], pieces[-1][3] + d)
+        else:
+            pieces.append((src, so, offs[k], d))
+    return pieces, w_row, w_col
+
+
+class MixedShardedStep:
+    """``FCP_PLACE_MIXED``: tables larger than one GPU are spread by rows (partial sums exchanged + ``fcp_shard_finalize``),
+    every other table lives whole on the rank the gate dealt it to (final column blocks exchanged) — two native steps
+    per request and one strided scatter (``fcp_concat_outputs_scatter_strided``) that puts their results side by side in
+    concat order.  A whole column sends 1/world of what the same column sends as a dense partial sum, so only the tables
+    that MUST be spread pay that price (BASELINE configs[4], every table fits: the row part is empty and this is the
+    column-sharded step)."""
+
+    def __init__(self, model, comm: Communicator, owners: Sequence[int], group: int = 0) -> None:
+        import torch
+        from . import lib as _lib
+        from .synth import submodel
+        self.torch, self._lib, self._L, self.comm = torch, _lib, _lib.load(), comm
+        self.dev = torch.device("cuda", comm.device)
+        spec = model.spec
+        self.row_cols, per_rank = mixed_assignment(spec, owners, comm.world)
+        col_cols = sorted(k for cols in per_rank for k in cols)
+        if any(len(c) == 0 for c in per_rank) and col_cols:
+            raise ValueError("mixed placement: every rank must hold at least one whole column")
+        self.pieces, self.w_row, self.w_col = _mixed_pieces(spec, self.row_cols, per_rank, group)
+        self.width = int(spec.group_width(group))
+        self.row_hosts = spec.column_subset(self.row_cols).host_inputs if self.row_cols else []
+        self.col_hosts = spec.column_subset(col_cols).host_inputs if col_cols else []
+        self.row_step = NativeShardedStep(submodel(model, self.row_cols), comm, "row", group) if self.row_cols else None
+        pos = {k: i for i, k in enumerate(col_cols)}
+        self.col_step = NativeShardedStep(submodel(model, col_cols), comm, "col", group,
+                                          assignment=[[pos[k] for k in cols] for cols in per_rank]) if col_cols else None
+        self._out = []          # ring of output buffers, allocated at the first request
+        self._next = 0
+
+    def prepare(self, inputs, symbols):
+        return (self.row_step.prepare([inputs[i] for i in self.row_hosts], symbols) if self.row_step else None,
+                self.col_step.prepare([inputs[i] for i in self.col_hosts], symbols) if self.col_step else None)
+
+    def run(self, request, stream=None):
+        import ctypes as C
+        torch = self.torch
+        srcs = [None, None]
+        begin = count = 0
+        if self.row_step:
+            srcs[0], begin, count = self.row_step.run(request[0], stream)
+        if self.col_step:
+            srcs[1], begin, count = self.col_step.run(request[1], stream)
+        if not self._out:
+            self._out = [torch.empty((max(count, 1) * 2, self.width), dtype=torch.float32, device=self.dev) for _ in range(3)]
+        out = self._out[self._next]
+        self._next = (self._next + 1) % len(self._out)
+        if count:
+            n = len(self.pieces)
+            widths = (self.w_row, self.w_col)
+            ins = (C.c_void_p * n)(*[srcs[s] + 4 * so for s, so, _, _ in self.pieces])
+            dims = np.asarray([w for _, _, _, w in self.pieces], np.int32)
+            strides = np.asarray([widths[s] for s, _, _, _ in self.pieces], np.int32)
+            offs = np.asarray([do for _, _, do, _ in self.pieces], np.int32)
+            st = torch.cuda.current_stream(self.dev).cuda_stream if stream is None else stream
+            self._lib.check(self._L.fcp_concat_outputs_scatter_strided(ins, dims.ctypes.data, strides.ctypes.data, offs.ctypes.data, n,
+                                                                       count, self.width, out.data_ptr(), st),
+                            "fcp_concat_outputs_scatter_strided")
+        return out.data_ptr(), begin, count
+
+    def result(self, ptr: int, count: int):
+        torch = self.torch
+        if not count:
+            return torch.empty((0, self.width), dtype=torch.float32, device=self.dev)
+        return _device_view(torch, ptr, count * self.width, self.dev).view(count, self.width).clone()
+
+    def exchanged_bytes(self, rows: int) -> int:
+        """bytes this rank sends per request (it receives as many): dense partial slices of the row part, final
+        blocks of the whole-column part"""
+        world = self.comm.world
+        w_mine = sum(w for (s, _, _, w) in self.pieces if s == 1) // max(world, 1)  # about 1/world of the whole columns are mine
+        return int(4 * rows * (world - 1) / world * (self.w_row + w_mine))
+
+    def close(self) -> None:
+        for st in (self.row_step, self.col_step):
+            if st is not None:
+                st.close()
+
+
 class _GlooShardedStep:
     """The sharded step with the exchange staged through the host (``_all_to_all`` under gloo): the interface of
     :class:`NativeShardedStep`, for ``bench.py --dist-backend gloo`` on a box whose ranks share one GPU."""
 
-    def __init__(self, model, rank: int, world: int, device: int, mode: str) -> None:
+    def __init__(self, model, rank: int, world: int, device: int, mode: str, owners=None) -> None:
         import torch
+        from .synth import submodel
         self.torch = torch
-        self.impl = (ShardedFeatureColumns if mode == "row" else ColumnShardedFeatureColumns)(model, rank, world, device)
         self.mode = mode
+        self.dev = torch.device("cuda", device)
+        if mode != "mixed":
+            self.impl = (ShardedFeatureColumns if mode == "row" else ColumnShardedFeatureColumns)(model, rank, world, device)
+            return
+        spec = model.spec
+        self.row_cols, per_rank = mixed_assignment(spec, owners, world)
+        col_cols = sorted(k for cols in per_rank for k in cols)
+        self.pieces, self.w_row, self.w_col = _mixed_pieces(spec, self.row_cols, per_rank)
+        self.width = int(spec.group_width(0))
+        self.row_hosts = spec.column_subset(self.row_cols).host_inputs if self.row_cols else []
+        self.col_hosts = spec.column_subset(col_cols).host_inputs if col_cols else []
+        pos = {k: i for i, k in enumerate(col_cols)}
+        self.row_impl = ShardedFeatureColumns(submodel(model, self.row_cols), rank, world, device) if self.row_cols else None
+        self.col_impl = ColumnShardedFeatureColumns(submodel(model, col_cols), rank, world, device,
+                                                    assignment=[[pos[k] for k in cols] for cols in per_rank]) if col_cols else None
+
+    def _pack(self, tensors, symbols):
+        from .ops import concat_inputs
+        blob, offsets, shapes = concat_inputs(tensors)
+        return (self.torch.from_numpy(blob).to(self.dev), offsets, shapes, symbols)
 
     def prepare(self, inputs, symbols):
-        from .ops import concat_inputs
-        mine = inputs if self.mode == "row" else self.impl.request_inputs(inputs)
-        blob, offsets, shapes = concat_inputs(mine)
-        return (self.torch.from_numpy(blob).to(self.impl.dev), offsets, shapes, symbols)
+        if self.mode == "mixed":
+            return (self._pack([inputs[i] for i in self.row_hosts], symbols) if self.row_impl else None,
+                    self._pack(self.col_impl.request_inputs([inputs[i] for i in self.col_hosts]), symbols) if self.col_impl else None)
+        return self._pack(inputs if self.mode == "row" else self.impl.request_inputs(inputs), symbols)
 
     def run(self, request):
-        out, begin, count = self.impl(*request)
+        if self.mode != "mixed":
+            return self.impl(*request)
+        parts = [None, None]
+        begin = count = 0
+        if self.row_impl:
+            parts[0], begin, count = self.row_impl(*request[0])
+        if self.col_impl:
+            parts[1], begin, count = self.col_impl(*request[1])
+        out = self.torch.empty((count, self.width), dtype=self.torch.float32, device=self.dev)
+        for s, so, do, w in self.pieces:
+            out[:, do:do + w] = parts[s][:, so:so + w]
         return out, begin, count
 
     def close(self) -> None:
@@ -376,16 +531,16 @@ def bench_sharded(args, model, placement, rank: int, world: int, local_rank: int
     4000 S2-shaped columns, 480 GB of tables): every rank holds its shard, every request runs partial
     kernel -> RCCL all-to-all over xGMI -> finalize / concat as one native call (NativeShardedStep)."""
     import torch
-    from .placement import ROW_SHARD
-    mode = "row" if placement.mode == ROW_SHARD else "col"
+    from .placement import MIXED, ROW_SHARD
+    mode = "row" if placement.mode == ROW_SHARD else "mixed" if placement.mode == MIXED else "col"
     if dist is not None and dist.get_backend() != "nccl":
         # RCCL refuses two ranks on one device: under gloo (several ranks sharing a GPU, a 1-GPU box exercising the N > 1
         # control flow) the exchange goes through the host and the step is the Python orchestration of the same kernels
-        step = _GlooShardedStep(model, rank, world, local_rank, mode)
+        step = _GlooShardedStep(model, rank, world, local_rank, mode, placement.owners)
         comm = None
     else:
         comm = Communicator(rank, world, local_rank, dist)
-        step = NativeShardedStep(model, comm, mode)
+        step = MixedShardedStep(model, comm, placement.owners) if mode == "mixed" else NativeShardedStep(model, comm, mode)
     reqs = [step.prepare(r.inputs, r.symbols) for r in (model.make_request(s) for s in range(8))]  # ids replicated on every rank
     for i in range(max(args.warmup, 1)):
         step.run(reqs[i % len(reqs)])
@@ -411,7 +566,15 @@ def bench_sharded(args, model, placement, rank: int, world: int, local_rank: int
     from .ops import concat_inputs
     r0 = model.make_request(0)
     bytes_alg = model.spec.algorithmic_bytes(concat_inputs(r0.inputs)[2], r0.symbols)
-    if mode == "row":
+    sent = batch * width * 4 * (world - 1) / world / (1 if mode == "row" else world)   # bytes one rank sends per request
+    if mode == "mixed":
+        row_cols, per_rank = mixed_assignment(model.spec, placement.owners, world)
+        w_row = sum(model.spec.columns[k].dim for k in row_cols)
+        sent = batch * 4 * (world - 1) / world * (w_row + (width - w_row) / world)
+        per_gpu = bytes_alg["total"] / world + 2 * sent + batch * width * 4 * 2 / world + batch * w_row * 4
+        par = (f"mixed x{world}: {len(row_cols)} column(s) row-sharded (tables larger than one GPU: partial sums + fcp_shard_finalize), "
+               f"{sum(len(c) for c in per_rank)} whole (final blocks), grouped ncclSend/ncclRecv (RCCL over xGMI) + strided concat")
+    elif mode == "row":
         # per-GPU algorithmic bytes: 1/world of the table rows, all ids, the partial
         # [rows, width] written once, its slices sent / received, the final slice written
         per_gpu = bytes_alg["rows"] / world + bytes_alg["ids"] + bytes_alg["boundaries"] + batch * width * 4 * (
@@ -428,7 +591,7 @@ def bench_sharded(args, model, placement, rank: int, world: int, local_rank: int
     if comm is not None:
         comm.close()
     return {
-        "metric": f"inference QPS, {'row' if mode == 'row' else 'column'}-sharded tables (SHARD config)",
+        "metric": f"inference QPS, {'row-sharded' if mode == 'row' else 'mixed-placement' if mode == 'mixed' else 'column-sharded'} tables (SHARD config)",
         "value": batch * args.steps / elapsed,
         "unit": "inferences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong",
@@ -436,7 +599,7 @@ def bench_sharded(args, model, placement, rank: int, world: int, local_rank: int
         "config": {"workload": f"{model.name}: {model.description}; tables {placement.name} over {world} GPU(s) by the "
                                f"placement gate ({placement.total_bytes / 1e9:.0f} GB of tables, {placement.bytes_per_gpu / 1e9:.0f} GB per GPU)",
                    "batch": batch, "columns": model.spec.n_columns, "table_bytes": model.table_bytes(),
-                   "parallelism": par},
+                   "parallelism": par, "exchange_bytes_sent_per_rank_per_request": int(sent)},
         "roofline": {"bound": "hbm", "achieved": per_gpu / dev_s / 1e9, "peak": 8000.0, "unit": "GB/s",
                      "frac": per_gpu / dev_s / 1e9 / 8000.0, "traffic": None,
                      "note": "per GPU, whole step (partial kernel + exchange + finalize / concat), events on the compute stream"},

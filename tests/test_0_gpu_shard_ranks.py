@@ -45,6 +45,12 @@ def _rank_main(rank, world, port, mode, q):
         from recom_amd.shard import ColumnShardedFeatureColumns, ShardedFeatureColumns, batch_slices
         torch.cuda.set_device(0)
         orc = O.COracle()
+        if mode == "mixed":
+            _mixed_rank(rank, world, orc)
+            dist.barrier()
+            dist.destroy_process_group()
+            q.put((rank, "ok"))
+            return
         for m in (synth.model_mixed(batch=50, vocab=997, n_groups=1), synth.model_s2(columns=64, vocab=5000, batch=96)):
             tabs_np = m.numpy_tables()
             sfc = (ShardedFeatureColumns if mode == "row" else ColumnShardedFeatureColumns)(m, rank, world, 0)
@@ -79,7 +85,57 @@ def _rank_main(rank, world, port, mode, q):
         q.put((rank, traceback.format_exc()))
 
 
-@pytest.mark.parametrize("mode", ["row", "col"])
+def _mixed_model():
+    """Ten columns of every lookup form; one table (1.28 MB, pooled) exceeds a 1.1 MB "GPU", the rest fit."""
+    from recom_amd import synth
+    from recom_amd.plan import COMBINER_MEAN, COMBINER_SUM, FORM_GATHER_SCATTER
+    b = synth._Builder()
+    synth._add_dense(b, 300, 8, slot=0)
+    synth._add_ragged(b, 20_000, 16, slot=1, combiner=COMBINER_MEAN, seg="indices")          # 1.28 MB: spread by rows
+    synth._add_dense(b, 101, 8, slot=2, id_source=synth.IDS_F32_BUCKETIZE, boundaries=synth.MICROBENCH_BOUNDARIES)
+    synth._add_dense(b, 6_250, 8, slot=3)
+    synth._add_ragged(b, 700, 32, slot=4, combiner=COMBINER_SUM, seg="csr")
+    synth._add_ragged(b, 900, 8, slot=5, combiner=COMBINER_SUM, seg="indices", form=FORM_GATHER_SCATTER)
+    synth._add_dense(b, 2_000, 16, slot=6)
+    synth._add_ragged(b, 1_500, 12, slot=7, combiner=COMBINER_MEAN, seg="rowids32")
+    synth._add_dense(b, 4_000, 4, slot=8)
+    synth._add_dense(b, 1_000, 20, slot=9)
+    return synth._finish("MIXED-PLACEMENT", b, batch=57, n_symbols=1, description="one table larger than one GPU")
+
+
+def _mixed_rank(rank, world, orc):
+    """FCP_PLACE_MIXED on two ranks: the gate spreads only the tables that exceed "one GPU" by rows, deals the others out
+    whole; the step = row-sharded part + whole-column part + strided concat; every column of the result against the
+    unsharded oracle (whole columns and one-owner-per-row columns bit-exact, pooled row-sharded ones to fp32 reassociation)."""
+    import torch
+    from recom_amd import synth
+    from recom_amd.ops import concat_inputs
+    from recom_amd.placement import MIXED, decide_placement, table_bytes
+    from recom_amd.shard import _GlooShardedStep, batch_slices, mixed_assignment
+    m = _mixed_model()
+    p = decide_placement(m.spec, world, hbm_bytes=1_100_000, reserve_bytes=0, prefer="mixed")
+    assert p.mode == MIXED and p.owners.count(-1) == 1 and p.owners[1] == -1 and all(o in (-1, 0, 1) for o in p.owners)
+    row_cols, per_rank = mixed_assignment(m.spec, p.owners, world)
+    assert row_cols and all(per_rank)
+    step = _GlooShardedStep(m, rank, world, 0, "mixed", p.owners)
+    tabs_np = m.numpy_tables()
+    for seed in (0, 1, 2):
+        req = m.make_request(seed)
+        want, _ = orc.process_feature_columns(m.spec.to_dict(), *concat_inputs(req.inputs), tabs_np, req.symbols)
+        mine, begin, count = step.run(step.prepare(req.inputs, req.symbols))
+        torch.cuda.synchronize()
+        assert (begin, count) == batch_slices(want[0].shape[0], world)[rank]
+        got, ref = mine.cpu().numpy(), want[0][begin:begin + count]
+        offs = m.spec.column_offsets()
+        for k, c in enumerate(m.spec.columns):
+            a, b = got[:, offs[k]:offs[k] + c.dim], ref[:, offs[k]:offs[k] + c.dim]
+            if k not in row_cols or c.form in (1, 3, 4, 5):
+                assert np.array_equal(a, b), (seed, k)
+            else:
+                assert np.abs(a - b).max(initial=0) < 1e-5, (seed, k)
+
+
+@pytest.mark.parametrize("mode", ["row", "col", "mixed"])
 def test_two_ranks_one_gpu_product_path(mode):
     import torch
     assert torch.cuda.device_count() >= 1, "needs a GPU"         # device_count() does not initialise HIP
@@ -103,7 +159,7 @@ def test_two_ranks_one_gpu_product_path(mode):
     assert results == {r: "ok" for r in range(world)}, "\n".join(f"rank {r}: {m}" for r, m in results.items())
 
 
-@pytest.mark.parametrize("workload", ["s2", "shard", "shard-col"])
+@pytest.mark.parametrize("workload", ["s2", "shard", "shard-row", "shard-col"])
 def test_bench_gpus_2_starts_its_ranks_and_prints_one_line(workload):
     """`python bench.py --gpus 2` with no launcher: bench.py starts the two ranks itself (torch.distributed.run on
     127.0.0.1), rank 0 prints ONE JSON line with n_gpus 2 — replicas for a model that fits (S2 reduced), the row- and the
@@ -127,7 +183,9 @@ def test_bench_gpus_2_starts_its_ranks_and_prints_one_line(workload):
     if workload == "s2":
         assert rec["scaling"] == "weak" and "replica" in rec["config"]["parallelism"]
     else:
-        assert ("row-sharded" if workload == "shard" else "column-sharded") in rec["config"]["parallelism"]
+        # `shard` follows the gate's mixed preference: every table of this model fits "one GPU" -> whole columns
+        assert ("row-sharded" if workload == "shard-row" else "column-sharded") in rec["config"]["parallelism"]
+        assert rec["config"]["exchange_bytes_sent_per_rank_per_request"] > 0
 
 
 def _rccl_rank_main(rank, world, port, q):

@@ -486,6 +486,21 @@ def test_placement_gate():
     # a shared table counts once
     m = synth.model_mixed()
     assert len(table_bytes(m.spec)) == m.spec.n_device_inputs
+    # the mixed preference: whole tables wherever a table fits one GPU, rows only for those that do not
+    from recom_amd.placement import MIXED
+    p = decide_placement(shard, 8, prefer="mixed")                 # configs[4]: every table fits -> whole columns, no rows spread
+    assert p.mode == COLUMN_SHARD and all(0 <= o < 8 for o in p.owners) and len(set(p.owners)) == 8
+    loads = np.bincount(p.owners, weights=table_bytes(shard), minlength=8)
+    assert loads.max() == p.bytes_per_gpu and loads.max() - loads.min() <= 256_000_000   # longest-first packing: balanced
+    p = decide_placement(big + [3 * 10**9] * 5, 2, prefer="mixed")  # one table exceeds a GPU: only that one is spread
+    assert p.mode == MIXED and p.owners[0] == -1 and all(o in (0, 1) for o in p.owners[1:])
+    assert p.bytes_per_gpu == 200 * 10**9 + max(np.bincount(p.owners[1:], weights=[10**9] + [3 * 10**9] * 5, minlength=2))
+    assert decide_placement(s2, 8, prefer="mixed").mode == REPLICATE and decide_placement(s2, 8, prefer="mixed").owners == [0] * 1000
+    # whole tables cannot be packed (3 x 200 GB on 2 GPUs of 250 GB) but rows can: falls back to rows for everything
+    p = decide_placement([200 * 10**9] * 3 + [10], 2, prefer="mixed", reserve_bytes=0, hbm_bytes=320 * 10**9)
+    assert p.mode == ROW_SHARD and set(p.owners) == {-1}
+    p = decide_placement(shard, 8, prefer="row")
+    assert set(p.owners) == {-1}
 
 
 def test_hot_kernels_keep_full_occupancy(tmp_path):
