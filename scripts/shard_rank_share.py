@@ -142,3 +142,16 @@ print(f"column-sharded: block kernel {t_blk:7.1f} us ({salg['total'] / 1e6:.1f} 
       f"{cat_bytes / t_cat / 1e6:.2f} TB/s), sum {t_both:7.1f} us per request -> {m.batch / t_both:.2f} M inferences/s "
       f"per 8-GPU node if the exchange hides; exchanged per rank and request: {7 / 8 * m.batch * widths[RANK] * 4 / 1e6:.0f} MB out "
       f"+ {7 / 8 * count * width * 4 / 1e6:.0f} MB in")
+
+# ---- what the gate chooses (bench.py --workload shard) -----------------------------------------------------------
+from recom_amd.placement import MODE_NAMES, decide_placement  # noqa: E402
+from recom_amd.shard import mixed_assignment  # noqa: E402
+
+p = decide_placement(m.spec, WORLD, prefer="mixed")
+row_cols, per_rank = mixed_assignment(m.spec, p.owners, WORLD)
+w_row = sum(m.spec.columns[k].dim for k in row_cols)
+w_mine = sum(m.spec.columns[k].dim for k in per_rank[RANK])
+sent = 4 * m.batch * (WORLD - 1) / WORLD * (w_row + w_mine)
+print(f"gate (mixed preference, the default of `bench.py --workload shard`): {MODE_NAMES[p.mode]}; {len(row_cols)} column(s) spread by rows, "
+      f"{sum(len(c) for c in per_rank)} whole ({len(per_rank[RANK])} on rank {RANK}, {p.bytes_per_gpu / 1e9:.1f} GB of tables on the fullest GPU); "
+      f"exchanged per rank and request: {sent / 1e6:.0f} MB out (row sharding: {7 / 8 * m.batch * width * 4 / 1e6:.0f} MB)")
