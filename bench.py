@@ -464,8 +464,10 @@ def main():
     if rank == 0:
         achieved = bytes_alg["total"] / (dev_ms_per_req * 1e-3) / 1e9
         # (the PMC record of RAGGED is for the default segment encoding: SparseTensor indices, pre-pass included)
-        traffic, traffic_source = measured_traffic(args.workload if args.workload != "ragged" or args.seg == "indices"
-                                                   else f"ragged_{args.seg}")
+        # (PMC records of RAGGED: the staged form = the default, and the request as delivered with its pre-pass)
+        traffic, traffic_source = measured_traffic(args.workload if args.workload != "ragged" else
+                                                   "ragged" if args.seg == "indices" and not args.as_delivered else
+                                                   "ragged_as_delivered" if args.seg == "indices" else f"ragged_{args.seg}")
         rec["roofline"] = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,

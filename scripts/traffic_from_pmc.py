@@ -1,15 +1,17 @@
 #!/usr/bin/env python3
 """Rewrite profiles/traffic.json from the PMC summaries of one refresh pass (scripts/pmc.sh / pmc_py.sh
 output: per kernel a block of "COUNTER n= N mean= X" lines; the first block is the path's own kernel).
-Usage: traffic_from_pmc.py DIR   (DIR holds r02_s2_pmc_fcp_bench.txt, r02_ragged_pmc.txt, r02_ae_model_e_pmc.txt)
+Usage: traffic_from_pmc.py DIR [PREFIX]   (DIR holds <PREFIX>_s2_pmc_fcp_bench.txt, <PREFIX>_ragged_pmc.txt, <PREFIX>_ae_model_e_pmc.txt; PREFIX defaults to r03)
 The record carries the sha of fcp_kernels.hip: bench.py reports `roofline.traffic` only while the kernels
 are the ones these passes measured."""
 import hashlib, json, os, re, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-FILES = {"s2": ("r02_s2_pmc_fcp_bench.txt", "fcp_dense_kernel<4,4,false>"),
-         "ragged": ("r02_ragged_pmc.txt", "fcp_ragged_kernel<4,false>"),
-         "e": ("r02_ae_model_e_pmc.txt", "fcp_hybrid_kernel<4,4,false>")}
+PREFIX = sys.argv[2] if len(sys.argv) > 2 else "r03"
+FILES = {"s2": (f"{PREFIX}_s2_pmc_fcp_bench.txt", "fcp_dense_kernel<4,4,false>"),
+         "ragged": (f"{PREFIX}_ragged_pmc.txt", "fcp_ragged_kernel<4,false>"),
+         "ragged_as_delivered": (f"{PREFIX}_ragged_as_delivered_pmc.txt", "fcp_ragged_kernel<4,false>"),
+         "e": (f"{PREFIX}_ae_model_e_pmc.txt", "fcp_hybrid_kernel<4,4,false>")}
 
 
 def kernel_block(path, kernel):
@@ -47,6 +49,8 @@ def main(d):
                        "at 64 bytes, so the read side is doubled (an upper bound here: requests for 32/64-byte rows are not wide).",
            "kernels_sha16": sha}
     for key, (name, kernel) in FILES.items():
+        if not os.path.exists(os.path.join(d, name)):
+            continue
         v = kernel_block(os.path.join(d, name), kernel)
         fetch, write = v["FETCH_SIZE"], v["WRITE_SIZE"]
         rec[key] = {"source": f"profiles/{name}", "kernel": kernel, "FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write,
