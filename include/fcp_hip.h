@@ -284,6 +284,32 @@ int fcp_concat_inputs(const fcp_host_tensor_t *inputs, int32_t n_inputs,
 
 /* ---- plan: replaces code generation + CreateConstBuffers ------------------ */
 int fcp_plan_create(const fcp_plan_desc_t *desc, fcp_plan_t **plan);
+
+/* Per-column extensions (the v2 structs above stay as they are; a column without extensions is all zeros).
+ *
+ * Segment ids that are a FUNCTION OF SEVERAL INDEX COORDINATES — a SparseReshape between the SparseTensor and
+ * the lookup, which the reference folds into the index expression of the generated code
+ * (EmitInputInline, cuda_emitter.cc:1874-1916: flat index from the input shape, then / and % by the output
+ * shape).  For the row coordinate of the reshaped tensor that is
+ *     seg(i) = (sum_{k < seg_map_n} idx[i * seg_stride + k] * seg_map_mul[k]) / seg_map_div
+ * over the first seg_map_n coordinates of element i (seg_stride = rank of the ORIGINAL indices matrix,
+ * seg_kind FCP_SEG_IDS_I32/I64, form FCP_FORM_SEGMENT_REDUCE).  Factors are >= 1; one of them may additionally
+ * be multiplied by a request's symbol (a dense_shape entry that is only known per request: [B, T, L] ->
+ * [B*T, L] gives seg = idx0 * T + idx1): seg_map_sym >= 0 names the symbol, seg_map_sym_slot the factor
+ * (0..3 = seg_map_mul[slot], 4 = seg_map_div).  seg_map_n = 0: plain segment ids, seg(i) = idx[i * seg_stride].
+ * Lexicographically sorted indices (TF's SparseTensor contract) give non-decreasing seg ids. */
+#define FCP_SEG_MAP_MAX 4
+typedef struct fcp_column_ext {
+  int32_t seg_map_n;        /* 0 = none, else 1..FCP_SEG_MAP_MAX coordinates  */
+  int32_t seg_map_sym;      /* symbol index, or -1                            */
+  int32_t seg_map_sym_slot; /* 0..3: seg_map_mul[slot]; 4: seg_map_div        */
+  int32_t reserved0;
+  int64_t seg_map_mul[FCP_SEG_MAP_MAX];
+  int64_t seg_map_div;
+  int64_t reserved1[2];
+} fcp_column_ext_t;
+/* `ext`: NULL, or one record per column of `desc`. */
+int fcp_plan_create_ex(const fcp_plan_desc_t *desc, const fcp_column_ext_t *ext, fcp_plan_t **plan);
 /* The same from a column-plan FILE — what the `dlpath` attr of
  * Addons>FeatureColumnProcess names in this build (the reference dlopen()s a
  * JIT-compiled .so there, feature_column_process_op_gpu.cu.cc:49-62).  Text
@@ -294,7 +320,9 @@ int fcp_plan_create(const fcp_plan_desc_t *desc, fcp_plan_t **plan);
  *   rows_arg concat_group concat_slot n_boundaries b0 b1 ..." — version 2 files
  *   ("fcp_plan 2") append "xform_mode xform_n substitute hash_buckets lo0 hi0 lo1
  *   hi1 ..." to every column line; version 3 files may end with a stage section
- *   (fcp_plan_file_stage_info) that tells Addons>ConcatInputs how to pack.
+ *   (fcp_plan_file_stage_info) that tells Addons>ConcatInputs how to pack;
+ *   version 4 files may carry, before it, "segmaps M" + M lines "column n sym
+ *   slot mul0 mul1 mul2 mul3 div" (fcp_column_ext_t::seg_map_*).
  * `flags`: fcp_plan_desc_t::flags.  FCP_ERR_INVALID_ARGUMENT for a missing or
  * malformed file. */
 int fcp_plan_create_from_file(const char *path, int32_t device, uint32_t flags,

@@ -474,17 +474,34 @@ static int xform_in(const orc_column_t *c, int64_t x) {
   return 0;
 }
 
-static void load_seg(const orc_column_t *c, const int8_t *src, int64_t n, int64_t *seg) {
+static int64_t load_index(const orc_column_t *c, const int8_t *src, int64_t e) {
+  if (c->seg_kind == ORC_SEG_IDS_I32) {
+    int32_t v;
+    memcpy(&v, src + 4 * e, 4);
+    return v;
+  }
+  int64_t v;
+  memcpy(&v, src + 8 * e, 8);
+  return v;
+}
+
+/* Segment ids: element i*seg_stride of the tensor (SparseTensor indices[:, 0]: cuda_emitter.cc:1836-1873), or — with a
+ * SparseReshape folded in (cuda_emitter.cc:1874-1916) — the row coordinate of the reshaped element. */
+static void load_seg(const orc_column_t *c, const int8_t *src, int64_t n, const int32_t *symbols, int64_t *seg) {
   for (int64_t i = 0; i < n; ++i) {
-    if (c->seg_kind == ORC_SEG_IDS_I32) {
-      int32_t v;
-      memcpy(&v, src + 4 * i * c->seg_stride, 4);
-      seg[i] = v;
-    } else {
-      int64_t v;
-      memcpy(&v, src + 8 * i * c->seg_stride, 8);
-      seg[i] = v;
+    if (c->seg_map_n <= 0) {
+      seg[i] = load_index(c, src, i * c->seg_stride);
+      continue;
     }
+    const int64_t sym = c->seg_map_sym >= 0 ? symbols[c->seg_map_sym] : 1;
+    int64_t lin = 0, neg = 0;
+    for (int32_t k = 0; k < c->seg_map_n; ++k) {
+      const int64_t v = load_index(c, src, i * c->seg_stride + k);
+      if (v < 0) neg = 1;
+      lin += v * (c->seg_map_sym_slot == k ? c->seg_map_mul[k] * sym : c->seg_map_mul[k]);
+    }
+    const int64_t div = c->seg_map_sym_slot == 4 ? c->seg_map_div * sym : c->seg_map_div;
+    seg[i] = neg ? -1 : lin / div;
   }
 }
 
@@ -592,7 +609,7 @@ static int64_t process_column(const orc_plan_t *p, int32_t k, const int8_t *blob
       memcpy(offs, blob + offsets[c->seg_input], sizeof(int32_t) * (size_t)(rows + 1));
     } else {
       seg = (int64_t *)malloc(sizeof(int64_t) * (size_t)(nnz + 1));
-      load_seg(c, blob + offsets[c->seg_input], nnz, seg);
+      load_seg(c, blob + offsets[c->seg_input], nnz, symbols, seg);
       orc_segment_offsets(seg, nnz, rows, offs);
     }
     if (keep && scatter && seg) {

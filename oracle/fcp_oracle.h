@@ -60,6 +60,15 @@ typedef struct orc_column {
    * StringToHashBucketFast, the graph of categorical_column_with_hash_bucket over integer features;
    * reference models: examples/python/dlrm.py "hash-int" columns) */
   int64_t hash_buckets;
+  /* seg_map_n > 0: the segment id of element i is a function of its first seg_map_n index coordinates — a
+   * SparseReshape between the SparseTensor and the lookup, which the reference folds into the generated index
+   * expression (EmitInputInline, cuda_emitter.cc:1874-1916: flat index over the input shape, "/" by the trailing
+   * output dims, "%" by the dim itself; for the row coordinate, offset 0, the "%" is absent):
+   *   seg = (sum_k idx[i*seg_stride + k] * seg_map_mul[k]) / seg_map_div,
+   * one factor (seg_map_sym_slot: 0..3 = mul, 4 = div) times symbols[seg_map_sym] when seg_map_sym >= 0. */
+  int32_t seg_map_n, seg_map_sym, seg_map_sym_slot, seg_map_pad;
+  int64_t seg_map_mul[4];
+  int64_t seg_map_div;
 } orc_column_t;
 
 /* TensorFlow 2.6.2's Fingerprint64 (core/platform/fingerprint.h -> FarmHash farmhashna::Hash64, third_party

@@ -55,6 +55,8 @@ class _Column(C.Structure):
         ("xform_mode", C.c_int32), ("xform_n", C.c_int32),
         ("xform_lo", C.POINTER(C.c_int64)), ("xform_hi", C.POINTER(C.c_int64)),
         ("xform_substitute", C.c_int64), ("hash_buckets", C.c_int64),
+        ("seg_map_n", C.c_int32), ("seg_map_sym", C.c_int32), ("seg_map_sym_slot", C.c_int32), ("seg_map_pad", C.c_int32),
+        ("seg_map_mul", C.c_int64 * 4), ("seg_map_div", C.c_int64),
     ]
 
 
@@ -232,6 +234,14 @@ class COracle:
                 xlo.ctypes.data_as(C.POINTER(C.c_int64)) if len(xlo) else None,
                 xhi.ctypes.data_as(C.POINTER(C.c_int64)) if len(xhi) else None, int(c.get("xform_substitute", 0)),
                 int(c.get("hash_buckets", 0)))
+            mul = [int(v) for v in c.get("seg_mul", ())]
+            if mul:                                                   # segment ids through a folded SparseReshape
+                arr[k].seg_map_n = len(mul)
+                arr[k].seg_map_sym = int(c.get("seg_sym", -1))
+                arr[k].seg_map_sym_slot = int(c.get("seg_sym_slot", 0))
+                for j, v in enumerate(mul):
+                    arr[k].seg_map_mul[j] = v
+                arr[k].seg_map_div = int(c.get("seg_div", 1))
         ranks = _i32(plan["host_input_ranks"])
         esz = _i32(plan["host_input_elem_sizes"])
         keep += [ranks, esz]
@@ -456,6 +466,16 @@ def np_process_feature_columns(plan: dict, blob: np.ndarray, offsets, shapes, ta
         else:
             raw = tensor(c["seg_input"], np.int32 if c["seg_kind"] == 1 else np.int64).ravel()
             seg = raw[::max(1, c["seg_stride"])][:ids.size]
+            mul = [int(v) for v in c.get("seg_mul", ())]
+            if mul:      # a SparseReshape folded into the index expression (cuda_emitter.cc:1874-1916), row coordinate
+                st = c["seg_stride"]
+                sym = int(np.asarray(symbols).reshape(-1)[c["seg_sym"]]) if c.get("seg_sym", -1) >= 0 else 1
+                slot = c.get("seg_sym_slot", 0) if c.get("seg_sym", -1) >= 0 else -1
+                coords = raw[:ids.size * st].reshape(ids.size, st).astype(np.int64)
+                lin = np.zeros(ids.size, np.int64)
+                for j, v in enumerate(mul):
+                    lin += coords[:, j] * (v * sym if slot == j else v)
+                seg = np.where((coords[:, :len(mul)] < 0).any(axis=1), -1, lin // (c.get("seg_div", 1) * (sym if slot == 4 else 1)))
             if c["form"] == 3:
                 # ScatterNd with row ids as delivered, in any order (GatherScatterRows, cuda_emitter.cc:296-345): a
                 # sequential scatter of the ids the filter kept; rows outside [0, rows) are dropped

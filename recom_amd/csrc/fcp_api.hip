@@ -62,6 +62,7 @@ constexpr uint32_t kFlagHostOnly = FCP_FLAG_HOST_ONLY; // plan without device re
 
 struct HostColumn {
   fcp_column_desc_t d;
+  fcp_column_ext_t ext = {}; // extensions (segment-id map); all zeros = none
   std::vector<float> boundaries;
   std::vector<int64_t> xf_lo, xf_hi; // id transform intervals (closed)
   int64_t xf_const_off = -1;         // byte offset in the const buffer of intervals 1.. as (lo, hi) pairs
@@ -153,6 +154,8 @@ struct fcp_plan {
   uint32_t *d_slot_map = nullptr;
   FcpColStatic *d_cols = nullptr;
   FcpXform *d_xforms = nullptr; // per column, only for plans with id transforms
+  FcpSegMap *d_segmaps = nullptr; // per column, only for plans with segment-id maps
+  bool has_seg_map = false;
   std::vector<FcpColStatic> h_cols;
   char *d_const = nullptr;
   int32_t *d_seg_cols = nullptr;
@@ -290,6 +293,26 @@ int validate_desc(const fcp_plan_desc_t *d) {
   return FCP_OK;
 }
 
+int validate_ext(const fcp_plan_desc_t *d, const fcp_column_ext_t *ext) {
+  for (int k = 0; k < d->n_columns; ++k) {
+    const fcp_column_ext_t &e = ext[k];
+    if (e.seg_map_n == 0) continue;
+    const fcp_column_desc_t &c = d->columns[k];
+    const std::string where = "column " + std::to_string(k) + ": ";
+    if (e.seg_map_n < 0 || e.seg_map_n > FCP_SEG_MAP_MAX) return fail(FCP_ERR_INVALID_ARGUMENT, where + "seg_map_n out of range");
+    if (c.form != FCP_FORM_SEGMENT_REDUCE || (c.seg_kind != FCP_SEG_IDS_I32 && c.seg_kind != FCP_SEG_IDS_I64))
+      return fail(FCP_ERR_INVALID_ARGUMENT, where + "a segment-id map needs a pooled column with segment ids");
+    if (c.seg_stride < e.seg_map_n) return fail(FCP_ERR_INVALID_ARGUMENT, where + "seg_stride is smaller than the number of mapped coordinates");
+    if (e.seg_map_div < 1) return fail(FCP_ERR_INVALID_ARGUMENT, where + "seg_map_div must be >= 1");
+    for (int i = 0; i < e.seg_map_n; ++i)
+      if (e.seg_map_mul[i] < 0) return fail(FCP_ERR_INVALID_ARGUMENT, where + "negative seg_map_mul");
+    if (e.seg_map_sym >= d->n_symbols || e.seg_map_sym < -1) return fail(FCP_ERR_INVALID_ARGUMENT, where + "seg_map_sym out of range");
+    if (e.seg_map_sym >= 0 && !(e.seg_map_sym_slot == 4 || (e.seg_map_sym_slot >= 0 && e.seg_map_sym_slot < e.seg_map_n)))
+      return fail(FCP_ERR_INVALID_ARGUMENT, where + "seg_map_sym_slot out of range");
+  }
+  return FCP_OK;
+}
+
 // Run-time shapes -> per-column dynamic records, arena layout and launch
 // geometry.  Mirrors what the generated host code evaluates per call from
 // SymEngine expressions (cuda_emitter.cc:2151-2179, :2410-2455).
@@ -360,7 +383,7 @@ int compute_dyn_slow(const fcp_plan *p, const int32_t *offsets, const int32_t *s
     const fcp_column_desc_t &c = hc.d;
     FcpColDyn &d = dyn[p->pos_of[k]];
     d.seg_off = 0;
-    d.pad_ = 0;
+    d.seg_sym = 1;
     const int64_t rows = col_rows[k];
     d.rows = (int32_t)rows;
     d.ids_off = c.form == FCP_FORM_EXTERNAL ? 0 : offsets[c.ids_input];
@@ -393,6 +416,15 @@ int compute_dyn_slow(const fcp_plan *p, const int32_t *offsets, const int32_t *s
         } else {
           if (n_seg < n_ids * c.seg_stride - (c.seg_stride - 1) && n_ids > 0)
             return fail(FCP_ERR_SHAPE_MISMATCH, "segment id tensor shorter than the id stream");
+          if (hc.ext.seg_map_n > 0) {
+            if (n_seg < n_ids * c.seg_stride) return fail(FCP_ERR_SHAPE_MISMATCH, "index matrix shorter than the id stream");
+            if (hc.ext.seg_map_sym >= 0) {
+              if (!symbols) return fail(FCP_ERR_INVALID_ARGUMENT, "plan needs the symbols tensor");
+              d.seg_sym = symbols[hc.ext.seg_map_sym];
+              if (d.seg_sym < (hc.ext.seg_map_sym_slot == 4 ? 1 : 0))
+                return fail(FCP_ERR_SHAPE_MISMATCH, "segment-id map: symbol value out of range");
+            }
+          }
           if (d.nnz > m->max_seg_nnz) m->max_seg_nnz = d.nnz;
           m->seg_pairs += rows;
         }
@@ -532,7 +564,7 @@ int compute_dyn_fast(const fcp_plan *p, const int32_t *offsets, const int32_t *s
     d.csr_base = -1;
     d.inner = 1;
     d.rows = (int32_t)rows;
-    d.pad_ = 0;
+    d.seg_sym = 1;
     if (c.form == FCP_FORM_GATHER) {
       if (n_ids != rows) return -1;
       d.nnz = (int32_t)n_ids;
@@ -633,6 +665,7 @@ void destroy_device(fcp_plan *p) {
   if (p->d_span_list) (void)hipFree(p->d_span_list);
   if (p->d_cols) (void)hipFree(p->d_cols);
   if (p->d_xforms) (void)hipFree(p->d_xforms);
+  if (p->d_segmaps) (void)hipFree(p->d_segmaps);
   if (p->d_const) (void)hipFree(p->d_const);
   if (p->d_seg_cols) (void)hipFree(p->d_seg_cols);
   if (p->d_bad) (void)hipFree(p->d_bad);
@@ -752,6 +785,19 @@ int init_device(fcp_plan *p) {
   if (!h_xforms.empty()) {
     HIP_TRY(hipMalloc(&p->d_xforms, nc * sizeof(FcpXform)));
     HIP_TRY(hipMemcpy(p->d_xforms, h_xforms.data(), nc * sizeof(FcpXform), hipMemcpyHostToDevice));
+  }
+  if (p->has_seg_map) {
+    std::vector<FcpSegMap> h_maps(nc);
+    for (int pos = 0; pos < nc; ++pos) {
+      const fcp_column_ext_t &e = p->cols[p->order[pos]].ext;
+      FcpSegMap &sm = h_maps[pos];
+      for (int i = 0; i < 4; ++i) sm.mul[i] = i < e.seg_map_n ? e.seg_map_mul[i] : 0;
+      sm.div = e.seg_map_n > 0 ? e.seg_map_div : 1;
+      sm.n = e.seg_map_n;
+      sm.sym_slot = e.seg_map_n > 0 && e.seg_map_sym >= 0 ? e.seg_map_sym_slot : -1;
+    }
+    HIP_TRY(hipMalloc(&p->d_segmaps, nc * sizeof(FcpSegMap)));
+    HIP_TRY(hipMemcpy(p->d_segmaps, h_maps.data(), nc * sizeof(FcpSegMap), hipMemcpyHostToDevice));
   }
   if (!p->seg_cols.empty()) {
     std::vector<int32_t> seg_pos;
@@ -1075,11 +1121,14 @@ int fcp_concat_inputs(const fcp_host_tensor_t *inputs, int32_t n, void *blob, in
 }
 
 // ---- plan ---------------------------------------------------------------------
-int fcp_plan_create(const fcp_plan_desc_t *desc, fcp_plan_t **out) {
+int fcp_plan_create(const fcp_plan_desc_t *desc, fcp_plan_t **out) { return fcp_plan_create_ex(desc, nullptr, out); }
+
+int fcp_plan_create_ex(const fcp_plan_desc_t *desc, const fcp_column_ext_t *ext, fcp_plan_t **out) {
   if (!out) return fail(FCP_ERR_INVALID_ARGUMENT, "null plan out pointer");
   *out = nullptr;
   int rc = validate_desc(desc);
   if (rc) return rc;
+  if (ext && (rc = validate_ext(desc, ext))) return rc;
   fcp_plan *p = new (std::nothrow) fcp_plan();
   if (!p) return fail(FCP_ERR_ALLOC, "out of host memory");
   p->desc = *desc;
@@ -1110,6 +1159,10 @@ int fcp_plan_create(const fcp_plan_desc_t *desc, fcp_plan_t **out) {
       hc.xf_hi.assign(hc.d.xform_hi, hc.d.xform_hi + hc.d.xform_n);
     }
     hc.d.xform_lo = hc.d.xform_hi = nullptr;
+    if (ext && ext[k].seg_map_n > 0) {
+      hc.ext = ext[k];
+      p->has_seg_map = true;
+    }
     if (hc.d.dim % 4) gcd4 = (hc.d.dim % 2) ? 1 : std::min(gcd4, 2);
     const int f = hc.d.form;
     if ((f == FCP_FORM_SEGMENT_REDUCE || f == FCP_FORM_GATHER_SCATTER) && hc.d.seg_kind != FCP_SEG_CSR_I32)
@@ -1121,6 +1174,7 @@ int fcp_plan_create(const fcp_plan_desc_t *desc, fcp_plan_t **out) {
   // ComputeSegmentOffsets pre-pass as a second, dependent launch.  Row-sharded plans keep the
   // pre-pass: fcp_shard_finalize needs the row lengths as CSR.  FCP_SEG_PREPASS=1: tuning aid.
   p->seg_search = desc->shard_world <= 1 && std::getenv("FCP_SEG_PREPASS") == nullptr;
+  if (p->has_seg_map) p->seg_search = false; // mapped segment ids are evaluated by the pre-pass only
   for (const HostColumn &hc : p->cols) {
     if (hc.d.seg_kind != FCP_SEG_NONE && hc.d.seg_stride > 0xffff) p->seg_search = false; // stride rides in 16 flag bits
     // ScatterNd columns take their row ids in any order (cuda_emitter.cc:296-345): nothing to search, the pre-pass
@@ -1169,7 +1223,7 @@ int fcp_plan_create(const fcp_plan_desc_t *desc, fcp_plan_t **out) {
   }
   p->pos_of.assign(desc->n_columns, 0);
   for (int pos = 0; pos < desc->n_columns; ++pos) p->pos_of[p->order[pos]] = pos;
-  if (desc->layout == FCP_LAYOUT_CONCAT && desc->n_groups <= 255) {
+  if (desc->layout == FCP_LAYOUT_CONCAT && desc->n_groups <= 255 && !p->has_seg_map) { // (maps: the general routine resolves their symbol)
     p->fast_cols.resize(desc->n_columns);
     p->group_rep.assign(desc->n_groups, -1);
     for (int pos = 0; pos < desc->n_columns; ++pos) {
@@ -1240,6 +1294,7 @@ struct ParsedPlanFile {
   std::vector<fcp_column_desc_t> cols;
   std::vector<std::vector<float>> bnd;
   std::vector<std::vector<int64_t>> xlo, xhi;
+  std::vector<fcp_column_ext_t> ext; // "segmaps" section (version 4); empty = no column has extensions
   // "stage" section (version 3): what Addons>ConcatInputs does to each of ITS inputs while packing
   std::vector<uint8_t> stage_modes;
   std::vector<int32_t> stage_rows_symbol;
@@ -1259,7 +1314,7 @@ int parse_plan_file(const char *path, ParsedPlanFile &P) {
   int version = 0, n_host = 0, n_cols = 0;
   fcp_plan_desc_t &d = P.d;
   std::memset(&d, 0, sizeof(d));
-  if (std::fscanf(f, "%31s %d", tag, &version) != 2 || std::strcmp(tag, "fcp_plan") || version < 1 || version > 3)
+  if (std::fscanf(f, "%31s %d", tag, &version) != 2 || std::strcmp(tag, "fcp_plan") || version < 1 || version > 4)
     return fail(FCP_ERR_INVALID_ARGUMENT, where + "bad header");
   if (std::fscanf(f, "%31s %d", tag, &d.layout) != 2 || std::strcmp(tag, "layout"))
     return fail(FCP_ERR_INVALID_ARGUMENT, where + "expected 'layout'");
@@ -1310,11 +1365,36 @@ int parse_plan_file(const char *path, ParsedPlanFile &P) {
       c.xform_hi = c.xform_n ? P.xhi[k].data() : nullptr;
     }
   }
-  if (version >= 3) { // optional: "stage N symbols_input K" + N x "mode rows_symbol"
-    int n_stage = 0, sym_in = -1;
-    const int got = std::fscanf(f, "%31s %d %31s %d", tag, &n_stage, t2, &sym_in);
-    if (got == 4) {
-      if (std::strcmp(tag, "stage") || std::strcmp(t2, "symbols_input") || n_stage < 0 || n_stage > (1 << 24) || sym_in < -1 || sym_in >= n_stage)
+  // optional trailing sections: "segmaps M" + M x "column n sym slot mul0 mul1 mul2 mul3 div" (version 4), then
+  // "stage N symbols_input K" + N x "mode rows_symbol" (version 3)
+  bool seen_maps = false;
+  for (;;) {
+    int count = 0;
+    const int got = std::fscanf(f, "%31s %d", tag, &count);
+    if (got == EOF || got == 0) break;
+    if (got != 2) return fail(FCP_ERR_INVALID_ARGUMENT, where + "malformed trailing section");
+    if (version >= 4 && !std::strcmp(tag, "segmaps") && !seen_maps && !P.has_stage) {
+      if (count < 0 || count > n_cols) return fail(FCP_ERR_INVALID_ARGUMENT, where + "bad 'segmaps M'");
+      seen_maps = true;
+      P.ext.assign(n_cols, fcp_column_ext_t{});
+      for (int i = 0; i < count; ++i) {
+        int col = -1, n = 0, sym = -1, slot = 0;
+        long long mul[4] = {0, 0, 0, 0}, div = 1;
+        if (std::fscanf(f, "%d %d %d %d %lld %lld %lld %lld %lld", &col, &n, &sym, &slot, &mul[0], &mul[1], &mul[2], &mul[3], &div) != 9 ||
+            col < 0 || col >= n_cols || n < 1 || n > FCP_SEG_MAP_MAX || P.ext[col].seg_map_n != 0)
+          return fail(FCP_ERR_INVALID_ARGUMENT, where + "malformed segmaps entry " + std::to_string(i));
+        fcp_column_ext_t &e = P.ext[col];
+        e.seg_map_n = n;
+        e.seg_map_sym = sym;
+        e.seg_map_sym_slot = slot;
+        for (int j = 0; j < 4; ++j) e.seg_map_mul[j] = mul[j];
+        e.seg_map_div = div;
+      }
+    } else if (version >= 3 && !std::strcmp(tag, "stage") && !P.has_stage) {
+      const int n_stage = count;
+      int sym_in = -1;
+      if (std::fscanf(f, "%31s %d", t2, &sym_in) != 2 || std::strcmp(t2, "symbols_input") || n_stage < 0 || n_stage > (1 << 24) ||
+          sym_in < -1 || sym_in >= n_stage)
         return fail(FCP_ERR_INVALID_ARGUMENT, where + "expected 'stage N symbols_input K'");
       P.stage_modes.resize(n_stage);
       P.stage_rows_symbol.resize(n_stage);
@@ -1328,8 +1408,8 @@ int parse_plan_file(const char *path, ParsedPlanFile &P) {
       }
       P.stage_symbols_input = sym_in;
       P.has_stage = true;
-    } else if (got != EOF && got != 0) {
-      return fail(FCP_ERR_INVALID_ARGUMENT, where + "malformed stage section");
+    } else {
+      return fail(FCP_ERR_INVALID_ARGUMENT, where + "unexpected section '" + tag + "'");
     }
   }
   d.abi_version = FCP_ABI_VERSION;
@@ -1356,7 +1436,7 @@ int fcp_plan_create_from_file(const char *path, int32_t device, uint32_t flags, 
                                               std::to_string(P.d.n_host_inputs) + " host inputs");
   P.d.device = device;
   P.d.flags = flags;
-  return fcp_plan_create(&P.d, out);
+  return fcp_plan_create_ex(&P.d, P.ext.empty() ? nullptr : P.ext.data(), out);
 }
 
 int fcp_plan_file_stage_info(const char *path, int32_t *n_inputs, uint8_t *modes, int32_t *rows_symbol, int32_t capacity,
@@ -1653,6 +1733,7 @@ int fcp_process_feature_columns(fcp_plan_t *p, const fcp_process_args_t *a, fcp_
     S.arena = L.arena;
     S.bad_ids = p->d_bad;
     S.xforms = p->d_xforms;
+    S.segmaps = p->d_segmaps;
     S.skip_inverse = 0;
     S.csr_arena_off = m.csr_arena_off;
     // any-order scatter columns build their inverse map with atomic max: their scratch starts from zero
@@ -1900,6 +1981,7 @@ int fcp_shard_finalize(fcp_plan_t *p, const fcp_process_args_t *a, int32_t group
     S.arena = static_cast<char *>(scratch);
     S.bad_ids = nullptr; // the partial pass has counted already
     S.xforms = p->d_xforms;
+    S.segmaps = p->d_segmaps;
     S.skip_inverse = 1;  // only the row lengths of mean columns are wanted here
     S.csr_arena_off = 0;
     const int e = fcp_launch_segment_offsets(S, (int)p->seg_cols.size(), m.max_seg_nnz, stream);

@@ -68,7 +68,17 @@ struct FcpColDyn {         // 48 bytes
   int32_t csr_base;        // int32 index into the arena CSR scratch (seg-id columns), or -1
   int32_t inner;           // BatchColReduction: rows reduced per output row
   int32_t rows;            // output rows (prefix size) of this column
-  int32_t pad_;
+  int32_t seg_sym;         // segment-id map: the request's value of the symbol one factor is multiplied by (else 1)
+};
+
+// Segment ids computed from several index coordinates (fcp_column_ext_t::seg_map_*: a SparseReshape folded into the
+// index expression, cuda_emitter.cc:1874-1916); per column, allocated only for plans that have one.  Read by the
+// segment-offset pre-pass only.
+struct FcpSegMap {         // 48 bytes
+  int64_t mul[4];
+  int64_t div;
+  int32_t n;               // 0: plain segment ids
+  int32_t sym_slot;        // which factor takes FcpColDyn::seg_sym: 0..3 = mul[slot], 4 = div, -1 = none
 };
 
 struct FcpGroupLaunch {
@@ -114,6 +124,7 @@ struct FcpSegLaunch {
   int64_t csr_arena_off;     // byte offset of the CSR scratch in the arena
   unsigned long long *bad_ids; // nullable: FCP_FLAG_COUNT_BAD_IDS also counts unsorted segment ids here
   const FcpXform *xforms;    // per column, or null (id filter of any-order scatter columns)
+  const FcpSegMap *segmaps;  // per column, or null (segment ids from several index coordinates)
   int32_t skip_inverse;      // 1: leave the any-order scatter columns alone (fcp_shard_finalize only wants row lengths)
 };
 

@@ -1167,6 +1167,22 @@ __device__ __forceinline__ int64_t load_seg(const char *seg, unsigned segkind, i
   return ld_i64_a4(seg + 8 * i * stride);
 }
 
+// Segment id of element i when it is a function of several index coordinates (FcpSegMap: a SparseReshape folded into
+// the index expression, cuda_emitter.cc:1874-1916): (sum_k idx[i*stride + k] * mul[k]) / div, one factor scaled by the
+// request's symbol.  Rare columns, cold code: out of line, 64-bit division and all.
+__device__ __noinline__ int64_t load_seg_mapped(const char *seg, unsigned segkind, int stride, int64_t i, const FcpSegMap *mp,
+                                                int64_t sym) {
+  const FcpSegMap m = *mp;
+  int64_t lin = 0;
+  for (int k = 0; k < m.n; ++k) {
+    const int64_t v = load_seg(seg, segkind, 1, i * stride + k);
+    if (v < 0) return -1; // not an index: sorts before every row
+    lin += v * (m.sym_slot == k ? m.mul[k] * sym : m.mul[k]);
+  }
+  const int64_t div = m.sym_slot == 4 ? m.div * sym : m.div;
+  return lin / div;
+}
+
 // One block = FCP_SEG_IDS_PER_BLOCK consecutive positions of one column's id stream, in rounds of 256 (neighbouring
 // lanes hold neighbouring ids); every load of the block is issued before the first boundary test, so the block is one
 // memory round trip long whatever the number of rounds.  (Round 1: one id per thread, 4x the blocks — the same time
@@ -1224,13 +1240,26 @@ __global__ void __launch_bounds__(FCP_BLOCK_THREADS) fcp_segment_offsets_kernel(
     return;
   }
   int64_t cur[FCP_SEG_ROUNDS], first_prev[FCP_SEG_ROUNDS];
+  if (L.segmaps && L.segmaps[c].n > 0) { // (uniform per block)
+    const FcpSegMap *mp = L.segmaps + c;
+    const int64_t sym = cd.seg_sym;
+#pragma unroll 1
+    for (int r = 0; r < FCP_SEG_ROUNDS; ++r) {
+      const int64_t i = base + r * FCP_BLOCK_THREADS + threadIdx.x;
+      cur[r] = rows;
+      if (i < nnz) cur[r] = load_seg_mapped(seg, segkind, stride, i, mp, sym);
+      first_prev[r] = -1;
+      if (lane == 0 && i > 0 && i <= nnz) first_prev[r] = load_seg_mapped(seg, segkind, stride, i - 1, mp, sym);
+    }
+  } else {
 #pragma unroll
-  for (int r = 0; r < FCP_SEG_ROUNDS; ++r) {
-    const int64_t i = base + r * FCP_BLOCK_THREADS + threadIdx.x;
-    cur[r] = rows;
-    if (i < nnz) cur[r] = load_seg(seg, segkind, stride, i);
-    first_prev[r] = -1;
-    if (lane == 0 && i > 0 && i <= nnz) first_prev[r] = load_seg(seg, segkind, stride, i - 1); // the neighbour wave's last id
+    for (int r = 0; r < FCP_SEG_ROUNDS; ++r) {
+      const int64_t i = base + r * FCP_BLOCK_THREADS + threadIdx.x;
+      cur[r] = rows;
+      if (i < nnz) cur[r] = load_seg(seg, segkind, stride, i);
+      first_prev[r] = -1;
+      if (lane == 0 && i > 0 && i <= nnz) first_prev[r] = load_seg(seg, segkind, stride, i - 1); // the neighbour wave's last id
+    }
   }
 #pragma unroll
   for (int r = 0; r < FCP_SEG_ROUNDS; ++r) {

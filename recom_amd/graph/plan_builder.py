@@ -83,6 +83,14 @@ class IndexSource:
     hash_buckets: int = 0                # StringToHashBucketFast(AsString(int ids)) absorbed: hash on the device
     filter_node: Optional[str] = None    # the Gather* node whose (indices, values) pair this operand belongs to
     generated_rows: bool = False         # indices output of GatherValueGenIndice: row i of the values tensor
+    # a SparseReshape folded into the index expression (cuda_emitter.cc:1874-1916): `reshaped` is set while the operand
+    # is the op's whole output_indices matrix, (input rank, mul, div, symbol source, symbol slot); the [:, 0:1] slice
+    # turns it into the segment-id map below (ColumnSpec.seg_mul / seg_div / seg_sym / seg_sym_slot)
+    reshaped: Optional[tuple] = None
+    seg_mul: Tuple[int, ...] = ()
+    seg_div: int = 1
+    seg_sym: Optional[Tuple[str, int]] = None      # (tensor, flat index) whose value multiplies one factor
+    seg_sym_slot: int = 0
 
 
 @dataclass
@@ -260,12 +268,16 @@ class PlanBuilder:
             src.hash_buckets = int(node.attr["num_buckets"].i)
             return src
         if node.op == "SparseReshape":
-            # output_indices of a reshape that provably keeps [rows, k]: read the input indices in place.
-            # Anything else (rank change, unprovable shapes) ends the walk: TensorFlow computes the op and
-            # its output tensor is shipped, as for any op the reference does not inline (:1924-1933).
-            if not self._sparse_reshape_is_identity(node):
-                raise Unsupported("SparseReshape is not provably the identity on [rows, k] indices")
-            return self.trace_index(*g.input(node, 0))
+            # output_indices of a reshape whose row coordinate is an expression of the input coordinates with
+            # provable factors (:1874-1916): the column reads the ORIGINAL index matrix and the pre-pass evaluates the
+            # expression.  Anything else (unprovable shapes, several run-time factors) ends the walk: TensorFlow
+            # computes the op and its output tensor is shipped, as for any op the reference does not inline (:1924-1933).
+            m = self._sparse_reshape_map(node)
+            src = self.trace_index(*g.input(node, 0))
+            if src.reshaped is not None or src.stride != 1 or src.boundaries is not None or src.rank != 2:
+                raise Unsupported("SparseReshape over a transformed index matrix")
+            src.reshaped = m
+            return src
         if node.op in RESHAPE_LIKE or node.op == "Identity":
             return self.trace_index(*g.input(node, 0))          # flat element index unchanged
         if node.op == "Cast":
@@ -305,6 +317,13 @@ class PlanBuilder:
             src = self.trace_index(in_node, in_port)
             if src.boundaries is not None:
                 raise Unsupported("slice of bucketized values")
+            if src.reshaped is not None:       # column 0 of a SparseReshape's output: the row coordinate of the map
+                rank, mul, div, sym, slot = src.reshaped
+                src.reshaped = None
+                src.stride *= rank
+                if not (mul == (1,) and div == 1 and sym is None):      # (the identity on idx0 needs no map)
+                    src.seg_mul, src.seg_div, src.seg_sym, src.seg_sym_slot = mul, div, sym, slot
+                return src
             src.stride *= int(in_shape[1])
             return src
         raise Unsupported("not an inlinable op")
@@ -354,25 +373,66 @@ class PlanBuilder:
             return src
         raise Unsupported("not an inlinable op")
 
-    def _sparse_reshape_is_identity(self, node) -> bool:
-        """``SparseReshape(indices [nnz, 2], shape [2], new_shape [2])`` with ``new_shape[1]`` provably the
-        same number as ``shape[1]``: then ``row' = (row * shape[1] + col) / new_shape[1] = row`` and
-        ``col' = col`` for every element (``0 <= col < shape[1]``), so the op changes nothing — the case the
-        reference's flat-index algebra (``cuda_emitter.cc:1874-1916``) reduces to for the 2-D SparseTensors
-        ``safe_embedding_lookup_sparse`` produces."""
+    def _sparse_reshape_map(self, node) -> tuple:
+        """``SparseReshape(indices [nnz, r], shape [r], new_shape [q])``: the row coordinate of the reshaped element is
+        ``(sum_k idx_k * prod(shape[k+1:])) // prod(new_shape[1:])`` (the reference's flat-index algebra,
+        ``cuda_emitter.cc:1874-1916``, offset 0; it asks SymEngine for the shapes' contents, here every entry is traced
+        to a constant or to a plain copy of one element of another tensor, ``GraphView.elem_source``).  A trailing
+        coordinate drops out when its dimension divides the denominator (``idx < dim``), which is what makes the usual
+        ``[B, L] -> [B, L]`` and ``[B, T, L] -> [B*T, L]`` reshapes independent of the run-time ``L``.  What remains may
+        contain ONE run-time factor (it becomes a symbol).  -> (r, mul, div, symbol source or None, symbol slot)."""
         g = self.g
         shape, new = g.input(node, 1), g.input(node, 2)
-        if g.static_shape(*shape) != [2] or g.static_shape(*new) != [2]:
-            return False
-        a, b = g.elem_source(*shape, 1), g.elem_source(*new, 1)
-        if a is None or a != b:
-            return False
-        return not (a[0] == "const" and a[1] <= 0)          # a literal -1 would be inferred at run time
+        rs, qs = g.static_shape(*shape), g.static_shape(*new)
+        if rs is None or qs is None or len(rs) != 1 or len(qs) != 1 or rs[0] is None or qs[0] is None:
+            raise Unsupported("SparseReshape: ranks unknown")
+        r, q = int(rs[0]), int(qs[0])
+        if not 1 <= r <= 4 or q < 1:
+            raise Unsupported("SparseReshape: more than 4 input coordinates")
+        ins = [g.elem_source(*shape, k) for k in range(1, r)]
+        outs = [g.elem_source(*new, k) for k in range(1, q)]
+        if any(e is None or (e[0] == "const" and e[1] <= 0) for e in ins + outs):
+            raise Unsupported("SparseReshape: a dimension is computed (or inferred at run time)")
+
+        def product(entries):
+            c, syms = 1, []
+            for e in entries:
+                if e[0] == "const":
+                    c *= int(e[1])
+                else:
+                    syms.append((e[1], int(e[2])))
+            return [c, syms]
+
+        mul = [product(ins[k:]) for k in range(r)]          # multiplier of coordinate k: prod(shape[k+1:])
+        div = product(outs)
+        n = r
+        while n >= 2:                                       # drop trailing coordinates whose dimension divides `div`
+            last = ins[n - 2]                               # shape[n-1]
+            if last[0] == "const":
+                if div[0] % last[1]:
+                    break
+                div[0] //= last[1]
+                for k in range(n - 1):
+                    mul[k][0] //= last[1]
+            else:
+                key = (last[1], int(last[2]))
+                if key not in div[1]:
+                    break
+                div[1].remove(key)
+                for k in range(n - 1):
+                    mul[k][1].remove(key)
+            n -= 1
+        mul = mul[:n]
+        runtime = [(slot, f[1]) for slot, f in list(enumerate(mul)) + [(4, div)] if f[1]]
+        if len(runtime) > 1 or (runtime and len(runtime[0][1]) != 1):
+            raise Unsupported("SparseReshape: more than one run-time factor")
+        sym, slot = (runtime[0][1][0], runtime[0][0]) if runtime else (None, 0)
+        return r, tuple(int(f[0]) for f in mul), int(div[0]), sym, slot
 
     def _ids_operand(self, node, port: int):
         """-> (host input, id_source, boundaries, transform kwargs for ColumnSpec, filter node)"""
         src = self.trace_index(node, port)
-        if src.stride != 1 or src.generated_rows:  # no strided id source in the column record
+        if src.stride != 1 or src.generated_rows or src.reshaped is not None:  # no strided id source in the column record
             src = self._terminal(node, port)
         if src.boundaries is not None:
             id_source = IDS_F32_BUCKETIZE
@@ -386,19 +446,23 @@ class PlanBuilder:
                   xform_substitute=src.xform_substitute, hash_buckets=src.hash_buckets)
         return self._host_input(src.tensor, src.dtype, src.rank), id_source, src.boundaries, xf, src.filter_node
 
-    def _seg_operand(self, node, port: int, filter_node: Optional[str] = None) -> Tuple[int, int, int]:
+    def _seg_operand(self, node, port: int, filter_node: Optional[str] = None, allow_map: bool = False) -> tuple:
         """``filter_node``: the Gather* op the column's ids went through; its indices output may be read
         through (the kernel drops the same pairs), any other filtered index stream may not."""
         src = self.trace_index(node, port)
         if src.boundaries is not None or src.xform_mode != XFORM_NONE or src.generated_rows or \
-                src.filter_node != filter_node:
+                src.filter_node != filter_node or src.reshaped is not None or (src.seg_mul and not allow_map):
             if filter_node is not None:
                 raise Unsupported("segment ids do not come from the id filter's indices output")
             src = self._terminal(node, port)
         kind = {P.DT_INT32: SEG_IDS_I32, P.DT_INT64: SEG_IDS_I64}.get(src.dtype)
         if kind is None:
             raise Unsupported(f"segment ids {src.tensor} have dtype {src.dtype}")
-        return self._host_input(src.tensor, src.dtype, src.rank), kind, src.stride
+        seg_map = {}
+        if src.seg_mul:                  # a SparseReshape folded in: the row coordinate as an expression of the original ones
+            seg_map = dict(seg_mul=src.seg_mul, seg_div=src.seg_div, seg_sym_slot=src.seg_sym_slot,
+                           seg_sym=-1 if src.seg_sym is None else self._symbol(*src.seg_sym))
+        return self._host_input(src.tensor, src.dtype, src.rank), kind, src.stride, seg_map
 
     # ---- EmitSubgraphCode dispatch (cuda_emitter.cc:1096-1152) --------------------------
     def _match_gather(self, node):
@@ -433,14 +497,14 @@ class PlanBuilder:
         if node.op in SEGMENT_OPS:                                                  # EmitSparseSegmentReduce* :1444-1760
             table, vocab, dim = self._table_of(*g.input(node, 0))
             ids_in, id_source, bnd, xf, fnode = self._ids_operand(*g.input(node, 1))
-            seg_in, seg_kind, stride = self._seg_operand(*g.input(node, 2), fnode)
+            seg_in, seg_kind, stride, seg_map = self._seg_operand(*g.input(node, 2), fnode, allow_map=True)
             n_node, n_port = g.input(node, 3)
             while n_node.op in RESHAPE_LIKE and n_port == 0:                        # Squeeze(num_segments) lookup_optimizer.cc:248-254
                 n_node, n_port = g.input(n_node, 0)
             sym = self._symbol(tensor_name(n_node.name, n_port), 0)
             return ColumnSpec(FORM_SEGMENT_REDUCE, dim, vocab, SEGMENT_OPS[node.op], id_source,
                               self._device_input(table), ids_in, seg_in, seg_kind, stride, ROWS_FROM_SYMBOL, sym, bnd,
-                              group, slot, **xf)
+                              group, slot, **xf, **seg_map)
         if node.op in ("SparseSegmentSum", "SparseSegmentMean"):
             raise Unsupported("row count is data dependent without num_segments")
         if node.op == "ScatterNd":                                                  # EmitGatherScatterRows :1332-1442
@@ -454,7 +518,7 @@ class PlanBuilder:
                 # goes to row i — a one-hot gather over the ORIGINAL values whose dropped ids leave zero rows
                 return ColumnSpec(FORM_GATHER, dim, vocab, COMBINER_NONE, id_source, self._device_input(table), ids_in,
                                   -1, SEG_NONE, 1, ROWS_FROM_IDS, 0, bnd, group, slot, **xf)
-            seg_in, seg_kind, stride = self._seg_operand(*g.input(node, 0), fnode)
+            seg_in, seg_kind, stride, _ = self._seg_operand(*g.input(node, 0), fnode)
             shp, shp_port = g.input(node, 2)
             sym = self._symbol(tensor_name(shp.name, shp_port), 0)
             return ColumnSpec(FORM_GATHER_SCATTER, dim, vocab, COMBINER_NONE, id_source, self._device_input(table),

@@ -46,6 +46,14 @@ class ColumnDesc(C.Structure):
     ]
 
 
+class ColumnExt(C.Structure):
+    """fcp_column_ext_t: per-column extensions (segment-id maps)"""
+    _fields_ = [
+        ("seg_map_n", C.c_int32), ("seg_map_sym", C.c_int32), ("seg_map_sym_slot", C.c_int32), ("reserved0", C.c_int32),
+        ("seg_map_mul", C.c_int64 * 4), ("seg_map_div", C.c_int64), ("reserved1", C.c_int64 * 2),
+    ]
+
+
 class PlanDesc(C.Structure):
     _fields_ = [
         ("abi_version", C.c_int32), ("n_columns", C.c_int32),
@@ -97,7 +105,7 @@ class HostTensor(C.Structure):
 EXPORTS = [
     "fcp_abi_version", "fcp_status_string", "fcp_last_error",
     "fcp_concat_inputs_sizes", "fcp_concat_inputs",
-    "fcp_plan_create", "fcp_plan_create_from_file", "fcp_plan_counts", "fcp_plan_destroy", "fcp_plan_group_width",
+    "fcp_plan_create", "fcp_plan_create_ex", "fcp_plan_create_from_file", "fcp_plan_counts", "fcp_plan_destroy", "fcp_plan_group_width",
     "fcp_plan_column_offset",
     "fcp_plan_arena_bytes", "fcp_plan_read_bad_ids", "fcp_plan_output_columns", "fcp_plan_table_bytes",
     "fcp_placement_decide", "fcp_plan_release_captures",
@@ -161,6 +169,8 @@ def load() -> C.CDLL:
     L.fcp_concat_inputs.argtypes = [C.POINTER(HostTensor), C.c_int32, C.c_void_p, C.c_int64,
                                     C.c_void_p, C.c_void_p]
     L.fcp_plan_create.argtypes = [C.POINTER(PlanDesc), C.POINTER(C.c_void_p)]
+    if hasattr(L, "fcp_plan_create_ex"):
+        L.fcp_plan_create_ex.argtypes = [C.POINTER(PlanDesc), C.POINTER(ColumnExt), C.POINTER(C.c_void_p)]
     L.fcp_plan_create_from_file.argtypes = [C.c_char_p, C.c_int32, C.c_uint32, C.POINTER(C.c_void_p)]
     L.fcp_plan_counts.argtypes = [C.c_void_p] + [C.POINTER(C.c_int32)] * 5
     L.fcp_plan_destroy.argtypes = [C.c_void_p]

@@ -133,7 +133,17 @@ class Plan:
             spec.n_device_inputs, spec.n_groups, spec.n_symbols, spec.layout, device,
             spec.shard_rank, spec.shard_world, flags)
         handle = C.c_void_p()
-        _lib.check(self._L.fcp_plan_create(C.byref(desc), C.byref(handle)), "fcp_plan_create")
+        if any(len(c.seg_mul) for c in spec.columns):                  # per-column extensions: segment-id maps
+            ext = (_lib.ColumnExt * spec.n_columns)()
+            for k, c in enumerate(spec.columns):
+                if len(c.seg_mul):
+                    ext[k].seg_map_n, ext[k].seg_map_sym, ext[k].seg_map_sym_slot = len(c.seg_mul), c.seg_sym, c.seg_sym_slot
+                    for j, v in enumerate(list(c.seg_mul)[:4]):
+                        ext[k].seg_map_mul[j] = int(v)
+                    ext[k].seg_map_div = int(c.seg_div)
+            _lib.check(self._L.fcp_plan_create_ex(C.byref(desc), ext, C.byref(handle)), "fcp_plan_create_ex")
+        else:
+            _lib.check(self._L.fcp_plan_create(C.byref(desc), C.byref(handle)), "fcp_plan_create")
         self.handle = handle
 
     @classmethod

@@ -66,6 +66,15 @@ class ColumnSpec:
     # > 0: integer ids are hashed into buckets first — Fingerprint64(decimal string) % hash_buckets, TensorFlow's
     # AsString -> StringToHashBucketFast (categorical_column_with_hash_bucket over integer features)
     hash_buckets: int = 0
+    # Segment ids that are a function of several index coordinates: a SparseReshape between the SparseTensor and the
+    # lookup, folded into the index expression as the reference does (EmitInputInline, cuda_emitter.cc:1874-1916):
+    #   seg(i) = (sum_k idx[i*seg_stride + k] * seg_mul[k]) // seg_div    over the first len(seg_mul) coordinates;
+    # one factor (seg_sym_slot: 0..3 = seg_mul[slot], 4 = seg_div) is multiplied by symbol seg_sym when seg_sym >= 0.
+    # () = plain segment ids, idx[i*seg_stride].  (fcp_column_ext_t in include/fcp_hip.h)
+    seg_mul: Sequence[int] = ()
+    seg_div: int = 1
+    seg_sym: int = -1
+    seg_sym_slot: int = 0
 
     def validate(self) -> None:
         if self.form not in (1, 2, 3, 4, 5, 6):
@@ -87,6 +96,14 @@ class ColumnSpec:
                 raise ValueError("pooled/scatter column needs an explicit row count source")
         if self.form == FORM_SEGMENT_REDUCE and self.combiner not in (COMBINER_SUM, COMBINER_MEAN):
             raise ValueError("segment-reduce column needs sum or mean")
+        if len(self.seg_mul):
+            if self.form != FORM_SEGMENT_REDUCE or self.seg_kind not in (SEG_IDS_I32, SEG_IDS_I64):
+                raise ValueError("a segment-id map needs a pooled column with segment ids")
+            if len(self.seg_mul) > 4 or self.seg_stride < len(self.seg_mul) or self.seg_div < 1 or \
+                    any(v < 0 for v in self.seg_mul):
+                raise ValueError("bad segment-id map")
+            if self.seg_sym >= 0 and not (self.seg_sym_slot == 4 or 0 <= self.seg_sym_slot < len(self.seg_mul)):
+                raise ValueError("bad segment-id map symbol slot")
         if self.hash_buckets:
             if self.form not in (FORM_GATHER, FORM_SEGMENT_REDUCE, FORM_GATHER_SCATTER) or self.hash_buckets < 0 or \
                     self.id_source == IDS_F32_BUCKETIZE:
@@ -198,6 +215,7 @@ class PlanSpec:
             c["boundaries"] = None if src.boundaries is None else np.asarray(src.boundaries, np.float32)
             c["xform_lo"] = [int(v) for v in src.xform_lo]
             c["xform_hi"] = [int(v) for v in src.xform_hi]
+            c["seg_mul"] = [int(v) for v in src.seg_mul]
         return d
 
     def with_shard(self, rank: int, world: int) -> "PlanSpec":
@@ -251,7 +269,9 @@ class PlanSpec:
             for k, c in enumerate(spec.columns):
                 # pooled columns only: their segment ids are sorted (TF's SparseSegment* contract); a ScatterNd column
                 # takes its row ids in any order (cuda_emitter.cc:296-345) and keeps them as they are
-                if c.form == FORM_SEGMENT_REDUCE and c.seg_kind in (SEG_IDS_I32, SEG_IDS_I64):
+                # (a column whose segment ids are computed from several coordinates keeps its index matrix: the
+                # pre-pass evaluates the map on the device)
+                if c.form == FORM_SEGMENT_REDUCE and c.seg_kind in (SEG_IDS_I32, SEG_IDS_I64) and not len(c.seg_mul):
                     users.setdefault(c.seg_input, []).append(k)
             for i, ks in users.items():
                 # an input is converted only if every reader is such a column with the same stride and the same row count

@@ -17,7 +17,8 @@ def save_plan(spec: PlanSpec, path: str, stage: "StageInfo | None" = None) -> No
     if stage is not None and len(stage.modes) != spec.n_host_inputs:
         raise ValueError("the stage section lists one entry per host input of the plan")
     with open(path, "w") as f:
-        f.write(f"fcp_plan {3 if stage is not None else 2}\n")
+        maps = [(k, c) for k, c in enumerate(spec.columns) if len(c.seg_mul)]
+        f.write(f"fcp_plan {4 if maps else 3 if stage is not None else 2}\n")
         f.write(f"layout {spec.layout}\n")
         f.write(f"groups {spec.n_groups} symbols {spec.n_symbols} device_inputs {spec.n_device_inputs}\n")
         f.write(f"host_inputs {spec.n_host_inputs}\n")
@@ -34,6 +35,11 @@ def save_plan(spec: PlanSpec, path: str, stage: "StageInfo | None" = None) -> No
             x = [c.xform_mode, len(c.xform_lo), c.xform_substitute, c.hash_buckets] + \
                 [v for p in zip(c.xform_lo, c.xform_hi) for v in p]
             f.write(" " + " ".join(str(int(v)) for v in x) + "\n")
+        if maps:     # version 4: segment-id maps — column, coordinates, symbol, symbol slot, mul0..mul3, div
+            f.write(f"segmaps {len(maps)}\n")
+            for k, c in maps:
+                mul = [int(v) for v in c.seg_mul] + [0] * (4 - len(c.seg_mul))
+                f.write(" ".join(str(int(v)) for v in [k, len(c.seg_mul), c.seg_sym, c.seg_sym_slot] + mul + [c.seg_div]) + "\n")
         if stage is not None:
             f.write(f"stage {len(stage.modes)} symbols_input {stage.symbols_input}\n")
             for m, k in zip(stage.modes, stage.rows_symbol):
@@ -53,7 +59,7 @@ def load_plan(path: str) -> PlanSpec:
     if nxt() != "fcp_plan":
         raise ValueError("bad plan header")
     version = int(nxt())
-    if version not in (1, 2, 3):
+    if version not in (1, 2, 3, 4):
         raise ValueError("bad plan header")
     assert nxt() == "layout"
     layout = int(nxt())
@@ -85,6 +91,13 @@ def load_plan(path: str) -> PlanSpec:
                                rows_arg=v[11], concat_group=v[12], concat_slot=v[13], boundaries=b,
                                xform_mode=mode, xform_lo=tuple(lo), xform_hi=tuple(hi), xform_substitute=sub,
                                hash_buckets=hb))
+    rest = list(it)
+    if version >= 4 and rest[:1] == ["segmaps"]:
+        import dataclasses
+        for j in range(int(rest[1])):
+            v = [int(x) for x in rest[2 + 9 * j: 11 + 9 * j]]
+            cols[v[0]] = dataclasses.replace(cols[v[0]], seg_mul=tuple(v[4:4 + v[1]]), seg_div=v[8], seg_sym=v[2],
+                                             seg_sym_slot=v[3])
     spec = PlanSpec(cols, ranks, esz, n_dev, n_groups=n_groups, n_symbols=n_symbols, layout=layout)
     spec.validate()
     return spec

@@ -342,8 +342,9 @@ def sparse_reshape_model(B=23, seed=0):
     """Two pooled columns whose SparseTensor indices pass through ``SparseReshape`` before ``[:, 0]``, the
     way ``safe_embedding_lookup_sparse`` flattens its ids (``tf.sparse.reshape(ids, [prod(shape[:-1]),
     shape[-1]])``): column ``p`` reshapes [B, L] -> [B, L] (provably the identity: the plan builder reads the
-    input indices in place), column ``q`` reshapes [B, 2L] -> [2B, L] (not the identity: the op stays in
-    TensorFlow and its output is shipped); each feeds its own ConcatV2 next to a one-hot column.
+    input indices in place), column ``q`` reshapes [B, 2L] -> [2B, L] (row = (idx0 * 2L + idx1) // L with 2L known per
+    request only: a segment-id map with one run-time factor); ``r``, ``s``, ``u`` below; each feeds its own ConcatV2
+    next to a one-hot column.
     Returns (graph_def, feeds, variables, fetches)."""
     rng = np.random.default_rng(seed)
     g = GB()
@@ -390,6 +391,59 @@ def sparse_reshape_model(B=23, seed=0):
         n_rows = rows if identity else 2 * rows             # q's reshape doubles the rows
         g.placeholder(f"{name}/dense_ids", np.int64, [-1])
         feeds[f"{name}/dense_ids"] = rng.integers(0, 40, size=n_rows).astype(np.int64)
+        dense = g.gather(f"input_layer/{name}_dense_embedding/GatherDense", d, f"{name}/dense_ids", np.int64)
+        g.const(f"{name}/concat/axis", np.asarray(1, np.int32))
+        g.node(f"{name}_layer/concat", "ConcatV2", [pooled, dense, f"{name}/concat/axis"], N=2, T=("type", P.DT_FLOAT),
+               Tidx=("type", P.DT_INT32))
+        ins.append(g.node(f"output_{name}", "Identity", [f"{name}_layer/concat"], T=("type", P.DT_FLOAT)))
+
+    # three more: `r` is safe_embedding_lookup_sparse over a RANK-3 SparseTensor, [B, T, L] -> [prod(shape[:-1]), shape[-1]]
+    # with T and L known per request only (row = idx0 * T + idx1: one run-time factor); `s` has constant shapes,
+    # [2B, 4, 6] -> [4B, 12] (row = (idx0 * 4 + idx1) // 2 after cancelling the 6); `u` takes its new shape from a
+    # placeholder: nothing is provable, the op stays in TensorFlow
+    for name, vocab, dim in (("r", 77, 12), ("s", 65, 20), ("u", 59, 4)):
+        T_, L = 3, 5
+        ishape = {"r": (B, T_, L), "s": (2 * B, 4, 6), "u": (B, 2 * L)}[name]
+        oshape = {"r": (B * T_, L), "s": (4 * B, 12), "u": (2 * B, L)}[name]
+        total = int(np.prod(ishape))
+        nnz = int(rng.integers(0, min(total, 6 * B) + 1))
+        flat = np.sort(rng.choice(total, size=nnz, replace=False))
+        idx = np.stack(np.unravel_index(flat, ishape), 1).astype(np.int64).reshape(nnz, len(ishape))
+        t = g.variable(f"input_layer/{name}_embedding/embedding_weights", vocab, dim)
+        variables[t] = rng.standard_normal((vocab, dim)).astype(np.float32)
+        g.placeholder(f"{name}/values", np.int64, [-1])
+        g.placeholder(f"{name}/indices", np.int64, [-1, len(ishape)])
+        feeds[f"{name}/values"] = rng.integers(0, vocab, size=nnz).astype(np.int64)
+        feeds[f"{name}/indices"] = idx
+        one = lambda s_, v: g.const(f"{name}/{s_}", np.asarray([v], np.int32))
+        if name == "s":
+            g.const(f"{name}/dense_shape", np.asarray(ishape, np.int64))
+            g.const(f"{name}/new_shape", np.asarray(oshape, np.int64))
+        else:
+            g.placeholder(f"{name}/dense_shape", np.int64, [len(ishape)])
+            feeds[f"{name}/dense_shape"] = np.asarray(ishape, np.int64)
+        if name == "r":
+            g.node(f"{name}/lead", "StridedSlice", [f"{name}/dense_shape", one("lb", 0), one("le", 2), one("ls", 1)],
+                   T=("type", P.DT_INT64), Index=("type", P.DT_INT32))
+            g.const(f"{name}/axis0", np.asarray([0], np.int32))
+            g.node(f"{name}/rows", "Prod", [f"{name}/lead", f"{name}/axis0"], T=("type", P.DT_INT64), Tidx=("type", P.DT_INT32))
+            g.node(f"{name}/last", "StridedSlice", [f"{name}/dense_shape", one("tb", 2), one("te", 3), one("ts", 1)],
+                   T=("type", P.DT_INT64), Index=("type", P.DT_INT32), shrink_axis_mask=1)
+            g.node(f"{name}/new_shape", "Pack", [f"{name}/rows", f"{name}/last"], N=2, T=("type", P.DT_INT64), axis=0)
+        if name == "u":
+            g.placeholder(f"{name}/new_shape", np.int64, [2])
+            feeds[f"{name}/new_shape"] = np.asarray(oshape, np.int64)
+        g.node(f"{name}/SparseReshape", "SparseReshape", [f"{name}/indices", f"{name}/dense_shape", f"{name}/new_shape"])
+        seg = g.slice_col0(f"{name}/added_strided_slice", f"{name}/SparseReshape", shrink=True)
+        g.node(f"{name}/num_segments", "StridedSlice", [f"{name}/SparseReshape:1", one("nb", 0), one("ne", 1), one("ns", 1)],
+               T=("type", P.DT_INT64), Index=("type", P.DT_INT32), shrink_axis_mask=1)
+        op = "SparseSegmentMeanWithNumSegments" if name == "r" else "SparseSegmentSumWithNumSegments"
+        pooled = g.node(f"{name}/{op}", op, [t, f"{name}/values", seg, f"{name}/num_segments"], T=("type", P.DT_FLOAT),
+                        Tidx=("type", P.DT_INT64), Tsegmentids=("type", P.DT_INT64), Tnumsegments=("type", P.DT_INT64))
+        d = g.variable(f"input_layer/{name}_dense_embedding/embedding_weights", 40, 4)
+        variables[d] = rng.standard_normal((40, 4)).astype(np.float32)
+        g.placeholder(f"{name}/dense_ids", np.int64, [-1])
+        feeds[f"{name}/dense_ids"] = rng.integers(0, 40, size=oshape[0]).astype(np.int64)
         dense = g.gather(f"input_layer/{name}_dense_embedding/GatherDense", d, f"{name}/dense_ids", np.int64)
         g.const(f"{name}/concat/axis", np.asarray(1, np.int32))
         g.node(f"{name}_layer/concat", "ConcatV2", [pooled, dense, f"{name}/concat/axis"], N=2, T=("type", P.DT_FLOAT),

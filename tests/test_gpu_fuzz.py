@@ -52,6 +52,7 @@ def random_model(rng, dense_only=False, extended=True):
     n_groups = int(rng.integers(1, 4))
     n_cols = int(rng.integers(1, 40)) if rng.random() > 0.12 else int(rng.integers(100, 400))   # some plans span dozens of 64-slot spans
     cols, ranks, esz, tables, gens = [], [], [], [], []
+    extra_syms = []                      # symbols beyond the groups' row counts: per-request factors of segment-id maps
     slots = [0] * n_groups
 
     def host(rank, e):
@@ -126,14 +127,27 @@ def random_model(rng, dense_only=False, extended=True):
         max_len = int(rng.choice([1, 1, 3])) if form == FORM_GATHER_SCATTER else int(rng.choice([0, 1, 3, 10, 10, 70, 200, 500]))
         shuffle = form == FORM_GATHER_SCATTER and seg != "csr" and rng.random() < 0.7
         i = host(1, id_esz)
+        # a SparseReshape folded into the segment ids (fcp_column_ext_t::seg_map_*, cuda_emitter.cc:1874-1916): the row is
+        # idx0 // A ("div": [B*A, L] -> [B, A*L]) or idx0 * T + idx1 ("mul": [B/T, T, L] -> [B, L]) of the index matrix,
+        # with A / T a constant or a per-request symbol
+        segmap, seg_kw = None, {}
+        if extended and seg == "indices" and form == FORM_SEGMENT_REDUCE and rng.random() < 0.35:
+            segmap = (str(rng.choice(["div", "mul"])), int(rng.integers(1, 6)))
+            as_symbol = rng.random() < 0.5
+            if as_symbol:
+                extra_syms.append(segmap[1])
+            sym = n_groups + len(extra_syms) - 1 if as_symbol else -1
+            f = 1 if as_symbol else segmap[1]
+            seg_kw = dict(seg_mul=(1,), seg_div=f, seg_sym=sym, seg_sym_slot=4) if segmap[0] == "div" else \
+                dict(seg_mul=(f, 1), seg_div=1, seg_sym=sym, seg_sym_slot=0)
         if seg == "csr":
             si, kind, stride = host(1, 4), SEG_CSR_I32, 1
         elif seg == "indices":
-            si, kind, stride = host(2, 8), SEG_IDS_I64, 2
+            si, kind, stride = host(2, 8), SEG_IDS_I64, (3 if segmap and segmap[0] == "mul" else 2)
         else:
             si, kind, stride = host(1, 4), SEG_IDS_I32, 1
 
-        def gen(r, B, d=draw_ids, seg=seg, max_len=max_len, shuffle=shuffle):
+        def gen(r, B, d=draw_ids, seg=seg, max_len=max_len, shuffle=shuffle, segmap=segmap):
             lens = r.integers(0, max_len + 1, B)
             nnz = int(lens.sum())
             rows = np.repeat(np.arange(B, dtype=np.int64), lens)
@@ -143,6 +157,14 @@ def random_model(rng, dense_only=False, extended=True):
                 rows[stray] = r.choice(np.asarray([-1, B, B + 5, -B - 1], np.int64), int(stray.sum()))
             if seg == "csr":
                 s = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+            elif seg == "indices" and segmap:
+                kind_, f = segmap
+                pos = np.arange(nnz, dtype=np.int64) - np.repeat(np.cumsum(lens) - lens, lens)     # position inside the bag
+                if kind_ == "div":     # idx0 = row * A + a, a non-decreasing inside the bag: idx0 // A = row
+                    a = np.minimum(pos * f // np.maximum(np.repeat(lens, lens), 1), f - 1)
+                    s = np.stack([rows * f + a, pos], axis=1).astype(np.int64).reshape(nnz, 2)
+                else:                  # (idx0, idx1) = divmod(row, T): idx0 * T + idx1 = row
+                    s = np.stack([rows // f, rows % f, pos], axis=1).astype(np.int64).reshape(nnz, 3)
             elif seg == "indices":
                 s = np.stack([rows, np.zeros_like(rows)], axis=1).astype(np.int64).reshape(nnz, 2)
             else:
@@ -151,7 +173,8 @@ def random_model(rng, dense_only=False, extended=True):
 
         gens.append((g, gen))
         comb = int(rng.choice([COMBINER_SUM, COMBINER_MEAN])) if form == FORM_SEGMENT_REDUCE else COMBINER_NONE
-        cols.append(ColumnSpec(form, dim, vocab, comb, src, t, i, si, kind, stride, ROWS_FROM_SYMBOL, g, bnd, g, slot, **xf))
+        cols.append(ColumnSpec(form, dim, vocab, comb, src, t, i, si, kind, stride, ROWS_FROM_SYMBOL, g, bnd, g, slot, **xf,
+                               **seg_kw))
     # every group needs a column
     for g in range(n_groups):
         if slots[g] == 0:
@@ -160,14 +183,14 @@ def random_model(rng, dense_only=False, extended=True):
             cols.append(ColumnSpec(FORM_PASSTHROUGH, vec, 0, COMBINER_NONE, IDS_I32, -1, i, -1, SEG_NONE, 1,
                                    ROWS_FROM_INPUT_DIM0, i, None, g, 0))
             slots[g] = 1
-    spec = PlanSpec(cols, ranks, esz, len(tables), n_groups=n_groups, n_symbols=n_groups)
+    spec = PlanSpec(cols, ranks, esz, len(tables), n_groups=n_groups, n_symbols=n_groups + len(extra_syms))
     spec.validate()
 
     def make(r, batches):
         inputs = []
         for g, gen in gens:
             inputs.extend(gen(r, batches[g]))
-        return inputs, np.asarray(batches, np.int32)
+        return inputs, np.asarray(list(batches) + extra_syms, np.int32)      # row counts, then the maps' factors
 
     return spec, tables, make
 

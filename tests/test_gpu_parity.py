@@ -1372,3 +1372,39 @@ def test_reference_ae_model_e_reduced(torch_cuda, oracle):
     req = m.make_request(0)
     out, packed, _ = run_gpu(torch_cuda, m.spec, req.inputs, tabs, req.symbols)
     assert_equal_oracle(oracle, m.spec, packed, tabs, req.symbols, out)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seg64", [True, False])
+def test_segment_ids_through_a_folded_sparse_reshape(torch_cuda, oracle, tmp_path, seg64):
+    """The general SparseReshape the reference folds into its generated index expression (EmitInputInline,
+    cuda_emitter.cc:1874-1916; fcp_column_ext_t::seg_map_*): the pre-pass evaluates seg = (sum idx_k * mul_k) / div on the
+    ORIGINAL index matrix.  Bit-exact against (a) the oracle on the same mapped plan, (b) the HIP path itself on the
+    plain plan whose segment ids were reshaped with NumPy beforehand; static and per-request factors; also through a
+    version-4 plan file, and row-sharded (the finalize pass re-reads the mapped ids for the mean's count)."""
+    from recom_amd.ops import FeatureColumnProcess
+    from recom_amd.plan_io import load_plan, save_plan
+    from segmap_cases import build
+    torch = torch_cuda
+    for seed in range(4):
+        spec_m, spec_p, ins_m, ins_p, tables, symbols = build(seed, batch=9 + 7 * seed, max_nnz=3000, seg64=seg64)
+        out_m, packed_m, _ = run_gpu(torch, spec_m, ins_m, tables, symbols)
+        assert_equal_oracle(oracle, spec_m, packed_m, tables, symbols, out_m)
+        out_p, _, _ = run_gpu(torch, spec_p, ins_p, tables, symbols)
+        for a, b in zip(out_m.groups, out_p.groups):
+            assert torch.equal(a, b)
+    # the plan file carries the maps
+    path = str(tmp_path / "mapped.fcp")
+    save_plan(spec_m, path)
+    assert open(path).read().startswith("fcp_plan 4\n") and load_plan(path).to_dict() == spec_m.to_dict()
+    op = FeatureColumnProcess.from_plan_file(path, 0)
+    out_f, _, _ = run_gpu(torch, spec_m, ins_m, tables, symbols, op=op)
+    for a, b in zip(out_f.groups, out_m.groups):
+        assert torch.equal(a, b)
+    # row-sharded partials equal the sharded oracle
+    world = 3
+    for rank in range(world):
+        spec = spec_m.with_shard(rank, world)
+        shard_tabs = [np.ascontiguousarray(t[rank::world]) for t in tables]
+        out, packed, _ = run_gpu(torch, spec, ins_m, shard_tabs, symbols)
+        assert_equal_oracle(oracle, spec, packed, shard_tabs, symbols, out)

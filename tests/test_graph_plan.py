@@ -263,28 +263,46 @@ def test_random_graphs(oracle, tmp_path, seed, host_concat):
 
 
 @pytest.mark.parametrize("B,seed", [(23, 0), (1, 1), (70, 2)])
-def test_sparse_reshape_inlined_when_it_is_the_identity(oracle, tmp_path, B, seed):
-    """a12, SparseReshape (cuda_emitter.cc:1874-1916): a reshape that provably keeps [rows, k] is read
-    through (the kernel takes row ids from the ORIGINAL indices, stride 2); one that is not stays in
-    TensorFlow and its output tensor is what ConcatInputs ships.  Either way the rewritten graph equals
-    the original bit for bit."""
+def test_sparse_reshape_is_folded_into_the_segment_ids(oracle, tmp_path, B, seed):
+    """a12, SparseReshape (cuda_emitter.cc:1874-1916): the row coordinate of the reshaped element is an expression of the
+    ORIGINAL coordinates — (sum idx_k * mul_k) // div — whenever the shapes' entries can be traced to constants or copies
+    of tensor elements: the column then reads the original indices (stride = their rank) and the op leaves the data
+    path; a reshape with an unprovable shape stays in TensorFlow and its output tensor is what ConcatInputs ships.
+    Either way the rewritten graph equals the original bit for bit."""
     from tf_graph_eval import GraphEvaluator
     gd, feeds, variables, fetches = sparse_reshape_model(B=B, seed=seed)
     expected = GraphEvaluator(gd, variables).run(fetches, feeds)
-    assert expected[0].shape == (B, 20) and expected[1].shape == (2 * B, 12)
+    assert [e.shape for e in expected] == [(B, 20), (2 * B, 12), (3 * B, 16), (4 * B, 24), (2 * B, 8)]
     built = build_plan(gd)
     c = built.spec.columns
-    assert [x.form for x in c] == [2, 1, 2, 1] and not built.skipped
-    assert built.host_inputs[c[0].seg_input] == ("p/indices", P.DT_INT64, 2) and c[0].seg_stride == 2      # inlined
-    assert built.host_inputs[c[2].seg_input] == ("q/SparseReshape", P.DT_INT64, 2) and c[2].seg_stride == 2  # computed by TF
-    assert [s.tensor for s in built.symbols] == ["p/num_segments", "q/num_segments"]
+    assert [x.form for x in c] == [2, 1] * 5 and not built.skipped
+    sym = [s.tensor for s in built.symbols]
+    # p: [B, L] -> [B, L], the identity: plain segment ids from the original indices
+    assert built.host_inputs[c[0].seg_input] == ("p/indices", P.DT_INT64, 2) and c[0].seg_stride == 2 and not c[0].seg_mul
+    # q: [B, 2L] -> [2B, L=6]: row = (idx0 * W + idx1) // 6, W = dense_shape[1] per request
+    assert built.host_inputs[c[2].seg_input] == ("q/indices", P.DT_INT64, 2) and c[2].seg_stride == 2
+    assert (tuple(c[2].seg_mul), c[2].seg_div, c[2].seg_sym_slot) == ((1, 1), 6, 0)
+    assert (built.symbols[c[2].seg_sym].tensor, built.symbols[c[2].seg_sym].index) == ("q/dense_shape", 1)
+    # r: [B, T, L] -> [B*T, L]: L cancels, row = idx0 * T + idx1, T = dense_shape[1] per request
+    assert built.host_inputs[c[4].seg_input] == ("r/indices", P.DT_INT64, 2) and c[4].seg_stride == 3
+    assert (tuple(c[4].seg_mul), c[4].seg_div, c[4].seg_sym_slot) == ((1, 1), 1, 0)
+    assert (built.symbols[c[4].seg_sym].tensor, built.symbols[c[4].seg_sym].index) == ("r/dense_shape", 1)
+    # s: constants [2B, 4, 6] -> [4B, 12]: row = (idx0 * 4 + idx1) // 2
+    assert built.host_inputs[c[6].seg_input] == ("s/indices", P.DT_INT64, 2) and c[6].seg_stride == 3
+    assert (tuple(c[6].seg_mul), c[6].seg_div, c[6].seg_sym) == ((4, 1), 2, -1)
+    # u: new_shape is fed: computed by TensorFlow
+    assert built.host_inputs[c[8].seg_input] == ("u/SparseReshape", P.DT_INT64, 2) and c[8].seg_stride == 2 and not c[8].seg_mul
+    assert sym == ["p/num_segments", "q/dense_shape", "q/num_segments", "r/dense_shape", "r/num_segments", "s/num_segments",
+                   "u/num_segments"]
     path = str(tmp_path / "m.fcp")
     save_plan(built.spec, path)
+    assert open(path).read().startswith("fcp_plan 4\n")
     out = parse_graphdef(rewrite_graph(gd, built, path).SerializeToString())
     names = {n.name for n in out.node}
-    assert "q/SparseReshape" in names                       # still needed: its indices are shipped
-    assert "p/SparseReshape" in names                       # kept for num_segments (output 1) only ...
-    assert "p/added_strided_slice" not in names             # ... its indices output is no longer read
+    assert "u/SparseReshape" in names and "u/added_strided_slice" not in names     # its indices are shipped whole
+    for k in "pqrs":
+        assert f"{k}/SparseReshape" in names                # kept for num_segments (output 1) only ...
+        assert f"{k}/added_strided_slice" not in names      # ... the indices output is no longer read
     got = GraphEvaluator(out, variables, oracle_ops(oracle, built, variables)).run(fetches, feeds)
     for e, o in zip(expected, got):
         assert np.array_equal(e, o)

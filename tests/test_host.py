@@ -632,3 +632,48 @@ def test_bench_starts_its_own_ranks(tmp_path):
     # N = 1 never launches anything
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, env=env, timeout=120)
     assert res.returncode == 0 and "--gpus" in res.stdout
+
+
+def test_segment_id_maps_in_the_descriptor_and_the_plan_file(tmp_path):
+    """fcp_column_ext_t (segment ids through a folded SparseReshape, cuda_emitter.cc:1874-1916): accepted by
+    fcp_plan_create_ex, carried by version-4 plan files (both parsers agree), refused when malformed — no GPU needed."""
+    import dataclasses
+    from recom_amd.lib import FcpError
+    from recom_amd.ops import Plan
+    from recom_amd.plan_io import load_plan, save_plan
+    from segmap_cases import build
+    spec, plain, *_ = build(1)
+    p = Plan(spec, host_only=True)
+    assert p.counts()["columns"] == spec.n_columns
+    path = str(tmp_path / "m.fcp")
+    save_plan(spec, path)
+    text = open(path).read()
+    assert text.startswith("fcp_plan 4\n") and f"segmaps {spec.n_columns}\n" in text
+    assert load_plan(path).to_dict() == spec.to_dict()
+    Plan.from_file(path, host_only=True)                       # the library's own parser
+    save_plan(plain, path)                                     # plans without maps keep their version
+    assert open(path).read().startswith("fcp_plan 2\n")
+    # a staged plan leaves mapped columns alone (the pre-pass evaluates the map on the device) ...
+    staged, stage = spec.staged_for_concat_inputs()
+    assert all(len(c.seg_mul) and c.seg_kind in (1, 2) for c in staged.columns)
+    save_plan(staged, path, stage)
+    assert open(path).read().startswith("fcp_plan 4\n") and "\nstage " in open(path).read()
+    Plan.from_file(path, host_only=True)
+    assert load_plan(path).to_dict() == staged.to_dict()
+    # ... and refusals
+    c0 = spec.columns[0]
+    for bad in (dict(seg_div=0), dict(seg_mul=(1, 1, 1, 1, 1)), dict(seg_stride=1), dict(seg_sym=99), dict(seg_sym=0, seg_sym_slot=3),
+                dict(seg_kind=3), dict(seg_mul=(-1, 1))):
+        cols = [dataclasses.replace(c0, **bad)] + list(spec.columns[1:])
+        broken = dataclasses.replace(spec, columns=cols)
+        with pytest.raises((ValueError, FcpError)):
+            Plan(broken, host_only=True)
+        broken.validate = lambda: None                         # past the Python check: the library refuses too
+        for c in cols:
+            c.validate = lambda: None
+        with pytest.raises(FcpError):
+            Plan(broken, host_only=True)
+    with open(path, "w") as f:                                 # a map that names a column twice
+        f.write(text.replace(f"segmaps {spec.n_columns}\n", f"segmaps {spec.n_columns}\n0 1 -1 0 1 0 0 0 1\n", 1))
+    with pytest.raises(FcpError):
+        Plan.from_file(path, host_only=True)
