@@ -482,12 +482,16 @@ def test_graphdef_to_hip_path_through_the_staged_concat_inputs(torch_cuda, tmp_p
 
 
 def test_sparse_reshape_graph_to_hip_path(torch_cuda, tmp_path):
-    """a12 on the GPU: segment ids read through an identity SparseReshape (inlined) and from the output of
-    one that is not (shipped), two concat groups with different row counts."""
+    """a12 on the GPU (cuda_emitter.cc:1874-1916): GraphDef -> plan -> HIP with segment ids read through SparseReshapes
+    that are the identity (plain ids from the original indices), folded into a segment-id map (run-time factor, rank-3
+    safe_embedding_lookup_sparse, constant shapes) or unprovable (computed by TensorFlow, shipped); five concat groups
+    with different row counts; the rewritten graph equals the original bit for bit."""
     from graph_fixtures import sparse_reshape_model
-    gd, feeds, variables, fetches = sparse_reshape_model(B=45, seed=4)
-    built = _graph_through_hip(torch_cuda, gd, feeds, variables, fetches, tmp_path)
-    assert built.spec.n_groups == 2 and [c.form for c in built.spec.columns] == [2, 1, 2, 1]
+    for B, seed in ((45, 4), (1, 0), (260, 7)):
+        gd, feeds, variables, fetches = sparse_reshape_model(B=B, seed=seed)
+        built = _graph_through_hip(torch_cuda, gd, feeds, variables, fetches, tmp_path)
+        assert built.spec.n_groups == 5 and [c.form for c in built.spec.columns] == [2, 1] * 5
+        assert [len(c.seg_mul) for c in built.spec.columns[::2]] == [0, 2, 2, 2, 0]
 
 
 def test_id_filter_graph_to_hip_path(torch_cuda, tmp_path):
