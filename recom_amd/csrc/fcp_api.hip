@@ -156,6 +156,7 @@ struct fcp_plan {
   FcpXform *d_xforms = nullptr; // per column, only for plans with id transforms
   FcpSegMap *d_segmaps = nullptr; // per column, only for plans with segment-id maps
   bool has_seg_map = false;
+  bool wide_rows = false; // some table shard has >= 2^32 - 3 slots: FcpLaunch::store_through bit 1
   std::vector<FcpColStatic> h_cols;
   char *d_const = nullptr;
   int32_t *d_seg_cols = nullptr;
@@ -1040,7 +1041,7 @@ void fill_launch(const fcp_plan *p, const DynSlot &s, int kind, const void *blob
     const char *e = std::getenv("FCP_STORE_THROUGH_BYTES"); // tuning aid
     return e ? std::atoll(e) : (int64_t)32 << 20;
   }();
-  L->store_through = s.meta.csr_arena_off >= through_bytes ? 1 : 0;
+  L->store_through = (s.meta.csr_arena_off >= through_bytes ? 1 : 0) | (p->wide_rows ? 2 : 0);
   for (int g = 0; g < p->desc.n_groups; ++g) L->groups[g] = s.meta.geo[kind].groups[g];
 }
 
@@ -1184,17 +1185,20 @@ int fcp_plan_create_ex(const fcp_plan_desc_t *desc, const fcp_column_ext_t *ext,
       p->seg_search = false;
     }
   }
-  // The kernels address table rows by a 32-bit slot offset (row * dim / vec): one
-  // table (or one shard of it) may hold up to 2^32 slots = 64 GB at vec 4.  (The
+  // The kernels park a table row as one 32-bit number (the three largest values are their sentinels): a table — or
+  // one shard of it — may hold up to 2^32 - 3 ROWS, of any width: the byte offset is formed in 64 bits where the row
+  // is read.  The dense body keeps round 2's pre-scaled 32-bit slot offsets (row * dim / vec) while every table of
+  // the plan stays below 2^32 - 3 slots (64 GB at vec 4), which saves it a 64-bit multiply per read.  (The
   // reference's int arithmetic stops at 2^31 elements = 8 GB, cuda_emitter.cc:270-271.)
   for (int k = 0; k < desc->n_columns; ++k) {
     const fcp_column_desc_t &c = p->cols[k].d;
     if (c.form == FCP_FORM_PASSTHROUGH || c.form == FCP_FORM_BATCH_COL_REDUCTION || c.form == FCP_FORM_EXTERNAL) continue;
     const int64_t local_vocab = (c.vocab - desc->shard_rank + desc->shard_world - 1) / desc->shard_world;
-    if (local_vocab * (c.dim / p->vec) >= 0xFFFFFFFDLL) { // (the three largest values are the kernels' sentinels)
+    if (local_vocab >= 0xFFFFFFFDLL) {
       delete p;
-      return fail(FCP_ERR_UNSUPPORTED, "column " + std::to_string(k) + ": table shard exceeds 2^32 slots");
+      return fail(FCP_ERR_UNSUPPORTED, "column " + std::to_string(k) + ": table shard exceeds 2^32 - 3 rows");
     }
+    if (local_vocab * (c.dim / p->vec) >= 0xFFFFFFFDLL || std::getenv("FCP_WIDE_ROWS") != nullptr) p->wide_rows = true; // (env: test aid)
   }
   // concat layout: offsets = prefix sums of dims in slot order
   // (concat_outputs_op_gpu.cu.cc:74-79)

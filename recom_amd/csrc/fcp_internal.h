@@ -107,7 +107,9 @@ struct FcpLaunch {
   int32_t rows_per_wave;
   int32_t shard_rank, shard_world;
   int32_t seg_search;          // 1: blocks find their rows' ranges in the sorted segment ids themselves (no pre-pass)
-  int32_t store_through;       // 1: output stores are write-through (`sc1 nt`): outputs larger than the L2s (host decides)
+  int32_t store_through;       // bit 0: output stores are write-through (`sc1 nt`): outputs larger than the L2s (host decides);
+                               // bit 1: some table (shard) of the plan has >= 2^32 - 3 slots: the dense body parks rows and
+                               // multiplies in 64 bits instead of parking pre-scaled 32-bit slot offsets
   unsigned long long *stamps;  // diagnostic builds (-DFCP_STAMPS) only: 8 timestamps per block
   FcpGroupLaunch groups[FCP_MAX_GROUPS];
   const FcpXform *xforms;      // per column (concat order), or null: no column has an id transform

@@ -108,9 +108,30 @@ template <int V> __device__ __forceinline__ void st_out(float *p, const VF<V> &v
 #endif
 }
 
-// Slot `off` (units of V floats) of a table whose lane-specific base is `tb`:
-// one v_lshl_add_u64 + one global_load.
-template <int V> __device__ __forceinline__ VF<V> ld_slot(const float *tb, uint32_t off) {
+// Row `off` of a table of `spr` slots (of V floats) per row whose lane-specific base is `tb`: one v_mad_u64_u32
+// (row x slots per row, 64-bit: a table may be of any size, rows < 2^32 - 3) + one global_load.
+template <int V> __device__ __forceinline__ VF<V> ld_slot32(const float *tb, uint32_t off);
+template <int V> __device__ __forceinline__ VF<V> ld_slot(const float *tb, uint32_t off, uint32_t spr) {
+  typedef typename VecType<V>::T T;
+#if defined(FCP_ABLATE) && FCP_ABLATE == 4 // timing-only build 4: no table reads at all (ragged kernel too)
+  VF<V> z = vzero<V>();
+  z.v[0] = (float)off;
+  return z;
+#endif
+  const FCP_GLOBAL T *g = as_global(reinterpret_cast<const T *>(tb)) + (uint64_t)off * spr;
+#if defined(FCP_NT_LOADS) // tuning build: stream table rows too (see the comment above st_out)
+  T t = __builtin_nontemporal_load(g);
+#else
+  T t = *g;
+#endif
+  VF<V> r;
+  __builtin_memcpy(&r, &t, sizeof(T));
+  return r;
+}
+// The same for a PRE-SCALED slot offset (row x slots per row < 2^32 - 3, known for the whole plan: FcpLaunch::store_through
+// bit 1 clear): one v_lshl_add_u64 + one global_load — what the dense kernel uses whenever every table allows it
+// (S2: 0.15-0.25 us per request against the 64-bit multiply-add, profiles/r03_row_index_ab.txt).
+template <int V> __device__ __forceinline__ VF<V> ld_slot32(const float *tb, uint32_t off) {
   typedef typename VecType<V>::T T;
 #if defined(FCP_ABLATE) && FCP_ABLATE == 4 // timing-only build 4: no table reads at all (ragged kernel too)
   VF<V> z = vzero<V>();
@@ -395,9 +416,9 @@ __device__ __attribute__((noinline)) int64_t apply_xform(uint32_t xform, const F
 
 // The index expression the reference inlines per column (EmitInputInline,
 // cuda_emitter.cc:1769-1949: raw int32 / int64 ids, or Bucketize(float value)),
-// the range check and the row shard, folded into ONE number per id: the offset of
-// the table row in units of V floats (row * dim / V; < 2^32 is checked when the
-// plan is created), or kNoRow.  Ids outside [0, vocab) read as zeros (the
+// the range check and the row shard, folded into ONE number per id: the (local) row
+// of the table (< 2^32 - 3 rows per table or shard is checked when the plan is created;
+// the byte offset is formed in 64 bits where the row is read), or kNoRow.  Ids outside [0, vocab) read as zeros (the
 // reference reads out of bounds, TF-GPU GatherV2 returns zeros); under row
 // sharding an id owned by another rank contributes nothing here.
 template <int V, bool SHARDED>
@@ -430,7 +451,7 @@ __device__ __forceinline__ uint32_t slot_offset_from_raw(const LdsCol &c, const 
     if (id - q * world != rank) return kNoRow;
     id = q;
   }
-  return (uint32_t)id * (uint32_t)(c.dim / V);
+  return (uint32_t)id;
 }
 
 template <int V, bool SHARDED>
@@ -541,6 +562,7 @@ __device__ __forceinline__ void dense_body(const FcpLaunch &L, int bid, char *sm
   const int q = B.q0 + lane;
   const uint32_t my_col = B.map[min(q, B.nslots - 1)];
   const int world = H.world, rank = H.rank;
+  const bool wide = (H.store_through & 2) != 0; // some table has 2^32 - 3 slots or more: rows are parked, not slot offsets
 
   // ---- phase 0 ----------------------------------------------------------------------
   if (tid < B.ncols) stage_col(H, &s_col[tid], H.cols + B.first_col + tid, H.dyn + B.first_col + tid);
@@ -637,12 +659,13 @@ __device__ __forceinline__ void dense_body(const FcpLaunch &L, int bid, char *sm
       if (form == FCP_FORM_PASSTHROUGH) {
         // a tensor of the blob copied into its concat slot; table-free columns
         // belong to shard rank 0
-        if (rank == 0) off = (uint32_t)b * (uint32_t)(c.dim / V);
+        if (rank == 0) off = wide ? (uint32_t)b : (uint32_t)b * (uint32_t)(c.dim / V);
       } else if (form == FCP_FORM_GATHER) {
         bool bad;
         off = slot_offset_from_raw<V, SHARDED>(c, L.xforms + B.first_col + j, raw_lo[h], raw_hi[h],
                                                c.bnd_off >= 0 ? s_bnd + c.bnd_off : nullptr,
                                                rank, world, bad);
+        if (!wide && is_row(off)) off *= (uint32_t)(c.dim / V); // every table of the plan has < 2^32 - 3 slots: pre-scaled
         // a column that straddles two spans is staged by two blocks: the one holding its first slot counts
         if (bad && H.bad_ids && c.out_off >= B.q0 * V) atomicAdd(H.bad_ids, 1ull);
       } // FCP_FORM_EXTERNAL: nothing to fetch, nothing to write
@@ -663,20 +686,21 @@ __device__ __forceinline__ void dense_body(const FcpLaunch &L, int bid, char *sm
   if (FCP_F_FORM(s_col[j].flags) == FCP_FORM_EXTERNAL) return; // somebody else's slot (ConcatOutputs host input)
   float *outp = reinterpret_cast<float *>(H.arena + s_col[j].out_base) + e;
   const int r0 = wave * R;
+  const uint32_t spr = (uint32_t)(s_col[j].dim / V); // slots per table row
   uint32_t off[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) off[r] = s_off[j * IDS + r0 + r];
 #if defined(FCP_ABLATE) && FCP_ABLATE == 3 // timing-only build: sequential instead of random rows
 #pragma unroll
   for (int r = 0; r < R; ++r)
-    off[r] = (uint32_t)((((int64_t)(B.row_blk + r0 + r) * 131 + my_col * 977) % s_col[j].vocab) * (s_col[j].dim / V));
+    off[r] = (uint32_t)(((int64_t)(B.row_blk + r0 + r) * 131 + my_col * 977) % s_col[j].vocab);
 #endif
   VF<V> v[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     v[r] = vzero<V>();
 #if !(defined(FCP_ABLATE) && FCP_ABLATE == 1) // timing-only build 1: no table reads
-    if (is_row(off[r])) v[r] = ld_slot<V>(tb, off[r]);
+    if (is_row(off[r])) v[r] = wide ? ld_slot<V>(tb, off[r], spr) : ld_slot32<V>(tb, off[r]);
 #else
     v[r].v[0] = (float)off[r];
 #endif
@@ -688,7 +712,7 @@ __device__ __forceinline__ void dense_body(const FcpLaunch &L, int bid, char *sm
     asm volatile("" ::"v"(v[r].v[0]), "v"(v[r].v[V - 1]));
     if (b < B.rows && v[r].v[0] == 1234.5f) st_out<V>(outp + (int64_t)b * ostride, v[r]);
 #else
-    if (b < B.rows) st_out<V>(outp + (int64_t)b * ostride, v[r], H.store_through != 0);
+    if (b < B.rows) st_out<V>(outp + (int64_t)b * ostride, v[r], (H.store_through & 1) != 0);
 #endif
   }
 #if defined(FCP_STAMPS)
@@ -817,9 +841,9 @@ __device__ __forceinline__ void wave_lds_order() {
 // range, another rank's row, dropped by the filter, past the end of the bag) — the plan's zero line: one hot
 // cache line instead of a predicated read, so the walk is branch-free (no exec-mask bookkeeping around every
 // read); adding its +0.0 is exact (acc is never -0.0: it starts at +0.0).
-template <int V> __device__ __forceinline__ VF<V> ld_slot_or_zero(const float *tb, const float *zeros, uint32_t off) {
+template <int V> __device__ __forceinline__ VF<V> ld_slot_or_zero(const float *tb, const float *zeros, uint32_t off, uint32_t spr) {
   typedef typename VecType<V>::T T;
-  const FCP_GLOBAL T *g = is_row(off) ? as_global(reinterpret_cast<const T *>(tb)) + off : as_global(reinterpret_cast<const T *>(zeros));
+  const FCP_GLOBAL T *g = is_row(off) ? as_global(reinterpret_cast<const T *>(tb)) + (uint64_t)off * spr : as_global(reinterpret_cast<const T *>(zeros));
 #if defined(FCP_ABLATE) && FCP_ABLATE == 4 // timing-only build 4: no table reads at all
   g = as_global(reinterpret_cast<const T *>(zeros));
 #endif
@@ -835,13 +859,13 @@ template <int V> __device__ __forceinline__ VF<V> ld_slot_or_zero(const float *t
 // only while some bag of the wave goes on.  (Round 2 walked "8, then 4" behind per-lane conditions: lanes with
 // up to 4 ids sat out the first pass and issued their reads only after it.)
 template <int V, int N>
-__device__ __forceinline__ void bag_walk_batch(const float *tb, const float *zeros, const uint32_t *s, int base, int n, VF<V> &acc) {
+__device__ __forceinline__ void bag_walk_batch(const float *tb, const float *zeros, uint32_t spr, const uint32_t *s, int base, int n, VF<V> &acc) {
   uint32_t off[N];
   VF<V> w[N];
 #pragma unroll
   for (int k = 0; k < N; ++k) off[k] = base + k < n ? s[base + k] : kNoRow;
 #pragma unroll
-  for (int k = 0; k < N; ++k) w[k] = ld_slot_or_zero<V>(tb, zeros, off[k]);
+  for (int k = 0; k < N; ++k) w[k] = ld_slot_or_zero<V>(tb, zeros, off[k], spr);
 #pragma unroll
   for (int k = 0; k < N; ++k)
 #pragma unroll
@@ -849,14 +873,14 @@ __device__ __forceinline__ void bag_walk_batch(const float *tb, const float *zer
 }
 
 template <int V, int WALK>
-__device__ __forceinline__ void bag_walk_sum(const float *tb, const float *zeros, const uint32_t *s, int n, VF<V> &acc) {
-  bag_walk_batch<V, WALK>(tb, zeros, s, 0, n, acc);
+__device__ __forceinline__ void bag_walk_sum(const float *tb, const float *zeros, uint32_t spr, const uint32_t *s, int n, VF<V> &acc) {
+  bag_walk_batch<V, WALK>(tb, zeros, spr, s, 0, n, acc);
   for (int base = WALK; __any(n > base);) { // wave-uniform trip count
     if (WALK > 4 && !__any(n > base + 4)) { // a short tail (bags of 9..12 ids): half a batch
-      bag_walk_batch<V, 4>(tb, zeros, s, base, n, acc);
+      bag_walk_batch<V, 4>(tb, zeros, spr, s, base, n, acc);
       base += 4;
     } else {
-      bag_walk_batch<V, WALK>(tb, zeros, s, base, n, acc);
+      bag_walk_batch<V, WALK>(tb, zeros, spr, s, base, n, acc);
       base += WALK;
     }
   }
@@ -1019,6 +1043,7 @@ __device__ __forceinline__ void ragged_body(const FcpLaunch &L, int bid, char *s
     constexpr int WALK = decltype(walk_width)::value;
     const unsigned form = FCP_F_FORM(s_col[j].flags);
     const float *tb = s_col[j].table + (q * V - s_col[j].out_off);
+    const uint32_t spr = (uint32_t)(s_col[j].dim / V); // slots per table row
     if (form == FCP_FORM_SEGMENT_REDUCE) {
       if ((s_col[j].xform & 3u) == FCP_XFORM_FILTER && FCP_F_COMBINER(s_col[j].flags) == FCP_COMBINER_MEAN) {
         // ids the filter dropped do not count in the mean: a separate pass over the staged offsets, only for
@@ -1026,7 +1051,7 @@ __device__ __forceinline__ void ragged_body(const FcpLaunch &L, int bid, char *s
 #pragma unroll 1
         for (int k = 0; k < n; ++k) dropped += s[k] == kFiltered;
       }
-      bag_walk_sum<V, WALK>(tb, H.zeros, s, n, acc);
+      bag_walk_sum<V, WALK>(tb, H.zeros, spr, s, n, acc);
     } else if (form == FCP_FORM_GATHER || form == FCP_FORM_GATHER_SCATTER) {
       // a pure copy of one row (rows without ids stay zero); of several ids the last one the filter kept wins
       // (TF: ScatterNd after the filter op; the oracle compacts first)
@@ -1035,7 +1060,7 @@ __device__ __forceinline__ void ragged_body(const FcpLaunch &L, int bid, char *s
       const uint32_t off = s[k];
       if (off != kFiltered) {
         acc = vzero<V>();
-        if (is_row(off)) acc = ld_slot<V>(tb, off);
+        if (is_row(off)) acc = ld_slot<V>(tb, off, spr);
         // the winner of a ScatterNd row is out of the vocabulary: counted once, by the lane of the column's first slot
         if (form == FCP_FORM_GATHER_SCATTER && off == kBadRow && H.bad_ids && q * V == s_col[j].out_off) atomicAdd(H.bad_ids, 1ull);
       }
@@ -1105,7 +1130,7 @@ __device__ __forceinline__ void ragged_body(const FcpLaunch &L, int bid, char *s
 #pragma unroll
     for (int t = 0; t < V; ++t) acc.v[t] = acc.v[t] / fc;
   }
-  st_out<V>(reinterpret_cast<float *>(H.arena + C.out_base) + e + (int64_t)b * C.out_stride, acc, H.store_through != 0);
+  st_out<V>(reinterpret_cast<float *>(H.arena + C.out_base) + e + (int64_t)b * C.out_stride, acc, (H.store_through & 1) != 0);
 #if defined(FCP_STAMPS)
   if (L.stamps && tid == 0) { // wave 0 = first row of the block
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

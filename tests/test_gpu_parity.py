@@ -1412,3 +1412,73 @@ def test_segment_ids_through_a_folded_sparse_reshape(torch_cuda, oracle, tmp_pat
         shard_tabs = [np.ascontiguousarray(t[rank::world]) for t in tables]
         out, packed, _ = run_gpu(torch, spec, ins_m, shard_tabs, symbols)
         assert_equal_oracle(oracle, spec, packed, shard_tabs, symbols, out)
+
+
+@pytest.mark.gpu
+def test_a_table_beyond_64_gb(torch_cuda, oracle):
+    """one table of 80 GB (1.25 G rows x 16 floats = 5 G slots of 16 bytes > 2^32).  The kernels park a
+    ROW per id and form the byte offset in 64 bits (round 2 parked 32-bit slot offsets: such a plan was refused).  A one-hot
+    column, a pooled one and a ScatterNd one over the same table — once as an all-one-hot plan (dense kernel, wide path) and
+    once mixed (hybrid launch) — against the oracle run on a COMPACT table that holds only the touched rows (closed-form
+    contents, synth.hash_rows): ids around slot 2^32, the last row, the first, random ones."""
+    import dataclasses
+    from recom_amd import synth
+    from recom_amd.plan import (COMBINER_MEAN, COMBINER_NONE, FORM_GATHER, FORM_GATHER_SCATTER, FORM_SEGMENT_REDUCE, IDS_I64,
+                                ROWS_FROM_IDS, ROWS_FROM_SYMBOL, SEG_CSR_I32, SEG_IDS_I64, SEG_NONE, ColumnSpec, PlanSpec)
+    torch = torch_cuda
+    vocab, dim, B = 1_250_000_000, 16, 96
+    free, _ = torch.cuda.mem_get_info()
+    if free < vocab * dim * 4 + (8 << 30):
+        pytest.skip(f"needs {vocab * dim * 4 / 2**30:.0f} GiB of HBM, {free / 2**30:.0f} GiB free")
+    dev = torch.device("cuda", 0)
+    table = synth.hash_table_torch(5, vocab, dim, dev)
+    rng = np.random.default_rng(3)
+    edge = np.asarray([0, 1, (1 << 30) - 1, 1 << 30, (1 << 30) + 1, (1 << 28), vocab - 1, vocab - 2, vocab, -1], np.int64)
+    def draw(n):
+        ids = rng.integers(0, vocab, n).astype(np.int64)
+        k = min(n, edge.size)
+        ids[rng.choice(n, k, replace=False)] = edge[:k]
+        return ids
+    lens = rng.integers(0, 9, B)
+    nnz = int(lens.sum())
+    rows = np.repeat(np.arange(B, dtype=np.int64), lens)
+    inputs = [draw(B), draw(nnz), np.concatenate([[0], np.cumsum(lens)]).astype(np.int32),
+              draw(B // 2), np.stack([rng.permutation(B)[:B // 2], np.zeros(B // 2, np.int64)], 1).astype(np.int64)]
+    cols = [ColumnSpec(FORM_GATHER, dim, vocab, COMBINER_NONE, IDS_I64, 0, 0, -1, SEG_NONE, 1, ROWS_FROM_IDS, 0, None, 0, 0),
+            ColumnSpec(FORM_SEGMENT_REDUCE, dim, vocab, COMBINER_MEAN, IDS_I64, 0, 1, 2, SEG_CSR_I32, 1, ROWS_FROM_SYMBOL, 0, None, 0, 1),
+            ColumnSpec(FORM_GATHER_SCATTER, dim, vocab, COMBINER_NONE, IDS_I64, 0, 3, 4, SEG_IDS_I64, 2, ROWS_FROM_SYMBOL, 0, None, 0, 2)]
+    spec = PlanSpec(cols, [1, 1, 1, 1, 2], [8, 8, 4, 8, 8], n_device_inputs=1, n_groups=1, n_symbols=1)
+    symbols = np.asarray([B], np.int32)
+    # the compact twin: touched rows only, ids renumbered (ids outside the vocabulary stay outside)
+    touched = np.unique(np.concatenate([inputs[0], inputs[1], inputs[3]]))
+    touched = touched[(touched >= 0) & (touched < vocab)]
+    compact = synth.hash_rows(5, touched, dim)
+    remap = lambda ids: np.where((ids >= 0) & (ids < vocab), np.searchsorted(touched, np.clip(ids, 0, vocab - 1)), -1).astype(np.int64)
+    c_inputs = [remap(inputs[0]), remap(inputs[1]), inputs[2], remap(inputs[3]), inputs[4]]
+    c_spec = dataclasses.replace(spec, columns=[dataclasses.replace(c, vocab=int(touched.size)) for c in cols])
+    blob, offsets, shapes = oracle.concat_inputs(c_inputs)
+    want, _ = oracle.process_feature_columns(c_spec.to_dict(), blob, offsets, shapes, [compact], symbols)
+    out, _, _ = run_gpu(torch, spec, inputs, None, symbols, tables_dev=[table])                    # hybrid launch
+    assert np.array_equal(out.groups[0].cpu().numpy(), want[0])
+    one_hot = PlanSpec([cols[0]], [1], [8], n_device_inputs=1, n_groups=1, n_symbols=0)           # dense kernel alone
+    out1, _, _ = run_gpu(torch, one_hot, inputs[:1], None, None, tables_dev=[table])
+    assert np.array_equal(out1.groups[0].cpu().numpy(), want[0][:, :dim])
+    del table, out, out1
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.gpu
+def test_wide_row_path_of_the_dense_kernel_on_ordinary_plans(torch_cuda, oracle, golden, monkeypatch):
+    """The dense body's 64-bit row path (taken when some table has 2^32 - 3 slots or more) forced onto ordinary plans
+    (FCP_WIDE_ROWS, read at plan creation): golden cases and the mixed model stay bit-exact."""
+    from recom_amd import synth
+    monkeypatch.setenv("FCP_WIDE_ROWS", "1")
+    for name in ("mixed_s0", "bucketize_kat", "scatter"):
+        case = golden[0][name]
+        out, _, _ = run_gpu(torch_cuda, case.spec(), case.inputs, case.tables, case.symbols)
+        check_against_expected(case, [g.cpu().numpy() for g in out.groups])
+    m = synth.model_s1() if hasattr(synth, "model_s1") else synth.model_mixed(batch=64)
+    tabs = m.numpy_tables()
+    req = m.make_request(2)
+    out, packed, _ = run_gpu(torch_cuda, m.spec, req.inputs, tabs, req.symbols)
+    assert_equal_oracle(oracle, m.spec, packed, tabs, req.symbols, out)

@@ -677,3 +677,24 @@ def test_segment_id_maps_in_the_descriptor_and_the_plan_file(tmp_path):
         f.write(text.replace(f"segmaps {spec.n_columns}\n", f"segmaps {spec.n_columns}\n0 1 -1 0 1 0 0 0 1\n", 1))
     with pytest.raises(FcpError):
         Plan.from_file(path, host_only=True)
+
+
+def test_table_size_limits_are_rows_not_bytes():
+    """A table (or the shard of one) may hold up to 2^32 - 3 ROWS of any width — the kernels park a row per id and form
+    the byte offset in 64 bits; round 2 stopped at 2^32 16-byte slots = 64 GB.  Host-only plans: no GPU needed."""
+    from recom_amd import lib
+    from recom_amd.lib import FcpError
+    from recom_amd.ops import Plan
+    from recom_amd.plan import COMBINER_NONE, FORM_GATHER, IDS_I64, ROWS_FROM_IDS, SEG_NONE, ColumnSpec, PlanSpec
+    def plan(vocab, dim, world=1):
+        c = ColumnSpec(FORM_GATHER, dim, vocab, COMBINER_NONE, IDS_I64, 0, 0, -1, SEG_NONE, 1, ROWS_FROM_IDS, 0, None, 0, 0)
+        return Plan(PlanSpec([c], [1], [8], n_device_inputs=1, shard_world=world), host_only=True)
+    import ctypes as C
+    p = plan(4_000_000_000, 64)                     # 1 TB: 64 G slots
+    total, largest = C.c_int64(), C.c_int64()
+    lib.check(lib.load().fcp_plan_table_bytes(p.handle, C.byref(total), C.byref(largest)), "fcp_plan_table_bytes")
+    assert total.value == largest.value == 4_000_000_000 * 64 * 4
+    with pytest.raises(FcpError, match="rows"):
+        plan((1 << 32) - 3, 4)
+    plan((1 << 32) - 4, 4)
+    plan(1 << 33, 8, world=4)                       # row-sharded: the limit applies to the shard
