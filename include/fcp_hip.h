@@ -401,7 +401,10 @@ int fcp_plan_read_bad_ids(fcp_plan_t *plan, void *stream, int64_t *count);
  * the slot is then kept until fcp_plan_release_captures (call it once the graphs are
  * destroyed).  Capturing a request whose shapes are NOT resident returns
  * FCP_ERR_UNSUPPORTED (descriptors cannot be installed inside a capture), as does a
- * request with new shapes once all 8 slots belong to captured graphs. */
+ * request with new shapes once all 8 slots belong to captured graphs — a plan serves
+ * at most 8 captured shapes at a time — and a request whose tables are not bound to
+ * the plan yet, or have moved (binding copies records and may synchronise the device).
+ * fcp_shard_finalize follows the same rules. */
 int fcp_plan_release_captures(fcp_plan_t *plan);
 int fcp_process_feature_columns(fcp_plan_t *plan,
                                 const fcp_process_args_t *args,
@@ -437,7 +440,9 @@ int fcp_concat_outputs_scatter_strided(const void *const *inputs, const int32_t 
  * — reading the pinned buffer through its device mapping when the payload is at
  * most 1 MiB (no copy at all), otherwise after ONE asynchronous H2D copy into
  * scratch obtained from `malloc_temp` (the reference's allocate_temp, :189-193;
- * called only then).  With FCP_LAYOUT_CONCAT `out` is the group's
+ * called only then: it may be NULL for payloads of at most 1 MiB).  Calls from
+ * several threads overlap: the per-device ring lock covers slot bookkeeping only.
+ * With FCP_LAYOUT_CONCAT `out` is the group's
  * matrix inside the FeatureColumnProcess arena, whose FCP_FORM_EXTERNAL slots are
  * exactly these columns.  No stream synchronisation (the reference blocks, :234);
  * the host tensors may be reused when the call returns. */

@@ -861,10 +861,22 @@ int init_device(fcp_plan *p) {
 
 // Bind the table addresses (FeatureColumnProcess `inputs`).  TF variables keep
 // their address between requests, so this uploads once.
-int bind_tables(fcp_plan *p, const void *const *input_ptrs) {
+bool stream_is_capturing(hipStream_t stream) {
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (stream && hipStreamIsCapturing(stream, &st) == hipSuccess) return st == hipStreamCaptureStatusActive;
+  (void)hipGetLastError();
+  return false;
+}
+
+// `capturing`: the caller's stream is being captured into a HIP graph — binding (or re-binding) tables copies records
+// and may synchronise the device, neither of which a capture tolerates: refused, the plan stays as it was.
+int bind_tables(fcp_plan *p, const void *const *input_ptrs, bool capturing) {
   const int nt = p->desc.n_device_inputs;
   if (p->tables_bound && std::memcmp(p->bound_tables.data(), input_ptrs, nt * sizeof(void *)) == 0)
     return FCP_OK;
+  if (capturing)
+    return fail(FCP_ERR_UNSUPPORTED, "stream capture of a request whose tables are not bound to the plan yet (or have moved): run it "
+                                     "once on this stream before capturing");
   // validate first and build the new records aside: a failure leaves the plan exactly as it was
   std::vector<FcpColStatic> cols = p->h_cols;
   for (size_t k = 0; k < p->cols.size(); ++k) {
@@ -1688,16 +1700,11 @@ int fcp_process_feature_columns(fcp_plan_t *p, const fcp_process_args_t *a, fcp_
   bool install = false;
   thread_local std::vector<int32_t> key;
   build_key(p, a, key);
-  bool capturing = false;
-  {
-    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-    if (stream && hipStreamIsCapturing(stream, &st) == hipSuccess) capturing = st == hipStreamCaptureStatusActive;
-    else (void)hipGetLastError();
-  }
+  const bool capturing = stream_is_capturing(stream);
   {
     std::unique_lock<std::mutex> lock(p->mu);
     if (p->desc.n_device_inputs > 0) {
-      rc = bind_tables(p, a->input_ptrs);
+      rc = bind_tables(p, a->input_ptrs, capturing);
       if (rc) return rc;
     }
     while ((rc = find_or_reserve(p, key, &slot, &install, capturing)) == kAllSlotsBusy) {
@@ -1830,9 +1837,10 @@ struct HostStageSlot {
   char *buf_dev = nullptr; // device mapping of buf
   size_t cap = 0;
   hipEvent_t copied = nullptr;
+  bool busy = false; // reserved by a call that is packing into it / enqueueing its reader (guarded by the ring mutex)
 };
 struct HostStageRing {
-  std::mutex mu;
+  std::mutex mu; // covers `next` and the slots' `busy` flags only: callers pack and launch outside it
   HostStageSlot slots[4];
   size_t next = 0;
 };
@@ -1870,7 +1878,6 @@ int fcp_concat_outputs_host(const void *const *host_inputs, const int32_t *dims,
                             void *malloc_temp_ctx, int32_t device, void *stream_) {
   int rc = check_scatter_args(host_inputs, dims, col_offsets, n, prefix_size, out_width, out);
   if (rc || n == 0 || prefix_size == 0) return rc;
-  if (!malloc_temp) return fail(FCP_ERR_INVALID_ARGUMENT, "malloc_temp callback is required");
   DeviceGuard guard;
   rc = guard.enter(device);
   if (rc) return rc;
@@ -1881,49 +1888,71 @@ int fcp_concat_outputs_host(const void *const *host_inputs, const int32_t *dims,
     at[k] = total;
     total += ((size_t)prefix_size * dims[k] * 4 + 15) / 16 * 16;
   }
+  // Small payloads (the reference's models E / F: 32 dense features, 64 KB per request): the scatter kernel reads the
+  // pinned slot through its device mapping — no copy, no device staging buffer, one runtime call less per request.
+  // Large ones keep the H2D copy (the scatter would hold its CUs for the length of the PCIe transfer).
+  static const size_t direct_max = [] { // tuning aid: FCP_CONCAT_HOST_DIRECT_MAX=<bytes> (0: always copy)
+    const char *e = std::getenv("FCP_CONCAT_HOST_DIRECT_MAX");
+    return e ? (size_t)std::atoll(e) : (size_t)1 << 20;
+  }();
+  const bool direct = total <= direct_max;
+  if (!direct && !malloc_temp) return fail(FCP_ERR_INVALID_ARGUMENT, "malloc_temp callback is required for payloads that are copied to the device");
   HostStageRing *ring = host_stage_ring(device);
-  {
-    // pack (the reference: one memcpy per input into a std::vector, concat_outputs_op_gpu.cu.cc:195-201) and
-    // enqueue the one H2D copy under the ring lock; concurrent callers take different slots
-    std::unique_lock<std::mutex> lock(ring->mu);
-    HostStageSlot &sl = ring->slots[ring->next];
-    ring->next = (ring->next + 1) % 4;
-    if (sl.copied && hipEventQuery(sl.copied) != hipSuccess) HIP_TRY(hipEventSynchronize(sl.copied));
-    if (sl.cap < total) {
-      if (sl.buf) HIP_TRY(hipHostFree(sl.buf));
-      sl.buf = nullptr;
-      sl.buf_dev = nullptr;
-      sl.cap = 0;
-      const size_t cap = std::max<size_t>(total, 1 << 16);
-      HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&sl.buf), cap, hipHostMallocMapped));
-      HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&sl.buf_dev), sl.buf, 0));
-      sl.cap = cap;
+  // Reserve a slot under the ring lock, then pack (the reference: one memcpy per input into a std::vector,
+  // concat_outputs_op_gpu.cu.cc:195-201), wait for the slot's previous reader if it is still running, and enqueue
+  // OUTSIDE it: concurrent serve workers (models E / F) only meet on the bookkeeping.
+  HostStageSlot *slp = nullptr;
+  for (;;) {
+    {
+      std::lock_guard<std::mutex> lock(ring->mu);
+      for (int t = 0; t < 4 && !slp; ++t) {
+        HostStageSlot &c = ring->slots[(ring->next + t) % 4];
+        if (!c.busy) {
+          c.busy = true;
+          ring->next = (ring->next + t + 1) % 4;
+          slp = &c;
+        }
+      }
     }
-    if (!sl.copied) HIP_TRY(hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming));
-    for (int32_t k = 0; k < n; ++k) std::memcpy(sl.buf + at[k], host_inputs[k], (size_t)prefix_size * dims[k] * 4);
-    // Small payloads (the reference's models E / F: 32 dense features, 64 KB per request): the scatter kernel reads the
-    // pinned slot through its device mapping — no copy, no device staging buffer, one runtime call less per request.
-    // Large ones keep the H2D copy (the scatter would hold its CUs for the length of the PCIe transfer).
-    static const size_t direct_max = [] { // tuning aid: FCP_CONCAT_HOST_DIRECT_MAX=<bytes> (0: always copy)
-      const char *e = std::getenv("FCP_CONCAT_HOST_DIRECT_MAX");
-      return e ? (size_t)std::atoll(e) : (size_t)1 << 20;
-    }();
-    const bool direct = total <= direct_max;
-    const char *src = sl.buf_dev;
-    if (!direct) {
-      char *d_stage = static_cast<char *>(malloc_temp(malloc_temp_ctx, total));
-      if (!d_stage) return fail(FCP_ERR_ALLOC, "malloc_temp returned NULL");
-      HIP_TRY(hipMemcpyAsync(d_stage, sl.buf, total, hipMemcpyHostToDevice, stream));
-      src = d_stage;
-    } else {
-      __atomic_thread_fence(__ATOMIC_SEQ_CST); // the packed bytes are in memory before the launch that reads them is queued
-    }
-    std::vector<const void *> d_in(n);
-    for (int32_t k = 0; k < n; ++k) d_in[k] = src + at[k];
-    const int e = fcp_launch_concat_outputs(d_in.data(), dims, col_offsets, nullptr, n, prefix_size, out_width, 0, out, stream);
-    if (e) return hip_fail("concat-outputs launch", (hipError_t)e);
-    HIP_TRY(hipEventRecord(sl.copied, stream)); // the slot is free once its last reader (copy or scatter) has run
+    if (slp) break;
+    std::this_thread::yield(); // more than four calls in flight on this device
   }
+  HostStageSlot &sl = *slp;
+  struct Release {
+    HostStageRing *r;
+    HostStageSlot *s;
+    ~Release() {
+      std::lock_guard<std::mutex> lock(r->mu);
+      s->busy = false;
+    }
+  } release{ring, slp};
+  if (sl.copied && hipEventQuery(sl.copied) != hipSuccess) HIP_TRY(hipEventSynchronize(sl.copied));
+  if (sl.cap < total) {
+    if (sl.buf) HIP_TRY(hipHostFree(sl.buf));
+    sl.buf = nullptr;
+    sl.buf_dev = nullptr;
+    sl.cap = 0;
+    const size_t cap = std::max<size_t>(total, 1 << 16);
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&sl.buf), cap, hipHostMallocMapped));
+    HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&sl.buf_dev), sl.buf, 0));
+    sl.cap = cap;
+  }
+  if (!sl.copied) HIP_TRY(hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming));
+  for (int32_t k = 0; k < n; ++k) std::memcpy(sl.buf + at[k], host_inputs[k], (size_t)prefix_size * dims[k] * 4);
+  const char *src = sl.buf_dev;
+  if (!direct) {
+    char *d_stage = static_cast<char *>(malloc_temp(malloc_temp_ctx, total));
+    if (!d_stage) return fail(FCP_ERR_ALLOC, "malloc_temp returned NULL");
+    HIP_TRY(hipMemcpyAsync(d_stage, sl.buf, total, hipMemcpyHostToDevice, stream));
+    src = d_stage;
+  } else {
+    __atomic_thread_fence(__ATOMIC_SEQ_CST); // the packed bytes are in memory before the launch that reads them is queued
+  }
+  std::vector<const void *> d_in(n);
+  for (int32_t k = 0; k < n; ++k) d_in[k] = src + at[k];
+  const int e = fcp_launch_concat_outputs(d_in.data(), dims, col_offsets, nullptr, n, prefix_size, out_width, 0, out, stream);
+  if (e) return hip_fail("concat-outputs launch", (hipError_t)e);
+  HIP_TRY(hipEventRecord(sl.copied, stream)); // the slot is free once its last reader (copy or scatter) has run
   return FCP_OK;
 }
 
@@ -1945,13 +1974,17 @@ int fcp_shard_finalize(fcp_plan_t *p, const fcp_process_args_t *a, int32_t group
   bool install = false;
   thread_local std::vector<int32_t> key;
   build_key(p, &args, key);
+  const bool capturing = stream_is_capturing(stream); // same rule as the process call: nothing is installed inside a capture
   {
     std::unique_lock<std::mutex> lock(p->mu);
-    while ((rc = find_or_reserve(p, key, &slot, &install, false)) == kAllSlotsBusy) {
+    while ((rc = find_or_reserve(p, key, &slot, &install, capturing)) == kAllSlotsBusy) {
       lock.unlock();
       std::this_thread::yield();
       lock.lock();
     }
+    if (rc == kNeedsInstall)
+      return fail(FCP_ERR_UNSUPPORTED, "stream capture of fcp_shard_finalize for shapes that are not resident: run the request once on "
+                                       "this stream before capturing (descriptors cannot be installed inside a capture)");
     if (rc) return rc;
   }
   SlotUnpin unpin{p, slot, false};

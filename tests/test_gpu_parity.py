@@ -918,6 +918,18 @@ def test_process_call_is_hip_graph_capturable(torch_cuda, oracle):
             op(d_fresh, fo, fs, tabs, fresh.symbols)
     assert e.value.status == lib.FCP_ERR_UNSUPPORTED and "capture" in str(e.value)
     torch.cuda.synchronize()
+    # ... nor one whose tables have MOVED (re-binding copies records and synchronises the device: ADVICE r02); the plan
+    # keeps its old binding, so the next ordinary request with the old tables needs no re-bind
+    moved = [t.clone() for t in tabs]
+    g3 = torch.cuda.CUDAGraph()
+    with pytest.raises(lib.FcpError) as e:
+        with torch.cuda.graph(g3, stream=s):
+            op(d_blob, offsets, shapes, moved, req.symbols)
+    assert e.value.status == lib.FCP_ERR_UNSUPPORTED and "tables" in str(e.value)
+    torch.cuda.synchronize()
+    g.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(out.groups[0].cpu().numpy(), want[0])
     lib.check(lib.load().fcp_plan_release_captures(op.plan.handle), "fcp_plan_release_captures")
     with torch.cuda.stream(s):                                 # the plan serves on after the release
         res = op(d_fresh, fo, fs, tabs, fresh.symbols)
@@ -1482,3 +1494,62 @@ def test_wide_row_path_of_the_dense_kernel_on_ordinary_plans(torch_cuda, oracle,
     req = m.make_request(2)
     out, packed, _ = run_gpu(torch_cuda, m.spec, req.inputs, tabs, req.symbols)
     assert_equal_oracle(oracle, m.spec, packed, tabs, req.symbols, out)
+
+
+@pytest.mark.gpu
+def test_concat_outputs_host_from_many_threads_and_without_an_allocator(torch_cuda):
+    """fcp_concat_outputs_host holds its per-device ring lock for the slot bookkeeping only — eight
+    threads on eight streams scatter their own payloads concurrently, more calls in flight than the ring has slots, small
+    (read through the pinned mapping) and large (copied) payloads mixed; and a payload of at most 1 MiB needs no
+    malloc_temp callback at all."""
+    import ctypes as C
+    import threading
+    from recom_amd import lib as _lib
+    from recom_amd.ops import concat_outputs_host
+    torch = torch_cuda
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(0)
+    errors = []
+
+    def worker(t):
+        try:
+            r = np.random.default_rng(100 + t)
+            stream = torch.cuda.Stream(dev)
+            with torch.cuda.stream(stream):
+                for it in range(25):
+                    prefix = int(r.choice([1, 64, 513, 6000 if (t + it) % 5 == 0 else 200]))
+                    dims = [int(d) for d in r.choice([4, 8, 12, 32, 64], size=3)]
+                    width = sum(dims) + 8
+                    offs = [4, 4 + dims[0], 8 + dims[0] + dims[1]]
+                    host = [r.standard_normal((prefix, d)).astype(np.float32) for d in dims]
+                    out = torch.full((prefix, width), -7.0, device=dev)
+                    concat_outputs_host(host, offs, out, stream.cuda_stream)
+                    stream.synchronize()
+                    got = out.cpu().numpy()
+                    want = np.full((prefix, width), -7.0, np.float32)
+                    for h, o, d in zip(host, offs, dims):
+                        want[:, o:o + d] = h
+                    assert np.array_equal(got, want), (t, it)
+        except Exception as e:                                  # noqa: BLE001 - reported by the main thread
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors[0]
+    # no allocator: fine for a small payload, refused (not crashed) for one that must be copied
+    L = _lib.load()
+    small = rng.standard_normal((16, 8)).astype(np.float32)
+    big = rng.standard_normal((70000, 8)).astype(np.float32)                 # 2.2 MB > the 1 MiB direct limit
+    for payload, ok in ((small, True), (big, False)):
+        out = torch.zeros((payload.shape[0], 8), device=dev)
+        ptrs = (C.c_void_p * 1)(payload.ctypes.data)
+        dims, offs = np.asarray([8], np.int32), np.asarray([0], np.int32)
+        rc = L.fcp_concat_outputs_host(ptrs, dims.ctypes.data, offs.ctypes.data, 1, payload.shape[0], 8, out.data_ptr(),
+                                       _lib.ALLOC_FN(), None, 0, torch.cuda.current_stream(dev).cuda_stream)
+        torch.cuda.synchronize()
+        assert (rc == 0) == ok
+        if ok:
+            assert np.array_equal(out.cpu().numpy(), payload)
