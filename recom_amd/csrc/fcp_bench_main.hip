@@ -11,6 +11,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <chrono>
 #include <cmath>
 #include <cstdint>
@@ -366,9 +368,6 @@ int main(int argc, char **argv) {
       cpu_set_t near;
       if (!std::getenv("FCP_STAGER_NO_PIN") && fcp::cpus_near_device(0, &near)) (void)sched_setaffinity(0, sizeof(near), &near);
     }
-    fcp_stager_t *st = nullptr;
-    CHECK_FCP(fcp_stager_create_ex(0, (int64_t)blobs[0].size() + 4096, columns, columns, stager_depth, pack_threads,
-                                   zero_copy ? FCP_STAGER_ZERO_COPY : FCP_STAGER_DEFAULT, &st));
     std::vector<uint8_t> nflags(columns, 0);
     size_t shipped = blobs[0].size();
     if (narrow) {
@@ -391,48 +390,88 @@ int main(int argc, char **argv) {
     std::vector<int64_t> dims(1, batch);
     for (int v = 0; v < requests; ++v)
       for (int c = 0; c < columns; ++c) host[v][c] = {blobs[v].data() + offs[v][c], esz[c], 1, dims.data()};
-    const int ring_n = 6;
-    std::vector<void *> ring(ring_n);
     int64_t arena_bytes = 0;
     CHECK_FCP(fcp_plan_arena_bytes(plan, shps[0].data(), nullptr, &arena_bytes));
-    for (auto &p : ring) CHECK_HIP(hipMalloc(&p, (size_t)arena_bytes));
-    struct RingCtx { std::vector<void *> *r; size_t i; } rc{&ring, 0};
-    hipStream_t stream;
-    CHECK_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-    double host_stage_us = 0, host_process_us = 0; // host time inside the two calls (the pipelined loop is host-bound when their sum exceeds the copy)
-    auto one = [&](int k) {
+    // `--threads N`: N serve workers (the reference harness' serve_workers), each with its own stager, stream and output
+    // ring, staging and serving its own requests: one caller's stage + process calls are ~55 us of host time per
+    // request, more than the 45 us the copy takes, so a single caller is host-bound; two share the copy engine.
+    struct RingCtx { std::vector<void *> *r; size_t i; };
+    struct Worker {
+      fcp_stager_t *st = nullptr;
+      hipStream_t stream = nullptr;
+      std::vector<void *> ring;
+      RingCtx rc{nullptr, 0};
+      double host_stage_us = 0, host_process_us = 0; // host time inside the two calls
+    };
+    const int nw = threads < 1 ? 1 : threads;
+    std::vector<Worker> W(nw);
+    for (Worker &w : W) {
+      CHECK_FCP(fcp_stager_create_ex(0, (int64_t)blobs[0].size() + 4096, columns, columns, stager_depth, pack_threads,
+                                     zero_copy ? FCP_STAGER_ZERO_COPY : FCP_STAGER_DEFAULT, &w.st));
+      w.ring.resize(6);
+      for (auto &p : w.ring) CHECK_HIP(hipMalloc(&p, (size_t)arena_bytes));
+      w.rc.r = &w.ring;
+      CHECK_HIP(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
+    }
+    auto one = [&](Worker &w, int k) {
       const int v = k % requests;
       fcp_process_args_t a;
       std::memset(&a, 0, sizeof(a));
       const auto h0 = std::chrono::steady_clock::now();
-      CHECK_FCP(fcp_stager_stage_narrow(st, host[v].data(), columns, narrow ? nflags.data() : nullptr, stream,
+      CHECK_FCP(fcp_stager_stage_narrow(w.st, host[v].data(), columns, narrow ? nflags.data() : nullptr, w.stream,
                                         &a.concated_inputs, &a.concated_bytes, &a.concated_offsets,
                                         &a.concated_shapes));
       const auto h1 = std::chrono::steady_clock::now();
       a.input_ptrs = tables.data();
-      a.stream = stream;
-      a.malloc_buff_ctx = &rc;
+      a.stream = w.stream;
+      a.malloc_buff_ctx = &w.rc;
       a.malloc_buff = [](void *ctx, size_t) -> void * { auto *x = static_cast<RingCtx *>(ctx); return (*x->r)[x->i++ % x->r->size()]; };
       CHECK_FCP(fcp_process_feature_columns(plan, &a, nullptr));
-      host_stage_us += std::chrono::duration<double, std::micro>(h1 - h0).count();
-      host_process_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - h1).count();
+      w.host_stage_us += std::chrono::duration<double, std::micro>(h1 - h0).count();
+      w.host_process_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - h1).count();
     };
-    for (int k = 0; k < warmup + 1; ++k) one(k);
-    CHECK_HIP(hipStreamSynchronize(stream));
-    host_stage_us = host_process_us = 0;
+    std::atomic<int> ready{0};
+    std::atomic<bool> go{false};
+    auto serve = [&](int wi) {
+      Worker &w = W[wi];
+      for (int k = 0; k < warmup + 1; ++k) one(w, k + wi);
+      CHECK_HIP(hipStreamSynchronize(w.stream));
+      w.host_stage_us = w.host_process_us = 0;
+      ready.fetch_add(1);
+      while (!go.load(std::memory_order_acquire)) std::this_thread::yield();
+      for (int k = 0; k < steps; ++k) one(w, k + wi);
+      CHECK_HIP(hipStreamSynchronize(w.stream));
+    };
+    std::vector<std::thread> pool;
+    for (int wi = 1; wi < nw; ++wi) pool.emplace_back(serve, wi);
+    // worker 0 runs on this thread (pinned near the GPU above); the others inherit the affinity
+    {
+      Worker &w = W[0];
+      for (int k = 0; k < warmup + 1; ++k) one(w, k);
+      CHECK_HIP(hipStreamSynchronize(w.stream));
+      w.host_stage_us = w.host_process_us = 0;
+      while (ready.load() < nw - 1) std::this_thread::yield();
+    }
     const auto t0 = std::chrono::steady_clock::now();
-    for (int k = 0; k < steps; ++k) one(k);
-    CHECK_HIP(hipStreamSynchronize(stream));
-    const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / steps;
-    const double hs = host_stage_us / steps, hp = host_process_us / steps;
+    go.store(true, std::memory_order_release);
+    for (int k = 0; k < steps; ++k) one(W[0], k);
+    CHECK_HIP(hipStreamSynchronize(W[0].stream));
+    for (auto &t : pool) t.join();
+    const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / ((double)steps * nw);
+    double hs = 0, hp = 0;
+    for (Worker &w : W) {
+      hs += w.host_stage_us / steps / nw;
+      hp += w.host_process_us / steps / nw;
+    }
     // single-request latency: stage + process + sync, nothing else in flight
     double lat = 0;
     for (int k = 0; k < 50; ++k) {
       const auto a0 = std::chrono::steady_clock::now();
-      one(k);
-      CHECK_HIP(hipStreamSynchronize(stream));
+      one(W[0], k);
+      CHECK_HIP(hipStreamSynchronize(W[0].stream));
       lat += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - a0).count();
     }
+    hipStream_t stream = W[0].stream;
     // the floor of this loop: what the box's host-to-device link does with a blob of this size (pinned memory,
     // back-to-back hipMemcpyAsync on one stream: the copies of a pipelined run follow each other the same way)
     double copy_us = 0;
@@ -450,11 +489,11 @@ int main(int argc, char **argv) {
       CHECK_HIP(hipFree(dp_buf));
       CHECK_HIP(hipHostFree(hp_buf));
     }
-    std::printf("{\"pcie_inclusive\": true, \"zero_copy\": %d, \"pack_threads\": %d, \"blob_MB\": %.2f, \"us_per_request_pipelined\": %.2f, "
+    std::printf("{\"pcie_inclusive\": true, \"zero_copy\": %d, \"serve_workers\": %d, \"pack_threads\": %d, \"blob_MB\": %.2f, \"us_per_request_pipelined\": %.2f, "
                 "\"us_latency_single\": %.2f, \"inferences_per_s\": %.0f, \"host_us_stage_call\": %.2f, \"host_us_process_call\": %.2f, "
                 "\"h2d_copy_alone_us\": %.2f, \"h2d_GBs\": %.1f}\n",
-                zero_copy, pack_threads, shipped / 1e6, us, lat / 50, batch / (us * 1e-6), hs, hp, copy_us, shipped / copy_us / 1e3);
-    CHECK_FCP(fcp_stager_destroy(st));
+                zero_copy, nw, pack_threads, shipped / 1e6, us, lat / 50, batch / (us * 1e-6), hs, hp, copy_us, shipped / copy_us / 1e3);
+    for (Worker &w : W) CHECK_FCP(fcp_stager_destroy(w.st));
     CHECK_FCP(fcp_plan_destroy(plan));
     return 0;
   }
