@@ -4,7 +4,7 @@
   python bench.py [--gpus N] [--steps K] [--warmup W] [--workload s2|dlrm|ragged|shard|shard-col|e|f]
                   [--seg indices|csr|rowids32]   (ragged: how row membership arrives; default SparseTensor indices)
                   [--max-len N] [--ids uniform|zipf]   (ragged: bag lengths U{0..N}; id distribution)
-                  [--as-delivered]   (ragged: int64 ids + SparseTensor indices resident on the device, pre-pass there;
+                  [--as-delivered]   (ragged / e / f: int64 ids + SparseTensor indices resident on the device, pre-pass there;
                                       default: as the staged Addons>ConcatInputs leaves the request, host cost stated)
 
 A *step* is one request: one pass of the fused feature-column path (ids resident
@@ -362,7 +362,9 @@ def main():
                                    **({'max_len': args.max_len} if args.max_len else {}))
 
     raw_model = model
-    if args.workload == "ragged" and args.seg == "indices" and not args.as_delivered:
+    # Workloads with SparseTensor features (RAGGED; the reference's models E / F) are timed in the form the rewritten
+    # graph's Addons>ConcatInputs leaves in HBM (plan-file stage section: ids int32, row offsets) unless --as-delivered
+    if ((args.workload == "ragged" and args.seg == "indices") or args.workload in ("e", "f")) and not args.as_delivered:
         args.staged = True
     if args.staged:
         model = synth.staged_model(model)
