@@ -135,12 +135,22 @@ def host_staging_cost(raw_model, n_requests: int = 8):
     plain_us = timed(lambda pr: L.fcp_concat_inputs(pr[2], n, blob.ctypes.data, blob.nbytes, offsets.ctypes.data, shapes.ctypes.data))
     staged_us = timed(lambda pr: L.fcp_concat_inputs_ex(pr[2], n, modes.ctypes.data, pr[3].ctypes.data, blob.ctypes.data, blob.nbytes,
                                                         offsets.ctypes.data, shapes.ctypes.data))
+    pooled = {}
+    if hasattr(L, "fcp_pack_pool_create"):                           # the same pack on a worker pool (FCP_CONCAT_INPUTS_THREADS in the shim)
+        for nt in (4, 8, 16):
+            pool = C.c_void_p()
+            _lib.check(L.fcp_pack_pool_create(nt, C.byref(pool)), "fcp_pack_pool_create")
+            pooled[str(nt)] = timed(lambda pr: L.fcp_concat_inputs_ex_pool(pool, pr[2], n, modes.ctypes.data, pr[3].ctypes.data,
+                                                                           blob.ctypes.data, blob.nbytes, offsets.ctypes.data,
+                                                                           shapes.ctypes.data))
+            L.fcp_pack_pool_destroy(pool)
     nb = C.c_int64(0)
     _lib.check(L.fcp_concat_inputs_ex_sizes(prepared[0][2], n, modes.ctypes.data, prepared[0][3].ctypes.data, C.byref(nb), None), "sizes")
     return {"what": "host cost of the request form timed above: Addons>ConcatInputs with the plan file's stage section "
-                    "(fcp_concat_inputs_ex, one thread, like the TF op) vs the reference's byte copy of the same tensors "
-                    "(fcp_concat_inputs = concat_inputs_ops.cc:42-77); the C calls alone; never part of `value`",
-            "concat_inputs_staged_us": staged_us, "concat_inputs_byte_copy_us": plain_us,
+                    "(fcp_concat_inputs_ex, one thread, like the TF op; fcp_concat_inputs_ex_pool on 4 / 8 / 16 threads) vs the "
+                    "reference's byte copy of the same tensors (fcp_concat_inputs = concat_inputs_ops.cc:42-77); the C calls "
+                    "alone; never part of `value`",
+            "concat_inputs_staged_us": staged_us, "concat_inputs_staged_pool_us": pooled, "concat_inputs_byte_copy_us": plain_us,
             "blob_bytes_staged": int(nb.value), "blob_bytes_byte_copy": int(sum(a.nbytes for a in raws[0])),
             "inputs": n}
 

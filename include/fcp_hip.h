@@ -520,6 +520,18 @@ int fcp_concat_inputs_ex_sizes(const fcp_host_tensor_t *inputs, int32_t n_inputs
 int fcp_concat_inputs_ex(const fcp_host_tensor_t *inputs, int32_t n_inputs,
                          const uint8_t *modes, const int64_t *mode_args, void *blob,
                          int64_t blob_capacity, int32_t *offsets, int32_t *shapes);
+/* The same on a worker pool: the reference's op packs on one thread (concat_inputs_ops.cc:42-77), which for RAGGED is
+ * 1.4 ms per request of the staged pack (0.5 ms of plain copying) — longer than everything the GPU does with it.  A
+ * pool is a set of sleeping threads that split one call's inputs into ranges of about equal INPUT bytes; the calling
+ * thread works too.  One call at a time uses a pool: a second concurrent caller packs on its own thread instead of
+ * waiting (so an op instance shared by several serve workers never blocks on it).  Host only. */
+typedef struct fcp_pack_pool fcp_pack_pool_t;
+int fcp_pack_pool_create(int32_t n_threads, fcp_pack_pool_t **pool);
+int fcp_pack_pool_destroy(fcp_pack_pool_t *pool);
+int fcp_concat_inputs_ex_pool(fcp_pack_pool_t *pool /* NULL: this thread only */,
+                              const fcp_host_tensor_t *inputs, int32_t n_inputs,
+                              const uint8_t *modes, const int64_t *mode_args,
+                              void *blob, int64_t blob_capacity, int32_t *offsets, int32_t *shapes);
 /* The stage section of a column-plan file (version 3, written by `python -m recom_amd.graph --staged`):
  *   stage N symbols_input K / N lines "mode rows_symbol"
  * N = number of Addons>ConcatInputs inputs of the rewritten graph (= the plan's host inputs); modes[i] = FCP_STAGE_*

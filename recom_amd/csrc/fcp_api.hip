@@ -2145,7 +2145,7 @@ int fcp_stager_stage_narrow(fcp_stager_t *s, const fcp_host_tensor_t *inputs, in
 namespace {
 // the two host loops of the staged pack, built per instruction set (fcp_pack.cc)
 extern "C" void fcp_pack_narrow_i64(const int64_t *src, int32_t *dst, int64_t n);
-extern "C" void fcp_pack_seg_to_csr(const void *seg, int elem_size, int64_t stride, int64_t nnz, int64_t rows, int32_t *out);
+extern "C" int fcp_pack_seg_to_csr(const void *seg, int elem_size, int64_t stride, int64_t nnz, int64_t rows, int32_t *out);
 
 // Layout of the staged blob: byte offsets (byte_off[0..n]), the op's `offsets` and `shapes` outputs — exactly
 // ConcatInputsOp::Compute (concat_inputs_ops.cc:52-66), except that a narrowed int64 input occupies 4 bytes per element
@@ -2193,16 +2193,19 @@ int stage_layout(const fcp_host_tensor_t *inputs, int32_t n, const uint8_t *mode
 }
 
 // One input into its place in the staged blob (`nbytes` = its bytes there).
-void stage_pack_one(const fcp_host_tensor_t &t, int mode, int64_t mode_arg, char *dst, int64_t nbytes) {
-  if (nbytes <= 0) return;
+// returns false for an input that cannot be converted: row ids that are not sorted (TF's SparseSegment* ops refuse them too)
+bool stage_pack_one(const fcp_host_tensor_t &t, int mode, int64_t mode_arg, char *dst, int64_t nbytes) {
+  if (nbytes <= 0) return true;
   if (mode == FCP_STAGE_SEG_TO_CSR) {
-    fcp_pack_seg_to_csr(t.data, t.elem_size, t.rank == 2 ? t.dims[1] : 1, t.dims[0], mode_arg, reinterpret_cast<int32_t *>(dst));
+    return fcp_pack_seg_to_csr(t.data, t.elem_size, t.rank == 2 ? t.dims[1] : 1, t.dims[0], mode_arg, reinterpret_cast<int32_t *>(dst)) == 0;
   } else if (mode == FCP_STAGE_NARROW_I64) {
     fcp_pack_narrow_i64(static_cast<const int64_t *>(t.data), reinterpret_cast<int32_t *>(dst), nbytes / 4);
   } else {
     std::memcpy(dst, t.data, (size_t)nbytes);
   }
+  return true;
 }
+const char *const kUnsortedRows = "row ids of a converted input are not sorted (segment ids must be non-decreasing)";
 } // namespace
 
 int fcp_stager_stage_ex(fcp_stager_t *s, const fcp_host_tensor_t *inputs, int32_t n, const uint8_t *modes,
@@ -2243,14 +2246,17 @@ int fcp_stager_stage_ex(fcp_stager_t *s, const fcp_host_tensor_t *inputs, int32_
   const int64_t *bo = s->byte_off.data();
   char *dst = sl.h_blob;
   const uint64_t t_layout = s->stats ? now_ns() : 0;
+  std::atomic<int> refused{0};
   s->pool->run(chunks, [&](int c) {
     const int64_t b0 = size * c / chunks, b1 = size * (c + 1) / chunks;
     // inputs whose start offset falls in [b0, b1)
     int lo = (int)(std::lower_bound(bo, bo + n, b0) - bo);
     const int hi = (int)(std::lower_bound(bo, bo + n, b1) - bo);
     for (; lo < hi; ++lo)
-      stage_pack_one(inputs[lo], modes ? modes[lo] : FCP_STAGE_COPY, mode_args ? mode_args[lo] : 0, dst + bo[lo], bo[lo + 1] - bo[lo]);
+      if (!stage_pack_one(inputs[lo], modes ? modes[lo] : FCP_STAGE_COPY, mode_args ? mode_args[lo] : 0, dst + bo[lo], bo[lo + 1] - bo[lo]))
+        refused.store(1, std::memory_order_relaxed);
   });
+  if (refused.load()) return fail(FCP_ERR_INVALID_ARGUMENT, kUnsortedRows); // nothing was enqueued; the slot is simply reused
   const uint64_t t_packed = s->stats ? now_ns() : 0;
   if (!s->zero_copy) {
     // the device twin is free once the work that read its previous contents has run
@@ -2302,10 +2308,71 @@ int fcp_concat_inputs_ex(const fcp_host_tensor_t *inputs, int32_t n, const uint8
   const int rc = stage_layout(inputs, n, modes, mode_args, blob_capacity, -1, bo.data(), offsets, shapes, nullptr);
   if (rc) return rc;
   if (bo[n] > 0 && !blob) return fail(FCP_ERR_INVALID_ARGUMENT, "blob too small");
+  bool ok = true;
   for (int32_t i = 0; i < n; ++i)
-    stage_pack_one(inputs[i], modes ? modes[i] : FCP_STAGE_COPY, mode_args ? mode_args[i] : 0, static_cast<char *>(blob) + bo[i],
-                   bo[i + 1] - bo[i]);
+    ok = stage_pack_one(inputs[i], modes ? modes[i] : FCP_STAGE_COPY, mode_args ? mode_args[i] : 0, static_cast<char *>(blob) + bo[i],
+                        bo[i + 1] - bo[i]) && ok;
+  return ok ? FCP_OK : fail(FCP_ERR_INVALID_ARGUMENT, kUnsortedRows);
+}
+
+struct fcp_pack_pool {
+  fcp::PackPool *pool = nullptr;
+  int n_threads = 1;
+  std::mutex busy; // one call at a time splits its work over the pool; others pack on their own thread
+};
+
+int fcp_pack_pool_create(int32_t n_threads, fcp_pack_pool_t **out) {
+  if (!out || n_threads < 1 || n_threads > 1024) return fail(FCP_ERR_INVALID_ARGUMENT, "bad pack pool arguments");
+  fcp_pack_pool *p = new (std::nothrow) fcp_pack_pool();
+  if (!p) return fail(FCP_ERR_ALLOC, "out of host memory");
+  p->n_threads = n_threads;
+  p->pool = new fcp::PackPool(n_threads);
+  *out = p;
   return FCP_OK;
+}
+
+int fcp_pack_pool_destroy(fcp_pack_pool_t *p) {
+  if (!p) return FCP_OK;
+  {
+    std::lock_guard<std::mutex> lock(p->busy); // a call in flight finishes first
+  }
+  delete p->pool;
+  delete p;
+  return FCP_OK;
+}
+
+int fcp_concat_inputs_ex_pool(fcp_pack_pool_t *pool, const fcp_host_tensor_t *inputs, int32_t n, const uint8_t *modes,
+                              const int64_t *mode_args, void *blob, int64_t blob_capacity, int32_t *offsets, int32_t *shapes) {
+  if (!pool || pool->n_threads <= 1 || n < 2) return fcp_concat_inputs_ex(inputs, n, modes, mode_args, blob, blob_capacity, offsets, shapes);
+  std::unique_lock<std::mutex> mine(pool->busy, std::try_to_lock);
+  if (!mine.owns_lock()) return fcp_concat_inputs_ex(inputs, n, modes, mode_args, blob, blob_capacity, offsets, shapes);
+  pool->pool->expect(); // the workers wake up while this thread lays the blob out
+  if (!inputs || !offsets || !shapes) return fail(FCP_ERR_INVALID_ARGUMENT, "null argument");
+  std::vector<int64_t> bo((size_t)n + 1), in_off((size_t)n + 1);
+  const int rc = stage_layout(inputs, n, modes, mode_args, blob_capacity, -1, bo.data(), offsets, shapes, nullptr);
+  if (rc) return rc;
+  if (bo[n] > 0 && !blob) return fail(FCP_ERR_INVALID_ARGUMENT, "blob too small");
+  // ranges of inputs of about equal INPUT bytes (a converted index matrix is 16 bytes per id in, 4 per row out)
+  in_off[0] = 0;
+  for (int32_t i = 0; i < n; ++i) {
+    int64_t ne = 1;
+    for (int32_t j = 0; j < inputs[i].rank; ++j) ne *= inputs[i].dims[j];
+    in_off[i + 1] = in_off[i] + ne * inputs[i].elem_size;
+  }
+  const int64_t total = in_off[n];
+  const int chunks = (int)std::min<int64_t>(std::max<int64_t>(1, total / (64 << 10)), 4 * pool->n_threads);
+  const int64_t *io = in_off.data();
+  std::atomic<int> refused{0};
+  pool->pool->run(chunks, [&](int c) {
+    const int64_t b0 = total * c / chunks, b1 = total * (c + 1) / chunks;
+    int lo = (int)(std::lower_bound(io, io + n, b0) - io);
+    const int hi = c + 1 == chunks ? n : (int)(std::lower_bound(io, io + n, b1) - io); // (the last chunk also takes trailing empty inputs)
+    for (; lo < hi; ++lo)
+      if (!stage_pack_one(inputs[lo], modes ? modes[lo] : FCP_STAGE_COPY, mode_args ? mode_args[lo] : 0, static_cast<char *>(blob) + bo[lo],
+                          bo[lo + 1] - bo[lo]))
+        refused.store(1, std::memory_order_relaxed);
+  });
+  return refused.load() ? fail(FCP_ERR_INVALID_ARGUMENT, kUnsortedRows) : FCP_OK;
 }
 
 int fcp_stager_stage(fcp_stager_t *s, const fcp_host_tensor_t *inputs, int32_t n, void *stream,

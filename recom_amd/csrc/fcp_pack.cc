@@ -29,7 +29,7 @@ extern "C" FCP_CLONES void fcp_pack_narrow_i64(const int64_t *src, int32_t *dst,
 // no load from `out`: every id stores the length of its row's run so far (the last store of a run is the row's count),
 // so neither a row boundary (one per ~5 ids, unpredictable) nor a store-to-load dependency on a counter stalls it;
 // rows beyond the last one go to a dummy, all rows below 0 count as "before row 0".
-template <typename T> static inline void seg_to_csr_t(const T *p, int64_t stride, int64_t nnz, int64_t rows, int32_t *out) {
+template <typename T> static inline int seg_to_csr_t(const T *p, int64_t stride, int64_t nnz, int64_t rows, int32_t *out) {
   memset(out, 0, sizeof(int32_t) * (size_t)(rows + 1));
   // blocks of ids: first the strided row words are gathered into a small dense int32 buffer, clamped to [-1, rows]
   // (a loop the compiler vectorises: this is the pass that touches the request's memory), then the run lengths
@@ -37,7 +37,7 @@ template <typename T> static inline void seg_to_csr_t(const T *p, int64_t stride
   constexpr int kBlock = 1024;
   int32_t tmp[kBlock];
   const int32_t hi = (int32_t)(rows < 0x7fffffff ? rows : 0x7fffffff);
-  int32_t dummy = 0, cur = INT32_MIN, run = 0;
+  int32_t dummy = 0, cur = INT32_MIN, run = 0, descending = 0;
   for (int64_t i0 = 0; i0 < nnz; i0 += kBlock) {
     const int n = (int)(nnz - i0 < kBlock ? nnz - i0 : kBlock);
     const T *q = p + i0 * stride;
@@ -55,6 +55,7 @@ template <typename T> static inline void seg_to_csr_t(const T *p, int64_t stride
     for (int i = 0; i < n; ++i) {
       const int32_t r = tmp[i];
       run = (run & -(int32_t)(r == cur)) + 1; // arithmetic, not a branch: one row in ~5 ends here, unpredictably
+      descending |= (int32_t)(r < cur);       // the ids must be sorted (TF: "segment ids are not increasing")
       cur = r;
       // counts[r + 1] = ids of row r; counts[0] = ids before row 0; rows >= `rows` go to a dummy
       const uintptr_t in = (uintptr_t)0 - (uintptr_t)(r < hi);
@@ -67,9 +68,11 @@ template <typename T> static inline void seg_to_csr_t(const T *p, int64_t stride
     acc += out[r];
     out[r] = acc;
   }
+  return descending;
 }
 
-extern "C" FCP_CLONES void fcp_pack_seg_to_csr(const void *seg, int elem_size, int64_t stride, int64_t nnz, int64_t rows, int32_t *out) {
-  if (elem_size == 8) seg_to_csr_t(static_cast<const int64_t *>(seg), stride, nnz, rows, out);
-  else seg_to_csr_t(static_cast<const int32_t *>(seg), stride, nnz, rows, out);
+// returns 1 if the ids were not sorted (the offsets are then meaningless), else 0
+extern "C" FCP_CLONES int fcp_pack_seg_to_csr(const void *seg, int elem_size, int64_t stride, int64_t nnz, int64_t rows, int32_t *out) {
+  if (elem_size == 8) return seg_to_csr_t(static_cast<const int64_t *>(seg), stride, nnz, rows, out);
+  return seg_to_csr_t(static_cast<const int32_t *>(seg), stride, nnz, rows, out);
 }

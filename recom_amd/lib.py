@@ -115,6 +115,7 @@ EXPORTS = [
     "fcp_shard_step_create", "fcp_shard_step_run", "fcp_shard_step_destroy",
     "fcp_stager_create", "fcp_stager_create_ex", "fcp_stager_stage", "fcp_stager_stage_ex", "fcp_stager_stage_narrow", "fcp_stager_destroy",
     "fcp_concat_inputs_ex_sizes", "fcp_concat_inputs_ex", "fcp_plan_file_stage_info",
+    "fcp_pack_pool_create", "fcp_pack_pool_destroy", "fcp_concat_inputs_ex_pool",
     "fcp_graph_build", "fcp_graph_free", "fcp_placement_assign", "fcp_concat_outputs_scatter_strided",
 ]
 
@@ -220,6 +221,11 @@ def load() -> C.CDLL:
                                           C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
                                           C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.POINTER(C.c_int32))]
     L.fcp_stager_destroy.argtypes = [C.c_void_p]
+    if hasattr(L, "fcp_pack_pool_create"):
+        L.fcp_pack_pool_create.argtypes = [C.c_int32, C.POINTER(C.c_void_p)]
+        L.fcp_pack_pool_destroy.argtypes = [C.c_void_p]
+        L.fcp_concat_inputs_ex_pool.argtypes = [C.c_void_p, C.POINTER(HostTensor), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                C.c_int64, C.c_void_p, C.c_void_p]
     if "FCP_LIB_DIR" not in os.environ or hasattr(L, "fcp_concat_inputs_ex"):  # (an older A/B build may predate these)
         L.fcp_concat_inputs_ex_sizes.argtypes = [C.POINTER(HostTensor), C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64),
                                                  C.POINTER(C.c_int32)]

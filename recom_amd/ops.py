@@ -17,6 +17,7 @@ All compute goes through ``libfcp_hip.so``; there is no Python/CPU fallback.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import List, Optional, Sequence
 
@@ -39,9 +40,26 @@ def _host_tensors(inputs):
     return arrs, dims_keep, tens
 
 
-def concat_inputs(inputs: Sequence[np.ndarray], stage=None):
+class PackPool:
+    """Worker pool for ``Addons>ConcatInputs`` (``fcp_pack_pool_create``): the reference's op packs on one thread
+    (``concat_inputs_ops.cc:42-77``); with a pool one call's inputs are split over sleeping worker threads."""
+
+    def __init__(self, n_threads: int) -> None:
+        self._L = _lib.load()
+        self.handle = C.c_void_p()
+        _lib.check(self._L.fcp_pack_pool_create(int(n_threads), C.byref(self.handle)), "fcp_pack_pool_create")
+
+    def close(self) -> None:
+        if getattr(self, "handle", None):
+            self._L.fcp_pack_pool_destroy(self.handle)
+            self.handle = None
+
+    __del__ = close
+
+
+def concat_inputs(inputs: Sequence[np.ndarray], stage=None, pool: Optional[PackPool] = None):
     """Pack N host tensors into ``(output:int8[sum bytes], offsets:int32[N],
-    shapes:int32[sum rank])`` — bit-exact with ``ConcatInputsOp::Compute``.
+    shapes:int32[sum rank])`` — bit-exact with ``ConcatInputsOp::Compute``.  ``pool``: pack on a worker pool.
 
     ``stage`` (a :class:`recom_amd.plan.StageInfo`, the stage section of the plan file): the staged form —
     int64 ids packed as int32, the sorted row ids / SparseTensor indices of pooled columns as int32 row offsets
@@ -63,7 +81,11 @@ def concat_inputs(inputs: Sequence[np.ndarray], stage=None):
     blob = np.empty(nbytes.value, np.int8)
     offsets = np.empty(n, np.int32)
     shapes = np.empty(rank_sum.value, np.int32)
-    if stage is None:
+    if pool is not None:
+        m, a = (None, None) if stage is None else (modes.ctypes.data, args.ctypes.data)
+        _lib.check(L.fcp_concat_inputs_ex_pool(pool.handle, tens, n, m, a, blob.ctypes.data, blob.nbytes, offsets.ctypes.data,
+                                               shapes.ctypes.data), "ConcatInputs")
+    elif stage is None:
         _lib.check(L.fcp_concat_inputs(tens, n, blob.ctypes.data, blob.nbytes, offsets.ctypes.data,
                                        shapes.ctypes.data), "ConcatInputs")
     else:
@@ -77,9 +99,12 @@ class ConcatInputs:
     (``concat_inputs_ops.cc:33-40``) and, when the graph was rewritten for a staged plan, the node's ``_fcp_plan``
     attr — the plan file whose stage section says how to pack (``tf_shim/fcp_tf_ops.cc``)."""
 
-    def __init__(self, ranks: Sequence[int], plan_path: Optional[str] = None) -> None:
+    def __init__(self, ranks: Sequence[int], plan_path: Optional[str] = None, threads: Optional[int] = None) -> None:
         self.ranks = [int(r) for r in ranks]
         self.stage = None
+        # FCP_CONCAT_INPUTS_THREADS (what the shim reads): pack on that many threads; default 1 = the reference's op
+        threads = int(os.environ.get("FCP_CONCAT_INPUTS_THREADS", "1")) if threads is None else int(threads)
+        self.pool = PackPool(threads) if threads > 1 else None
         if plan_path:
             from .plan_io import load_stage
             self.stage = load_stage(plan_path)
@@ -89,7 +114,7 @@ class ConcatInputs:
     def __call__(self, inputs: Sequence[np.ndarray]):
         if [np.asarray(a).ndim for a in inputs] != self.ranks:
             raise ValueError("ConcatInputs: input ranks differ from attr `ranks`")
-        return concat_inputs(inputs, self.stage)
+        return concat_inputs(inputs, self.stage, self.pool)
 
 
 # ----------------------------------------------------------------------------

@@ -19,6 +19,7 @@
 //     $(python -c 'import tensorflow as tf; print(" ".join(tf.sysconfig.get_compile_flags()+tf.sysconfig.get_link_flags()))')
 //     -I../../include -L.. -lfcp_hip -Wl,-rpath,'$ORIGIN/..' -DTENSORFLOW_USE_ROCM=1
 #include <algorithm>
+#include <cstdlib>
 #include <numeric>
 #include <string>
 #include <vector>
@@ -88,7 +89,15 @@ public:
                     errors::InvalidArgument("the symbols input of ConcatInputs must be int32"));
       }
     }
+    // FCP_CONCAT_INPUTS_THREADS=<n>: pack on n threads (the reference's op packs on one, concat_inputs_ops.cc:42-77; for a
+    // request of a thousand SparseTensor features that is a millisecond).  Concurrent Compute calls on this instance never
+    // wait for the pool: whoever finds it busy packs on its own thread.
+    if (const char *e = std::getenv("FCP_CONCAT_INPUTS_THREADS")) {
+      const int n_threads = std::atoi(e);
+      if (n_threads > 1) OP_REQUIRES_OK(c, FcpStatus(fcp_pack_pool_create(n_threads, &pool_), "pack pool"));
+    }
   }
+  ~ConcatInputsOp() override { fcp_pack_pool_destroy(pool_); }
   void Compute(OpKernelContext *c) override {
     std::vector<fcp_host_tensor_t> ts(num_inputs_);
     std::vector<std::vector<int64_t>> dims(num_inputs_);
@@ -122,9 +131,9 @@ public:
     OP_REQUIRES_OK(c, c->allocate_output(0, {bytes}, &blob, pinned));
     OP_REQUIRES_OK(c, c->allocate_output(1, {num_inputs_}, &offsets));
     OP_REQUIRES_OK(c, c->allocate_output(2, {rank_sum}, &shapes));
-    OP_REQUIRES_OK(c, FcpStatus(fcp_concat_inputs_ex(ts.data(), num_inputs_, modes, mode_args.empty() ? nullptr : mode_args.data(),
-                                                     blob->data(), bytes, offsets->flat<int32>().data(),
-                                                     shapes->flat<int32>().data()),
+    OP_REQUIRES_OK(c, FcpStatus(fcp_concat_inputs_ex_pool(pool_, ts.data(), num_inputs_, modes, mode_args.empty() ? nullptr : mode_args.data(),
+                                                          blob->data(), bytes, offsets->flat<int32>().data(),
+                                                          shapes->flat<int32>().data()),
                                 "ConcatInputs"));
   }
 private:
@@ -132,6 +141,7 @@ private:
   std::vector<uint8_t> modes_;        // FCP_STAGE_* per input (empty: plain byte copy)
   std::vector<int32_t> rows_symbol_;  // which symbol holds the row count of a converted input
   int32_t symbols_input_ = -1;        // which input is the symbols vector
+  fcp_pack_pool_t *pool_ = nullptr;   // optional pack workers (FCP_CONCAT_INPUTS_THREADS)
 };
 
 // ---- Addons>FeatureColumnProcess[WithSymbols] (GPU) --------------------------------------------

@@ -698,3 +698,52 @@ def test_table_size_limits_are_rows_not_bytes():
         plan((1 << 32) - 3, 4)
     plan((1 << 32) - 4, 4)
     plan(1 << 33, 8, world=4)                       # row-sharded: the limit applies to the shard
+
+
+def test_concat_inputs_on_a_pack_pool_equals_the_single_thread_pack():
+    """fcp_concat_inputs_ex_pool: one call's inputs split over a worker pool (ranges of about equal INPUT bytes) — the
+    blob, offsets and shapes are those of the single-thread call, staged and unstaged, ragged and empty inputs; two
+    threads sharing one pool (an op instance shared by serve workers) never block each other and agree as well."""
+    import threading
+    from recom_amd import lib, synth
+    from recom_amd.ops import ConcatInputs, PackPool, concat_inputs
+    m = synth.model_ragged(columns=96, vocab=5000, batch=64, seg="indices")
+    spec, stage = m.spec.staged_for_concat_inputs()
+    pool = PackPool(6)
+    reqs = [m.make_request(s) for s in range(6)]
+    for r in reqs:
+        ins = list(r.inputs) + [r.symbols]
+        for st in (None, stage):
+            x = ins if st is not None else ins[:-1]
+            a, b = concat_inputs(x, st), concat_inputs(x, st, pool)
+            assert all(np.array_equal(p, q) for p, q in zip(a, b))
+    # tiny and empty requests
+    for x in ([np.zeros(0, np.int64)], [np.arange(3, dtype=np.int32), np.zeros((0, 2), np.int64), np.float32(1.5)], []):
+        a, b = concat_inputs(x), concat_inputs(x, None, pool)
+        assert all(np.array_equal(p, q) for p, q in zip(a, b))
+    # a malformed request is refused by the pool path as by the plain one (unsorted row ids)
+    bad = list(reqs[0].inputs) + [reqs[0].symbols]
+    k = next(i for i, mode in enumerate(stage.modes) if mode == 2 and bad[i].shape[0] > 2)
+    bad[k] = bad[k][::-1].copy()
+    for p in (None, pool):
+        with pytest.raises(lib.FcpError):
+            concat_inputs(bad, stage, p)
+    errors = []
+
+    def worker(t):
+        try:
+            for it in range(40):
+                r = reqs[(t + it) % len(reqs)]
+                ins = list(r.inputs) + [r.symbols]
+                got, want = concat_inputs(ins, stage, pool), concat_inputs(ins, stage)
+                assert all(np.array_equal(p, q) for p, q in zip(got, want))
+        except Exception as e:                                    # noqa: BLE001
+            errors.append(e)
+
+    ts = [threading.Thread(target=worker, args=(t,)) for t in range(3)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errors, errors[0]
+    op = ConcatInputs(spec.host_input_ranks[:-1] + [1], threads=4)          # the op object with a pool of its own
+    assert op.pool is not None
+    pool.close()
