@@ -1,6 +1,6 @@
-// ref_bucketize_wrap.cc — C entry point around the REFERENCE's `Bucketize` template, whose text oracle/ref_extract.py
-// takes from /root/reference/tensorflow_addons/graph_optimizers/cuda_emitter.cc:233-247 into oracle/_ref/bucketize_ref.inc
-// at build time (the text is never part of this repository).  Test infrastructure only.
+// ref_bucketize_wrap.cc — C entry points around the REFERENCE's `Bucketize` template and its `alignmem` helper, whose text
+// oracle/ref_extract.py takes from /root/reference/tensorflow_addons/graph_optimizers/cuda_emitter.cc:233-247 and :967-969
+// into oracle/_ref/*.inc at build time (the text is never part of this repository).  Test infrastructure only.
 #include <stdint.h>
 
 #include <utility>
@@ -9,6 +9,8 @@
 #define __device__
 #define __forceinline__ inline
 #include "bucketize_ref.inc"
+// `alignmem` of the reference's generated host code (cuda_emitter.cc:967-969): plain C
+#include "alignmem_ref.inc"
 
 namespace {
 constexpr int kMaxBoundaries = 1024; // instantiated for every count 1..kMaxBoundaries (NUM_BOUNDARIES is a template argument)
@@ -31,3 +33,5 @@ extern "C" int ref_bucketize(const float *boundaries, int n, float value) {
 extern "C" void ref_bucketize_many(const float *boundaries, int n, const float *values, int64_t count, int32_t *out) {
   for (int64_t i = 0; i < count; ++i) out[i] = ref_bucketize(boundaries, n, values[i]);
 }
+// the arena alignment of the reference's generated host code (cuda_emitter.cc:2151-2179 sums / steps by it)
+extern "C" int ref_alignmem(int x) { return alignmem(x); }

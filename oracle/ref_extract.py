@@ -2,12 +2,14 @@
 """Builds oracle/_ref/libref_bucketize.so from the REFERENCE's own source, where it lies.
 
 Almost nothing of the reference's hot path can be compiled in this image: its device code exists only as C++ string
-fragments that need TensorFlow 2.6.2, SymEngine, nvcc and CUB.  One function is plain C++ inside
-its literal: `Bucketize` (tensorflow_addons/graph_optimizers/cuda_emitter.cc:233-247).  This recipe
+fragments that need TensorFlow 2.6.2, SymEngine, nvcc and CUB.  Two functions are plain C++ inside
+their literals: `Bucketize` (tensorflow_addons/graph_optimizers/cuda_emitter.cc:233-247) and the arena alignment helper
+`alignmem` of the generated host code (:967-969, used by :2151-2179).  This recipe
 
   1. reads that file under /root/reference (never copied into the repository),
-  2. takes the adjacent string literals of the `Bucketize` template and un-escapes them into oracle/_ref/bucketize_ref.inc
-     (a generated file: oracle/_ref/ is git-ignored, it only travels to the GPU box next to the built library),
+  2. takes the adjacent string literals of the `Bucketize` template and of `alignmem` and un-escapes them into
+     oracle/_ref/bucketize_ref.inc / alignmem_ref.inc (generated files: oracle/_ref/ is git-ignored, it only travels to
+     the GPU box next to the built library),
   3. compiles oracle/ref_bucketize_wrap.cc (ours: it defines the two CUDA qualifiers away and instantiates the
      template for every boundary count the tests use) with g++ into oracle/_ref/libref_bucketize.so.
 
@@ -34,15 +36,25 @@ def extract() -> str:
     return body
 
 
+def extract_alignmem() -> str:
+    text = open(SRC).read()
+    start = text.index('"static __inline__ int alignmem(int x) {\\n"')
+    end = text.index('";\n', start) + 1
+    body = "".join(re.findall(r'"((?:[^"\\]|\\.)*)"', text[start:end])).encode().decode("unicode_escape")
+    if "alignmem(int x)" not in body or body.count("{") != 1 or body.count("}") != 1:
+        raise SystemExit("ref_extract: the alignmem literal does not look as expected")
+    return body
+
+
 def build(force: bool = False) -> bool:
     if not os.path.exists(SRC):
         return os.path.exists(os.path.join(OUT, "libref_bucketize.so"))
     os.makedirs(OUT, exist_ok=True)
     inc, lib = os.path.join(OUT, "bucketize_ref.inc"), os.path.join(OUT, "libref_bucketize.so")
-    body = extract()
-    if force or not os.path.exists(inc) or open(inc).read() != body:
-        open(inc, "w").write(body)
-        force = True
+    for path, body in ((inc, extract()), (os.path.join(OUT, "alignmem_ref.inc"), extract_alignmem())):
+        if force or not os.path.exists(path) or open(path).read() != body:
+            open(path, "w").write(body)
+            force = True
     wrap = os.path.join(HERE, "ref_bucketize_wrap.cc")
     if force or not os.path.exists(lib) or os.path.getmtime(lib) < os.path.getmtime(wrap):
         subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-fno-fast-math", "-I", OUT, wrap, "-o", lib])

@@ -45,6 +45,22 @@ def ref_bucketize():
     return run
 
 
+@pytest.fixture(scope="session")
+def ref_alignmem():
+    """The REFERENCE's own `alignmem` (the arena alignment of its generated host code, cuda_emitter.cc:967-969, used by
+    :2151-2179), compiled from its source by oracle/ref_extract.py next to `Bucketize`.  Returns f(bytes) -> bytes."""
+    import ctypes as C
+    import ref_extract
+    if not ref_extract.build():
+        pytest.skip("oracle/_ref/libref_bucketize.so is absent and /root/reference is not here to build it from")
+    lib = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libref_bucketize.so"))
+    if not hasattr(lib, "ref_alignmem"):
+        pytest.skip("oracle/_ref was built before ref_alignmem existed")
+    lib.ref_alignmem.argtypes = [C.c_int]
+    lib.ref_alignmem.restype = C.c_int
+    return lambda x: int(lib.ref_alignmem(int(x)))
+
+
 class GoldenCase:
     def __init__(self, z, name):
         self.name = name

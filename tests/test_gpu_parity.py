@@ -195,9 +195,10 @@ def test_narrow_vector_widths(torch_cuda, oracle, dims):
     assert_equal_oracle(oracle, d.spec, packed, tabs, req.symbols, out)
 
 
-def test_per_column_layout_and_concat_outputs(torch_cuda, oracle):
+def test_per_column_layout_and_concat_outputs(torch_cuda, oracle, ref_alignmem):
     """FCP_LAYOUT_PER_COLUMN reproduces the reference arena (128-byte aligned
-    per-column buffers, cuda_emitter.cc:967-969, :2151-2179); ConcatOutputs
+    per-column buffers, cuda_emitter.cc:967-969, :2151-2179: offsets step by the
+    REFERENCE's own `alignmem`, compiled from its source); ConcatOutputs
     (concat_outputs_op_gpu.cu.cc:85-131) then yields the fused result."""
     from recom_amd import synth
     from recom_amd.ops import concat_outputs
@@ -214,7 +215,7 @@ def test_per_column_layout_and_concat_outputs(torch_cuda, oracle):
     for k, c in enumerate(spec_pc.columns):
         assert int(pc.output_ptrs[k]) - base == cursor
         assert pc.output_row_strides[k] == c.dim
-        cursor += (50 * c.dim * 4 + 127) // 128 * 128
+        cursor += ref_alignmem(50 * c.dim * 4)
     order = sorted(range(spec_pc.n_columns), key=lambda k: spec_pc.columns[k].concat_slot)
     cat = concat_outputs([pc.column(k) for k in order])
     torch_cuda.cuda.synchronize()

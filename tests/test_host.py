@@ -747,3 +747,29 @@ def test_concat_inputs_on_a_pack_pool_equals_the_single_thread_pack():
     op = ConcatInputs(spec.host_input_ranks[:-1] + [1], threads=4)          # the op object with a pool of its own
     assert op.pool is not None
     pool.close()
+
+
+def test_per_column_arena_steps_by_the_references_own_alignmem(ref_alignmem):
+    """FCP_LAYOUT_PER_COLUMN is the reference's arena (cuda_emitter.cc:2151-2179): buffer_size_sum = sum of
+    alignmem(elements * sizeof) over the columns' buffers.  `alignmem` here is the REFERENCE's function, compiled from
+    its own source (oracle/_ref): the library's arena size for per-column plans must be that sum — no GPU needed."""
+    import ctypes as C
+    from recom_amd import lib, synth
+    from recom_amd.ops import Plan
+    from recom_amd.plan import LAYOUT_PER_COLUMN
+    assert [ref_alignmem(x) for x in (0, 1, 127, 128, 129)] == [0, 128, 128, 128, 256]
+    for batch in (1, 7, 50, 333):
+        m = synth.model_s1(columns=23, dim=12, batch=batch)              # one-hot and multi-hot columns
+        spec = m.spec.with_layout(LAYOUT_PER_COLUMN)
+        p = Plan(spec, host_only=True)
+        req = m.make_request(0)
+        shapes = np.concatenate([np.asarray(np.asarray(a).shape, np.int32) for a in req.inputs]).astype(np.int32)
+        got = C.c_int64()
+        sym = None if req.symbols is None else np.ascontiguousarray(req.symbols, np.int32)
+        lib.check(lib.load().fcp_plan_arena_bytes(p.handle, shapes.ctypes.data, None if sym is None else sym.ctypes.data,
+                                                  C.byref(got)), "fcp_plan_arena_bytes")
+        # outputs, then the row-offset buffers of the columns that bring sorted segment ids (the reference's
+        # segment_offsets buffer, cuda_emitter.cc:1734-1737: num_segments + 1 ints, one more of its fc_meta buffers)
+        want = sum(ref_alignmem(batch * c.dim * 4) for c in spec.columns) + \
+            sum(ref_alignmem((batch + 1) * 4) for c in spec.columns if c.seg_kind in (1, 2))
+        assert got.value == want
