@@ -13,8 +13,15 @@
  * semantics that ARE importable in the build container — PyTorch-CPU
  * `embedding_bag` / `bucketize(right=True)` / `index_select` and a NumPy
  * float64 restatement — through tests/test_oracle.py and the committed
- * fixtures in tests/golden/.  Relative to the reference itself parity is
- * "unpinned by reference-owned vectors" and DESIGN.md says so.
+ * fixtures in tests/golden/, and TensorFlow's documented examples of every
+ * fused op (tests/golden/tf_doc_examples.py).  Two fragments of the reference
+ * ARE plain C++ inside their string literals and are compiled from the
+ * reference's own source, where it lies, into oracle/_ref/ by
+ * oracle/ref_extract.py: `Bucketize` (cuda_emitter.cc:233-247) and the arena
+ * alignment `alignmem` (:967-969); orc_bucketize and the per-column arena
+ * layout are held to them.  For everything else parity relative to the
+ * reference itself is "unpinned by reference-owned vectors" and DESIGN.md
+ * says so.
  */
 #ifndef FCP_ORACLE_H_
 #define FCP_ORACLE_H_
