@@ -316,6 +316,7 @@ def main():
                     help="ragged: time the request as the graph's tensors are (int64 ids, SparseTensor indices resident on the "
                          "device, segment-offset pre-pass on the device) instead of as the staged ConcatInputs leaves it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true", help="skip the closed-form check of the resident requests before the warm-up")
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive pass (host tensors -> pinned ring -> H2D -> kernel)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="skip the extra overlapped-serving pass (3 streams): keeps a kernel trace of this run single-stream")
@@ -410,6 +411,9 @@ def main():
     h = ServingHarness(model, device=local_rank, n_requests=args.requests, arena_ring=6, n_threads=args.threads,
                        seed0=1000 * rank)
     bytes_alg = h.algorithmic_bytes()
+    # a wrong kernel is not timed: every resident request is served once and compared with the closed-form tables (no
+    # oracle: recom_amd.harness.verify_resident); this also reads every request blob once before the warm-up
+    verified = h.verify_resident() if not args.no_verify else {"checked": 0, "note": "--no-verify"}
 
     h.run(max(args.warmup, 1))                       # W untimed warm-up steps
     if dist:
@@ -469,6 +473,7 @@ def main():
                                   f"{model.table_bytes() / 1e9:.0f} GB of tables fit one GPU)",
                    "serve_workers": args.threads},
         "requests_per_s": value / batch,
+        "verified": verified,
         "p50_latency_ms": float(np.percentile(it, 50)), "p95_latency_ms": float(np.percentile(it, 95)),
         "latency_scope": f"device latency of one request (HIP event pair around it on the launch stream, {len(it)} samples), "
                          "inputs resident in HBM; host packing + H2D are reported separately (DESIGN.md section 4, PCIe-inclusive rate)",

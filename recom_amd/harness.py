@@ -103,6 +103,70 @@ class ServingHarness:
                    "fcp_harness_run_graph")
         return wall.value, dev.value
 
+    def verify_resident(self, max_columns: int = 48, pooled_rows: int = 12) -> dict:
+        """Every resident request is served ONCE through the library and checked against the closed-form table contents
+        (``synth.hash_rows``; no oracle involved) before anything is timed: one-hot columns are exact copies of table
+        rows, pooled columns exact fp32 sums / means in id order of them (a sample of columns and rows; columns with id
+        transforms, hashing or ScatterNd are left to the test suite).  A wrong kernel is refused here, not timed.  It
+        also means that every request blob has been read once before the warm-up starts."""
+        from . import synth
+        from .ops import FeatureColumnProcess
+        from .plan import (COMBINER_MEAN, FORM_GATHER, FORM_PASSTHROUGH, FORM_SEGMENT_REDUCE, IDS_F32_BUCKETIZE, SEG_CSR_I32,
+                           XFORM_NONE)
+        torch = self.torch
+        spec = self.spec
+        if spec.shard_world > 1 or any(not hasattr(t, "seed") for t in self.model.tables):
+            return {"checked": 0, "note": "sharded or table contents not closed-form: not verified here"}
+        op = FeatureColumnProcess(spec, self.dev.index or 0, plan=self.plan)
+        offs = spec.column_offsets()
+        plain = [k for k, c in enumerate(spec.columns) if c.xform_mode == XFORM_NONE and not c.hash_buckets and not len(c.seg_mul)]
+        dense = [k for k in plain if spec.columns[k].form in (FORM_GATHER, FORM_PASSTHROUGH)]
+        pooled = [k for k in plain if spec.columns[k].form == FORM_SEGMENT_REDUCE]
+        step = max(1, len(dense) // max_columns)
+        dense, pooled = dense[::step][:max_columns], pooled[::max(1, len(pooled) // 8)][:8]
+        n_checked = 0
+        for (blob, offsets, shapes), r, keep in zip(self.packed, self.requests, self._keep[1::4]):
+            out = op(keep, offsets, shapes, self.tables, r.symbols)
+            torch.cuda.synchronize()
+            groups = [g.cpu().numpy() for g in out.groups]
+            for k in dense + pooled:
+                c = spec.columns[k]
+                got = groups[c.concat_group][:, offs[k]:offs[k] + c.dim]
+                raw = np.asarray(r.inputs[c.ids_input])
+                if c.form == FORM_PASSTHROUGH:
+                    ok = np.array_equal(got, raw.reshape(got.shape))
+                else:
+                    ids = raw.reshape(-1)
+                    if c.id_source == IDS_F32_BUCKETIZE:
+                        b = np.asarray(c.boundaries, np.float32)
+                        ids = np.where(np.isnan(ids), b.size, np.searchsorted(b, ids, side="right")).astype(np.int64)
+                    seed = self.model.tables[c.table_input].seed
+                    valid = (ids >= 0) & (ids < c.vocab)
+                    if c.form == FORM_GATHER:
+                        want = np.where(valid[:, None], synth.hash_rows(seed, np.where(valid, ids, 0), c.dim), np.float32(0))
+                        ok = np.array_equal(got, want)
+                    else:
+                        seg = np.asarray(r.inputs[c.seg_input])
+                        if c.seg_kind == SEG_CSR_I32:
+                            csr = seg.reshape(-1).astype(np.int64)
+                        else:
+                            rows_of = seg.reshape(-1)[::max(1, c.seg_stride)][:ids.size]
+                            csr = np.searchsorted(rows_of, np.arange(got.shape[0] + 1), side="left")
+                        ok = True
+                        for b_ in range(min(pooled_rows, got.shape[0])):
+                            acc = np.zeros(c.dim, np.float32)
+                            sel = ids[csr[b_]:csr[b_ + 1]]
+                            for v in sel[(sel >= 0) & (sel < c.vocab)]:
+                                acc = acc + synth.hash_rows(seed, np.asarray([v]), c.dim)[0]        # fp32, id order
+                            if c.combiner == COMBINER_MEAN and sel.size:
+                                acc = acc / np.float32(sel.size)
+                            ok = ok and np.array_equal(got[b_], acc)
+                if not ok:
+                    raise RuntimeError(f"resident request check failed: column {k} (form {c.form}) differs from the closed-form tables")
+                n_checked += 1
+        return {"checked": n_checked, "requests": len(self.requests), "one_hot_columns": len(dense), "pooled_columns": len(pooled),
+                "note": "each resident request served once and compared with closed-form table rows (exact) before the warm-up"}
+
     def algorithmic_bytes(self) -> dict:
         """Mean algorithmic bytes per request over the resident requests."""
         acc = None
