@@ -598,3 +598,98 @@ def resource_variable_model(B=21, seed=0):
     g.node("input_layer/concat", "ConcatV2", ins + ["concat/axis"], N=len(ins), T=("type", P.DT_FLOAT), Tidx=("type", P.DT_INT32))
     g.node("output", "Identity", ["input_layer/concat"], T=("type", P.DT_FLOAT))
     return g.gd, feeds, variables, ["output"]
+
+
+def random_sparse_reshape_model(seed):
+    """One to four pooled columns whose SparseTensor passes through a SparseReshape with RANDOM shapes: input rank 1-4,
+    output rank 1-3 (any factorisation of the element count), the input shape a constant or fed, every output dimension
+    a constant, a copy of an input dimension (StridedSlice of the fed shape), a Prod over leading dimensions, or -1, or
+    the whole new_shape fed.  Whatever the plan builders make of each — identity, segment-id map with or without a
+    run-time factor, or "stays in TensorFlow" — the rewritten graph must equal the original.
+    Returns (graph_def, feeds, variables, fetches)."""
+    rng = np.random.default_rng(7000 + seed)
+    g = GB()
+    feeds, variables, outs = {}, {}, []
+    for ci in range(int(rng.integers(1, 5))):
+        name = f"c{ci}"
+        r = int(rng.integers(1, 5))
+        ishape = [int(rng.integers(1, 7)) for _ in range(r)]
+        ishape[0] = int(rng.integers(1, 12))
+        total = int(np.prod(ishape))
+        # a random factorisation of `total` into q output dims
+        q = int(rng.integers(1, 4))
+        oshape, rest = [], total
+        for _ in range(q - 1):
+            divs = [d for d in range(1, rest + 1) if rest % d == 0]
+            d = int(rng.choice(divs))
+            oshape.append(d)
+            rest //= d
+        oshape.append(rest)
+        rng.shuffle(oshape)
+        oshape = [int(d) for d in oshape]
+        nnz = int(rng.integers(0, min(total, 40) + 1))
+        flat = np.sort(rng.choice(total, size=nnz, replace=False))
+        idx = np.stack(np.unravel_index(flat, ishape), 1).astype(np.int64).reshape(nnz, r)
+        vocab, dim = int(rng.integers(5, 60)), int(rng.choice([4, 8, 12]))
+        t = g.variable(f"input_layer/{name}_embedding/embedding_weights", vocab, dim)
+        variables[t] = rng.standard_normal((vocab, dim)).astype(np.float32)
+        g.placeholder(f"{name}/values", np.int64, [-1])
+        g.placeholder(f"{name}/indices", np.int64, [-1, r])
+        feeds[f"{name}/values"] = rng.integers(0, vocab, size=nnz).astype(np.int64)
+        feeds[f"{name}/indices"] = idx
+        one = lambda s_, v: g.const(f"{name}/{s_}", np.asarray([v], np.int32))
+        fed_shape = rng.random() < 0.6
+        if fed_shape:
+            g.placeholder(f"{name}/dense_shape", np.int64, [r])
+            feeds[f"{name}/dense_shape"] = np.asarray(ishape, np.int64)
+        else:
+            g.const(f"{name}/dense_shape", np.asarray(ishape, np.int64))
+        kind = str(rng.choice(["const", "fed", "pack", "pack", "pack"]))
+        if kind == "const":
+            ns = list(oshape)
+            if rng.random() < 0.3:
+                ns[int(rng.integers(0, q))] = -1                      # inferred at run time
+            g.const(f"{name}/new_shape", np.asarray(ns, np.int64))
+        elif kind == "fed":
+            g.placeholder(f"{name}/new_shape", np.int64, [q])
+            feeds[f"{name}/new_shape"] = np.asarray(oshape, np.int64)
+        else:
+            parts = []
+            for k, d in enumerate(oshape):
+                same = [j for j in range(r) if ishape[j] == d]
+                pick = rng.random()
+                if same and pick < 0.5:                               # a copy of an input dimension
+                    j = int(rng.choice(same))
+                    parts.append(g.node(f"{name}/o{k}", "StridedSlice", [f"{name}/dense_shape", one(f"o{k}b", j), one(f"o{k}e", j + 1),
+                                                                          one(f"o{k}s", 1)],
+                                        T=("type", P.DT_INT64), Index=("type", P.DT_INT32), shrink_axis_mask=1))
+                elif k == 0 and pick < 0.8 and r >= 2 and int(np.prod(ishape[:r - 1])) == d:   # Prod over the leading dims
+                    g.node(f"{name}/lead", "StridedSlice", [f"{name}/dense_shape", one("lb", 0), one("le", r - 1), one("ls", 1)],
+                           T=("type", P.DT_INT64), Index=("type", P.DT_INT32))
+                    g.const(f"{name}/axis0", np.asarray([0], np.int32))
+                    g.node(f"{name}/prod", "Prod", [f"{name}/lead", f"{name}/axis0"], T=("type", P.DT_INT64), Tidx=("type", P.DT_INT32))
+                    parts.append(g.node(f"{name}/o{k}", "Squeeze", [f"{name}/prod"], T=("type", P.DT_INT64)))
+                else:
+                    parts.append(g.const(f"{name}/o{k}", np.asarray(d, np.int64)))
+            g.node(f"{name}/new_shape", "Pack", parts, N=q, T=("type", P.DT_INT64), axis=0)
+        g.node(f"{name}/SparseReshape", "SparseReshape", [f"{name}/indices", f"{name}/dense_shape", f"{name}/new_shape"])
+        if q >= 2:
+            seg = g.slice_col0(f"{name}/added_strided_slice", f"{name}/SparseReshape", shrink=bool(rng.integers(0, 2)))
+        else:                                                         # [nnz, 1]: the lookup optimizer's Squeeze / Reshape form
+            g.const(f"{name}/flat", np.asarray([-1], np.int32))
+            seg = g.node(f"{name}/seg", "Reshape", [f"{name}/SparseReshape", f"{name}/flat"], T=("type", P.DT_INT64), Tshape=("type", P.DT_INT32))
+        g.node(f"{name}/num_segments", "StridedSlice", [f"{name}/SparseReshape:1", one("nb", 0), one("ne", 1), one("ns", 1)],
+               T=("type", P.DT_INT64), Index=("type", P.DT_INT32), shrink_axis_mask=1)
+        op = "SparseSegmentMeanWithNumSegments" if rng.random() < 0.5 else "SparseSegmentSumWithNumSegments"
+        pooled = g.node(f"{name}/{op}", op, [t, f"{name}/values", seg, f"{name}/num_segments"], T=("type", P.DT_FLOAT),
+                        Tidx=("type", P.DT_INT64), Tsegmentids=("type", P.DT_INT64), Tnumsegments=("type", P.DT_INT64))
+        d_ = g.variable(f"input_layer/{name}_dense_embedding/embedding_weights", 20, 4)
+        variables[d_] = rng.standard_normal((20, 4)).astype(np.float32)
+        g.placeholder(f"{name}/dense_ids", np.int64, [-1])
+        feeds[f"{name}/dense_ids"] = rng.integers(0, 20, size=oshape[0]).astype(np.int64)
+        dense = g.gather(f"input_layer/{name}_dense_embedding/GatherDense", d_, f"{name}/dense_ids", np.int64)
+        g.const(f"{name}/concat/axis", np.asarray(1, np.int32))
+        g.node(f"{name}_layer/concat", "ConcatV2", [pooled, dense, f"{name}/concat/axis"], N=2, T=("type", P.DT_FLOAT),
+               Tidx=("type", P.DT_INT32))
+        outs.append(g.node(f"output_{name}", "Identity", [f"{name}_layer/concat"], T=("type", P.DT_FLOAT)))
+    return g.gd, feeds, variables, outs

@@ -1554,3 +1554,14 @@ def test_concat_outputs_host_from_many_threads_and_without_an_allocator(torch_cu
         assert (rc == 0) == ok
         if ok:
             assert np.array_equal(out.cpu().numpy(), payload)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(16))
+def test_random_sparse_reshape_graphs_to_hip_path(torch_cuda, tmp_path, seed):
+    """GraphDef -> plan -> HIP for random SparseReshapes (identity, constant and run-time segment-id maps, ops left to
+    TensorFlow; tests/graph_fixtures.py::random_sparse_reshape_model): the rewritten graph with the HIP path behind its
+    ops equals the original graph bit for bit."""
+    from graph_fixtures import random_sparse_reshape_model
+    gd, feeds, variables, fetches = random_sparse_reshape_model(seed)
+    _graph_through_hip(torch_cuda, gd, feeds, variables, fetches, tmp_path)

@@ -557,3 +557,27 @@ def test_native_plan_builder_errors(tmp_path):
         native_build(gd.SerializeToString(), str(tmp_path / "no" / "such" / "dir" / "z.fcp"))
     graph, _ = native_build(gd.SerializeToString(), str(tmp_path / "k.fcp"), prune=False)
     assert len(parse_graphdef(graph).node) > len(gd.node)          # nothing pruned: the original nodes + the new ones
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_random_sparse_reshapes_through_both_builders(oracle, tmp_path, seed):
+    """The segment-id maps of random SparseReshapes (cuda_emitter.cc:1874-1916): whatever each reshape becomes — the
+    identity, a map with constant factors, one with a run-time factor, or an op left to TensorFlow — the rewritten graph
+    (C oracle behind the ops) equals the original graph evaluated op by op (NumPy ravel / unravel), and the C++ builder
+    writes the same plan file and graph as the Python one."""
+    from graph_fixtures import random_sparse_reshape_model
+    from recom_amd.graph import native_build
+    from tf_graph_eval import GraphEvaluator
+    gd, feeds, variables, fetches = random_sparse_reshape_model(seed)
+    expected = GraphEvaluator(gd, variables).run(fetches, feeds)
+    built = build_plan(gd)
+    assert not built.skipped
+    path, cpath = str(tmp_path / "m.fcp"), str(tmp_path / "c.fcp")
+    save_plan(built.spec, path)
+    out = parse_graphdef(rewrite_graph(gd, built, path).SerializeToString())
+    got = GraphEvaluator(out, variables, oracle_ops(oracle, built, variables)).run(fetches, feeds)
+    for e, o in zip(expected, got):
+        assert e.shape == o.shape and np.array_equal(e, o)
+    c_graph, _ = native_build(gd.SerializeToString(), cpath)
+    assert open(cpath).read() == open(path).read()
+    assert parse_graphdef(c_graph) == rewrite_graph(gd, built, cpath)
