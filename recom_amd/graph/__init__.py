@@ -24,10 +24,10 @@ def native_build(graph_def_bytes: bytes, plan_path: str, host_concat: str = "pas
                            C.byref(out) if want_graph else None, C.byref(n), C.byref(desc))
     try:
         if rc == _lib.FCP_ERR_UNSUPPORTED:
-            raise Unsupported(L.fcp_last_error().decode())
+            raise Unsupported(L.fcp_last_error().decode(errors="replace"))
         _lib.check(rc, "fcp_graph_build")
         graph = C.string_at(out.value, n.value) if want_graph and out.value else None
-        text = C.cast(desc, C.c_char_p).value.decode() if desc else ""
+        text = C.cast(desc, C.c_char_p).value.decode(errors="replace") if desc else ""
         return graph, text
     finally:
         if out.value:

@@ -250,5 +250,5 @@ def load() -> C.CDLL:
 def check(status: int, what: str) -> None:
     if status != FCP_OK:
         L = load()
-        detail = L.fcp_last_error().decode() or L.fcp_status_string(status).decode()
+        detail = L.fcp_last_error().decode(errors="replace") or L.fcp_status_string(status).decode()
         raise FcpError(status, what, detail)

@@ -581,3 +581,68 @@ def test_random_sparse_reshapes_through_both_builders(oracle, tmp_path, seed):
     c_graph, _ = native_build(gd.SerializeToString(), cpath)
     assert open(cpath).read() == open(path).read()
     assert parse_graphdef(c_graph) == rewrite_graph(gd, built, cpath)
+
+
+def test_native_builder_and_plan_parser_survive_mutated_inputs(tmp_path):
+    """The GraphDef wire reader of fcp_graph.cc and the plan-file parser of the library are hand-written: byte-level
+    mutations of valid inputs (flips, truncations, spliced garbage, huge varints) must end in a status code or a valid
+    result, never in a crash or a hang — `scripts/asan_host.sh` runs this under ASan + UBSan."""
+    import ctypes as C
+    from recom_amd import lib as _lib
+    from recom_amd.graph import native_build
+    from recom_amd.lib import FcpError
+    rng = np.random.default_rng(0)
+    L = _lib.load()
+    seeds = [canonical_model(B=7, seed=1)[0], sparse_reshape_model(B=5, seed=2)[0], id_filter_model(B=6, seed=3)[0]]
+    ok = bad = 0
+    for gd in seeds:
+        data = bytearray(gd.SerializeToString())
+        for it in range(150):
+            m = bytearray(data)
+            kind = it % 5
+            if kind == 0:
+                for _ in range(int(rng.integers(1, 4))):
+                    m[int(rng.integers(0, len(m)))] ^= 1 << int(rng.integers(0, 8))
+            elif kind == 1:
+                m = m[:int(rng.integers(0, len(m)))]
+            elif kind == 2:
+                p = int(rng.integers(0, len(m)))
+                m[p:p] = bytes(rng.integers(0, 256, int(rng.integers(1, 12)), dtype=np.uint8))
+            elif kind == 3:
+                p = int(rng.integers(0, len(m)))
+                m[p:p + 1] = b"\xff\xff\xff\xff\xff\xff\xff\xff\xff\x01"     # a 10-byte varint where a byte was
+            else:
+                a, b = sorted(int(v) for v in rng.integers(0, len(m), 2))
+                del m[a:b]
+            try:
+                native_build(bytes(m), str(tmp_path / "m.fcp"), staged=bool(it & 1))
+                ok += 1
+            except (FcpError, Unsupported):
+                bad += 1
+    assert ok + bad == 450 and bad > 50
+    # plan files: the same treatment for fcp_plan_create_from_file / fcp_plan_file_stage_info (host-only: no device)
+    built = build_plan(seeds[1])
+    spec, stage = built.spec.staged_for_concat_inputs()
+    path = str(tmp_path / "p.fcp")
+    save_plan(spec, path, stage)
+    text = open(path).read()
+    toks = text.split()
+    for it in range(300):
+        t = list(toks)
+        kind = it % 4
+        if kind == 0:
+            t[int(rng.integers(0, len(t)))] = str(int(rng.choice([-1, 0, 1 << 31, 1 << 40, -(1 << 40), 99999999])))
+        elif kind == 1:
+            t = t[:int(rng.integers(0, len(t)))]
+        elif kind == 2:
+            t.insert(int(rng.integers(0, len(t))), str(rng.choice(["stage", "segmaps", "x", "1e400", "nan", "-"])))
+        else:
+            del t[int(rng.integers(0, len(t)))]
+        with open(path, "w") as f:
+            f.write(" ".join(t) + "\n")
+        h = C.c_void_p()
+        rc = L.fcp_plan_create_from_file(path.encode(), 0, _lib.FLAG_HOST_ONLY, C.byref(h))
+        if rc == 0:
+            L.fcp_plan_destroy(h)
+        n = C.c_int32()
+        L.fcp_plan_file_stage_info(path.encode(), C.byref(n), None, None, 0, None)
