@@ -918,6 +918,11 @@ __device__ __forceinline__ void ragged_body(const FcpLaunch &L, int bid, char *s
 #if defined(FCP_STAMPS)
   const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
 #endif
+  // The front of a block (records -> CSR ranges -> ids) is a chain of dependent round trips with a handful of
+  // instructions between them; issued at a higher wave priority those instructions do not queue behind the long
+  // walk loops of the CU's other waves (back to 0 before the walk): RAGGED -0.35 us, batch 1024 -0.5 us
+  // (profiles/r03_ragged_front_priority_ab.txt).  The dense body showed no difference.
+  __builtin_amdgcn_s_setprio(3);
   const Hot H = load_hot(L);
   if (!locate_block<RB>(L, H, bid, B)) return;
   const int tid = threadIdx.x;
@@ -1037,6 +1042,7 @@ __device__ __forceinline__ void ragged_body(const FcpLaunch &L, int bid, char *s
   const unsigned long long t_ids = __builtin_amdgcn_s_memrealtime();
 #endif
 
+  __builtin_amdgcn_s_setprio(0);
   // ---- phase 2 (wave): the owning lanes consume their column's slice ------------------------------------------
   // (a slot's column facts are re-read from LDS where they are used: few registers live across the staging)
   auto consume = [&](auto walk_width, const uint32_t *s, int n) __attribute__((always_inline)) {
