@@ -741,6 +741,9 @@ __global__ void __launch_bounds__(FCP_BLOCK_THREADS) fcp_dense_kernel(const FcpL
 #if !defined(FCP_WALK)
 #define FCP_WALK 8
 #endif
+#if !defined(FCP_WALK_FIRST) // widest first batch of a bag walk (10: 64 VGPRs, the most that keeps 8 waves per SIMD without scratch)
+#define FCP_WALK_FIRST 10
+#endif
 #if !defined(FCP_WALK_LONG) // the same in the rounds after the first (rows whose bags exceed the wave's tile)
 #define FCP_WALK_LONG 6 // (8 would need 66 VGPRs in the loop around the rounds)
 #endif
@@ -874,8 +877,21 @@ __device__ __forceinline__ void bag_walk_batch(const float *tb, const float *zer
 
 template <int V, int WALK>
 __device__ __forceinline__ void bag_walk_sum(const float *tb, const float *zeros, uint32_t spr, const uint32_t *s, int n, VF<V> &acc) {
-  bag_walk_batch<V, WALK>(tb, zeros, spr, s, 0, n, acc);
-  for (int base = WALK; __any(n > base);) { // wave-uniform trip count
+  // The first batch is as wide as the wave's longest bag needs, up to FCP_WALK_FIRST reads per lane: every bag of
+  // the wave in ONE round of reads whenever none is longer than that (BASELINE's RAGGED and the reference's models
+  // E / F draw 0..10 / 1..10 ids per row: with 8-wide batches nearly every wave ran a second round for its one or two
+  // 9- and 10-id bags; RAGGED 30.2 -> 28.9 us, profiles/r03_ragged_walk_width_ab.txt).  Wave-uniform choices.
+  int base = WALK;
+  if (WALK >= 8 && !__any(n > 4)) {
+    bag_walk_batch<V, 4>(tb, zeros, spr, s, 0, n, acc);
+    return;
+  } else if (WALK >= 8 && FCP_WALK_FIRST > WALK && __any(n > WALK)) {
+    bag_walk_batch<V, FCP_WALK_FIRST>(tb, zeros, spr, s, 0, n, acc);
+    base = FCP_WALK_FIRST;
+  } else {
+    bag_walk_batch<V, WALK>(tb, zeros, spr, s, 0, n, acc);
+  }
+  for (; __any(n > base);) { // wave-uniform trip count
     if (WALK > 4 && !__any(n > base + 4)) { // a short tail (bags of 9..12 ids): half a batch
       bag_walk_batch<V, 4>(tb, zeros, spr, s, base, n, acc);
       base += 4;
