@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -997,12 +998,25 @@ int install_slot(fcp_plan *p, const fcp_process_args_t *a, DynSlot &s) {
     }
     if (!p->host_writes_dyn && hipEventQuery(s.uploaded) != hipSuccess) HIP_TRY(hipEventSynchronize(s.uploaded));
   }
+  static const bool stats = std::getenv("FCP_INSTALL_STATS") != nullptr; // diagnostic: where a descriptor installation spends its host time
+  auto now_ns = [] { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const uint64_t t0 = stats ? now_ns() : 0;
   int rc = compute_dyn(p, a->concated_offsets, a->concated_shapes, a->symbols, a->concated_bytes, s.h_dyn, &s.meta);
   if (rc) return rc;
+  const uint64_t t1 = stats ? now_ns() : 0;
   const size_t dyn_bytes = p->cols.size() * sizeof(FcpColDyn);
   if (p->host_writes_dyn) {
     std::memcpy(s.d_dyn, s.h_dyn, dyn_bytes); // CPU stores through the BAR into fine-grained VRAM
     __builtin_ia32_sfence();                  // posted before the launch's doorbell write
+    if (stats) {
+      static std::atomic<uint64_t> n{0}, ns_dyn{0}, ns_bar{0};
+      const uint64_t t2 = now_ns();
+      ns_dyn += t1 - t0;
+      ns_bar += t2 - t1;
+      if ((++n & 1023) == 0)
+        std::fprintf(stderr, "fcp install: %llu installs, shapes -> records %.2f us, records -> device (%zu bytes through the BAR) %.2f us\n",
+                     (unsigned long long)n.load(), ns_dyn.load() / 1e3 / n.load(), dyn_bytes, ns_bar.load() / 1e3 / n.load());
+    }
   } else {
     const int e = fcp_launch_upload(s.h_dyn_dev, s.d_dyn, dyn_bytes, stream);
     if (e) return hip_fail("descriptor upload launch", (hipError_t)e);

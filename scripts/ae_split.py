@@ -23,6 +23,8 @@ def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "e"
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
     m = synth.model_ae(which.upper())
+    if os.environ.get("AE_STAGED", "1") != "0":          # the form the rewritten graph's ConcatInputs leaves (the bench default)
+        m = synth.staged_model(m)
     dense = [k for k, c in enumerate(m.spec.columns) if c.form in (1, 4)]
     ragged = [k for k, c in enumerate(m.spec.columns) if c.form not in (1, 4)]
     small = [k for k in ragged if m.spec.columns[k].vocab < (1 << 20)]
