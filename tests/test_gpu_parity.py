@@ -1565,3 +1565,26 @@ def test_random_sparse_reshape_graphs_to_hip_path(torch_cuda, tmp_path, seed):
     from graph_fixtures import random_sparse_reshape_model
     gd, feeds, variables, fetches = random_sparse_reshape_model(seed)
     _graph_through_hip(torch_cuda, gd, feeds, variables, fetches, tmp_path)
+
+
+@pytest.mark.gpu
+def test_bench_refuses_to_time_wrong_results(torch_cuda):
+    """bench.py serves every resident request once and compares it with the closed-form tables before the warm-up
+    (ServingHarness.verify_resident, no oracle): correct kernels pass on one-hot and pooled columns alike, and one
+    flipped table value is caught."""
+    from recom_amd import synth
+    from recom_amd.harness import ServingHarness
+    torch = torch_cuda
+    for model in (synth.model_s1(columns=40, dim=12, vocab=500, batch=64),
+                  synth.staged_model(synth.model_ragged(columns=24, vocab=400, batch=48, seg="indices"))):
+        h = ServingHarness(model, n_requests=4)
+        got = h.verify_resident()
+        assert got["checked"] > 0
+        h.close()
+        tables = model.torch_tables(torch.device("cuda", 0))
+        for t in tables:
+            t += 0.25                                       # every row differs from the closed form now
+        h = ServingHarness(model, n_requests=4, tables=tables)
+        with pytest.raises(RuntimeError, match="closed-form"):
+            h.verify_resident()
+        h.close()
