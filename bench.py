@@ -456,6 +456,28 @@ def main():
         overlap = {"serve_workers": best, **sweep[best],
                    "sweep_us_per_request": {str(k): v["us_per_request"] for k, v in sweep.items()},
                    "env": {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")}}
+    # The same overlap behind ONE caller stream and ONE host thread — what the TensorFlow op has: the plan's private
+    # streams (fcp_plan_set_private_streams), the consumer of each request (fcp_result_wait + a reader kernel on the
+    # caller's stream, standing for Addons>ConcatOutputs) enqueued `lanes - 1` requests behind it.  Extra field only.
+    single_caller = None
+    if args.threads == 1 and not dist and not args.no_overlap:
+        sweep = {}
+        for lanes in (2, 3, 4):
+            hp = ServingHarness(model, device=local_rank, n_requests=args.requests, arena_ring=6, n_threads=1,
+                                tables=h.tables, seed0=1000 * rank)
+            hp.plan.set_private_streams(lanes)
+            sc_warm, sc_steps = max(args.warmup, 100), max(args.steps, 1200)
+            hp.run_private(sc_warm, lanes)
+            w_ms, d_ms = hp.run_private(sc_steps, lanes)
+            sweep[lanes] = {"requests": sc_steps, "warmup": sc_warm, "us_per_request": w_ms * 1e3 / sc_steps,
+                            "device_us_per_request": d_ms * 1e3 / sc_steps}
+            hp.close()
+        best = min(sweep, key=lambda k: sweep[k]["us_per_request"])
+        single_caller = {"what": "one host thread, one caller stream (the TF op's situation): requests run on the plan's private "
+                                 "streams, the consumer of request k (fcp_result_wait + a reader kernel on the caller's stream) is "
+                                 "enqueued `private_streams - 1` requests later; host wall clock over the loop incl. the final sync",
+                         "private_streams": best, **sweep[best],
+                         "sweep_us_per_request": {str(k): v["us_per_request"] for k, v in sweep.items()}}
     batch = model.batch
     steps_total = args.steps * args.threads
     ms_per_step = elapsed * 1e3 / steps_total
@@ -505,6 +527,10 @@ def main():
                                      "examples/cc/recom_examples.patch:193-225 - is overlapped_serving.inferences_per_s "
                                      f"({overlap['inferences_per_s'] / 1e6:.1f} M with {overlap['serve_workers']} workers), next to the single-request "
                                      "p50 above")
+        if single_caller:
+            single_caller["inferences_per_s"] = batch / (single_caller["us_per_request"] * 1e-6)
+            single_caller["frac_of_peak"] = bytes_alg["total"] / (single_caller["us_per_request"] * 1e-6) / 1e9 / HBM_PEAK_GBS
+            rec["single_caller_stream"] = single_caller
         if args.staged and "FCP_LIB_DIR" not in os.environ:
             rec["staging"] = host_staging_cost(raw_model)
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only

@@ -410,6 +410,55 @@ int fcp_process_feature_columns(fcp_plan_t *plan,
                                 const fcp_process_args_t *args,
                                 fcp_process_result_t *result);
 
+/* ---- plan-owned private streams: overlap behind ONE caller stream ---------- */
+/* TensorFlow hands a GPU op exactly one compute stream
+ * (feature_column_process_op_gpu.cu.cc:65-131 takes it from the op context; the
+ * serve workers of the reference harness share one Session and therefore that one
+ * stream, examples/cc/recom_examples.patch:193-216).  On one stream every request
+ * pays its own kernel boundary, dependent front and drain; requests on
+ * neighbouring streams hide them (S2, batch 512: ~28.5 us alone, ~23 us
+ * overlapped).  fcp_plan_set_private_streams(plan, n, flags) gives the plan n
+ * streams of its own (0 = off, the default; at most 16).  From then on
+ * fcp_process_feature_columns
+ *   - records an event on args->stream (everything enqueued there so far: the
+ *     producer of the blob, earlier users of the memory malloc_buff hands out —
+ *     TF's allocator reuses memory in compute-stream order),
+ *   - runs the request on the next private stream (round robin), which first
+ *     waits for that event,
+ *   - files the request's completion event under the address range of its arena
+ *     (fcp_process_result_t::buffer, buffer_bytes).
+ * args->stream itself does NOT wait for the kernels.  Whoever reads the arena —
+ * Addons>ConcatOutputs in the rewritten graph, whose `tensor_buffers` inputs keep
+ * blob, tables and arena alive until then (cuda_emitter.cc:2632-2643) — calls
+ * fcp_result_wait(pointer into the arena, its stream) before it enqueues the
+ * reader: a device-side wait, the host never blocks.  fcp_result_synchronize is
+ * the same for a host reader.  Both return FCP_OK at once when nothing is pending
+ * for that address (private streams off, or the request long complete).
+ * fcp_concat_outputs_host performs the wait itself for its `out` pointer.
+ *
+ * FCP_PRIVATE_NO_CALLER_WAIT: the private stream does not wait for args->stream.
+ * Only for callers that guarantee by other means that the blob is complete and
+ * that nothing still enqueued on their stream touches the arena memory (a
+ * harness with its own arena ring); never under TensorFlow's allocator.
+ * Requests issued while args->stream is being captured into a HIP graph stay on
+ * args->stream.  Call it while no request of the plan is in flight (normally
+ * right after plan creation); changing the count synchronises the old streams.
+ * The sharded step (fcp_shard_step_run) always runs on args->stream.
+ *
+ * Which requests take a private stream: the cross-stream events cost the host
+ * about 8 us per request, so a request only gains when its kernel is long enough
+ * to have something to overlap (S2 28 -> 24.5 us, RAGGED 27.8 -> 22 us per
+ * request; the reference's models E / F, 10 us kernels, LOSE: 10 -> 16 us).  The
+ * plan therefore keeps requests whose work — table rows gathered + output bytes
+ * of the shapes it installed last — is below 48 MiB on args->stream
+ * (FCP_PRIVATE_MIN_WORK_BYTES overrides); FCP_PRIVATE_ALWAYS sends every request
+ * to a private stream.  Three streams measured best (two: 27 us on S2; four or
+ * more: slower than one stream, profiles/r04_private_streams_sweep.txt). */
+enum { FCP_PRIVATE_NO_CALLER_WAIT = 1u << 0, FCP_PRIVATE_ALWAYS = 1u << 1 };
+int fcp_plan_set_private_streams(fcp_plan_t *plan, int32_t n_streams, uint32_t flags);
+int fcp_result_wait(const void *buffer, void *stream);
+int fcp_result_synchronize(const void *buffer);
+
 /* ---- ConcatOutputs (concat_outputs_op_gpu.cu.cc:85-140) ------------------ */
 /* out[p, off_k : off_k + dims[k]] = inputs[k][p*dims[k] ...] for k < n.
  * `inputs` is a HOST array of device pointers; the pointer table is passed to

@@ -24,6 +24,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <map>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <string>
@@ -58,7 +60,7 @@ int fail(int code, const std::string &msg) {
 
 inline int64_t align128(int64_t x) { return (x + 127) / 128 * 128; } // alignmem, cuda_emitter.cc:967-969
 
-constexpr int kSlots = 8;
+constexpr int kSlots = 32; // descriptor slots per plan: distinct (shapes, stream) pairs resident at once (8 until round 4: 16 rotating shapes reinstalled on every request)
 constexpr uint32_t kFlagHostOnly = FCP_FLAG_HOST_ONLY; // plan without device resources (layout queries)
 
 struct HostColumn {
@@ -86,6 +88,7 @@ struct DynMeta {
   int32_t max_seg_nnz = 0;
   int64_t seg_pairs = 0;   // sum of rows over the segment-id columns: cost of the in-block search
   bool seg_search = false; // this request: blocks search the segment ids (no pre-pass launch)
+  int64_t work_bytes = 0;  // table rows gathered + output written: what decides whether a private lane pays (fcp_plan_set_private_streams)
   // launch geometry per kernel kind: [0] dense kernel (spans whose columns all have exactly
   // one source row per output row), [1] ragged kernel (spans with pooled / scatter / reduction columns)
   struct Geo {
@@ -116,6 +119,46 @@ struct DynSlot {
   bool was_valid = false;        // reserved for installation: the previous content had readers to wait for
   DynMeta meta;
 };
+
+// One private stream of a plan (fcp_plan_set_private_streams).  A request that takes the lane holds `mu` while it
+// enqueues (record on the caller's stream, wait on the lane, kernels, record on the lane), so an event pair is never
+// interleaved between two host threads.  Events rotate: re-recording an event that an older consumer has not waited
+// for yet makes that consumer wait for LATER work of the same lane, which covers the older request (same stream).
+constexpr int kLaneEvents = 8;
+struct PrivateLane {
+  hipStream_t stream = nullptr;
+  std::mutex mu;
+  hipEvent_t in[kLaneEvents] = {};  // recorded on the caller's stream: everything the request may depend on
+  hipEvent_t out[kLaneEvents] = {}; // recorded on the lane behind the request's last kernel
+  uint32_t next = 0;
+};
+
+// Results whose kernels run on a private lane, by arena address range: what fcp_result_wait looks up.  An entry is
+// replaced when its address range is handed out again and dropped once its event has completed (nothing to wait for).
+struct PendingResult {
+  uintptr_t end;
+  hipEvent_t done;
+  const void *owner; // the plan whose lane owns `done`
+};
+std::mutex g_pending_mu;
+std::map<uintptr_t, PendingResult> g_pending;
+
+void pending_register(const void *owner, void *arena, int64_t bytes, hipEvent_t done) {
+  const uintptr_t b = reinterpret_cast<uintptr_t>(arena), e = b + (uintptr_t)std::max<int64_t>(bytes, 1);
+  std::lock_guard<std::mutex> lock(g_pending_mu);
+  auto it = g_pending.lower_bound(b);
+  if (it != g_pending.begin() && std::prev(it)->second.end > b) --it;
+  while (it != g_pending.end() && it->first < e) it = g_pending.erase(it); // every older result that overlaps this range
+  g_pending[b] = PendingResult{e, done, owner};
+  if (g_pending.size() > 256) // ranges that are never handed out again: drop what has completed
+    for (auto j = g_pending.begin(); j != g_pending.end();)
+      j = (j->first != b && hipEventQuery(j->second.done) == hipSuccess) ? g_pending.erase(j) : std::next(j);
+}
+
+void pending_forget(const void *owner) {
+  std::lock_guard<std::mutex> lock(g_pending_mu);
+  for (auto j = g_pending.begin(); j != g_pending.end();) j = j->second.owner == owner ? g_pending.erase(j) : std::next(j);
+}
 
 } // namespace
 
@@ -176,6 +219,17 @@ struct fcp_plan {
   std::mutex mu;
   DynSlot slots[kSlots];
   uint64_t tick = 0;
+
+  // Plan-owned private streams (fcp_plan_set_private_streams): requests of ONE caller stream run on a rotating set of
+  // lanes so that consecutive requests overlap on the GPU (the front of one launch under the memory phase of another).
+  std::vector<std::unique_ptr<PrivateLane>> lanes;
+  std::atomic<uint32_t> lane_rr{0};
+  uint32_t lane_flags = 0;
+  // The cross-stream events of a lane cost the host ~8 us per request and the GPU's command processor a few packets:
+  // a request pays for them only when its kernel is long enough to have something to overlap.  The plan remembers
+  // the work of the shapes it installed last (gathered rows + output bytes); lighter requests stay on the caller's stream.
+  std::atomic<int64_t> last_work_bytes{0};
+  int64_t lane_min_work = 0;
 };
 
 namespace {
@@ -552,6 +606,7 @@ int compute_dyn_fast(const fcp_plan *p, const int32_t *offsets, const int32_t *s
   }
   int32_t max_seg_nnz = 0;
   int64_t seg_pairs = 0;
+  int64_t gathered = 0; // floats
   for (int i = 0; i < nc; ++i) {
     const fcp_plan::FastCol &c = p->fast_cols[i];
     const int64_t rows = rows_of(c);
@@ -593,7 +648,9 @@ int compute_dyn_fast(const fcp_plan *p, const int32_t *offsets, const int32_t *s
         seg_pairs += rows;
       }
     }
+    gathered += (int64_t)d.nnz * c.dim;
   }
+  m->work_bytes = gathered * 4 + cursor;
   m->max_seg_nnz = max_seg_nnz;
   m->seg_pairs = seg_pairs;
   m->seg_search = p->seg_search && seg_pairs <= kSegSearchMaxPairs;
@@ -616,7 +673,13 @@ int compute_dyn(const fcp_plan *p, const int32_t *offsets, const int32_t *shapes
     const int rc = compute_dyn_fast(p, offsets, shapes, symbols, blob_bytes, dyn, m);
     if (rc >= 0) return rc;
   }
-  return compute_dyn_slow(p, offsets, shapes, symbols, blob_bytes, dyn, m);
+  const int rc = compute_dyn_slow(p, offsets, shapes, symbols, blob_bytes, dyn, m);
+  if (rc == FCP_OK) {
+    int64_t gathered = 0;
+    for (size_t i = 0; i < p->cols.size(); ++i) gathered += (int64_t)dyn[i].nnz * p->cols[p->order[i]].d.dim;
+    m->work_bytes = gathered * 4 + m->csr_arena_off;
+  }
+  return rc;
 }
 
 // Are the boundaries evenly spaced closely enough that floor((x - b0) * inv) + 1 names the right bucket
@@ -1003,6 +1066,7 @@ int install_slot(fcp_plan *p, const fcp_process_args_t *a, DynSlot &s) {
   const uint64_t t0 = stats ? now_ns() : 0;
   int rc = compute_dyn(p, a->concated_offsets, a->concated_shapes, a->symbols, a->concated_bytes, s.h_dyn, &s.meta);
   if (rc) return rc;
+  p->last_work_bytes.store(s.meta.work_bytes, std::memory_order_relaxed);
   const uint64_t t1 = stats ? now_ns() : 0;
   const size_t dyn_bytes = p->cols.size() * sizeof(FcpColDyn);
   if (p->host_writes_dyn) {
@@ -1631,6 +1695,14 @@ int fcp_plan_destroy(fcp_plan_t *p) {
     DeviceGuard guard;
     if (guard.enter(p->desc.device) == FCP_OK) {
       (void)hipDeviceSynchronize();
+      pending_forget(p);
+      for (auto &l : p->lanes) {
+        for (int i = 0; i < kLaneEvents; ++i) {
+          if (l->in[i]) (void)hipEventDestroy(l->in[i]);
+          if (l->out[i]) (void)hipEventDestroy(l->out[i]);
+        }
+        if (l->stream) (void)hipStreamDestroy(l->stream);
+      }
       destroy_device(p);
     }
   }
@@ -1674,13 +1746,16 @@ int fcp_plan_read_bad_ids(fcp_plan_t *p, void *stream, int64_t *count) {
   if (rc) return rc;
   unsigned long long v = 0;
   HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+  for (auto &l : p->lanes) HIP_TRY(hipStreamSynchronize(l->stream)); // requests of that stream may have run on a private lane
   HIP_TRY(hipMemcpy(&v, p->d_bad, sizeof(v), hipMemcpyDeviceToHost));
   *count = (int64_t)v;
   return FCP_OK;
 }
 
 // ---- ProcessFeatureColumns ------------------------------------------------------
-int fcp_process_feature_columns(fcp_plan_t *p, const fcp_process_args_t *a, fcp_process_result_t *r) {
+// The request on the stream it names (not part of the ABI: the sharded step calls it — its exchange follows on the same
+// stream — and fcp_process_feature_columns below after it has chosen a private lane).
+int fcp_internal_process(fcp_plan_t *p, const fcp_process_args_t *a, fcp_process_result_t *r) {
   if (!p || !a) return fail(FCP_ERR_INVALID_ARGUMENT, "null plan / args");
   if (p->host_only) return fail(FCP_ERR_NO_DEVICE, "host-only plan cannot run");
   if (!a->concated_offsets || !a->concated_shapes) {
@@ -1811,6 +1886,120 @@ int fcp_process_feature_columns(fcp_plan_t *p, const fcp_process_args_t *a, fcp_
   return FCP_OK;
 }
 
+// Plan-owned private streams.  TensorFlow gives a GPU op ONE compute stream (feature_column_process_op_gpu.cu.cc:65-131
+// takes it from the op context; the reference harness' serve workers share one Session, recom_examples.patch:193-216), so
+// behind the op surface consecutive requests serialise: every launch pays its own kernel boundary, its dependent front
+// and its drain (S2: ~28.5 us isolated against ~23 us when neighbours cover them).  With n lanes the request
+//   1. records an event on the CALLER's stream (everything enqueued there so far: the blob's producer, the previous user
+//      of the arena memory the allocator hands out — TF's allocator reuses memory in compute-stream order),
+//   2. runs on lane k = round robin, which waits for that event,
+//   3. records the lane's `out` event and files it under the arena's address range;
+// the consumer (Addons>ConcatOutputs, or any reader of the arena) calls fcp_result_wait(buffer, its stream) before it
+// enqueues work that reads the result.  Lifetime: blob, tables and arena are `tensor_buffers` inputs of ConcatOutputs in
+// the rewritten graph (cuda_emitter.cc:2632-2643), i.e. alive until the consumer has been enqueued behind that wait.
+int fcp_plan_set_private_streams(fcp_plan_t *p, int32_t n_streams, uint32_t flags) {
+  if (!p || n_streams < 0 || n_streams > 16) return fail(FCP_ERR_INVALID_ARGUMENT, "private streams: 0..16");
+  if (flags & ~(uint32_t)(FCP_PRIVATE_NO_CALLER_WAIT | FCP_PRIVATE_ALWAYS)) return fail(FCP_ERR_INVALID_ARGUMENT, "unknown private-stream flags");
+  if (p->host_only) return fail(FCP_ERR_NO_DEVICE, "host-only plan");
+  DeviceGuard guard;
+  int rc = guard.enter(p->desc.device);
+  if (rc) return rc;
+  std::lock_guard<std::mutex> lock(p->mu);
+  for (auto &l : p->lanes) HIP_TRY(hipStreamSynchronize(l->stream)); // results of the old lanes are complete from here on
+  pending_forget(p);
+  for (auto &l : p->lanes) {
+    for (int i = 0; i < kLaneEvents; ++i) {
+      if (l->in[i]) (void)hipEventDestroy(l->in[i]);
+      if (l->out[i]) (void)hipEventDestroy(l->out[i]);
+    }
+    (void)hipStreamDestroy(l->stream);
+  }
+  p->lanes.clear();
+  p->lane_flags = flags;
+  {
+    const char *e = std::getenv("FCP_PRIVATE_MIN_WORK_BYTES"); // tuning aid
+    p->lane_min_work = (flags & FCP_PRIVATE_ALWAYS) ? 0 : (e ? std::atoll(e) : (int64_t)48 << 20);
+  }
+  for (int k = 0; k < n_streams; ++k) {
+    std::unique_ptr<PrivateLane> l(new PrivateLane());
+    HIP_TRY(hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking));
+    p->lanes.push_back(std::move(l)); // owned from here on: a failure below leaves lanes that plan destruction releases
+    PrivateLane &L = *p->lanes.back();
+    for (int i = 0; i < kLaneEvents; ++i) {
+      HIP_TRY(hipEventCreateWithFlags(&L.in[i], hipEventDisableTiming | hipEventDisableSystemFence));
+      HIP_TRY(hipEventCreateWithFlags(&L.out[i], hipEventDisableTiming | hipEventDisableSystemFence));
+    }
+  }
+  return FCP_OK;
+}
+
+int fcp_process_feature_columns(fcp_plan_t *p, const fcp_process_args_t *a, fcp_process_result_t *r) {
+  if (!p || !a) return fail(FCP_ERR_INVALID_ARGUMENT, "null plan / args");
+  if (p->lanes.empty() || p->last_work_bytes.load(std::memory_order_relaxed) < p->lane_min_work) return fcp_internal_process(p, a, r);
+  hipStream_t caller = static_cast<hipStream_t>(a->stream);
+  // a capture records the caller's stream only: the request stays there (cross-stream events would fork the capture)
+  if (stream_is_capturing(caller)) return fcp_internal_process(p, a, r);
+  DeviceGuard guard;
+  int rc = guard.enter(p->desc.device);
+  if (rc) return rc;
+  PrivateLane &L = *p->lanes[p->lane_rr.fetch_add(1, std::memory_order_relaxed) % p->lanes.size()];
+  std::lock_guard<std::mutex> lane_lock(L.mu);
+  const uint32_t e = L.next++ % kLaneEvents;
+  if (!(p->lane_flags & FCP_PRIVATE_NO_CALLER_WAIT)) {
+    HIP_TRY(hipEventRecord(L.in[e], caller));
+    HIP_TRY(hipStreamWaitEvent(L.stream, L.in[e], 0));
+  }
+  fcp_process_args_t b = *a;
+  b.stream = L.stream;
+  fcp_process_result_t local{};
+  if (!r) r = &local;
+  // the completion event rides on the dispatch packet of the request's last kernel (no marker packet of its own);
+  // a request without a kernel (nothing to compute) records it the plain way
+  static const bool attach = [] {
+    const char *v = std::getenv("FCP_LANE_STOP_EVENT"); // tuning aid: 0 = always record a marker
+    return !v || std::atoi(v) != 0;
+  }();
+  if (attach) fcp_set_stop_event(L.out[e]);
+  rc = fcp_internal_process(p, &b, r);
+  const bool pending = fcp_stop_event_pending();
+  fcp_set_stop_event(nullptr);
+  if (rc) return rc;
+  if (!attach || pending) HIP_TRY(hipEventRecord(L.out[e], L.stream));
+  pending_register(p, r->buffer, r->buffer_bytes, L.out[e]);
+  return FCP_OK;
+}
+
+// The consumer's half: `stream` waits (on the device; the host does not block) for the request whose arena contains
+// `buffer`.  Nothing pending for that address — no private streams, or the request has long completed — is FCP_OK.
+int fcp_result_wait(const void *buffer, void *stream) {
+  if (!buffer) return fail(FCP_ERR_INVALID_ARGUMENT, "null buffer");
+  const uintptr_t x = reinterpret_cast<uintptr_t>(buffer);
+  std::lock_guard<std::mutex> lock(g_pending_mu); // (held over the runtime call: the owning plan may not go away meanwhile)
+  auto it = g_pending.upper_bound(x);
+  if (it == g_pending.begin()) return FCP_OK;
+  --it;
+  if (x >= it->second.end) return FCP_OK;
+  HIP_TRY(hipStreamWaitEvent(static_cast<hipStream_t>(stream), it->second.done, 0));
+  return FCP_OK;
+}
+
+// The same for a HOST reader: returns when the request whose arena contains `buffer` has completed.
+int fcp_result_synchronize(const void *buffer) {
+  if (!buffer) return fail(FCP_ERR_INVALID_ARGUMENT, "null buffer");
+  const uintptr_t x = reinterpret_cast<uintptr_t>(buffer);
+  hipEvent_t ev = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(g_pending_mu);
+    auto it = g_pending.upper_bound(x);
+    if (it == g_pending.begin()) return FCP_OK;
+    --it;
+    if (x >= it->second.end) return FCP_OK;
+    ev = it->second.done;
+    HIP_TRY(hipEventSynchronize(ev));
+  }
+  return FCP_OK;
+}
+
 // ---- ConcatOutputs ----------------------------------------------------------------
 int fcp_concat_outputs(const void *const *inputs, const int32_t *dims, int32_t n, int64_t prefix_size,
                        void *out, void *stream) {
@@ -1823,6 +2012,9 @@ int fcp_concat_outputs(const void *const *inputs, const int32_t *dims, int32_t n
     width += dims[k];
   }
   if (width > 0x7fffffff) return fail(FCP_ERR_UNSUPPORTED, "concat width exceeds 2^31");
+  // per-column layout: the inputs are columns of ONE FeatureColumnProcess arena (output_ptrs); with private streams the
+  // kernel that fills it runs elsewhere
+  if (int rc = fcp_result_wait(inputs[0], stream)) return rc;
   const int e = fcp_launch_concat_outputs(inputs, dims, nullptr, nullptr, n, prefix_size, (int32_t)width, 0, out,
                                           static_cast<hipStream_t>(stream));
   if (e) return hip_fail("concat-outputs launch", (hipError_t)e);
@@ -1896,6 +2088,8 @@ int fcp_concat_outputs_host(const void *const *host_inputs, const int32_t *dims,
   rc = guard.enter(device);
   if (rc) return rc;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
+  rc = fcp_result_wait(out, stream_); // `out` lies in an arena whose lookup kernel may run on a private stream: write after it
+  if (rc) return rc;
   size_t total = 0;
   std::vector<size_t> at(n);
   for (int32_t k = 0; k < n; ++k) {

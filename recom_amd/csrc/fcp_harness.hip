@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 #include <vector>
@@ -190,6 +191,83 @@ int fcp_harness_run_graph(fcp_harness *h, int steps, int group, double *wall_ms,
   if (dev_ms) H_TRY(hipEventElapsedTime(dev_ms, h->e0, h->e1));
   (void)hipGraphExecDestroy(exec);
   (void)hipGraphDestroy(graph);
+  return FCP_OK;
+}
+
+// One host thread, ONE caller stream — what a TensorFlow op sees — over a plan with private streams
+// (fcp_plan_set_private_streams, set by the caller of this function): request k is issued on the caller's stream, its
+// kernels run on a plan-owned lane, and the consumer of request k - (depth - 1) — fcp_result_wait on the caller's stream
+// followed by a small kernel that READS the finished arena there, standing for Addons>ConcatOutputs and the layers
+// behind it — is enqueued right after it, so `depth` requests are in flight.  Timed like fcp_harness_run: events on the
+// caller's stream (which has waited for every result by the end) and the host clock around the loop.
+__global__ void fcp_consume_probe_kernel(const float *arena, size_t n_floats, float *sink) {
+  // first and last 256 floats of the result: a reader on the caller's stream, ordered behind the wait
+  float acc = 0.f;
+  const size_t i = threadIdx.x;
+  if (i < n_floats) acc += arena[i] + arena[n_floats - 1 - i];
+  if (acc == 12345.678f) *sink = acc;
+}
+
+int fcp_harness_run_private(fcp_harness *h, int steps, int depth, double *wall_ms, float *dev_ms) {
+  if (!h || steps < 1 || depth < 1 || depth > (int)h->rings[0].bufs.size()) return FCP_ERR_INVALID_ARGUMENT;
+  hipStream_t caller = h->streams[0];
+  static float *sink = nullptr;
+  if (!sink) H_TRY(hipMalloc(&sink, sizeof(float)));
+  const int nv = (int)h->variants.size();
+  std::vector<std::pair<void *, int64_t>> pending; // results not consumed yet, oldest first
+  size_t head = 0;
+  static const bool reader = [] { // tuning aid: FCP_HARNESS_NO_READER=1 leaves the wait alone on the caller's stream
+    const char *v = std::getenv("FCP_HARNESS_NO_READER");
+    return !(v && std::atoi(v) != 0);
+  }();
+  auto consume = [&](const std::pair<void *, int64_t> &res) -> int {
+    int rc = fcp_result_wait(res.first, caller);
+    if (rc || !reader) return rc;
+    hipLaunchKernelGGL(fcp_consume_probe_kernel, dim3(1), dim3(256), 0, caller, static_cast<const float *>(res.first),
+                       (size_t)(res.second / 4), sink);
+    return FCP_OK;
+  };
+  static const bool stats = std::getenv("FCP_HARNESS_STATS") != nullptr; // diagnostic: host time inside the two calls
+  double ns_process = 0, ns_consume = 0;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  const long begin = h->issued;
+  const auto t0 = std::chrono::steady_clock::now();
+  H_TRY(hipEventRecord(h->e0, caller));
+  for (long k = begin; k < begin + steps; ++k) {
+    fcp_process_args_t a = h->variants[(size_t)(k % nv)];
+    a.stream = caller;
+    a.malloc_buff = ring_alloc;
+    a.malloc_buff_ctx = &h->rings[0];
+    a.malloc_temp = nullptr;
+    a.malloc_temp_ctx = nullptr;
+    fcp_process_result_t res{};
+    const auto p0 = stats ? now() : t0;
+    int rc = fcp_process_feature_columns(h->plan, &a, &res);
+    if (rc) return rc;
+    const auto p1 = stats ? now() : t0;
+    pending.emplace_back(res.buffer, res.buffer_bytes);
+    if ((int)(pending.size() - head) >= depth) {
+      rc = consume(pending[head++]);
+      if (rc) return rc;
+    }
+    if (stats) {
+      ns_process += std::chrono::duration<double, std::nano>(p1 - p0).count();
+      ns_consume += std::chrono::duration<double, std::nano>(now() - p1).count();
+    }
+  }
+  if (stats)
+    std::fprintf(stderr, "fcp_harness_run_private: depth %d, host time per request: process call %.2f us, consumer (wait + reader) %.2f us\n",
+                 depth, ns_process / steps / 1e3, ns_consume / steps / 1e3);
+  while (head < pending.size()) {
+    const int rc = consume(pending[head++]);
+    if (rc) return rc;
+  }
+  H_TRY(hipEventRecord(h->e1, caller));
+  H_TRY(hipStreamSynchronize(caller));
+  const auto t1 = std::chrono::steady_clock::now();
+  h->issued += steps;
+  if (wall_ms) *wall_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+  if (dev_ms) H_TRY(hipEventElapsedTime(dev_ms, h->e0, h->e1));
   return FCP_OK;
 }
 

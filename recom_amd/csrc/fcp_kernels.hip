@@ -39,6 +39,7 @@
 #include <type_traits>
 
 #include "../../include/fcp_hip.h"
+#include <hip/hip_ext.h>
 #include "fcp_internal.h"
 
 namespace {
@@ -1444,19 +1445,35 @@ __global__ void __launch_bounds__(FCP_BLOCK_THREADS) fcp_upload_kernel(const uin
 
 // ------------------------------- launchers ---------------------------------
 
+// Private-stream requests (fcp_api.hip): the completion event of a request is attached to the dispatch packet of its
+// LAST kernel (hipExtLaunchKernelGGL's stop event) instead of being recorded as a marker packet of its own behind it.
+// Thread-local: set by the request path just before it enqueues, taken (and cleared) by the fused / hybrid launcher.
+static thread_local hipEvent_t tl_stop_event = nullptr;
+void fcp_set_stop_event(void *ev) { tl_stop_event = static_cast<hipEvent_t>(ev); }
+bool fcp_stop_event_pending() { return tl_stop_event != nullptr; }
+#define FCP_KLAUNCH(KERNEL, GRID, BLOCK, LDS, STREAM, ...)                                      \
+  do {                                                                                          \
+    hipEvent_t stop_ = tl_stop_event;                                                           \
+    tl_stop_event = nullptr;                                                                    \
+    if (stop_)                                                                                  \
+      hipExtLaunchKernelGGL(KERNEL, GRID, BLOCK, LDS, STREAM, nullptr, stop_, 0, __VA_ARGS__);  \
+    else                                                                                        \
+      hipLaunchKernelGGL(KERNEL, GRID, BLOCK, LDS, STREAM, __VA_ARGS__);                        \
+  } while (0)
+
 #define FCP_LAUNCH_DENSE(VV, RR)                                                                            \
   do {                                                                                                      \
     if (L.shard_world > 1)                                                                                  \
-      hipLaunchKernelGGL((fcp_dense_kernel<VV, RR, true>), dim3(grid_blocks), dim3(FCP_BLOCK_THREADS), lds_pad, s, L); \
+      FCP_KLAUNCH((fcp_dense_kernel<VV, RR, true>), dim3(grid_blocks), dim3(FCP_BLOCK_THREADS), lds_pad, s, L); \
     else                                                                                                    \
-      hipLaunchKernelGGL((fcp_dense_kernel<VV, RR, false>), dim3(grid_blocks), dim3(FCP_BLOCK_THREADS), lds_pad, s, L); \
+      FCP_KLAUNCH((fcp_dense_kernel<VV, RR, false>), dim3(grid_blocks), dim3(FCP_BLOCK_THREADS), lds_pad, s, L); \
   } while (0)
 #define FCP_LAUNCH_RAGGED(VV)                                                                               \
   do {                                                                                                      \
     if (L.shard_world > 1)                                                                                  \
-      hipLaunchKernelGGL((fcp_ragged_kernel<VV, true>), dim3(grid_blocks), dim3(FCP_BLOCK_THREADS), lds_pad, s, L); \
+      FCP_KLAUNCH((fcp_ragged_kernel<VV, true>), dim3(grid_blocks), dim3(FCP_BLOCK_THREADS), lds_pad, s, L); \
     else                                                                                                    \
-      hipLaunchKernelGGL((fcp_ragged_kernel<VV, false>), dim3(grid_blocks), dim3(FCP_BLOCK_THREADS), lds_pad, s, L); \
+      FCP_KLAUNCH((fcp_ragged_kernel<VV, false>), dim3(grid_blocks), dim3(FCP_BLOCK_THREADS), lds_pad, s, L); \
   } while (0)
 
 // rows_per_wave: dense 1 | 2 | 4 (rows per block = 4 x that); ragged always 1.
@@ -1506,9 +1523,9 @@ int fcp_launch_hybrid(const FcpLaunch &Ldense, int dense_blocks, const FcpLaunch
 #define FCP_HYB(VV, RR)                                                                   \
   do {                                                                                    \
     if (sharded)                                                                          \
-      hipLaunchKernelGGL((fcp_hybrid_kernel<VV, RR, true>), grid, block, 0, s, H);        \
+      FCP_KLAUNCH((fcp_hybrid_kernel<VV, RR, true>), grid, block, 0, s, H);               \
     else                                                                                  \
-      hipLaunchKernelGGL((fcp_hybrid_kernel<VV, RR, false>), grid, block, 0, s, H);       \
+      FCP_KLAUNCH((fcp_hybrid_kernel<VV, RR, false>), grid, block, 0, s, H);              \
   } while (0)
 #define FCP_HYB_R(VV)                        \
   switch (Ldense.rows_per_wave) {            \

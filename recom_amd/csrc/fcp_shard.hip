@@ -30,6 +30,7 @@
 
 // failure reporting shared with fcp_api.hip
 int fcp_internal_fail(int code, const std::string &msg);
+extern "C" int fcp_internal_process(fcp_plan_t *p, const fcp_process_args_t *a, fcp_process_result_t *r); // fcp_api.hip
 
 namespace {
 
@@ -419,7 +420,7 @@ int fcp_shard_step_run(fcp_shard_step_t *s, const fcp_process_args_t *args, void
   std::memset(&res, 0, sizeof(res));
   res.group_ptrs = group_ptr;
   res.group_shapes = group_shape;
-  rc = fcp_process_feature_columns(s->plan, &a, &res);
+  rc = fcp_internal_process(s->plan, &a, &res); // on a.stream itself: the exchange follows there
   if (rc) return rc;
   const int64_t rows = group_shape[2 * s->group];
   if (rows > s->max_rows) return fcp_internal_fail(FCP_ERR_SHAPE_MISMATCH, "more rows than the shard step was created for");

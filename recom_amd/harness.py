@@ -39,6 +39,8 @@ def load() -> C.CDLL:
         H.fcp_harness_run_graph.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double),
                                             C.POINTER(C.c_float)]
         H.fcp_harness_destroy.argtypes = [C.c_void_p]
+        if hasattr(H, "fcp_harness_run_private"):
+            H.fcp_harness_run_private.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_float)]
         H.fcp_harness_copy_probe.argtypes = [C.c_size_t, C.c_int, C.POINTER(C.c_float)]
         H.fcp_harness_gather_probe.argtypes = [C.c_size_t, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float),
                                                C.POINTER(C.c_double)]
@@ -94,6 +96,15 @@ class ServingHarness:
         _lib.check(self.H.fcp_harness_run(self.handle, steps, C.byref(wall), C.byref(dev),
                                           None if it is None else it.ctypes.data), "fcp_harness_run")
         return wall.value, dev.value, it
+
+    def run_private(self, steps: int, depth: int = 3):
+        """One host thread and ONE caller stream over a plan with private streams (``self.plan.set_private_streams``
+        first): request k's consumer — ``fcp_result_wait`` + a reader kernel on the caller's stream — is enqueued
+        ``depth - 1`` requests behind it.  Returns (wall_ms, dev_ms)."""
+        wall, dev = C.c_double(), C.c_float()
+        _lib.check(self.H.fcp_harness_run_private(self.handle, steps, depth, C.byref(wall), C.byref(dev)),
+                   "fcp_harness_run_private")
+        return wall.value, dev.value
 
     def run_graph(self, steps: int, group: int):
         """`group` requests captured once into a HIP graph, replayed steps / group times

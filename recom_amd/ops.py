@@ -223,6 +223,14 @@ class Plan:
                    "fcp_plan_arena_bytes")
         return out.value
 
+    def set_private_streams(self, n_streams: int, no_caller_wait: bool = False, always: bool = False) -> None:
+        """``fcp_plan_set_private_streams``: requests of one caller stream run on ``n_streams`` plan-owned streams
+        (0 = off); readers of a result order themselves behind it with ``fcp_result_wait``.  ``always``: also requests
+        whose work is below the library's threshold (48 MiB gathered + written), which otherwise stay on the caller's stream."""
+        _lib.check(self._L.fcp_plan_set_private_streams(self.handle, int(n_streams), (1 if no_caller_wait else 0) | (2 if always else 0)),
+                   "fcp_plan_set_private_streams")
+        self.private_streams = int(n_streams)
+
     def read_bad_ids(self, stream: int = 0) -> int:
         out = C.c_int64()
         _lib.check(self._L.fcp_plan_read_bad_ids(self.handle, stream, C.byref(out)), "fcp_plan_read_bad_ids")
@@ -239,6 +247,15 @@ class ProcessOutputs:
     buffer: "object"             # torch.uint8 arena (output 2)
     groups: list                 # torch.float32 [rows, width] views per concat group (CONCAT layout)
     group_shapes: np.ndarray
+
+    def wait(self, stream: Optional[int] = None) -> None:
+        """Plans with private streams, ``defer_wait=True``: make ``stream`` (default: torch's current stream) wait
+        on the device for this result — what ``Addons>ConcatOutputs`` does before it reads the arena
+        (``fcp_result_wait``).  A no-op when nothing is pending."""
+        import torch
+        if stream is None:
+            stream = torch.cuda.current_stream(self.buffer.device).cuda_stream
+        _lib.check(_lib.load().fcp_result_wait(self.buffer.data_ptr(), stream), "fcp_result_wait")
 
     def column(self, k: int):
         """torch view of column k's output ([rows, dim], possibly strided)."""
@@ -329,6 +346,8 @@ class FeatureColumnProcess:
         _lib.check(self._L.fcp_process_feature_columns(self.plan.handle, C.byref(a), C.byref(res)),
                    "FeatureColumnProcess")
         arena = keep[5]["arena"]
+        if getattr(self.plan, "private_streams", 0):
+            _lib.check(self._L.fcp_result_wait(arena.data_ptr(), a.stream), "fcp_result_wait")
         f = arena.view(torch.float32)
         out = []
         for gi in range(g):
@@ -338,7 +357,10 @@ class FeatureColumnProcess:
         return out
 
     def __call__(self, concated_inputs, concated_offsets, concated_shapes, inputs, symbols=None,
-                 stream: Optional[int] = None) -> ProcessOutputs:
+                 stream: Optional[int] = None, defer_wait: bool = False) -> ProcessOutputs:
+        """``defer_wait`` (plans with private streams only): do not order ``stream`` behind the result here; the reader
+        calls ``ProcessOutputs.wait`` — the split between FeatureColumnProcess and ConcatOutputs in the rewritten
+        graph.  Default: the wait is enqueued at once, so torch code on ``stream`` may read the result as always."""
         torch = self.torch
         a, keep = self._args(concated_inputs, concated_offsets, concated_shapes, inputs, symbols, stream)
         n, g = self.spec.n_columns, self.spec.n_groups
@@ -351,6 +373,8 @@ class FeatureColumnProcess:
         _lib.check(self._L.fcp_process_feature_columns(self.plan.handle, C.byref(a), C.byref(res)),
                    "FeatureColumnProcess")
         arena = keep[5]["arena"]
+        if getattr(self.plan, "private_streams", 0) and not defer_wait:
+            _lib.check(self._L.fcp_result_wait(arena.data_ptr(), a.stream), "fcp_result_wait")
         out_ptrs = np.array([_out_ptrs[k] or 0 for k in range(n)], np.int64)
         out_shapes = np.array(_out_shapes[:], np.int32)
         strides = np.array(_out_strides[:], np.int64)

@@ -893,11 +893,11 @@ def test_process_call_is_hip_graph_capturable(torch_cuda, oracle):
         torch.cuda.synchronize()
         want, _ = oracle.process_feature_columns(m.spec.to_dict(), blob2, offsets, shapes, tabs_np, req.symbols)
         assert np.array_equal(out.groups[0].cpu().numpy(), want[0])
-    # The captured launch reads its descriptor slot at every replay: 12 requests with other shapes (more than
-    # the 8 slots) on the same stream must not evict it ...
+    # The captured launch reads its descriptor slot at every replay: 36 requests with other shapes (more than
+    # the 32 slots) on the same stream must not evict it ...
     import ctypes as C
     from recom_amd import lib
-    others = [m.make_request(100 + k, B=40 + k) for k in range(12)]
+    others = [m.make_request(100 + k, B=40 + k) for k in range(36)]
     with torch.cuda.stream(s):
         for r in others:
             b, o, sh = concat_inputs(r.inputs)

@@ -1,0 +1,168 @@
+"""Plan-owned private streams (fcp_plan_set_private_streams / fcp_result_wait): ONE host thread and ONE caller stream —
+what the TensorFlow op has (feature_column_process_op_gpu.cu.cc:65-131; the reference harness' serve workers share one
+Session, recom_examples.patch:193-216) — with several requests in flight on the plan's own streams.  The consumer on
+the caller's stream (what Addons>ConcatOutputs and the layers behind it are in the rewritten graph) must always see a
+complete arena; results stay bit-exact with the oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from recom_amd import lib
+    lib.load()  # fail loudly if the HIP extension is missing
+    return torch
+
+
+def _busy(torch, stream, ms=2.0):
+    """Keep `stream` busy for about `ms` milliseconds so that whatever is enqueued behind it runs LATE: a reader that did
+    not wait for the private stream's kernel would then race with it instead of trivially finding it finished."""
+    with torch.cuda.stream(stream):
+        if hasattr(torch.cuda, "_sleep"):
+            torch.cuda._sleep(int(ms * 2.0e6))
+        else:  # pragma: no cover
+            a = torch.empty((4096, 4096), device="cuda")
+            for _ in range(8):
+                a = a @ a
+
+
+def _poison_allocator(torch, nbytes, n=8):
+    """The arenas torch hands out next are blocks that held NaNs: an unfinished arena cannot look right by accident."""
+    junk = [torch.full((nbytes // 4 + 64,), float("nan"), dtype=torch.float32, device="cuda") for _ in range(n)]
+    torch.cuda.synchronize()
+    del junk
+
+
+@pytest.mark.parametrize("no_caller_wait", [False, True])
+def test_three_requests_in_flight_behind_one_caller_stream(torch_cuda, oracle, no_caller_wait):
+    from recom_amd import synth
+    from recom_amd.ops import FeatureColumnProcess, concat_inputs
+    torch = torch_cuda
+    m = synth.model_mixed(batch=192, vocab=4999, n_groups=1)          # every column form, dynamic shapes
+    tabs_np = m.numpy_tables()
+    tabs = [torch.from_numpy(t).cuda() for t in tabs_np]
+    op = FeatureColumnProcess(m.spec, 0)
+    op.plan.set_private_streams(3, no_caller_wait=no_caller_wait, always=True)   # (small requests: below the work threshold)
+    caller = torch.cuda.Stream()
+    reqs = [m.make_request(50 + k, B=150 + 7 * k) for k in range(14)]  # new shapes on every request
+    packed = [concat_inputs(r.inputs) for r in reqs]
+    blobs = [torch.from_numpy(p[0]).cuda() for p in packed]
+    torch.cuda.synchronize()
+    _poison_allocator(torch, op.plan.arena_bytes(packed[-1][2], reqs[-1].symbols))
+    depth, in_flight, snaps, keep = 3, [], [], []
+    with torch.cuda.stream(caller):
+        for k, (r, p, b) in enumerate(zip(reqs, packed, blobs)):
+            if k % 4 == 0:
+                _busy(torch, caller)                                   # the caller's stream runs behind the host
+            out = op(b, p[1], p[2], tabs, r.symbols, defer_wait=True)  # enqueued on a private stream; caller does not wait
+            in_flight.append(out)
+            keep.append(out)                                           # arenas stay allocated until everything is checked
+            if len(in_flight) >= depth:
+                done = in_flight.pop(0)
+                done.wait()                                            # Addons>ConcatOutputs: fcp_result_wait on ITS stream
+                snaps.append(done.groups[0].clone())                   # the consumer kernel, on the caller's stream
+        while in_flight:
+            done = in_flight.pop(0)
+            done.wait()
+            snaps.append(done.groups[0].clone())
+    caller.synchronize()
+    for r, p, snap in zip(reqs, packed, snaps):
+        want, _ = oracle.process_feature_columns(m.spec.to_dict(), p[0], p[1], p[2], tabs_np, r.symbols)
+        assert np.array_equal(snap.cpu().numpy(), want[0])
+    # a host reader: fcp_result_synchronize instead of a stream wait
+    out = op(blobs[0], packed[0][1], packed[0][2], tabs, reqs[0].symbols, stream=caller.cuda_stream, defer_wait=True)
+    from recom_amd import lib
+    lib.check(lib.load().fcp_result_synchronize(out.buffer.data_ptr()), "fcp_result_synchronize")
+    want, _ = oracle.process_feature_columns(m.spec.to_dict(), *packed[0], tabs_np, reqs[0].symbols)
+    got = torch.empty_like(out.groups[0], device="cpu").pin_memory()
+    side = torch.cuda.Stream()                                         # neither the caller's nor a private stream
+    with torch.cuda.stream(side):
+        got.copy_(out.groups[0], non_blocking=True)
+    side.synchronize()
+    assert np.array_equal(got.numpy(), want[0])
+    torch.cuda.synchronize()
+    op.plan.set_private_streams(0)                                     # off again: the request runs on the caller's stream
+    with torch.cuda.stream(caller):
+        out = op(blobs[1], packed[1][1], packed[1][2], tabs, reqs[1].symbols)
+    caller.synchronize()
+    want, _ = oracle.process_feature_columns(m.spec.to_dict(), *packed[1], tabs_np, reqs[1].symbols)
+    assert np.array_equal(out.groups[0].cpu().numpy(), want[0])
+
+
+def test_default_call_orders_the_callers_stream_itself(torch_cuda, oracle):
+    """Without defer_wait the Python op enqueues the wait at once: torch code on the caller's stream reads results as
+    before, the bad-id counter covers private lanes, and a stream capture keeps the request on the captured stream."""
+    from recom_amd import synth
+    from recom_amd.ops import FeatureColumnProcess, concat_inputs
+    from recom_amd.plan import FLAG_COUNT_BAD_IDS
+    import dataclasses
+    torch = torch_cuda
+    m = synth.model_mixed(batch=96, vocab=997, n_groups=1)
+    spec = dataclasses.replace(m.spec, flags=m.spec.flags | FLAG_COUNT_BAD_IDS)
+    tabs_np = m.numpy_tables()
+    tabs = [torch.from_numpy(t).cuda() for t in tabs_np]
+    op = FeatureColumnProcess(spec, 0)
+    op.plan.set_private_streams(2, always=True)
+    s = torch.cuda.Stream()
+    total_bad = 0
+    for k in range(6):
+        r = m.make_request(300 + k, B=80 + k)
+        ids0 = r.inputs[spec.columns[0].ids_input]
+        ids0.reshape(-1)[:3] = 10 ** 6                                  # three ids outside the vocabulary
+        blob, offsets, shapes = concat_inputs(r.inputs)
+        with torch.cuda.stream(s):
+            _busy(torch, s, 0.5)
+            out = op(torch.from_numpy(blob).cuda(), offsets, shapes, tabs, r.symbols)
+            got = out.groups[0].clone()
+        s.synchronize()
+        want, bad = oracle.process_feature_columns(spec.to_dict(), blob, offsets, shapes, tabs_np, r.symbols)
+        total_bad += bad
+        assert np.array_equal(got.cpu().numpy(), want[0])
+    assert total_bad > 0 and op.plan.read_bad_ids(s.cuda_stream) == total_bad
+    # capture: the request is recorded on the captured stream (no cross-stream events inside a capture)
+    r = m.make_request(1, B=64)
+    blob, offsets, shapes = concat_inputs(r.inputs)
+    d_blob = torch.from_numpy(blob).cuda()
+    op.plan.set_private_streams(0)
+    with torch.cuda.stream(s):
+        op(d_blob, offsets, shapes, tabs, r.symbols)                    # descriptors resident for stream s
+    torch.cuda.synchronize()
+    op.plan.set_private_streams(2, always=True)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        out = op(d_blob, offsets, shapes, tabs, r.symbols)
+    g.replay()
+    torch.cuda.synchronize()
+    want, _ = oracle.process_feature_columns(spec.to_dict(), blob, offsets, shapes, tabs_np, r.symbols)
+    assert np.array_equal(out.groups[0].cpu().numpy(), want[0])
+    from recom_amd import lib
+    lib.check(lib.load().fcp_plan_release_captures(op.plan.handle), "release")
+
+
+def test_native_single_caller_loop_runs_s2_shape_and_is_faster_than_serial(torch_cuda):
+    """The native loop bench.py times (fcp_harness_run_private): S2's shape at a small vocabulary, one caller stream,
+    depth 3 over 3 private streams against the same requests back to back on that stream.  Asserts that it runs, that the
+    arenas it leaves are the closed-form results, and reports both times (no timing assertion: boxes differ)."""
+    from recom_amd import synth
+    from recom_amd.harness import ServingHarness
+    torch = torch_cuda
+    model = synth.model_s2(columns=1000, vocab=2000)
+    h = ServingHarness(model, device=0, n_requests=8, arena_ring=6, n_threads=1)
+    assert h.verify_resident()["checked"] > 0
+    h.run(50)
+    serial_ms, _, _ = h.run(300)
+    h.plan.set_private_streams(3)
+    h.run_private(50, 3)
+    priv_ms, priv_dev = h.run_private(300, 3)
+    torch.cuda.synchronize()
+    assert h.verify_resident()["checked"] > 0                            # the Python op over the same plan, private streams on
+    print(f"S2 shape, vocab 2000: {serial_ms / 300 * 1e3:.2f} us per request on one stream, "
+          f"{priv_ms / 300 * 1e3:.2f} us with 3 private streams behind one caller stream")
+    assert priv_ms > 0 and priv_dev > 0
+    h.close()
