@@ -1,66 +1,117 @@
 #!/usr/bin/env python3
-"""Builds oracle/_ref/libref_bucketize.so from the REFERENCE's own source, where it lies.
+"""Builds oracle/_ref/*.so from the REFERENCE's own source, where it lies.
 
 Almost nothing of the reference's hot path can be compiled in this image: its device code exists only as C++ string
-fragments that need TensorFlow 2.6.2, SymEngine, nvcc and CUB.  Two functions are plain C++ inside
-their literals: `Bucketize` (tensorflow_addons/graph_optimizers/cuda_emitter.cc:233-247) and the arena alignment helper
-`alignmem` of the generated host code (:967-969, used by :2151-2179).  This recipe
+fragments that need TensorFlow 2.6.2, SymEngine, nvcc and CUB.  The fragments that are
+self-contained C++ inside their literals are compiled here, unmodified, behind small wrappers of ours:
 
+  libref_bucketize.so (g++, host)         `Bucketize` (tensorflow_addons/graph_optimizers/cuda_emitter.cc:233-247) and the
+                                           arena alignment helper `alignmem` of the generated host code (:967-969)
+  libref_device.so (hipcc, gfx950 device)  `GatherRowsToGlbMem` (:250-293), `GatherScatterRows` (:296-345), `AlignedVector`
+                                           (:664-765), `experiment::ComputeSegmentOffsets` / `SparseSegmentReduce` (:768-962);
+                                           run on the GPU by tests/test_gpu_reference_kernels.py
+
+This recipe
   1. reads that file under /root/reference (never copied into the repository),
-  2. takes the adjacent string literals of the `Bucketize` template and of `alignmem` and un-escapes them into
-     oracle/_ref/bucketize_ref.inc / alignmem_ref.inc (generated files: oracle/_ref/ is git-ignored, it only travels to
-     the GPU box next to the built library),
-  3. compiles oracle/ref_bucketize_wrap.cc (ours: it defines the two CUDA qualifiers away and instantiates the
-     template for every boundary count the tests use) with g++ into oracle/_ref/libref_bucketize.so.
+  2. takes the adjacent string literals of each `headers += "..." "..." ...;` statement and un-escapes them into a
+     TEMPORARY directory,
+  3. compiles oracle/ref_bucketize_wrap.cc / oracle/ref_device_wrap.hip (ours) against them into oracle/_ref/,
+  4. deletes the temporary directory: no reference text is left in the tree, only the built libraries travel to the GPU
+     box (oracle/_ref/ is git-ignored).  oracle/_ref/BUILD_STAMP holds a sha256 over literals + wrappers so that a
+     second call does nothing.
 
-Used by tests only (the oracle's a5 restatement and the HIP kernels' three Bucketize tiers are compared with it); a
-no-op with exit code 0 when /root/reference is absent (the GPU box uses the prebuilt library)."""
+Used by tests only; a no-op with exit code 0 when /root/reference is absent (the GPU box uses the prebuilt libraries).
+SparseSegmentSum / SparseSegmentMean for dim <= 20 (:402-661) need cub::BlockScan (CUB 1.8, absent) and cannot be built."""
+import hashlib
 import os
 import re
+import shutil
 import subprocess
 import sys
+import tempfile
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = "/root/reference/tensorflow_addons/graph_optimizers/cuda_emitter.cc"
 OUT = os.path.join(HERE, "_ref")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+LIBS = ("libref_bucketize.so", "libref_device.so")
 
 
-def extract() -> str:
-    text = open(SRC).read()
-    start = text.index('"template <int NUM_BOUNDARIES, typename T>\\n"')
-    end = text.index('";\n', start) + 1               # the statement `headers += "..." "..." ... ;` ends after a closing quote
+def _statement(text: str, first_literal: str, occurrence: int = 0) -> str:
+    """The un-escaped text of the `headers += "..." "..." ... ;` statement whose first literal is `first_literal`."""
+    start = -1
+    for _ in range(occurrence + 1):
+        start = text.index(first_literal, start + 1)
+    end = text.index('";\n', start) + 1               # the statement ends after a closing quote
     lits = re.findall(r'"((?:[^"\\]|\\.)*)"', text[start:end])
-    body = "".join(lits).encode().decode("unicode_escape")
-    if "Bucketize(" not in body or body.count("{") != body.count("}"):
-        raise SystemExit("ref_extract: the Bucketize literal does not look as expected")
-    return body
+    return "".join(lits).encode().decode("unicode_escape")
 
 
-def extract_alignmem() -> str:
+def extract_all() -> dict:
     text = open(SRC).read()
-    start = text.index('"static __inline__ int alignmem(int x) {\\n"')
-    end = text.index('";\n', start) + 1
-    body = "".join(re.findall(r'"((?:[^"\\]|\\.)*)"', text[start:end])).encode().decode("unicode_escape")
-    if "alignmem(int x)" not in body or body.count("{") != 1 or body.count("}") != 1:
-        raise SystemExit("ref_extract: the alignmem literal does not look as expected")
-    return body
+    bucketize = _statement(text, '"template <int NUM_BOUNDARIES, typename T>\\n"')
+    alignmem = _statement(text, '"static __inline__ int alignmem(int x) {\\n"')
+    gather_first = '"template <bool FULL_BLOCK, int EmbedDim, int BLOCK_THREADS, typename "'
+    gather = _statement(text, gather_first, 0) + "\n" + _statement(text, gather_first, 1)
+    experiment = _statement(text, '"// Ported from TensorFlow 2.6\\n"')
+    checks = (("Bucketize(" in bucketize and bucketize.count("{") == bucketize.count("}")),
+              ("alignmem(int x)" in alignmem and alignmem.count("{") == 1),
+              ("GatherRowsToGlbMem(" in gather and "GatherScatterRows(" in gather and gather.count("{") == gather.count("}")),
+              ("class alignas(alignof(T) * N) AlignedVector" in experiment and "namespace experiment" in experiment
+               and "ComputeSegmentOffsets" in experiment and experiment.rstrip().endswith("// namespace experiment")))
+    if not all(checks):
+        raise SystemExit(f"ref_extract: the reference literals do not look as expected {checks}")
+    return {"bucketize_ref.inc": bucketize, "alignmem_ref.inc": alignmem, "ref_gather.inc": gather, "ref_experiment.inc": experiment}
+
+
+def _stamp(files: dict) -> str:
+    h = hashlib.sha256()
+    for name in sorted(files):
+        h.update(name.encode() + b"\0" + files[name].encode() + b"\0")
+    for w in ("ref_bucketize_wrap.cc", "ref_device_wrap.hip"):
+        h.update(open(os.path.join(HERE, w), "rb").read())
+    return h.hexdigest()
 
 
 def build(force: bool = False) -> bool:
+    """True when the libraries are there (built now or earlier)."""
+    have = all(os.path.exists(os.path.join(OUT, lib)) for lib in LIBS)
     if not os.path.exists(SRC):
-        return os.path.exists(os.path.join(OUT, "libref_bucketize.so"))
+        return have or os.path.exists(os.path.join(OUT, LIBS[0]))
+    files = extract_all()
+    stamp, stamp_path = _stamp(files), os.path.join(OUT, "BUILD_STAMP")
+    if have and not force and os.path.exists(stamp_path) and open(stamp_path).read().strip() == stamp:
+        return True
     os.makedirs(OUT, exist_ok=True)
-    inc, lib = os.path.join(OUT, "bucketize_ref.inc"), os.path.join(OUT, "libref_bucketize.so")
-    for path, body in ((inc, extract()), (os.path.join(OUT, "alignmem_ref.inc"), extract_alignmem())):
-        if force or not os.path.exists(path) or open(path).read() != body:
-            open(path, "w").write(body)
-            force = True
-    wrap = os.path.join(HERE, "ref_bucketize_wrap.cc")
-    if force or not os.path.exists(lib) or os.path.getmtime(lib) < os.path.getmtime(wrap):
-        subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-fno-fast-math", "-I", OUT, wrap, "-o", lib])
+    for stale in os.listdir(OUT):                      # earlier rounds left the un-escaped text here
+        if stale.endswith(".inc"):
+            os.remove(os.path.join(OUT, stale))
+    tmp = tempfile.mkdtemp(prefix="fcp_ref_")
+    try:
+        for name, body in files.items():
+            with open(os.path.join(tmp, name), "w") as f:
+                f.write(body)
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-fno-fast-math", "-I", tmp,
+                               os.path.join(HERE, "ref_bucketize_wrap.cc"), "-o", os.path.join(OUT, LIBS[0])])
+        if os.path.exists(HIPCC):
+            # -ffp-contract=off: the reference's sums contain no multiply, but nothing may be fused either way
+            subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-std=c++17", "-O2", "-fPIC", "-shared", "-ffp-contract=off",
+                                   "-Wno-unused-value", "-I", tmp, os.path.join(HERE, "ref_device_wrap.hip"), "-o",
+                                   os.path.join(OUT, LIBS[1])])
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    with open(stamp_path, "w") as f:
+        f.write(stamp + "\n")
     return True
+
+
+def device_lib_path():
+    """oracle/_ref/libref_device.so, or None when it has not been built (no /root/reference and nothing prebuilt)."""
+    build()
+    p = os.path.join(OUT, LIBS[1])
+    return p if os.path.exists(p) else None
 
 
 if __name__ == "__main__":
     ok = build("--force" in sys.argv)
-    print("oracle/_ref/libref_bucketize.so " + ("built from " + SRC if os.path.exists(SRC) else ("present" if ok else "absent (no reference here)")))
+    print("oracle/_ref: " + ("built from " + SRC if os.path.exists(SRC) else ("present" if ok else "absent (no reference here)")))

@@ -167,6 +167,14 @@ public:
     out_cols_.resize(n_out);
     OP_REQUIRES(c, static_cast<size_t>(n_out) == output_types_.size(), errors::InvalidArgument("plan output columns != output_types"));
     OP_REQUIRES(c, static_cast<size_t>(n_tables) == input_types_.size(), errors::InvalidArgument("plan tables != input_types"));
+    // FCP_PRIVATE_STREAMS=<n> (3 measured best): TensorFlow gives this op one compute stream, shared by every Session::Run
+    // thread; with private streams the lookup kernels of consecutive requests overlap and only Addons>ConcatOutputs
+    // (fcp_result_wait below) orders the compute stream behind them.  Blob, tables and arena are inputs of that
+    // ConcatOutputs node (`tensor_buffers`, cuda_emitter.cc:2632-2643), so they outlive the kernels.
+    if (const char *e = std::getenv("FCP_PRIVATE_STREAMS")) {
+      const int n = std::atoi(e);
+      if (n > 0) OP_REQUIRES_OK(c, FcpStatus(fcp_plan_set_private_streams(plan_, n, 0), "fcp_plan_set_private_streams"));
+    }
   }
   ~FeatureColumnProcessOp() override { fcp_plan_destroy(plan_); } // the reference frees const_buff here
 
@@ -286,6 +294,9 @@ public:
     OP_REQUIRES(c, begin >= 0 && begin + bytes <= arena.NumElements(), errors::Internal("group outside the arena"));
     Tensor out;
     OP_REQUIRES_OK(c, out.BitcastFrom(arena.Slice(begin, begin + bytes), DataTypeToEnum<T>::value, out_shape));
+    // the lookup kernels may run on one of the plan's private streams: this op's stream — and with it everything
+    // downstream of `output` — waits for them on the device (a no-op when private streams are off)
+    OP_REQUIRES_OK(c, FcpStatus(fcp_result_wait(arena.data(), GpuStream(c)), "fcp_result_wait"));
     if (n_host_ > 0) {
       std::vector<const void *> host(n_host_);
       std::vector<int32_t> dims(n_host_), offs(n_host_);
