@@ -8,8 +8,10 @@
  * Integer / index / copy work is restated exactly; floating-point pooling uses
  * sequential fp32 accumulation in id order (the order of the reference-owned
  * plain-C++ segment mean, custom_ops/extended_sparse_segment_reduce/
- * extended_sparse_segment_reduce_ops.cc:53-107, and of TF-CPU's
- * SparseSegmentReduction functor), NOT the CUB block-scan tree order of the
+ * extended_sparse_segment_reduce_ops.cc:53-107; TF-CPU's SparseSegmentReduction
+ * functor adds in the same order for bags of up to 9 ids and sums every further 8
+ * rows among themselves first — orc_sparse_segment_reduce_tfcpu restates that
+ * order), NOT the CUB block-scan tree order of the
  * generated CUDA (graph_optimizers/cuda_emitter.cc:452-455), which cannot be
  * pinned without CUB 1.8 and is only tolerance-comparable anyway.
  *
@@ -183,6 +185,53 @@ int64_t orc_sparse_segment_reduce(const float *table, int64_t vocab, int32_t dim
     }
   }
   return bad;
+}
+
+/* a7 / a8 in the addition order of TENSORFLOW's CPU kernel — what the north star's "vs TF-CPU" tolerance is measured
+ * against.  THIRD-PARTY arithmetic, not under /root/reference and not installed here: TensorFlow 2.6.2 (the reference's
+ * pin, docs/build_from_source.md:8), tensorflow/core/kernels/segment_reduction_ops_impl.h,
+ * SparseSegmentReductionOpBase::Reduce, restated from its published source; PARITY UNPINNED for this function (no
+ * TensorFlow to run it against).  For a segment of `num` rows l0 .. l(num-1), per output coefficient:
+ *   num == 1:  out = l0                                   (no division, mean or not)
+ *   else       r = num & 7;  m = (mean && num < 10) ? float(num) : 1
+ *              first chunk = the first r rows for r in 2..7, the first 8 rows for r == 0, the first 9 rows for r == 1:
+ *                out = ((..(l0 + l1) + l2 ..) + l(k-1)) / m        (one left-to-right Eigen expression, then the division)
+ *              then chunks of 8:  out = out + (((((((la + lb) + lc) + ld) + le) + lf) + lg) + lh)
+ *              mean && num >= 10:  out = out / float(num)
+ * i.e. bags of up to 9 ids are summed strictly left to right — the same additions as orc_sparse_segment_reduce — and
+ * from 10 ids on every further 8 rows are summed among themselves first.  Segments without ids are zeros
+ * (SparseSegment*WithNumSegments fills them with the default value 0).  Ids are assumed valid (TF raises otherwise). */
+void orc_sparse_segment_reduce_tfcpu(const float *table, int32_t dim, const int64_t *ids, const int32_t *offsets,
+                                     int64_t num_segments, int32_t mean, float *out, int64_t out_stride) {
+  for (int64_t s = 0; s < num_segments; ++s) {
+    float *o = out + s * out_stride;
+    const int64_t lo = offsets[s], num = (int64_t)offsets[s + 1] - lo;
+    if (num <= 0) {
+      for (int32_t e = 0; e < dim; ++e) o[e] = 0.0f;
+      continue;
+    }
+    if (num == 1) {
+      const float *w = table + ids[lo] * dim;
+      for (int32_t e = 0; e < dim; ++e) o[e] = w[e];
+      continue;
+    }
+    int64_t r = num & 7;
+    const float m = (mean && num < 10) ? (float)num : 1.0f;
+    if (r == 0) r = 8;
+    if (r == 1) r = 9;
+    for (int32_t e = 0; e < dim; ++e) {
+      float acc = table[ids[lo] * dim + e];
+      for (int64_t k = 1; k < r; ++k) acc = acc + table[ids[lo + k] * dim + e];
+      acc = acc / m;
+      for (int64_t c = r; c < num; c += 8) {
+        float t = table[ids[lo + c] * dim + e];
+        for (int64_t k = 1; k < 8; ++k) t = t + table[ids[lo + c + k] * dim + e];
+        acc = acc + t;
+      }
+      if (mean && num >= 10) acc = acc / (float)num;
+      o[e] = acc;
+    }
+  }
 }
 
 /* a8 in the reference's own order: VBLOCK_DIM_Y = 8 `ty` lanes take rows

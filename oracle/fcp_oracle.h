@@ -138,6 +138,14 @@ void orc_sparse_segment_reduce_ref8x8(const float *table, int32_t dim,
                                       int64_t num_segments, int32_t mean,
                                       float *out, int64_t out_stride);
 
+/* a7 / a8 in the addition order of TensorFlow 2.6.2's CPU kernel (SparseSegmentReductionOpBase::Reduce,
+ * tensorflow/core/kernels/segment_reduction_ops_impl.h — third party, restated from its published source, unpinned):
+ * first num & 7 rows (8 for 0, 9 for 1) left to right, divided by num at once when mean && num < 10, then every further
+ * 8 rows summed among themselves and added; mean && num >= 10 divides at the end.  Equal to the sequential order for
+ * bags of up to 9 ids.  Used to bound the HIP path against the north star's "vs TF-CPU" tolerance. */
+void orc_sparse_segment_reduce_tfcpu(const float *table, int32_t dim, const int64_t *ids, const int32_t *offsets,
+                                     int64_t num_segments, int32_t mean, float *out, int64_t out_stride);
+
 /* a7 in the reference's own summation order for dim <= 20 (64-id tiles, CUB 1.8 BlockScan with
  * BLOCK_SCAN_WARP_SCANS over (row vector, head flag) pairs, carry across tiles; cuda_emitter.cc:348-661,
  * :1542-1618).  row_ids[nnz] sorted ascending.  Used only to bound the fp32 reordering error. */

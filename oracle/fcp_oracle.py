@@ -94,6 +94,8 @@ class COracle:
         L.orc_sparse_segment_reduce.restype = C.c_int64
         L.orc_sparse_segment_reduce.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
                                                 C.c_int64, C.c_int32, C.c_void_p, C.c_int64]
+        L.orc_sparse_segment_reduce_tfcpu.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
+                                                      C.c_void_p, C.c_int64]
         L.orc_sparse_segment_reduce_ref8x8.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                                        C.c_int64, C.c_int32, C.c_void_p, C.c_int64]
         L.orc_sparse_segment_reduce_refscan.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64,
@@ -168,6 +170,16 @@ class COracle:
                                                  o.ctypes.data, S, int(mean), out.ctypes.data,
                                                  t.shape[1])
         return out, bad
+
+    def sparse_segment_reduce_tfcpu(self, table, ids, offsets, mean: bool) -> np.ndarray:
+        """Form 2 in the addition order of TensorFlow 2.6.2's CPU kernel (orc_sparse_segment_reduce_tfcpu); ids valid."""
+        t = np.ascontiguousarray(table, np.float32)
+        i = np.ascontiguousarray(ids, np.int64).ravel()
+        o = np.ascontiguousarray(offsets, np.int32)
+        out = np.empty((o.size - 1, t.shape[1]), np.float32)
+        self.lib.orc_sparse_segment_reduce_tfcpu(t.ctypes.data, t.shape[1], i.ctypes.data, o.ctypes.data, o.size - 1, int(mean),
+                                                 out.ctypes.data, t.shape[1])
+        return out
 
     def sparse_segment_reduce_refscan(self, table, ids, row_ids, num_segments: int, mean: bool) -> np.ndarray:
         """Form 2 in the reference GPU kernel's own order for dim <= 20 (CUB block scan over 64-id tiles)."""

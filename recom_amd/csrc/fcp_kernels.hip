@@ -768,8 +768,9 @@ __global__ void __launch_bounds__(FCP_BLOCK_THREADS) fcp_dense_kernel(const FcpL
 //   phase 2  (wave) lane q walks its column's bag — range and slice come from the
 //            owner lane by cross-lane reads: 8 (then 4) slot offsets -> as many
 //            independent 16-byte table reads in flight -> adds in id order
-//            (sequential fp32 order: deterministic, equal to TF-CPU's and the
-//            oracle's), divides for mean (sum / count, cuda_emitter.cc:625,
+//            (sequential fp32 order: deterministic, the oracle's; the additions TF-CPU
+//            performs for bags of up to 9 ids — from 10 on TF sums every further 8 rows among
+//            themselves first, orc_sparse_segment_reduce_tfcpu, within 1e-5), divides for mean (sum / count, cuda_emitter.cc:625,
 //            :903); the wave stores 1 KiB contiguous of the concat row.
 // Bags longer than 64 ids, or bags that do not fit the wave's 384-entry tile, are
 // walked from global memory by the lanes themselves (same arithmetic order).
@@ -858,7 +859,7 @@ template <int V> __device__ __forceinline__ VF<V> ld_slot_or_zero(const float *t
 }
 
 // The walk of one bag slice for one output slot: the n table slot offsets staged at s[0..n) are added to `acc`
-// in id order (sequential fp32 adds: the order of TF-CPU and of the oracle), FCP_WALK table reads in flight
+// in id order (sequential fp32 adds: the order of the oracle; TF-CPU's up to 9 ids per bag), FCP_WALK table reads in flight
 // per lane.  EVERY lane issues its first FCP_WALK reads at once, whatever its bag length; further batches
 // only while some bag of the wave goes on.  (Round 2 walked "8, then 4" behind per-lane conditions: lanes with
 // up to 4 ids sat out the first pass and issued their reads only after it.)

@@ -1082,8 +1082,8 @@ def test_wide_columns_and_large_boundary_lists(torch_cuda, oracle):
 
 
 def test_pooled_vectors_vs_the_reference_kernels_own_orders(torch_cuda, oracle):
-    """North star: pooled vectors within 1e-5 of the reference.  The HIP path adds in id order (= TF-CPU);
-    the reference's GPU kernels add in block-scan order for dim <= 20 (cuda_emitter.cc:348-661) and in 8
+    """North star: pooled vectors within 1e-5 of the reference.  The HIP path adds in id order (TF-CPU's order for
+    bags of up to 9 ids, see the next test); the reference's GPU kernels add in block-scan order for dim <= 20 (cuda_emitter.cc:348-661) and in 8
     strided partials + an LDS tree for dim > 20 (:820-962).  Both orders are restated in the oracle
     (orc_sparse_segment_reduce_refscan / _ref8x8): the HIP result must sit within 1e-5 of either."""
     from recom_amd import synth
@@ -1109,6 +1109,40 @@ def test_pooled_vectors_vs_the_reference_kernels_own_orders(torch_cuda, oracle):
             large += 1
         assert np.abs(got[:, offs[k]:offs[k] + c.dim] - ref).max() < 1e-5, f"column {k} (dim {c.dim})"
     assert small and large
+
+
+def test_pooled_vectors_vs_tensorflow_cpus_addition_order(torch_cuda, oracle):
+    """North star: pooled vectors within 1e-5 of TF-CPU.  TF 2.6.2's CPU kernel adds the first num & 7 rows of a bag
+    left to right and every further 8 rows among themselves first (orc_sparse_segment_reduce_tfcpu: third-party
+    arithmetic restated from its published source, unpinned).  RAGGED-shaped bags (BASELINE configs[3]: U{0..10} ids per
+    row, every dim, sum and mean) with 9-, 10- and 17-id bags forced in: the HIP result is BIT-IDENTICAL to that order
+    for bags of up to 9 ids (the same additions) and within 1e-5 beyond."""
+    from recom_amd import synth
+    torch = torch_cuda
+    B = 160
+    m = synth.model_ragged(columns=28, vocab=5000, batch=B, dims=(4, 8, 12, 16, 20, 32, 64), max_len=10)
+    tabs_np = m.numpy_tables()
+    req = m.make_request(21)
+    rng = np.random.default_rng(5)
+    for c in m.spec.columns:                                     # bags of exactly 9, 10, 17 (and 25) ids in every column
+        csr = np.asarray(req.inputs[c.seg_input]).astype(np.int64)
+        lens = np.diff(csr)
+        lens[[3, 40, 77, 120]] = [9, 10, 17, 25]
+        req.inputs[c.seg_input] = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        req.inputs[c.ids_input] = rng.integers(0, c.vocab, int(lens.sum())).astype(np.asarray(req.inputs[c.ids_input]).dtype)
+    out, packed, _ = run_gpu(torch, m.spec, req.inputs, tabs_np, req.symbols)
+    got = out.groups[0].cpu().numpy()
+    offs = m.spec.column_offsets()
+    seen_long = 0
+    for k, c in enumerate(m.spec.columns):
+        ids, csr = req.inputs[c.ids_input], req.inputs[c.seg_input]
+        tf = oracle.sparse_segment_reduce_tfcpu(tabs_np[c.table_input], ids, csr, c.combiner == 2)
+        mine = got[:, offs[k]:offs[k] + c.dim]
+        lens = np.diff(csr)
+        assert np.array_equal(mine[lens <= 9], tf[lens <= 9]), f"column {k}"
+        assert np.abs(mine - tf).max() < 1e-5, f"column {k} (dim {c.dim})"
+        seen_long += int((lens >= 10).sum())
+    assert seen_long >= 3 * len(m.spec.columns)
 
 
 @pytest.mark.parametrize("batch,seed", [(33, 0), (1, 1), (257, 2)])

@@ -111,8 +111,8 @@ def test_segment_reduce_vs_embedding_bag(oracle, mean, dim):
 def test_reference_block_scan_order_dim_le_20(oracle, mean, dim):
     """The reference's dim <= 20 template adds in CUB block-scan order (64-id tiles, Kogge-Stone inside each
     32-lane warp, warp aggregate, carry across tiles: cuda_emitter.cc:348-661, :1542-1618), restated in
-    orc_sparse_segment_reduce_refscan.  Against the sequential id order of the oracle (= the HIP path, =
-    TF-CPU) it differs by fp32 reassociation only; segments of one or two ids are identical in any order;
+    orc_sparse_segment_reduce_refscan.  Against the sequential id order of the oracle (= the HIP path; TF-CPU's order
+    for bags of up to 9 ids, test_tensorflow_cpu_addition_order) it differs by fp32 reassociation only; segments of one or two ids are identical in any order;
     the restatement's own tile logic (segments crossing tiles, empty rows, leading empty rows, nnz a
     multiple of 64) is checked against float64."""
     rng = np.random.default_rng(100 * dim + mean)
@@ -136,6 +136,64 @@ def test_reference_block_scan_order_dim_le_20(oracle, mean, dim):
     seq, _ = oracle.sparse_segment_reduce(W2, ids, np.asarray([0, 64], np.int32), False)
     ref = oracle.sparse_segment_reduce_refscan(W2, ids, np.zeros(64, np.int64), 1, False)
     assert not np.array_equal(seq, ref) and np.allclose(seq, ref, rtol=1e-4, atol=1e-2)
+
+
+def _np_tfcpu_segment(rows, mean):
+    """Independent NumPy-float32 statement of TensorFlow 2.6.2's SparseSegmentReductionOpBase::Reduce for ONE segment
+    (rows: [num, dim] float32): first num & 7 rows (8 for 0, 9 for 1) left to right, / num at once when mean and num < 10,
+    every further 8 rows summed among themselves and added, / num at the end when mean and num >= 10."""
+    num = rows.shape[0]
+    if num == 0:
+        return np.zeros(rows.shape[1], np.float32)
+    if num == 1:
+        return rows[0].copy()
+    r = num & 7
+    r = {0: 8, 1: 9}.get(r, r)
+    acc = rows[0].copy()
+    for k in range(1, r):
+        acc = acc + rows[k]
+    if mean and num < 10:
+        acc = acc / np.float32(num)
+    for c in range(r, num, 8):
+        t = rows[c].copy()
+        for k in range(1, 8):
+            t = t + rows[c + k]
+        acc = acc + t
+    if mean and num >= 10:
+        acc = acc / np.float32(num)
+    return acc
+
+
+@pytest.mark.parametrize("mean", [False, True])
+@pytest.mark.parametrize("dim", [4, 8, 32])
+def test_tensorflow_cpu_addition_order(oracle, mean, dim):
+    """The north star's tolerance is "vs TF-CPU".  TF 2.6.2's CPU kernel (segment_reduction_ops_impl.h,
+    SparseSegmentReductionOpBase::Reduce; third party, absent here, restated from its published source in
+    orc_sparse_segment_reduce_tfcpu — unpinned) adds the first num & 7 rows left to right and from then on every 8 rows
+    among themselves first.  So: for bags of UP TO 9 ids it performs exactly the additions of the sequential order (the
+    oracle's default and the HIP path's): bit-identical.  From 10 ids on it differs by fp32 reassociation, bounded here
+    at the north star's 1e-5 for BASELINE's bag lengths (<= 10) and against float64 for long bags."""
+    rng = np.random.default_rng(1000 * dim + mean)
+    W = (rng.standard_normal((500, dim)) * dim ** -0.5).astype(np.float32)
+    lens = np.concatenate([np.arange(0, 27), rng.integers(0, 11, 200), [63, 64, 65, 300]])
+    ids = rng.integers(0, 500, int(lens.sum()))
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    tf = oracle.sparse_segment_reduce_tfcpu(W, ids, off, mean)
+    seq, _ = oracle.sparse_segment_reduce(W, ids, off, mean)
+    truth = O.np_sparse_segment_reduce(W, ids, off, mean)
+    for s, n in enumerate(lens):                                # the C restatement against the independent NumPy one
+        assert np.array_equal(tf[s], _np_tfcpu_segment(W[ids[off[s]:off[s + 1]]], mean)), (s, n)
+    short = lens <= 9
+    assert np.array_equal(tf[short], seq[short])                # the same additions: bit-identical
+    assert not tf[lens == 0].any()
+    base = lens <= 10                                           # BASELINE configs[3] draws U{0..10} ids per row
+    assert np.abs(tf[base] - seq[base]).max() < 1e-5 and np.abs(tf[base] - truth[base]).max() < 1e-5
+    assert np.abs(tf - truth).max() < (1e-5 if mean else 1e-4) and np.abs(tf - seq).max() < (1e-5 if mean else 1e-4)
+    # and the order really is different from 10 ids on: badly conditioned rows expose it in the last bits
+    W2 = (rng.standard_normal((500, dim)) * 10.0 ** rng.integers(-3, 4, (500, 1))).astype(np.float32)
+    ids2 = rng.integers(0, 500, 10 * 64)
+    off2 = (np.arange(65) * 10).astype(np.int32)
+    assert not np.array_equal(oracle.sparse_segment_reduce_tfcpu(W2, ids2, off2, mean), oracle.sparse_segment_reduce(W2, ids2, off2, mean)[0])
 
 
 def _xform_spec(m, transforms):
