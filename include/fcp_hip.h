@@ -358,7 +358,8 @@ enum {
   /* whole tables wherever a table fits one GPU, rows only for the tables that do not: the fewest bytes on the wire
    * (a whole column sends its FINAL block, 1/world of a row-sharded column's dense partial sums).  As a preference
    * (prefer_mode) it resolves to COLUMN_SHARD when every table fits, to MIXED when some do not, and falls back to
-   * ROW_SHARD when whole tables cannot be packed. */
+   * ROW_SHARD when whole tables cannot be packed or fewer tables than ranks would stay whole (the whole-column step
+   * gives every rank a block). */
   FCP_PLACE_MIXED = 3
 };
 typedef struct fcp_placement {

@@ -1621,6 +1621,7 @@ int fcp_placement_assign(const int64_t *table_bytes, int32_t n_tables, int64_t h
   // whole tables, longest first onto the least loaded rank (longest-processing-time packing), on top of the row
   // share of the tables that are spread: `spread_over` = the threshold above which a table is spread by rows
   std::vector<int32_t> assign(n_tables, -1);
+  int32_t n_whole = 0; // tables the last pack() left whole
   auto pack = [&](int64_t spread_over, int64_t *share) {
     int64_t spread = 0;
     std::vector<int32_t> order;
@@ -1640,6 +1641,7 @@ int fcp_placement_assign(const int64_t *table_bytes, int32_t n_tables, int64_t h
       assign[t] = r;
     }
     *share = *std::max_element(load.begin(), load.end());
+    n_whole = (int32_t)order.size();
     return *share <= budget;
   };
   int64_t col_share = 0, mixed_share = 0;
@@ -1647,7 +1649,9 @@ int fcp_placement_assign(const int64_t *table_bytes, int32_t n_tables, int64_t h
   int mode;
   if (prefer_mode == FCP_PLACE_MIXED) {
     if (col_ok) mode = FCP_PLACE_COLUMN_SHARD;                                       // every table fits a GPU: no rows spread at all
-    else if (world > 1 && largest > budget && pack(budget, &mixed_share)) mode = FCP_PLACE_MIXED;
+    // (MIXED needs a whole table for every rank — the whole-column step gives every rank a block; with fewer, the few
+    // small tables are spread by rows like the large ones: their partial sums are a rounding error on the wire)
+    else if (world > 1 && largest > budget && pack(budget, &mixed_share) && n_whole >= world) mode = FCP_PLACE_MIXED;
     else if (row_ok) mode = FCP_PLACE_ROW_SHARD;
     else mode = -1;
   } else {

@@ -370,14 +370,16 @@ def _mixed_pieces(spec, row_cols, per_rank, group: int = 0):
     offs = spec.column_offsets()
     src_of = {}
     at = 0
-    for k in row_cols:
+    # a sub-plan keeps the concat slots of its columns (PlanSpec.column_subset): its group matrix holds them in CONCAT
+    # order, whatever their order in the plan — so that is the order in which a part's columns are numbered here
+    for k in sorted(row_cols, key=lambda k: offs[k]):
         if spec.columns[k].concat_group == group:
             src_of[k] = (0, at)
             at += spec.columns[k].dim
     w_row = at
     at = 0
     for cols in per_rank:
-        for k in cols:
+        for k in sorted(cols, key=lambda k: offs[k]):
             if spec.columns[k].concat_group == group:
                 src_of[k] = (1, at)
                 at += spec.columns[k].dim
@@ -411,7 +413,10 @@ class MixedShardedStep:
         self.row_cols, per_rank = mixed_assignment(spec, owners, comm.world)
         col_cols = sorted(k for cols in per_rank for k in cols)
         if any(len(c) == 0 for c in per_rank) and col_cols:
-            raise ValueError("mixed placement: every rank must hold at least one whole column")
+            # fcp_placement_assign never answers MIXED with fewer whole tables than ranks (it spreads everything by rows
+            # instead); an assignment made by hand may
+            raise ValueError("mixed placement: every rank must hold at least one whole column (fewer whole tables than "
+                             "ranks: use row sharding)")
         self.pieces, self.w_row, self.w_col = _mixed_pieces(spec, self.row_cols, per_rank, group)
         self.width = int(spec.group_width(group))
         self.row_hosts = spec.column_subset(self.row_cols).host_inputs if self.row_cols else []
@@ -421,6 +426,7 @@ class MixedShardedStep:
         self.col_step = NativeShardedStep(submodel(model, col_cols), comm, "col", group,
                                           assignment=[[pos[k] for k in cols] for cols in per_rank]) if col_cols else None
         self._out = []          # ring of output buffers, allocated at the first request
+        self._retired = []      # buffers a larger request replaced
         self._next = 0
 
     def prepare(self, inputs, symbols):
@@ -438,6 +444,11 @@ class MixedShardedStep:
             srcs[1], begin, count = self.col_step.run(request[1], stream)
         if not self._out:
             self._out = [torch.empty((max(count, 1) * 2, self.width), dtype=torch.float32, device=self.dev) for _ in range(3)]
+        if count > self._out[self._next].shape[0]:
+            # a larger batch than the ring was sized for: a new buffer for this entry (the old one may still be read by work
+            # enqueued earlier on any stream: it is kept for the life of the step)
+            self._retired.append(self._out[self._next])
+            self._out[self._next] = torch.empty((count * 2, self.width), dtype=torch.float32, device=self.dev)
         out = self._out[self._next]
         self._next = (self._next + 1) % len(self._out)
         if count:

@@ -85,21 +85,22 @@ def _rank_main(rank, world, port, mode, q):
         q.put((rank, traceback.format_exc()))
 
 
-def _mixed_model():
-    """Ten columns of every lookup form; one table (1.28 MB, pooled) exceeds a 1.1 MB "GPU", the rest fit."""
+def _mixed_model(slots=tuple(range(10))):
+    """Ten columns of every lookup form; one table (1.28 MB, pooled) exceeds a 1.1 MB "GPU", the rest fit.  `slots`: the
+    concat slot of every column — a permutation makes the plan's column order differ from the concat order."""
     from recom_amd import synth
     from recom_amd.plan import COMBINER_MEAN, COMBINER_SUM, FORM_GATHER_SCATTER
     b = synth._Builder()
-    synth._add_dense(b, 300, 8, slot=0)
-    synth._add_ragged(b, 20_000, 16, slot=1, combiner=COMBINER_MEAN, seg="indices")          # 1.28 MB: spread by rows
-    synth._add_dense(b, 101, 8, slot=2, id_source=synth.IDS_F32_BUCKETIZE, boundaries=synth.MICROBENCH_BOUNDARIES)
-    synth._add_dense(b, 6_250, 8, slot=3)
-    synth._add_ragged(b, 700, 32, slot=4, combiner=COMBINER_SUM, seg="csr")
-    synth._add_ragged(b, 900, 8, slot=5, combiner=COMBINER_SUM, seg="indices", form=FORM_GATHER_SCATTER)
-    synth._add_dense(b, 2_000, 16, slot=6)
-    synth._add_ragged(b, 1_500, 12, slot=7, combiner=COMBINER_MEAN, seg="rowids32")
-    synth._add_dense(b, 4_000, 4, slot=8)
-    synth._add_dense(b, 1_000, 20, slot=9)
+    synth._add_dense(b, 300, 8, slot=slots[0])
+    synth._add_ragged(b, 20_000, 16, slot=slots[1], combiner=COMBINER_MEAN, seg="indices")          # 1.28 MB: spread by rows
+    synth._add_dense(b, 101, 8, slot=slots[2], id_source=synth.IDS_F32_BUCKETIZE, boundaries=synth.MICROBENCH_BOUNDARIES)
+    synth._add_dense(b, 6_250, 8, slot=slots[3])
+    synth._add_ragged(b, 700, 32, slot=slots[4], combiner=COMBINER_SUM, seg="csr")
+    synth._add_ragged(b, 900, 8, slot=slots[5], combiner=COMBINER_SUM, seg="indices", form=FORM_GATHER_SCATTER)
+    synth._add_dense(b, 2_000, 16, slot=slots[6])
+    synth._add_ragged(b, 1_500, 12, slot=slots[7], combiner=COMBINER_MEAN, seg="rowids32")
+    synth._add_dense(b, 4_000, 4, slot=slots[8])
+    synth._add_dense(b, 1_000, 20, slot=slots[9])
     return synth._finish("MIXED-PLACEMENT", b, batch=57, n_symbols=1, description="one table larger than one GPU")
 
 
@@ -188,9 +189,53 @@ def test_bench_gpus_2_starts_its_ranks_and_prints_one_line(workload):
         assert rec["config"]["exchange_bytes_sent_per_rank_per_request"] > 0
 
 
-def _rccl_rank_main(rank, world, port, q):
-    """One rank per GPU, RCCL: the NATIVE sharded step (fcp_shard_step_run: grouped ncclSend / ncclRecv) for both modes
-    against the unsharded oracle."""
+def build_fake_rccl():
+    """tests/native/libfake_rccl.so: the test double for the RCCL entry points (tests/native/fake_rccl.cc)."""
+    import subprocess
+    src, lib = os.path.join(ROOT, "tests", "native", "fake_rccl.cc"), os.path.join(ROOT, "tests", "native", "libfake_rccl.so")
+    if not os.path.exists(lib) or os.path.getmtime(lib) < os.path.getmtime(src):
+        subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "-std=c++17", "-O1", "-fPIC", "-shared", src, "-o",
+                               lib + ".tmp", "-lrt", "-lpthread"])
+        os.replace(lib + ".tmp", lib)
+    return lib
+
+
+def _native_mixed(rank, world, orc, comm, slots):
+    """FCP_PLACE_MIXED through the NATIVE steps (MixedShardedStep: fcp_shard_step_run for the row part and for the whole-
+    column part + fcp_concat_outputs_scatter_strided), every column against the unsharded oracle.  `slots`: concat slots
+    that differ from the plan's column order (the pieces must follow the sub-plans' own concat order)."""
+    import torch
+    from recom_amd.ops import concat_inputs
+    from recom_amd.placement import MIXED, decide_placement
+    from recom_amd.shard import MixedShardedStep, batch_slices, mixed_assignment
+    m = _mixed_model(slots)
+    p = decide_placement(m.spec, world, hbm_bytes=1_100_000, reserve_bytes=0, prefer="mixed")
+    assert p.mode == MIXED and p.owners.count(-1) == 1
+    row_cols, per_rank = mixed_assignment(m.spec, p.owners, world)
+    assert row_cols and all(per_rank)
+    step = MixedShardedStep(m, comm, p.owners)
+    tabs_np = m.numpy_tables()
+    for seed, B in ((0, 57), (1, 57), (2, 40), (3, 57), (4, 111), (5, 57)):   # ring reuse; a batch larger than the first one
+        req = m.make_request(seed, B)
+        want, _ = orc.process_feature_columns(m.spec.to_dict(), *concat_inputs(req.inputs), tabs_np, req.symbols)
+        ptr, begin, count = step.run(step.prepare(req.inputs, req.symbols))
+        torch.cuda.synchronize()
+        assert (begin, count) == batch_slices(want[0].shape[0], world)[rank]
+        got, ref = step.result(ptr, count).cpu().numpy(), want[0][begin:begin + count]
+        offs = m.spec.column_offsets()
+        for k, c in enumerate(m.spec.columns):
+            a, b = got[:, offs[k]:offs[k] + c.dim], ref[:, offs[k]:offs[k] + c.dim]
+            if k not in row_cols or c.form in (1, 3, 4, 5):
+                assert np.array_equal(a, b), (slots, seed, k)
+            else:
+                assert np.abs(a - b).max(initial=0) < 1e-5, (slots, seed, k)
+    step.close()
+
+
+def _rccl_rank_main(rank, world, port, q, fake_lib=None):
+    """One rank per GPU over RCCL — or, with `fake_lib`, `world` ranks as processes on cuda:0 over the test double
+    tests/native/fake_rccl.cc bound through FCP_RCCL_PATH: the NATIVE sharded step (fcp_shard_step_run: grouped ncclSend /
+    ncclRecv, batch slices, ring reuse, finalize / concat) for both modes and the mixed step against the unsharded oracle."""
     try:
         for p in (ROOT, os.path.join(ROOT, "oracle")):
             if p not in sys.path:
@@ -198,16 +243,24 @@ def _rccl_rank_main(rank, world, port, q):
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if fake_lib:
+            os.environ["FCP_RCCL_PATH"] = fake_lib
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+        device = 0 if fake_lib else rank
+        torch.cuda.set_device(device)
+        if fake_lib:
+            dist.init_process_group("gloo", rank=rank, world_size=world)     # only carries the communicator id
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
         import fcp_oracle as O
         from recom_amd import synth
         from recom_amd.ops import concat_inputs
         from recom_amd.shard import Communicator, NativeShardedStep, batch_slices
         orc = O.COracle()
-        comm = Communicator(rank, world, rank, dist)
+        comm = Communicator(rank, world, device, dist)
+        _native_mixed(rank, world, orc, comm, tuple(range(10)))
+        _native_mixed(rank, world, orc, comm, (3, 0, 7, 1, 9, 2, 5, 8, 4, 6))
         for m in (synth.model_mixed(batch=50, vocab=997, n_groups=1), synth.model_s2(columns=64, vocab=5000, batch=96)):
             tabs_np = m.numpy_tables()
             for mode in ("row", "col"):
@@ -230,6 +283,37 @@ def _rccl_rank_main(rank, world, port, q):
         q.put((rank, "ok"))
     except Exception:
         q.put((rank, traceback.format_exc()))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_native_sharded_step_over_the_rccl_test_double(world):
+    """fcp_shard.hip with MORE THAN ONE RANK on a 1-GPU box.  RCCL is bound at run time
+    (FCP_RCCL_PATH), so a test double (tests/native/fake_rccl.cc: ncclSend / ncclRecv / ncclGroup* between processes through
+    shared memory, sizes checked on both sides) stands in for it and `world` processes share cuda:0: the native step's
+    send / recv schedule, batch-slice order against fcp_shard_finalize, column blocks against the concat, ring reuse over
+    more requests than ring entries, and the mixed step (row part + whole-column part + strided concat, with concat slots
+    that differ from the plan's column order and a batch larger than the first one) — all against the unsharded oracle."""
+    import torch
+    assert torch.cuda.device_count() >= 1, "needs a GPU"
+    lib = build_fake_rccl()
+    ctx = multiprocessing.get_context("fork")                     # the parent has not touched the GPU (see the file's docstring)
+    assert not torch.cuda.is_initialized()
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rccl_rank_main, args=(r, world, port, q, lib)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = {}
+    try:
+        for _ in range(world):
+            rank, msg = q.get(timeout=900)
+            results[rank] = msg
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.kill()
+    assert results == {r: "ok" for r in range(world)}, "\n".join(f"rank {r}: {m}" for r, m in results.items())
 
 
 def test_native_sharded_step_over_rccl_two_gpus():
