@@ -300,8 +300,16 @@ std::optional<Array> tensor_to_array(const Message &t) {
     if (!s) return std::nullopt;
     for (const Dim &d : *s) a.shape.push_back(d ? *d : 0);
   }
+  // The walk only reads axes, slice bounds and reshape targets: a Const beyond kMaxConstElements is "not a constant we
+  // look at" (a crafted shape such as [2^61 + 1] with a one-value splat list must neither overflow the product nor make
+  // this reader allocate what the shape claims).
+  constexpr size_t kMaxConstElements = (size_t)1 << 20;
   size_t n = 1;
-  for (int64_t d : a.shape) n *= (size_t)d;
+  for (int64_t d : a.shape) {
+    if (d < 0) return std::nullopt;
+    if (d != 0 && n > kMaxConstElements / (size_t)d) return std::nullopt;
+    n *= (size_t)d;
+  }
   const Field *content = find_field(t, 4);
   if (content && !content->bytes.empty()) {
     if (content->bytes.size() < n * elem) return std::nullopt;
@@ -1953,6 +1961,10 @@ int fcp_graph_build(const void *graphdef, size_t n_bytes, uint32_t flags, const 
     return fcp_internal_fail(FCP_ERR_INVALID_ARGUMENT, why.what());
   } catch (const std::bad_alloc &) {
     return fcp_internal_fail(FCP_ERR_ALLOC, "out of host memory");
+  } catch (const std::exception &why) { // nothing may cross the C boundary (std::length_error, out_of_range, ... of a crafted graph)
+    return fcp_internal_fail(FCP_ERR_INVALID_ARGUMENT, std::string("malformed GraphDef: ") + why.what());
+  } catch (...) {
+    return fcp_internal_fail(FCP_ERR_INVALID_ARGUMENT, "malformed GraphDef");
   }
 }
 

@@ -97,12 +97,20 @@ class GraphView:
         return [(n, i) for n, i in self.consumers.get(name, []) if i >= 0]
 
     # ---- constants ------------------------------------------------------------
+    MAX_CONST_ELEMENTS = 1 << 20   # the walk reads axes, slice bounds, reshape targets; larger Consts are not looked at (as fcp_graph.cc)
+
     def const_array(self, node, port: int = 0) -> Optional[np.ndarray]:
         while node.op in ("Identity", "StopGradient") and port == 0:
             node, port = self.input(node, 0)
         if node.op != "Const" or port != 0:
             return None
-        return tensor_to_numpy(node.attr["value"].tensor)
+        t = node.attr["value"].tensor
+        n = 1
+        for d in t.tensor_shape.dim:
+            if d.size < 0 or (d.size and n > self.MAX_CONST_ELEMENTS // int(d.size)):
+                return None
+            n *= int(d.size)
+        return tensor_to_numpy(t)
 
     # ---- dtypes ---------------------------------------------------------------
     def out_dtype(self, node, port: int = 0) -> int:

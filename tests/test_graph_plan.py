@@ -16,6 +16,7 @@ from graph_fixtures import (MICRO_BOUNDARIES, canonical_model, id_filter_model, 
 from recom_amd import plan as PL
 from recom_amd.graph import Unsupported, build_plan, parse_graphdef, rewrite_graph
 from recom_amd.graph import tf_proto as P
+from recom_amd.graph.view import tensor_to_numpy
 from recom_amd.plan_io import load_plan, save_plan
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -620,6 +621,35 @@ def test_native_builder_and_plan_parser_survive_mutated_inputs(tmp_path):
             except (FcpError, Unsupported):
                 bad += 1
     assert ok + bad == 450 and bad > 50
+    # crafted, well-formed input: a Const whose declared shape is astronomically large over a one-value splat
+    # list — the GatherV2 axis, a reshape target — must neither overflow the element count nor make the reader allocate what
+    # the shape claims; both builders treat such a Const as "not a constant the walk looks at" and agree on the outcome
+    from recom_amd.graph import build_plan as py_build
+    for dims in ([2 ** 61 + 1], [2 ** 34], [2 ** 32, 2 ** 32], [3, 2 ** 62], [1 << 21]):
+        for gd0 in seeds[:2]:
+            gd = parse_graphdef(gd0.SerializeToString())
+            hit = 0
+            for node in gd.node:
+                if node.op == "Const" and node.attr["value"].tensor.dtype in (3, 9) and len(node.attr["value"].tensor.tensor_shape.dim) <= 1:
+                    t = node.attr["value"].tensor
+                    first = int(tensor_to_numpy(t).reshape(-1)[0]) if tensor_to_numpy(t).size else 0
+                    t.ClearField("tensor_content")
+                    del t.int_val[:]
+                    del t.int64_val[:]
+                    (t.int_val if t.dtype == 3 else t.int64_val).append(first)
+                    del t.tensor_shape.dim[:]
+                    for d in dims:
+                        t.tensor_shape.dim.add().size = d
+                    hit += 1
+            assert hit
+            outcomes = []
+            for build in (lambda: native_build(gd.SerializeToString(), str(tmp_path / "g.fcp")), lambda: py_build(gd)):
+                try:
+                    build()
+                    outcomes.append("ok")
+                except (FcpError, Unsupported, ValueError) as e:
+                    outcomes.append("refused")
+            assert outcomes[0] == outcomes[1], (dims, outcomes)
     # plan files: the same treatment for fcp_plan_create_from_file / fcp_plan_file_stage_info (host-only: no device)
     built = build_plan(seeds[1])
     spec, stage = built.spec.staged_for_concat_inputs()

@@ -501,6 +501,11 @@ def test_placement_gate():
     assert p.mode == ROW_SHARD and set(p.owners) == {-1}
     p = decide_placement(shard, 8, prefer="row")
     assert set(p.owners) == {-1}
+    # fewer whole tables than ranks: the whole-column step could not give every rank a block -> everything by rows
+    p = decide_placement([400 * 10**9, 10**9, 2 * 10**9], 4, prefer="mixed")
+    assert p.mode == ROW_SHARD and set(p.owners) == {-1}
+    p = decide_placement([400 * 10**9] + [10**9] * 4, 4, prefer="mixed")          # four whole tables for four ranks: mixed
+    assert p.mode == MIXED and p.owners[0] == -1 and sorted(p.owners[1:]) == [0, 1, 2, 3]
 
 
 def test_hot_kernels_keep_full_occupancy(tmp_path):
