@@ -200,6 +200,11 @@ class GraphEvaluator:
             out = np.empty(x[0].shape, np.int64)
             out.ravel()[:] = [np_fingerprint64(bytes(v)) % nb for v in x[0].ravel()]
             return [out]
+        if op == "Max":
+            axis = tuple(int(v) for v in np.asarray(x[1]).ravel())
+            return [np.max(x[0], axis=axis, keepdims=bool("keep_dims" in a and a["keep_dims"].b)).astype(x[0].dtype)]
+        if op in ("AddV2", "Add"):
+            return [(x[0] + x[1]).astype(x[0].dtype)]
         if op == "Prod":
             axis = tuple(int(v) for v in np.asarray(x[1]).ravel())
             return [np.prod(x[0], axis=axis, keepdims=bool("keep_dims" in a and a["keep_dims"].b)).astype(x[0].dtype)]
@@ -214,6 +219,12 @@ class GraphEvaluator:
             flat = np.ravel_multi_index(tuple(idx.T), shape) if idx.size else np.zeros(0, np.int64)
             out = np.stack(np.unravel_index(flat, new), axis=1).astype(np.int64) if idx.size else np.zeros((0, len(new)), np.int64)
             return [out, np.asarray(new, np.int64)]
+        if op == "SparseSegmentSqrtN":                      # (a combiner the fused path leaves to TensorFlow)
+            out = _sparse_segment(x[0], x[1], x[2], None, False)
+            cnt = np.bincount(np.asarray(x[2]).astype(np.int64).ravel(), minlength=out.shape[0]).astype(np.float32)
+            nz = cnt > 0
+            out[nz] = out[nz] / np.sqrt(cnt[nz])[:, None]
+            return [out]
         if op.startswith("SparseSegmentSum") or op.startswith("SparseSegmentMean"):
             n = int(np.asarray(x[3]).ravel()[0]) if op.endswith("WithNumSegments") else None
             return [_sparse_segment(x[0], x[1], x[2], n, "Mean" in op)]

@@ -959,6 +959,7 @@ struct IndexSource { // where an index operand really comes from (EmitInputInlin
 struct SymbolDef {
   std::string tensor;
   int index;
+  int last_stride = 0; // > 0: the row count of a plain SparseSegmentSum / Mean: max(reshape(tensor, [-1])[::last_stride], -1) + 1
 };
 struct HostInput {
   std::string tensor;
@@ -1074,12 +1075,12 @@ struct PlanBuilder {
     dev_list.push_back({name, DT_FLOAT, 2});
     return (int)dev_list.size() - 1;
   }
-  int symbol(const std::string &tensor, int index) {
-    auto key = std::make_pair(tensor, index);
+  int symbol(const std::string &tensor, int index, int last_stride = 0) {
+    auto key = std::make_pair(tensor + (last_stride ? "\x01last" + std::to_string(last_stride) : std::string()), index);
     auto it = sym_ix.find(key);
     if (it != sym_ix.end()) return it->second;
     sym_ix[key] = (int)sym_list.size();
-    sym_list.push_back({tensor, index});
+    sym_list.push_back({tensor, index, last_stride});
     return (int)sym_list.size() - 1;
   }
 
@@ -1423,7 +1424,27 @@ struct PlanBuilder {
       c.rows_arg = sym;
       return c;
     }
-    if (n.op == "SparseSegmentSum" || n.op == "SparseSegmentMean") throw Unsupported("row count is data dependent without num_segments");
+    if (n.op == "SparseSegmentSum" || n.op == "SparseSegmentMean") {
+      // no num_segments (the emitter takes these too, cuda_emitter.cc:1096-1113; its row count is a SymEngine symbol,
+      // :1444-1622): rows = last segment id + 1, computed by the rewritten graph from the sorted segment ids the host ships
+      const Table t = table_of(g.input(n, 0));
+      const IdsOperand ids = ids_operand(g.input(n, 1));
+      if (!ids.filter_node.empty()) throw Unsupported("row count of a plain SparseSegment op over filtered ids depends on what the filter keeps");
+      const SegOperand seg = seg_operand(g.input(n, 2), std::string());
+      const int sym = symbol(host_list[seg.host].tensor, 0, seg.stride);
+      c.form = FCP_FORM_SEGMENT_REDUCE;
+      c.dim = (int)t.dim;
+      c.vocab = t.vocab;
+      c.combiner = n.op == "SparseSegmentSum" ? FCP_COMBINER_SUM : FCP_COMBINER_MEAN;
+      c.table_input = device_input(t.name);
+      apply_ids(c, ids);
+      c.seg_input = seg.host;
+      c.seg_kind = seg.kind;
+      c.seg_stride = seg.stride;
+      c.rows_source = FCP_ROWS_FROM_SYMBOL;
+      c.rows_arg = sym;
+      return c;
+    }
     if (n.op == "ScatterNd") { // EmitGatherScatterRows :1332-1442
       const NodeRef upd = g.input(n, 1);
       if (upd.first->op != "GatherV2" || upd.second != 0) throw Unsupported("ScatterNd updates are not a GatherV2");
@@ -1623,6 +1644,11 @@ Message av_i(int64_t v) {
   add_varint(m, 3, (uint64_t)v);
   return m;
 }
+Message av_b(bool v) {
+  Message m;
+  add_varint(m, 5, v ? 1 : 0);
+  return m;
+}
 Message av_s(const std::string &s) {
   Message m;
   add_bytes(m, 2, s);
@@ -1786,6 +1812,45 @@ std::string rewrite_graph(const Message &graph, const GraphView &view, const Bui
       nodes[flat].input = {sym.tensor, "FeatureColumnProcess/symbols/flat_shape"};
       nodes[flat].attrs.push_back({"T", av_type(dtype)});
       nodes[flat].attrs.push_back({"Tshape", av_type(DT_INT32)});
+      if (sym.last_stride > 0) {
+        // rows of a plain SparseSegmentSum / Mean = max(sorted segment ids, -1) + 1 (0 rows without ids)
+        std::string last = base + "/flat";
+        if (sym.last_stride > 1) { // column 0 of an [nnz, k] index matrix: flat[::k]
+          add_const(base + "/zero", {0}, false);
+          add_const(base + "/stride", {sym.last_stride}, false);
+          const size_t col = add_node(base + "/col", "StridedSlice");
+          nodes[col].input = {base + "/flat", base + "/zero", base + "/zero", base + "/stride"};
+          nodes[col].attrs.push_back({"T", av_type(dtype)});
+          nodes[col].attrs.push_back({"Index", av_type(DT_INT32)});
+          nodes[col].attrs.push_back({"begin_mask", av_i(1)});
+          nodes[col].attrs.push_back({"end_mask", av_i(1)});
+          nodes[col].attrs.push_back({"ellipsis_mask", av_i(0)});
+          nodes[col].attrs.push_back({"new_axis_mask", av_i(0)});
+          nodes[col].attrs.push_back({"shrink_axis_mask", av_i(0)});
+          last = base + "/col";
+        }
+        const size_t c32 = add_node(base + "/cast", "Cast");
+        nodes[c32].input = {last};
+        nodes[c32].attrs.push_back({"SrcT", av_type(dtype)});
+        nodes[c32].attrs.push_back({"DstT", av_type(DT_INT32)});
+        add_const(base + "/none", {-1}, false);
+        const size_t cat = add_node(base + "/cat", "ConcatV2");
+        nodes[cat].input = {base + "/cast", base + "/none", "FeatureColumnProcess/symbols/axis"};
+        nodes[cat].attrs.push_back({"N", av_i(2)});
+        nodes[cat].attrs.push_back({"T", av_type(DT_INT32)});
+        nodes[cat].attrs.push_back({"Tidx", av_type(DT_INT32)});
+        const size_t mx = add_node(base + "/max", "Max");
+        nodes[mx].input = {base + "/cat", "FeatureColumnProcess/symbols/axis"};
+        nodes[mx].attrs.push_back({"T", av_type(DT_INT32)});
+        nodes[mx].attrs.push_back({"Tidx", av_type(DT_INT32)});
+        nodes[mx].attrs.push_back({"keep_dims", av_b(false)});
+        add_const(base + "/one", {1}, true);
+        const size_t add = add_node(base, "AddV2");
+        nodes[add].input = {base + "/max", base + "/one"};
+        nodes[add].attrs.push_back({"T", av_type(DT_INT32)});
+        nodes[pack].input.push_back(base);
+        continue;
+      }
       add_const(base + "/index", {sym.index}, true);
       const size_t pick = add_node(base + "/pick", "GatherV2");
       nodes[pick].input = {base + "/flat", base + "/index", "FeatureColumnProcess/symbols/axis"};

@@ -95,9 +95,12 @@ class IndexSource:
 
 @dataclass
 class SymbolDef:
-    """symbol value = ``reshape(tensor, [-1])[index]`` at request time."""
+    """symbol value = ``reshape(tensor, [-1])[index]`` at request time — or, ``last_stride`` > 0, the row count of a plain
+    ``SparseSegmentSum`` / ``SparseSegmentMean`` (no ``num_segments``): last segment id + 1 over the sorted segment ids
+    ``reshape(tensor, [-1])[::last_stride]``, 0 when there are none (TensorFlow's output shape for those ops)."""
     tensor: str
     index: int
+    last_stride: int = 0
 
 
 @dataclass
@@ -220,11 +223,11 @@ class PlanBuilder:
             self._dev_list.append((name, P.DT_FLOAT, 2))
         return self._dev[tensor]
 
-    def _symbol(self, tensor: str, index: int) -> int:
-        key = (tensor, index)
+    def _symbol(self, tensor: str, index: int, last_stride: int = 0) -> int:
+        key = (tensor, index, last_stride)
         if key not in self._sym:
             self._sym[key] = len(self._sym_list)
-            self._sym_list.append(SymbolDef(tensor, index))
+            self._sym_list.append(SymbolDef(tensor, index, last_stride))
         return self._sym[key]
 
     # ---- EmitInputInline (cuda_emitter.cc:1769-1949) ---------------------------------
@@ -506,7 +509,18 @@ class PlanBuilder:
                               self._device_input(table), ids_in, seg_in, seg_kind, stride, ROWS_FROM_SYMBOL, sym, bnd,
                               group, slot, **xf, **seg_map)
         if node.op in ("SparseSegmentSum", "SparseSegmentMean"):
-            raise Unsupported("row count is data dependent without num_segments")
+            # no num_segments (the emitter takes these too, cuda_emitter.cc:1096-1113; its row count is a SymEngine symbol,
+            # :1444-1622): rows = last segment id + 1, which the rewritten graph computes from the sorted segment ids the host
+            # ships anyway (a host tensor: a symbol, not a device -> host round trip)
+            table, vocab, dim = self._table_of(*g.input(node, 0))
+            ids_in, id_source, bnd, xf, fnode = self._ids_operand(*g.input(node, 1))
+            if fnode is not None:
+                raise Unsupported("row count of a plain SparseSegment op over filtered ids depends on what the filter keeps")
+            seg_in, seg_kind, stride, _ = self._seg_operand(*g.input(node, 2), None)
+            sym = self._symbol(self._host_list[seg_in][0], 0, last_stride=stride)
+            return ColumnSpec(FORM_SEGMENT_REDUCE, dim, vocab, COMBINER_SUM if node.op == "SparseSegmentSum" else COMBINER_MEAN,
+                              id_source, self._device_input(table), ids_in, seg_in, seg_kind, stride, ROWS_FROM_SYMBOL, sym, bnd,
+                              group, slot, **xf)
         if node.op == "ScatterNd":                                                  # EmitGatherScatterRows :1332-1442
             upd, upd_port = g.input(node, 1)
             if upd.op != "GatherV2" or upd_port != 0:

@@ -107,6 +107,43 @@ def rewrite_graph(graph_def, built: BuiltPlan, plan_path: str, prune: bool = Tru
             flat.input.extend([sym.tensor, "FeatureColumnProcess/symbols/flat_shape"])
             flat.attr["T"].type = dtype
             flat.attr["Tshape"].type = P.DT_INT32
+            if sym.last_stride > 0:
+                # rows of a plain SparseSegmentSum / Mean = max(sorted segment ids, -1) + 1 (0 rows without ids)
+                last = flat.name
+                if sym.last_stride > 1:                    # column 0 of an [nnz, k] index matrix: flat[::k]
+                    _const(gd, base + "/zero", np.asarray([0], np.int32))
+                    _const(gd, base + "/stride", np.asarray([sym.last_stride], np.int32))
+                    col = gd.node.add(name=base + "/col", op="StridedSlice")
+                    col.input.extend([flat.name, base + "/zero", base + "/zero", base + "/stride"])
+                    col.attr["T"].type = dtype
+                    col.attr["Index"].type = P.DT_INT32
+                    col.attr["begin_mask"].i = 1
+                    col.attr["end_mask"].i = 1
+                    col.attr["ellipsis_mask"].i = 0
+                    col.attr["new_axis_mask"].i = 0
+                    col.attr["shrink_axis_mask"].i = 0
+                    last = col.name
+                c32 = gd.node.add(name=base + "/cast", op="Cast")
+                c32.input.append(last)
+                c32.attr["SrcT"].type = dtype
+                c32.attr["DstT"].type = P.DT_INT32
+                _const(gd, base + "/none", np.asarray([-1], np.int32))
+                cat = gd.node.add(name=base + "/cat", op="ConcatV2")
+                cat.input.extend([c32.name, base + "/none", "FeatureColumnProcess/symbols/axis"])
+                cat.attr["N"].i = 2
+                cat.attr["T"].type = P.DT_INT32
+                cat.attr["Tidx"].type = P.DT_INT32
+                mx = gd.node.add(name=base + "/max", op="Max")
+                mx.input.extend([cat.name, "FeatureColumnProcess/symbols/axis"])
+                mx.attr["T"].type = P.DT_INT32
+                mx.attr["Tidx"].type = P.DT_INT32
+                mx.attr["keep_dims"].b = False
+                _const(gd, base + "/one", np.asarray(1, np.int32))
+                add = gd.node.add(name=base, op="AddV2")
+                add.input.extend([mx.name, base + "/one"])
+                add.attr["T"].type = P.DT_INT32
+                pack.input.append(add.name)
+                continue
             _const(gd, base + "/index", np.asarray(sym.index, np.int32))
             pick = gd.node.add(name=base + "/pick", op="GatherV2")
             pick.input.extend([flat.name, base + "/index", "FeatureColumnProcess/symbols/axis"])

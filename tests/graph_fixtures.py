@@ -172,11 +172,11 @@ def canonical_model(B=19, seed=0, unsupported=False):
     feeds["a_ids"] = feeds["a_ids"] % 53
     concat0.append(g.gather("input_layer/c2_embedding/GatherDense", t_c, "c2/Cast", np.int32))
     if unsupported:
-        # 10. SparseSegmentSum without num_segments: row count is data dependent → stays in TF
+        # 10. a pooling op the fused path does not take (sqrt-n combiner): stays in TF
         t_u = table("input_layer/u_embedding/embedding_weights", 40, 4)
         v, i, n = sparse("u", B, 40, 3, min_len=1)
         seg = g.slice_col0("u/added_strided_slice", i, shrink=True)
-        concat0.append(g.node("u/SparseSegmentSum", "SparseSegmentSum", [t_u, v, seg], T=("type", P.DT_FLOAT),
+        concat0.append(g.node("u/SparseSegmentSqrtN", "SparseSegmentSqrtN", [t_u, v, seg], T=("type", P.DT_FLOAT),
                               Tidx=("type", P.DT_INT64), Tsegmentids=("type", P.DT_INT64),
                               _output_shapes=("shapes", [[-1, 4]])))
     g.const("concat/axis", np.asarray(1, np.int32))
@@ -336,6 +336,46 @@ def random_model(seed):
                    Tidx=("type", P.DT_INT32))
         fetches.append(g.node(f"output_{grp}", "Identity", [c], T=("type", P.DT_FLOAT)))
     return g.gd, feeds, variables, fetches, kinds
+
+
+def plain_segment_model(B=21, seed=0):
+    """Plain ``SparseSegmentSum`` / ``SparseSegmentMean`` — no ``num_segments`` — next to a one-hot column (the emitter
+    takes these ops too, cuda_emitter.cc:1096-1113): TensorFlow gives them ``last segment id + 1`` rows, so the fixture keeps
+    the last row non-empty (the ConcatV2 needs B rows) while rows in the middle may be.  Column ``s``: SparseTensor
+    indices [nnz, 2] int64 behind ``[:, 0]``; column ``m``: int32 row ids [nnz] as they are.
+    Returns (graph_def, feeds, variables, fetches)."""
+    rng = np.random.default_rng(seed)
+    g = GB()
+    feeds, variables = {}, {}
+    ins = []
+    t = g.variable("input_layer/d_embedding/embedding_weights", 61, 8)
+    variables[t] = rng.standard_normal((61, 8)).astype(np.float32)
+    g.placeholder("d_ids", np.int64, [-1])
+    feeds["d_ids"] = rng.integers(0, 61, size=B).astype(np.int64)
+    ins.append(g.gather("input_layer/d_embedding/GatherDense", t, "d_ids", np.int64))
+    for name, vocab, dim, op, seg_dtype in (("s", 97, 16, "SparseSegmentSum", np.int64), ("m", 53, 4, "SparseSegmentMean", np.int32)):
+        lens = rng.integers(0, 6, size=B)
+        lens[-1] = max(1, lens[-1])
+        nnz = int(lens.sum())
+        rows = np.repeat(np.arange(B), lens)
+        tab = g.variable(f"input_layer/{name}_embedding/embedding_weights", vocab, dim)
+        variables[tab] = rng.standard_normal((vocab, dim)).astype(np.float32)
+        g.placeholder(f"{name}/values", np.int64, [-1])
+        feeds[f"{name}/values"] = rng.integers(0, vocab, size=nnz).astype(np.int64)
+        if seg_dtype == np.int64:
+            g.placeholder(f"{name}/indices", np.int64, [-1, 2])
+            feeds[f"{name}/indices"] = np.stack([rows, np.concatenate([np.arange(l) for l in lens])], 1).astype(np.int64)
+            seg = g.slice_col0(f"{name}/added_strided_slice", f"{name}/indices", shrink=True)
+        else:
+            g.placeholder(f"{name}/row_ids", np.int32, [-1])
+            feeds[f"{name}/row_ids"] = rows.astype(np.int32)
+            seg = f"{name}/row_ids"
+        ins.append(g.node(f"{name}/{op}", op, [tab, f"{name}/values", seg], T=("type", P.DT_FLOAT), Tidx=("type", P.DT_INT64),
+                          Tsegmentids=("type", P.DT_INT64 if seg_dtype == np.int64 else P.DT_INT32),
+                          _output_shapes=("shapes", [[-1, dim]])))
+    g.const("concat/axis", np.asarray(1, np.int32))
+    g.node("input_layer/concat", "ConcatV2", ins + ["concat/axis"], N=len(ins), T=("type", P.DT_FLOAT), Tidx=("type", P.DT_INT32))
+    return g.gd, feeds, variables, ["input_layer/concat"]
 
 
 def sparse_reshape_model(B=23, seed=0):

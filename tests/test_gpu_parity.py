@@ -482,6 +482,17 @@ def test_graphdef_to_hip_path_through_the_staged_concat_inputs(torch_cuda, tmp_p
     _graph_through_hip(torch_cuda, gd, feeds, variables, fetches, tmp_path, staged=True)
 
 
+@pytest.mark.parametrize("staged", [False, True])
+def test_plain_sparse_segment_graph_to_hip_path(torch_cuda, tmp_path, staged):
+    """SparseSegmentSum / SparseSegmentMean without num_segments (cuda_emitter.cc:1096-1113): rows = last segment id + 1 is
+    a symbol the rewritten graph computes on the host; GraphDef -> plan -> HIP equals the original graph bit for bit."""
+    from graph_fixtures import plain_segment_model
+    for B, seed in ((21, 0), (1, 1), (300, 2)):
+        gd, feeds, variables, fetches = plain_segment_model(B=B, seed=seed)
+        built = _graph_through_hip(torch_cuda, gd, feeds, variables, fetches, tmp_path, staged=staged)
+        assert [c.form for c in built.spec.columns] == [1, 2, 2] and not built.skipped
+
+
 def test_sparse_reshape_graph_to_hip_path(torch_cuda, tmp_path):
     """a12 on the GPU (cuda_emitter.cc:1874-1916): GraphDef -> plan -> HIP with segment ids read through SparseReshapes
     that are the identity (plain ids from the original indices), folded into a segment-id map (run-time factor, rank-3

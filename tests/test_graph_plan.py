@@ -211,17 +211,55 @@ def test_unsupported_lookup_stays_in_tensorflow(oracle, tmp_path):
     from tf_graph_eval import GraphEvaluator
     gd, feeds, variables, fetches = canonical_model(unsupported=True)
     built = build_plan(gd)
-    assert ("u/SparseSegmentSum", "row count is data dependent without num_segments") in built.skipped
+    assert ("u/SparseSegmentSqrtN", "op SparseSegmentSqrtN is not a lookup") in built.skipped
     k = built.groups[0].columns[-1]
     assert built.spec.columns[k].form == PL.FORM_PASSTHROUGH
-    assert built.host_inputs[built.spec.columns[k].ids_input][0] == "u/SparseSegmentSum"
+    assert built.host_inputs[built.spec.columns[k].ids_input][0] == "u/SparseSegmentSqrtN"
     path = str(tmp_path / "m.fcp")
     save_plan(built.spec, path)
     out = rewrite_graph(gd, built, path)
-    assert any(n.name == "u/SparseSegmentSum" for n in out.node)            # still computed by TF
+    assert any(n.name == "u/SparseSegmentSqrtN" for n in out.node)          # still computed by TF
     expected = GraphEvaluator(gd, variables).run(fetches, feeds)
     got = GraphEvaluator(out, variables, oracle_ops(oracle, built, variables)).run(fetches, feeds)
     assert all(np.array_equal(e, o) for e, o in zip(expected, got))
+
+
+@pytest.mark.parametrize("staged", [False, True])
+def test_plain_sparse_segment_ops_take_their_rows_from_the_last_segment_id(oracle, tmp_path, staged):
+    """SparseSegmentSum / SparseSegmentMean WITHOUT num_segments (cuda_emitter.cc:1096-1113 takes them; VERDICT r03
+    missing 2): TensorFlow's row count, last segment id + 1, is a host-side fact of the sorted segment ids the request
+    ships — a symbol the rewritten graph computes (max(ids, -1) + 1: zero rows without ids) — so the columns are fused
+    like their WithNumSegments twins; both builders, byte-identical; rewritten graph == original graph."""
+    from tf_graph_eval import GraphEvaluator
+    from recom_amd.graph import native_build
+    from graph_fixtures import plain_segment_model
+    gd, feeds, variables, fetches = plain_segment_model()
+    built = build_plan(gd)
+    assert not built.skipped
+    forms = [(c.form, c.combiner, c.rows_source, c.seg_stride) for c in built.spec.columns]
+    assert forms == [(PL.FORM_GATHER, PL.COMBINER_NONE, PL.ROWS_FROM_IDS, 1), (PL.FORM_SEGMENT_REDUCE, PL.COMBINER_SUM, PL.ROWS_FROM_SYMBOL, 2),
+                     (PL.FORM_SEGMENT_REDUCE, PL.COMBINER_MEAN, PL.ROWS_FROM_SYMBOL, 1)]
+    assert [(s.tensor, s.last_stride) for s in built.symbols] == [("s/indices", 2), ("m/row_ids", 1)]
+    path = str(tmp_path / "m.fcp")
+    stage = None
+    if staged:
+        spec, stage = built.spec.staged_for_concat_inputs()
+        save_plan(spec, path, stage)
+    else:
+        save_plan(built.spec, path)
+    out = rewrite_graph(gd, built, path, stage=stage)
+    assert not any(n.op.startswith("SparseSegment") for n in out.node)        # fused away
+    expected = GraphEvaluator(gd, variables).run(fetches, feeds)
+    got = GraphEvaluator(out, variables, oracle_ops(oracle, built, variables)).run(fetches, feeds)
+    assert expected[0].shape[0] == 21 and np.array_equal(expected[0], got[0])
+    cpath = str(tmp_path / "c.fcp")
+    c_graph, _ = native_build(gd.SerializeToString(), cpath, staged=staged)
+    assert open(cpath).read() == open(path).read()
+    assert parse_graphdef(c_graph) == rewrite_graph(gd, built, cpath, stage=stage)
+    # no ids at all: zero rows, as TensorFlow says (the symbol graph alone; a ConcatV2 next to a [B] column could not hold it)
+    sym = GraphEvaluator(out, variables).run(["FeatureColumnProcess/symbols"],
+                                             {**feeds, "s/indices": np.zeros((0, 2), np.int64), "m/row_ids": np.zeros(0, np.int32)})[0]
+    assert sym.tolist() == [0, 0]
 
 
 def test_microbenchmark_graph(oracle, tmp_path):
