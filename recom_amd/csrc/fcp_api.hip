@@ -171,6 +171,7 @@ struct fcp_plan {
   std::vector<int32_t> ranks, elem_sizes, shape_off;
   std::vector<int32_t> group_width, group_nslots, group_map_off;
   std::vector<int32_t> seg_cols;
+  int32_t n_seg_plain = 0;  // seg_cols[0 .. n_seg_plain): pooled columns; the rest: any-order ScatterNd columns (inverse maps)
   bool seg_search = false;  // blocks search the segment ids themselves; no segment-offset pre-pass
   bool has_inverse = false; // some ScatterNd column brings its row ids as delivered (any order): inverse map in the pre-pass
   // device arrays are kept in concat order (group-major, ascending concat offset)
@@ -479,6 +480,11 @@ int compute_dyn_slow(const fcp_plan *p, const int32_t *offsets, const int32_t *s
               d.seg_sym = symbols[hc.ext.seg_map_sym];
               if (d.seg_sym < (hc.ext.seg_map_sym_slot == 4 ? 1 : 0))
                 return fail(FCP_ERR_SHAPE_MISMATCH, "segment-id map: symbol value out of range");
+              // the pre-pass multiplies the factor by the symbol in 64 bits (load_seg_mapped): the product — and with it
+              // every idx * factor for idx < 2^31 — must stay inside int64
+              const int64_t factor = hc.ext.seg_map_sym_slot == 4 ? hc.ext.seg_map_div : hc.ext.seg_map_mul[hc.ext.seg_map_sym_slot];
+              if (d.seg_sym > 0 && factor > (INT64_MAX >> 32) / d.seg_sym)
+                return fail(FCP_ERR_UNSUPPORTED, "segment-id map: factor x symbol exceeds 2^31 (the reshaped row index would overflow)");
             }
           }
           if (d.nnz > m->max_seg_nnz) m->max_seg_nnz = d.nnz;
@@ -1260,6 +1266,11 @@ int fcp_plan_create_ex(const fcp_plan_desc_t *desc, const fcp_column_ext_t *ext,
       p->seg_cols.push_back(k);
   }
   p->vec = gcd4;
+  // any-order ScatterNd columns last: their part of the CSR scratch (the inverse maps, built with atomic max from zero)
+  // is then ONE range at the tail, the only one a request has to clear
+  std::stable_partition(p->seg_cols.begin(), p->seg_cols.end(), [&](int32_t k) { return p->cols[k].d.form != FCP_FORM_GATHER_SCATTER; });
+  p->n_seg_plain = 0;
+  for (int32_t k : p->seg_cols) p->n_seg_plain += p->cols[k].d.form != FCP_FORM_GATHER_SCATTER;
   // Segment-id columns (SparseTensor indices / row ids): unsharded plans let every block find its rows'
   // ranges with a 16-ary search (fcp_kernels.hip::seg_lower_bound) instead of running the
   // ComputeSegmentOffsets pre-pass as a second, dependent launch.  Row-sharded plans keep the
@@ -1840,9 +1851,12 @@ int fcp_internal_process(fcp_plan_t *p, const fcp_process_args_t *a, fcp_process
     S.segmaps = p->d_segmaps;
     S.skip_inverse = 0;
     S.csr_arena_off = m.csr_arena_off;
-    // any-order scatter columns build their inverse map with atomic max: their scratch starts from zero
-    if (p->has_inverse && m.arena_bytes > m.csr_arena_off)
-      HIP_TRY(hipMemsetAsync(static_cast<char *>(arena) + m.csr_arena_off, 0, (size_t)(m.arena_bytes - m.csr_arena_off), stream));
+    // any-order scatter columns build their inverse map with atomic max: their scratch — the tail of the CSR area, the
+    // pooled columns' offsets in front of it are overwritten by the pre-pass anyway — starts from zero
+    if (p->has_inverse) {
+      const int64_t first = m.csr_arena_off + 4 * (int64_t)slot->h_dyn[p->pos_of[p->seg_cols[p->n_seg_plain]]].csr_base;
+      if (m.arena_bytes > first) HIP_TRY(hipMemsetAsync(static_cast<char *>(arena) + first, 0, (size_t)(m.arena_bytes - first), stream));
+    }
     const int e = fcp_launch_segment_offsets(S, (int)p->seg_cols.size(), m.max_seg_nnz, stream);
     if (e) return hip_fail("segment-offsets launch", (hipError_t)e);
   }

@@ -16,12 +16,16 @@
 #endif
 
 // int64 -> int32; values that do not fit are not valid ids / rows anyway: -1 (reads as zeros on the device)
-extern "C" FCP_CLONES void fcp_pack_narrow_i64(const int64_t *src, int32_t *dst, int64_t n) {
+FCP_CLONES static void narrow_plain(const int64_t *src, int32_t *dst, int64_t n) {
   for (int64_t k = 0; k < n; ++k) {
     const int64_t v = src[k];
     dst[k] = (uint64_t)v <= 0x7fffffffull ? (int32_t)v : -1;
   }
 }
+
+// (Streaming stores for the destination — it is only read by the DMA engine next — were measured and dropped: the same
+// at 8-16 pack threads, 15-40 % slower at 1-4, profiles/r04_pcie_staging.txt.)
+extern "C" void fcp_pack_narrow_i64(const int64_t *src, int32_t *dst, int64_t n) { narrow_plain(src, dst, n); }
 
 // Sorted segment / row ids (element i at index i * stride, int32 or int64) -> CSR offsets[0..rows]: offsets[r] = number
 // of ids below r — what the device pre-pass (fcp_segment_offsets_kernel) and ComputeSegmentOffsets

@@ -6,7 +6,7 @@ directly with arguments marshalled once (the loop is Python, ~10 us per iteratio
   narrow  : int64 ids / indices shipped as int32
   staged  : + sorted row ids -> CSR offsets on the host while packing (FCP_STAGE_SEG_TO_CSR): no pre-pass
 each with the H2D copy and with FCP_STAGER_ZERO_COPY.  Also the device time of the fused kernel on resident inputs of
-each form.  GPU box: python scripts/ragged_staged.py [steps]"""
+each form.  GPU box: [PACK_THREADS=8] python scripts/ragged_staged.py [steps] [ragged|e|f]"""
 import ctypes as C
 import os
 import sys
@@ -23,8 +23,10 @@ from recom_amd.ops import FeatureColumnProcess, RequestStager  # noqa: E402
 from recom_amd.plan import STAGE_COPY  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+which = sys.argv[2] if len(sys.argv) > 2 else "ragged"          # ragged | e | f
 dev = torch.device("cuda", 0)
-m = synth.model_ragged(seg="indices")
+m = synth.model_ragged(seg="indices") if which == "ragged" else synth.model_ae(which)
+print(f"== {m.name}: {m.description}; pack threads {os.environ.get('PACK_THREADS', '8')}")
 L = _lib.load()
 tabs = m.torch_tables(dev)
 tptrs = (C.c_void_p * len(tabs))(*[t.data_ptr() for t in tabs])
