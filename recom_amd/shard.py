@@ -537,13 +537,10 @@ class _GlooShardedStep:
         pass
 
 
-def bench_sharded(args, model, placement, rank: int, world: int, local_rank: int, dist) -> dict:
-    """`bench.py --workload shard[-col]` once the placement gate has decided to shard (BASELINE.json config 5:
-    4000 S2-shaped columns, 480 GB of tables): every rank holds its shard, every request runs partial
-    kernel -> RCCL all-to-all over xGMI -> finalize / concat as one native call (NativeShardedStep)."""
+def _time_sharded_step(args, model, placement, mode: str, rank: int, world: int, local_rank: int, dist):
+    """One sharded serving mode timed the bench contract's way: W warm-up requests, barrier + synchronize, exactly K timed
+    requests, synchronize + barrier, MAX over ranks.  Returns (elapsed seconds, device seconds per request)."""
     import torch
-    from .placement import MIXED, ROW_SHARD
-    mode = "row" if placement.mode == ROW_SHARD else "mixed" if placement.mode == MIXED else "col"
     if dist is not None and dist.get_backend() != "nccl":
         # RCCL refuses two ranks on one device: under gloo (several ranks sharing a GPU, a 1-GPU box exercising the N > 1
         # control flow) the exchange goes through the host and the step is the Python orchestration of the same kernels
@@ -572,36 +569,56 @@ def bench_sharded(args, model, placement, rank: int, world: int, local_rank: int
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    dev_s = e0.elapsed_time(e1) * 1e-3 / args.steps
+    step.close()
+    if comm is not None:
+        comm.close()
+    del step, reqs
+    torch.cuda.empty_cache()
+    return elapsed, dev_s
+
+
+def bench_sharded(args, model, placement, rank: int, world: int, local_rank: int, dist) -> dict:
+    """`bench.py --workload shard[-row|-col]` once the placement gate has decided to shard (BASELINE.json config 5:
+    4000 S2-shaped columns, 480 GB of tables): every rank holds its shard, every request runs partial
+    kernel -> RCCL all-to-all over xGMI -> finalize / concat as one native call (NativeShardedStep).  `--workload shard`
+    follows the gate's mixed preference (configs[4]: every table fits a GPU -> whole columns, 8x fewer bytes on the wire)
+    and ALSO times the row-sharded step BASELINE configs[4] names, reported beside it as `row_sharded_conformity`."""
+    from .placement import MIXED, ROW_SHARD
+    mode = "row" if placement.mode == ROW_SHARD else "mixed" if placement.mode == MIXED else "col"
+    elapsed, dev_s = _time_sharded_step(args, model, placement, mode, rank, world, local_rank, dist)
     batch = model.batch
     width = model.spec.group_width(0)
     from .ops import concat_inputs
     r0 = model.make_request(0)
     bytes_alg = model.spec.algorithmic_bytes(concat_inputs(r0.inputs)[2], r0.symbols)
-    sent = batch * width * 4 * (world - 1) / world / (1 if mode == "row" else world)   # bytes one rank sends per request
-    if mode == "mixed":
-        row_cols, per_rank = mixed_assignment(model.spec, placement.owners, world)
-        w_row = sum(model.spec.columns[k].dim for k in row_cols)
-        sent = batch * 4 * (world - 1) / world * (w_row + (width - w_row) / world)
-        per_gpu = bytes_alg["total"] / world + 2 * sent + batch * width * 4 * 2 / world + batch * w_row * 4
-        par = (f"mixed x{world}: {len(row_cols)} column(s) row-sharded (tables larger than one GPU: partial sums + fcp_shard_finalize), "
-               f"{sum(len(c) for c in per_rank)} whole (final blocks), grouped ncclSend/ncclRecv (RCCL over xGMI) + strided concat")
-    elif mode == "row":
-        # per-GPU algorithmic bytes: 1/world of the table rows, all ids, the partial
-        # [rows, width] written once, its slices sent / received, the final slice written
-        per_gpu = bytes_alg["rows"] / world + bytes_alg["ids"] + bytes_alg["boundaries"] + batch * width * 4 * (
-            1 + 2.0 * (world - 1) / world + 1.0 / world)
-        par = f"row-sharded x{world}: grouped ncclSend/ncclRecv of partial sums (RCCL over xGMI) + fcp_shard_finalize"
-    else:
-        # 1/world of the rows, ids and output; the block's remote slices sent / received,
-        # and (world > 1) the final [count, width] slice read + written by the concat
-        per_gpu = bytes_alg["total"] / world + batch * width * 4 / world * (
-            2.0 * (world - 1) / world + (2.0 if world > 1 else 0.0))
-        par = f"column-sharded x{world}: grouped ncclSend/ncclRecv of final column blocks (RCCL over xGMI) + concat"
-    dev_s = e0.elapsed_time(e1) * 1e-3 / args.steps
-    step.close()
-    if comm is not None:
-        comm.close()
-    return {
+
+    def accounting(mode):
+        """(bytes one rank sends per request, per-GPU algorithmic bytes, description)"""
+        sent = batch * width * 4 * (world - 1) / world / (1 if mode == "row" else world)
+        if mode == "mixed":
+            row_cols, per_rank = mixed_assignment(model.spec, placement.owners, world)
+            w_row = sum(model.spec.columns[k].dim for k in row_cols)
+            sent = batch * 4 * (world - 1) / world * (w_row + (width - w_row) / world)
+            per_gpu = bytes_alg["total"] / world + 2 * sent + batch * width * 4 * 2 / world + batch * w_row * 4
+            par = (f"mixed x{world}: {len(row_cols)} column(s) row-sharded (tables larger than one GPU: partial sums + fcp_shard_finalize), "
+                   f"{sum(len(c) for c in per_rank)} whole (final blocks), grouped ncclSend/ncclRecv (RCCL over xGMI) + strided concat")
+        elif mode == "row":
+            # per-GPU algorithmic bytes: 1/world of the table rows, all ids, the partial
+            # [rows, width] written once, its slices sent / received, the final slice written
+            per_gpu = bytes_alg["rows"] / world + bytes_alg["ids"] + bytes_alg["boundaries"] + batch * width * 4 * (
+                1 + 2.0 * (world - 1) / world + 1.0 / world)
+            par = f"row-sharded x{world}: grouped ncclSend/ncclRecv of partial sums (RCCL over xGMI) + fcp_shard_finalize"
+        else:
+            # 1/world of the rows, ids and output; the block's remote slices sent / received,
+            # and (world > 1) the final [count, width] slice read + written by the concat
+            per_gpu = bytes_alg["total"] / world + batch * width * 4 / world * (
+                2.0 * (world - 1) / world + (2.0 if world > 1 else 0.0))
+            par = f"column-sharded x{world}: grouped ncclSend/ncclRecv of final column blocks (RCCL over xGMI) + concat"
+        return sent, per_gpu, par
+
+    sent, per_gpu, par = accounting(mode)
+    rec = {
         "metric": f"inference QPS, {'row-sharded' if mode == 'row' else 'mixed-placement' if mode == 'mixed' else 'column-sharded'} tables (SHARD config)",
         "value": batch * args.steps / elapsed,
         "unit": "inferences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -615,3 +632,14 @@ def bench_sharded(args, model, placement, rank: int, world: int, local_rank: int
                      "frac": per_gpu / dev_s / 1e9 / 8000.0, "traffic": None,
                      "note": "per GPU, whole step (partial kernel + exchange + finalize / concat), events on the compute stream"},
     }
+    if getattr(args, "workload", "") == "shard" and mode != "row" and world > 1:
+        # BASELINE configs[4] says ROW-sharded: the conformity figure, in the same run, beside the gate's choice
+        e_row, d_row = _time_sharded_step(args, model, placement, "row", rank, world, local_rank, dist)
+        s_row, g_row, p_row = accounting("row")
+        rec["row_sharded_conformity"] = {
+            "what": "BASELINE configs[4] as written: every table row-sharded (id % world), partial sums exchanged + fcp_shard_finalize; "
+                    "`--workload shard-row` makes this the headline",
+            "value": batch * args.steps / e_row, "unit": "inferences/s", "ms_per_step": e_row * 1e3 / args.steps,
+            "parallelism": p_row, "exchange_bytes_sent_per_rank_per_request": int(s_row),
+            "roofline_frac": g_row / d_row / 1e9 / 8000.0}
+    return rec

@@ -187,6 +187,12 @@ def test_bench_gpus_2_starts_its_ranks_and_prints_one_line(workload):
         # `shard` follows the gate's mixed preference: every table of this model fits "one GPU" -> whole columns
         assert ("row-sharded" if workload == "shard-row" else "column-sharded") in rec["config"]["parallelism"]
         assert rec["config"]["exchange_bytes_sent_per_rank_per_request"] > 0
+        if workload == "shard":                                  # the gate's choice AND BASELINE configs[4]'s row sharding, one run
+            conf = rec["row_sharded_conformity"]
+            assert "row-sharded" in conf["parallelism"] and conf["value"] > 0
+            assert conf["exchange_bytes_sent_per_rank_per_request"] > rec["config"]["exchange_bytes_sent_per_rank_per_request"]
+        else:
+            assert "row_sharded_conformity" not in rec
 
 
 def build_fake_rccl():
