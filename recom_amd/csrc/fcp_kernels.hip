@@ -556,6 +556,27 @@ __device__ __forceinline__ void dense_body(const FcpLaunch &L, int bid, char *sm
   const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
 #endif
   const Hot H = load_hot(L);
+#if defined(FCP_ABLATE) && FCP_ABLATE == 6
+  // timing-only build 6 (S2's blob layout only; results are NOT the request's): what would a block-tile-major id layout buy?
+  // Every thread requests the 8-byte id words of its pairs at t = 0 — one contiguous 1152-byte chunk of valid int64 ids per
+  // block, at an address that needs nothing but the block index — in parallel with the slot map and the column records,
+  // instead of after them (the upper bound of "ids stored block-tile-major by ConcatInputs").
+  constexpr int PT4 = (FCP_WAVE * RB + FCP_BLOCK_THREADS - 1) / FCP_BLOCK_THREADS;
+  uint32_t early_lo[PT4], early_hi[PT4];
+  {
+    const int k = bid % 3000;
+    const char *chunk = H.blob + (size_t)(k % 100) * 38912 + 2048 + (size_t)(k / 100) * 1152;
+#pragma unroll
+    for (int h = 0; h < PT4; ++h) {
+      const int p = threadIdx.x + h * FCP_BLOCK_THREADS;
+      early_lo[h] = early_hi[h] = 0;
+      if (p < 160) { // a span of S2 holds 8-10 columns x 16 rows: the pairs a block really has
+        early_lo[h] = *as_global(reinterpret_cast<const uint32_t *>(chunk + 8 * (p % 144)));
+        early_hi[h] = *as_global(reinterpret_cast<const uint32_t *>(chunk + 8 * (p % 144) + 4));
+      }
+    }
+  }
+#endif
   if (!locate_block<RB>(L, H, bid, B)) return;
   const int tid = threadIdx.x;
   const int lane = tid & (FCP_WAVE - 1);
@@ -594,12 +615,19 @@ __device__ __forceinline__ void dense_body(const FcpLaunch &L, int bid, char *sm
     const int b = B.row_blk + p % RB;
     const unsigned form = FCP_F_FORM(pflags[h]);
     raw_lo[h] = raw_hi[h] = 0;
+#if defined(FCP_ABLATE) && FCP_ABLATE == 6
+    if (p < npairs && b < B.rows && form == FCP_FORM_GATHER) {
+      raw_lo[h] = early_lo[h];
+      raw_hi[h] = early_hi[h];
+    }
+#else
     if (p < npairs && b < B.rows && form == FCP_FORM_GATHER) {
       const bool is64 = FCP_F_IDSRC(pflags[h]) == FCP_IDS_I64;
       const char *a = pids[h] + (is64 ? 8 : 4) * (int64_t)b;
       raw_lo[h] = *as_global(reinterpret_cast<const uint32_t *>(a));
       raw_hi[h] = *as_global(reinterpret_cast<const uint32_t *>(a + (is64 ? 4 : 0)));
     }
+#endif
   }
 
   // ---- phase 0b: bucketize boundaries -> LDS (skipped when the span has none) --------------
