@@ -2291,7 +2291,7 @@ struct fcp_stager {
   fcp::PackPool *pool = nullptr;
   int n_threads = 1;
   std::mutex mu;
-  std::vector<int64_t> byte_off; // scratch
+  std::vector<int64_t> byte_off, in_off; // scratch
   bool zero_copy = false;        // the kernels read the pinned ring over PCIe themselves (no H2D copy)
   // FCP_STAGER_STATS=1: where a call spends its host time (ns per phase, printed when the stager is destroyed)
   bool stats = false;
@@ -2418,6 +2418,22 @@ int stage_layout(const fcp_host_tensor_t *inputs, int32_t n, const uint8_t *mode
   return FCP_OK;
 }
 
+// A request is a thousand or two SMALL tensors (RAGGED: 11 KB of ids and 22 KB of indices per column), each somewhere else
+// in memory: the hardware prefetcher starts over at every one of them.  While tensor i is packed the head of tensor
+// i + 1 is requested (FCP_PACK_PREFETCH_BYTES, default 2 KiB: tuning aid; 0 = off).
+inline void prefetch_head(const fcp_host_tensor_t &t) {
+  static const int64_t bytes = [] {
+    const char *e = std::getenv("FCP_PACK_PREFETCH_BYTES");
+    return e ? std::atoll(e) : (int64_t)2048;
+  }();
+  if (!t.data) return;
+  int64_t n = t.elem_size;
+  for (int32_t j = 0; j < t.rank; ++j) n *= t.dims[j];
+  if (n > bytes) n = bytes;
+  const char *p = static_cast<const char *>(t.data);
+  for (int64_t o = 0; o < n; o += 64) __builtin_prefetch(p + o, 0, 0);
+}
+
 // One input into its place in the staged blob (`nbytes` = its bytes there).
 // returns false for an input that cannot be converted: row ids that are not sorted (TF's SparseSegment* ops refuse them too)
 bool stage_pack_one(const fcp_host_tensor_t &t, int mode, int64_t mode_arg, char *dst, int64_t nbytes) {
@@ -2432,6 +2448,33 @@ bool stage_pack_one(const fcp_host_tensor_t &t, int mode, int64_t mode_arg, char
   return true;
 }
 const char *const kUnsortedRows = "row ids of a converted input are not sorted (segment ids must be non-decreasing)";
+
+// The pack of one request on a pool: contiguous ranges of inputs of about equal INPUT bytes per chunk (a converted index
+// matrix is 16 bytes per id in and 4 bytes per ROW out: output bytes say little about the work), the head of the next
+// input requested while the current one is packed.  `in_off`: scratch, n + 1 entries.  false: some row ids were not sorted.
+bool pack_on_pool(fcp::PackPool &pool, int n_threads, const fcp_host_tensor_t *inputs, int32_t n, const uint8_t *modes,
+                  const int64_t *mode_args, char *dst, const int64_t *bo, int64_t *in_off) {
+  in_off[0] = 0;
+  for (int32_t i = 0; i < n; ++i) {
+    int64_t ne = 1;
+    for (int32_t j = 0; j < inputs[i].rank; ++j) ne *= inputs[i].dims[j];
+    in_off[i + 1] = in_off[i] + ne * inputs[i].elem_size;
+  }
+  const int64_t total = in_off[n];
+  const int chunks = (int)std::min<int64_t>(std::max<int64_t>(1, total / (64 << 10)), 4 * n_threads);
+  std::atomic<int> refused{0};
+  pool.run(chunks, [&](int c) {
+    const int64_t b0 = total * c / chunks, b1 = total * (c + 1) / chunks;
+    int lo = (int)(std::lower_bound(in_off, in_off + n, b0) - in_off);
+    const int hi = c + 1 == chunks ? n : (int)(std::lower_bound(in_off, in_off + n, b1) - in_off); // (the last chunk also takes trailing empty inputs)
+    for (; lo < hi; ++lo) {
+      if (lo + 1 < hi) prefetch_head(inputs[lo + 1]);
+      if (!stage_pack_one(inputs[lo], modes ? modes[lo] : FCP_STAGE_COPY, mode_args ? mode_args[lo] : 0, dst + bo[lo], bo[lo + 1] - bo[lo]))
+        refused.store(1, std::memory_order_relaxed);
+    }
+  });
+  return refused.load() == 0;
+}
 } // namespace
 
 int fcp_stager_stage_ex(fcp_stager_t *s, const fcp_host_tensor_t *inputs, int32_t n, const uint8_t *modes,
@@ -2468,21 +2511,10 @@ int fcp_stager_stage_ex(fcp_stager_t *s, const fcp_host_tensor_t *inputs, int32_
   int rc2 = stage_layout(inputs, n, modes, mode_args, s->capacity, s->max_rank_sum, s->byte_off.data(), sl.offsets, sl.shapes, nullptr);
   if (rc2) return rc2;
   const int64_t size = s->byte_off[n];
-  const int chunks = (int)std::min<int64_t>(std::max<int64_t>(1, size / (64 << 10)), 4 * s->n_threads);
-  const int64_t *bo = s->byte_off.data();
-  char *dst = sl.h_blob;
   const uint64_t t_layout = s->stats ? now_ns() : 0;
-  std::atomic<int> refused{0};
-  s->pool->run(chunks, [&](int c) {
-    const int64_t b0 = size * c / chunks, b1 = size * (c + 1) / chunks;
-    // inputs whose start offset falls in [b0, b1)
-    int lo = (int)(std::lower_bound(bo, bo + n, b0) - bo);
-    const int hi = (int)(std::lower_bound(bo, bo + n, b1) - bo);
-    for (; lo < hi; ++lo)
-      if (!stage_pack_one(inputs[lo], modes ? modes[lo] : FCP_STAGE_COPY, mode_args ? mode_args[lo] : 0, dst + bo[lo], bo[lo + 1] - bo[lo]))
-        refused.store(1, std::memory_order_relaxed);
-  });
-  if (refused.load()) return fail(FCP_ERR_INVALID_ARGUMENT, kUnsortedRows); // nothing was enqueued; the slot is simply reused
+  s->in_off.resize((size_t)n + 1);
+  if (!pack_on_pool(*s->pool, s->n_threads, inputs, n, modes, mode_args, sl.h_blob, s->byte_off.data(), s->in_off.data()))
+    return fail(FCP_ERR_INVALID_ARGUMENT, kUnsortedRows); // nothing was enqueued; the slot is simply reused
   const uint64_t t_packed = s->stats ? now_ns() : 0;
   if (!s->zero_copy) {
     // the device twin is free once the work that read its previous contents has run
@@ -2578,27 +2610,9 @@ int fcp_concat_inputs_ex_pool(fcp_pack_pool_t *pool, const fcp_host_tensor_t *in
   const int rc = stage_layout(inputs, n, modes, mode_args, blob_capacity, -1, bo.data(), offsets, shapes, nullptr);
   if (rc) return rc;
   if (bo[n] > 0 && !blob) return fail(FCP_ERR_INVALID_ARGUMENT, "blob too small");
-  // ranges of inputs of about equal INPUT bytes (a converted index matrix is 16 bytes per id in, 4 per row out)
-  in_off[0] = 0;
-  for (int32_t i = 0; i < n; ++i) {
-    int64_t ne = 1;
-    for (int32_t j = 0; j < inputs[i].rank; ++j) ne *= inputs[i].dims[j];
-    in_off[i + 1] = in_off[i] + ne * inputs[i].elem_size;
-  }
-  const int64_t total = in_off[n];
-  const int chunks = (int)std::min<int64_t>(std::max<int64_t>(1, total / (64 << 10)), 4 * pool->n_threads);
-  const int64_t *io = in_off.data();
-  std::atomic<int> refused{0};
-  pool->pool->run(chunks, [&](int c) {
-    const int64_t b0 = total * c / chunks, b1 = total * (c + 1) / chunks;
-    int lo = (int)(std::lower_bound(io, io + n, b0) - io);
-    const int hi = c + 1 == chunks ? n : (int)(std::lower_bound(io, io + n, b1) - io); // (the last chunk also takes trailing empty inputs)
-    for (; lo < hi; ++lo)
-      if (!stage_pack_one(inputs[lo], modes ? modes[lo] : FCP_STAGE_COPY, mode_args ? mode_args[lo] : 0, static_cast<char *>(blob) + bo[lo],
-                          bo[lo + 1] - bo[lo]))
-        refused.store(1, std::memory_order_relaxed);
-  });
-  return refused.load() ? fail(FCP_ERR_INVALID_ARGUMENT, kUnsortedRows) : FCP_OK;
+  return pack_on_pool(*pool->pool, pool->n_threads, inputs, n, modes, mode_args, static_cast<char *>(blob), bo.data(), in_off.data())
+             ? FCP_OK
+             : fail(FCP_ERR_INVALID_ARGUMENT, kUnsortedRows);
 }
 
 int fcp_stager_stage(fcp_stager_t *s, const fcp_host_tensor_t *inputs, int32_t n, void *stream,

@@ -4,6 +4,7 @@
 // multi-versioning): they read 16 bytes per id of a request and are what the CPU op spends its time in.
 #include <stddef.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #if defined(__x86_64__) && defined(__has_attribute)
@@ -75,8 +76,102 @@ template <typename T> static inline int seg_to_csr_t(const T *p, int64_t stride,
   return descending;
 }
 
-// returns 1 if the ids were not sorted (the offsets are then meaningless), else 0
-extern "C" FCP_CLONES int fcp_pack_seg_to_csr(const void *seg, int elem_size, int64_t stride, int64_t nnz, int64_t rows, int32_t *out) {
+// the run-length form for any element size / stride, built per instruction set
+FCP_CLONES static int seg_to_csr_any(const void *seg, int elem_size, int64_t stride, int64_t nnz, int64_t rows, int32_t *out) {
   if (elem_size == 8) return seg_to_csr_t(static_cast<const int64_t *>(seg), stride, nnz, rows, out);
   return seg_to_csr_t(static_cast<const int32_t *>(seg), stride, nnz, rows, out);
+}
+
+#if defined(__x86_64__)
+#include <immintrin.h>
+// The same offsets from the BOUNDARIES of the sorted ids, 16 ids per step (AVX-512): offsets[r] = the first position whose
+// id is >= r.  One pass: the row words of 16 ids are taken out of the index matrix with two permutes (int64, stride 2: the
+// SparseTensor indices [nnz, 2] of BASELINE configs[3]) or loaded as they are (stride 1), clamped to [-1, rows] and
+// narrowed; a lane-shifted copy gives every id its predecessor; one compare marks the positions where a new row starts
+// (one id in ~5: the only scalar work left), another the descents.  The run-length form above spends ~6 cycles on every
+// id in a dependent chain and runs at half the speed of a plain read of the same bytes
+// (profiles/r03_pcie_staging_phase_timers.txt: 1108 vs 530 us per RAGGED request on one core); this one follows the read.
+enum { kSegI64x2 = 0, kSegI64 = 1, kSegI32 = 2 };
+
+__attribute__((target("avx512f"))) static inline __m512i seg_rows16(int kind, const void *seg, int64_t i, __m512i lo64, __m512i hi64) {
+  if (kind == kSegI64x2) {
+    const int64_t *q = static_cast<const int64_t *>(seg) + 2 * i;
+    const __m512i even = _mm512_setr_epi64(0, 2, 4, 6, 8, 10, 12, 14);
+    const __m512i a = _mm512_permutex2var_epi64(_mm512_loadu_si512(q), even, _mm512_loadu_si512(q + 8));
+    const __m512i b = _mm512_permutex2var_epi64(_mm512_loadu_si512(q + 16), even, _mm512_loadu_si512(q + 24));
+    return _mm512_inserti64x4(_mm512_castsi256_si512(_mm512_cvtepi64_epi32(_mm512_min_epi64(_mm512_max_epi64(a, lo64), hi64))),
+                              _mm512_cvtepi64_epi32(_mm512_min_epi64(_mm512_max_epi64(b, lo64), hi64)), 1);
+  }
+  if (kind == kSegI64) {
+    const int64_t *q = static_cast<const int64_t *>(seg) + i;
+    const __m512i a = _mm512_loadu_si512(q), b = _mm512_loadu_si512(q + 8);
+    return _mm512_inserti64x4(_mm512_castsi256_si512(_mm512_cvtepi64_epi32(_mm512_min_epi64(_mm512_max_epi64(a, lo64), hi64))),
+                              _mm512_cvtepi64_epi32(_mm512_min_epi64(_mm512_max_epi64(b, lo64), hi64)), 1);
+  }
+  const __m512i x = _mm512_loadu_si512(static_cast<const int32_t *>(seg) + i);
+  const __m512i hi32 = _mm512_broadcastd_epi32(_mm512_castsi512_si128(hi64)); // (the low dword of the 64-bit limit: rows <= 2^31 - 1)
+  return _mm512_min_epi32(_mm512_max_epi32(x, _mm512_set1_epi32(-1)), hi32);
+}
+
+__attribute__((target("avx512f"))) static int seg_to_csr_avx512(int kind, const void *seg, int64_t nnz, int64_t rows, int32_t *out) {
+  const int32_t hi = (int32_t)(rows < 0x7fffffff ? rows : 0x7fffffff);
+  const __m512i lo64 = _mm512_set1_epi64(-1), hi64 = _mm512_set1_epi64(hi);
+  auto row_at = [&](int64_t i) -> int32_t { // the clamped row of one id (the last < 16 of them)
+    const int64_t r = kind == kSegI64x2 ? static_cast<const int64_t *>(seg)[2 * i]
+                                        : kind == kSegI64 ? static_cast<const int64_t *>(seg)[i] : (int64_t) static_cast<const int32_t *>(seg)[i];
+    return (int32_t)(r < -1 ? -1 : (r > hi ? hi : r));
+  };
+  int64_t next_row = 0; // offsets[0 .. next_row) are written
+  int descending = 0;
+  alignas(64) int32_t cur_a[16];
+  auto boundary = [&](int32_t r, int64_t pos) { // the first id of row r (> every row before it) sits at position pos
+    const int64_t top = r < hi ? r : hi;
+    for (int64_t rr = next_row; rr <= top; ++rr) out[rr] = (int32_t)pos;
+    if (top + 1 > next_row) next_row = top + 1;
+  };
+  int64_t i = 0;
+  __m512i last = _mm512_set1_epi32(-1); // "the row before the first id": ids of rows < 0 (clamped to -1) never start a row
+  for (; i + 16 <= nnz; i += 16) {
+    const __m512i cur = seg_rows16(kind, seg, i, lo64, hi64);
+    const __m512i prv = _mm512_alignr_epi32(cur, last, 15); // lane j = row of id i + j - 1
+    last = cur;
+    const __mmask16 up = _mm512_cmpgt_epi32_mask(cur, prv);
+    descending |= (int)_mm512_cmplt_epi32_mask(cur, prv);
+    if (up) {
+      _mm512_store_si512(cur_a, cur);
+      unsigned m = up;
+      do {
+        const int j = __builtin_ctz(m);
+        m &= m - 1;
+        boundary(cur_a[j], i + j);
+      } while (m);
+    }
+  }
+  int32_t prev = -1;
+  if (i > 0) {
+    _mm512_store_si512(cur_a, last);
+    prev = cur_a[15];
+  }
+  for (; i < nnz; ++i) {
+    const int32_t r = row_at(i);
+    descending |= (int)(r < prev);
+    if (r > prev) boundary(r, i);
+    prev = r;
+  }
+  for (int64_t rr = next_row; rr <= rows; ++rr) out[rr] = (int32_t)nnz; // the rows behind the last id's
+  return descending != 0;
+}
+#endif
+
+// returns 1 if the ids were not sorted (the offsets are then meaningless), else 0
+extern "C" int fcp_pack_seg_to_csr(const void *seg, int elem_size, int64_t stride, int64_t nnz, int64_t rows, int32_t *out) {
+#if defined(__x86_64__)
+  static const bool avx512 = __builtin_cpu_supports("avx512f") && !getenv("FCP_PACK_NO_AVX512"); // (tuning / test aid)
+  if (avx512 && rows >= 0 && nnz < 0x7fffffff) {
+    if (elem_size == 8 && stride == 2) return seg_to_csr_avx512(kSegI64x2, seg, nnz, rows, out);
+    if (elem_size == 8 && stride == 1) return seg_to_csr_avx512(kSegI64, seg, nnz, rows, out);
+    if (elem_size == 4 && stride == 1) return seg_to_csr_avx512(kSegI32, seg, nnz, rows, out);
+  }
+#endif
+  return seg_to_csr_any(seg, elem_size, stride, nnz, rows, out);
 }

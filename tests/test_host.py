@@ -508,6 +508,64 @@ def test_placement_gate():
     assert p.mode == MIXED and p.owners[0] == -1 and sorted(p.owners[1:]) == [0, 1, 2, 3]
 
 
+def test_row_ids_to_row_offsets_loop_both_code_paths():
+    """fcp_pack_seg_to_csr (the host loop behind FCP_STAGE_SEG_TO_CSR): sorted row ids -> offsets[rows + 1], offsets[r] = the
+    number of ids below row r — ComputeSegmentOffsets (cuda_emitter.cc:768-818) on the host.  The AVX-512 boundary form
+    (int64 stride 2 = SparseTensor indices, int64 / int32 stride 1) and the portable run-length form (any stride; forced
+    with FCP_PACK_NO_AVX512 in a child process) against NumPy on adversarial inputs: empty, one id, nnz around multiples of
+    16, empty rows at both ends, ids of rows < 0 and >= rows (dropped), values beyond int32, unsorted ids (refused)."""
+    import ctypes as C
+    import subprocess
+    import sys
+    code = r"""
+import ctypes as C, numpy as np, sys
+sys.path.insert(0, %r)
+from recom_amd import lib
+L = lib.load()
+L.fcp_pack_seg_to_csr.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]
+rng = np.random.default_rng(5)
+def check(rows_of, rows, dtype, stride):
+    n = rows_of.size
+    mat = np.zeros((n, stride), dtype)
+    mat[:, 0] = rows_of.astype(dtype) if n else 0
+    if stride > 1:
+        mat[:, 1:] = rng.integers(0, 7, (n, stride - 1))
+    out = np.full(rows + 1, -777, np.int32)
+    rc = L.fcp_pack_seg_to_csr(mat.ctypes.data, mat.dtype.itemsize, stride, n, rows, out.ctypes.data)
+    srt = bool(np.all(np.diff(rows_of) >= 0))
+    assert rc == (0 if srt else 1), (rc, srt)
+    if srt:
+        clamped = np.clip(rows_of.astype(np.int64), -1, rows)
+        want = np.searchsorted(clamped, np.arange(rows + 1), side="left").astype(np.int32)
+        assert np.array_equal(out, want), (dtype, stride, n, rows, out[:8], want[:8])
+cases = 0
+for dtype, strides in ((np.int64, (1, 2, 3)), (np.int32, (1, 2))):
+    for rows in (1, 2, 7, 64, 257, 1000):
+        for n in (0, 1, 2, 15, 16, 17, 31, 32, 33, 100, 1000, 4099):
+            for flavour in range(5):
+                if flavour == 0:
+                    r = np.sort(rng.integers(0, rows, n))
+                elif flavour == 1:                                   # empty rows at both ends, long runs
+                    r = np.sort(rng.integers(rows // 3, max(rows // 3 + 1, rows // 2), n))
+                elif flavour == 2:                                   # strays: below 0 and at / beyond `rows`
+                    r = np.sort(rng.integers(-5, rows + 5, n))
+                elif flavour == 3:                                   # values that do not fit int32 (int64 inputs only)
+                    r = np.sort(rng.integers(0, rows, n))
+                    if n and dtype == np.int64:
+                        r[-1:] = 2 ** 40
+                        r[:1] = -(2 ** 40)
+                else:                                                # not sorted: refused
+                    r = rng.integers(0, rows, n)
+                for stride in strides:
+                    check(np.asarray(r, np.int64), rows, dtype, stride)
+                    cases += 1
+print("ok", cases)
+""" % ROOT
+    for env_extra in ({}, {"FCP_PACK_NO_AVX512": "1"}):
+        res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env={**os.environ, **env_extra}, timeout=600)
+        assert res.returncode == 0 and res.stdout.startswith("ok"), res.stderr[-3000:] + res.stdout[-500:]
+
+
 def test_hot_kernels_keep_full_occupancy(tmp_path):
     """The fused kernels must stay at <= 64 VGPRs (8 waves per SIMD, MI355X_MICROARCH.md register table) and
     use no scratch: round 2 lost 2 us of 29 on S2 when a rarely-taken branch (the id transform) pushed the
