@@ -322,7 +322,10 @@ def main():
                     help="skip the extra overlapped-serving pass (3 streams): keeps a kernel trace of this run single-stream")
     ap.add_argument("--vocab", type=int, default=0, help="override the vocabulary size (debug only)")
     ap.add_argument("--batch", type=int, default=0, help="override the batch size (debug only)")
-    ap.add_argument("--requests", type=int, default=16, help="distinct resident requests cycled through")
+    ap.add_argument("--requests", type=int, default=0,
+                    help="distinct resident requests cycled through (default: 16; 64 for the dynamic-shape workloads ragged / e / f, "
+                         "more than the plan's 32 descriptor slots: every request brings shapes that are NOT resident, as real "
+                         "dynamic-shape traffic does)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) normally; gloo only to exercise the N>1 control flow on a 1-GPU box")
     args = ap.parse_args()
 
@@ -372,6 +375,8 @@ def main():
                                    **({'vocab': args.vocab} if args.vocab else {}),
                                    **({'max_len': args.max_len} if args.max_len else {}))
 
+    if not args.requests:
+        args.requests = 64 if args.workload in ("ragged", "e", "f") else 16
     raw_model = model
     # Workloads with SparseTensor features (RAGGED; the reference's models E / F) are timed in the form the rewritten
     # graph's Addons>ConcatInputs leaves in HBM (plan-file stage section: ids int32, row offsets) unless --as-delivered
