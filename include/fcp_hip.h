@@ -457,6 +457,22 @@ int fcp_process_feature_columns(fcp_plan_t *plan,
  * more: slower than one stream, profiles/r04_private_streams_sweep.txt). */
 enum { FCP_PRIVATE_NO_CALLER_WAIT = 1u << 0, FCP_PRIVATE_ALWAYS = 1u << 1 };
 int fcp_plan_set_private_streams(fcp_plan_t *plan, int32_t n_streams, uint32_t flags);
+
+/* The cheap half of the same idea, for callers that OWN their buffers: FCP_ORDER_INPUTS_READY is the caller's promise, for
+ * every request of the plan, that when fcp_process_feature_columns is CALLED the blob is complete in device memory and
+ * nothing still queued or running on args->stream touches the memory malloc_buff returns.  The fused kernel is then
+ * launched without the queue's barrier bit: it may begin while the commands queued in front of it on args->stream still
+ * run, so the tail of request k covers the kernel boundary and the dependent front of request k + 1 — on ONE stream,
+ * without events or extra streams (S2 back to back: 28.3 -> 26.0-26.5 us per request, 0.60-0.61 of 8 TB/s; Zipf ids
+ * 25.4 -> 23.4).  Everything queued BEHIND the kernel on args->stream (the consumer) still waits for it, as any
+ * stream-ordered command waits for all commands before it — which is also why the gain is only there while requests
+ * follow each other directly: an ordinary command between two requests (a consumer kernel, an event record) orders
+ * the second request behind the first again; private streams (above) are the tool for that pattern.  NOT for
+ * TensorFlow's allocator, which hands out memory that earlier, still queued kernels of the compute stream may be using.
+ * Requests that queue work of their own in front of the kernel (segment-offset pre-pass, descriptor upload kernel)
+ * keep stream order.  Default: FCP_ORDER_STREAM. */
+enum { FCP_ORDER_STREAM = 0, FCP_ORDER_INPUTS_READY = 1 };
+int fcp_plan_set_request_order(fcp_plan_t *plan, int32_t order);
 int fcp_result_wait(const void *buffer, void *stream);
 int fcp_result_synchronize(const void *buffer);
 

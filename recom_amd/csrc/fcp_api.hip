@@ -231,6 +231,7 @@ struct fcp_plan {
   // the work of the shapes it installed last (gathered rows + output bytes); lighter requests stay on the caller's stream.
   std::atomic<int64_t> last_work_bytes{0};
   int64_t lane_min_work = 0;
+  int32_t request_order = FCP_ORDER_STREAM; // fcp_plan_set_request_order
 };
 
 namespace {
@@ -1875,6 +1876,13 @@ int fcp_internal_process(fcp_plan_t *p, const fcp_process_args_t *a, fcp_process
       if (armed) fcp_set_stop_event(nullptr);
     }
   } clear_stop{attach_done};
+  // FCP_ORDER_INPUTS_READY: nothing this kernel reads or writes depends on the commands queued in front of it — unless this
+  // very call has queued some (segment-offset pre-pass, inverse-map memset, descriptor upload kernel): then stream order it is
+  const bool queued_before = (!p->seg_cols.empty() && !m.seg_search) || (install && !p->host_writes_dyn);
+  struct ClearAnyOrder {
+    ~ClearAnyOrder() { fcp_set_any_order(false); }
+  } clear_any_order;
+  if (p->request_order == FCP_ORDER_INPUTS_READY && !queued_before && !capturing) fcp_set_any_order(true);
   // hybrid dispatch: spans with pooled columns -> ragged body, all other spans -> dense body
   if (m.geo[1].grid_blocks > 0 && m.geo[0].grid_blocks > 0) {
     FcpLaunch Ld;
@@ -1966,6 +1974,12 @@ int fcp_plan_set_private_streams(fcp_plan_t *p, int32_t n_streams, uint32_t flag
       HIP_TRY(hipEventCreateWithFlags(&L.out[i], hipEventDisableTiming | hipEventDisableSystemFence));
     }
   }
+  return FCP_OK;
+}
+
+int fcp_plan_set_request_order(fcp_plan_t *p, int32_t order) {
+  if (!p || (order != FCP_ORDER_STREAM && order != FCP_ORDER_INPUTS_READY)) return fail(FCP_ERR_INVALID_ARGUMENT, "bad request order");
+  p->request_order = order;
   return FCP_OK;
 }
 

@@ -135,6 +135,8 @@ struct ihipStream_t;
 // the next fused / hybrid launch of THIS thread carries `event` (hipEvent_t) as its stop event; pending = not taken yet
 void fcp_set_stop_event(void *event);
 bool fcp_stop_event_pending();
+// the next fused / hybrid launch of THIS thread is an any-order launch (no barrier bit); cleared by the launch
+void fcp_set_any_order(bool on);
 int fcp_launch_fused(const FcpLaunch &L, int vec, bool dense_kernel, int grid_blocks, ihipStream_t *s);
 int fcp_launch_hybrid(const FcpLaunch &Ldense, int dense_blocks, const FcpLaunch &Lragged, int ragged_blocks, int vec,
                       ihipStream_t *s);

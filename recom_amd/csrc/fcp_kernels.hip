@@ -1480,12 +1480,20 @@ __global__ void __launch_bounds__(FCP_BLOCK_THREADS) fcp_upload_kernel(const uin
 static thread_local hipEvent_t tl_stop_event = nullptr;
 void fcp_set_stop_event(void *ev) { tl_stop_event = static_cast<hipEvent_t>(ev); }
 bool fcp_stop_event_pending() { return tl_stop_event != nullptr; }
+// FCP_ORDER_INPUTS_READY plans (fcp_plan_set_request_order): the next fused / hybrid launch of this thread goes out WITHOUT
+// the barrier bit (hipExtAnyOrderLaunch): it may start while the commands queued in front of it on the same stream still
+// run — the previous request's kernel above all, whose tail then covers this one's kernel boundary and dependent front
+// (S2: 28.3 -> 26.0-26.5 us per request back to back on one stream, no events, no extra streams).
+static thread_local int tl_launch_flags = 0;
+void fcp_set_any_order(bool on) { tl_launch_flags = on ? (int)hipExtAnyOrderLaunch : 0; }
 #define FCP_KLAUNCH(KERNEL, GRID, BLOCK, LDS, STREAM, ...)                                      \
   do {                                                                                          \
     hipEvent_t stop_ = tl_stop_event;                                                           \
+    const int flags_ = tl_launch_flags;                                                         \
     tl_stop_event = nullptr;                                                                    \
-    if (stop_)                                                                                  \
-      hipExtLaunchKernelGGL(KERNEL, GRID, BLOCK, LDS, STREAM, nullptr, stop_, 0, __VA_ARGS__);  \
+    tl_launch_flags = 0;                                                                        \
+    if (stop_ || flags_)                                                                        \
+      hipExtLaunchKernelGGL(KERNEL, GRID, BLOCK, LDS, STREAM, nullptr, stop_, flags_, __VA_ARGS__); \
     else                                                                                        \
       hipLaunchKernelGGL(KERNEL, GRID, BLOCK, LDS, STREAM, __VA_ARGS__);                        \
   } while (0)

@@ -231,6 +231,11 @@ class Plan:
                    "fcp_plan_set_private_streams")
         self.private_streams = int(n_streams)
 
+    def set_inputs_ready(self, on: bool = True) -> None:
+        """``fcp_plan_set_request_order(FCP_ORDER_INPUTS_READY)``: the caller's promise that blobs are complete and arenas
+        unused when a request is issued; consecutive requests of one stream then overlap (any-order kernel launch)."""
+        _lib.check(self._L.fcp_plan_set_request_order(self.handle, 1 if on else 0), "fcp_plan_set_request_order")
+
     def read_bad_ids(self, stream: int = 0) -> int:
         out = C.c_int64()
         _lib.check(self._L.fcp_plan_read_bad_ids(self.handle, stream, C.byref(out)), "fcp_plan_read_bad_ids")
