@@ -516,7 +516,7 @@ def main():
         "verified": verified,
         "p50_latency_ms": float(np.percentile(it, 50)), "p95_latency_ms": float(np.percentile(it, 95)),
         "latency_scope": f"device latency of one request (HIP event pair around it on the launch stream, {len(it)} samples), "
-                         "inputs resident in HBM; host packing + H2D are reported separately (DESIGN.md section 4, PCIe-inclusive rate)",
+                         "inputs resident in HBM; host packing + H2D are reported separately (profiles/HISTORY.md, PCIe-inclusive rate; DESIGN.md section 5)",
     }
     if rank == 0:
         achieved = bytes_alg["total"] / (dev_ms_per_req * 1e-3) / 1e9

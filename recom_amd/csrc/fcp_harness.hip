@@ -287,7 +287,7 @@ int fcp_harness_destroy(fcp_harness *h) {
 // Device-side copy bandwidth probe (float4 copy of `bytes` bytes, `iters` times): the "measured copy
 // peak" the roofline is also quoted against.  One element per thread — the shape that reaches the
 // highest rate on MI355X (6.0-6.25 TB/s read+write; a grid-stride loop over the same buffers only
-// reaches 4.6-4.95 TB/s, scripts/probes/copy_variants.hip).
+// reaches 4.6-4.95 TB/s, scripts/probes/copy_variants.hip, profiles/HISTORY.md section 4).
 __global__ void __launch_bounds__(256) fcp_copy_probe_kernel(const float4 *__restrict__ src,
                                                              float4 *__restrict__ dst, size_t n) {
   typedef float __attribute__((ext_vector_type(4))) f4;

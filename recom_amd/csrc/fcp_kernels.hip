@@ -766,7 +766,7 @@ __global__ void __launch_bounds__(FCP_BLOCK_THREADS) fcp_dense_kernel(const FcpL
 }
 
 // Table reads a lane of the ragged kernel keeps in flight while it walks a bag (tuning builds:
-// 12 / 16 need 71 / 87 VGPRs and lose more to occupancy than they gain).
+// 12 / 16 need 71 / 87 VGPRs and lose more to occupancy than they gain, profiles/HISTORY.md section 4).
 #if !defined(FCP_WALK)
 #define FCP_WALK 8
 #endif
@@ -806,7 +806,7 @@ __global__ void __launch_bounds__(FCP_BLOCK_THREADS) fcp_dense_kernel(const FcpL
 // rows behind four barriers, 19.7 KB of LDS); measured against this form on RAGGED,
 // E and F the two are equal within noise (30.3-30.7 us RAGGED): a launch is bounded
 // by its ramp, tail and the ~2.4 us kernel boundary, not by the barriers
-// (DESIGN.md section 4).  The wave-scope form stays: 15.1 KB of LDS, one barrier.
+// (profiles/HISTORY.md section 4b).  The wave-scope form stays: 15.1 KB of LDS, one barrier.
 // The kernel is instruction-issue bound rather than HBM bound (rocprofv3: ~490
 // VALU per wave before this layout), hence the pre-scaled 32-bit slot offsets:
 // a table read costs one LDS read, one compare, one 64-bit shift-add, one load.

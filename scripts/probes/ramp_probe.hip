@@ -1,4 +1,4 @@
-// ramp_probe — what does the FRONT of a launch cost on this box?  (round 2)
+// ramp_probe — what does the FRONT of a launch cost on this box?  (round 2, profiles/HISTORY.md section 4b)
 //
 // A grid shaped like the S2 dense launch (3776 blocks x 256 threads, 640-byte by-value argument,
 // 8 blocks per CU resident) in which every block runs a chain of dependent loads and stamps
