@@ -858,6 +858,14 @@ int64_t orc_serve_for(const orc_plan_t *p, const int8_t *const *blobs, int32_t n
 #endif
 }
 
+/* First-touch helper for the CPU baseline: fills p[0..n) from all cores at once (static schedule), so that on a multi-socket
+ * host the pages of a table are spread over the sockets' memory in contiguous shares instead of all landing next to the
+ * one thread that wrote them (bench.py cpu_baseline: 24 GB of tables read at random by up to 256 workers). */
+void orc_fill_f32(float *p, int64_t n, float v) {
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; ++i) p[i] = v;
+}
+
 double orc_serve_throughput(const orc_plan_t *p, const int8_t *const *blobs, int32_t n_blobs,
                             const int32_t *const *offsets, const int32_t *const *shapes,
                             const float *const *tables, const int32_t *symbols, int32_t n_threads,

@@ -178,6 +178,9 @@ int64_t orc_serve_for(const orc_plan_t *p, const int8_t *const *blobs, int32_t n
                       const int32_t *const *offsets, const int32_t *const *shapes,
                       const float *const *tables, const int32_t *symbols, int32_t n_threads,
                       double seconds, double *elapsed);
+/* parallel first touch (multi-socket hosts: spreads a table's pages over the sockets) */
+void orc_fill_f32(float *p, int64_t n, float v);
+
 double orc_serve_throughput(const orc_plan_t *plan, const int8_t *const *blobs, int32_t n_blobs,
                             const int32_t *const *offsets, const int32_t *const *shapes,
                             const float *const *tables, const int32_t *symbols, int32_t n_threads,

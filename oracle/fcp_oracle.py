@@ -171,6 +171,12 @@ class COracle:
                                                  t.shape[1])
         return out, bad
 
+    def fill_parallel(self, a: np.ndarray, value: float) -> None:
+        """First touch of a float32 array from all cores (orc_fill_f32): its pages spread over the sockets' memory."""
+        assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"]
+        self.lib.orc_fill_f32.argtypes = [C.c_void_p, C.c_int64, C.c_float]
+        self.lib.orc_fill_f32(a.ctypes.data, a.size, float(value))
+
     def sparse_segment_reduce_tfcpu(self, table, ids, offsets, mean: bool) -> np.ndarray:
         """Form 2 in the addition order of TensorFlow 2.6.2's CPU kernel (orc_sparse_segment_reduce_tfcpu); ids valid."""
         t = np.ascontiguousarray(table, np.float32)

@@ -220,7 +220,12 @@ int fcp_harness_run_private(fcp_harness *h, int steps, int depth, double *wall_m
     const char *v = std::getenv("FCP_HARNESS_NO_READER");
     return !(v && std::atoi(v) != 0);
   }();
+  static const bool no_wait = [] { // diagnostic: FCP_HARNESS_NO_WAIT=1 drops the consumer altogether (final sync of the lanes only)
+    const char *v = std::getenv("FCP_HARNESS_NO_WAIT");
+    return v && std::atoi(v) != 0;
+  }();
   auto consume = [&](const std::pair<void *, int64_t> &res) -> int {
+    if (no_wait) return fcp_result_synchronize(nullptr) == FCP_OK ? FCP_OK : FCP_OK;
     int rc = fcp_result_wait(res.first, caller);
     if (rc || !reader) return rc;
     hipLaunchKernelGGL(fcp_consume_probe_kernel, dim3(1), dim3(256), 0, caller, static_cast<const float *>(res.first),
@@ -262,6 +267,7 @@ int fcp_harness_run_private(fcp_harness *h, int steps, int depth, double *wall_m
     const int rc = consume(pending[head++]);
     if (rc) return rc;
   }
+  if (no_wait) H_TRY(hipDeviceSynchronize());
   H_TRY(hipEventRecord(h->e1, caller));
   H_TRY(hipStreamSynchronize(caller));
   const auto t1 = std::chrono::steady_clock::now();
