@@ -200,3 +200,59 @@ def test_inputs_ready_requests_overlap_on_one_stream_and_consumers_still_wait(to
             for r, p, snap in zip(reqs, packed, snaps):
                 want, _ = oracle.process_feature_columns(m.spec.to_dict(), p[0], p[1], p[2], tabs_np, r.symbols)
                 assert np.array_equal(snap.cpu().numpy(), want[0]), (m.name, burst)
+
+
+def test_host_threads_share_a_plan_with_private_streams(torch_cuda, oracle):
+    """The reference harness' serve workers share one Session — several host threads call the op concurrently, here each
+    with its own caller stream (and, second pass, ALL on one stream: TensorFlow's single compute stream) over ONE plan with
+    three private streams: lane rotation, per-lane event pairs and the result registry under concurrency; every result
+    bit-exact with the oracle."""
+    import threading
+    from recom_amd import synth
+    from recom_amd.ops import FeatureColumnProcess, concat_inputs
+    torch = torch_cuda
+    m = synth.model_mixed(batch=120, vocab=2999, n_groups=1)
+    tabs_np = m.numpy_tables()
+    tabs = [torch.from_numpy(t).cuda() for t in tabs_np]
+    op = FeatureColumnProcess(m.spec, 0)
+    op.plan.set_private_streams(3, always=True)
+    n_threads, per_thread = 4, 10
+    reqs = [[m.make_request(2000 + 100 * t + k, B=90 + 3 * t + k) for k in range(per_thread)] for t in range(n_threads)]
+    packed = [[concat_inputs(r.inputs) for r in rs] for rs in reqs]
+    blobs = [[torch.from_numpy(p[0]).cuda() for p in ps] for ps in packed]
+    want = [[oracle.process_feature_columns(m.spec.to_dict(), p[0], p[1], p[2], tabs_np, r.symbols)[0][0] for r, p in zip(rs, ps)]
+            for rs, ps in zip(reqs, packed)]
+    torch.cuda.synchronize()
+    for shared_stream in (False, True):
+        one = torch.cuda.Stream()
+        errors, results = [], [[None] * per_thread for _ in range(n_threads)]
+
+        def worker(t):
+            try:
+                s = one if shared_stream else torch.cuda.Stream()
+                pending = []
+                with torch.cuda.stream(s):
+                    for k in range(per_thread):
+                        out = op(blobs[t][k], packed[t][k][1], packed[t][k][2], tabs, reqs[t][k].symbols, defer_wait=True)
+                        pending.append((k, out))
+                        if len(pending) >= 2:
+                            j, o = pending.pop(0)
+                            o.wait()
+                            results[t][j] = (o, o.groups[0].clone())
+                    for j, o in pending:
+                        o.wait()
+                        results[t][j] = (o, o.groups[0].clone())
+                s.synchronize()
+            except BaseException as e:  # noqa: BLE001
+                errors.append((t, repr(e)))
+
+        threads = [threading.Thread(target=worker, args=(t,)) for t in range(n_threads)]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+        assert not errors, errors
+        torch.cuda.synchronize()
+        for t in range(n_threads):
+            for k in range(per_thread):
+                assert np.array_equal(results[t][k][1].cpu().numpy(), want[t][k]), (shared_stream, t, k)
