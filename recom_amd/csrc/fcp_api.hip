@@ -2303,6 +2303,8 @@ namespace {
 
 struct StageSlot {
   char *h_blob = nullptr; // pinned
+  char *h_blob_dev = nullptr; // the device's mapping of h_blob (what a zero-copy slot hands out)
+  bool direct = false;    // the slot's current contents are read from the pinned buffer (zero copy, or the fallback below)
   char *d_blob = nullptr;
   int32_t *offsets = nullptr, *shapes = nullptr;
   hipEvent_t copied = nullptr;   // H2D of this slot done (copy stream)
@@ -2325,6 +2327,13 @@ struct fcp_stager {
   std::mutex mu;
   std::vector<int64_t> byte_off, in_off; // scratch
   bool zero_copy = false;        // the kernels read the pinned ring over PCIe themselves (no H2D copy)
+  // Fallback of the copying mode: on a busy host hipMemcpyAsync sometimes BLOCKS the caller for 25-70 us per call, request
+  // after request (profiles/r04_pcie_staging_memcpy_anomaly.txt: one run in two with unpinned pack workers, rarely with
+  // pinned ones), which doubles the pipelined time.  Eight such calls among the last 32 and the next 256 requests are served zero
+  // copy (steady 65 us on S2); then the copy engine gets another chance.  FCP_STAGER_NO_FALLBACK=1 disables it.
+  uint32_t blocked_hist = 0;
+  int direct_left = 0;
+  uint64_t n_fallbacks = 0, n_blocked = 0;
   // FCP_STAGER_STATS=1: where a call spends its host time (ns per phase, printed when the stager is destroyed)
   bool stats = false;
   uint64_t n_calls = 0, ns_wait = 0, ns_layout = 0, ns_pack = 0, ns_enqueue = 0, ns_api[4] = {0, 0, 0, 0};
@@ -2361,8 +2370,8 @@ int fcp_stager_create_ex(int32_t device, int64_t capacity_bytes, int32_t max_inp
   s->slots.resize(depth);
   for (auto &sl : s->slots) {
     if (hipHostMalloc(reinterpret_cast<void **>(&sl.h_blob), capacity_bytes, hipHostMallocMapped) != hipSuccess ||
-        (s->zero_copy ? hipHostGetDevicePointer(reinterpret_cast<void **>(&sl.d_blob), sl.h_blob, 0)
-                      : hipMalloc(reinterpret_cast<void **>(&sl.d_blob), capacity_bytes)) != hipSuccess ||
+        hipHostGetDevicePointer(reinterpret_cast<void **>(&sl.h_blob_dev), sl.h_blob, 0) != hipSuccess ||
+        (s->zero_copy ? ((sl.d_blob = sl.h_blob_dev), hipSuccess) : hipMalloc(reinterpret_cast<void **>(&sl.d_blob), capacity_bytes)) != hipSuccess ||
         hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&sl.consumed, hipEventDisableTiming) != hipSuccess) {
       fcp_stager_destroy(s);
@@ -2533,11 +2542,14 @@ int fcp_stager_stage_ex(fcp_stager_t *s, const fcp_host_tensor_t *inputs, int32_
   StageSlot &sl = s->slots[s->next];
   s->next = (s->next + 1) % s->slots.size();
   // the slot's previous copy must have left the pinned buffer (zero copy: the kernels that read it must have run)
-  if (s->zero_copy) {
+  if (s->zero_copy || sl.direct) {
     if (sl.consumed_valid && hipEventQuery(sl.consumed) != hipSuccess) HIP_TRY(hipEventSynchronize(sl.consumed));
   } else if (hipEventQuery(sl.copied) != hipSuccess) {
     HIP_TRY(hipEventSynchronize(sl.copied));
   }
+  static const bool no_fallback = std::getenv("FCP_STAGER_NO_FALLBACK") != nullptr;
+  const bool direct = s->zero_copy || s->direct_left > 0;
+  if (s->direct_left > 0) --s->direct_left;
   const uint64_t t_waited = s->stats ? now_ns() : 0;
   // sizes / offsets / shapes (stage_layout), then the pack: contiguous ranges of inputs per chunk, ~equal bytes
   int rc2 = stage_layout(inputs, n, modes, mode_args, s->capacity, s->max_rank_sum, s->byte_off.data(), sl.offsets, sl.shapes, nullptr);
@@ -2548,12 +2560,24 @@ int fcp_stager_stage_ex(fcp_stager_t *s, const fcp_host_tensor_t *inputs, int32_
   if (!pack_on_pool(*s->pool, s->n_threads, inputs, n, modes, mode_args, sl.h_blob, s->byte_off.data(), s->in_off.data()))
     return fail(FCP_ERR_INVALID_ARGUMENT, kUnsortedRows); // nothing was enqueued; the slot is simply reused
   const uint64_t t_packed = s->stats ? now_ns() : 0;
-  if (!s->zero_copy) {
+  sl.direct = direct;
+  if (!direct) {
     // the device twin is free once the work that read its previous contents has run
-    uint64_t a0 = s->stats ? now_ns() : 0, a1;
+    uint64_t a0 = now_ns(), a1;
     if (sl.consumed_valid) HIP_TRY(hipStreamWaitEvent(s->copy_stream, sl.consumed, 0));
     if (s->stats) { a1 = now_ns(); s->ns_api[0] += a1 - a0; a0 = a1; }
+    const uint64_t c0 = now_ns();
     if (size) HIP_TRY(hipMemcpyAsync(sl.d_blob, sl.h_blob, (size_t)size, hipMemcpyHostToDevice, s->copy_stream));
+    const uint64_t c1 = now_ns();
+    if (!no_fallback) {
+      s->blocked_hist = (s->blocked_hist << 1) | (c1 - c0 > 20000 ? 1u : 0u); // the last 32 copy calls: which blocked > 20 us
+      s->n_blocked += c1 - c0 > 20000;
+      if (__builtin_popcount(s->blocked_hist) >= 8) { // the copy call holds the host up: the kernels read the pinned ring for a while
+        s->blocked_hist = 0;
+        s->direct_left = 256;
+        ++s->n_fallbacks;
+      }
+    }
     if (s->stats) { a1 = now_ns(); s->ns_api[1] += a1 - a0; a0 = a1; }
     HIP_TRY(hipEventRecord(sl.copied, s->copy_stream));
     if (s->stats) { a1 = now_ns(); s->ns_api[2] += a1 - a0; a0 = a1; }
@@ -2571,7 +2595,7 @@ int fcp_stager_stage_ex(fcp_stager_t *s, const fcp_host_tensor_t *inputs, int32_
     s->ns_enqueue += t_end - t_packed;
   }
   s->last = slot_idx;
-  if (device_blob) *device_blob = sl.d_blob;
+  if (device_blob) *device_blob = direct ? sl.h_blob_dev : sl.d_blob;
   if (blob_bytes) *blob_bytes = size;
   if (offsets) *offsets = sl.offsets;
   if (shapes) *shapes = sl.shapes;
@@ -2657,14 +2681,15 @@ int fcp_stager_destroy(fcp_stager_t *s) {
   if (!s) return FCP_OK;
   if (s->stats && s->n_calls)
     std::fprintf(stderr, "fcp_stager: %llu calls, host us per call: wait for the slot %.2f, layout %.2f, pack %.2f (%d threads), enqueue %.2f "
-                         "(wait-event on the copy stream %.2f, hipMemcpyAsync %.2f, event record %.2f, wait-event on the request's stream %.2f)\n",
+                         "(wait-event on the copy stream %.2f, hipMemcpyAsync %.2f, event record %.2f, wait-event on the request's stream %.2f); "
+                         "copy calls that blocked > 20 us: %llu, zero-copy fallbacks %llu\n",
                  (unsigned long long)s->n_calls, s->ns_wait / 1e3 / s->n_calls, s->ns_layout / 1e3 / s->n_calls, s->ns_pack / 1e3 / s->n_calls,
                  s->n_threads, s->ns_enqueue / 1e3 / s->n_calls, s->ns_api[0] / 1e3 / s->n_calls, s->ns_api[1] / 1e3 / s->n_calls,
-                 s->ns_api[2] / 1e3 / s->n_calls, s->ns_api[3] / 1e3 / s->n_calls);
+                 s->ns_api[2] / 1e3 / s->n_calls, s->ns_api[3] / 1e3 / s->n_calls, (unsigned long long)s->n_blocked, (unsigned long long)s->n_fallbacks);
   DeviceGuard guard;
   (void)guard.enter(s->device);
   delete s->pool;
-  if (s->zero_copy) (void)hipDeviceSynchronize(); // kernels may still be reading the pinned ring
+  (void)hipDeviceSynchronize(); // kernels may still be reading the pinned ring (zero copy, or a slot served by the fallback)
   if (s->copy_stream) {
     (void)hipStreamSynchronize(s->copy_stream);
     (void)hipStreamDestroy(s->copy_stream);
