@@ -546,6 +546,11 @@ class ConcatOutputs:
         if begin < 0 or begin + nbytes > arena.numel() * arena.element_size():
             raise ValueError("ConcatOutputs: group outside the arena")
         out = arena.view(torch.uint8)[begin:begin + nbytes].view(torch.float32).view(prefix_shape + (width,))
+        # the lookup kernels may run on one of the plan's private streams: this op's stream — and everything downstream of
+        # its output — waits for them on the device (a no-op when private streams are off; tf_shim/fcp_tf_ops.cc does the same)
+        if stream is None:
+            stream = torch.cuda.current_stream(arena.device).cuda_stream
+        _lib.check(_lib.load().fcp_result_wait(arena.data_ptr(), stream), "fcp_result_wait")
         if len(host_inputs) != len(self.host_pos):
             raise ValueError("ConcatOutputs: wrong number of host inputs")
         if host_inputs:

@@ -379,7 +379,7 @@ def test_column_sharded_blocks_concat(torch_cuda, oracle):
         assert np.array_equal(got.cpu().numpy(), ref[begin:begin + count])
 
 
-def _graph_through_hip(torch, gd, feeds, variables, fetches, tmp_path, host_concat="passthrough", staged=False):
+def _graph_through_hip(torch, gd, feeds, variables, fetches, tmp_path, host_concat="passthrough", staged=False, private_streams=0):
     """original graph in NumPy vs rewritten graph with the HIP path behind the Addons> ops.  ``staged``: the graph is
     rewritten for the staged plan (`python -m recom_amd.graph --staged`): ConcatInputs packs as the plan file's stage
     section says (what the shim does with the node's `_fcp_plan` attr)."""
@@ -414,8 +414,19 @@ def _graph_through_hip(torch, gd, feeds, variables, fetches, tmp_path, host_conc
         tables = [torch.from_numpy(np.ascontiguousarray(t)).cuda() for t in x[3:3 + n_tab]]
         symbols = x[3 + n_tab] if node.op.endswith("WithSymbols") else None
         assert symbols is None or symbols.dtype == np.int32
-        res = op(torch.from_numpy(x[0]).cuda(), x[1], x[2], tables, symbols)
-        torch.cuda.synchronize()
+        if private_streams:
+            # the shim with FCP_PRIVATE_STREAMS: the lookup runs on a plan-owned stream, nothing here waits for it — the
+            # ConcatOutputs node below does (fcp_result_wait); the op's stream is kept busy so that the reader would race
+            if not getattr(op.plan, "private_streams", 0):
+                op.plan.set_private_streams(private_streams, always=True)
+            blob = torch.from_numpy(x[0]).cuda()
+            torch.cuda.synchronize()
+            if hasattr(torch.cuda, "_sleep"):
+                torch.cuda._sleep(2_000_000)
+            res = op(blob, x[1], x[2], tables, symbols, defer_wait=True)
+        else:
+            res = op(torch.from_numpy(x[0]).cuda(), x[1], x[2], tables, symbols)
+            torch.cuda.synchronize()
         # the op's outputs: one pointer / shape pair per OUTPUT column (external slots are not outputs)
         assert len(out_cols) == len(node.attr["output_types"].list.type)
         ptrs = res.output_ptrs[out_cols]
@@ -452,6 +463,17 @@ def test_graphdef_to_hip_path(torch_cuda, tmp_path, B, seed, host_concat):
     gd, feeds, variables, fetches = canonical_model(B=B, seed=seed)
     built = _graph_through_hip(torch_cuda, gd, feeds, variables, fetches, tmp_path, host_concat)
     assert built.spec.n_columns == 11 and built.spec.n_groups == 2
+
+
+@pytest.mark.parametrize("host_concat", ["passthrough", "external"])
+def test_graphdef_to_hip_path_with_private_streams(torch_cuda, tmp_path, host_concat):
+    """The rewritten graph as the shim runs it with FCP_PRIVATE_STREAMS=3: Addons>FeatureColumnProcess enqueues on a
+    plan-owned stream and returns, Addons>ConcatOutputs[NoHost] makes ITS stream wait (fcp_result_wait; with host inputs,
+    fcp_concat_outputs_host writes the external slots behind the same wait) — equal to the original graph bit for bit."""
+    from graph_fixtures import canonical_model
+    for B, seed in ((300, 3), (19, 0)):
+        gd, feeds, variables, fetches = canonical_model(B=B, seed=seed)
+        _graph_through_hip(torch_cuda, gd, feeds, variables, fetches, tmp_path, host_concat, private_streams=3)
 
 
 @pytest.mark.parametrize("host_concat", ["passthrough", "external"])

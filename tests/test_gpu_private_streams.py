@@ -256,3 +256,33 @@ def test_host_threads_share_a_plan_with_private_streams(torch_cuda, oracle):
         for t in range(n_threads):
             for k in range(per_thread):
                 assert np.array_equal(results[t][k][1].cpu().numpy(), want[t][k]), (shared_stream, t, k)
+
+
+def test_per_column_layout_concat_outputs_waits_for_the_private_stream(torch_cuda, oracle):
+    """FCP_LAYOUT_PER_COLUMN (the reference's arena: one buffer per column) with private streams: fcp_concat_outputs — the
+    reference's second pass, here on the caller's stream — orders itself behind the lookup kernels it reads from."""
+    import dataclasses
+    from recom_amd import synth
+    from recom_amd.ops import FeatureColumnProcess, concat_inputs, concat_outputs
+    from recom_amd.plan import LAYOUT_PER_COLUMN
+    torch = torch_cuda
+    m = synth.model_mixed(batch=140, vocab=1999, n_groups=1)
+    spec = dataclasses.replace(m.spec, layout=LAYOUT_PER_COLUMN)
+    tabs_np = m.numpy_tables()
+    tabs = [torch.from_numpy(t).cuda() for t in tabs_np]
+    op = FeatureColumnProcess(spec, 0)
+    op.plan.set_private_streams(2, always=True)
+    s = torch.cuda.Stream()
+    order = [k for _, k in sorted((c.concat_slot, k) for k, c in enumerate(spec.columns))]
+    for seed in range(4):
+        r = m.make_request(70 + seed, B=120 + seed)
+        blob, offsets, shapes = concat_inputs(r.inputs)
+        d_blob = torch.from_numpy(blob).cuda()
+        torch.cuda.synchronize()
+        with torch.cuda.stream(s):
+            _busy(torch, s, 1.0)
+            out = op(d_blob, offsets, shapes, tabs, r.symbols, defer_wait=True)
+            cat = concat_outputs([out.column(k) for k in order])       # fcp_concat_outputs waits for the arena itself
+        s.synchronize()
+        want, _ = oracle.process_feature_columns(m.spec.to_dict(), blob, offsets, shapes, tabs_np, r.symbols)
+        assert np.array_equal(cat.cpu().numpy(), want[0])
