@@ -209,11 +209,20 @@ def test_random_plans_match_oracle(oracle, seed):
     dev = torch.device("cuda", 0)
     d_tabs = [torch.from_numpy(t).to(dev) for t in tables]
     op = FeatureColumnProcess(spec, 0)
+    # (r4) the serving modes ride along: a third of the seeds on the plan's private streams, a third with the inputs-ready
+    # request order (any-order launch; the blob is synchronised first, the arena fresh: the promise holds)
+    mode = ("stream", "private", "inputs_ready")[seed % 3]
+    if mode == "private":
+        op.plan.set_private_streams(1 + seed % 4, always=True)
+    elif mode == "inputs_ready":
+        op.plan.set_inputs_ready(True)
     for trial in range(4):
         batches = [int(rng.choice([1, 2, 5, 33, 64, 130, 257, 700])) for _ in range(spec.n_groups)]
         inputs, symbols = make(rng, batches)
         blob, offsets, shapes = concat_inputs(inputs)
         d_blob = torch.from_numpy(blob).to(dev) if blob.size else torch.empty(0, dtype=torch.int8, device=dev)
+        if mode == "inputs_ready":
+            torch.cuda.synchronize()
         out = op(d_blob, offsets, shapes, d_tabs, symbols)
         torch.cuda.synchronize()
         want, _bad = oracle.process_feature_columns(spec.to_dict(), blob, offsets, shapes, tables, symbols)
