@@ -469,8 +469,10 @@ int fcp_plan_set_private_streams(fcp_plan_t *plan, int32_t n_streams, uint32_t f
  * follow each other directly: an ordinary command between two requests (a consumer kernel, an event record) orders
  * the second request behind the first again; private streams (above) are the tool for that pattern.  NOT for
  * TensorFlow's allocator, which hands out memory that earlier, still queued kernels of the compute stream may be using.
- * Requests that queue work of their own in front of the kernel (segment-offset pre-pass, descriptor upload kernel)
- * keep stream order.  Default: FCP_ORDER_STREAM. */
+ * Requests that queue work of their own in front of the kernel keep stream order for the kernel; of that work the
+ * segment-offset pre-pass is itself launched without the barrier bit (it reads the blob and writes the new arena only:
+ * RAGGED as delivered 34.4 -> 33.5 us), the inverse-map memset and the descriptor upload kernel are not.
+ * Default: FCP_ORDER_STREAM. */
 enum { FCP_ORDER_STREAM = 0, FCP_ORDER_INPUTS_READY = 1 };
 int fcp_plan_set_request_order(fcp_plan_t *plan, int32_t order);
 int fcp_result_wait(const void *buffer, void *stream);

@@ -1858,7 +1858,11 @@ int fcp_internal_process(fcp_plan_t *p, const fcp_process_args_t *a, fcp_process
       const int64_t first = m.csr_arena_off + 4 * (int64_t)slot->h_dyn[p->pos_of[p->seg_cols[p->n_seg_plain]]].csr_base;
       if (m.arena_bytes > first) HIP_TRY(hipMemsetAsync(static_cast<char *>(arena) + first, 0, (size_t)(m.arena_bytes - first), stream));
     }
-    const int e = fcp_launch_segment_offsets(S, (int)p->seg_cols.size(), m.max_seg_nnz, stream);
+    // FCP_ORDER_INPUTS_READY: the pre-pass depends on nothing queued before it (blob complete, arena unused) unless this call
+    // has queued the inverse-map memset or a descriptor upload in front of it
+    const bool prepass_any_order = p->request_order == FCP_ORDER_INPUTS_READY && !capturing && !p->has_inverse &&
+                                   !(install && !p->host_writes_dyn);
+    const int e = fcp_launch_segment_offsets(S, (int)p->seg_cols.size(), m.max_seg_nnz, stream, prepass_any_order);
     if (e) return hip_fail("segment-offsets launch", (hipError_t)e);
   }
   // Freshly installed descriptors: the slot's `done` event rides on the dispatch packet of the request's last kernel (its

@@ -1591,10 +1591,16 @@ int fcp_launch_upload(const void *host_mapped_src, void *dst, size_t bytes, ihip
   return (int)hipGetLastError();
 }
 
-int fcp_launch_segment_offsets(const FcpSegLaunch &L, int n_seg_cols, int max_nnz, ihipStream_t *s) {
+// any_order: FCP_ORDER_INPUTS_READY plans — the pre-pass reads the blob and writes the new arena's scratch only, so it may
+// begin under the tail of the previous request's kernel; the fused kernel behind it keeps the barrier bit and waits for it
+int fcp_launch_segment_offsets(const FcpSegLaunch &L, int n_seg_cols, int max_nnz, ihipStream_t *s, bool any_order) {
   if (n_seg_cols <= 0) return 0;
   const int gx = (max_nnz + 1 + FCP_SEG_IDS_PER_BLOCK - 1) / FCP_SEG_IDS_PER_BLOCK;
-  hipLaunchKernelGGL(fcp_segment_offsets_kernel, dim3(gx, n_seg_cols), dim3(FCP_BLOCK_THREADS), 0, s, L);
+  if (any_order)
+    hipExtLaunchKernelGGL(fcp_segment_offsets_kernel, dim3(gx, n_seg_cols), dim3(FCP_BLOCK_THREADS), 0, s, nullptr, nullptr,
+                          (int)hipExtAnyOrderLaunch, L);
+  else
+    hipLaunchKernelGGL(fcp_segment_offsets_kernel, dim3(gx, n_seg_cols), dim3(FCP_BLOCK_THREADS), 0, s, L);
   return (int)hipGetLastError();
 }
 
