@@ -296,10 +296,18 @@ static void refscan_op(const float *av, const orc_scan_head_t *ah, const float *
   *rh = h;
 }
 
-void orc_sparse_segment_reduce_refscan(const float *table, int32_t dim, const int64_t *ids,
-                                       const int64_t *row_ids, int64_t nnz, int64_t num_segments,
-                                       int32_t mean, float *out, int64_t out_stride) {
-  enum { BT = 64, WARP = 32 };
+/* assoc selects ONLY the order inside the 64-item inclusive scan; flags, operator, carry and write-out are shared:
+ *   ORC_SCAN_CUB18     the reference's: CUB 1.8 WarpScanShfl on 32-lane warps + the first warp's aggregate (above);
+ *   ORC_SCAN_ROCPRIM64 rocPRIM's one-wavefront scan (rocprim/warp/detail/warp_scan_dpp.hpp: Kogge-Stone with d = 1, 2, 4, 8
+ *                      inside rows of 16 lanes, then lane 15 of each 32 folded into lanes 16..31 (row_bcast:15), then lane 31
+ *                      into lanes 32..63 (row_bcast:31)) — what hipCUB's BlockScan<.., 64, BLOCK_SCAN_WARP_SCANS> runs on
+ *                      gfx950.  It exists so that the reference's template compiled against hipCUB (oracle/_ref/
+ *                      libref_device_scan.so) can be held to this restatement BIT FOR BIT: everything here but the dozen
+ *                      lines of the CUB 1.8 scan order is then pinned by the reference's own text. */
+void orc_sparse_segment_reduce_refscan_assoc(const float *table, int32_t dim, const int64_t *ids,
+                                             const int64_t *row_ids, int64_t nnz, int64_t num_segments,
+                                             int32_t mean, int32_t assoc, float *out, int64_t out_stride) {
+  enum { BT = 64, WARP = 32, ROW = 16 };
   float *x = (float *)malloc(sizeof(float) * BT * (size_t)dim);
   float *t = (float *)malloc(sizeof(float) * BT * (size_t)dim);
   float *carry = (float *)calloc((size_t)dim, sizeof(float));
@@ -320,22 +328,33 @@ void orc_sparse_segment_reduce_refscan(const float *table, int32_t dim, const in
       for (int32_t e = 0; e < dim; ++e)
         x[i * dim + e] = base + i < nnz ? table[ids[base + i] * dim + e] : 0.0f; /* lanes past the end: not read */
     }
-    for (int w = 0; w < BT / WARP; ++w) /* Kogge-Stone inside each warp */
-      for (int d = 1; d < WARP; d <<= 1) {
+    const int group = assoc == ORC_SCAN_ROCPRIM64 ? ROW : WARP;
+    for (int w = 0; w < BT / group; ++w) /* Kogge-Stone inside each warp (CUB) / each row of 16 lanes (rocPRIM) */
+      for (int d = 1; d < group; d <<= 1) {
         memcpy(t, x, sizeof(float) * BT * (size_t)dim);
         memcpy(th, h, sizeof(h));
-        for (int i = w * WARP + d; i < (w + 1) * WARP; ++i)
+        for (int i = w * group + d; i < (w + 1) * group; ++i)
           refscan_op(t + (i - d) * dim, &th[i - d], t + i * dim, &th[i], x + i * dim, &h[i], dim);
       }
-    for (int w = 1; w < BT / WARP; ++w) { /* warp prefixes: aggregates of the earlier warps, in order */
-      memcpy(tmp, x + (w * WARP - 1) * dim, sizeof(float) * (size_t)dim);
-      const orc_scan_head_t agg = h[w * WARP - 1];
-      for (int i = w * WARP; i < (w + 1) * WARP; ++i) {
-        memcpy(t, x + i * dim, sizeof(float) * (size_t)dim);
-        const orc_scan_head_t hi = h[i];
-        refscan_op(tmp, &agg, t, &hi, x + i * dim, &h[i], dim);
-      }
+    /* fold the aggregate of lane `src` into lanes [lo, hi): x[i] = op(x[src], x[i]) */
+#define ORC_FOLD(src, lo, hi)                                         \
+  do {                                                                \
+    memcpy(tmp, x + (src) * dim, sizeof(float) * (size_t)dim);        \
+    const orc_scan_head_t agg = h[(src)];                             \
+    for (int i = (lo); i < (hi); ++i) {                               \
+      memcpy(t, x + i * dim, sizeof(float) * (size_t)dim);            \
+      const orc_scan_head_t hi_ = h[i];                               \
+      refscan_op(tmp, &agg, t, &hi_, x + i * dim, &h[i], dim);        \
+    }                                                                 \
+  } while (0)
+    if (assoc == ORC_SCAN_ROCPRIM64) {
+      ORC_FOLD(15, 16, 32); /* row_bcast:15, lanes with lane % 32 >= 16 */
+      ORC_FOLD(47, 48, 64);
+      ORC_FOLD(31, 32, 64); /* row_bcast:31 */
+    } else {
+      for (int w = 1; w < BT / WARP; ++w) ORC_FOLD(w * WARP - 1, w * WARP, (w + 1) * WARP); /* warp prefixes, in order */
     }
+#undef ORC_FOLD
     for (int i = 0; i < BT; ++i) {
       const int tail = row[i + 2] != row[i + 1];
       if (base + i >= nnz) break;
@@ -357,6 +376,12 @@ void orc_sparse_segment_reduce_refscan(const float *table, int32_t dim, const in
   free(t);
   free(carry);
   free(tmp);
+}
+
+void orc_sparse_segment_reduce_refscan(const float *table, int32_t dim, const int64_t *ids,
+                                       const int64_t *row_ids, int64_t nnz, int64_t num_segments,
+                                       int32_t mean, float *out, int64_t out_stride) {
+  orc_sparse_segment_reduce_refscan_assoc(table, dim, ids, row_ids, nnz, num_segments, mean, ORC_SCAN_CUB18, out, out_stride);
 }
 
 /* --------------------------------------------------------------------------

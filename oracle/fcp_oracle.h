@@ -152,6 +152,12 @@ void orc_sparse_segment_reduce_tfcpu(const float *table, int32_t dim, const int6
 void orc_sparse_segment_reduce_refscan(const float *table, int32_t dim, const int64_t *ids,
                                        const int64_t *row_ids, int64_t nnz, int64_t num_segments,
                                        int32_t mean, float *out, int64_t out_stride);
+/* the same with the order INSIDE the 64-item scan selectable: CUB 1.8's (the function above) or rocPRIM's one-wavefront
+ * scan, which is what the reference's template runs on when compiled against hipCUB (oracle/_ref/libref_device_scan.so) */
+enum { ORC_SCAN_CUB18 = 0, ORC_SCAN_ROCPRIM64 = 1 };
+void orc_sparse_segment_reduce_refscan_assoc(const float *table, int32_t dim, const int64_t *ids,
+                                             const int64_t *row_ids, int64_t nnz, int64_t num_segments,
+                                             int32_t mean, int32_t assoc, float *out, int64_t out_stride);
 
 /* a11 cuda_emitter.cc:1216-1241 */
 void orc_batch_col_reduction(const float *x, int64_t batch, int64_t rows,

@@ -100,6 +100,8 @@ class COracle:
                                                        C.c_int64, C.c_int32, C.c_void_p, C.c_int64]
         L.orc_sparse_segment_reduce_refscan.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64,
                                                         C.c_int64, C.c_int32, C.c_void_p, C.c_int64]
+        L.orc_sparse_segment_reduce_refscan_assoc.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64,
+                                                              C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int64]
         L.orc_fingerprint64.restype = C.c_uint64
         L.orc_fingerprint64.argtypes = [C.c_char_p, C.c_size_t]
         L.orc_hash_bucket_int64.restype = C.c_int64
@@ -187,15 +189,16 @@ class COracle:
                                                  out.ctypes.data, t.shape[1])
         return out
 
-    def sparse_segment_reduce_refscan(self, table, ids, row_ids, num_segments: int, mean: bool) -> np.ndarray:
-        """Form 2 in the reference GPU kernel's own order for dim <= 20 (CUB block scan over 64-id tiles)."""
+    def sparse_segment_reduce_refscan(self, table, ids, row_ids, num_segments: int, mean: bool, rocprim: bool = False) -> np.ndarray:
+        """Form 2 in the reference GPU kernel's own order for dim <= 20 (CUB block scan over 64-id tiles); rocprim=True swaps
+        ONLY the order inside the 64-item scan for rocPRIM's (what the template compiled against hipCUB runs on)."""
         t = np.ascontiguousarray(table, np.float32)
         i = np.ascontiguousarray(ids, np.int64).ravel()
         r = np.ascontiguousarray(row_ids, np.int64).ravel()
         assert i.size == r.size
         out = np.empty((num_segments, t.shape[1]), np.float32)
-        self.lib.orc_sparse_segment_reduce_refscan(t.ctypes.data, t.shape[1], i.ctypes.data, r.ctypes.data, i.size,
-                                                   num_segments, int(mean), out.ctypes.data, t.shape[1])
+        self.lib.orc_sparse_segment_reduce_refscan_assoc(t.ctypes.data, t.shape[1], i.ctypes.data, r.ctypes.data, i.size,
+                                                         num_segments, int(mean), int(rocprim), out.ctypes.data, t.shape[1])
         return out
 
     def batch_col_reduction(self, x) -> np.ndarray:

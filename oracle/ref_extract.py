@@ -10,6 +10,10 @@ self-contained C++ inside their literals are compiled here, unmodified, behind s
   libref_device.so (hipcc, gfx950 device)  `GatherRowsToGlbMem` (:250-293), `GatherScatterRows` (:296-345), `AlignedVector`
                                            (:664-765), `experiment::ComputeSegmentOffsets` / `SparseSegmentReduce` (:768-962);
                                            run on the GPU by tests/test_gpu_reference_kernels.py
+  libref_device_scan.so (hipcc, gfx950)    `SparseSegmentSum` / `SparseSegmentMean` for dim <= 20 (:348-661) — against hipCUB,
+                                           the image's port of the CUB interface, NOT CUB 1.8: the templates' own logic runs
+                                           as written, the order inside the 64-item scan is rocPRIM's (the oracle restates
+                                           both orders behind one selector and equals this library bit for bit in rocPRIM's)
 
 This recipe
   1. reads that file under /root/reference (never copied into the repository),
@@ -21,7 +25,7 @@ This recipe
      second call does nothing.
 
 Used by tests only; a no-op with exit code 0 when /root/reference is absent (the GPU box uses the prebuilt libraries).
-SparseSegmentSum / SparseSegmentMean for dim <= 20 (:402-661) need cub::BlockScan (CUB 1.8, absent) and cannot be built."""
+CUB 1.8 itself is absent: the order inside the reference's 64-item scan for dim <= 20 stays restated (ORC_SCAN_CUB18)."""
 import hashlib
 import os
 import re
@@ -34,7 +38,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = "/root/reference/tensorflow_addons/graph_optimizers/cuda_emitter.cc"
 OUT = os.path.join(HERE, "_ref")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-LIBS = ("libref_bucketize.so", "libref_device.so")
+LIBS = ("libref_bucketize.so", "libref_device.so", "libref_device_scan.so")
 
 
 def _statement(text: str, first_literal: str, occurrence: int = 0) -> str:
@@ -54,21 +58,26 @@ def extract_all() -> dict:
     gather_first = '"template <bool FULL_BLOCK, int EmbedDim, int BLOCK_THREADS, typename "'
     gather = _statement(text, gather_first, 0) + "\n" + _statement(text, gather_first, 1)
     experiment = _statement(text, '"// Ported from TensorFlow 2.6\\n"')
+    scan = (_statement(text, '"template <int ScanDim, typename Tparam> struct ScanVecPair {\\n"') + "\n" +
+            _statement(text, '"template <int ScanDim, typename Tparam> struct ScanVecCntTuple {\\n"'))
     checks = (("Bucketize(" in bucketize and bucketize.count("{") == bucketize.count("}")),
               ("alignmem(int x)" in alignmem and alignmem.count("{") == 1),
               ("GatherRowsToGlbMem(" in gather and "GatherScatterRows(" in gather and gather.count("{") == gather.count("}")),
               ("class alignas(alignof(T) * N) AlignedVector" in experiment and "namespace experiment" in experiment
-               and "ComputeSegmentOffsets" in experiment and experiment.rstrip().endswith("// namespace experiment")))
+               and "ComputeSegmentOffsets" in experiment and experiment.rstrip().endswith("// namespace experiment")),
+              ("SparseSegmentSum(" in scan and "SparseSegmentMean(" in scan and scan.count("cub::BlockScan") == 4
+               and scan.count("{") == scan.count("}")))
     if not all(checks):
         raise SystemExit(f"ref_extract: the reference literals do not look as expected {checks}")
-    return {"bucketize_ref.inc": bucketize, "alignmem_ref.inc": alignmem, "ref_gather.inc": gather, "ref_experiment.inc": experiment}
+    return {"bucketize_ref.inc": bucketize, "alignmem_ref.inc": alignmem, "ref_gather.inc": gather, "ref_experiment.inc": experiment,
+            "ref_segment_scan.inc": scan}
 
 
 def _stamp(files: dict) -> str:
     h = hashlib.sha256()
     for name in sorted(files):
         h.update(name.encode() + b"\0" + files[name].encode() + b"\0")
-    for w in ("ref_bucketize_wrap.cc", "ref_device_wrap.hip"):
+    for w in ("ref_bucketize_wrap.cc", "ref_device_wrap.hip", "ref_device_scan_wrap.hip"):
         h.update(open(os.path.join(HERE, w), "rb").read())
     return h.hexdigest()
 
@@ -98,6 +107,10 @@ def build(force: bool = False) -> bool:
             subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-std=c++17", "-O2", "-fPIC", "-shared", "-ffp-contract=off",
                                    "-Wno-unused-value", "-I", tmp, os.path.join(HERE, "ref_device_wrap.hip"), "-o",
                                    os.path.join(OUT, LIBS[1])])
+            # the dim <= 20 templates against hipCUB (the image's port of the CUB interface; CUB 1.8 itself is absent: the
+            # scan's fp32 association is rocPRIM's, see the header of ref_device_scan_wrap.hip)
+            subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-std=c++17", "-O2", "-fPIC", "-shared", "-ffp-contract=off",
+                                   "-I", tmp, os.path.join(HERE, "ref_device_scan_wrap.hip"), "-o", os.path.join(OUT, LIBS[2])])
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     with open(stamp_path, "w") as f:
@@ -105,10 +118,11 @@ def build(force: bool = False) -> bool:
     return True
 
 
-def device_lib_path():
-    """oracle/_ref/libref_device.so, or None when it has not been built (no /root/reference and nothing prebuilt)."""
+def device_lib_path(which: int = 1):
+    """oracle/_ref/libref_device.so (which = 1) or libref_device_scan.so (2), or None when it has not been built (no
+    /root/reference and nothing prebuilt)."""
     build()
-    p = os.path.join(OUT, LIBS[1])
+    p = os.path.join(OUT, LIBS[which])
     return p if os.path.exists(p) else None
 
 

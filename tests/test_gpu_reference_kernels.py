@@ -10,8 +10,10 @@ Held to it, bit for bit:
     orc_sparse_segment_reduce_ref8x8 (the dim > 20 template in ITS OWN summation order),
   * the HIP product path through the C ABI for the copy forms (a6, a9) and for segment offsets (a8, via the pooled result).
 The pooled HIP result (sequential id order) is bounded against it at the north star's 1e-5.
-Function-level pinning: the templates are the reference's, the dozen driver lines around them are restated; the dim <= 20
-templates (SparseSegmentSum / Mean, :402-661) need cub::BlockScan (CUB 1.8, absent) and stay restated only.
+Function-level pinning: the templates are the reference's, the dozen driver lines around them are restated.  The dim <= 20
+templates (SparseSegmentSum / Mean, :348-661) need cub::BlockScan: CUB 1.8 is absent, so they run against hipCUB's BlockScan
+(oracle/_ref/libref_device_scan.so, last test of this file) and the oracle's restatement equals that bit for bit once the
+order inside its 64-item scan is switched to rocPRIM's; the CUB 1.8 order itself (a dozen lines) stays restated only.
 Documented divergences, asserted below: an empty MEAN segment is 0/0 = NaN in the reference's dim > 20 template and 0 in
 TensorFlow, the oracle and the HIP path; ids / rows outside their range are read / written out of bounds by the reference
 (never fed to it here) and are zeros / dropped in the oracle and the HIP path."""
@@ -209,3 +211,70 @@ def test_segment_reduce_in_the_references_order_equals_the_references_kernel(tor
             l1 = np.zeros(B)
             np.add.at(l1, seg, np.abs(table[ids]).sum(axis=1) / dim)
             assert (np.abs(hip - np.where(empty[:, None], 0, want)).max(axis=1) <= 1e-6 * np.maximum(l1, 1.0)).all()
+
+
+@pytest.fixture(scope="module")
+def ref_scan(torch_cuda):
+    """oracle/_ref/libref_device_scan.so: the reference's dim <= 20 SparseSegmentSum / SparseSegmentMean templates
+    (cuda_emitter.cc:348-661) compiled against hipCUB — the image's port of the CUB interface, not CUB 1.8 (absent)."""
+    import ref_extract
+    path = ref_extract.device_lib_path(2)
+    if path is None:
+        pytest.skip("oracle/_ref/libref_device_scan.so is absent and /root/reference is not here to build it from")
+    L = C.CDLL(path)
+
+    def run(table, ids, seg, num_segments, mean, seg_stride=1):
+        t, i = np.ascontiguousarray(table, np.float32), np.ascontiguousarray(ids, np.int64).ravel()
+        s = np.ascontiguousarray(seg, np.int64).ravel()
+        assert s.size == i.size * seg_stride
+        out = np.full((num_segments, t.shape[1]), np.float32(-7e7))
+        rc = L.ref_dev_scan_segment_reduce(C.c_void_p(t.ctypes.data), C.c_int64(t.shape[0]), t.shape[1], C.c_void_p(i.ctypes.data),
+                                           C.c_void_p(s.ctypes.data), seg_stride, i.size, num_segments, int(mean), C.c_void_p(out.ctypes.data))
+        assert rc == 0, rc
+        return out
+    return run
+
+
+@pytest.mark.parametrize("dim", [1, 2, 3, 4, 8, 12, 16, 20])
+@pytest.mark.parametrize("mean", [False, True])
+def test_dim_le_20_templates_of_the_reference_run_against_hipcub(torch_cuda, oracle, ref_scan, dim, mean):
+    """a7: the reference's OWN dim <= 20 templates — head / tail flags, segmented scan operator, carry across 64-id tiles,
+    which rows are written, mean = sum / integer counter, 8-float slabs + the LEFT_DIM tail — executed on the GPU with
+    hipCUB's BlockScan standing where CUB 1.8's was (same interface; the order inside the 64-item scan is rocPRIM's).  Held to it:
+      * the oracle's restatement orc_sparse_segment_reduce_refscan_assoc with ONLY the order inside the 64-item scan swapped
+        for rocPRIM's one-wavefront order (ORC_SCAN_ROCPRIM64) — BIT FOR BIT, every row, every dim: the restatement's flags,
+        operator, carry, write-out and mean are thereby pinned by the reference's own text; what stays restated only is the
+        dozen lines of CUB 1.8's order (32-lane Kogge-Stone + first warp's aggregate), which this image cannot run;
+      * bags of one or two ids and empty rows — no association involved — bit for bit: the oracle (both orders) and the HIP path;
+      * every other bag within the north star's 1e-5 (BASELINE's bag lengths) / a reassociation bound (long bags);
+      * tiles: nnz around multiples of 64, a bag crossing three tiles, leading / trailing empty rows, SparseTensor stride 2."""
+    from recom_amd.plan import COMBINER_MEAN, COMBINER_SUM, FORM_SEGMENT_REDUCE, SEG_IDS_I64
+    rng = np.random.default_rng(700 + 2 * dim + int(mean))
+    vocab = 1511
+    table = (rng.standard_normal((vocab, dim)) * max(dim, 1) ** -0.5).astype(np.float32)
+    cases = [rng.integers(0, 11, 200), np.asarray([0, 0, 1, 2, 63, 64, 65, 130, 0, 1, 0]), np.full(32, 2), np.asarray([0, 128]),
+             np.asarray([3]), np.asarray([1] * 64), np.asarray([0, 0, 5, 0, 0])]
+    for lens in cases:
+        B = len(lens)
+        seg = np.repeat(np.arange(B), lens).astype(np.int64)
+        ids = rng.integers(0, vocab, seg.size).astype(np.int64)
+        offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        want = ref_scan(table, ids, seg, B, mean)
+        seq, _ = oracle.sparse_segment_reduce(table, ids, offs, mean)
+        scan = oracle.sparse_segment_reduce_refscan(table, ids, seg, B, mean)
+        assert np.array_equal(want, oracle.sparse_segment_reduce_refscan(table, ids, seg, B, mean, rocprim=True))
+        short = np.asarray(lens) <= 2
+        assert np.array_equal(want[short], seq[short]) and np.array_equal(want[short], scan[short])   # copies, a + b, zeros: exact
+        assert not want[np.asarray(lens) == 0].any()
+        l1 = np.zeros(B)
+        np.add.at(l1, seg, np.abs(table[ids]).max(axis=1))
+        tol = np.where(np.asarray(lens) <= 10, 1e-5, 2e-6 * np.maximum(l1, 1.0))
+        assert (np.abs(want - seq).max(axis=1) <= tol).all() and (np.abs(want - scan).max(axis=1) <= tol).all()
+        if seg.size:                                                        # SparseTensor indices [nnz, 2]: stride 2
+            idx = np.stack([seg, rng.integers(0, 4, seg.size)], axis=1).astype(np.int64)
+            assert np.array_equal(ref_scan(table, ids, idx, B, mean, seg_stride=2), want)
+        if dim % 4 == 0 or dim in (1, 2, 3):
+            hip = _one_column_hip(torch_cuda, FORM_SEGMENT_REDUCE, dim, vocab, table, [ids, seg], [1, 1], [8, 8], B,
+                                  combiner=COMBINER_MEAN if mean else COMBINER_SUM, seg_kind=SEG_IDS_I64)
+            assert np.array_equal(hip, seq)
+            assert np.array_equal(hip[short], want[short]) and (np.abs(hip - want).max(axis=1) <= tol).all()

@@ -138,6 +138,45 @@ def test_reference_block_scan_order_dim_le_20(oracle, mean, dim):
     assert not np.array_equal(seq, ref) and np.allclose(seq, ref, rtol=1e-4, atol=1e-2)
 
 
+def test_block_scan_order_selector_changes_the_scan_order_only(oracle):
+    """orc_sparse_segment_reduce_refscan_assoc: ORC_SCAN_ROCPRIM64 (the order of hipCUB's 64-thread BlockScan on one wavefront;
+    tests/test_gpu_reference_kernels.py holds the reference's template compiled against hipCUB to it bit for bit) and
+    ORC_SCAN_CUB18 share everything but the order inside a 64-item tile: identical on integer-valued rows (any order is exact),
+    on bags of up to two ids and on empty rows; equal to a NumPy statement of each tree for one full tile of one bag."""
+    rng = np.random.default_rng(77)
+    Wi = rng.integers(-50, 50, (300, 12)).astype(np.float32)
+    lens = rng.integers(0, 30, 120)
+    ids = rng.integers(0, 300, int(lens.sum()))
+    rows = np.repeat(np.arange(len(lens)), lens)
+    for mean in (False, True):
+        a = oracle.sparse_segment_reduce_refscan(Wi, ids, rows, len(lens), mean)
+        b = oracle.sparse_segment_reduce_refscan(Wi, ids, rows, len(lens), mean, rocprim=True)
+        assert np.array_equal(a, b) and not b[lens == 0].any()
+    W = (rng.standard_normal((300, 8)) * 10.0 ** rng.integers(-3, 4, (300, 1))).astype(np.float32)
+    ids = rng.integers(0, 300, 64)
+    x = W[ids]
+
+    def kogge_stone(v):                       # inclusive scan of v[n, dim], float32, d = 1, 2, 4 ...
+        v = v.copy()
+        d = 1
+        while d < len(v):
+            v[d:] = v[:-d] + v[d:]
+            d *= 2
+        return v
+    cub = np.concatenate([kogge_stone(x[:32]), kogge_stone(x[32:])])
+    cub[32:] = cub[31] + cub[32:]
+    roc = np.concatenate([kogge_stone(x[r:r + 16]) for r in range(0, 64, 16)])
+    roc[16:32] = roc[15] + roc[16:32]
+    roc[48:64] = roc[47] + roc[48:64]
+    roc[32:64] = roc[31] + roc[32:64]
+    assert np.array_equal(cub[63], roc[63])   # the last lane's tree is the same in both; lane 20's is not
+    for last in (63, 20, 40, 27):             # a bag of ids 0..last, then a second bag with the rest of the tile
+        rows = (np.arange(64) > last).astype(np.int64)
+        assert np.array_equal(oracle.sparse_segment_reduce_refscan(W, ids, rows, 2, False)[0], cub[last])
+        assert np.array_equal(oracle.sparse_segment_reduce_refscan(W, ids, rows, 2, False, rocprim=True)[0], roc[last])
+    assert not np.array_equal(cub[20], roc[20]) and not np.array_equal(cub[27], roc[27])
+
+
 def _np_tfcpu_segment(rows, mean):
     """Independent NumPy-float32 statement of TensorFlow 2.6.2's SparseSegmentReductionOpBase::Reduce for ONE segment
     (rows: [num, dim] float32): first num & 7 rows (8 for 0, 9 for 1) left to right, / num at once when mean and num < 10,
