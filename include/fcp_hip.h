@@ -453,8 +453,13 @@ int fcp_process_feature_columns(fcp_plan_t *plan,
  * plan therefore keeps requests whose work — table rows gathered + output bytes
  * of the shapes it installed last — is below 48 MiB on args->stream
  * (FCP_PRIVATE_MIN_WORK_BYTES overrides); FCP_PRIVATE_ALWAYS sends every request
- * to a private stream.  Three streams measured best (two: 27 us on S2; four or
- * more: slower than one stream, profiles/r04_private_streams_sweep.txt). */
+ * to a private stream.  Three streams measured best (two: 25-27 us on S2); with
+ * four or more event-linked streams in flight every request took 35-100 us, so
+ * at most three are created whatever n_streams says (the call still succeeds).
+ * The streams live in the runtime's low-priority queue pool: their hardware
+ * queues are then not shared with the caller's streams, and the mode works with
+ * the default GPU_MAX_HW_QUEUES (profiles/r04_private_streams_queue_pools.txt;
+ * FCP_LANE_PRIORITY=normal|high|low overrides). */
 enum { FCP_PRIVATE_NO_CALLER_WAIT = 1u << 0, FCP_PRIVATE_ALWAYS = 1u << 1 };
 int fcp_plan_set_private_streams(fcp_plan_t *plan, int32_t n_streams, uint32_t flags);
 

@@ -1968,9 +1968,33 @@ int fcp_plan_set_private_streams(fcp_plan_t *p, int32_t n_streams, uint32_t flag
     const char *e = std::getenv("FCP_PRIVATE_MIN_WORK_BYTES"); // tuning aid
     p->lane_min_work = (flags & FCP_PRIVATE_ALWAYS) ? 0 : (e ? std::atoll(e) : (int64_t)48 << 20);
   }
+  // The lanes are created in the runtime's LOW-priority queue pool.  ROCm maps a process' streams onto GPU_MAX_HW_QUEUES
+  // (default 4) hardware queues PER PRIORITY LEVEL, round robin: lanes of normal priority share hardware queues with the
+  // caller's own streams as soon as the process has more than four, and a lane that shares a queue with the stream its
+  // consumer waits on serialises behind that wait — measured: no gain at all with the default environment (27.6-35.9 us
+  // against 28.5 on one stream), 24.8-25.3 us with the lanes in a pool of their own, whatever the variable says
+  // (profiles/r04_private_streams_queue_pools.txt).  Low rather than high: the embedding stage of a LATER request yields to
+  // the consumers of earlier ones where they compete.  FCP_LANE_PRIORITY=normal|high|low overrides.
+  // More than three lanes are not created: with four or more event-linked queues in flight every request took 35-100 us
+  // (one stream: 28.5) under every queue count and priority tried (same file); independent streams do not show it (2..8
+  // serve workers: 23-25 us).  The request stays accepted — the round robin simply runs over three.
+  constexpr int kMaxLanes = 3;
+  if (n_streams > kMaxLanes && !std::getenv("FCP_PRIVATE_LANES_UNCAPPED")) n_streams = kMaxLanes;
+  int least = 0, greatest = 0;
+  HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+  int lane_priority = least;
+  bool with_priority = least != greatest;
+  if (const char *e = std::getenv("FCP_LANE_PRIORITY")) {
+    if (!std::strcmp(e, "normal")) with_priority = false;
+    else lane_priority = !std::strcmp(e, "high") ? greatest : least;
+  }
   for (int k = 0; k < n_streams; ++k) {
     std::unique_ptr<PrivateLane> l(new PrivateLane());
-    HIP_TRY(hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking));
+    if (with_priority) {
+      HIP_TRY(hipStreamCreateWithPriority(&l->stream, hipStreamNonBlocking, lane_priority));
+    } else {
+      HIP_TRY(hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking));
+    }
     p->lanes.push_back(std::move(l)); // owned from here on: a failure below leaves lanes that plan destruction releases
     PrivateLane &L = *p->lanes.back();
     for (int i = 0; i < kLaneEvents; ++i) {

@@ -225,7 +225,8 @@ class Plan:
 
     def set_private_streams(self, n_streams: int, no_caller_wait: bool = False, always: bool = False) -> None:
         """``fcp_plan_set_private_streams``: requests of one caller stream run on ``n_streams`` plan-owned streams
-        (0 = off); readers of a result order themselves behind it with ``fcp_result_wait``.  ``always``: also requests
+        (0 = off; the library creates at most three, in the runtime's low-priority queue pool); readers of a result order
+        themselves behind it with ``fcp_result_wait``.  ``always``: also requests
         whose work is below the library's threshold (48 MiB gathered + written), which otherwise stay on the caller's stream."""
         _lib.check(self._L.fcp_plan_set_private_streams(self.handle, int(n_streams), (1 if no_caller_wait else 0) | (2 if always else 0)),
                    "fcp_plan_set_private_streams")
