@@ -35,7 +35,7 @@ trace ragged --workload ragged
 trace ragged_as_delivered --workload ragged --as-delivered
 trace e --workload e
 # one host thread, one caller stream, the plan's private streams: lanes x depth, next to the one-stream and 3-worker figures
-python scripts/r04_private_sweep.py --combos 2x2,2x3,3x3,3x4,4x4 --nowait 0,1 > $O/r04_private_streams_sweep.txt 2>&1
+python scripts/r04_private_sweep.py --combos 2x2,2x3,3x3,3x4 --nowait 0,1 > $O/r04_private_streams_sweep.txt 2>&1
 python scripts/r04_private_sweep.py --workload ragged --combos 2x3,3x3,3x4 --nowait 0 >> $O/r04_private_streams_sweep.txt 2>&1
 python scripts/r04_private_sweep.py --workload e --combos 2x3,3x3 --nowait 0 >> $O/r04_private_streams_sweep.txt 2>&1
 find $O -name "*.csv" -size +2M -delete
