@@ -456,12 +456,39 @@ int fcp_process_feature_columns(fcp_plan_t *plan,
  * to a private stream.  Three streams measured best (two: 25-27 us on S2); with
  * four or more event-linked streams in flight every request took 35-100 us, so
  * at most three are created whatever n_streams says (the call still succeeds).
- * The streams live in the runtime's low-priority queue pool: their hardware
- * queues are then not shared with the caller's streams, and the mode works with
- * the default GPU_MAX_HW_QUEUES (profiles/r04_private_streams_queue_pools.txt;
- * FCP_LANE_PRIORITY=normal|high|low overrides). */
-enum { FCP_PRIVATE_NO_CALLER_WAIT = 1u << 0, FCP_PRIVATE_ALWAYS = 1u << 1 };
+ *
+ * Verification.  Whether event-linked streams overlap on the GPU depends on which
+ * hardware queues the HIP runtime mapped them to — the creation order of every
+ * stream of the process, GPU_MAX_HW_QUEUES, stream priorities — and no API shows
+ * it: the same three private streams ran S2 at 24.5 us per request or at 40-86 us
+ * (one stream: 28.6) with nothing changed but the number of streams the process
+ * had created before (profiles/r04_private_streams_queue_mapping.txt).  The first
+ * request of every caller stream that would take a private stream therefore runs
+ * a short synthetic probe of the request pattern behind that stream (kernels that
+ * only wait; the host blocks for ~4 ms and args->stream drains once).  While no
+ * caller has been found good, other mappings are tried — the private streams are
+ * re-created with the next priority (normal, low, high) and behind up to six
+ * spacer streams, ~4 ms each.  A caller behind which no mapping overlaps keeps
+ * its requests on its own stream: the mode then costs nothing instead of a
+ * multiple.  FCP_PRIVATE_NO_VERIFY skips all of it (the streams are used as
+ * created); FCP_LANE_PRIORITY=normal|low|high chooses the priority the search
+ * starts with; FCP_PRIVATE_VERIFY_VERBOSE=1 prints the search. */
+enum { FCP_PRIVATE_NO_CALLER_WAIT = 1u << 0, FCP_PRIVATE_ALWAYS = 1u << 1, FCP_PRIVATE_NO_VERIFY = 1u << 2 };
 int fcp_plan_set_private_streams(fcp_plan_t *plan, int32_t n_streams, uint32_t flags);
+
+/* Diagnostic: do the plan's private streams overlap behind THIS caller stream, in THIS process?  Whether event-linked
+ * streams overlap depends on which hardware queues the HIP runtime mapped them to — the creation order of every stream of
+ * the process, GPU_MAX_HW_QUEUES, stream priorities — and cannot be told from the API: the same three private streams
+ * measured 24.5 us per S2 request or 40-85 us (one stream: 28.6) with nothing changed but the number of streams the
+ * process had created before (profiles/r04_private_streams_queue_mapping.txt).  The probe replays the request pattern
+ * with kernels that only wait: `requests` kernels of `spin_us` microseconds on grid_blocks x 256 threads, each followed
+ * — n_streams - 1 requests later — by its consumer (a stream wait + a one-thread kernel) on `stream`; once back to back
+ * on `stream` (*serial_us), once through the private streams (*lanes_us, 0 without private streams); host clock, each
+ * ending with a synchronisation of `stream`.  *lanes_us well below *serial_us: they overlap.  (The library runs this
+ * probe itself on the first request of every caller stream, see Verification above; the entry point is for harnesses
+ * and for processes that pass FCP_PRIVATE_NO_VERIFY.) */
+int fcp_plan_probe_private_streams(fcp_plan_t *plan, void *stream, int32_t requests, int32_t spin_us, int32_t grid_blocks,
+                                   double *serial_us, double *lanes_us);
 
 /* The cheap half of the same idea, for callers that OWN their buffers: FCP_ORDER_INPUTS_READY is the caller's promise, for
  * every request of the plan, that when fcp_process_feature_columns is CALLED the blob is complete in device memory and

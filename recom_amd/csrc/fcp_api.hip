@@ -15,6 +15,7 @@
 //   * 64-bit byte offsets and row offsets (the reference's int arithmetic
 //     overflows beyond 2^31).
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <atomic>
@@ -155,6 +156,18 @@ void pending_register(const void *owner, void *arena, int64_t bytes, hipEvent_t 
       j = (j->first != b && hipEventQuery(j->second.done) == hipSuccess) ? g_pending.erase(j) : std::next(j);
 }
 
+// A request that stays on the caller's stream although its plan has private streams (below the work threshold, or the
+// stream is being captured) writes its arena in stream order: an older entry for that memory would make the reader wait
+// for an event that has nothing to do with it — harmless outside a capture, an isolation error inside one.
+void pending_clear_range(void *arena, int64_t bytes) {
+  const uintptr_t b = reinterpret_cast<uintptr_t>(arena), e = b + (uintptr_t)std::max<int64_t>(bytes, 1);
+  std::lock_guard<std::mutex> lock(g_pending_mu);
+  if (g_pending.empty()) return;
+  auto it = g_pending.lower_bound(b);
+  if (it != g_pending.begin() && std::prev(it)->second.end > b) --it;
+  while (it != g_pending.end() && it->first < e) it = g_pending.erase(it);
+}
+
 void pending_forget(const void *owner) {
   std::lock_guard<std::mutex> lock(g_pending_mu);
   for (auto j = g_pending.begin(); j != g_pending.end();) j = j->second.owner == owner ? g_pending.erase(j) : std::next(j);
@@ -226,6 +239,15 @@ struct fcp_plan {
   std::vector<std::unique_ptr<PrivateLane>> lanes;
   std::atomic<uint32_t> lane_rr{0};
   uint32_t lane_flags = 0;
+  // Verification (verify_lanes): whether event-linked streams overlap depends on the hardware queues the runtime mapped
+  // them to, which no API shows.  The first request of every caller stream runs a synthetic probe of the request pattern;
+  // while no caller has been found good, other mappings are tried (lanes re-created with another priority, behind
+  // `spacers` — streams that only hold hardware queues); a caller behind which no mapping overlaps keeps its requests.
+  std::mutex lane_cal_mu;                               // lane_verdicts, spacers, and every re-creation of `lanes`
+  std::vector<std::pair<void *, bool>> lane_verdicts;   // caller stream -> its requests may take the lanes
+  std::atomic<void *> lane_good_caller{nullptr};        // the last caller found good: the request path's shortcut
+  std::vector<hipStream_t> spacers;
+  int32_t lane_count = 0;                               // lanes asked for (<= kMaxLanes)
   // The cross-stream events of a lane cost the host ~8 us per request and the GPU's command processor a few packets:
   // a request pays for them only when its kernel is long enough to have something to overlap.  The plan remembers
   // the work of the shapes it installed last (gathered rows + output bytes); lighter requests stay on the caller's stream.
@@ -1705,6 +1727,45 @@ int fcp_plan_release_captures(fcp_plan_t *p) {
   return FCP_OK;
 }
 
+namespace {
+// (callers hold lane_cal_mu, or own the plan exclusively)
+void destroy_lanes(fcp_plan *p, bool spacers_too) {
+  for (auto &l : p->lanes) {
+    for (int i = 0; i < kLaneEvents; ++i) {
+      if (l->in[i]) (void)hipEventDestroy(l->in[i]);
+      if (l->out[i]) (void)hipEventDestroy(l->out[i]);
+    }
+    if (l->stream) (void)hipStreamDestroy(l->stream);
+  }
+  p->lanes.clear();
+  if (spacers_too) {
+    for (hipStream_t s : p->spacers) (void)hipStreamDestroy(s);
+    p->spacers.clear();
+  }
+}
+
+// prio: 0 = the caller's (normal), 1 = lowest, 2 = highest
+int create_lanes(fcp_plan *p, int n, int prio) {
+  int least = 0, greatest = 0;
+  HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+  for (int k = 0; k < n; ++k) {
+    std::unique_ptr<PrivateLane> l(new PrivateLane());
+    if (prio != 0 && least != greatest) {
+      HIP_TRY(hipStreamCreateWithPriority(&l->stream, hipStreamNonBlocking, prio == 1 ? least : greatest));
+    } else {
+      HIP_TRY(hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking));
+    }
+    p->lanes.push_back(std::move(l)); // owned from here on: a failure below leaves lanes that plan destruction releases
+    PrivateLane &L = *p->lanes.back();
+    for (int i = 0; i < kLaneEvents; ++i) {
+      HIP_TRY(hipEventCreateWithFlags(&L.in[i], hipEventDisableTiming | hipEventDisableSystemFence));
+      HIP_TRY(hipEventCreateWithFlags(&L.out[i], hipEventDisableTiming | hipEventDisableSystemFence));
+    }
+  }
+  return FCP_OK;
+}
+} // namespace
+
 int fcp_plan_destroy(fcp_plan_t *p) {
   if (!p) return FCP_OK;
   if (!p->host_only) {
@@ -1712,13 +1773,7 @@ int fcp_plan_destroy(fcp_plan_t *p) {
     if (guard.enter(p->desc.device) == FCP_OK) {
       (void)hipDeviceSynchronize();
       pending_forget(p);
-      for (auto &l : p->lanes) {
-        for (int i = 0; i < kLaneEvents; ++i) {
-          if (l->in[i]) (void)hipEventDestroy(l->in[i]);
-          if (l->out[i]) (void)hipEventDestroy(l->out[i]);
-        }
-        if (l->stream) (void)hipStreamDestroy(l->stream);
-      }
+      destroy_lanes(p, true);
       destroy_device(p);
     }
   }
@@ -1947,62 +2002,195 @@ int fcp_internal_process(fcp_plan_t *p, const fcp_process_args_t *a, fcp_process
 // the rewritten graph (cuda_emitter.cc:2632-2643), i.e. alive until the consumer has been enqueued behind that wait.
 int fcp_plan_set_private_streams(fcp_plan_t *p, int32_t n_streams, uint32_t flags) {
   if (!p || n_streams < 0 || n_streams > 16) return fail(FCP_ERR_INVALID_ARGUMENT, "private streams: 0..16");
-  if (flags & ~(uint32_t)(FCP_PRIVATE_NO_CALLER_WAIT | FCP_PRIVATE_ALWAYS)) return fail(FCP_ERR_INVALID_ARGUMENT, "unknown private-stream flags");
+  if (flags & ~(uint32_t)(FCP_PRIVATE_NO_CALLER_WAIT | FCP_PRIVATE_ALWAYS | FCP_PRIVATE_NO_VERIFY)) return fail(FCP_ERR_INVALID_ARGUMENT, "unknown private-stream flags");
   if (p->host_only) return fail(FCP_ERR_NO_DEVICE, "host-only plan");
   DeviceGuard guard;
   int rc = guard.enter(p->desc.device);
   if (rc) return rc;
   std::lock_guard<std::mutex> lock(p->mu);
+  std::lock_guard<std::mutex> cal_lock(p->lane_cal_mu);
   for (auto &l : p->lanes) HIP_TRY(hipStreamSynchronize(l->stream)); // results of the old lanes are complete from here on
   pending_forget(p);
-  for (auto &l : p->lanes) {
-    for (int i = 0; i < kLaneEvents; ++i) {
-      if (l->in[i]) (void)hipEventDestroy(l->in[i]);
-      if (l->out[i]) (void)hipEventDestroy(l->out[i]);
-    }
-    (void)hipStreamDestroy(l->stream);
-  }
-  p->lanes.clear();
+  destroy_lanes(p, true);
+  p->lane_verdicts.clear();
+  p->lane_good_caller.store(nullptr, std::memory_order_release);
   p->lane_flags = flags;
   {
     const char *e = std::getenv("FCP_PRIVATE_MIN_WORK_BYTES"); // tuning aid
     p->lane_min_work = (flags & FCP_PRIVATE_ALWAYS) ? 0 : (e ? std::atoll(e) : (int64_t)48 << 20);
   }
-  // The lanes are created in the runtime's LOW-priority queue pool.  ROCm maps a process' streams onto GPU_MAX_HW_QUEUES
-  // (default 4) hardware queues PER PRIORITY LEVEL, round robin: lanes of normal priority share hardware queues with the
-  // caller's own streams as soon as the process has more than four, and a lane that shares a queue with the stream its
-  // consumer waits on serialises behind that wait — measured: no gain at all with the default environment (27.6-35.9 us
-  // against 28.5 on one stream), 24.8-25.3 us with the lanes in a pool of their own, whatever the variable says
-  // (profiles/r04_private_streams_queue_pools.txt).  Low rather than high: the embedding stage of a LATER request yields to
-  // the consumers of earlier ones where they compete.  FCP_LANE_PRIORITY=normal|high|low overrides.
   // More than three lanes are not created: with four or more event-linked queues in flight every request took 35-100 us
-  // (one stream: 28.5) under every queue count and priority tried (same file); independent streams do not show it (2..8
-  // serve workers: 23-25 us).  The request stays accepted — the round robin simply runs over three.
+  // (one stream: 28.5) under every queue count and priority tried (profiles/r04_private_streams_queue_pools.txt);
+  // independent streams do not show it (2..8 serve workers: 23-25 us).  The request stays accepted — the round robin
+  // simply runs over three.
   constexpr int kMaxLanes = 3;
   if (n_streams > kMaxLanes && !std::getenv("FCP_PRIVATE_LANES_UNCAPPED")) n_streams = kMaxLanes;
-  int least = 0, greatest = 0;
-  HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
-  int lane_priority = least;
-  bool with_priority = least != greatest;
-  if (const char *e = std::getenv("FCP_LANE_PRIORITY")) {
-    if (!std::strcmp(e, "normal")) with_priority = false;
-    else lane_priority = !std::strcmp(e, "high") ? greatest : least;
+  p->lane_count = n_streams;
+  // FCP_LANE_PRIORITY=normal|low|high: the priority the lanes START with (normal: a mapping that does not overlap then
+  // costs 29-44 us per S2 request; with another priority 74-87 us, profiles/r04_private_streams_queue_mapping.txt).
+  // Verification (below) moves on to the others.
+  int prio = 0;
+  if (const char *e = std::getenv("FCP_LANE_PRIORITY")) prio = !std::strcmp(e, "low") ? 1 : !std::strcmp(e, "high") ? 2 : 0;
+  return create_lanes(p, n_streams, prio);
+}
+
+// ---- diagnostic: do the plan's private streams overlap behind THIS caller stream, in THIS process? ----------------------
+// Whether event-linked streams overlap depends on which hardware queues the runtime gave them (creation order of every
+// stream of the process, GPU_MAX_HW_QUEUES, priorities): the same three lanes measured 24.5 us per S2 request or 40-85 us
+// (one stream: 28.6) with nothing changed but the number of streams the process had created before
+// (profiles/r04_private_streams_queue_mapping.txt).  The probe replays the request pattern with kernels that only wait:
+// `requests` kernels of `spin_us` microseconds (grid_blocks x 256 threads), each followed — lanes - 1 requests later — by
+// its consumer (fcp_result_wait's stream wait + a one-thread kernel) on the caller's stream; once back to back on the
+// caller's stream (serial_us), once through the lanes (lanes_us); host clock around each, ending with a synchronisation
+// of `stream`.  lanes_us well below serial_us: the lanes overlap; at or above it: they do not, or worse.
+namespace {
+__global__ void fcp_spin_kernel(unsigned long long ticks) { // s_memrealtime: 100 MHz
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(4);
+}
+__global__ void fcp_probe_consumer_kernel() {}
+} // namespace
+
+namespace {
+// (the plan's device is current; lane_cal_mu is held: the lanes are not re-created meanwhile)
+int run_lane_probe(fcp_plan *p, hipStream_t caller, int requests, int spin_us, int grid_blocks, double *serial_us, double *lanes_us) {
+  const unsigned long long ticks = 100ull * (unsigned long long)spin_us;
+  const dim3 grid(grid_blocks), block(FCP_BLOCK_THREADS);
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+    return std::chrono::duration<double, std::micro>(b - a).count();
+  };
+  HIP_TRY(hipStreamSynchronize(caller));
+  auto t0 = now();
+  for (int i = 0; i < requests; ++i) {
+    hipLaunchKernelGGL(fcp_spin_kernel, grid, block, 0, caller, ticks);
+    hipLaunchKernelGGL(fcp_probe_consumer_kernel, dim3(1), dim3(1), 0, caller);
   }
-  for (int k = 0; k < n_streams; ++k) {
-    std::unique_ptr<PrivateLane> l(new PrivateLane());
-    if (with_priority) {
-      HIP_TRY(hipStreamCreateWithPriority(&l->stream, hipStreamNonBlocking, lane_priority));
-    } else {
-      HIP_TRY(hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking));
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(caller));
+  if (serial_us) *serial_us = us(t0, now());
+  if (p->lanes.empty()) {
+    if (lanes_us) *lanes_us = 0.0;
+    return FCP_OK;
+  }
+  const int nl = (int)p->lanes.size();
+  std::vector<hipEvent_t> done((size_t)requests, nullptr);
+  t0 = now();
+  for (int i = 0; i < requests; ++i) {
+    PrivateLane &L = *p->lanes[i % nl];
+    {
+      std::lock_guard<std::mutex> lane_lock(L.mu);
+      const uint32_t e = L.next++ % kLaneEvents;
+      if (!(p->lane_flags & FCP_PRIVATE_NO_CALLER_WAIT)) {
+        HIP_TRY(hipEventRecord(L.in[e], caller));
+        HIP_TRY(hipStreamWaitEvent(L.stream, L.in[e], 0));
+      }
+      hipExtLaunchKernelGGL(fcp_spin_kernel, grid, block, 0, L.stream, nullptr, L.out[e], 0, ticks);
+      HIP_TRY(hipGetLastError());
+      done[i] = L.out[e];
     }
-    p->lanes.push_back(std::move(l)); // owned from here on: a failure below leaves lanes that plan destruction releases
-    PrivateLane &L = *p->lanes.back();
-    for (int i = 0; i < kLaneEvents; ++i) {
-      HIP_TRY(hipEventCreateWithFlags(&L.in[i], hipEventDisableTiming | hipEventDisableSystemFence));
-      HIP_TRY(hipEventCreateWithFlags(&L.out[i], hipEventDisableTiming | hipEventDisableSystemFence));
+    const int k = i - (nl - 1);
+    if (k >= 0) {
+      HIP_TRY(hipStreamWaitEvent(caller, done[k], 0));
+      hipLaunchKernelGGL(fcp_probe_consumer_kernel, dim3(1), dim3(1), 0, caller);
     }
   }
+  for (int k = std::max(requests - (nl - 1), 0); k < requests; ++k) {
+    HIP_TRY(hipStreamWaitEvent(caller, done[k], 0));
+    hipLaunchKernelGGL(fcp_probe_consumer_kernel, dim3(1), dim3(1), 0, caller);
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(caller));
+  if (lanes_us) *lanes_us = us(t0, now());
   return FCP_OK;
+}
+
+// The first lane-eligible request of a caller stream: do the lanes overlap behind it?  While no caller has been found
+// good, other mappings are tried: the lanes re-created with the next priority, then behind one more spacer stream (a
+// stream that has run one empty kernel holds a hardware queue and shifts everything created after it), up to
+// kMaxSpacers.  The probe: 24 one-block kernels of 40 us with their consumers, three times (the first pass brings the
+// queues up, the better of the other two counts); serial / lanes >= 1.5 (three lanes) counts as overlap: 1.9-2.0 on
+// mappings where S2 runs at 24.5-25.1 us per request, <= 1.34 where it runs at 28.7-86 us
+// (scripts/probes/lane_probe_vs_real.py, profiles/r04_private_streams_queue_mapping.txt).
+// Costs the first request ~4 ms per mapping tried (host blocked, caller's stream drained).  *ok = false: this caller's
+// requests stay on its own stream.
+int verify_lanes(fcp_plan *p, hipStream_t caller, bool *ok) {
+  std::lock_guard<std::mutex> cal_lock(p->lane_cal_mu);
+  *ok = false;
+  for (auto &v : p->lane_verdicts)
+    if (v.first == caller) {
+      *ok = v.second;
+      return FCP_OK;
+    }
+  if (p->lanes.empty()) return FCP_OK;
+  const bool verbose = std::getenv("FCP_PRIVATE_VERIFY_VERBOSE") != nullptr; // (read per verification: rare)
+  constexpr int kMaxSpacers = 6, kProbeSpinUs = 40;
+  // three lanes: 1.9-2.0 on mappings that overlap, <= 1.34 on the others; two lanes: 1.29-1.44 against <= 1.15; one lane
+  // never gains (its consumer waits for it at once: S2 45 us per request against 28.7 on the caller's stream, probe 0.73)
+  const double kProbeGood = p->lane_count >= 3 ? 1.5 : p->lane_count == 2 ? 1.25 : 1.1;
+  auto overlap = [&](double *ratio) -> int {
+    double best = 0;
+    for (int pass = 0; pass < 3; ++pass) { // the first pass brings the queues up; the better of the other two counts
+      double a = 0, b = 0;
+      const int rc = run_lane_probe(p, caller, 24, kProbeSpinUs, 1, &a, &b);
+      if (rc) return rc;
+      if (pass > 0 && b > 0) best = std::max(best, a / b);
+    }
+    *ratio = best;
+    return FCP_OK;
+  };
+  bool any_good = false;
+  for (auto &v : p->lane_verdicts) any_good |= v.second;
+  const int n = p->lane_count;
+  int first_prio = 0;
+  if (const char *e = std::getenv("FCP_LANE_PRIORITY")) first_prio = !std::strcmp(e, "low") ? 1 : !std::strcmp(e, "high") ? 2 : 0;
+  double ratio = 0;
+  int rc = overlap(&ratio);
+  if (rc) return rc;
+  bool good = ratio >= kProbeGood;
+  if (verbose) std::fprintf(stderr, "fcp private streams: caller %p, lanes as created: serial / lanes = %.2f\n", (void *)caller, ratio);
+  // other mappings only while nobody relies on the present one
+  for (int spacers = 0; !good && !any_good && spacers <= kMaxSpacers; ++spacers) {
+    if (spacers > 0) {
+      hipStream_t sp = nullptr;
+      HIP_TRY(hipStreamCreateWithFlags(&sp, hipStreamNonBlocking));
+      p->spacers.push_back(sp);
+      hipLaunchKernelGGL(fcp_probe_consumer_kernel, dim3(1), dim3(1), 0, sp);
+      HIP_TRY(hipStreamSynchronize(sp));
+    }
+    for (int k = (spacers == 0 ? 1 : 0); !good && k < 3; ++k) { // (spacers == 0, first priority: probed above)
+      const int prio = (first_prio + k) % 3;
+      for (auto &l : p->lanes) HIP_TRY(hipStreamSynchronize(l->stream));
+      destroy_lanes(p, false);
+      rc = create_lanes(p, n, prio);
+      if (rc) return rc;
+      rc = overlap(&ratio);
+      if (rc) return rc;
+      good = ratio >= kProbeGood;
+      if (verbose)
+        std::fprintf(stderr, "fcp private streams: caller %p, %d spacer(s), priority %s: serial / lanes = %.2f\n", (void *)caller,
+                     spacers, prio == 0 ? "normal" : prio == 1 ? "low" : "high", ratio);
+    }
+  }
+  p->lane_verdicts.emplace_back((void *)caller, good);
+  if (good) p->lane_good_caller.store((void *)caller, std::memory_order_release);
+  *ok = good;
+  return FCP_OK;
+}
+} // namespace
+
+int fcp_plan_probe_private_streams(fcp_plan_t *p, void *stream, int32_t requests, int32_t spin_us, int32_t grid_blocks,
+                                   double *serial_us, double *lanes_us) {
+  if (!p || requests < 1 || requests > 4096 || spin_us < 1 || spin_us > 10000 || grid_blocks < 1 || grid_blocks > (1 << 20))
+    return fail(FCP_ERR_INVALID_ARGUMENT, "probe: bad arguments");
+  if (p->host_only) return fail(FCP_ERR_NO_DEVICE, "host-only plan");
+  hipStream_t caller = static_cast<hipStream_t>(stream);
+  if (stream_is_capturing(caller)) return fail(FCP_ERR_INVALID_ARGUMENT, "probe: the stream is being captured");
+  DeviceGuard guard;
+  int rc = guard.enter(p->desc.device);
+  if (rc) return rc;
+  std::lock_guard<std::mutex> cal_lock(p->lane_cal_mu);
+  return run_lane_probe(p, caller, requests, spin_us, grid_blocks, serial_us, lanes_us);
 }
 
 int fcp_plan_set_request_order(fcp_plan_t *p, int32_t order) {
@@ -2013,13 +2201,32 @@ int fcp_plan_set_request_order(fcp_plan_t *p, int32_t order) {
 
 int fcp_process_feature_columns(fcp_plan_t *p, const fcp_process_args_t *a, fcp_process_result_t *r) {
   if (!p || !a) return fail(FCP_ERR_INVALID_ARGUMENT, "null plan / args");
-  if (p->lanes.empty() || p->last_work_bytes.load(std::memory_order_relaxed) < p->lane_min_work) return fcp_internal_process(p, a, r);
+  if (p->lanes.empty()) return fcp_internal_process(p, a, r);
   hipStream_t caller = static_cast<hipStream_t>(a->stream);
-  // a capture records the caller's stream only: the request stays there (cross-stream events would fork the capture)
-  if (stream_is_capturing(caller)) return fcp_internal_process(p, a, r);
+  // small requests stay on the caller's stream; so does a capture, which records the caller's stream only (cross-stream
+  // events would fork it)
+  if (p->last_work_bytes.load(std::memory_order_relaxed) < p->lane_min_work || stream_is_capturing(caller)) {
+    fcp_process_result_t local{};
+    if (!r) r = &local;
+    const int rc = fcp_internal_process(p, a, r);
+    if (rc == FCP_OK && r->buffer) pending_clear_range(r->buffer, r->buffer_bytes);
+    return rc;
+  }
   DeviceGuard guard;
   int rc = guard.enter(p->desc.device);
   if (rc) return rc;
+  if (!(p->lane_flags & FCP_PRIVATE_NO_VERIFY) && p->lane_good_caller.load(std::memory_order_acquire) != (void *)caller) {
+    bool ok = false;
+    rc = verify_lanes(p, caller, &ok); // first request of this caller: probes (and may re-create) the lanes; later: a lookup
+    if (rc) return rc;
+    if (!ok) {
+      fcp_process_result_t local{};
+      if (!r) r = &local;
+      rc = fcp_internal_process(p, a, r);
+      if (rc == FCP_OK && r->buffer) pending_clear_range(r->buffer, r->buffer_bytes);
+      return rc;
+    }
+  }
   PrivateLane &L = *p->lanes[p->lane_rr.fetch_add(1, std::memory_order_relaxed) % p->lanes.size()];
   std::lock_guard<std::mutex> lane_lock(L.mu);
   const uint32_t e = L.next++ % kLaneEvents;

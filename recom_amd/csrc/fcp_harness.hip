@@ -277,6 +277,9 @@ int fcp_harness_run_private(fcp_harness *h, int steps, int depth, double *wall_m
   return FCP_OK;
 }
 
+// worker `t`'s stream (what fcp_harness_run_private issues on is worker 0's): for probes that need the caller's stream
+void *fcp_harness_stream(fcp_harness *h, int t) { return (h && t >= 0 && t < (int)h->streams.size()) ? h->streams[t] : nullptr; }
+
 int fcp_harness_destroy(fcp_harness *h) {
   if (!h) return FCP_OK;
   for (size_t t = 0; t < h->streams.size(); ++t) {

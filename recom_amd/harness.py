@@ -39,6 +39,9 @@ def load() -> C.CDLL:
         H.fcp_harness_run_graph.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double),
                                             C.POINTER(C.c_float)]
         H.fcp_harness_destroy.argtypes = [C.c_void_p]
+        if hasattr(H, "fcp_harness_stream"):
+            H.fcp_harness_stream.argtypes = [C.c_void_p, C.c_int]
+            H.fcp_harness_stream.restype = C.c_void_p
         if hasattr(H, "fcp_harness_run_private"):
             H.fcp_harness_run_private.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_float)]
         H.fcp_harness_copy_probe.argtypes = [C.c_size_t, C.c_int, C.POINTER(C.c_float)]
@@ -96,6 +99,10 @@ class ServingHarness:
         _lib.check(self.H.fcp_harness_run(self.handle, steps, C.byref(wall), C.byref(dev),
                                           None if it is None else it.ctypes.data), "fcp_harness_run")
         return wall.value, dev.value, it
+
+    def caller_stream(self, worker: int = 0) -> int:
+        """The HIP stream worker ``worker`` issues on (``run_private``: worker 0's is the caller's stream)."""
+        return int(self.H.fcp_harness_stream(self.handle, worker) or 0)
 
     def run_private(self, steps: int, depth: int = 3):
         """One host thread and ONE caller stream over a plan with private streams (``self.plan.set_private_streams``

@@ -223,14 +223,24 @@ class Plan:
                    "fcp_plan_arena_bytes")
         return out.value
 
-    def set_private_streams(self, n_streams: int, no_caller_wait: bool = False, always: bool = False) -> None:
+    def set_private_streams(self, n_streams: int, no_caller_wait: bool = False, always: bool = False, verify: bool = True) -> None:
         """``fcp_plan_set_private_streams``: requests of one caller stream run on ``n_streams`` plan-owned streams
-        (0 = off; the library creates at most three, in the runtime's low-priority queue pool); readers of a result order
-        themselves behind it with ``fcp_result_wait``.  ``always``: also requests
-        whose work is below the library's threshold (48 MiB gathered + written), which otherwise stay on the caller's stream."""
-        _lib.check(self._L.fcp_plan_set_private_streams(self.handle, int(n_streams), (1 if no_caller_wait else 0) | (2 if always else 0)),
+        (0 = off; the library creates at most three); readers of a result order themselves behind it with
+        ``fcp_result_wait``.  ``always``: also requests whose work is below the library's threshold (48 MiB gathered +
+        written), which otherwise stay on the caller's stream.  ``verify`` (default): the first such request of every caller
+        stream probes whether the streams really overlap behind it in this process and otherwise looks for a mapping that
+        does, or keeps that caller's requests on its own stream (``FCP_PRIVATE_NO_VERIFY`` when False)."""
+        _lib.check(self._L.fcp_plan_set_private_streams(self.handle, int(n_streams),
+                                                        (1 if no_caller_wait else 0) | (2 if always else 0) | (0 if verify else 4)),
                    "fcp_plan_set_private_streams")
         self.private_streams = int(n_streams)
+
+    def probe_private_streams(self, stream: int, requests: int = 24, spin_us: int = 20, grid_blocks: int = 2048):
+        """``fcp_plan_probe_private_streams``: (serial_us, lanes_us) of the synthetic request pattern behind ``stream``."""
+        a, b = C.c_double(), C.c_double()
+        _lib.check(self._L.fcp_plan_probe_private_streams(self.handle, C.c_void_p(stream), requests, spin_us, grid_blocks,
+                                                         C.byref(a), C.byref(b)), "fcp_plan_probe_private_streams")
+        return a.value, b.value
 
     def set_inputs_ready(self, on: bool = True) -> None:
         """``fcp_plan_set_request_order(FCP_ORDER_INPUTS_READY)``: the caller's promise that blobs are complete and arenas

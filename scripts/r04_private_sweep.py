@@ -19,6 +19,7 @@ ap.add_argument("--nowait", default="0,1")
 ap.add_argument("--requests", type=int, default=16)
 args = ap.parse_args()
 model = {"s2": synth.model_s2, "ragged": lambda: synth.staged_model(synth.model_ragged(seg="indices")),
+         "ragged_ad": lambda: synth.model_ragged(seg="indices"), "ragged_csr": lambda: synth.model_ragged(seg="csr"),
          "e": lambda: synth.staged_model(synth.model_ae("e"))}[args.workload]()
 base = ServingHarness(model, n_requests=args.requests, arena_ring=8, n_threads=1)
 base.run(200)

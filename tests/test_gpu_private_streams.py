@@ -145,6 +145,115 @@ def test_default_call_orders_the_callers_stream_itself(torch_cuda, oracle):
     lib.check(lib.load().fcp_plan_release_captures(op.plan.handle), "release")
 
 
+def test_request_on_the_callers_stream_forgets_the_older_private_stream_result_of_its_arena(torch_cuda, oracle, monkeypatch):
+    """A plan with private streams keeps some requests on the caller's stream (below the work threshold; a stream that is
+    being captured).  Such a request writes its arena in stream order: the registry entry an OLDER private-stream request
+    left for the same memory is dropped, so the reader's fcp_result_wait finds nothing — inside a capture it would
+    otherwise wait for an event of another stream that the capture knows nothing about.  One arena address for every
+    request; first request on the caller's stream (nothing installed yet), second on a private stream, third captured."""
+    from recom_amd import lib, synth
+    from recom_amd.ops import FeatureColumnProcess, concat_inputs
+    torch = torch_cuda
+    monkeypatch.setenv("FCP_PRIVATE_MIN_WORK_BYTES", "1")              # read by fcp_plan_set_private_streams
+    m = synth.model_mixed(batch=96, vocab=997, n_groups=1)
+    tabs_np = m.numpy_tables()
+    tabs = [torch.from_numpy(t).cuda() for t in tabs_np]
+    op = FeatureColumnProcess(m.spec, 0)
+    fixed = torch.empty(32 << 20, dtype=torch.uint8, device="cuda")
+
+    def allocators():
+        state = {"arena": None, "temps": []}
+
+        def _alloc(_ctx, nbytes):
+            assert nbytes <= fixed.numel()
+            state["arena"] = fixed[:int(nbytes)]
+            return fixed.data_ptr()
+
+        def _alloc_temp(_ctx, nbytes):
+            t = torch.empty(int(nbytes), dtype=torch.uint8, device="cuda")
+            state["temps"].append(t)
+            return t.data_ptr()
+        return state, lib.ALLOC_FN(_alloc), lib.ALLOC_FN(_alloc_temp)
+    op._allocators = allocators
+    op.plan.set_private_streams(2)
+    r = m.make_request(7, B=64)
+    blob, offsets, shapes = concat_inputs(r.inputs)
+    d_blob = torch.from_numpy(blob).cuda()
+    want, _ = oracle.process_feature_columns(m.spec.to_dict(), blob, offsets, shapes, tabs_np, r.symbols)
+    s = torch.cuda.Stream()
+    L = lib.load()
+    with torch.cuda.stream(s):
+        out = op(d_blob, offsets, shapes, tabs, r.symbols)             # 1: caller's stream (no work figure yet), installs the shapes for s
+        first = out.groups[0].clone()
+        _busy(torch, s, 0.3)
+        out = op(d_blob, offsets, shapes, tabs, r.symbols, defer_wait=True)   # 2: private stream; the registry now names the arena
+        out.wait()
+        second = out.groups[0].clone()
+    torch.cuda.synchronize()
+    assert np.array_equal(first.cpu().numpy(), want[0]) and np.array_equal(second.cpu().numpy(), want[0])
+    fixed.zero_()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        out = op(d_blob, offsets, shapes, tabs, r.symbols)             # 3: captured: stays on s, and so does the reader's wait
+        lib.check(L.fcp_result_wait(fixed.data_ptr(), s.cuda_stream), "fcp_result_wait inside the capture")
+    g.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(out.groups[0].cpu().numpy(), want[0])
+    lib.check(L.fcp_plan_release_captures(op.plan.handle), "release")
+
+
+def test_private_streams_are_verified_per_caller_stream_and_results_do_not_depend_on_the_verdict(torch_cuda, oracle, capfd, monkeypatch):
+    """Whether event-linked streams overlap depends on the hardware queues the runtime mapped them to (N streams created
+    before the lanes change it, profiles/r04_private_streams_queue_mapping.txt), so the first request of a caller stream
+    probes it and the library may re-create its lanes or leave that caller's requests on its own stream.  Here: dummy
+    streams shift the mapping; every caller stream gets its verdict exactly once (FCP_PRIVATE_VERIFY_VERBOSE names it);
+    results are bit-exact with the oracle whatever the verdict; FCP_PRIVATE_NO_VERIFY probes nothing; the diagnostic entry
+    point reports both times of the synthetic pattern."""
+    from recom_amd import synth
+    from recom_amd.ops import FeatureColumnProcess, concat_inputs
+    torch = torch_cuda
+    monkeypatch.setenv("FCP_PRIVATE_VERIFY_VERBOSE", "1")
+    m = synth.model_mixed(batch=96, vocab=997, n_groups=1)
+    tabs_np = m.numpy_tables()
+    tabs = [torch.from_numpy(t).cuda() for t in tabs_np]
+    reqs = [m.make_request(900 + k, B=70 + k) for k in range(6)]
+    packed = [concat_inputs(r.inputs) for r in reqs]
+    blobs = [torch.from_numpy(p[0]).cuda() for p in packed]
+    want = [oracle.process_feature_columns(m.spec.to_dict(), p[0], p[1], p[2], tabs_np, r.symbols)[0][0] for r, p in zip(reqs, packed)]
+    dummies = []
+    for n_dummy in (0, 2, 3):
+        while len(dummies) < n_dummy:                                  # streams that have run something hold hardware queues
+            d = torch.cuda.Stream()
+            with torch.cuda.stream(d):
+                torch.zeros(8, device="cuda").add_(1)
+            d.synchronize()
+            dummies.append(d)
+        for verify in (True, False):
+            op = FeatureColumnProcess(m.spec, 0)
+            op.plan.set_private_streams(3, always=True, verify=verify)
+            callers = [torch.cuda.Stream(), torch.cuda.Stream()]
+            capfd.readouterr()
+            for rounds in range(2):
+                for s in callers:
+                    outs = []
+                    with torch.cuda.stream(s):
+                        for k in range(len(reqs)):
+                            outs.append(op(blobs[k], packed[k][1], packed[k][2], tabs, reqs[k].symbols, defer_wait=True))
+                        for o in outs:
+                            o.wait()
+                        got = [o.groups[0].clone() for o in outs]
+                    s.synchronize()
+                    for k in range(len(reqs)):
+                        assert np.array_equal(got[k].cpu().numpy(), want[k]), (n_dummy, verify, rounds, k)
+            err = capfd.readouterr().err
+            verdicts = [ln for ln in err.splitlines() if "lanes as created" in ln]
+            assert len(verdicts) == (2 if verify else 0), err          # once per caller stream, never again
+            a, b = op.plan.probe_private_streams(callers[0].cuda_stream, requests=12, spin_us=20, grid_blocks=1)
+            assert a > 12 * 20 and b > 0
+            del op
+
+
 def test_native_single_caller_loop_runs_s2_shape_and_is_faster_than_serial(torch_cuda):
     """The native loop bench.py times (fcp_harness_run_private): S2's shape at a small vocabulary, one caller stream,
     depth 3 over 3 private streams against the same requests back to back on that stream.  Asserts that it runs, that the
