@@ -112,6 +112,15 @@ def test_host_only_plan_cannot_run_and_real_plan_needs_a_gpu():
     p = _host_plan(m.spec)
     a = lib.ProcessArgs()
     assert p._L.fcp_process_feature_columns(p.handle, C.byref(a), None) == lib.FCP_ERR_NO_DEVICE
+    # the serving-mode entry points refuse a plan without a device the same way, and check their arguments first
+    assert p._L.fcp_plan_set_private_streams(p.handle, 3, 0) == lib.FCP_ERR_NO_DEVICE
+    assert p._L.fcp_plan_set_private_streams(p.handle, 17, 0) == lib.FCP_ERR_INVALID_ARGUMENT
+    assert p._L.fcp_plan_set_private_streams(p.handle, 3, 1 << 3) == lib.FCP_ERR_INVALID_ARGUMENT     # unknown flag
+    sa, sb = C.c_double(), C.c_double()
+    assert p._L.fcp_plan_probe_private_streams(p.handle, None, 24, 20, 1, C.byref(sa), C.byref(sb)) == lib.FCP_ERR_NO_DEVICE
+    assert p._L.fcp_plan_probe_private_streams(p.handle, None, 0, 20, 1, C.byref(sa), C.byref(sb)) == lib.FCP_ERR_INVALID_ARGUMENT
+    assert p._L.fcp_plan_probe_private_streams(None, None, 24, 20, 1, C.byref(sa), C.byref(sb)) == lib.FCP_ERR_INVALID_ARGUMENT
+    assert p._L.fcp_result_wait(None, None) == lib.FCP_ERR_INVALID_ARGUMENT
     p.close()
     if not torch.cuda.is_available():
         with pytest.raises(lib.FcpError) as e:
