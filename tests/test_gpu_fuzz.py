@@ -196,7 +196,8 @@ def random_model(rng, dense_only=False, extended=True):
 
 
 # FCP_FUZZ_SEEDS=<n>: longer soak runs (the suite keeps 24)
-@pytest.mark.parametrize("seed", range(int(os.environ.get("FCP_FUZZ_SEEDS", "24"))))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FCP_FUZZ_SEED0", "0")),
+                                        int(os.environ.get("FCP_FUZZ_SEED0", "0")) + int(os.environ.get("FCP_FUZZ_SEEDS", "24"))))
 def test_random_plans_match_oracle(oracle, seed):
     import dataclasses
     import torch
