@@ -494,7 +494,8 @@ def main():
         single_caller = {"what": "one host thread, one caller stream (the TF op's situation): requests run on the plan's private "
                                  "streams, the consumer of request k (fcp_result_wait + a reader kernel on the caller's stream) is "
                                  "enqueued `private_streams - 1` requests later; host wall clock over the loop incl. the final sync.  The "
-                                 "private streams live in the runtime's low-priority queue pool (no dependence on GPU_MAX_HW_QUEUES)",
+                                 "library verified on the first request that its private streams overlap behind this caller stream (or searched a "
+                                 "hardware-queue mapping that does; profiles/r04_private_streams_queue_mapping.txt)",
                          "private_streams": best, **sweep[best],
                          "sweep_us_per_request": {str(k): v["us_per_request"] for k, v in sweep.items()},
                          "inputs_ready_back_to_back": inputs_ready}
