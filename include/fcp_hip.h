@@ -562,6 +562,10 @@ int fcp_concat_outputs_host(const void *const *host_inputs, const int32_t *dims,
  * overlaps the kernel of request k); `stream` is made to wait for that copy.  The
  * returned pointers stay valid until the slot is reused, i.e. for the next depth-1
  * calls; the work that reads them must be enqueued on `stream` before the next call.
+ * (A plan with private streams runs that work elsewhere: fcp_process_feature_columns
+ * then files the blob it was given next to the arena, and the stager waits for that
+ * reader — the copy stream, or the host for a zero-copy slot — before it overwrites
+ * the slot.  Nothing to do for the caller.)
  *
  * fcp_stager_stage_narrow additionally converts the int64 inputs flagged in
  * `narrow_int64[n_inputs]` to int32 while packing (values outside [0, 2^31) become

@@ -142,18 +142,37 @@ struct PendingResult {
   const void *owner; // the plan whose lane owns `done`
 };
 std::mutex g_pending_mu;
-std::map<uintptr_t, PendingResult> g_pending;
+using PendingMap = std::map<uintptr_t, PendingResult>;
+PendingMap g_pending;
+// The same by the address range of the request's INPUT blob: the lane kernel is its last reader, and nothing on the caller's
+// stream says when it has run.  TensorFlow's allocator cannot hand the blob out again before Addons>ConcatOutputs (which
+// holds it as a `tensor_buffers` input and waits for the result) has been enqueued; the request stager recycles its ring by
+// itself and asks here (stager_input_wait / stager_input_synchronize) before it overwrites a slot.
+PendingMap g_pending_inputs;
 
-void pending_register(const void *owner, void *arena, int64_t bytes, hipEvent_t done) {
-  const uintptr_t b = reinterpret_cast<uintptr_t>(arena), e = b + (uintptr_t)std::max<int64_t>(bytes, 1);
+void pending_put(PendingMap &m, const void *owner, const void *base, int64_t bytes, hipEvent_t done) { // (g_pending_mu held)
+  const uintptr_t b = reinterpret_cast<uintptr_t>(base), e = b + (uintptr_t)std::max<int64_t>(bytes, 1);
+  auto it = m.lower_bound(b);
+  if (it != m.begin() && std::prev(it)->second.end > b) --it;
+  while (it != m.end() && it->first < e) it = m.erase(it); // every older entry that overlaps this range
+  m[b] = PendingResult{e, done, owner};
+  if (m.size() > 256) // ranges that are never handed out again: drop what has completed
+    for (auto j = m.begin(); j != m.end();)
+      j = (j->first != b && hipEventQuery(j->second.done) == hipSuccess) ? m.erase(j) : std::next(j);
+}
+
+void pending_register(const void *owner, void *arena, int64_t bytes, const void *blob, int64_t blob_bytes, hipEvent_t done) {
   std::lock_guard<std::mutex> lock(g_pending_mu);
-  auto it = g_pending.lower_bound(b);
-  if (it != g_pending.begin() && std::prev(it)->second.end > b) --it;
-  while (it != g_pending.end() && it->first < e) it = g_pending.erase(it); // every older result that overlaps this range
-  g_pending[b] = PendingResult{e, done, owner};
-  if (g_pending.size() > 256) // ranges that are never handed out again: drop what has completed
-    for (auto j = g_pending.begin(); j != g_pending.end();)
-      j = (j->first != b && hipEventQuery(j->second.done) == hipSuccess) ? g_pending.erase(j) : std::next(j);
+  pending_put(g_pending, owner, arena, bytes, done);
+  if (blob && blob_bytes > 0) pending_put(g_pending_inputs, owner, blob, blob_bytes, done);
+}
+
+// the event of the last private-stream request that read [base, base + bytes), or nullptr (g_pending_mu held)
+hipEvent_t pending_input_event(const void *base, int64_t bytes) {
+  const uintptr_t b = reinterpret_cast<uintptr_t>(base), e = b + (uintptr_t)std::max<int64_t>(bytes, 1);
+  auto it = g_pending_inputs.lower_bound(b);
+  if (it != g_pending_inputs.begin() && std::prev(it)->second.end > b) --it;
+  return (it != g_pending_inputs.end() && it->first < e) ? it->second.done : nullptr;
 }
 
 // A request that stays on the caller's stream although its plan has private streams (below the work threshold, or the
@@ -170,7 +189,29 @@ void pending_clear_range(void *arena, int64_t bytes) {
 
 void pending_forget(const void *owner) {
   std::lock_guard<std::mutex> lock(g_pending_mu);
-  for (auto j = g_pending.begin(); j != g_pending.end();) j = j->second.owner == owner ? g_pending.erase(j) : std::next(j);
+  for (PendingMap *m : {&g_pending, &g_pending_inputs})
+    for (auto j = m->begin(); j != m->end();) j = j->second.owner == owner ? m->erase(j) : std::next(j);
+}
+
+// The request stager is about to overwrite a device blob / a pinned buffer the kernels read directly: `stream` (the copy
+// stream) or the host waits for the private-stream request that read it last.  (The stager's own `consumed` events are
+// recorded on the caller's stream, which does not wait for private-stream kernels.)
+bool stager_reader_wait_off() { // test aid: FCP_STAGER_NO_READER_WAIT=1 reproduces the hazard the two functions below close
+  static const bool off = std::getenv("FCP_STAGER_NO_READER_WAIT") != nullptr;
+  return off;
+}
+int stager_input_wait(const void *base, int64_t bytes, hipStream_t stream) {
+  if (stager_reader_wait_off()) return FCP_OK;
+  std::lock_guard<std::mutex> lock(g_pending_mu); // (held over the runtime call: the owning plan may not go away meanwhile)
+  if (hipEvent_t ev = pending_input_event(base, bytes)) HIP_TRY(hipStreamWaitEvent(stream, ev, 0));
+  return FCP_OK;
+}
+int stager_input_synchronize(const void *base, int64_t bytes) {
+  if (stager_reader_wait_off()) return FCP_OK;
+  std::lock_guard<std::mutex> lock(g_pending_mu);
+  if (hipEvent_t ev = pending_input_event(base, bytes))
+    if (hipEventQuery(ev) != hipSuccess) HIP_TRY(hipEventSynchronize(ev));
+  return FCP_OK;
 }
 
 } // namespace
@@ -2250,7 +2291,7 @@ int fcp_process_feature_columns(fcp_plan_t *p, const fcp_process_args_t *a, fcp_
   fcp_set_stop_event(nullptr);
   if (rc) return rc;
   if (!attach || pending) HIP_TRY(hipEventRecord(L.out[e], L.stream));
-  pending_register(p, r->buffer, r->buffer_bytes, L.out[e]);
+  pending_register(p, r->buffer, r->buffer_bytes, a->concated_inputs, a->concated_bytes, L.out[e]);
   return FCP_OK;
 }
 
@@ -2779,6 +2820,8 @@ int fcp_stager_stage_ex(fcp_stager_t *s, const fcp_host_tensor_t *inputs, int32_
   // the slot's previous copy must have left the pinned buffer (zero copy: the kernels that read it must have run)
   if (s->zero_copy || sl.direct) {
     if (sl.consumed_valid && hipEventQuery(sl.consumed) != hipSuccess) HIP_TRY(hipEventSynchronize(sl.consumed));
+    // a plan with private streams runs the reader elsewhere; `consumed` (caller's stream) does not cover it
+    if (int rc3 = stager_input_synchronize(sl.h_blob_dev, s->capacity)) return rc3;
   } else if (hipEventQuery(sl.copied) != hipSuccess) {
     HIP_TRY(hipEventSynchronize(sl.copied));
   }
@@ -2800,6 +2843,7 @@ int fcp_stager_stage_ex(fcp_stager_t *s, const fcp_host_tensor_t *inputs, int32_
     // the device twin is free once the work that read its previous contents has run
     uint64_t a0 = now_ns(), a1;
     if (sl.consumed_valid) HIP_TRY(hipStreamWaitEvent(s->copy_stream, sl.consumed, 0));
+    if (int rc3 = stager_input_wait(sl.d_blob, s->capacity, s->copy_stream)) return rc3; // (private-stream readers, see there)
     if (s->stats) { a1 = now_ns(); s->ns_api[0] += a1 - a0; a0 = a1; }
     const uint64_t c0 = now_ns();
     if (size) HIP_TRY(hipMemcpyAsync(sl.d_blob, sl.h_blob, (size_t)size, hipMemcpyHostToDevice, s->copy_stream));

@@ -254,6 +254,68 @@ def test_private_streams_are_verified_per_caller_stream_and_results_do_not_depen
             del op
 
 
+class _RawBlob:
+    """A device address handed to the op wrapper in place of a torch tensor (the stager's blob)."""
+
+    def __init__(self, ptr, nbytes):
+        self._p, self._n = ptr, nbytes
+
+    def data_ptr(self):
+        return self._p
+
+    def numel(self):
+        return self._n
+
+    def element_size(self):
+        return 1
+
+
+@pytest.mark.parametrize("zero_copy", [False, True])
+def test_stager_does_not_recycle_a_blob_that_a_private_stream_still_reads(torch_cuda, oracle, zero_copy):
+    """The request stager recycles its ring behind events recorded on the CALLER's stream — which does not wait for
+    private-stream kernels.  The library therefore files a private-stream request's input blob next to its arena, and the
+    stager waits for that reader before it overwrites the slot.  Provoked here: ONE private stream (unverified) kept busy
+    by a dozen slow requests, a ring of ONE slot, small requests staged back to back: each of them sits in the lane's queue while
+    the next one is staged into the same slot.  Every result must be that of ITS request."""
+    from recom_amd import synth
+    from recom_amd.ops import FeatureColumnProcess, RequestStager, concat_inputs
+    torch = torch_cuda
+    m = synth.model_s2(columns=120, vocab=3000, batch=256)
+    tabs_np = m.numpy_tables()
+    tabs = [torch.from_numpy(t).cuda() for t in tabs_np]
+    op = FeatureColumnProcess(m.spec, 0)
+    op.plan.set_private_streams(1, always=True, verify=False)
+    st = RequestStager(4 << 20, m.spec.n_host_inputs, sum(m.spec.host_input_ranks), depth=1, n_threads=2, zero_copy=zero_copy)
+    big = m.make_request(1, B=50000)                                   # ~1 GB of output: the lane is busy for a while
+    big_blob, big_off, big_shp = concat_inputs(big.inputs)
+    d_big = torch.from_numpy(big_blob).cuda()
+    small = [m.make_request(10 + k, B=48 + k) for k in range(5)]
+    want = []
+    for r in small:
+        blob, offsets, shapes = concat_inputs(r.inputs)
+        want.append(oracle.process_feature_columns(m.spec.to_dict(), blob, offsets, shapes, tabs_np, r.symbols)[0][0])
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    for attempt in range(3):
+        with torch.cuda.stream(s):
+            slow = [op(d_big, big_off, big_shp, tabs, big.symbols, defer_wait=True) for _ in range(12)]   # several ms of lane time
+            outs = []
+            for r in small:
+                ptr, nbytes, offsets, shapes = st.stage(r.inputs, stream=s.cuda_stream)
+                outs.append(op(_RawBlob(ptr, nbytes), offsets, shapes, tabs, r.symbols, defer_wait=True))
+            got = []
+            for o in outs:
+                o.wait()
+                got.append(o.groups[0].clone())
+            for o in slow:
+                o.wait()
+        s.synchronize()
+        for k in range(len(small)):
+            assert np.array_equal(got[k].cpu().numpy(), want[k]), (zero_copy, attempt, k)
+        del slow, outs
+    st.close()
+
+
 def test_native_single_caller_loop_runs_s2_shape_and_is_faster_than_serial(torch_cuda):
     """The native loop bench.py times (fcp_harness_run_private): S2's shape at a small vocabulary, one caller stream,
     depth 3 over 3 private streams against the same requests back to back on that stream.  Asserts that it runs, that the
