@@ -4,9 +4,13 @@ The reference has no tests or golden vectors for this path, so t
 C oracle is pinned against (1) the committed fixtures in tests/golden/ (NumPy
 float64 + PyTorch-CPU expectations, see make_golden.py), (2) PyTorch-CPU
 ``embedding_bag`` / ``bucketize`` / ``index_select`` evaluated live, (3) its own
-NumPy restatement, and (4) the reference's dim>20 summation order restated in
-``orc_sparse_segment_reduce_ref8x8`` (tolerance only).
+NumPy restatement, (4) the reference's dim>20 summation order restated in
+``orc_sparse_segment_reduce_ref8x8``, and (5) tests/golden/ref_device_goldens.npz:
+outputs of the reference's OWN device templates, compiled unmodified for gfx950
+and run on an MI355X (make_ref_device_goldens.py) — bit for bit, see the last test.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -495,3 +499,50 @@ def test_segment_ids_through_a_folded_sparse_reshape(oracle, seg64):
         for w, g, t in zip(want, got, twin):
             assert np.array_equal(w, g)
             assert np.abs(np.asarray(t, np.float64) - w).max(initial=0.0) < 1e-5
+
+
+def test_oracle_equals_the_vectors_the_references_kernels_produced(oracle):
+    """tests/golden/ref_device_goldens.npz: outputs of the REFERENCE's own device templates — GatherRowsToGlbMem,
+    GatherScatterRows, experiment::ComputeSegmentOffsets / SparseSegmentReduce (cuda_emitter.cc:250-345, 664-962) and the
+    dim <= 20 SparseSegmentSum / Mean (:348-661, against hipCUB) — compiled unmodified for gfx950 and run on an MI355X by
+    tests/golden/make_ref_device_goldens.py (committed with the file).  The inputs are re-drawn from the seeds stored with
+    every case; the C oracle's restatements must equal the stored outputs BIT FOR BIT, here on the CPU, without a GPU:
+    orc_gather_rows, orc_gather_scatter_rows, orc_segment_offsets, orc_sparse_segment_reduce_ref8x8 (non-empty segments; an
+    empty MEAN segment is NaN in the reference, zero in TF and the oracle) and orc_sparse_segment_reduce_refscan_assoc with
+    the scan order of the library the vectors were produced against (ORC_SCAN_ROCPRIM64)."""
+    import importlib.util
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_ref_device_goldens", os.path.join(here, "make_ref_device_goldens.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    G = np.load(os.path.join(here, "ref_device_goldens.npz"))
+    n = int(G["n_cases"])
+    assert n == len(gen.CASES) >= 50
+    kinds = set()
+    for k in range(n):
+        rec = [str(v) for v in G[f"case_{k}"]]
+        case = dict(kind=rec[0], seed=int(rec[1]), dim=int(rec[2]), vocab=int(rec[3]), B=int(rec[4]), max_len=int(rec[5]), mean=int(rec[6]))
+        assert case == gen.CASES[k]                                       # the file belongs to this generator
+        x, want, B, mean = gen.inputs_of(case), G[f"out_{k}"], case["B"], bool(case["mean"])
+        kinds.add(case["kind"])
+        if case["kind"] == "gather_rows":
+            got, bad = oracle.gather_rows(x["table"], x["ids"])
+            assert bad == 0 and np.array_equal(got, want)
+        elif case["kind"] == "gather_scatter_rows":
+            got, bad = oracle.gather_scatter_rows(x["table"], x["ids"], x["rows"], B)
+            assert bad == 0 and np.array_equal(got, want)
+        elif case["kind"] == "segment_offsets":
+            assert np.array_equal(oracle.segment_offsets(x["seg"], B), want)
+        elif case["kind"] == "segment_reduce_8x8":
+            offs = G[f"offs_{k}"]
+            assert np.array_equal(oracle.segment_offsets(x["seg"], B), offs)
+            got, _ = oracle.sparse_segment_reduce(x["table"], x["ids"], offs, mean, ref_order=True)
+            empty = x["lens"] == 0
+            assert np.array_equal(got[~empty], want[~empty])
+            assert (np.isnan(want[empty]).all() if mean else not want[empty].any()) and not got[empty].any()
+        else:
+            got = oracle.sparse_segment_reduce_refscan(x["table"], x["ids"], x["seg"], B, mean, rocprim=True)
+            assert np.array_equal(got, want)
+            cub = oracle.sparse_segment_reduce_refscan(x["table"], x["ids"], x["seg"], B, mean)
+            assert np.abs(cub - want).max(initial=0) < (1e-5 if case["max_len"] <= 10 else 1e-4)   # the other scan order: reassociation only
+    assert kinds == {"gather_rows", "gather_scatter_rows", "segment_offsets", "segment_reduce_8x8", "segment_reduce_scan"}
