@@ -455,7 +455,10 @@ int fcp_process_feature_columns(fcp_plan_t *plan,
  * (FCP_PRIVATE_MIN_WORK_BYTES overrides); FCP_PRIVATE_ALWAYS sends every request
  * to a private stream.  Three streams measured best (two: 25-27 us on S2); with
  * four or more event-linked streams in flight every request took 35-100 us, so
- * at most three are created whatever n_streams says (the call still succeeds).
+ * at most three are used whatever n_streams says (the call still succeeds) — and
+ * the streams belong to the DEVICE, not to the plan: every plan of the process on
+ * that GPU rotates over the same three (two models with streams of their own
+ * would be six event-linked queues).  They live as long as the process.
  *
  * Verification.  Whether event-linked streams overlap on the GPU depends on which
  * hardware queues the HIP runtime mapped them to — the creation order of every
@@ -466,8 +469,8 @@ int fcp_process_feature_columns(fcp_plan_t *plan,
  * request of every caller stream that would take a private stream therefore runs
  * a short synthetic probe of the request pattern behind that stream (kernels that
  * only wait; the host blocks for ~4 ms and args->stream drains once).  While no
- * caller has been found good, other mappings are tried — the private streams are
- * re-created with the next priority (normal, low, high) and behind up to six
+ * live plan relies on the present mapping, other mappings are tried — the private
+ * streams are re-created with the next priority (normal, low, high) and behind up to six
  * spacer streams, ~4 ms each.  A caller behind which no mapping overlaps keeps
  * its requests on its own stream: the mode then costs nothing instead of a
  * multiple.  FCP_PRIVATE_NO_VERIFY skips all of it (the streams are used as

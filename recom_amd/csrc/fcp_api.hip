@@ -134,6 +134,26 @@ struct PrivateLane {
   uint32_t next = 0;
 };
 
+// The private lanes of ONE DEVICE, shared by every plan on it (created on first use, kept for the life of the process).
+// The command processor overlaps at most four event-linked queues — a caller's stream and three lanes; with a fifth every
+// request costs a multiple (profiles/r04_private_streams_queue_mapping.txt).  Lanes per plan would multiply them: two
+// models served by one process, three lanes each, fall off that cliff as soon as both are busy.
+struct LanePool {
+  std::mutex cal_mu;                                  // lanes / spacers are created, probed and re-created under it
+  std::vector<std::unique_ptr<PrivateLane>> lanes;
+  std::vector<hipStream_t> spacers;                   // streams that only hold hardware queues (verify_lanes)
+  std::atomic<int> n_relying{0};                      // live plans that found the present mapping good, or use it unverified
+  std::atomic<uint32_t> rr{0};
+};
+std::mutex g_lane_pools_mu;
+std::map<int, LanePool *> g_lane_pools;
+LanePool *lane_pool_for(int device) {
+  std::lock_guard<std::mutex> lock(g_lane_pools_mu);
+  LanePool *&lp = g_lane_pools[device];
+  if (!lp) lp = new LanePool();
+  return lp;
+}
+
 // Results whose kernels run on a private lane, by arena address range: what fcp_result_wait looks up.  An entry is
 // replaced when its address range is handed out again and dropped once its event has completed (nothing to wait for).
 struct PendingResult {
@@ -277,18 +297,16 @@ struct fcp_plan {
 
   // Plan-owned private streams (fcp_plan_set_private_streams): requests of ONE caller stream run on a rotating set of
   // lanes so that consecutive requests overlap on the GPU (the front of one launch under the memory phase of another).
-  std::vector<std::unique_ptr<PrivateLane>> lanes;
-  std::atomic<uint32_t> lane_rr{0};
+  LanePool *pool = nullptr;                             // the device's lanes; the plan uses the first lane_count of them
   uint32_t lane_flags = 0;
   // Verification (verify_lanes): whether event-linked streams overlap depends on the hardware queues the runtime mapped
   // them to, which no API shows.  The first request of every caller stream runs a synthetic probe of the request pattern;
   // while no caller has been found good, other mappings are tried (lanes re-created with another priority, behind
   // `spacers` — streams that only hold hardware queues); a caller behind which no mapping overlaps keeps its requests.
-  std::mutex lane_cal_mu;                               // lane_verdicts, spacers, and every re-creation of `lanes`
-  std::vector<std::pair<void *, bool>> lane_verdicts;   // caller stream -> its requests may take the lanes
+  std::vector<std::pair<void *, bool>> lane_verdicts;   // caller stream -> its requests may take the lanes (under pool->cal_mu)
   std::atomic<void *> lane_good_caller{nullptr};        // the last caller found good: the request path's shortcut
-  std::vector<hipStream_t> spacers;
-  int32_t lane_count = 0;                               // lanes asked for (<= kMaxLanes)
+  int32_t lane_count = 0;                               // lanes asked for (<= kMaxLanes); 0: private streams off
+  std::atomic<bool> lane_relies{false};                 // counted in pool->n_relying
   // The cross-stream events of a lane cost the host ~8 us per request and the GPU's command processor a few packets:
   // a request pays for them only when its kernel is long enough to have something to overlap.  The plan remembers
   // the work of the shapes it installed last (gathered rows + output bytes); lighter requests stay on the caller's stream.
@@ -1769,35 +1787,31 @@ int fcp_plan_release_captures(fcp_plan_t *p) {
 }
 
 namespace {
-// (callers hold lane_cal_mu, or own the plan exclusively)
-void destroy_lanes(fcp_plan *p, bool spacers_too) {
-  for (auto &l : p->lanes) {
+// (callers hold pool->cal_mu)
+void destroy_lanes(LanePool *pool) {
+  for (auto &l : pool->lanes) {
     for (int i = 0; i < kLaneEvents; ++i) {
       if (l->in[i]) (void)hipEventDestroy(l->in[i]);
       if (l->out[i]) (void)hipEventDestroy(l->out[i]);
     }
     if (l->stream) (void)hipStreamDestroy(l->stream);
   }
-  p->lanes.clear();
-  if (spacers_too) {
-    for (hipStream_t s : p->spacers) (void)hipStreamDestroy(s);
-    p->spacers.clear();
-  }
+  pool->lanes.clear();
 }
 
-// prio: 0 = the caller's (normal), 1 = lowest, 2 = highest
-int create_lanes(fcp_plan *p, int n, int prio) {
+// appends lanes until the pool holds n; prio: 0 = the caller's (normal), 1 = lowest, 2 = highest
+int create_lanes(LanePool *pool, int n, int prio) {
   int least = 0, greatest = 0;
   HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
-  for (int k = 0; k < n; ++k) {
+  while ((int)pool->lanes.size() < n) {
     std::unique_ptr<PrivateLane> l(new PrivateLane());
     if (prio != 0 && least != greatest) {
       HIP_TRY(hipStreamCreateWithPriority(&l->stream, hipStreamNonBlocking, prio == 1 ? least : greatest));
     } else {
       HIP_TRY(hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking));
     }
-    p->lanes.push_back(std::move(l)); // owned from here on: a failure below leaves lanes that plan destruction releases
-    PrivateLane &L = *p->lanes.back();
+    pool->lanes.push_back(std::move(l)); // owned from here on
+    PrivateLane &L = *pool->lanes.back();
     for (int i = 0; i < kLaneEvents; ++i) {
       HIP_TRY(hipEventCreateWithFlags(&L.in[i], hipEventDisableTiming | hipEventDisableSystemFence));
       HIP_TRY(hipEventCreateWithFlags(&L.out[i], hipEventDisableTiming | hipEventDisableSystemFence));
@@ -1813,8 +1827,8 @@ int fcp_plan_destroy(fcp_plan_t *p) {
     DeviceGuard guard;
     if (guard.enter(p->desc.device) == FCP_OK) {
       (void)hipDeviceSynchronize();
-      pending_forget(p);
-      destroy_lanes(p, true);
+      pending_forget(p); // (the lanes belong to the device's pool and stay)
+      if (p->pool && p->lane_relies.exchange(false)) p->pool->n_relying.fetch_sub(1, std::memory_order_acq_rel);
       destroy_device(p);
     }
   }
@@ -1858,7 +1872,10 @@ int fcp_plan_read_bad_ids(fcp_plan_t *p, void *stream, int64_t *count) {
   if (rc) return rc;
   unsigned long long v = 0;
   HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
-  for (auto &l : p->lanes) HIP_TRY(hipStreamSynchronize(l->stream)); // requests of that stream may have run on a private lane
+  if (p->pool && p->lane_count > 0) { // requests of that stream may have run on a private lane
+    std::lock_guard<std::mutex> cal_lock(p->pool->cal_mu);
+    for (auto &l : p->pool->lanes) HIP_TRY(hipStreamSynchronize(l->stream));
+  }
   HIP_TRY(hipMemcpy(&v, p->d_bad, sizeof(v), hipMemcpyDeviceToHost));
   *count = (int64_t)v;
   return FCP_OK;
@@ -2049,30 +2066,34 @@ int fcp_plan_set_private_streams(fcp_plan_t *p, int32_t n_streams, uint32_t flag
   int rc = guard.enter(p->desc.device);
   if (rc) return rc;
   std::lock_guard<std::mutex> lock(p->mu);
-  std::lock_guard<std::mutex> cal_lock(p->lane_cal_mu);
-  for (auto &l : p->lanes) HIP_TRY(hipStreamSynchronize(l->stream)); // results of the old lanes are complete from here on
+  LanePool *pool = p->pool ? p->pool : lane_pool_for(p->desc.device);
+  std::lock_guard<std::mutex> cal_lock(pool->cal_mu);
+  if (p->lane_count > 0)
+    for (auto &l : pool->lanes) HIP_TRY(hipStreamSynchronize(l->stream)); // this plan's results are complete from here on
   pending_forget(p);
-  destroy_lanes(p, true);
   p->lane_verdicts.clear();
   p->lane_good_caller.store(nullptr, std::memory_order_release);
+  if (p->lane_relies.exchange(false)) pool->n_relying.fetch_sub(1, std::memory_order_acq_rel);
   p->lane_flags = flags;
   {
     const char *e = std::getenv("FCP_PRIVATE_MIN_WORK_BYTES"); // tuning aid
     p->lane_min_work = (flags & FCP_PRIVATE_ALWAYS) ? 0 : (e ? std::atoll(e) : (int64_t)48 << 20);
   }
-  // More than three lanes are not created: with four or more event-linked queues in flight every request took 35-100 us
-  // (one stream: 28.5) under every queue count and priority tried (profiles/r04_private_streams_queue_pools.txt);
+  // More than three lanes are not used: with four or more event-linked queues in flight every request took 35-100 us
+  // (one stream: 28.5) under every queue count, priority and mapping tried (profiles/r04_private_streams_queue_mapping.txt);
   // independent streams do not show it (2..8 serve workers: 23-25 us).  The request stays accepted — the round robin
   // simply runs over three.
   constexpr int kMaxLanes = 3;
   if (n_streams > kMaxLanes && !std::getenv("FCP_PRIVATE_LANES_UNCAPPED")) n_streams = kMaxLanes;
   p->lane_count = n_streams;
-  // FCP_LANE_PRIORITY=normal|low|high: the priority the lanes START with (normal: a mapping that does not overlap then
-  // costs 29-44 us per S2 request; with another priority 74-87 us, profiles/r04_private_streams_queue_mapping.txt).
-  // Verification (below) moves on to the others.
+  p->pool = n_streams > 0 ? pool : nullptr;
+  if (n_streams == 0) return FCP_OK;
+  // The device's pool holds three lanes (more only for experiments); a plan that asks for fewer uses the first ones.
+  // FCP_LANE_PRIORITY=normal|low|high: the priority lanes are CREATED with (normal: a mapping that does not overlap then
+  // costs 29-44 us per S2 request; with another priority 74-87 us).  Verification (below) moves on to the others.
   int prio = 0;
   if (const char *e = std::getenv("FCP_LANE_PRIORITY")) prio = !std::strcmp(e, "low") ? 1 : !std::strcmp(e, "high") ? 2 : 0;
-  return create_lanes(p, n_streams, prio);
+  return create_lanes(pool, std::max(n_streams, kMaxLanes), prio);
 }
 
 // ---- diagnostic: do the plan's private streams overlap behind THIS caller stream, in THIS process? ----------------------
@@ -2093,7 +2114,7 @@ __global__ void fcp_probe_consumer_kernel() {}
 } // namespace
 
 namespace {
-// (the plan's device is current; lane_cal_mu is held: the lanes are not re-created meanwhile)
+// (the plan's device is current; pool->cal_mu is held: the lanes are not re-created meanwhile)
 int run_lane_probe(fcp_plan *p, hipStream_t caller, int requests, int spin_us, int grid_blocks, double *serial_us, double *lanes_us) {
   const unsigned long long ticks = 100ull * (unsigned long long)spin_us;
   const dim3 grid(grid_blocks), block(FCP_BLOCK_THREADS);
@@ -2110,15 +2131,15 @@ int run_lane_probe(fcp_plan *p, hipStream_t caller, int requests, int spin_us, i
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(caller));
   if (serial_us) *serial_us = us(t0, now());
-  if (p->lanes.empty()) {
+  if (!p->pool || p->lane_count == 0) {
     if (lanes_us) *lanes_us = 0.0;
     return FCP_OK;
   }
-  const int nl = (int)p->lanes.size();
+  const int nl = p->lane_count;
   std::vector<hipEvent_t> done((size_t)requests, nullptr);
   t0 = now();
   for (int i = 0; i < requests; ++i) {
-    PrivateLane &L = *p->lanes[i % nl];
+    PrivateLane &L = *p->pool->lanes[i % nl];
     {
       std::lock_guard<std::mutex> lane_lock(L.mu);
       const uint32_t e = L.next++ % kLaneEvents;
@@ -2156,14 +2177,16 @@ int run_lane_probe(fcp_plan *p, hipStream_t caller, int requests, int spin_us, i
 // Costs the first request ~4 ms per mapping tried (host blocked, caller's stream drained).  *ok = false: this caller's
 // requests stay on its own stream.
 int verify_lanes(fcp_plan *p, hipStream_t caller, bool *ok) {
-  std::lock_guard<std::mutex> cal_lock(p->lane_cal_mu);
+  LanePool *pool = p->pool;
   *ok = false;
+  if (!pool) return FCP_OK;
+  std::lock_guard<std::mutex> cal_lock(pool->cal_mu);
   for (auto &v : p->lane_verdicts)
     if (v.first == caller) {
       *ok = v.second;
       return FCP_OK;
     }
-  if (p->lanes.empty()) return FCP_OK;
+  if (p->lane_count == 0 || pool->lanes.empty()) return FCP_OK;
   const bool verbose = std::getenv("FCP_PRIVATE_VERIFY_VERBOSE") != nullptr; // (read per verification: rare)
   constexpr int kMaxSpacers = 6, kProbeSpinUs = 40;
   // three lanes: 1.9-2.0 on mappings that overlap, <= 1.34 on the others; two lanes: 1.29-1.44 against <= 1.15; one lane
@@ -2180,9 +2203,7 @@ int verify_lanes(fcp_plan *p, hipStream_t caller, bool *ok) {
     *ratio = best;
     return FCP_OK;
   };
-  bool any_good = false;
-  for (auto &v : p->lane_verdicts) any_good |= v.second;
-  const int n = p->lane_count;
+  const int n = (int)pool->lanes.size();
   int first_prio = 0;
   if (const char *e = std::getenv("FCP_LANE_PRIORITY")) first_prio = !std::strcmp(e, "low") ? 1 : !std::strcmp(e, "high") ? 2 : 0;
   double ratio = 0;
@@ -2190,31 +2211,38 @@ int verify_lanes(fcp_plan *p, hipStream_t caller, bool *ok) {
   if (rc) return rc;
   bool good = ratio >= kProbeGood;
   if (verbose) std::fprintf(stderr, "fcp private streams: caller %p, lanes as created: serial / lanes = %.2f\n", (void *)caller, ratio);
-  // other mappings only while nobody relies on the present one
-  for (int spacers = 0; !good && !any_good && spacers <= kMaxSpacers; ++spacers) {
+  // other mappings only while nobody — no live plan of this device — relies on the present one
+  if (!good && pool->n_relying.load(std::memory_order_acquire) == 0 && pool->spacers.size() > 12) { // earlier searches' spacers
+    for (hipStream_t sp : pool->spacers) (void)hipStreamDestroy(sp);
+    pool->spacers.clear();
+  }
+  for (int spacers = 0; !good && pool->n_relying.load(std::memory_order_acquire) == 0 && spacers <= kMaxSpacers; ++spacers) {
     if (spacers > 0) {
       hipStream_t sp = nullptr;
       HIP_TRY(hipStreamCreateWithFlags(&sp, hipStreamNonBlocking));
-      p->spacers.push_back(sp);
+      pool->spacers.push_back(sp);
       hipLaunchKernelGGL(fcp_probe_consumer_kernel, dim3(1), dim3(1), 0, sp);
       HIP_TRY(hipStreamSynchronize(sp));
     }
     for (int k = (spacers == 0 ? 1 : 0); !good && k < 3; ++k) { // (spacers == 0, first priority: probed above)
       const int prio = (first_prio + k) % 3;
-      for (auto &l : p->lanes) HIP_TRY(hipStreamSynchronize(l->stream));
-      destroy_lanes(p, false);
-      rc = create_lanes(p, n, prio);
+      for (auto &l : pool->lanes) HIP_TRY(hipStreamSynchronize(l->stream));
+      destroy_lanes(pool);
+      rc = create_lanes(pool, n, prio);
       if (rc) return rc;
       rc = overlap(&ratio);
       if (rc) return rc;
       good = ratio >= kProbeGood;
       if (verbose)
         std::fprintf(stderr, "fcp private streams: caller %p, %d spacer(s), priority %s: serial / lanes = %.2f\n", (void *)caller,
-                     spacers, prio == 0 ? "normal" : prio == 1 ? "low" : "high", ratio);
+                     (int)pool->spacers.size(), prio == 0 ? "normal" : prio == 1 ? "low" : "high", ratio);
     }
   }
   p->lane_verdicts.emplace_back((void *)caller, good);
-  if (good) p->lane_good_caller.store((void *)caller, std::memory_order_release);
+  if (good) {
+    if (!p->lane_relies.exchange(true)) pool->n_relying.fetch_add(1, std::memory_order_acq_rel);
+    p->lane_good_caller.store((void *)caller, std::memory_order_release);
+  }
   *ok = good;
   return FCP_OK;
 }
@@ -2230,7 +2258,8 @@ int fcp_plan_probe_private_streams(fcp_plan_t *p, void *stream, int32_t requests
   DeviceGuard guard;
   int rc = guard.enter(p->desc.device);
   if (rc) return rc;
-  std::lock_guard<std::mutex> cal_lock(p->lane_cal_mu);
+  LanePool *pool = p->pool ? p->pool : lane_pool_for(p->desc.device);
+  std::lock_guard<std::mutex> cal_lock(pool->cal_mu);
   return run_lane_probe(p, caller, requests, spin_us, grid_blocks, serial_us, lanes_us);
 }
 
@@ -2242,7 +2271,7 @@ int fcp_plan_set_request_order(fcp_plan_t *p, int32_t order) {
 
 int fcp_process_feature_columns(fcp_plan_t *p, const fcp_process_args_t *a, fcp_process_result_t *r) {
   if (!p || !a) return fail(FCP_ERR_INVALID_ARGUMENT, "null plan / args");
-  if (p->lanes.empty()) return fcp_internal_process(p, a, r);
+  if (!p->pool || p->lane_count == 0) return fcp_internal_process(p, a, r);
   hipStream_t caller = static_cast<hipStream_t>(a->stream);
   // small requests stay on the caller's stream; so does a capture, which records the caller's stream only (cross-stream
   // events would fork it)
@@ -2268,7 +2297,9 @@ int fcp_process_feature_columns(fcp_plan_t *p, const fcp_process_args_t *a, fcp_
       return rc;
     }
   }
-  PrivateLane &L = *p->lanes[p->lane_rr.fetch_add(1, std::memory_order_relaxed) % p->lanes.size()];
+  if (!p->lane_relies.load(std::memory_order_relaxed) && !p->lane_relies.exchange(true)) // (unverified use)
+    p->pool->n_relying.fetch_add(1, std::memory_order_acq_rel);
+  PrivateLane &L = *p->pool->lanes[p->pool->rr.fetch_add(1, std::memory_order_relaxed) % (uint32_t)p->lane_count];
   std::lock_guard<std::mutex> lane_lock(L.mu);
   const uint32_t e = L.next++ % kLaneEvents;
   if (!(p->lane_flags & FCP_PRIVATE_NO_CALLER_WAIT)) {

@@ -429,6 +429,71 @@ def test_host_threads_share_a_plan_with_private_streams(torch_cuda, oracle):
                 assert np.array_equal(results[t][k][1].cpu().numpy(), want[t][k]), (shared_stream, t, k)
 
 
+def test_two_plans_share_the_devices_private_streams(torch_cuda, oracle):
+    """The command processor overlaps at most four event-linked queues, so the private streams belong to the DEVICE, not to
+    the plan: two models served by one process (two plans, two host threads, ONE caller stream — TensorFlow's situation)
+    rotate over the same three streams.  Every result bit-exact; a plan that switches the mode off and on again, or is
+    destroyed, leaves the other's results intact."""
+    import threading
+    from recom_amd import synth
+    from recom_amd.ops import FeatureColumnProcess, concat_inputs
+    torch = torch_cuda
+    models = [synth.model_mixed(batch=110, vocab=1999, n_groups=1), synth.model_s2(columns=60, vocab=900, batch=128)]
+    ops, tabs, tabs_np, reqs, packed, blobs, want = [], [], [], [], [], [], []
+    for i, m in enumerate(models):
+        tn = m.numpy_tables()
+        tabs_np.append(tn)
+        tabs.append([torch.from_numpy(t).cuda() for t in tn])
+        op = FeatureColumnProcess(m.spec, 0)
+        op.plan.set_private_streams(3, always=True)
+        ops.append(op)
+        rs = [m.make_request(700 + 50 * i + k, B=64 + 5 * k + i) for k in range(8)]
+        ps = [concat_inputs(r.inputs) for r in rs]
+        reqs.append(rs)
+        packed.append(ps)
+        blobs.append([torch.from_numpy(p[0]).cuda() for p in ps])
+        want.append([oracle.process_feature_columns(m.spec.to_dict(), p[0], p[1], p[2], tn, r.symbols)[0][0] for r, p in zip(rs, ps)])
+    torch.cuda.synchronize()
+    one = torch.cuda.Stream()
+    for rounds in range(3):
+        errors, results = [], [[None] * 8 for _ in models]
+
+        def worker(i):
+            try:
+                pending = []
+                with torch.cuda.stream(one):
+                    for k in range(8):
+                        o = ops[i](blobs[i][k], packed[i][k][1], packed[i][k][2], tabs[i], reqs[i][k].symbols, defer_wait=True)
+                        pending.append((k, o))
+                        if len(pending) >= 3:
+                            j, oo = pending.pop(0)
+                            oo.wait()
+                            results[i][j] = oo.groups[0].clone()
+                    for j, oo in pending:
+                        oo.wait()
+                        results[i][j] = oo.groups[0].clone()
+            except BaseException as e:  # noqa: BLE001
+                errors.append((i, repr(e)))
+
+        threads = [threading.Thread(target=worker, args=(i,)) for i in range(len(models))]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+        one.synchronize()
+        assert not errors, errors
+        for i in range(len(models)):
+            for k in range(8):
+                assert np.array_equal(results[i][k].cpu().numpy(), want[i][k]), (rounds, i, k)
+        if rounds == 0:
+            ops[1].plan.set_private_streams(0)                         # off ...
+            ops[1].plan.set_private_streams(2, always=True)            # ... and on again, with fewer streams
+        elif rounds == 1:
+            ops[1].plan.close()                                        # the other plan keeps working on the shared streams
+            ops[1] = FeatureColumnProcess(models[1].spec, 0)
+            ops[1].plan.set_private_streams(3, always=True, verify=False)
+
+
 def test_per_column_layout_concat_outputs_waits_for_the_private_stream(torch_cuda, oracle):
     """FCP_LAYOUT_PER_COLUMN (the reference's arena: one buffer per column) with private streams: fcp_concat_outputs — the
     reference's second pass, here on the caller's stream — orders itself behind the lookup kernels it reads from."""
