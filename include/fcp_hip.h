@@ -473,7 +473,9 @@ int fcp_process_feature_columns(fcp_plan_t *plan,
  * streams are re-created with the next priority (normal, low, high) and behind up to six
  * spacer streams, ~4 ms each.  A caller behind which no mapping overlaps keeps
  * its requests on its own stream: the mode then costs nothing instead of a
- * multiple.  FCP_PRIVATE_NO_VERIFY skips all of it (the streams are used as
+ * multiple.  (A verdict is kept per stream HANDLE for the life of the plan: a
+ * process that destroys and re-creates its streams calls this function again.)
+ * FCP_PRIVATE_NO_VERIFY skips all of it (the streams are used as
  * created); FCP_LANE_PRIORITY=normal|low|high chooses the priority the search
  * starts with; FCP_PRIVATE_VERIFY_VERBOSE=1 prints the search. */
 enum { FCP_PRIVATE_NO_CALLER_WAIT = 1u << 0, FCP_PRIVATE_ALWAYS = 1u << 1, FCP_PRIVATE_NO_VERIFY = 1u << 2 };
