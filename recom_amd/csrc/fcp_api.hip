@@ -2809,9 +2809,33 @@ bool pack_on_pool(fcp::PackPool &pool, int n_threads, const fcp_host_tensor_t *i
     in_off[i + 1] = in_off[i] + ne * inputs[i].elem_size;
   }
   const int64_t total = in_off[n];
-  const int chunks = (int)std::min<int64_t>(std::max<int64_t>(1, total / (64 << 10)), 4 * n_threads);
+  static const int per_thread = [] { // tuning aid: chunks per pack thread (every chunk costs two contended atomics)
+    const char *e = std::getenv("FCP_PACK_CHUNKS_PER_THREAD");
+    const int v = e ? std::atoi(e) : 0;
+    return v > 0 ? v : 4;
+  }();
+  const int chunks = (int)std::min<int64_t>(std::max<int64_t>(1, total / (64 << 10)), (int64_t)per_thread * n_threads);
   std::atomic<int> refused{0};
+  // FCP_PACK_TRACE=1 (diagnostic): when did every chunk of a call start and end, and on which thread — printed for every 128th call
+  static const bool trace = std::getenv("FCP_PACK_TRACE") != nullptr;
+  static std::atomic<uint64_t> n_calls{0};
+  struct ChunkTrace { uint64_t t0, t1; unsigned long tid; };
+  std::vector<ChunkTrace> tr;
+  const bool tracing = trace && (n_calls.fetch_add(1) & 127) == 100;
+  auto now_ns = [] { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  if (tracing) tr.resize((size_t)chunks);
+  const uint64_t t_pub = tracing ? now_ns() : 0;
   pool.run(chunks, [&](int c) {
+    struct Stamp { // (scope guard: the end stamp on every exit path of the chunk)
+      ChunkTrace *e;
+      uint64_t (*now)();
+      ~Stamp() { if (e) e->t1 = now(); }
+    };
+    if (tracing) {
+      tr[(size_t)c].t0 = now_ns();
+      tr[(size_t)c].tid = (unsigned long)pthread_self();
+    }
+    Stamp stamp{tracing ? &tr[(size_t)c] : nullptr, +[] { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }};
     const int64_t b0 = total * c / chunks, b1 = total * (c + 1) / chunks;
     int lo = (int)(std::lower_bound(in_off, in_off + n, b0) - in_off);
     const int hi = c + 1 == chunks ? n : (int)(std::lower_bound(in_off, in_off + n, b1) - in_off); // (the last chunk also takes trailing empty inputs)
@@ -2821,6 +2845,13 @@ bool pack_on_pool(fcp::PackPool &pool, int n_threads, const fcp_host_tensor_t *i
         refused.store(1, std::memory_order_relaxed);
     }
   });
+  if (tracing) {
+    const uint64_t t_end = now_ns();
+    std::fprintf(stderr, "fcp pack trace: %d chunks, %d threads, call %.1f us; chunk: start-after-publish us, duration us, thread\n", chunks,
+                 n_threads, (t_end - t_pub) / 1e3);
+    for (int c = 0; c < chunks; ++c)
+      std::fprintf(stderr, "  %2d: %6.1f %6.1f %lx\n", c, (tr[(size_t)c].t0 - t_pub) / 1e3, (tr[(size_t)c].t1 - tr[(size_t)c].t0) / 1e3, tr[(size_t)c].tid & 0xffffff);
+  }
   return refused.load() == 0;
 }
 } // namespace
