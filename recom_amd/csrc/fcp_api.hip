@@ -2778,8 +2778,18 @@ inline void prefetch_head(const fcp_host_tensor_t &t) {
   int64_t n = t.elem_size;
   for (int32_t j = 0; j < t.rank; ++j) n *= t.dims[j];
   if (n > bytes) n = bytes;
+  static const int hint = [] { // FCP_PACK_PREFETCH_HINT (tuning aid): 0 = non-temporal, 1 = every cache level, 2 = L2 and up
+    const char *e = std::getenv("FCP_PACK_PREFETCH_HINT");
+    return e ? std::atoi(e) : 0;
+  }();
   const char *p = static_cast<const char *>(t.data);
-  for (int64_t o = 0; o < n; o += 64) __builtin_prefetch(p + o, 0, 0);
+  if (hint == 2) {
+    for (int64_t o = 0; o < n; o += 64) __builtin_prefetch(p + o, 0, 2);
+  } else if (hint == 1) {
+    for (int64_t o = 0; o < n; o += 64) __builtin_prefetch(p + o, 0, 3);
+  } else {
+    for (int64_t o = 0; o < n; o += 64) __builtin_prefetch(p + o, 0, 0);
+  }
 }
 
 // One input into its place in the staged blob (`nbytes` = its bytes there).
