@@ -477,7 +477,10 @@ def main():
             hp.run_private(sc_warm, lanes)
             w_ms, d_ms = hp.run_private(sc_steps, lanes)
             sweep[lanes] = {"requests": sc_steps, "warmup": sc_warm, "us_per_request": w_ms * 1e3 / sc_steps,
-                            "device_us_per_request": d_ms * 1e3 / sc_steps}
+                            "device_us_per_request": d_ms * 1e3 / sc_steps,
+                            # 1: the library found its streams to overlap behind this caller stream and used them; 0: it did not
+                            # and kept the requests on the caller's stream; -1: never asked (requests below the work threshold)
+                            "verified_overlap": hp.plan.private_streams_verdict(hp.caller_stream())}
             hp.close()
         # and the cheap variant for callers that own their buffers (this harness does): FCP_ORDER_INPUTS_READY — the same K
         # requests back to back on the one stream, the fused kernel launched without the queue's barrier bit
@@ -498,6 +501,7 @@ def main():
                                  "hardware-queue mapping that does; profiles/r04_private_streams_queue_mapping.txt)",
                          "private_streams": best, **sweep[best],
                          "sweep_us_per_request": {str(k): v["us_per_request"] for k, v in sweep.items()},
+                         "sweep_verified_overlap": {str(k): v["verified_overlap"] for k, v in sweep.items()},
                          "inputs_ready_back_to_back": inputs_ready}
     batch = model.batch
     steps_total = args.steps * args.threads

@@ -494,6 +494,9 @@ int fcp_plan_set_private_streams(fcp_plan_t *plan, int32_t n_streams, uint32_t f
  * and for processes that pass FCP_PRIVATE_NO_VERIFY.) */
 int fcp_plan_probe_private_streams(fcp_plan_t *plan, void *stream, int32_t requests, int32_t spin_us, int32_t grid_blocks,
                                    double *serial_us, double *lanes_us);
+/* What the verification decided for `stream`: *verdict = 1 (its requests take the private streams), 0 (they stay on
+ * `stream`: nothing overlapped behind it) or -1 (no request of that stream verified yet, or the mode is off). */
+int fcp_plan_private_streams_verdict(fcp_plan_t *plan, void *stream, int32_t *verdict);
 
 /* The cheap half of the same idea, for callers that OWN their buffers: FCP_ORDER_INPUTS_READY is the caller's promise, for
  * every request of the plan, that when fcp_process_feature_columns is CALLED the blob is complete in device memory and

@@ -2248,6 +2248,19 @@ int verify_lanes(fcp_plan *p, hipStream_t caller, bool *ok) {
 }
 } // namespace
 
+// What the verification decided for `stream`: 1 = its requests take the private streams, 0 = they stay on `stream` (nothing
+// overlapped behind it), -1 = no request of that stream has been verified yet, or the mode is off.
+int fcp_plan_private_streams_verdict(fcp_plan_t *p, void *stream, int32_t *verdict) {
+  if (!p || !verdict) return fail(FCP_ERR_INVALID_ARGUMENT, "null argument");
+  *verdict = -1;
+  LanePool *pool = p->pool;
+  if (!pool || p->lane_count == 0) return FCP_OK;
+  std::lock_guard<std::mutex> cal_lock(pool->cal_mu);
+  for (auto &v : p->lane_verdicts)
+    if (v.first == stream) *verdict = v.second ? 1 : 0;
+  return FCP_OK;
+}
+
 int fcp_plan_probe_private_streams(fcp_plan_t *p, void *stream, int32_t requests, int32_t spin_us, int32_t grid_blocks,
                                    double *serial_us, double *lanes_us) {
   if (!p || requests < 1 || requests > 4096 || spin_us < 1 || spin_us > 10000 || grid_blocks < 1 || grid_blocks > (1 << 20))

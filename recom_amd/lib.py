@@ -118,7 +118,7 @@ EXPORTS = [
     "fcp_pack_pool_create", "fcp_pack_pool_destroy", "fcp_concat_inputs_ex_pool",
     "fcp_graph_build", "fcp_graph_free", "fcp_placement_assign", "fcp_concat_outputs_scatter_strided",
     "fcp_plan_set_private_streams", "fcp_result_wait", "fcp_result_synchronize", "fcp_plan_set_request_order",
-    "fcp_plan_probe_private_streams",
+    "fcp_plan_probe_private_streams", "fcp_plan_private_streams_verdict",
 ]
 
 _lib = None
@@ -249,6 +249,7 @@ def load() -> C.CDLL:
         L.fcp_result_synchronize.argtypes = [C.c_void_p]
     L.fcp_plan_probe_private_streams.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                                  C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.fcp_plan_private_streams_verdict.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]
     if hasattr(L, "fcp_plan_set_request_order"):
         L.fcp_plan_set_request_order.argtypes = [C.c_void_p, C.c_int32]
     if L.fcp_abi_version() != FCP_ABI_VERSION:

@@ -242,6 +242,13 @@ class Plan:
                                                          C.byref(a), C.byref(b)), "fcp_plan_probe_private_streams")
         return a.value, b.value
 
+    def private_streams_verdict(self, stream: int) -> int:
+        """``fcp_plan_private_streams_verdict``: 1 = requests of ``stream`` take the private streams, 0 = they stay on it
+        (verified: nothing overlapped), -1 = not verified yet / mode off."""
+        v = C.c_int32(-1)
+        _lib.check(self._L.fcp_plan_private_streams_verdict(self.handle, C.c_void_p(stream), C.byref(v)), "fcp_plan_private_streams_verdict")
+        return int(v.value)
+
     def set_inputs_ready(self, on: bool = True) -> None:
         """``fcp_plan_set_request_order(FCP_ORDER_INPUTS_READY)``: the caller's promise that blobs are complete and arenas
         unused when a request is issued; consecutive requests of one stream then overlap (any-order kernel launch)."""

@@ -249,6 +249,9 @@ def test_private_streams_are_verified_per_caller_stream_and_results_do_not_depen
             err = capfd.readouterr().err
             verdicts = [ln for ln in err.splitlines() if "lanes as created" in ln]
             assert len(verdicts) == (2 if verify else 0), err          # once per caller stream, never again
+            for s in callers:                                          # ... and the plan says what it decided
+                assert op.plan.private_streams_verdict(s.cuda_stream) in ((0, 1) if verify else (-1,))
+            assert op.plan.private_streams_verdict(torch.cuda.Stream().cuda_stream) == -1
             a, b = op.plan.probe_private_streams(callers[0].cuda_stream, requests=12, spin_us=20, grid_blocks=1)
             assert a > 12 * 20 and b > 0
             del op

@@ -121,6 +121,9 @@ def test_host_only_plan_cannot_run_and_real_plan_needs_a_gpu():
     assert p._L.fcp_plan_probe_private_streams(p.handle, None, 0, 20, 1, C.byref(sa), C.byref(sb)) == lib.FCP_ERR_INVALID_ARGUMENT
     assert p._L.fcp_plan_probe_private_streams(None, None, 24, 20, 1, C.byref(sa), C.byref(sb)) == lib.FCP_ERR_INVALID_ARGUMENT
     assert p._L.fcp_result_wait(None, None) == lib.FCP_ERR_INVALID_ARGUMENT
+    v = C.c_int32(5)
+    assert p._L.fcp_plan_private_streams_verdict(p.handle, None, C.byref(v)) == lib.FCP_OK and v.value == -1   # mode off
+    assert p._L.fcp_plan_private_streams_verdict(p.handle, None, None) == lib.FCP_ERR_INVALID_ARGUMENT
     p.close()
     if not torch.cuda.is_available():
         with pytest.raises(lib.FcpError) as e:
