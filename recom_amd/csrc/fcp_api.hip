@@ -2313,11 +2313,17 @@ int fcp_process_feature_columns(fcp_plan_t *p, const fcp_process_args_t *a, fcp_
   if (!p->lane_relies.load(std::memory_order_relaxed) && !p->lane_relies.exchange(true)) // (unverified use)
     p->pool->n_relying.fetch_add(1, std::memory_order_acq_rel);
   PrivateLane &L = *p->pool->lanes[p->pool->rr.fetch_add(1, std::memory_order_relaxed) % (uint32_t)p->lane_count];
+  static const bool lane_stats = std::getenv("FCP_LANE_STATS") != nullptr; // diagnostic: host time of a private-stream request by part
+  auto now_ns = [] { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const uint64_t s0 = lane_stats ? now_ns() : 0;
   std::lock_guard<std::mutex> lane_lock(L.mu);
   const uint32_t e = L.next++ % kLaneEvents;
+  uint64_t s1 = s0, s2 = s0;
   if (!(p->lane_flags & FCP_PRIVATE_NO_CALLER_WAIT)) {
     HIP_TRY(hipEventRecord(L.in[e], caller));
+    if (lane_stats) s1 = now_ns();
     HIP_TRY(hipStreamWaitEvent(L.stream, L.in[e], 0));
+    if (lane_stats) s2 = now_ns();
   }
   fcp_process_args_t b = *a;
   b.stream = L.stream;
@@ -2334,8 +2340,20 @@ int fcp_process_feature_columns(fcp_plan_t *p, const fcp_process_args_t *a, fcp_
   const bool pending = fcp_stop_event_pending();
   fcp_set_stop_event(nullptr);
   if (rc) return rc;
+  const uint64_t s3 = lane_stats ? now_ns() : 0;
   if (!attach || pending) HIP_TRY(hipEventRecord(L.out[e], L.stream));
   pending_register(p, r->buffer, r->buffer_bytes, a->concated_inputs, a->concated_bytes, L.out[e]);
+  if (lane_stats) {
+    static std::atomic<uint64_t> n{0}, a_rec{0}, a_wait{0}, a_proc{0}, a_reg{0};
+    const uint64_t s4 = now_ns();
+    a_rec += s1 - s0;
+    a_wait += s2 - s1;
+    a_proc += s3 - s2;
+    a_reg += s4 - s3;
+    if ((++n & 1023) == 0)
+      std::fprintf(stderr, "fcp private-stream request, host us: record on the caller's stream %.2f, lane waits %.2f, request itself %.2f, completion event + registry %.2f\n",
+                   a_rec.load() / 1e3 / n.load(), a_wait.load() / 1e3 / n.load(), a_proc.load() / 1e3 / n.load(), a_reg.load() / 1e3 / n.load());
+  }
   return FCP_OK;
 }
 
