@@ -468,10 +468,10 @@ int fcp_process_feature_columns(fcp_plan_t *plan,
  * had created before (profiles/r04_private_streams_queue_mapping.txt).  The first
  * request of every caller stream that would take a private stream therefore runs
  * a short synthetic probe of the request pattern behind that stream (kernels that
- * only wait; the host blocks for ~4 ms and args->stream drains once).  While no
+ * only wait; the host blocks for ~8 ms and args->stream drains once).  While no
  * live plan relies on the present mapping, other mappings are tried — the private
  * streams are re-created with the next priority (normal, low, high) and behind up to six
- * spacer streams, ~4 ms each.  A caller behind which no mapping overlaps keeps
+ * spacer streams, ~8 ms each.  A caller behind which no mapping overlaps keeps
  * its requests on its own stream: the mode then costs nothing instead of a
  * multiple.  (A verdict is kept per stream HANDLE for the life of the plan: a
  * process that destroys and re-creates its streams calls this function again.)

@@ -2170,11 +2170,10 @@ int run_lane_probe(fcp_plan *p, hipStream_t caller, int requests, int spin_us, i
 // The first lane-eligible request of a caller stream: do the lanes overlap behind it?  While no caller has been found
 // good, other mappings are tried: the lanes re-created with the next priority, then behind one more spacer stream (a
 // stream that has run one empty kernel holds a hardware queue and shifts everything created after it), up to
-// kMaxSpacers.  The probe: 24 one-block kernels of 40 us with their consumers, three times (the first pass brings the
-// queues up, the better of the other two counts); serial / lanes >= 1.5 (three lanes) counts as overlap: 1.9-2.0 on
-// mappings where S2 runs at 24.5-25.1 us per request, <= 1.34 where it runs at 28.7-86 us
-// (scripts/probes/lane_probe_vs_real.py, profiles/r04_private_streams_queue_mapping.txt).
-// Costs the first request ~4 ms per mapping tried (host blocked, caller's stream drained).  *ok = false: this caller's
+// kMaxSpacers.  The probe: 24 one-block kernels of 80 us with their consumers, three times (the first pass brings the
+// queues up, the better of the other two counts); serial / lanes >= 2.15 (three lanes) counts as overlap
+// (scripts/probes/lane_probe_vs_real.py, lanes_cold_start.py, profiles/r04_private_streams_queue_mapping.txt).
+// Costs the first request ~8 ms per mapping tried (host blocked, caller's stream drained).  *ok = false: this caller's
 // requests stay on its own stream.
 int verify_lanes(fcp_plan *p, hipStream_t caller, bool *ok) {
   LanePool *pool = p->pool;
@@ -2188,10 +2187,13 @@ int verify_lanes(fcp_plan *p, hipStream_t caller, bool *ok) {
     }
   if (p->lane_count == 0 || pool->lanes.empty()) return FCP_OK;
   const bool verbose = std::getenv("FCP_PRIVATE_VERIFY_VERBOSE") != nullptr; // (read per verification: rare)
-  constexpr int kMaxSpacers = 6, kProbeSpinUs = 40;
-  // three lanes: 1.9-2.0 on mappings that overlap, <= 1.34 on the others; two lanes: 1.29-1.44 against <= 1.15; one lane
-  // never gains (its consumer waits for it at once: S2 45 us per request against 28.7 on the caller's stream, probe 0.73)
-  const double kProbeGood = p->lane_count >= 3 ? 1.5 : p->lane_count == 2 ? 1.25 : 1.1;
+  constexpr int kMaxSpacers = 6, kProbeSpinUs = 80;
+  // With 40-us kernels three lanes gave 1.9-2.1 on mappings that overlap (the lanes' side is then bound by the host's five
+  // runtime calls per request) and up to 1.48 on mappings that do not (S2 at 29-44 us per request) — too close: one process in
+  // a dozen accepted a bad one.  80-us kernels: 2.31-2.42 where three lanes overlap, 1.8-1.97 where only two do (two of the
+  // streams on one hardware queue), <= 1.5 otherwise.  Two lanes: ~1.7 against <= 1.4.  One lane never gains (its consumer
+  // waits for it at once: S2 45 us per request against 28.7 on the caller's stream, ratio 0.7-1.0).
+  const double kProbeGood = p->lane_count >= 3 ? 2.15 : p->lane_count == 2 ? 1.55 : 1.3;
   auto overlap = [&](double *ratio) -> int {
     double best = 0;
     for (int pass = 0; pass < 3; ++pass) { // the first pass brings the queues up; the better of the other two counts
