@@ -28,12 +28,12 @@ for n in range(0, 9):
     hp.plan.set_private_streams(LANES, verify=False)
     caller = hp.caller_stream()
     probes = []
-    for spin, blocks in ((40, 1), (20, 1)):
+    for spin, blocks in ((80, 1), (40, 1)):
         hp.plan.probe_private_streams(caller, 12, spin, blocks)
         a, b = hp.plan.probe_private_streams(caller, 24, spin, blocks)
         probes.append(round(a / b, 2))
     hp.run_private(100, LANES)
     real = round(hp.run_private(steps, LANES)[0] * 1e3 / steps, 2)
-    out["by_dummy_streams"][n] = {"real_us": real, "probe(40us x1, 20us x1)": probes}
+    out["by_dummy_streams"][n] = {"real_us": real, "probe(80us x1, 40us x1)": probes}
     hp.close()
 print(json.dumps(out))
