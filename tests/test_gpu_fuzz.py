@@ -235,7 +235,8 @@ def test_random_plans_match_oracle(oracle, seed):
         assert op.plan.read_bad_ids() == bad_total, (seed, trial)
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("FCP_FUZZ_SHARD_SEEDS", "8"))))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FCP_FUZZ_SEED0", "0")),
+                                        int(os.environ.get("FCP_FUZZ_SEED0", "0")) + int(os.environ.get("FCP_FUZZ_SHARD_SEEDS", "8"))))
 def test_random_plans_row_sharded_match_oracle(oracle, seed):
     """The same random plans as one rank of a row-sharded world (rows id % world == rank of every table): the
     rank's partial sums equal the sharded oracle bit for bit — transforms and hashing run before the ownership
@@ -264,7 +265,8 @@ def test_random_plans_row_sharded_match_oracle(oracle, seed):
                 assert got.shape == w.shape and np.array_equal(got, w), (seed, rank, world, trial, g)
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("FCP_FUZZ_FINALIZE_SEEDS", "6"))))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FCP_FUZZ_SEED0", "0")),
+                                        int(os.environ.get("FCP_FUZZ_SEED0", "0")) + int(os.environ.get("FCP_FUZZ_FINALIZE_SEEDS", "6"))))
 def test_random_plans_sharded_then_finalized_equal_the_unsharded_result(oracle, seed):
     """All ranks' partial sums of a random plan, a random batch slice of each, fcp_shard_finalize: equal to the
     unsharded oracle — exactly for columns with one owner per row (gathers, scatters, table-free columns),
@@ -390,7 +392,8 @@ class _RawBlob:
         return 1
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("FCP_FUZZ_STAGER_SEEDS", "6"))))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FCP_FUZZ_SEED0", "0")),
+                                        int(os.environ.get("FCP_FUZZ_SEED0", "0")) + int(os.environ.get("FCP_FUZZ_STAGER_SEEDS", "6"))))
 def test_random_plans_through_the_stager(oracle, seed):
     """Random plans, requests staged from host tensors with PlanSpec.staged() / fcp_stager_stage_ex (ids narrowed where the
     plan allows, sorted row ids -> CSR offsets on the host), copy and zero-copy rings: the staged plan on the staged blob
