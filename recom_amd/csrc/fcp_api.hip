@@ -106,6 +106,7 @@ struct DynSlot {
   void *h_dyn_dev = nullptr;  // device-side address of h_dyn
   FcpColDyn *d_dyn = nullptr; // what the kernels read
   hipEvent_t uploaded = nullptr; // upload-kernel path: recorded after the upload
+  uint64_t done_gen = 0;         // != 0: `done` is a private lane's completion event of that lane generation (see g_lane_generation)
   hipEvent_t done = nullptr;     // recorded after the first kernel that used this content; one event per
                                  // (slot, stream) — re-recording an event last used on ANOTHER stream costs
                                  // ~20 us under concurrency (HIP serialises it), on its own stream < 1 us
@@ -138,6 +139,14 @@ struct PrivateLane {
 // The command processor overlaps at most four event-linked queues — a caller's stream and three lanes; with a fifth every
 // request costs a multiple (profiles/r04_private_streams_queue_mapping.txt).  Lanes per plan would multiply them: two
 // models served by one process, three lanes each, fall off that cliff as soon as both are busy.
+// Lanes are destroyed and re-created only while no live plan relies on them (verify_lanes), i.e. after every plan that used
+// them has synchronised them and let go.  A descriptor slot whose `done` event is a lane's completion event remembers the
+// generation it was taken from: a different generation now means those lanes — and every kernel that ran on them — are gone.
+std::atomic<uint64_t> g_lane_generation{1};
+// the completion event of the private-stream request this thread is issuing (fcp_process_feature_columns -> fcp_internal_process)
+thread_local hipEvent_t tl_lane_done = nullptr;
+thread_local uint64_t tl_lane_done_gen = 0;
+
 struct LanePool {
   std::mutex cal_mu;                                  // lanes / spacers are created, probed and re-created under it
   std::vector<std::unique_ptr<PrivateLane>> lanes;
@@ -1055,6 +1064,7 @@ int bind_tables(fcp_plan *p, const void *const *input_ptrs, bool capturing) {
 // device reads depends on it, so it needs no system-scope fence (a fenced record costs 2.9 us of GPU
 // timeline between two kernels, an unfenced one 1.1 us: RAGGED with new shapes 33.5 -> 31.5 us).
 int done_event_for(DynSlot &s, void *stream) {
+  s.done_gen = 0;
   for (auto &e : s.done_pool)
     if (e.first == stream) {
       s.done = e.second;
@@ -1144,6 +1154,8 @@ int install_slot(fcp_plan *p, const fcp_process_args_t *a, DynSlot &s) {
       } else {
         HIP_TRY(hipDeviceSynchronize());
       }
+    } else if (s.done_gen != 0 && s.done_gen != g_lane_generation.load(std::memory_order_acquire)) {
+      // `done` was a private lane's event and those lanes have been let go of since: their kernels have all run
     } else if (hipEventQuery(s.done) != hipSuccess) {
       HIP_TRY(hipEventSynchronize(s.done)); // back-pressure: at most kSlots requests in flight
     }
@@ -1789,6 +1801,7 @@ int fcp_plan_release_captures(fcp_plan_t *p) {
 namespace {
 // (callers hold pool->cal_mu)
 void destroy_lanes(LanePool *pool) {
+  g_lane_generation.fetch_add(1, std::memory_order_acq_rel);
   for (auto &l : pool->lanes) {
     for (int i = 0; i < kLaneEvents; ++i) {
       if (l->in[i]) (void)hipEventDestroy(l->in[i]);
@@ -2018,7 +2031,15 @@ int fcp_internal_process(fcp_plan_t *p, const fcp_process_args_t *a, fcp_process
     const bool taken = attach_done && !fcp_stop_event_pending(); // the launcher took it: the kernel carries the event
     clear_stop.armed = false;
     if (attach_done && !taken) fcp_set_stop_event(nullptr);      // nothing was launched (an empty request)
-    if (!taken) HIP_TRY(hipEventRecord(slot->done, stream));
+    if (tl_lane_done) {
+      // a private-stream request: its completion event — on the last kernel's dispatch packet, or recorded by the caller of
+      // this function right behind it — IS "the readers of this slot have finished": no event of the slot's own (one runtime
+      // call and one marker packet less per request with new shapes)
+      slot->done = tl_lane_done;
+      slot->done_gen = tl_lane_done_gen;
+    } else if (!taken) {
+      HIP_TRY(hipEventRecord(slot->done, stream));
+    }
     unpin.recorded = true;
   }
 
@@ -2338,7 +2359,16 @@ int fcp_process_feature_columns(fcp_plan_t *p, const fcp_process_args_t *a, fcp_
     return !v || std::atoi(v) != 0;
   }();
   if (attach) fcp_set_stop_event(L.out[e]);
+  static const bool alias_done = [] {
+    const char *v = std::getenv("FCP_LANE_DONE_ALIAS"); // tuning aid: 0 = the slot records an event of its own
+    return !v || std::atoi(v) != 0;
+  }();
+  if (alias_done) {
+    tl_lane_done = L.out[e];
+    tl_lane_done_gen = g_lane_generation.load(std::memory_order_acquire);
+  }
   rc = fcp_internal_process(p, &b, r);
+  tl_lane_done = nullptr;
   const bool pending = fcp_stop_event_pending();
   fcp_set_stop_event(nullptr);
   if (rc) return rc;
