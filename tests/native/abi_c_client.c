@@ -107,6 +107,18 @@ int main(void) {
   /* no device behind this plan: computing fails loudly, there is no CPU fallback */
   memset(&args, 0, sizeof(args));
   CHECK(fcp_process_feature_columns(plan, &args, NULL) == FCP_ERR_NO_DEVICE);
+  { /* the serving-mode entry points (round 4) from plain C: a plan without a device refuses them, arguments are checked */
+    double serial_us = 0.0, lanes_us = 0.0;
+    int32_t verdict = 7;
+    CHECK(fcp_plan_set_private_streams(plan, 3, FCP_PRIVATE_ALWAYS | FCP_PRIVATE_NO_VERIFY) == FCP_ERR_NO_DEVICE);
+    CHECK(fcp_plan_set_private_streams(plan, 3, 1u << 9) == FCP_ERR_INVALID_ARGUMENT);
+    CHECK(fcp_plan_probe_private_streams(plan, NULL, 24, 80, 1, &serial_us, &lanes_us) == FCP_ERR_NO_DEVICE);
+    CHECK(fcp_plan_private_streams_verdict(plan, NULL, &verdict) == FCP_OK && verdict == -1);
+    CHECK(fcp_plan_set_request_order(plan, FCP_ORDER_INPUTS_READY) == FCP_OK);
+    CHECK(fcp_plan_set_request_order(plan, 9) == FCP_ERR_INVALID_ARGUMENT);
+    CHECK(fcp_result_wait(NULL, NULL) == FCP_ERR_INVALID_ARGUMENT);
+    CHECK(fcp_result_synchronize(blob) == FCP_OK); /* nothing pending for an address no request ever used */
+  }
   CHECK(strlen(fcp_status_string(FCP_ERR_NO_DEVICE)) > 0);
   CHECK(fcp_plan_destroy(plan) == FCP_OK);
   puts("abi_c_client ok");
