@@ -296,18 +296,20 @@ def model_s1(columns: int = 100, dim: int = 16, vocab: int = 10_000, batch: int 
 
 
 def model_s2(columns: int = 1000, vocab: int = 1_000_000, batch: int = 512, dist: str = "uniform",
-             dims: Sequence[int] = (8, 16, 32, 64)) -> SynthModel:
+             dims: Sequence[int] = (8, 16, 32, 64), vocab_of: Optional[dict] = None) -> SynthModel:
     """S2 (headline): 1000 columns, dims cycling 8/16/32/64, vocab 1M (120 GB of
     tables), batch 512, one id per row (form 1); every 10th column is sourced by
     a float feature bucketized with 100 boundaries (the reference's dominant
-    column type), the others by int64 ids."""
+    column type), the others by int64 ids.  `vocab_of`: {column: vocab} for the
+    few columns whose table is of another size (placement tests)."""
     b = _Builder()
     for c in range(columns):
         d = dims[c % len(dims)]
+        v = (vocab_of or {}).get(c, vocab)
         if c % 10 == 0:
-            _add_dense(b, vocab, d, slot=c, id_source=IDS_F32_BUCKETIZE, boundaries=MICROBENCH_BOUNDARIES)
+            _add_dense(b, v, d, slot=c, id_source=IDS_F32_BUCKETIZE, boundaries=MICROBENCH_BOUNDARIES)
         else:
-            _add_dense(b, vocab, d, slot=c, dist=dist)
+            _add_dense(b, v, d, slot=c, dist=dist)
     return _finish("S2", b, batch,
                    description=f"{columns} cols, dims {'/'.join(map(str, dims))}, vocab {vocab}, B {batch}, "
                                f"1 id/row, 10% bucketize-f32, ids {dist}")
@@ -339,9 +341,9 @@ def model_ragged(columns: int = 512, vocab: int = 100_000, batch: int = 256, seg
                    description=f"{columns} cols multi-hot U{{0..{max_len}}}, vocab {vocab}, B {batch}, seg={seg}")
 
 
-def model_shard(columns: int = 4000, vocab: int = 1_000_000, batch: int = 512) -> SynthModel:
+def model_shard(columns: int = 4000, vocab: int = 1_000_000, batch: int = 512, vocab_of: Optional[dict] = None) -> SynthModel:
     """SHARD: as S2 with 4000 columns (480 GB) — row-sharded over 8 GPUs."""
-    m = model_s2(columns, vocab, batch)
+    m = model_s2(columns, vocab, batch, vocab_of=vocab_of)
     m.name = "SHARD"
     return m
 

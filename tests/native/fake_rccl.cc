@@ -8,9 +8,9 @@
 // world x world matrix of single-message mailboxes.  ncclSend / ncclRecv are queued between ncclGroupStart / ncclGroupEnd, as
 // RCCL queues them; ncclGroupEnd (or a lone call) then
 //   1. synchronises the stream (everything the caller enqueued before the collective has produced its data),
-//   2. copies every send device -> host into the peer's mailbox and publishes it (all sends first: no rank waits for a
-//      receive before its own sends are out, so the exchange cannot deadlock),
-//   3. waits for every receive's mailbox, copies host -> device, releases the mailbox.
+//   2. moves every queued message through its pair's mailbox in chunks of at most one slot (device -> host on the sending
+//      side, host -> device on the receiving side), all operations progressing together: no operation waits for another,
+//      so the exchange cannot deadlock whatever the message sizes.
 // It BLOCKS the host where RCCL would only enqueue; ordering on the stream is what a real collective guarantees, timing is not
 // what this double is for.  Message sizes must match between the two sides (checked): a schedule that pairs the wrong slices
 // fails loudly.  Build: hipcc -shared -fPIC tests/native/fake_rccl.cc -o tests/native/libfake_rccl.so
@@ -20,6 +20,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cstdint>
@@ -52,7 +53,7 @@ struct Header {
 
 size_t slot_capacity() {
   const char *e = std::getenv("FCP_FAKE_RCCL_SLOT_BYTES");
-  return e ? (size_t)std::atoll(e) : (size_t)16 << 20;
+  return e ? (size_t)std::atoll(e) : (size_t)4 << 20;
 }
 
 struct Op {
@@ -115,38 +116,69 @@ size_t type_size(int datatype) {
 }
 
 int flush() {
+  // A progress engine over every queued operation: a message travels in chunks of at most one mailbox slot, the first
+  // chunk announcing the message's total size (checked against what the receiver expects).  No operation ever blocks the
+  // others — each pass moves whatever can move — so any schedule RCCL would complete completes here too, whatever the
+  // message sizes (SHARD's 30.7 MB slices through 4 MiB slots), and a schedule that pairs the wrong slices fails loudly.
   std::vector<std::pair<ncclComm_t, Op>> ops;
   ops.swap(g_queue);
   if (ops.empty()) return kSuccess;
   for (auto &o : ops)
     if (hipStreamSynchronize(o.second.stream) != hipSuccess) return fail(kUnhandledCudaError, "hipStreamSynchronize before the exchange");
-  for (auto &o : ops) { // every send first
-    if (!o.second.send) continue;
-    ncclComm_t c = o.first;
-    Mailbox *b = c->box(c->rank, o.second.peer);
-    if (o.second.bytes > c->hdr->slot_bytes) return fail(kInvalidArgument, "message larger than FCP_FAKE_RCCL_SLOT_BYTES");
-    if (!wait_until([&] { return b->written.load(std::memory_order_acquire) == b->read.load(std::memory_order_acquire); }))
-      return fail(kSystemError, "timeout: the peer never consumed the previous message");
-    if (o.second.bytes && hipMemcpy(c->data(c->rank, o.second.peer), o.second.src, o.second.bytes, hipMemcpyDeviceToHost) != hipSuccess)
-      return fail(kUnhandledCudaError, "device -> host copy of a send");
-    b->bytes = o.second.bytes;
-    b->written.fetch_add(1, std::memory_order_release);
-  }
-  for (auto &o : ops) {
-    if (o.second.send) continue;
-    ncclComm_t c = o.first;
-    Mailbox *b = c->box(o.second.peer, c->rank);
-    if (!wait_until([&] { return b->written.load(std::memory_order_acquire) > b->read.load(std::memory_order_acquire); }))
-      return fail(kSystemError, "timeout: the peer never sent");
-    if (b->bytes != o.second.bytes) {
-      char msg[160];
-      std::snprintf(msg, sizeof(msg), "rank %d expects %zu bytes from rank %d, which sent %llu: the two sides disagree about the slices",
-                    c->rank, o.second.bytes, o.second.peer, (unsigned long long)b->bytes);
-      return fail(kInvalidArgument, msg);
+  std::vector<size_t> done(ops.size(), 0);
+  std::vector<char> finished(ops.size(), 0);
+  // several operations of one group towards the same peer share that pair's mailbox: they take turns in queue order
+  auto earlier_unfinished = [&](size_t i) {
+    for (size_t j = 0; j < i; ++j)
+      if (!finished[j] && ops[j].first == ops[i].first && ops[j].second.send == ops[i].second.send && ops[j].second.peer == ops[i].second.peer) return true;
+    return false;
+  };
+  size_t left = ops.size();
+  const auto t0 = std::chrono::steady_clock::now();
+  int idle = 0;
+  while (left) {
+    bool moved = false;
+    for (size_t i = 0; i < ops.size(); ++i) {
+      if (finished[i] || earlier_unfinished(i)) continue;
+      ncclComm_t c = ops[i].first;
+      Op &o = ops[i].second;
+      const size_t slot = c->hdr->slot_bytes;
+      if (o.send) {
+        Mailbox *b = c->box(c->rank, o.peer);
+        if (b->written.load(std::memory_order_acquire) != b->read.load(std::memory_order_acquire)) continue; // previous chunk not consumed yet
+        const size_t n = std::min(slot, o.bytes - done[i]);
+        if (n && hipMemcpy(c->data(c->rank, o.peer), static_cast<const char *>(o.src) + done[i], n, hipMemcpyDeviceToHost) != hipSuccess)
+          return fail(kUnhandledCudaError, "device -> host copy of a send");
+        b->bytes = o.bytes; // every chunk carries the message's total size
+        b->written.fetch_add(1, std::memory_order_release);
+        done[i] += n;
+        moved = true;
+        if (done[i] == o.bytes) finished[i] = 1, --left;
+      } else {
+        Mailbox *b = c->box(o.peer, c->rank);
+        if (b->written.load(std::memory_order_acquire) == b->read.load(std::memory_order_acquire)) continue; // nothing there yet
+        if (b->bytes != o.bytes) {
+          char msg[160];
+          std::snprintf(msg, sizeof(msg), "rank %d expects %zu bytes from rank %d, which sent %llu: the two sides disagree about the slices",
+                        c->rank, o.bytes, o.peer, (unsigned long long)b->bytes);
+          return fail(kInvalidArgument, msg);
+        }
+        const size_t n = std::min(slot, o.bytes - done[i]);
+        if (n && hipMemcpy(static_cast<char *>(o.dst) + done[i], c->data(o.peer, c->rank), n, hipMemcpyHostToDevice) != hipSuccess)
+          return fail(kUnhandledCudaError, "host -> device copy of a receive");
+        b->read.fetch_add(1, std::memory_order_release);
+        done[i] += n;
+        moved = true;
+        if (done[i] == o.bytes) finished[i] = 1, --left;
+      }
     }
-    if (o.second.bytes && hipMemcpy(o.second.dst, c->data(o.second.peer, c->rank), o.second.bytes, hipMemcpyHostToDevice) != hipSuccess)
-      return fail(kUnhandledCudaError, "host -> device copy of a receive");
-    b->read.fetch_add(1, std::memory_order_release);
+    if (moved) {
+      idle = 0;
+      continue;
+    }
+    if (++idle > 2000) std::this_thread::sleep_for(std::chrono::microseconds(50));
+    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > kTimeoutSeconds)
+      return fail(kSystemError, "timeout: a peer never sent, or never consumed, a message");
   }
   return kSuccess;
 }

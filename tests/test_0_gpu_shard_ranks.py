@@ -322,6 +322,142 @@ def test_native_sharded_step_over_the_rccl_test_double(world):
     assert results == {r: "ok" for r in range(world)}, "\n".join(f"rank {r}: {m}" for r, m in results.items())
 
 
+# --- BASELINE configs[4] at its own shape: 4000 columns over 8 ranks -------------------------------------------------------
+_SHARD_SHAPE = {}        # filled by the parent BEFORE it forks: the ranks inherit the oracle's results copy-on-write
+
+
+def _shard_shape_models():
+    """configs[4]'s shape with a vocabulary that fits a test: 4000 S2-shaped columns (dims 8/16/32/64, sum 120 000 floats per
+    row, every 10th column bucketized), batch 512, vocab 2000 (0.96 GB of tables instead of 480 GB).  The second model grows
+    two dim-64 tables beyond "one GPU" (200 MB) so that the gate answers MIXED: two columns by rows, 3998 whole."""
+    from recom_amd import synth
+    plain = synth.model_shard(columns=4000, vocab=2000, batch=512)
+    grown = synth.model_shard(columns=4000, vocab=2000, batch=512, vocab_of={1003: 800_000, 2507: 800_000})
+    return plain, grown
+
+
+def _shard_shape_rank_main(rank, world, port, q, fake_lib):
+    try:
+        for p in (ROOT, os.path.join(ROOT, "oracle")):
+            if p not in sys.path:
+                sys.path.insert(0, p)
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ["FCP_RCCL_PATH"] = fake_lib
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)         # only carries the communicator id
+        from recom_amd.placement import MIXED, decide_placement
+        from recom_amd.shard import Communicator, MixedShardedStep, NativeShardedStep, batch_slices, mixed_assignment
+        plain, grown = _SHARD_SHAPE["models"]
+        comm = Communicator(rank, world, 0, dist)
+        B, width = plain.batch, plain.spec.group_width(0)
+        assert (plain.spec.n_columns, B, width) == (4000, 512, 120_000)
+        for mode in ("row", "col", "mixed"):
+            model = grown if mode == "mixed" else plain
+            if mode == "mixed":
+                p = decide_placement(model.spec, world, hbm_bytes=200_000_000, reserve_bytes=0, prefer="mixed")
+                assert p.mode == MIXED and sorted(k for k, o in enumerate(p.owners) if o < 0) == [1003, 2507]
+                row_cols, per_rank = mixed_assignment(model.spec, p.owners, world)
+                assert row_cols == [1003, 2507] and all(per_rank) and sum(map(len, per_rank)) == 3998
+                step = MixedShardedStep(model, comm, p.owners)
+            else:
+                step = NativeShardedStep(model, comm, mode)
+            for seed, want in enumerate(_SHARD_SHAPE[mode]):                 # 5 requests over a ring of 3 buffers
+                req = model.make_request(seed)                               # ids replicated on every rank
+                ptr, begin, count = step.run(step.prepare(req.inputs, req.symbols))
+                torch.cuda.synchronize()
+                assert (begin, count) == batch_slices(B, world)[rank] and count == B // world
+                got = step.result(ptr, count).cpu().numpy()
+                # one id per row: every output row has exactly one owning rank, so the partial sums (row mode: seven slices
+                # of zeros + the owner's) come out bit-identical to the unsharded oracle in all three modes
+                assert got.shape == (count, width) and np.array_equal(got, want[begin:begin + count]), (mode, seed)
+            if mode == "row":                                                # what BASELINE configs[4] puts on the wire per rank
+                assert (world - 1) * (B // world) * width * 4 == 7 * 64 * 120_000 * 4
+            step.close()
+            dist.barrier()
+        comm.close()
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except BaseException:                                                    # noqa: BLE001 - report to the parent
+        q.put((rank, traceback.format_exc()))
+
+
+def test_native_sharded_step_at_configs4_shape_eight_ranks():
+    """BASELINE configs[4] AT ITS OWN SHAPE through the native step — 8 ranks x 4000 columns x batch 512
+    (30.7 MB per peer and request in row mode, the send / recv schedule of world 8), row-sharded, column-sharded and mixed,
+    5 requests each (ring reuse), every rank's batch slice bit for bit against the UNSHARDED oracle.  Eight processes share
+    cuda:0 over the RCCL test double; the oracle's results are computed once here, before the fork."""
+    import torch
+    assert torch.cuda.device_count() >= 1, "needs a GPU"
+    assert not torch.cuda.is_initialized()
+    for p in (ROOT, os.path.join(ROOT, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import fcp_oracle as O
+    from recom_amd.ops import concat_inputs
+    lib = build_fake_rccl()
+    orc = O.COracle()
+    plain, grown = _shard_shape_models()
+    _SHARD_SHAPE.clear()
+    _SHARD_SHAPE["models"] = (plain, grown)
+    for mode, model in (("row", plain), ("mixed", grown)):
+        tabs = model.numpy_tables()
+        wants = []
+        for seed in range(5):
+            req = model.make_request(seed)
+            want, bad = orc.process_feature_columns(model.spec.to_dict(), *concat_inputs(req.inputs), tabs, req.symbols)
+            assert bad == 0 and want[0].shape == (512, 120_000)
+            wants.append(want[0])
+        _SHARD_SHAPE[mode] = wants
+        del tabs
+    _SHARD_SHAPE["col"] = _SHARD_SHAPE["row"]                                # same model, same requests
+    world = 8
+    ctx = multiprocessing.get_context("fork")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_shard_shape_rank_main, args=(r, world, port, q, lib)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = {}
+    try:
+        for _ in range(world):
+            rank, msg = q.get(timeout=1500)
+            results[rank] = msg
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.kill()
+        _SHARD_SHAPE.clear()
+    assert results == {r: "ok" for r in range(world)}, "\n".join(f"rank {r}: {m}" for r, m in sorted(results.items()))
+
+
+def test_bench_gpus_8_row_sharded_at_configs4_shape():
+    """`python bench.py --gpus 8 --workload shard-row` at configs[4]'s column count and batch (vocab 2000; the gate is told the
+    GPU holds 200 MB): the N = 8 control flow on the 1-GPU box (gloo, all ranks on cuda:0), ONE JSON line, and the bytes one
+    rank puts on the wire per request = 7 peers x B/8 rows x 120 000 floats x 4 bytes."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["FCP_BENCH_DEVICE"] = "0"
+    env["FCP_BENCH_HBM_BYTES"] = str(200_000_000)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dist-backend", "gloo", "--steps", "4", "--warmup", "1",
+           "--workload", "shard-row", "--vocab", "2000", "--no-cpu-baseline", "--no-pcie", "--no-overlap"]
+    res = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=1500)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 8 and rec["steps"] == 4 and rec["value"] > 0 and rec["scaling"] == "strong"
+    assert rec["config"]["columns"] == 4000 and rec["config"]["batch"] == 512
+    assert "row-sharded x8" in rec["config"]["parallelism"]
+    assert rec["config"]["exchange_bytes_sent_per_rank_per_request"] == 7 * (512 // 8) * 120_000 * 4
+
+
 def test_native_sharded_step_over_rccl_two_gpus():
     """the native RCCL step (grouped send / recv layout, batch-slice order against fcp_shard_finalize, ring
     reuse) with world = 2 on two GPUs, both modes, against the unsharded oracle.  Needs 2 GPUs (skipped on the 1-GPU
