@@ -469,19 +469,56 @@ def main():
     single_caller = None
     if args.threads == 1 and not dist and not args.no_overlap:
         sweep = {}
+        sc_warm, sc_steps = max(args.warmup, 100), max(args.steps, 1200)
+        # the figure every private-stream number has to beat: the SAME loop — same consumer kernel behind every request —
+        # with the requests in stream order on the caller's stream (private streams off)
+        hs = ServingHarness(model, device=local_rank, n_requests=args.requests, arena_ring=6, n_threads=1, tables=h.tables,
+                            seed0=1000 * rank)
+        hs.run_private(sc_warm, 3)
+        so_ms, so_dev = hs.run_private(sc_steps, 3)
+        stream_order_consumer = {"us_per_request": so_ms * 1e3 / sc_steps, "device_us_per_request": so_dev * 1e3 / sc_steps}
+        hs.close()
         for lanes in (2, 3):                         # the library creates at most three (more were slower than one)
             hp = ServingHarness(model, device=local_rank, n_requests=args.requests, arena_ring=6, n_threads=1,
                                 tables=h.tables, seed0=1000 * rank)
             hp.plan.set_private_streams(lanes)
-            sc_warm, sc_steps = max(args.warmup, 100), max(args.steps, 1200)
+            hp.run(1)
+            t_v = time.perf_counter()
+            hp.plan.verify_private_streams(hp.caller_stream(), 400)   # ... and the verification, as the shim's first Compute runs it
+            verify_ms = (time.perf_counter() - t_v) * 1e3
             hp.run_private(sc_warm, lanes)
             w_ms, d_ms = hp.run_private(sc_steps, lanes)
             sweep[lanes] = {"requests": sc_steps, "warmup": sc_warm, "us_per_request": w_ms * 1e3 / sc_steps,
-                            "device_us_per_request": d_ms * 1e3 / sc_steps,
+                            "device_us_per_request": d_ms * 1e3 / sc_steps, "verify_at_warmup_ms": verify_ms,
                             # 1: the library found its streams to overlap behind this caller stream and used them; 0: it did not
                             # and kept the requests on the caller's stream; -1: never asked (requests below the work threshold)
-                            "verified_overlap": hp.plan.private_streams_verdict(hp.caller_stream())}
+                            "verified_overlap": hp.plan.private_streams_verdict(hp.caller_stream()),
+                            "supervisor": {k: v for k, v in hp.plan.private_streams_stats().items() if k != "supervised_stream"}}
             hp.close()
+        # The reference's real protocol: `serve_workers` host threads share ONE Session, hence one compute stream
+        # (recom_examples.patch:193-216): T threads issue on the one caller stream over the 3 private streams, every thread
+        # enqueues the consumer of its request `depth - 1` of its own requests later.  depth 1 = FeatureColumnProcess and
+        # Addons>ConcatOutputs back to back inside one Session::Run (what the rewritten graph does); depth 3 = a graph that
+        # runs other work of the same thread between the two.  Every figure next to the same threads in stream order.
+        threads_sweep = {}
+        for T in (1, 2, 4):
+            for depth in (1, 3):
+                ht = ServingHarness(model, device=local_rank, n_requests=args.requests, arena_ring=6, n_threads=T, tables=h.tables,
+                                    seed0=1000 * rank)
+                per = max(sc_steps // T, 300)
+                ht.run_private(max(sc_warm // T, 50), depth, T)      # private streams off: stream order + the same consumers
+                b_ms, _ = ht.run_private(per, depth, T)
+                ht.plan.set_private_streams(3)
+                ht.run(1)
+                ht.plan.verify_private_streams(ht.caller_stream(), 400)
+                ht.run_private(max(sc_warm // T, 50), depth, T)
+                w_ms, d_ms = ht.run_private(per, depth, T)
+                st = ht.plan.private_streams_stats()
+                threads_sweep[f"threads_{T}_depth_{depth}"] = {
+                    "private_streams_us": w_ms * 1e3 / (per * T), "stream_order_same_consumer_us": b_ms * 1e3 / (per * T),
+                    "verified_overlap": ht.plan.private_streams_verdict(ht.caller_stream()), "supervisor_demoted": st["demoted"],
+                    "supervisor_last_ratio": st["last_ratio"], "requests_per_thread": per}
+                ht.close()
         # and the cheap variant for callers that own their buffers (this harness does): FCP_ORDER_INPUTS_READY — the same K
         # requests back to back on the one stream, the fused kernel launched without the queue's barrier bit
         hr = ServingHarness(model, device=local_rank, n_requests=args.requests, arena_ring=6, n_threads=1, tables=h.tables,
@@ -500,6 +537,16 @@ def main():
                                  "library verified on the first request that its private streams overlap behind this caller stream (or searched a "
                                  "hardware-queue mapping that does; profiles/r04_private_streams_queue_mapping.txt)",
                          "private_streams": best, **sweep[best],
+                         "stream_order_same_consumer": {**stream_order_consumer,
+                                                        "what": "the same loop with private streams OFF: requests in stream order on the caller's "
+                                                                "stream, the same consumer kernel behind each — the figure the private-stream number "
+                                                                "has to beat (the plain `value` loop has no consumer)"},
+                         "host_threads_sweep": {"what": "T host threads issuing on the ONE caller stream (the reference's serve_workers share one "
+                                                        "Session = one compute stream, recom_examples.patch:193-216), 3 private streams; depth 1 = the "
+                                                        "consumer right behind its request (FeatureColumnProcess -> Addons>ConcatOutputs inside one "
+                                                        "Session::Run), depth 3 = two more requests of the thread in between; us per request over all "
+                                                        "threads, next to the same threads in stream order (a demoted caller runs in stream order)",
+                                                **threads_sweep},
                          "sweep_us_per_request": {str(k): v["us_per_request"] for k, v in sweep.items()},
                          "sweep_verified_overlap": {str(k): v["verified_overlap"] for k, v in sweep.items()},
                          "inputs_ready_back_to_back": inputs_ready}

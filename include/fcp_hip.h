@@ -421,11 +421,13 @@ int fcp_process_feature_columns(fcp_plan_t *plan,
  * overlapped).  fcp_plan_set_private_streams(plan, n, flags) gives the plan n
  * streams of its own (0 = off, the default; at most 16).  From then on
  * fcp_process_feature_columns
- *   - records an event on args->stream (everything enqueued there so far: the
- *     producer of the blob, earlier users of the memory malloc_buff hands out —
- *     TF's allocator reuses memory in compute-stream order),
- *   - runs the request on the next private stream (round robin), which first
- *     waits for that event,
+ *   - calls malloc_buff, THEN records an event on args->stream (everything
+ *     enqueued there up to the allocation: the producer of the blob, and whatever
+ *     still uses the memory malloc_buff has just handed out — TF's allocator reuses
+ *     memory in compute-stream order, and another Session::Run thread may queue a
+ *     reader of that memory at any time before the allocation),
+ *   - runs the request on the next private stream (round robin), which waits for
+ *     that event before its first command that touches the arena,
  *   - files the request's completion event under the address range of its arena
  *     (fcp_process_result_t::buffer, buffer_bytes).
  * args->stream itself does NOT wait for the kernels.  Whoever reads the arena —
@@ -435,7 +437,8 @@ int fcp_process_feature_columns(fcp_plan_t *plan,
  * reader: a device-side wait, the host never blocks.  fcp_result_synchronize is
  * the same for a host reader.  Both return FCP_OK at once when nothing is pending
  * for that address (private streams off, or the request long complete).
- * fcp_concat_outputs_host performs the wait itself for its `out` pointer.
+ * fcp_concat_outputs_host performs the wait itself for its `out` pointer, fcp_concat_outputs and the
+ * scatter variants for EVERY input (columns of one arena or of several) and for `out`.
  *
  * FCP_PRIVATE_NO_CALLER_WAIT: the private stream does not wait for args->stream.
  * Only for callers that guarantee by other means that the blob is complete and
@@ -471,13 +474,34 @@ int fcp_process_feature_columns(fcp_plan_t *plan,
  * only wait; the host blocks for ~8 ms and args->stream drains once).  While no
  * live plan relies on the present mapping, other mappings are tried — the private
  * streams are re-created with the next priority (normal, low, high) and behind up to six
- * spacer streams, ~8 ms each.  A caller behind which no mapping overlaps keeps
+ * spacer streams, ~8 ms each — within a WALL-TIME budget (a request: 120 ms,
+ * FCP_PRIVATE_VERIFY_BUDGET_MS; fcp_plan_verify_private_streams: its argument).
+ * A caller behind which no mapping overlaps keeps
  * its requests on its own stream: the mode then costs nothing instead of a
  * multiple.  (A verdict is kept per stream HANDLE for the life of the plan: a
  * process that destroys and re-creates its streams calls this function again.)
  * FCP_PRIVATE_NO_VERIFY skips all of it (the streams are used as
  * created); FCP_LANE_PRIORITY=normal|low|high chooses the priority the search
- * starts with; FCP_PRIVATE_VERIFY_VERBOSE=1 prints the search. */
+ * starts with; FCP_PRIVATE_VERIFY_VERBOSE=1 prints the search.
+ * Callers with a warm-up request (every deployment of the reference has one,
+ * docs/build_from_source.md:42) call fcp_plan_verify_private_streams there: no
+ * serving request then ever pays for the search.
+ *
+ * Supervision.  A verdict is learnt once; the mapping can stop overlapping later
+ * (another library of the process creates streams).  The plan therefore keeps
+ * measuring: the first four lane-eligible requests of a caller stream run on THAT
+ * stream between two timing events (the stream-order time per byte of work of the
+ * plan's real requests); afterwards every 256th private-stream request opens a
+ * window of 48 requests between two timing events on one private stream.  A
+ * window counts when at least 3/4 of its requests found their private stream
+ * still busy with the previous one (otherwise the host set the pace); when two
+ * consecutive counted windows ran slower than 1.10x the stream-order time per
+ * byte (private streams that overlap measure 0.64-0.92, those that do not
+ * 1.13-1.64: profiles/r05_caller_threads_grid.txt), the caller is DEMOTED: verdict 0, one line on stderr, its requests stay
+ * on its own stream (results are unaffected at every point).
+ * fcp_plan_verify_private_streams searches a new mapping and re-admits it.
+ * FCP_LANE_SUPERVISE=0 turns the supervisor off; FCP_LANE_SUPERVISE_PERIOD,
+ * FCP_LANE_DEMOTE_RATIO tune it; fcp_plan_private_streams_stats reads it. */
 enum { FCP_PRIVATE_NO_CALLER_WAIT = 1u << 0, FCP_PRIVATE_ALWAYS = 1u << 1, FCP_PRIVATE_NO_VERIFY = 1u << 2 };
 int fcp_plan_set_private_streams(fcp_plan_t *plan, int32_t n_streams, uint32_t flags);
 
@@ -497,6 +521,28 @@ int fcp_plan_probe_private_streams(fcp_plan_t *plan, void *stream, int32_t reque
 /* What the verification decided for `stream`: *verdict = 1 (its requests take the private streams), 0 (they stay on
  * `stream`: nothing overlapped behind it) or -1 (no request of that stream verified yet, or the mode is off). */
 int fcp_plan_private_streams_verdict(fcp_plan_t *plan, void *stream, int32_t *verdict);
+/* The verification at a time of the caller's choosing (warm-up): probes the private streams behind `stream` now and, while
+ * no live plan relies on the present mapping, searches another one for at most about budget_ms of wall time (<= 0: 400 ms;
+ * one mapping costs ~8 ms, the whole search space ~22 of them).  A negative verdict of an earlier, cheaper look — or a
+ * demotion by the supervisor — is forgotten and the search runs again; a positive one is returned as it is.  Blocks the
+ * host, drains `stream`.  *verdict (optional) as fcp_plan_private_streams_verdict; -1 when the mode is off, or when the
+ * plan's requests so far are below the work threshold (they stay on `stream` anyway: nothing is probed).  Call it after
+ * the first (warm-up) request of the plan, as the shim does. */
+int fcp_plan_verify_private_streams(fcp_plan_t *plan, void *stream, int32_t budget_ms, int32_t *verdict);
+/* What the run-time supervisor of the plan's private streams has seen (see Supervision above). */
+typedef struct fcp_private_streams_stats {
+  void *supervised_stream;     /* the caller stream under supervision (the first that took the private streams), or NULL */
+  int64_t lane_requests;       /* its requests that ran on a private stream                                              */
+  int64_t windows;             /* timed windows completed                                                                */
+  int64_t windows_counted;     /* ... of which GPU-bound (>= 3/4 of the requests found their stream busy)                */
+  double baseline_us_per_mib;  /* stream-order time per MiB of work (rows gathered + output written), 0: not known yet   */
+  double last_ratio;           /* last counted window: time per byte on the private streams / baseline                   */
+  double worst_ratio;          /* the largest such ratio so far                                                          */
+  double demote_ratio;         /* threshold (1.10)                                                                       */
+  int32_t demoted;             /* 1: the supervisor has moved this caller back to its own stream                         */
+  int32_t baseline_samples;    /* baseline requests read so far (4)                                                      */
+} fcp_private_streams_stats_t;
+int fcp_plan_private_streams_stats(fcp_plan_t *plan, fcp_private_streams_stats_t *out);
 
 /* The cheap half of the same idea, for callers that OWN their buffers: FCP_ORDER_INPUTS_READY is the caller's promise, for
  * every request of the plan, that when fcp_process_feature_columns is CALLED the blob is complete in device memory and
@@ -516,6 +562,10 @@ int fcp_plan_private_streams_verdict(fcp_plan_t *plan, void *stream, int32_t *ve
 enum { FCP_ORDER_STREAM = 0, FCP_ORDER_INPUTS_READY = 1 };
 int fcp_plan_set_request_order(fcp_plan_t *plan, int32_t order);
 int fcp_result_wait(const void *buffer, void *stream);
+/* A host reader: returns once the request has completed on the device.  What that guarantees is device-scope: copies and
+ * kernels issued afterwards (hipMemcpy*, any stream) see the result.  A host that reads the arena DIRECTLY — host-mapped or
+ * fine-grained memory — gets no system-scope visibility from it (the completion events carry no system fence, which is what
+ * keeps them off the GPU's critical path): such a reader copies through the device or synchronises a stream of its own. */
 int fcp_result_synchronize(const void *buffer);
 
 /* ---- ConcatOutputs (concat_outputs_op_gpu.cu.cc:85-140) ------------------ */

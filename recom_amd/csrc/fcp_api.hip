@@ -127,6 +127,7 @@ struct DynSlot {
 // interleaved between two host threads.  Events rotate: re-recording an event that an older consumer has not waited
 // for yet makes that consumer wait for LATER work of the same lane, which covers the older request (same stream).
 constexpr int kLaneEvents = 8;
+constexpr int kMaxPoolLanes = 16; // (more than three only for experiments: FCP_PRIVATE_LANES_UNCAPPED)
 struct PrivateLane {
   hipStream_t stream = nullptr;
   std::mutex mu;
@@ -147,19 +148,76 @@ std::atomic<uint64_t> g_lane_generation{1};
 thread_local hipEvent_t tl_lane_done = nullptr;
 thread_local uint64_t tl_lane_done_gen = 0;
 
+// What a private-stream request waits for on the caller's stream is known only once the allocator has answered: TF's
+// allocator hands out memory in compute-stream order, and between this call's entry and its malloc_buff another
+// Session::Run thread may have queued a kernel that still reads the very memory the arena gets.  So
+// fcp_process_feature_columns leaves the dependency here and fcp_internal_process enqueues it — event record on the caller's
+// stream, wait on the lane — right behind malloc_buff, in front of the first command that touches the arena.
+struct LaneDep {
+  hipEvent_t in;
+  hipStream_t caller, lane;
+};
+thread_local const LaneDep *tl_lane_dep = nullptr;
+// gathered + written bytes of the request this thread processed last (DynMeta::work_bytes; the supervisor's unit of work)
+thread_local int64_t tl_work_bytes = 0;
+
+// Supervision of one plan's lane traffic behind ONE caller stream (the first that took the lanes; TensorFlow has one).
+//   baseline: the first kBaseline lane-eligible requests run on the CALLER's stream between two timing events: the
+//             stream-order cost per byte of work of this plan's real requests (minimum of the samples);
+//   window:   every `period`-th lane request opens one: a timing event behind that request on its lane, a second one behind
+//             the first request at least kWindow requests later that lands on the same lane; work bytes summed in between,
+//             and per request whether its lane still had the previous request in flight when it was issued (hipEventQuery);
+//   verdict:  a window counts only when >= 3/4 of its requests found their lane busy (otherwise the host, not the GPU, set
+//             the pace and the window says nothing); its time per byte over the baseline's is the ratio; two consecutive
+//             counted windows above `demote_ratio` (1.10: lanes that overlap measure 0.64-0.92, lanes that do not 1.13-1.64,
+//             profiles/r05_caller_threads_grid.txt) demote the caller: verdict 0, logged once, requests stay on its stream.
+// Cost: two marker packets per window and ~kWindow event queries — nothing between windows but one mutex and a counter.
+constexpr int kSupBaseline = 4, kSupWindow = 48;
+struct LaneSupervisor {
+  std::mutex mu;
+  bool on = true;
+  uint32_t period = 256;
+  double demote_ratio = 1.10;
+  void *caller = nullptr;
+  int base_issued = 0, base_read = 0;
+  hipEvent_t b0[kSupBaseline] = {}, b1[kSupBaseline] = {};
+  int64_t base_bytes[kSupBaseline] = {};
+  double base_ns_per_byte = 0; // 0: not known yet
+  uint64_t seq = 0;
+  int state = 0; // 0 idle, 1 window open, 2 window closed (events pending)
+  hipEvent_t w0 = nullptr, w1 = nullptr;
+  PrivateLane *w_lane = nullptr;
+  int w_count = 0, w_busy = 0;
+  int64_t w_bytes = 0;
+  int strikes = 0;
+  uint64_t windows = 0, counted = 0;
+  double last_ratio = 0, worst_ratio = 0;
+  bool demoted = false;
+};
+
 struct LanePool {
   std::mutex cal_mu;                                  // lanes / spacers are created, probed and re-created under it
   std::vector<std::unique_ptr<PrivateLane>> lanes;
   std::vector<hipStream_t> spacers;                   // streams that only hold hardware queues (verify_lanes)
   std::atomic<int> n_relying{0};                      // live plans that found the present mapping good, or use it unverified
   std::atomic<uint32_t> rr{0};
+  // Test aid (FCP_LANE_FAULT_US=N, read by fcp_plan_set_private_streams): every lane request first waits for the device's
+  // previous lane request and then spins for N us on its lane — lanes that serialise and stall, the signature of a
+  // hardware-queue mapping that does not overlap (profiles/r04_private_streams_queue_mapping.txt: 29-86 us per S2
+  // request), made deterministic for the supervisor's test.
+  std::atomic<int> fault_us{0};
+  std::atomic<hipEvent_t> last_out{nullptr};
 };
+void sup_reset(LaneSupervisor &S);
 std::mutex g_lane_pools_mu;
 std::map<int, LanePool *> g_lane_pools;
 LanePool *lane_pool_for(int device) {
   std::lock_guard<std::mutex> lock(g_lane_pools_mu);
   LanePool *&lp = g_lane_pools[device];
-  if (!lp) lp = new LanePool();
+  if (!lp) {
+    lp = new LanePool();
+    lp->lanes.reserve(kMaxPoolLanes);
+  }
   return lp;
 }
 
@@ -322,6 +380,11 @@ struct fcp_plan {
   std::atomic<int64_t> last_work_bytes{0};
   int64_t lane_min_work = 0;
   int32_t request_order = FCP_ORDER_STREAM; // fcp_plan_set_request_order
+  // Run-time supervision of the lanes (LaneSupervisor below): a verdict is learnt once, a mapping can go bad later (another
+  // library of the process creates streams; the runtime re-maps queues): sampled windows of lane requests are timed
+  // against the stream-order rate of the same requests and the caller is demoted to its own stream when they lose.
+  std::atomic<bool> lane_demoted{false};                // some caller of this plan has been demoted (NO_VERIFY plans look it up)
+  LaneSupervisor sup;
 };
 
 namespace {
@@ -1800,34 +1863,41 @@ int fcp_plan_release_captures(fcp_plan_t *p) {
 
 namespace {
 // (callers hold pool->cal_mu)
+// Only the STREAMS go: the PrivateLane objects and their events live as long as the process, so a request that raced
+// with a re-creation (a plan using the lanes unverified, a descriptor slot querying a lane's completion event it
+// remembered) finds a lane without a stream — and stays on its caller's stream — or a valid, long-completed event,
+// never freed memory.
 void destroy_lanes(LanePool *pool) {
   g_lane_generation.fetch_add(1, std::memory_order_acq_rel);
   for (auto &l : pool->lanes) {
-    for (int i = 0; i < kLaneEvents; ++i) {
-      if (l->in[i]) (void)hipEventDestroy(l->in[i]);
-      if (l->out[i]) (void)hipEventDestroy(l->out[i]);
-    }
+    std::lock_guard<std::mutex> lane_lock(l->mu);
     if (l->stream) (void)hipStreamDestroy(l->stream);
+    l->stream = nullptr;
   }
-  pool->lanes.clear();
 }
 
-// appends lanes until the pool holds n; prio: 0 = the caller's (normal), 1 = lowest, 2 = highest
+// makes the pool's first n lanes usable (objects appended, streams created where a lane has none); prio: 0 = the
+// caller's (normal), 1 = lowest, 2 = highest
 int create_lanes(LanePool *pool, int n, int prio) {
   int least = 0, greatest = 0;
   HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+  if (n > kMaxPoolLanes) n = kMaxPoolLanes; // (the vector never reallocates: requests index it without the pool's mutex)
   while ((int)pool->lanes.size() < n) {
     std::unique_ptr<PrivateLane> l(new PrivateLane());
-    if (prio != 0 && least != greatest) {
-      HIP_TRY(hipStreamCreateWithPriority(&l->stream, hipStreamNonBlocking, prio == 1 ? least : greatest));
-    } else {
-      HIP_TRY(hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking));
-    }
-    pool->lanes.push_back(std::move(l)); // owned from here on
-    PrivateLane &L = *pool->lanes.back();
     for (int i = 0; i < kLaneEvents; ++i) {
-      HIP_TRY(hipEventCreateWithFlags(&L.in[i], hipEventDisableTiming | hipEventDisableSystemFence));
-      HIP_TRY(hipEventCreateWithFlags(&L.out[i], hipEventDisableTiming | hipEventDisableSystemFence));
+      HIP_TRY(hipEventCreateWithFlags(&l->in[i], hipEventDisableTiming | hipEventDisableSystemFence));
+      HIP_TRY(hipEventCreateWithFlags(&l->out[i], hipEventDisableTiming | hipEventDisableSystemFence));
+    }
+    pool->lanes.push_back(std::move(l));
+  }
+  for (int i = 0; i < n; ++i) {
+    PrivateLane &L = *pool->lanes[i];
+    std::lock_guard<std::mutex> lane_lock(L.mu);
+    if (L.stream) continue;
+    if (prio != 0 && least != greatest) {
+      HIP_TRY(hipStreamCreateWithPriority(&L.stream, hipStreamNonBlocking, prio == 1 ? least : greatest));
+    } else {
+      HIP_TRY(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
     }
   }
   return FCP_OK;
@@ -1887,7 +1957,8 @@ int fcp_plan_read_bad_ids(fcp_plan_t *p, void *stream, int64_t *count) {
   HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
   if (p->pool && p->lane_count > 0) { // requests of that stream may have run on a private lane
     std::lock_guard<std::mutex> cal_lock(p->pool->cal_mu);
-    for (auto &l : p->pool->lanes) HIP_TRY(hipStreamSynchronize(l->stream));
+    for (auto &l : p->pool->lanes)
+      if (l->stream) HIP_TRY(hipStreamSynchronize(l->stream));
   }
   HIP_TRY(hipMemcpy(&v, p->d_bad, sizeof(v), hipMemcpyDeviceToHost));
   *count = (int64_t)v;
@@ -1956,6 +2027,7 @@ int fcp_internal_process(fcp_plan_t *p, const fcp_process_args_t *a, fcp_process
     publish_slot(p, *slot, key, a->stream);
   }
   const DynMeta &m = slot->meta;
+  tl_work_bytes = m.work_bytes;
   // an empty blob (every input tensor empty: all bags empty) may come with a null pointer, as an empty
   // TF tensor does; nothing dereferences it then
   if (m.arena_bytes > 0 && !a->concated_inputs && !p->ranks.empty() && a->concated_bytes != 0)
@@ -1963,6 +2035,13 @@ int fcp_internal_process(fcp_plan_t *p, const fcp_process_args_t *a, fcp_process
 
   void *arena = a->malloc_buff(a->malloc_buff_ctx, (size_t)std::max<int64_t>(m.arena_bytes, 128)); // never a zero-size request
   if (!arena) return fail(FCP_ERR_ALLOC, "malloc_buff returned NULL");
+  if (const LaneDep *dep = tl_lane_dep) {
+    // a private-stream request: everything queued on the caller's stream UP TO THE ALLOCATION — the blob's producer, and
+    // whatever still uses the memory the allocator has just handed out — before the lane's first command on the arena
+    tl_lane_dep = nullptr;
+    HIP_TRY(hipEventRecord(dep->in, dep->caller));
+    HIP_TRY(hipStreamWaitEvent(dep->lane, dep->in, 0));
+  }
 
   FcpLaunch L;
   fill_launch(p, *slot, 1, a->concated_inputs, arena, &L);
@@ -2090,11 +2169,22 @@ int fcp_plan_set_private_streams(fcp_plan_t *p, int32_t n_streams, uint32_t flag
   LanePool *pool = p->pool ? p->pool : lane_pool_for(p->desc.device);
   std::lock_guard<std::mutex> cal_lock(pool->cal_mu);
   if (p->lane_count > 0)
-    for (auto &l : pool->lanes) HIP_TRY(hipStreamSynchronize(l->stream)); // this plan's results are complete from here on
+    for (auto &l : pool->lanes)
+      if (l->stream) HIP_TRY(hipStreamSynchronize(l->stream)); // this plan's results are complete from here on
   pending_forget(p);
   p->lane_verdicts.clear();
   p->lane_good_caller.store(nullptr, std::memory_order_release);
   if (p->lane_relies.exchange(false)) pool->n_relying.fetch_sub(1, std::memory_order_acq_rel);
+  {
+    std::lock_guard<std::mutex> sup_lock(p->sup.mu);
+    sup_reset(p->sup);
+  }
+  p->lane_demoted.store(false, std::memory_order_release);
+  {
+    const char *e = std::getenv("FCP_LANE_FAULT_US"); // test aid, see LanePool::fault_us
+    pool->fault_us.store(e ? std::max(std::atoi(e), 0) : 0, std::memory_order_relaxed);
+    pool->last_out.store(nullptr, std::memory_order_relaxed);
+  }
   p->lane_flags = flags;
   {
     const char *e = std::getenv("FCP_PRIVATE_MIN_WORK_BYTES"); // tuning aid
@@ -2188,27 +2278,34 @@ int run_lane_probe(fcp_plan *p, hipStream_t caller, int requests, int spin_us, i
   return FCP_OK;
 }
 
-// The first lane-eligible request of a caller stream: do the lanes overlap behind it?  While no caller has been found
-// good, other mappings are tried: the lanes re-created with the next priority, then behind one more spacer stream (a
-// stream that has run one empty kernel holds a hardware queue and shifts everything created after it), up to
-// kMaxSpacers.  The probe: 24 one-block kernels of 80 us with their consumers, three times (the first pass brings the
-// queues up, the better of the other two counts); serial / lanes >= 2.15 (three lanes) counts as overlap
-// (scripts/probes/lane_probe_vs_real.py, lanes_cold_start.py, profiles/r04_private_streams_queue_mapping.txt).
-// Costs the first request ~8 ms per mapping tried (host blocked, caller's stream drained).  *ok = false: this caller's
-// requests stay on its own stream.
-int verify_lanes(fcp_plan *p, hipStream_t caller, bool *ok) {
+// The first lane-eligible request of a caller stream (or fcp_plan_verify_private_streams, at warm-up): do the lanes overlap
+// behind it?  While no caller has been found good, other mappings are tried: the lanes re-created with the next priority,
+// then behind one more spacer stream (a stream that has run one empty kernel holds a hardware queue and shifts everything
+// created after it), up to kMaxSpacers — and, whatever is left to try, until `budget_ms` of wall time are spent (a mapping
+// costs ~8 ms: the search never holds a request for more than the budget plus one probe).  The probe: 24 one-block kernels
+// of 80 us with their consumers, three times (the first pass brings the queues up, the better of the other two counts);
+// serial / lanes >= 2.15 (three lanes) counts as overlap (scripts/probes/lane_probe_vs_real.py, lanes_cold_start.py,
+// profiles/r04_private_streams_queue_mapping.txt).  *ok = false: this caller's requests stay on its own stream.
+// `again`: forget an earlier verdict of this caller and verify afresh (the warm-up entry point after a cheap first look).
+int verify_lanes(fcp_plan *p, hipStream_t caller, int budget_ms, bool again, bool *ok) {
   LanePool *pool = p->pool;
   *ok = false;
   if (!pool) return FCP_OK;
   std::lock_guard<std::mutex> cal_lock(pool->cal_mu);
-  for (auto &v : p->lane_verdicts)
-    if (v.first == caller) {
-      *ok = v.second;
-      return FCP_OK;
+  for (size_t i = 0; i < p->lane_verdicts.size(); ++i)
+    if (p->lane_verdicts[i].first == caller) {
+      if (!again || p->lane_verdicts[i].second) {
+        *ok = p->lane_verdicts[i].second;
+        return FCP_OK;
+      }
+      p->lane_verdicts.erase(p->lane_verdicts.begin() + (long)i);
+      break;
     }
   if (p->lane_count == 0 || pool->lanes.empty()) return FCP_OK;
   const bool verbose = std::getenv("FCP_PRIVATE_VERIFY_VERBOSE") != nullptr; // (read per verification: rare)
   constexpr int kMaxSpacers = 6, kProbeSpinUs = 80;
+  const auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(std::max(budget_ms, 0));
+  auto in_budget = [&] { return std::chrono::steady_clock::now() < deadline; };
   // With 40-us kernels three lanes gave 1.9-2.1 on mappings that overlap (the lanes' side is then bound by the host's five
   // runtime calls per request) and up to 1.48 on mappings that do not (S2 at 29-44 us per request) — too close: one process in
   // a dozen accepted a bad one.  80-us kernels: 2.31-2.42 where three lanes overlap, 1.8-1.97 where only two do (two of the
@@ -2233,13 +2330,14 @@ int verify_lanes(fcp_plan *p, hipStream_t caller, bool *ok) {
   int rc = overlap(&ratio);
   if (rc) return rc;
   bool good = ratio >= kProbeGood;
+  int tried = 1;
   if (verbose) std::fprintf(stderr, "fcp private streams: caller %p, lanes as created: serial / lanes = %.2f\n", (void *)caller, ratio);
   // other mappings only while nobody — no live plan of this device — relies on the present one
   if (!good && pool->n_relying.load(std::memory_order_acquire) == 0 && pool->spacers.size() > 12) { // earlier searches' spacers
     for (hipStream_t sp : pool->spacers) (void)hipStreamDestroy(sp);
     pool->spacers.clear();
   }
-  for (int spacers = 0; !good && pool->n_relying.load(std::memory_order_acquire) == 0 && spacers <= kMaxSpacers; ++spacers) {
+  for (int spacers = 0; !good && pool->n_relying.load(std::memory_order_acquire) == 0 && spacers <= kMaxSpacers && in_budget(); ++spacers) {
     if (spacers > 0) {
       hipStream_t sp = nullptr;
       HIP_TRY(hipStreamCreateWithFlags(&sp, hipStreamNonBlocking));
@@ -2247,20 +2345,24 @@ int verify_lanes(fcp_plan *p, hipStream_t caller, bool *ok) {
       hipLaunchKernelGGL(fcp_probe_consumer_kernel, dim3(1), dim3(1), 0, sp);
       HIP_TRY(hipStreamSynchronize(sp));
     }
-    for (int k = (spacers == 0 ? 1 : 0); !good && k < 3; ++k) { // (spacers == 0, first priority: probed above)
+    for (int k = (spacers == 0 ? 1 : 0); !good && k < 3 && in_budget(); ++k) { // (spacers == 0, first priority: probed above)
       const int prio = (first_prio + k) % 3;
-      for (auto &l : pool->lanes) HIP_TRY(hipStreamSynchronize(l->stream));
+      for (auto &l : pool->lanes)
+        if (l->stream) HIP_TRY(hipStreamSynchronize(l->stream));
       destroy_lanes(pool);
       rc = create_lanes(pool, n, prio);
       if (rc) return rc;
       rc = overlap(&ratio);
       if (rc) return rc;
       good = ratio >= kProbeGood;
+      ++tried;
       if (verbose)
         std::fprintf(stderr, "fcp private streams: caller %p, %d spacer(s), priority %s: serial / lanes = %.2f\n", (void *)caller,
                      (int)pool->spacers.size(), prio == 0 ? "normal" : prio == 1 ? "low" : "high", ratio);
     }
   }
+  if (verbose && !good)
+    std::fprintf(stderr, "fcp private streams: caller %p keeps its requests: %d mapping(s) tried within %d ms, none overlaps\n", (void *)caller, tried, budget_ms);
   p->lane_verdicts.emplace_back((void *)caller, good);
   if (good) {
     if (!p->lane_relies.exchange(true)) pool->n_relying.fetch_add(1, std::memory_order_acq_rel);
@@ -2269,10 +2371,108 @@ int verify_lanes(fcp_plan *p, hipStream_t caller, bool *ok) {
   *ok = good;
   return FCP_OK;
 }
+
+// wall-time budget of a verification that a REQUEST triggers (FCP_PRIVATE_VERIFY_BUDGET_MS; the warm-up entry point
+// fcp_plan_verify_private_streams names its own)
+int default_verify_budget_ms() {
+  static const int ms = [] {
+    const char *e = std::getenv("FCP_PRIVATE_VERIFY_BUDGET_MS");
+    return e ? std::max(std::atoi(e), 0) : 120;
+  }();
+  return ms;
+}
+
+// ---- the supervisor (struct LaneSupervisor above) -----------------------------------------------------------------------
+void sup_reset(LaneSupervisor &S) { // (S.mu held, or no request in flight); events are kept
+  S.caller = nullptr;
+  S.base_issued = S.base_read = 0;
+  S.base_ns_per_byte = 0;
+  S.seq = 0;
+  S.state = 0;
+  S.w_lane = nullptr;
+  S.strikes = 0;
+  S.windows = S.counted = 0;
+  S.last_ratio = S.worst_ratio = 0;
+  S.demoted = false;
+  if (const char *e = std::getenv("FCP_LANE_SUPERVISE")) S.on = std::atoi(e) != 0;
+  if (const char *e = std::getenv("FCP_LANE_SUPERVISE_PERIOD")) S.period = (uint32_t)std::max(std::atoi(e), kSupWindow + 8);
+  if (const char *e = std::getenv("FCP_LANE_DEMOTE_RATIO")) S.demote_ratio = std::max(std::atof(e), 1.0);
+}
+
+int sup_events(LaneSupervisor &S) { // timing events, created on first use (S.mu held)
+  if (S.w0) return FCP_OK;
+  HIP_TRY(hipEventCreate(&S.w0));
+  HIP_TRY(hipEventCreate(&S.w1));
+  for (int i = 0; i < kSupBaseline; ++i) {
+    HIP_TRY(hipEventCreate(&S.b0[i]));
+    HIP_TRY(hipEventCreate(&S.b1[i]));
+  }
+  return FCP_OK;
+}
+
+// completed baseline samples -> base_ns_per_byte (S.mu held)
+void sup_read_baseline(LaneSupervisor &S) {
+  while (S.base_read < S.base_issued && hipEventQuery(S.b1[S.base_read]) == hipSuccess) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, S.b0[S.base_read], S.b1[S.base_read]) == hipSuccess && ms > 0 && S.base_bytes[S.base_read] > 0) {
+      const double r = (double)ms * 1e6 / (double)S.base_bytes[S.base_read];
+      S.base_ns_per_byte = S.base_ns_per_byte > 0 ? std::min(S.base_ns_per_byte, r) : r;
+    }
+    ++S.base_read;
+  }
+}
+
+// a closed window whose events have completed -> strikes; returns true when the caller is to be demoted (S.mu held)
+bool sup_read_window(LaneSupervisor &S) {
+  if (S.state != 2 || hipEventQuery(S.w1) != hipSuccess) return false;
+  S.state = 0;
+  ++S.windows;
+  sup_read_baseline(S);
+  float ms = 0;
+  if (hipEventElapsedTime(&ms, S.w0, S.w1) != hipSuccess || S.w_bytes <= 0 || S.base_ns_per_byte <= 0) return false;
+  if (4 * S.w_busy < 3 * S.w_count) return false; // the host set the pace: says nothing about the lanes
+  ++S.counted;
+  S.last_ratio = (double)ms * 1e6 / (double)S.w_bytes / S.base_ns_per_byte;
+  S.worst_ratio = std::max(S.worst_ratio, S.last_ratio);
+  S.strikes = S.last_ratio > S.demote_ratio ? S.strikes + 1 : 0;
+  return S.strikes >= 2 && !S.demoted;
+}
+
+// (no lane mutex held: cal_mu is taken, and verify_lanes takes the lanes' mutexes under cal_mu)
+void demote_caller(fcp_plan *p, void *caller) {
+  LanePool *pool = p->pool;
+  if (!pool) return;
+  double ratio = 0;
+  uint64_t counted = 0;
+  {
+    std::lock_guard<std::mutex> sup_lock(p->sup.mu);
+    if (p->sup.demoted) return;
+    p->sup.demoted = true;
+    ratio = p->sup.last_ratio;
+    counted = p->sup.counted;
+  }
+  std::lock_guard<std::mutex> cal_lock(pool->cal_mu);
+  bool found = false;
+  for (auto &v : p->lane_verdicts)
+    if (v.first == caller) v.second = false, found = true;
+  if (!found) p->lane_verdicts.emplace_back(caller, false);
+  void *expect = caller;
+  p->lane_good_caller.compare_exchange_strong(expect, nullptr, std::memory_order_acq_rel);
+  p->lane_demoted.store(true, std::memory_order_release);
+  bool any_good = false;
+  for (auto &v : p->lane_verdicts) any_good = any_good || v.second;
+  // nobody of this plan relies on the mapping any more: a later verification may search another one
+  if (!any_good && p->lane_relies.exchange(false)) pool->n_relying.fetch_sub(1, std::memory_order_acq_rel);
+  std::fprintf(stderr, "fcp private streams: caller stream %p DEMOTED to its own stream: its requests ran at %.2fx the stream-order "
+                       "time per byte on the private streams (threshold %.2f, %llu supervised window(s)); the hardware-queue mapping "
+                       "no longer overlaps — fcp_plan_verify_private_streams searches a new one\n",
+               caller, ratio, p->sup.demote_ratio, (unsigned long long)counted);
+}
+
 } // namespace
 
 // What the verification decided for `stream`: 1 = its requests take the private streams, 0 = they stay on `stream` (nothing
-// overlapped behind it), -1 = no request of that stream has been verified yet, or the mode is off.
+// overlapped behind it, or the supervisor demoted it), -1 = no request of that stream has been verified yet, or the mode is off.
 int fcp_plan_private_streams_verdict(fcp_plan_t *p, void *stream, int32_t *verdict) {
   if (!p || !verdict) return fail(FCP_ERR_INVALID_ARGUMENT, "null argument");
   *verdict = -1;
@@ -2281,6 +2481,52 @@ int fcp_plan_private_streams_verdict(fcp_plan_t *p, void *stream, int32_t *verdi
   std::lock_guard<std::mutex> cal_lock(pool->cal_mu);
   for (auto &v : p->lane_verdicts)
     if (v.first == stream) *verdict = v.second ? 1 : 0;
+  return FCP_OK;
+}
+
+// The verification at a time of the caller's choosing — the warm-up request every deployment of the reference runs anyway
+// (docs/build_from_source.md:42) — so that no serving request pays for it.
+int fcp_plan_verify_private_streams(fcp_plan_t *p, void *stream, int32_t budget_ms, int32_t *verdict) {
+  if (!p) return fail(FCP_ERR_INVALID_ARGUMENT, "null plan");
+  if (verdict) *verdict = -1;
+  if (p->host_only) return fail(FCP_ERR_NO_DEVICE, "host-only plan");
+  if (!p->pool || p->lane_count == 0) return FCP_OK; // mode off: nothing to verify
+  // a plan whose requests (the shapes it has seen last) are below the work threshold keeps them on the caller's stream:
+  // nothing to verify, nothing to pay (a later, heavier request verifies itself within the request budget)
+  const int64_t seen = p->last_work_bytes.load(std::memory_order_relaxed);
+  if (seen > 0 && seen < p->lane_min_work) return FCP_OK;
+  hipStream_t caller = static_cast<hipStream_t>(stream);
+  if (stream_is_capturing(caller)) return fail(FCP_ERR_INVALID_ARGUMENT, "verify: the stream is being captured");
+  DeviceGuard guard;
+  int rc = guard.enter(p->desc.device);
+  if (rc) return rc;
+  bool ok = false;
+  rc = verify_lanes(p, caller, budget_ms > 0 ? budget_ms : 400, /*again=*/true, &ok);
+  if (rc) return rc;
+  if (ok) { // a new mapping, or a new look at the old one: the supervisor starts over
+    std::lock_guard<std::mutex> sup_lock(p->sup.mu);
+    if (p->sup.demoted || p->sup.caller != stream) sup_reset(p->sup);
+    p->lane_demoted.store(false, std::memory_order_release);
+  }
+  if (verdict) *verdict = ok ? 1 : 0;
+  return FCP_OK;
+}
+
+int fcp_plan_private_streams_stats(fcp_plan_t *p, fcp_private_streams_stats_t *out) {
+  if (!p || !out) return fail(FCP_ERR_INVALID_ARGUMENT, "null argument");
+  std::memset(out, 0, sizeof(*out));
+  std::lock_guard<std::mutex> sup_lock(p->sup.mu);
+  const LaneSupervisor &S = p->sup;
+  out->supervised_stream = S.caller;
+  out->lane_requests = (int64_t)S.seq;
+  out->windows = (int64_t)S.windows;
+  out->windows_counted = (int64_t)S.counted;
+  out->baseline_us_per_mib = S.base_ns_per_byte * 1048576.0 / 1e3;
+  out->last_ratio = S.last_ratio;
+  out->worst_ratio = S.worst_ratio;
+  out->demote_ratio = S.demote_ratio;
+  out->demoted = S.demoted ? 1 : 0;
+  out->baseline_samples = S.base_read;
   return FCP_OK;
 }
 
@@ -2305,120 +2551,233 @@ int fcp_plan_set_request_order(fcp_plan_t *p, int32_t order) {
   return FCP_OK;
 }
 
+namespace {
+// the request on the caller's own stream although the plan has private streams (small, captured, unverified, demoted)
+int process_on_caller(fcp_plan_t *p, const fcp_process_args_t *a, fcp_process_result_t *r) {
+  fcp_process_result_t local{};
+  if (!r) r = &local;
+  const int rc = fcp_internal_process(p, a, r);
+  if (rc == FCP_OK && r->buffer) pending_clear_range(r->buffer, r->buffer_bytes);
+  return rc;
+}
+} // namespace
+
 int fcp_process_feature_columns(fcp_plan_t *p, const fcp_process_args_t *a, fcp_process_result_t *r) {
   if (!p || !a) return fail(FCP_ERR_INVALID_ARGUMENT, "null plan / args");
   if (!p->pool || p->lane_count == 0) return fcp_internal_process(p, a, r);
   hipStream_t caller = static_cast<hipStream_t>(a->stream);
   // small requests stay on the caller's stream; so does a capture, which records the caller's stream only (cross-stream
   // events would fork it)
-  if (p->last_work_bytes.load(std::memory_order_relaxed) < p->lane_min_work || stream_is_capturing(caller)) {
-    fcp_process_result_t local{};
-    if (!r) r = &local;
-    const int rc = fcp_internal_process(p, a, r);
-    if (rc == FCP_OK && r->buffer) pending_clear_range(r->buffer, r->buffer_bytes);
-    return rc;
-  }
+  if (p->last_work_bytes.load(std::memory_order_relaxed) < p->lane_min_work || stream_is_capturing(caller)) return process_on_caller(p, a, r);
   DeviceGuard guard;
   int rc = guard.enter(p->desc.device);
   if (rc) return rc;
-  if (!(p->lane_flags & FCP_PRIVATE_NO_VERIFY) && p->lane_good_caller.load(std::memory_order_acquire) != (void *)caller) {
-    bool ok = false;
-    rc = verify_lanes(p, caller, &ok); // first request of this caller: probes (and may re-create) the lanes; later: a lookup
-    if (rc) return rc;
-    if (!ok) {
-      fcp_process_result_t local{};
-      if (!r) r = &local;
-      rc = fcp_internal_process(p, a, r);
-      if (rc == FCP_OK && r->buffer) pending_clear_range(r->buffer, r->buffer_bytes);
-      return rc;
+  if (!(p->lane_flags & FCP_PRIVATE_NO_VERIFY)) {
+    if (p->lane_good_caller.load(std::memory_order_acquire) != (void *)caller) {
+      bool ok = false;
+      // first request of this caller: probes (and may re-create) the lanes within the budget; later: a lookup
+      rc = verify_lanes(p, caller, default_verify_budget_ms(), /*again=*/false, &ok);
+      if (rc) return rc;
+      if (!ok) return process_on_caller(p, a, r);
+    }
+  } else {
+    if (p->lane_demoted.load(std::memory_order_acquire)) { // the supervisor has demoted a caller of this plan: this one?
+      bool mine = false;
+      {
+        std::lock_guard<std::mutex> cal_lock(p->pool->cal_mu);
+        for (auto &v : p->lane_verdicts) mine = mine || (v.first == (void *)caller && !v.second);
+      }
+      if (mine) return process_on_caller(p, a, r);
+    }
+    if (!p->lane_relies.load(std::memory_order_acquire)) {
+      // first unverified use: counted under the pool's mutex, where verify_lanes of another plan reads the count before it
+      // re-creates the lanes
+      std::lock_guard<std::mutex> cal_lock(p->pool->cal_mu);
+      if (!p->lane_relies.exchange(true)) p->pool->n_relying.fetch_add(1, std::memory_order_acq_rel);
     }
   }
-  if (!p->lane_relies.load(std::memory_order_relaxed) && !p->lane_relies.exchange(true)) // (unverified use)
-    p->pool->n_relying.fetch_add(1, std::memory_order_acq_rel);
-  PrivateLane &L = *p->pool->lanes[p->pool->rr.fetch_add(1, std::memory_order_relaxed) % (uint32_t)p->lane_count];
   static const bool lane_stats = std::getenv("FCP_LANE_STATS") != nullptr; // diagnostic: host time of a private-stream request by part
   auto now_ns = [] { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-  const uint64_t s0 = lane_stats ? now_ns() : 0;
-  std::lock_guard<std::mutex> lane_lock(L.mu);
-  const uint32_t e = L.next++ % kLaneEvents;
-  uint64_t s1 = s0, s2 = s0;
-  if (!(p->lane_flags & FCP_PRIVATE_NO_CALLER_WAIT)) {
-    HIP_TRY(hipEventRecord(L.in[e], caller));
-    if (lane_stats) s1 = now_ns();
-    HIP_TRY(hipStreamWaitEvent(L.stream, L.in[e], 0));
-    if (lane_stats) s2 = now_ns();
+  LaneSupervisor &S = p->sup;
+  // -- supervisor: the stream-order baseline (the first lane-eligible requests of the supervised caller stay on its stream,
+  //    between two timing events) -------------------------------------------------------------------------------------------
+  if (S.on) {
+    std::unique_lock<std::mutex> sup_lock(S.mu);
+    if (!S.caller) S.caller = (void *)caller;
+    if (S.caller == (void *)caller && !S.demoted && S.base_issued < kSupBaseline) {
+      rc = sup_events(S);
+      if (rc) return rc;
+      const int i = S.base_issued++;
+      HIP_TRY(hipEventRecord(S.b0[i], caller));
+      const int prc = process_on_caller(p, a, r); // (S.mu held over the call: baseline samples are serial by construction)
+      if (prc) {
+        --S.base_issued;
+        return prc;
+      }
+      S.base_bytes[i] = tl_work_bytes;
+      HIP_TRY(hipEventRecord(S.b1[i], caller));
+      return FCP_OK;
+    }
   }
-  fcp_process_args_t b = *a;
-  b.stream = L.stream;
-  fcp_process_result_t local{};
-  if (!r) r = &local;
-  // the completion event rides on the dispatch packet of the request's last kernel (no marker packet of its own);
-  // a request without a kernel (nothing to compute) records it the plain way
-  static const bool attach = [] {
-    const char *v = std::getenv("FCP_LANE_STOP_EVENT"); // tuning aid: 0 = always record a marker
-    return !v || std::atoi(v) != 0;
-  }();
-  if (attach) fcp_set_stop_event(L.out[e]);
-  static const bool alias_done = [] {
-    const char *v = std::getenv("FCP_LANE_DONE_ALIAS"); // tuning aid: 0 = the slot records an event of its own
-    return !v || std::atoi(v) != 0;
-  }();
-  if (alias_done) {
-    tl_lane_done = L.out[e];
-    tl_lane_done_gen = g_lane_generation.load(std::memory_order_acquire);
+  bool demote = false;
+  {
+    PrivateLane &L = *p->pool->lanes[p->pool->rr.fetch_add(1, std::memory_order_relaxed) % (uint32_t)p->lane_count];
+    const uint64_t s0 = lane_stats ? now_ns() : 0;
+    std::unique_lock<std::mutex> lane_lock(L.mu);
+    if (!L.stream) { // the lanes are being re-created by another plan's verification (this plan uses them unverified)
+      lane_lock.unlock();
+      return process_on_caller(p, a, r);
+    }
+    const uint32_t e = L.next++ % kLaneEvents;
+    // -- supervisor: window bookkeeping in front of the request -----------------------------------------------------------
+    int mark = 0; // 1: this request opens a window (w0 behind it), 2: it closes one (w1 behind it)
+    bool in_window = false;
+    if (S.on) {
+      std::lock_guard<std::mutex> sup_lock(S.mu);
+      if (S.caller == (void *)caller && !S.demoted) {
+        ++S.seq;
+        if (S.state == 2) demote = sup_read_window(S);
+        if (S.state == 0 && S.seq % S.period == 1 && S.base_issued >= kSupBaseline) {
+          if ((rc = sup_events(S))) return rc;
+          S.state = 1;
+          S.w_lane = &L;
+          S.w_count = S.w_busy = 0;
+          S.w_bytes = 0;
+          mark = 1;
+        } else if (S.state == 1) {
+          in_window = true;
+          ++S.w_count;
+          // was this lane still working on its previous request when this one was issued?
+          if (L.next >= 2 && hipEventQuery(L.out[(e + kLaneEvents - 1) % kLaneEvents]) == hipErrorNotReady) ++S.w_busy;
+          if (S.w_count >= kSupWindow && S.w_lane == &L) mark = 2;
+        }
+      }
+    }
+    LaneDep dep{L.in[e], caller, L.stream};
+    uint64_t s1 = s0, s2 = s0;
+    fcp_process_args_t b = *a;
+    b.stream = L.stream;
+    fcp_process_result_t local{};
+    if (!r) r = &local;
+    const int fault = p->pool->fault_us.load(std::memory_order_relaxed);
+    if (fault) {
+      if (hipEvent_t prev = p->pool->last_out.load(std::memory_order_acquire)) HIP_TRY(hipStreamWaitEvent(L.stream, prev, 0));
+      hipLaunchKernelGGL(fcp_spin_kernel, dim3(1), dim3(64), 0, L.stream, 100ull * (unsigned long long)fault);
+    }
+    // the completion event rides on the dispatch packet of the request's last kernel (no marker packet of its own);
+    // a request without a kernel (nothing to compute) records it the plain way
+    static const bool attach = [] {
+      const char *v = std::getenv("FCP_LANE_STOP_EVENT"); // tuning aid: 0 = always record a marker
+      return !v || std::atoi(v) != 0;
+    }();
+    if (attach) fcp_set_stop_event(L.out[e]);
+    static const bool alias_done = [] {
+      const char *v = std::getenv("FCP_LANE_DONE_ALIAS"); // tuning aid: 0 = the slot records an event of its own
+      return !v || std::atoi(v) != 0;
+    }();
+    if (alias_done) {
+      tl_lane_done = L.out[e];
+      tl_lane_done_gen = g_lane_generation.load(std::memory_order_acquire);
+    }
+    // the caller's stream is recorded, and the lane made to wait for it, inside the call: right behind malloc_buff
+    if (!(p->lane_flags & FCP_PRIVATE_NO_CALLER_WAIT)) tl_lane_dep = &dep;
+    rc = fcp_internal_process(p, &b, r);
+    const bool dep_left = tl_lane_dep != nullptr; // (an error before the allocation)
+    tl_lane_dep = nullptr;
+    tl_lane_done = nullptr;
+    const bool pending = fcp_stop_event_pending();
+    fcp_set_stop_event(nullptr);
+    if (rc) return rc;
+    if (dep_left) return fail(FCP_ERR_HIP, "private streams: the request never reached its allocation");
+    const uint64_t s3 = lane_stats ? now_ns() : 0;
+    if (!attach || pending) HIP_TRY(hipEventRecord(L.out[e], L.stream));
+    pending_register(p, r->buffer, r->buffer_bytes, a->concated_inputs, a->concated_bytes, L.out[e]);
+    if (fault) p->pool->last_out.store(L.out[e], std::memory_order_release);
+    if (mark || in_window) {
+      std::lock_guard<std::mutex> sup_lock(S.mu);
+      if (in_window && S.state == 1) S.w_bytes += tl_work_bytes;
+      if (mark == 1 && S.state == 1) HIP_TRY(hipEventRecord(S.w0, L.stream));
+      if (mark == 2 && S.state == 1) {
+        HIP_TRY(hipEventRecord(S.w1, L.stream));
+        S.state = 2;
+      }
+    }
+    if (lane_stats) {
+      static std::atomic<uint64_t> n{0}, a_proc{0}, a_reg{0};
+      const uint64_t s4 = now_ns();
+      (void)s1;
+      (void)s2;
+      a_proc += s3 - s0;
+      a_reg += s4 - s3;
+      if ((++n & 1023) == 0)
+        std::fprintf(stderr, "fcp private-stream request, host us: lane lock + request itself (incl. the record on the caller's stream and the lane's wait) %.2f, completion event + registry %.2f\n",
+                     a_proc.load() / 1e3 / n.load(), a_reg.load() / 1e3 / n.load());
+    }
   }
-  rc = fcp_internal_process(p, &b, r);
-  tl_lane_done = nullptr;
-  const bool pending = fcp_stop_event_pending();
-  fcp_set_stop_event(nullptr);
-  if (rc) return rc;
-  const uint64_t s3 = lane_stats ? now_ns() : 0;
-  if (!attach || pending) HIP_TRY(hipEventRecord(L.out[e], L.stream));
-  pending_register(p, r->buffer, r->buffer_bytes, a->concated_inputs, a->concated_bytes, L.out[e]);
-  if (lane_stats) {
-    static std::atomic<uint64_t> n{0}, a_rec{0}, a_wait{0}, a_proc{0}, a_reg{0};
-    const uint64_t s4 = now_ns();
-    a_rec += s1 - s0;
-    a_wait += s2 - s1;
-    a_proc += s3 - s2;
-    a_reg += s4 - s3;
-    if ((++n & 1023) == 0)
-      std::fprintf(stderr, "fcp private-stream request, host us: record on the caller's stream %.2f, lane waits %.2f, request itself %.2f, completion event + registry %.2f\n",
-                   a_rec.load() / 1e3 / n.load(), a_wait.load() / 1e3 / n.load(), a_proc.load() / 1e3 / n.load(), a_reg.load() / 1e3 / n.load());
-  }
+  if (demote) demote_caller(p, (void *)caller);
   return FCP_OK;
 }
+
+namespace {
+// the pending result whose address range contains x, or nullptr (g_pending_mu held)
+const PendingResult *pending_find(uintptr_t x, uintptr_t *base) {
+  auto it = g_pending.upper_bound(x);
+  if (it == g_pending.begin()) return nullptr;
+  --it;
+  if (x >= it->second.end) return nullptr;
+  if (base) *base = it->first;
+  return &it->second;
+}
+} // namespace
 
 // The consumer's half: `stream` waits (on the device; the host does not block) for the request whose arena contains
 // `buffer`.  Nothing pending for that address — no private streams, or the request has long completed — is FCP_OK.
 int fcp_result_wait(const void *buffer, void *stream) {
   if (!buffer) return fail(FCP_ERR_INVALID_ARGUMENT, "null buffer");
-  const uintptr_t x = reinterpret_cast<uintptr_t>(buffer);
-  std::lock_guard<std::mutex> lock(g_pending_mu); // (held over the runtime call: the owning plan may not go away meanwhile)
-  auto it = g_pending.upper_bound(x);
-  if (it == g_pending.begin()) return FCP_OK;
-  --it;
-  if (x >= it->second.end) return FCP_OK;
-  HIP_TRY(hipStreamWaitEvent(static_cast<hipStream_t>(stream), it->second.done, 0));
+  std::lock_guard<std::mutex> lock(g_pending_mu); // (held over the runtime call: the entry may not be replaced meanwhile)
+  if (const PendingResult *pr = pending_find(reinterpret_cast<uintptr_t>(buffer), nullptr))
+    HIP_TRY(hipStreamWaitEvent(static_cast<hipStream_t>(stream), pr->done, 0));
   return FCP_OK;
 }
 
-// The same for a HOST reader: returns when the request whose arena contains `buffer` has completed.
+// The same for a HOST reader: returns when the request whose arena contains `buffer` has completed.  The registry's mutex
+// is NOT held while the host waits (every other thread's request, wait or stager call would block for a kernel's duration,
+// ADVICE r04): lane events live as long as the process (destroy_lanes), so the handle stays valid outside the lock; an event
+// re-recorded meanwhile belongs to a LATER request of the same lane, whose completion implies this one's.
 int fcp_result_synchronize(const void *buffer) {
   if (!buffer) return fail(FCP_ERR_INVALID_ARGUMENT, "null buffer");
-  const uintptr_t x = reinterpret_cast<uintptr_t>(buffer);
   hipEvent_t ev = nullptr;
   {
     std::lock_guard<std::mutex> lock(g_pending_mu);
-    auto it = g_pending.upper_bound(x);
-    if (it == g_pending.begin()) return FCP_OK;
-    --it;
-    if (x >= it->second.end) return FCP_OK;
-    ev = it->second.done;
-    HIP_TRY(hipEventSynchronize(ev));
+    const PendingResult *pr = pending_find(reinterpret_cast<uintptr_t>(buffer), nullptr);
+    if (!pr || hipEventQuery(pr->done) == hipSuccess) return FCP_OK;
+    ev = pr->done;
+  }
+  HIP_TRY(hipEventSynchronize(ev));
+  return FCP_OK;
+}
+
+namespace {
+// ConcatOutputs reads columns of FeatureColumnProcess arenas — normally ONE arena (output_ptrs of one op), possibly several
+// (per-column inputs that come from two ops; callers of the scatter variants): `stream` waits for every distinct pending
+// result that contains an input.  One map lookup per arena, a range comparison per input; nothing pending: one lock.
+int wait_for_inputs(const void *const *inputs, int32_t n, void *stream) {
+  std::lock_guard<std::mutex> lock(g_pending_mu);
+  if (g_pending.empty()) return FCP_OK;
+  uintptr_t lo = 1, hi = 0; // the range found (or known to hold nothing) last
+  for (int32_t k = 0; k < n; ++k) {
+    const uintptr_t x = reinterpret_cast<uintptr_t>(inputs[k]);
+    if (!x || (x >= lo && x < hi)) continue;
+    uintptr_t base = 0;
+    if (const PendingResult *pr = pending_find(x, &base)) {
+      HIP_TRY(hipStreamWaitEvent(static_cast<hipStream_t>(stream), pr->done, 0));
+      lo = base;
+      hi = pr->end;
+    }
   }
   return FCP_OK;
 }
+} // namespace
 
 // ---- ConcatOutputs ----------------------------------------------------------------
 int fcp_concat_outputs(const void *const *inputs, const int32_t *dims, int32_t n, int64_t prefix_size,
@@ -2432,9 +2791,9 @@ int fcp_concat_outputs(const void *const *inputs, const int32_t *dims, int32_t n
     width += dims[k];
   }
   if (width > 0x7fffffff) return fail(FCP_ERR_UNSUPPORTED, "concat width exceeds 2^31");
-  // per-column layout: the inputs are columns of ONE FeatureColumnProcess arena (output_ptrs); with private streams the
-  // kernel that fills it runs elsewhere
-  if (int rc = fcp_result_wait(inputs[0], stream)) return rc;
+  // per-column layout: the inputs are columns of FeatureColumnProcess arenas (output_ptrs); with private streams the
+  // kernels that fill them run elsewhere
+  if (int rc = wait_for_inputs(inputs, n, stream)) return rc;
   const int e = fcp_launch_concat_outputs(inputs, dims, nullptr, nullptr, n, prefix_size, (int32_t)width, 0, out,
                                           static_cast<hipStream_t>(stream));
   if (e) return hip_fail("concat-outputs launch", (hipError_t)e);
@@ -2488,6 +2847,9 @@ int fcp_concat_outputs_scatter_strided(const void *const *inputs, const int32_t 
   if (in_strides)
     for (int32_t k = 0; k < n; ++k)
       if (in_strides[k] < dims[k]) return fail(FCP_ERR_INVALID_ARGUMENT, "input row stride smaller than its width");
+  // inputs (and an `out` that lies in an arena with external slots) may be results of private-stream requests
+  if ((rc = wait_for_inputs(inputs, n, stream))) return rc;
+  if ((rc = wait_for_inputs(&out, 1, stream))) return rc;
   const int e = fcp_launch_concat_outputs(inputs, dims, col_offsets, in_strides, n, prefix_size, out_width, 0, out,
                                           static_cast<hipStream_t>(stream));
   if (e) return hip_fail("concat-outputs launch", (hipError_t)e);

@@ -10,6 +10,14 @@
 // The arena allocator plays the role of TF's allocator: a ring of pre-allocated
 // arenas, sized so that consecutive requests never write the same bytes while
 // they could still sit in the 256 MiB Infinity Cache.
+// Under FCP_ORDER_INPUTS_READY (kernels launched without the queue's barrier bit) nothing orders request k + ring against
+// request k, which wrote the same arena: the harness relies on the queue processing its packets in order — a kernel's
+// workgroups are dispatched only after every workgroup of the packets in front of it has been dispatched — so request
+// k + 6 cannot begin before requests k .. k + 5 are all at least in their tails; a straggling wave of request k would have
+// to outlive five whole requests.  The harness reads no result of such a run (verify_resident runs in stream order).  A
+// caller that consumes results must not copy this: it gives every in-flight request an arena nothing else writes
+// (the promise FCP_ORDER_INPUTS_READY states in fcp_hip.h), e.g. by waiting for request k's completion event before it
+// hands arena k out again.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -208,14 +216,19 @@ __global__ void fcp_consume_probe_kernel(const float *arena, size_t n_floats, fl
   if (acc == 12345.678f) *sink = acc;
 }
 
-int fcp_harness_run_private(fcp_harness *h, int steps, int depth, double *wall_ms, float *dev_ms) {
-  if (!h || steps < 1 || depth < 1 || depth > (int)h->rings[0].bufs.size()) return FCP_ERR_INVALID_ARGUMENT;
+// `threads` host threads (1 = the loop described above) issue `steps` requests EACH on the one caller stream — the
+// reference's serving protocol: serve_workers threads share ONE Session, hence one compute stream
+// (examples/cc/recom_examples.patch:193-216).  Every thread keeps `depth` of its own requests in flight (its own arena ring)
+// and enqueues their consumers on the caller's stream; the host time of a request (event record, lane wait, launch,
+// registry, consumer) is split between the threads.  With the plan's private streams OFF the same loop is "stream order +
+// the same consumer": the figure a private-stream number has to beat.
+int fcp_harness_run_private_threads(fcp_harness *h, int steps, int depth, int threads, double *wall_ms, float *dev_ms) {
+  if (!h || steps < 1 || depth < 1 || threads < 1 || threads > (int)h->rings.size() || depth > (int)h->rings[0].bufs.size())
+    return FCP_ERR_INVALID_ARGUMENT;
   hipStream_t caller = h->streams[0];
   static float *sink = nullptr;
   if (!sink) H_TRY(hipMalloc(&sink, sizeof(float)));
   const int nv = (int)h->variants.size();
-  std::vector<std::pair<void *, int64_t>> pending; // results not consumed yet, oldest first
-  size_t head = 0;
   static const bool reader = [] { // tuning aid: FCP_HARNESS_NO_READER=1 leaves the wait alone on the caller's stream
     const char *v = std::getenv("FCP_HARNESS_NO_READER");
     return !(v && std::atoi(v) != 0);
@@ -224,49 +237,61 @@ int fcp_harness_run_private(fcp_harness *h, int steps, int depth, double *wall_m
     const char *v = std::getenv("FCP_HARNESS_NO_WAIT");
     return v && std::atoi(v) != 0;
   }();
+  static const bool stats = std::getenv("FCP_HARNESS_STATS") != nullptr; // diagnostic: host time inside the two calls
   auto consume = [&](const std::pair<void *, int64_t> &res) -> int {
-    if (no_wait) return fcp_result_synchronize(nullptr) == FCP_OK ? FCP_OK : FCP_OK;
+    if (no_wait) return FCP_OK;
     int rc = fcp_result_wait(res.first, caller);
     if (rc || !reader) return rc;
     hipLaunchKernelGGL(fcp_consume_probe_kernel, dim3(1), dim3(256), 0, caller, static_cast<const float *>(res.first),
                        (size_t)(res.second / 4), sink);
     return FCP_OK;
   };
-  static const bool stats = std::getenv("FCP_HARNESS_STATS") != nullptr; // diagnostic: host time inside the two calls
-  double ns_process = 0, ns_consume = 0;
-  auto now = [] { return std::chrono::steady_clock::now(); };
   const long begin = h->issued;
-  const auto t0 = std::chrono::steady_clock::now();
-  H_TRY(hipEventRecord(h->e0, caller));
-  for (long k = begin; k < begin + steps; ++k) {
-    fcp_process_args_t a = h->variants[(size_t)(k % nv)];
-    a.stream = caller;
-    a.malloc_buff = ring_alloc;
-    a.malloc_buff_ctx = &h->rings[0];
-    a.malloc_temp = nullptr;
-    a.malloc_temp_ctx = nullptr;
-    fcp_process_result_t res{};
-    const auto p0 = stats ? now() : t0;
-    int rc = fcp_process_feature_columns(h->plan, &a, &res);
-    if (rc) return rc;
-    const auto p1 = stats ? now() : t0;
-    pending.emplace_back(res.buffer, res.buffer_bytes);
-    if ((int)(pending.size() - head) >= depth) {
-      rc = consume(pending[head++]);
+  auto serve = [&](int t) -> int {
+    std::vector<std::pair<void *, int64_t>> pending; // results not consumed yet, oldest first
+    size_t head = 0;
+    double ns_process = 0, ns_consume = 0;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    for (long k = begin; k < begin + steps; ++k) {
+      fcp_process_args_t a = h->variants[(size_t)((k * threads + t) % nv)];
+      a.stream = caller;
+      a.malloc_buff = ring_alloc;
+      a.malloc_buff_ctx = &h->rings[t];
+      a.malloc_temp = nullptr;
+      a.malloc_temp_ctx = nullptr;
+      fcp_process_result_t res{};
+      const auto p0 = now();
+      int rc = fcp_process_feature_columns(h->plan, &a, &res);
+      if (rc) return rc;
+      const auto p1 = now();
+      pending.emplace_back(res.buffer, res.buffer_bytes);
+      if ((int)(pending.size() - head) >= depth) {
+        rc = consume(pending[head++]);
+        if (rc) return rc;
+      }
+      if (stats) {
+        ns_process += std::chrono::duration<double, std::nano>(p1 - p0).count();
+        ns_consume += std::chrono::duration<double, std::nano>(now() - p1).count();
+      }
+    }
+    if (stats)
+      std::fprintf(stderr, "fcp_harness_run_private: thread %d of %d, depth %d, host time per request: process call %.2f us, consumer (wait + reader) %.2f us\n",
+                   t, threads, depth, ns_process / steps / 1e3, ns_consume / steps / 1e3);
+    while (head < pending.size()) {
+      const int rc = consume(pending[head++]);
       if (rc) return rc;
     }
-    if (stats) {
-      ns_process += std::chrono::duration<double, std::nano>(p1 - p0).count();
-      ns_consume += std::chrono::duration<double, std::nano>(now() - p1).count();
-    }
-  }
-  if (stats)
-    std::fprintf(stderr, "fcp_harness_run_private: depth %d, host time per request: process call %.2f us, consumer (wait + reader) %.2f us\n",
-                 depth, ns_process / steps / 1e3, ns_consume / steps / 1e3);
-  while (head < pending.size()) {
-    const int rc = consume(pending[head++]);
+    return FCP_OK;
+  };
+  const auto t0 = std::chrono::steady_clock::now();
+  H_TRY(hipEventRecord(h->e0, caller));
+  std::vector<int> rcs((size_t)threads, FCP_OK);
+  std::vector<std::thread> workers;
+  for (int t = 1; t < threads; ++t) workers.emplace_back([&, t] { rcs[(size_t)t] = serve(t); });
+  rcs[0] = serve(0);
+  for (auto &w : workers) w.join();
+  for (int rc : rcs)
     if (rc) return rc;
-  }
   if (no_wait) H_TRY(hipDeviceSynchronize());
   H_TRY(hipEventRecord(h->e1, caller));
   H_TRY(hipStreamSynchronize(caller));
@@ -275,6 +300,10 @@ int fcp_harness_run_private(fcp_harness *h, int steps, int depth, double *wall_m
   if (wall_ms) *wall_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
   if (dev_ms) H_TRY(hipEventElapsedTime(dev_ms, h->e0, h->e1));
   return FCP_OK;
+}
+
+int fcp_harness_run_private(fcp_harness *h, int steps, int depth, double *wall_ms, float *dev_ms) {
+  return fcp_harness_run_private_threads(h, steps, depth, 1, wall_ms, dev_ms);
 }
 
 // worker `t`'s stream (what fcp_harness_run_private issues on is worker 0's): for probes that need the caller's stream

@@ -44,6 +44,8 @@ def load() -> C.CDLL:
             H.fcp_harness_stream.restype = C.c_void_p
         if hasattr(H, "fcp_harness_run_private"):
             H.fcp_harness_run_private.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_float)]
+        if hasattr(H, "fcp_harness_run_private_threads"):
+            H.fcp_harness_run_private_threads.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_float)]
         H.fcp_harness_copy_probe.argtypes = [C.c_size_t, C.c_int, C.POINTER(C.c_float)]
         H.fcp_harness_gather_probe.argtypes = [C.c_size_t, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float),
                                                C.POINTER(C.c_double)]
@@ -104,13 +106,16 @@ class ServingHarness:
         """The HIP stream worker ``worker`` issues on (``run_private``: worker 0's is the caller's stream)."""
         return int(self.H.fcp_harness_stream(self.handle, worker) or 0)
 
-    def run_private(self, steps: int, depth: int = 3):
-        """One host thread and ONE caller stream over a plan with private streams (``self.plan.set_private_streams``
-        first): request k's consumer — ``fcp_result_wait`` + a reader kernel on the caller's stream — is enqueued
-        ``depth - 1`` requests behind it.  Returns (wall_ms, dev_ms)."""
+    def run_private(self, steps: int, depth: int = 3, threads: int = 1):
+        """``threads`` host threads and ONE caller stream (the reference's serve workers share one Session, hence one
+        compute stream) over a plan with private streams (``self.plan.set_private_streams`` first) — or without, which
+        is "stream order + the same consumer": every thread issues ``steps`` requests, request k's consumer —
+        ``fcp_result_wait`` + a reader kernel on the caller's stream — is enqueued ``depth - 1`` of that thread's requests
+        behind it.  The harness needs ``n_threads >= threads`` (an arena ring per thread).  Returns (wall_ms, dev_ms) over
+        all ``threads * steps`` requests."""
         wall, dev = C.c_double(), C.c_float()
-        _lib.check(self.H.fcp_harness_run_private(self.handle, steps, depth, C.byref(wall), C.byref(dev)),
-                   "fcp_harness_run_private")
+        _lib.check(self.H.fcp_harness_run_private_threads(self.handle, steps, depth, threads, C.byref(wall), C.byref(dev)),
+                   "fcp_harness_run_private_threads")
         return wall.value, dev.value
 
     def run_graph(self, steps: int, group: int):

@@ -96,6 +96,13 @@ class Placement(C.Structure):
     _fields_ = [("mode", C.c_int32), ("min_world", C.c_int32), ("bytes_per_gpu", C.c_int64)]
 
 
+class PrivateStreamsStats(C.Structure):
+    """fcp_private_streams_stats_t"""
+    _fields_ = [("supervised_stream", C.c_void_p), ("lane_requests", C.c_int64), ("windows", C.c_int64),
+                ("windows_counted", C.c_int64), ("baseline_us_per_mib", C.c_double), ("last_ratio", C.c_double),
+                ("worst_ratio", C.c_double), ("demote_ratio", C.c_double), ("demoted", C.c_int32), ("baseline_samples", C.c_int32)]
+
+
 class HostTensor(C.Structure):
     _fields_ = [("data", C.c_void_p), ("elem_size", C.c_int32), ("rank", C.c_int32),
                 ("dims", C.POINTER(C.c_int64))]
@@ -118,7 +125,8 @@ EXPORTS = [
     "fcp_pack_pool_create", "fcp_pack_pool_destroy", "fcp_concat_inputs_ex_pool",
     "fcp_graph_build", "fcp_graph_free", "fcp_placement_assign", "fcp_concat_outputs_scatter_strided",
     "fcp_plan_set_private_streams", "fcp_result_wait", "fcp_result_synchronize", "fcp_plan_set_request_order",
-    "fcp_plan_probe_private_streams", "fcp_plan_private_streams_verdict",
+    "fcp_plan_probe_private_streams", "fcp_plan_private_streams_verdict", "fcp_plan_verify_private_streams",
+    "fcp_plan_private_streams_stats",
 ]
 
 _lib = None
@@ -247,9 +255,13 @@ def load() -> C.CDLL:
         L.fcp_plan_set_private_streams.argtypes = [C.c_void_p, C.c_int32, C.c_uint32]
         L.fcp_result_wait.argtypes = [C.c_void_p, C.c_void_p]
         L.fcp_result_synchronize.argtypes = [C.c_void_p]
-    L.fcp_plan_probe_private_streams.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
-                                                 C.POINTER(C.c_double), C.POINTER(C.c_double)]
-    L.fcp_plan_private_streams_verdict.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]
+    if hasattr(L, "fcp_plan_probe_private_streams"):
+        L.fcp_plan_probe_private_streams.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                                     C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.fcp_plan_private_streams_verdict.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]
+    if hasattr(L, "fcp_plan_verify_private_streams"):
+        L.fcp_plan_verify_private_streams.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
+        L.fcp_plan_private_streams_stats.argtypes = [C.c_void_p, C.POINTER(PrivateStreamsStats)]
     if hasattr(L, "fcp_plan_set_request_order"):
         L.fcp_plan_set_request_order.argtypes = [C.c_void_p, C.c_int32]
     if L.fcp_abi_version() != FCP_ABI_VERSION:

@@ -249,6 +249,20 @@ class Plan:
         _lib.check(self._L.fcp_plan_private_streams_verdict(self.handle, C.c_void_p(stream), C.byref(v)), "fcp_plan_private_streams_verdict")
         return int(v.value)
 
+    def verify_private_streams(self, stream: int, budget_ms: int = 0) -> int:
+        """``fcp_plan_verify_private_streams``: the verification at warm-up (searches a hardware-queue mapping that overlaps
+        behind ``stream`` for at most ``budget_ms``; forgets an earlier negative verdict or a demotion).  Returns the verdict."""
+        v = C.c_int32(-1)
+        _lib.check(self._L.fcp_plan_verify_private_streams(self.handle, C.c_void_p(stream), int(budget_ms), C.byref(v)),
+                   "fcp_plan_verify_private_streams")
+        return int(v.value)
+
+    def private_streams_stats(self) -> dict:
+        """``fcp_plan_private_streams_stats``: what the run-time supervisor of the private streams has seen."""
+        st = _lib.PrivateStreamsStats()
+        _lib.check(self._L.fcp_plan_private_streams_stats(self.handle, C.byref(st)), "fcp_plan_private_streams_stats")
+        return {k: getattr(st, k) for k, _ in st._fields_}
+
     def set_inputs_ready(self, on: bool = True) -> None:
         """``fcp_plan_set_request_order(FCP_ORDER_INPUTS_READY)``: the caller's promise that blobs are complete and arenas
         unused when a request is issued; consecutive requests of one stream then overlap (any-order kernel launch)."""

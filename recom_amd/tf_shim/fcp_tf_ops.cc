@@ -19,6 +19,7 @@
 //     $(python -c 'import tensorflow as tf; print(" ".join(tf.sysconfig.get_compile_flags()+tf.sysconfig.get_link_flags()))')
 //     -I../../include -L.. -lfcp_hip -Wl,-rpath,'$ORIGIN/..' -DTENSORFLOW_USE_ROCM=1
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <numeric>
 #include <string>
@@ -174,6 +175,7 @@ public:
     if (const char *e = std::getenv("FCP_PRIVATE_STREAMS")) {
       const int n = std::atoi(e);
       if (n > 0) OP_REQUIRES_OK(c, FcpStatus(fcp_plan_set_private_streams(plan_, n, 0), "fcp_plan_set_private_streams"));
+      private_streams_ = n > 0;
     }
   }
   ~FeatureColumnProcessOp() override { fcp_plan_destroy(plan_); } // the reference frees const_buff here
@@ -222,6 +224,15 @@ public:
     r.output_ptrs = out_ptrs.data();
     r.output_shapes = out_shapes.data();
     OP_REQUIRES_OK(c, FcpStatus(fcp_process_feature_columns(plan_, &a, &r), "FeatureColumnProcess"));
+    // The first Compute is the deployment's warm-up request (the reference requires one: docs/build_from_source.md:42): with
+    // private streams on, the search for a hardware-queue mapping that overlaps behind this compute stream runs HERE, once,
+    // within FCP_PRIVATE_VERIFY_WARMUP_MS (default 400) — no serving request pays for it later; the run-time supervisor
+    // keeps watching the verdict from then on.
+    if (private_streams_ && !warmup_verified_.exchange(true)) {
+      const char *e = std::getenv("FCP_PRIVATE_VERIFY_WARMUP_MS");
+      OP_REQUIRES_OK(c, FcpStatus(fcp_plan_verify_private_streams(plan_, a.stream, e ? std::atoi(e) : 400, nullptr),
+                                  "fcp_plan_verify_private_streams"));
+    }
     auto shapes = shapes_t->flat<int32>();
     for (int i = 0; i < n_out; ++i) {
       shapes(2 * i) = out_shapes[2 * out_cols_[i]];
@@ -241,6 +252,8 @@ private:
   std::vector<int32_t> out_cols_; // plan column of every op output
   int32_t n_columns_ = 0;
   fcp_plan_t *plan_ = nullptr;
+  bool private_streams_ = false;
+  std::atomic<bool> warmup_verified_{false};
 };
 
 // ---- Addons>ConcatOutputs[NoHost] (GPU) ----------------------------------------------------------

@@ -114,6 +114,14 @@ int main(void) {
     CHECK(fcp_plan_set_private_streams(plan, 3, 1u << 9) == FCP_ERR_INVALID_ARGUMENT);
     CHECK(fcp_plan_probe_private_streams(plan, NULL, 24, 80, 1, &serial_us, &lanes_us) == FCP_ERR_NO_DEVICE);
     CHECK(fcp_plan_private_streams_verdict(plan, NULL, &verdict) == FCP_OK && verdict == -1);
+    { /* round 5: verification at warm-up, the supervisor's record */
+      fcp_private_streams_stats_t st;
+      verdict = 7;
+      CHECK(fcp_plan_verify_private_streams(plan, NULL, 50, &verdict) == FCP_ERR_NO_DEVICE && verdict == -1);
+      CHECK(fcp_plan_verify_private_streams(NULL, NULL, 50, NULL) == FCP_ERR_INVALID_ARGUMENT);
+      CHECK(fcp_plan_private_streams_stats(plan, &st) == FCP_OK && st.lane_requests == 0 && st.demoted == 0 && st.supervised_stream == NULL);
+      CHECK(fcp_plan_private_streams_stats(plan, NULL) == FCP_ERR_INVALID_ARGUMENT);
+    }
     CHECK(fcp_plan_set_request_order(plan, FCP_ORDER_INPUTS_READY) == FCP_OK);
     CHECK(fcp_plan_set_request_order(plan, 9) == FCP_ERR_INVALID_ARGUMENT);
     CHECK(fcp_result_wait(NULL, NULL) == FCP_ERR_INVALID_ARGUMENT);

@@ -525,3 +525,154 @@ def test_per_column_layout_concat_outputs_waits_for_the_private_stream(torch_cud
         s.synchronize()
         want, _ = oracle.process_feature_columns(m.spec.to_dict(), blob, offsets, shapes, tabs_np, r.symbols)
         assert np.array_equal(cat.cpu().numpy(), want[0])
+
+
+def test_lane_waits_for_caller_stream_work_queued_up_to_the_allocation(torch_cuda, oracle, monkeypatch):
+    """TF's allocator hands out memory in compute-stream order, and between a request's entry and its
+    malloc_buff another Session::Run thread may queue a kernel K that still READS the memory the arena then gets.  Here the
+    allocator itself plays that thread: inside malloc_buff it queues — on the caller's stream — a long sleep and then K
+    (a copy of the block's old content), and returns the block.  The private stream must wait for K: the event it waits
+    for is recorded on the caller's stream AFTER the allocation.  (Recorded before it, the lane writes the block while K is
+    still waiting behind the sleep, and K copies the new result instead of the old content.)"""
+    from recom_amd import lib, synth
+    from recom_amd.ops import FeatureColumnProcess, concat_inputs
+    torch = torch_cuda
+    monkeypatch.setenv("FCP_LANE_SUPERVISE", "0")                       # (its baseline would keep the first requests on the caller's stream)
+    m = synth.model_mixed(batch=160, vocab=2999, n_groups=1)
+    tabs_np = m.numpy_tables()
+    tabs = [torch.from_numpy(t).cuda() for t in tabs_np]
+    op = FeatureColumnProcess(m.spec, 0)
+    op.plan.set_private_streams(3, always=True, verify=False)           # the lanes as they are: every request takes one
+    caller = torch.cuda.Stream()
+    for seed in range(3):
+        r = m.make_request(900 + seed, B=150 + seed)
+        blob, offsets, shapes = concat_inputs(r.inputs)
+        d_blob = torch.from_numpy(blob).cuda()
+        nbytes = op.plan.arena_bytes(shapes, r.symbols)
+        block = torch.full((max(nbytes, 128) + 256,), 0x5A, dtype=torch.uint8, device="cuda")     # "tensor X", still in use
+        seen_by_k = torch.zeros_like(block)
+        torch.cuda.synchronize()
+        state = {"arena": None, "temps": [], "calls": 0}
+
+        def _alloc(_ctx, n, state=state, block=block, seen_by_k=seen_by_k):
+            state["calls"] += 1
+            assert n <= block.numel()
+            with torch.cuda.stream(caller):                             # the other thread's kernel K, queued just before X is "freed"
+                _busy(torch, caller, 3.0)
+                seen_by_k.copy_(block)
+            state["arena"] = block                                       # ... and the allocator hands X out as the arena
+            return block.data_ptr()
+
+        def _alloc_temp(_ctx, n, state=state):
+            t = torch.empty(int(n), dtype=torch.uint8, device="cuda")
+            state["temps"].append(t)
+            return t.data_ptr()
+
+        monkeypatch.setattr(op, "_allocators", lambda: (state, lib.ALLOC_FN(_alloc), lib.ALLOC_FN(_alloc_temp)))
+        with torch.cuda.stream(caller):
+            out = op(d_blob, offsets, shapes, tabs, r.symbols, defer_wait=True)
+            out.wait()
+            got = out.groups[0].clone()
+        caller.synchronize()
+        assert state["calls"] == 1
+        assert bool((seen_by_k == 0x5A).all()), "the private stream wrote the arena while a kernel queued before the allocation still read it"
+        want, _ = oracle.process_feature_columns(m.spec.to_dict(), blob, offsets, shapes, tabs_np, r.symbols)
+        assert np.array_equal(got.cpu().numpy(), want[0])
+    torch.cuda.synchronize()
+
+
+def test_supervisor_demotes_a_caller_whose_private_streams_stop_overlapping(torch_cuda, oracle, monkeypatch, capfd):
+    """a verdict is learnt once, the hardware-queue mapping can go bad later.  FCP_LANE_FAULT_US makes the
+    lanes behave like a mapping that does not overlap (every lane request waits for the device's previous lane request and
+    stalls 60 us: requests serialise at several times their stream-order cost), the lanes are used unverified
+    (FCP_PRIVATE_NO_VERIFY) and the native loop keeps them busy: the supervisor — baseline on the caller's stream, timed
+    windows of 48 lane requests — must demote the caller within 1000 requests, log it once, and every result before, at and
+    after the demotion stays bit-exact.  With the fault gone and the mode set again the supervisor starts over."""
+    from recom_amd import synth
+    from recom_amd.harness import ServingHarness
+    from recom_amd.ops import FeatureColumnProcess
+    torch = torch_cuda
+    monkeypatch.setenv("FCP_LANE_FAULT_US", "60")
+    monkeypatch.setenv("FCP_LANE_SUPERVISE_PERIOD", "128")
+    model = synth.model_s2(columns=96, vocab=5000, batch=512)
+    h = ServingHarness(model, device=0, n_requests=8, arena_ring=6, n_threads=1)
+    tabs_np = model.numpy_tables()
+    op = FeatureColumnProcess(model.spec, 0, plan=h.plan)
+    caller = h.caller_stream()
+    ext = torch.cuda.ExternalStream(caller)
+
+    def check_one(k):
+        blob, offsets, shapes = h.packed[k]
+        with torch.cuda.stream(ext):
+            out = op(h._keep[1 + 4 * k], offsets, shapes, h.tables, h.requests[k].symbols)
+            got = out.groups[0].clone()
+        ext.synchronize()
+        want, _ = oracle.process_feature_columns(model.spec.to_dict(), blob, offsets, shapes, tabs_np, h.requests[k].symbols)
+        assert np.array_equal(got.cpu().numpy(), want[0])
+
+    h.plan.set_private_streams(3, always=True, verify=False)
+    capfd.readouterr()
+    issued, demoted_at = 0, None
+    for chunk in range(10):
+        h.run_private(100, 3)
+        issued += 100
+        check_one(chunk % 8)
+        issued += 1
+        st = h.plan.private_streams_stats()
+        if st["demoted"] and demoted_at is None:
+            demoted_at = issued
+    st = h.plan.private_streams_stats()
+    assert st["baseline_samples"] == 4 and st["baseline_us_per_mib"] > 0
+    assert st["demoted"] == 1 and demoted_at is not None and demoted_at <= 1000, st
+    assert st["windows_counted"] >= 2 and st["worst_ratio"] > st["demote_ratio"], st
+    assert st["lane_requests"] < 1000, st                               # requests after the demotion no longer take a lane
+    assert h.plan.private_streams_verdict(caller) == 0
+    err = capfd.readouterr().err
+    assert err.count("DEMOTED") == 1, err
+    # the fault gone, the mode set again: the supervisor starts over (what it then decides about THIS box's real mapping is
+    # its business — a mapping that does not overlap is demoted rightly; results stay exact either way)
+    monkeypatch.delenv("FCP_LANE_FAULT_US")
+    h.plan.set_private_streams(3, always=True, verify=False)
+    st2 = h.plan.private_streams_stats()
+    assert (st2["demoted"], st2["lane_requests"], st2["windows"], st2["baseline_samples"]) == (0, 0, 0, 0), st2
+    assert h.plan.private_streams_verdict(caller) == -1
+    for chunk in range(4):
+        h.run_private(100, 3)
+        check_one(chunk % 8)
+    st2 = h.plan.private_streams_stats()
+    assert st2["baseline_samples"] == 4 and st2["lane_requests"] > 0, st2
+    print("supervisor without the fault:", st2)
+    torch.cuda.synchronize()
+    h.close()
+
+
+def test_verification_at_warm_up_and_its_wall_time_budget(torch_cuda, monkeypatch):
+    """fcp_plan_verify_private_streams runs the search at a time of the caller's choosing (the shim: its
+    first Compute), bounded by wall time; a request after it only looks the verdict up.  Below the work threshold nothing is
+    probed at all."""
+    import time
+    from recom_amd import synth
+    from recom_amd.harness import ServingHarness
+    torch = torch_cuda
+    model = synth.model_s2(columns=96, vocab=5000, batch=512)
+    h = ServingHarness(model, device=0, n_requests=4, arena_ring=6, n_threads=1)
+    caller = h.caller_stream()
+    h.run(4)                                                            # the warm-up request: the plan has seen its shapes
+    h.plan.set_private_streams(3)                                       # default threshold 48 MiB: this model is far below
+    t0 = time.perf_counter()
+    assert h.plan.verify_private_streams(caller, 300) == -1             # nothing to verify: requests stay on the caller's stream
+    assert time.perf_counter() - t0 < 0.05
+    h.plan.set_private_streams(3, always=True)
+    t0 = time.perf_counter()
+    v = h.plan.verify_private_streams(caller, 60)                       # 60 ms of search at most (+ the probe in flight)
+    took = time.perf_counter() - t0
+    assert v in (0, 1) and took < 0.060 + 0.060, (v, took)
+    assert h.plan.private_streams_verdict(caller) == v
+    t0 = time.perf_counter()
+    h.run_private(50, 3)                                                # requests after it: no probe, whatever the verdict
+    assert time.perf_counter() - t0 < 0.05
+    if v == 0:                                                          # a negative verdict is forgotten and searched again on request
+        v2 = h.plan.verify_private_streams(caller, 400)
+        assert v2 in (0, 1) and h.plan.private_streams_verdict(caller) == v2
+    torch.cuda.synchronize()
+    h.close()
