@@ -87,16 +87,20 @@ def pcie_inclusive():
     import subprocess
     exe = os.path.join(os.environ.get("FCP_LIB_DIR", os.path.join(ROOT, "recom_amd")), "fcp_bench")
     out = {"what": "host int64 id tensors -> fcp_stager_stage_narrow (pinned ring, ids packed as int32) -> fused kernel, host clock, "
-                   "`recom_amd/fcp_bench --h2d 1 --narrow 1 [--zero-copy 1]`; h2d_copy: one hipMemcpyAsync on the stager's stream; "
-                   "zero_copy: the kernel reads the pinned ring over PCIe itself (FCP_STAGER_ZERO_COPY)"}
-    for key, extra in (("h2d_copy", []), ("zero_copy", ["--zero-copy", "1"])):
+                   "`recom_amd/fcp_bench --h2d 1 --narrow 1 [--copy-kernel 0 | --zero-copy 1]`; h2d_copy: the stager's default since "
+                   "round 5 - a copy KERNEL on the stager's stream reads the pinned ring (no SDMA engine: hipMemcpyAsync's submission "
+                   "stalls for 6-14 ms a few times per thousand calls, profiles/r05_pcie_staging_stalls.txt), a lone request packed and "
+                   "shipped in 4 groups; h2d_copy_sdma: hipMemcpyAsync as in rounds 2-4; zero_copy: the fused kernel reads the pinned ring "
+                   "over PCIe itself (FCP_STAGER_ZERO_COPY); copy_calls_over_1ms / max_copy_call_us: stalls of the copy CALL on the host"}
+    for key, extra in (("h2d_copy", []), ("h2d_copy_sdma", ["--copy-kernel", "0"]), ("zero_copy", ["--zero-copy", "1"])):
         cmd = [exe, "--h2d", "1", "--narrow", "1", "--steps", "300", "--warmup", "50", "--verify", "0", "--pack-threads", "16"] + extra
         try:
             res = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
             line = [ln for ln in res.stdout.splitlines() if ln.startswith("{") and "pcie_inclusive" in ln][-1]
             r = json.loads(line)
             out[key] = {k: r[k] for k in ("pack_threads", "blob_MB", "us_per_request_pipelined", "us_latency_single", "inferences_per_s",
-                                          "host_us_stage_call", "host_us_process_call", "h2d_copy_alone_us", "h2d_GBs") if k in r}
+                                          "host_us_stage_call", "host_us_process_call", "h2d_copy_alone_us", "h2d_GBs", "copy_calls",
+                                          "copy_calls_over_1ms", "max_copy_call_us", "zero_copy_fallback_switches") if k in r}
         except Exception as e:  # the bench line must not depend on this extra
             out[key] = {"error": f"{type(e).__name__}: {e}"[:300]}
     return out

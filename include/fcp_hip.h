@@ -638,9 +638,19 @@ int fcp_concat_outputs_host(const void *const *host_inputs, const int32_t *dims,
  * the copying form swings between 63 and 150 us with the host's load; lone-request
  * latency 100-117 vs 121-137 us), at the price of a kernel that holds its CUs for the
  * duration of the transfer.  A slot is repacked only after the work that read it has
- * finished (the call waits on the host if it must). */
+ * finished (the call waits on the host if it must).
+ *
+ * (r5) Inside one request the pack and the copy overlap: the inputs are packed in up to four groups (FCP_STAGER_GROUPS) and
+ * every group is shipped the moment its last byte is in the pinned buffer (by the calling thread, which watches the pack
+ * workers instead of packing) — a lone request costs pack + copy / 4 + kernel instead of pack + copy + kernel.
+ * (Groups are used when the caller is not issuing back to back — more than 40 us since the previous call returned: under
+ * load they cost throughput, S2 58 -> 66 us per request, because the caller no longer packs.)
+ * The copies themselves are KERNELS on the stager's copy stream that read the pinned ring through its device mapping
+ * (FCP_STAGER_COPY_KERNEL, the default since round 5): hipMemcpyAsync's SDMA submission blocks its caller for 6-14 ms a few
+ * times per thousand calls on the boxes this was measured on (profiles/r05_pcie_staging_stalls.txt), kernel copies never
+ * did.  FCP_STAGER_COPY_SDMA asks for the copy engine; FCP_STAGER_COPY=kernel|sdma overrides both at run time. */
 typedef struct fcp_stager fcp_stager_t;
-enum { FCP_STAGER_DEFAULT = 0, FCP_STAGER_ZERO_COPY = 1 };
+enum { FCP_STAGER_DEFAULT = 0, FCP_STAGER_ZERO_COPY = 1, FCP_STAGER_COPY_KERNEL = 2, FCP_STAGER_COPY_SDMA = 4 };
 int fcp_stager_create(int32_t device, int64_t capacity_bytes, int32_t max_inputs,
                       int32_t max_rank_sum, int32_t depth, int32_t n_threads,
                       fcp_stager_t **stager);
@@ -667,6 +677,14 @@ int fcp_stager_stage_ex(fcp_stager_t *stager, const fcp_host_tensor_t *inputs, i
                         const void **device_blob, int64_t *blob_bytes, const int32_t **offsets,
                         const int32_t **shapes);
 int fcp_stager_destroy(fcp_stager_t *stager);
+/* What the stager has seen so far: staging calls, copy calls (one per group), how long the slowest copy CALL held its host
+ * thread, how many held it for more than a millisecond (the "14 ms stalls" of profiles/r04_pcie_staging_memcpy_anomaly.txt),
+ * requests the zero-copy fallback served. */
+typedef struct fcp_stager_stats {
+  int64_t calls, copy_calls, copy_calls_over_1ms, fallback_switches, requests_with_blocked_copy;
+  double max_copy_call_us;
+} fcp_stager_stats_t;
+int fcp_stager_stats(fcp_stager_t *stager, fcp_stager_stats_t *out);
 
 /* ---- Addons>ConcatInputs in its staged form (host only; replaces concat_inputs_ops.cc:42-77) ---- */
 /* The same packing as fcp_stager_stage_ex — modes[n_inputs] / mode_args[n_inputs] as there, NULL = plain

@@ -3066,6 +3066,21 @@ struct fcp_stager {
   uint32_t blocked_hist = 0;
   int direct_left = 0;
   uint64_t n_fallbacks = 0, n_blocked = 0;
+  // (r5) a request is packed in `groups` groups of inputs and every group is shipped as soon as it is packed — by the calling
+  // thread, which watches the workers instead of packing — so the H2D copy of the first groups runs under the pack of the later ones: a lone request
+  // costs pack + copy / groups + kernel instead of pack + copy + kernel.  copy_kernel: the copies are kernels on the copy
+  // stream that read the pinned ring through its device mapping (no SDMA engine, no runtime copy path: the eliminating
+  // experiment for the ~14 ms hipMemcpyAsync stalls, profiles/r05_pcie_staging_stalls.txt).
+  int groups = 4;
+  bool copy_kernel = true;
+  // Groups cost throughput (the caller watches instead of packing, four copy launches instead of one: S2 58 -> 66 us per
+  // request pipelined) and buy latency (lone request 142 -> 130 us): they are used when the caller is NOT issuing back to
+  // back — more than kLatencyGapNs since the previous staging call returned — i.e. when nothing is there to overlap with
+  // but the request itself.  FCP_STAGER_GROUPS_ALWAYS=1: every request.
+  uint64_t t_last_return_ns = 0;
+  bool groups_always = false;
+  std::atomic<uint64_t> max_copy_call_ns{0}, n_copy_calls{0}, n_copy_over_1ms{0};
+  uint64_t n_total_calls = 0;
   // FCP_STAGER_STATS=1: where a call spends its host time (ns per phase, printed when the stager is destroyed)
   bool stats = false;
   uint64_t n_calls = 0, ns_wait = 0, ns_layout = 0, ns_pack = 0, ns_enqueue = 0, ns_api[4] = {0, 0, 0, 0};
@@ -3082,7 +3097,8 @@ int fcp_stager_create(int32_t device, int64_t capacity_bytes, int32_t max_inputs
 
 int fcp_stager_create_ex(int32_t device, int64_t capacity_bytes, int32_t max_inputs, int32_t max_rank_sum,
                          int32_t depth, int32_t n_threads, uint32_t flags, fcp_stager_t **out) {
-  if (flags & ~(uint32_t)FCP_STAGER_ZERO_COPY) return fail(FCP_ERR_INVALID_ARGUMENT, "unknown stager flags");
+  if (flags & ~(uint32_t)(FCP_STAGER_ZERO_COPY | FCP_STAGER_COPY_KERNEL | FCP_STAGER_COPY_SDMA)) return fail(FCP_ERR_INVALID_ARGUMENT, "unknown stager flags");
+  if ((flags & FCP_STAGER_COPY_KERNEL) && (flags & FCP_STAGER_COPY_SDMA)) return fail(FCP_ERR_INVALID_ARGUMENT, "copy kernel and SDMA at once");
   if (!out || capacity_bytes <= 0 || capacity_bytes > 0x7fffffff || max_inputs <= 0 || max_rank_sum < 0 ||
       depth < 1 || n_threads < 1)
     return fail(FCP_ERR_INVALID_ARGUMENT, "bad stager parameters (capacity is limited to 2^31 bytes: int32 offsets)");
@@ -3098,6 +3114,13 @@ int fcp_stager_create_ex(int32_t device, int64_t capacity_bytes, int32_t max_inp
   s->max_rank_sum = max_rank_sum;
   s->n_threads = n_threads;
   s->zero_copy = (flags & FCP_STAGER_ZERO_COPY) != 0;
+  // Copies are KERNELS by default since round 5: hipMemcpyAsync's SDMA submission (hsa_amd_memory_async_copy_on_engine) blocks
+  // its caller for 6-14 ms a few times per thousand calls on this pool's boxes; 28 fresh processes with kernel copies (or
+  // HSA_ENABLE_SDMA=0) showed none (profiles/r05_pcie_staging_stalls.txt).  FCP_STAGER_COPY_SDMA / FCP_STAGER_COPY=sdma: the engine.
+  s->copy_kernel = (flags & FCP_STAGER_COPY_SDMA) == 0;
+  if (const char *e = std::getenv("FCP_STAGER_COPY")) s->copy_kernel = std::strcmp(e, "sdma") != 0; // tuning aid: kernel | sdma
+  s->groups_always = std::getenv("FCP_STAGER_GROUPS_ALWAYS") != nullptr;
+  if (const char *e = std::getenv("FCP_STAGER_GROUPS")) s->groups = std::max(1, std::min(std::atoi(e), 16)); // tuning aid; 1 = one copy per request
   s->stats = std::getenv("FCP_STAGER_STATS") != nullptr;
   s->slots.resize(depth);
   for (auto &sl : s->slots) {
@@ -3115,6 +3138,15 @@ int fcp_stager_create_ex(int32_t device, int64_t capacity_bytes, int32_t max_inp
   if (hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking) != hipSuccess) {
     fcp_stager_destroy(s);
     return hip_fail("stager copy stream", hipGetLastError());
+  }
+  if (!s->zero_copy && !s->slots.empty()) {
+    // the copy kernel's first launch loads its code object (~3.5 ms, once per process): here, not inside a request
+    std::memset(s->slots[0].h_blob, 0, 64);
+    if (fcp_launch_h2d_copy(s->slots[0].h_blob_dev, s->slots[0].d_blob, 64, s->copy_stream) != 0 ||
+        hipStreamSynchronize(s->copy_stream) != hipSuccess) {
+      fcp_stager_destroy(s);
+      return hip_fail("stager copy kernel warm-up", hipGetLastError());
+    }
   }
   {
     // pack next to the GPU: the H2D copy reads the pinned ring from that socket's memory
@@ -3235,8 +3267,18 @@ const char *const kUnsortedRows = "row ids of a converted input are not sorted (
 // The pack of one request on a pool: contiguous ranges of inputs of about equal INPUT bytes per chunk (a converted index
 // matrix is 16 bytes per id in and 4 bytes per ROW out: output bytes say little about the work), the head of the next
 // input requested while the current one is packed.  `in_off`: scratch, n + 1 entries.  false: some row ids were not sorted.
+// `groups` (optional): the chunks are dealt into groups->n consecutive groups of about equal input bytes; the CALLING thread
+// does not pack (the pool's workers do) but watches the groups complete and calls groups->done(ctx, group, first byte, end byte
+// of the group in the blob) for each, in order — the stager ships a group over PCIe while the later groups are still being
+// packed.  (Runtime calls from the pack workers themselves: hipMemcpyAsync issued from many threads stalled for ~8.5 ms a
+// dozen times per 700 requests, profiles/r05_pcie_staging_stalls.txt.)
+struct PackGroups {
+  int n;
+  void (*done)(void *ctx, int group, int64_t byte_begin, int64_t byte_end);
+  void *ctx;
+};
 bool pack_on_pool(fcp::PackPool &pool, int n_threads, const fcp_host_tensor_t *inputs, int32_t n, const uint8_t *modes,
-                  const int64_t *mode_args, char *dst, const int64_t *bo, int64_t *in_off) {
+                  const int64_t *mode_args, char *dst, const int64_t *bo, int64_t *in_off, const PackGroups *groups = nullptr) {
   in_off[0] = 0;
   for (int32_t i = 0; i < n; ++i) {
     int64_t ne = 1;
@@ -3251,6 +3293,18 @@ bool pack_on_pool(fcp::PackPool &pool, int n_threads, const fcp_host_tensor_t *i
   }();
   const int chunks = (int)std::min<int64_t>(std::max<int64_t>(1, total / (64 << 10)), (int64_t)per_thread * n_threads);
   std::atomic<int> refused{0};
+  // group bookkeeping: chunk c belongs to group c * ng / chunks; first input of every chunk up front (the groups' byte ranges)
+  constexpr int kMaxGroups = 16;
+  const int ng = groups ? std::max(1, std::min(std::min(groups->n, chunks), kMaxGroups)) : 0;
+  std::atomic<int> group_left[kMaxGroups];
+  std::vector<int> chunk_lo;
+  if (ng > 0) {
+    chunk_lo.resize((size_t)chunks + 1);
+    for (int c = 0; c < chunks; ++c) chunk_lo[(size_t)c] = (int)(std::lower_bound(in_off, in_off + n, total * c / chunks) - in_off);
+    chunk_lo[(size_t)chunks] = n;
+    for (int g = 0; g < ng; ++g) group_left[g].store(0, std::memory_order_relaxed);
+    for (int c = 0; c < chunks; ++c) group_left[c * ng / chunks].fetch_add(1, std::memory_order_relaxed);
+  }
   // FCP_PACK_TRACE=1 (diagnostic): when did every chunk of a call start and end, and on which thread — printed for every 128th call
   static const bool trace = std::getenv("FCP_PACK_TRACE") != nullptr;
   static std::atomic<uint64_t> n_calls{0};
@@ -3260,7 +3314,7 @@ bool pack_on_pool(fcp::PackPool &pool, int n_threads, const fcp_host_tensor_t *i
   auto now_ns = [] { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   if (tracing) tr.resize((size_t)chunks);
   const uint64_t t_pub = tracing ? now_ns() : 0;
-  pool.run(chunks, [&](int c) {
+  auto chunk_fn = [&](int c) {
     struct Stamp { // (scope guard: the end stamp on every exit path of the chunk)
       ChunkTrace *e;
       uint64_t (*now)();
@@ -3279,7 +3333,27 @@ bool pack_on_pool(fcp::PackPool &pool, int n_threads, const fcp_host_tensor_t *i
       if (!stage_pack_one(inputs[lo], modes ? modes[lo] : FCP_STAGE_COPY, mode_args ? mode_args[lo] : 0, dst + bo[lo], bo[lo + 1] - bo[lo]))
         refused.store(1, std::memory_order_relaxed);
     }
-  });
+    if (ng > 0) group_left[c * ng / chunks].fetch_sub(1, std::memory_order_release);
+  };
+  auto ship = [&](int g) { // (all chunks of group g are packed)
+    int c0 = 0;
+    while (c0 < chunks && c0 * ng / chunks < g) ++c0;
+    int c1 = c0;
+    while (c1 < chunks && c1 * ng / chunks == g) ++c1;
+    groups->done(groups->ctx, g, bo[chunk_lo[(size_t)c0]], bo[chunk_lo[(size_t)c1]]);
+  };
+  if (ng > 0 && pool.start(chunks, chunk_fn)) {
+    for (int g = 0; g < ng; ++g) {
+      // the last group: help with what is left instead of watching
+      if (g == ng - 1) pool.finish();
+      while (group_left[g].load(std::memory_order_acquire) > 0) __builtin_ia32_pause();
+      ship(g);
+    }
+    pool.finish();
+  } else {
+    pool.run(chunks, chunk_fn);
+    for (int g = 0; g < ng; ++g) ship(g);
+  }
   if (tracing) {
     const uint64_t t_end = now_ns();
     std::fprintf(stderr, "fcp pack trace: %d chunks, %d threads, call %.1f us; chunk: start-after-publish us, duration us, thread\n", chunks,
@@ -3332,29 +3406,67 @@ int fcp_stager_stage_ex(fcp_stager_t *s, const fcp_host_tensor_t *inputs, int32_
   const int64_t size = s->byte_off[n];
   const uint64_t t_layout = s->stats ? now_ns() : 0;
   s->in_off.resize((size_t)n + 1);
-  if (!pack_on_pool(*s->pool, s->n_threads, inputs, n, modes, mode_args, sl.h_blob, s->byte_off.data(), s->in_off.data()))
-    return fail(FCP_ERR_INVALID_ARGUMENT, kUnsortedRows); // nothing was enqueued; the slot is simply reused
-  const uint64_t t_packed = s->stats ? now_ns() : 0;
-  sl.direct = direct;
+  // Copying mode: the slot's device twin is free once the work that read its previous contents has run — queued on the copy
+  // stream BEFORE the pack, because the groups of this request are shipped from inside it
+  struct Ship {
+    fcp_stager *s;
+    StageSlot *sl;
+    std::atomic<int> err{0};
+    std::atomic<uint64_t> max_ns{0};
+  } ship{s, &sl};
+  constexpr uint64_t kLatencyGapNs = 40000;
+  const bool lone = s->groups_always || s->t_last_return_ns == 0 || now_ns() - s->t_last_return_ns > kLatencyGapNs;
+  PackGroups pg{lone ? s->groups : 1, nullptr, &ship};
+  pg.done = [](void *ctx, int, int64_t b0, int64_t b1) {
+    Ship &x = *static_cast<Ship *>(ctx);
+    if (b1 <= b0) return;
+    const auto t0 = std::chrono::steady_clock::now();
+    hipError_t e;
+    if (x.s->copy_kernel)
+      e = (hipError_t)fcp_launch_h2d_copy(x.sl->h_blob_dev + b0, x.sl->d_blob + b0, (size_t)(b1 - b0), x.s->copy_stream);
+    else
+      e = hipMemcpyAsync(x.sl->d_blob + b0, x.sl->h_blob + b0, (size_t)(b1 - b0), hipMemcpyHostToDevice, x.s->copy_stream);
+    if (e != hipSuccess) x.err.store((int)e, std::memory_order_relaxed);
+    const uint64_t ns = (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+    uint64_t m = x.max_ns.load(std::memory_order_relaxed);
+    while (ns > m && !x.max_ns.compare_exchange_weak(m, ns, std::memory_order_relaxed)) {
+    }
+    x.s->n_copy_calls.fetch_add(1, std::memory_order_relaxed);
+    if (ns > 1000000) x.s->n_copy_over_1ms.fetch_add(1, std::memory_order_relaxed);
+    m = x.s->max_copy_call_ns.load(std::memory_order_relaxed);
+    while (ns > m && !x.s->max_copy_call_ns.compare_exchange_weak(m, ns, std::memory_order_relaxed)) {
+    }
+  };
+  uint64_t a0 = now_ns(), a1;
   if (!direct) {
-    // the device twin is free once the work that read its previous contents has run
-    uint64_t a0 = now_ns(), a1;
     if (sl.consumed_valid) HIP_TRY(hipStreamWaitEvent(s->copy_stream, sl.consumed, 0));
     if (int rc3 = stager_input_wait(sl.d_blob, s->capacity, s->copy_stream)) return rc3; // (private-stream readers, see there)
-    if (s->stats) { a1 = now_ns(); s->ns_api[0] += a1 - a0; a0 = a1; }
-    const uint64_t c0 = now_ns();
-    if (size) HIP_TRY(hipMemcpyAsync(sl.d_blob, sl.h_blob, (size_t)size, hipMemcpyHostToDevice, s->copy_stream));
-    const uint64_t c1 = now_ns();
-    if (!no_fallback) {
-      s->blocked_hist = (s->blocked_hist << 1) | (c1 - c0 > 20000 ? 1u : 0u); // the last 32 copy calls: which blocked > 20 us
-      s->n_blocked += c1 - c0 > 20000;
+    if (s->stats) { a1 = now_ns(); s->ns_api[0] += a1 - a0; }
+  }
+  const uint64_t t_pack0 = s->stats ? now_ns() : 0;
+  const bool sorted = pack_on_pool(*s->pool, s->n_threads, inputs, n, modes, mode_args, sl.h_blob, s->byte_off.data(), s->in_off.data(),
+                                   direct || size == 0 ? nullptr : &pg);
+  const uint64_t t_packed = s->stats ? now_ns() : 0;
+  (void)t_pack0;
+  sl.direct = direct;
+  if (!direct) {
+    // (whatever was shipped before a refusal is ordinary traffic on the copy stream: the slot is simply reused)
+    if (ship.err.load()) return hip_fail("H2D copy of a request group", (hipError_t)ship.err.load());
+    const uint64_t worst = ship.max_ns.load();
+    if (!no_fallback && sorted) {
+      s->blocked_hist = (s->blocked_hist << 1) | (worst > 20000 ? 1u : 0u); // the last 32 requests: whose copy calls blocked > 20 us
+      s->n_blocked += worst > 20000;
       if (__builtin_popcount(s->blocked_hist) >= 8) { // the copy call holds the host up: the kernels read the pinned ring for a while
         s->blocked_hist = 0;
         s->direct_left = 256;
         ++s->n_fallbacks;
       }
     }
-    if (s->stats) { a1 = now_ns(); s->ns_api[1] += a1 - a0; a0 = a1; }
+    if (s->stats) s->ns_api[1] += worst;
+  }
+  if (!sorted) return fail(FCP_ERR_INVALID_ARGUMENT, kUnsortedRows);
+  if (!direct) {
+    a0 = now_ns();
     HIP_TRY(hipEventRecord(sl.copied, s->copy_stream));
     if (s->stats) { a1 = now_ns(); s->ns_api[2] += a1 - a0; a0 = a1; }
     HIP_TRY(hipStreamWaitEvent(user, sl.copied, 0));
@@ -3371,6 +3483,8 @@ int fcp_stager_stage_ex(fcp_stager_t *s, const fcp_host_tensor_t *inputs, int32_
     s->ns_enqueue += t_end - t_packed;
   }
   s->last = slot_idx;
+  ++s->n_total_calls;
+  s->t_last_return_ns = now_ns();
   if (device_blob) *device_blob = direct ? sl.h_blob_dev : sl.d_blob;
   if (blob_bytes) *blob_bytes = size;
   if (offsets) *offsets = sl.offsets;
@@ -3453,15 +3567,30 @@ int fcp_stager_stage(fcp_stager_t *s, const fcp_host_tensor_t *inputs, int32_t n
   return fcp_stager_stage_narrow(s, inputs, n, nullptr, stream, device_blob, blob_bytes, offsets, shapes);
 }
 
+int fcp_stager_stats(fcp_stager_t *s, fcp_stager_stats_t *out) {
+  if (!s || !out) return fail(FCP_ERR_INVALID_ARGUMENT, "null argument");
+  std::lock_guard<std::mutex> lock(s->mu);
+  out->calls = (int64_t)s->n_total_calls;
+  out->copy_calls = (int64_t)s->n_copy_calls.load();
+  out->copy_calls_over_1ms = (int64_t)s->n_copy_over_1ms.load();
+  out->fallback_switches = (int64_t)s->n_fallbacks;
+  out->requests_with_blocked_copy = (int64_t)s->n_blocked;
+  out->max_copy_call_us = s->max_copy_call_ns.load() / 1e3;
+  return FCP_OK;
+}
+
 int fcp_stager_destroy(fcp_stager_t *s) {
   if (!s) return FCP_OK;
   if (s->stats && s->n_calls)
     std::fprintf(stderr, "fcp_stager: %llu calls, host us per call: wait for the slot %.2f, layout %.2f, pack %.2f (%d threads), enqueue %.2f "
                          "(wait-event on the copy stream %.2f, hipMemcpyAsync %.2f, event record %.2f, wait-event on the request's stream %.2f); "
-                         "copy calls that blocked > 20 us: %llu, zero-copy fallbacks %llu\n",
+                         "requests whose copy calls blocked > 20 us: %llu, zero-copy fallbacks %llu; %llu copy calls (%s, %d groups), slowest %.1f us, "
+                         "%llu over 1 ms\n",
                  (unsigned long long)s->n_calls, s->ns_wait / 1e3 / s->n_calls, s->ns_layout / 1e3 / s->n_calls, s->ns_pack / 1e3 / s->n_calls,
                  s->n_threads, s->ns_enqueue / 1e3 / s->n_calls, s->ns_api[0] / 1e3 / s->n_calls, s->ns_api[1] / 1e3 / s->n_calls,
-                 s->ns_api[2] / 1e3 / s->n_calls, s->ns_api[3] / 1e3 / s->n_calls, (unsigned long long)s->n_blocked, (unsigned long long)s->n_fallbacks);
+                 s->ns_api[2] / 1e3 / s->n_calls, s->ns_api[3] / 1e3 / s->n_calls, (unsigned long long)s->n_blocked, (unsigned long long)s->n_fallbacks,
+                 (unsigned long long)s->n_copy_calls.load(), s->copy_kernel ? "copy kernel" : "hipMemcpyAsync", s->groups,
+                 s->max_copy_call_ns.load() / 1e3, (unsigned long long)s->n_copy_over_1ms.load());
   DeviceGuard guard;
   (void)guard.enter(s->device);
   delete s->pool;

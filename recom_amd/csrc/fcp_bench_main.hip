@@ -107,6 +107,7 @@ int main(int argc, char **argv) {
   int fixed_dim = 0;        // 0: dims cycle 8/16/32/64 (S2); D: every column has dim D (E/F-like models: --dim 8)
   int pack_threads = 8;
   int stager_depth = 4;     // with --h2d: slots of the stager's pinned ring
+  int copy_kernel = 1;      // with --h2d: the stager's copies are kernels reading the pinned ring (the default); 0: hipMemcpyAsync (SDMA)
   long vocab = 1000000;
   for (int i = 1; i + 1 < argc; i += 2) {
     std::string k = argv[i];
@@ -128,6 +129,7 @@ int main(int argc, char **argv) {
     else if (k == "--dim") fixed_dim = (int)v;
     else if (k == "--pack-threads") pack_threads = (int)v;
     else if (k == "--stager-depth") stager_depth = (int)v;
+    else if (k == "--copy-kernel") copy_kernel = (int)v;
     else if (k == "--bw-probe") {
       const char *names[4] = {"read", "write", "write-nt", "chunked-write-nt"};
       for (int kind = 0; kind < 4; ++kind) {
@@ -407,7 +409,7 @@ int main(int argc, char **argv) {
     std::vector<Worker> W(nw);
     for (Worker &w : W) {
       CHECK_FCP(fcp_stager_create_ex(0, (int64_t)blobs[0].size() + 4096, columns, columns, stager_depth, pack_threads,
-                                     zero_copy ? FCP_STAGER_ZERO_COPY : FCP_STAGER_DEFAULT, &w.st));
+                                     zero_copy ? FCP_STAGER_ZERO_COPY : copy_kernel ? FCP_STAGER_COPY_KERNEL : FCP_STAGER_COPY_SDMA, &w.st));
       w.ring.resize(6);
       for (auto &p : w.ring) CHECK_HIP(hipMalloc(&p, (size_t)arena_bytes));
       w.rc.r = &w.ring;
@@ -489,10 +491,16 @@ int main(int argc, char **argv) {
       CHECK_HIP(hipFree(dp_buf));
       CHECK_HIP(hipHostFree(hp_buf));
     }
-    std::printf("{\"pcie_inclusive\": true, \"zero_copy\": %d, \"serve_workers\": %d, \"pack_threads\": %d, \"blob_MB\": %.2f, \"us_per_request_pipelined\": %.2f, "
+    fcp_stager_stats_t sst;
+    std::memset(&sst, 0, sizeof(sst));
+    CHECK_FCP(fcp_stager_stats(W[0].st, &sst));
+    std::printf("{\"pcie_inclusive\": true, \"zero_copy\": %d, \"copy_kernel\": %d, \"serve_workers\": %d, \"pack_threads\": %d, \"blob_MB\": %.2f, \"us_per_request_pipelined\": %.2f, "
                 "\"us_latency_single\": %.2f, \"inferences_per_s\": %.0f, \"host_us_stage_call\": %.2f, \"host_us_process_call\": %.2f, "
-                "\"h2d_copy_alone_us\": %.2f, \"h2d_GBs\": %.1f}\n",
-                zero_copy, nw, pack_threads, shipped / 1e6, us, lat / 50, batch / (us * 1e-6), hs, hp, copy_us, shipped / copy_us / 1e3);
+                "\"h2d_copy_alone_us\": %.2f, \"h2d_GBs\": %.1f, \"stager_calls\": %lld, \"copy_calls\": %lld, \"copy_calls_over_1ms\": %lld, "
+                "\"max_copy_call_us\": %.1f, \"zero_copy_fallback_switches\": %lld}\n",
+                zero_copy, copy_kernel, nw, pack_threads, shipped / 1e6, us, lat / 50, batch / (us * 1e-6), hs, hp, copy_us, shipped / copy_us / 1e3,
+                (long long)sst.calls, (long long)sst.copy_calls, (long long)sst.copy_calls_over_1ms, sst.max_copy_call_us,
+                (long long)sst.fallback_switches);
     for (Worker &w : W) CHECK_FCP(fcp_stager_destroy(w.st));
     CHECK_FCP(fcp_plan_destroy(plan));
     return 0;

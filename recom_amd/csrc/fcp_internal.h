@@ -141,6 +141,9 @@ int fcp_launch_fused(const FcpLaunch &L, int vec, bool dense_kernel, int grid_bl
 int fcp_launch_hybrid(const FcpLaunch &Ldense, int dense_blocks, const FcpLaunch &Lragged, int ragged_blocks, int vec,
                       ihipStream_t *s);
 int fcp_launch_upload(const void *host_mapped_src, void *dst, size_t bytes, ihipStream_t *s);
+// bytes (a multiple of 4) from host-mapped pinned memory to device memory by a kernel; both 4-byte aligned and equally
+// misaligned against 16 bytes
+int fcp_launch_h2d_copy(const void *host_mapped_src, void *dst, size_t bytes, ihipStream_t *s);
 int fcp_launch_segment_offsets(const FcpSegLaunch &L, int n_seg_cols, int max_nnz, ihipStream_t *s, bool any_order = false);
 // col_offsets: destination column of every input, or NULL = side by side starting at first_off;
 // in_strides: row stride of every input in floats, or NULL = contiguous [prefix, dims[k]] inputs

@@ -1472,6 +1472,33 @@ __global__ void __launch_bounds__(FCP_BLOCK_THREADS) fcp_upload_kernel(const uin
 
 } // namespace
 
+// ---------------------------------------------------------------------------
+// The request stager's copy as a KERNEL (FCP_STAGER_COPY_KERNEL): bytes [0, n) from the pinned staging ring (read over
+// PCIe through its device mapping) to the slot's device twin.  src and dst are 4-byte aligned and equally misaligned
+// against 16 bytes (the same offset into two page-aligned buffers), n is a multiple of 4: head and tail by dwords, the
+// body by 16-byte words, four independent loads in flight per thread (a PCIe read is ~2 us away: 64 blocks x 256
+// threads x 4 x 16 B = 1 MB requested per round).
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(FCP_BLOCK_THREADS) fcp_h2d_copy_kernel(const char *__restrict__ src, char *__restrict__ dst, size_t n) {
+  const size_t head = min((size_t)((16 - (reinterpret_cast<uintptr_t>(dst) & 15)) & 15), n);
+  const size_t body = (n - head) & ~(size_t)15, tail = n - head - body;
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (size_t)gridDim.x * blockDim.x;
+  if (t < head / 4) reinterpret_cast<uint32_t *>(dst)[t] = reinterpret_cast<const uint32_t *>(src)[t];
+  if (t < tail / 4) reinterpret_cast<uint32_t *>(dst + head + body)[t] = reinterpret_cast<const uint32_t *>(src + head + body)[t];
+  const uint4 *s4 = reinterpret_cast<const uint4 *>(src + head);
+  uint4 *d4 = reinterpret_cast<uint4 *>(dst + head);
+  const size_t n4 = body / 16;
+  for (size_t i = t; i < n4; i += 4 * nt) {
+    uint4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (i + k * nt < n4) v[k] = s4[i + k * nt];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (i + k * nt < n4) d4[i + k * nt] = v[k];
+  }
+}
+
 // ------------------------------- launchers ---------------------------------
 
 // Private-stream requests (fcp_api.hip): the completion event of a request is attached to the dispatch packet of its
@@ -1579,6 +1606,17 @@ int fcp_launch_hybrid(const FcpLaunch &Ldense, int dense_blocks, const FcpLaunch
   }
 #undef FCP_HYB_R
 #undef FCP_HYB
+  return (int)hipGetLastError();
+}
+
+int fcp_launch_h2d_copy(const void *host_mapped_src, void *dst, size_t bytes, ihipStream_t *s) {
+  if (bytes == 0) return 0;
+  if ((bytes & 3) || ((reinterpret_cast<uintptr_t>(host_mapped_src) ^ reinterpret_cast<uintptr_t>(dst)) & 15) ||
+      (reinterpret_cast<uintptr_t>(dst) & 3))
+    return (int)hipErrorInvalidValue;
+  const int blocks = (int)std::min<size_t>(64, (bytes / 16 + FCP_BLOCK_THREADS - 1) / FCP_BLOCK_THREADS + 1);
+  hipLaunchKernelGGL(fcp_h2d_copy_kernel, dim3(blocks), dim3(FCP_BLOCK_THREADS), 0, s, static_cast<const char *>(host_mapped_src),
+                     static_cast<char *>(dst), bytes);
   return (int)hipGetLastError();
 }
 

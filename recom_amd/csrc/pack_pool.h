@@ -59,6 +59,29 @@ public:
     }
     wake();
   }
+  // run() in two halves: start() publishes the job and returns at once — the workers pack while the caller does something
+  // else (the stager: ships the groups of the request over PCIe as they complete) — finish() lets the caller help with what is
+  // left and waits for the last chunk.  `fn` must stay alive until finish() has returned.  Returns false when the pool has
+  // no workers (or the job a single chunk): nothing was started, the caller runs the chunks itself.
+  template <typename F> bool start(int n_chunks, F &fn) {
+    if (workers_.empty() || n_chunks <= 1) return false;
+    if (n_chunks > kMaxChunks) n_chunks = kMaxChunks;
+    call_ = [](void *p, int c) { (*static_cast<F *>(p))(c); };
+    ctx_ = static_cast<void *>(&fn);
+    const uint64_t e = epoch_.load(std::memory_order_relaxed) + 1;
+    pending_.store(n_chunks, std::memory_order_relaxed);
+    next_.store(pack(e, n_chunks, 0), std::memory_order_release);
+    epoch_.store(e, std::memory_order_release);
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+    }
+    wake();
+    return true;
+  }
+  void finish() {
+    work(epoch_.load(std::memory_order_relaxed));
+    while (pending_.load(std::memory_order_acquire) > 0) __builtin_ia32_pause();
+  }
   template <typename F> void run(int n_chunks, F &&fn) {
     if (workers_.empty() || n_chunks <= 1) {
       for (int c = 0; c < n_chunks; ++c) fn(c);

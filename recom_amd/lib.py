@@ -103,6 +103,12 @@ class PrivateStreamsStats(C.Structure):
                 ("worst_ratio", C.c_double), ("demote_ratio", C.c_double), ("demoted", C.c_int32), ("baseline_samples", C.c_int32)]
 
 
+class StagerStats(C.Structure):
+    """fcp_stager_stats_t"""
+    _fields_ = [("calls", C.c_int64), ("copy_calls", C.c_int64), ("copy_calls_over_1ms", C.c_int64), ("fallback_switches", C.c_int64),
+                ("requests_with_blocked_copy", C.c_int64), ("max_copy_call_us", C.c_double)]
+
+
 class HostTensor(C.Structure):
     _fields_ = [("data", C.c_void_p), ("elem_size", C.c_int32), ("rank", C.c_int32),
                 ("dims", C.POINTER(C.c_int64))]
@@ -120,7 +126,7 @@ EXPORTS = [
     "fcp_shard_finalize", "fcp_comm_unique_id", "fcp_comm_create", "fcp_comm_destroy", "fcp_comm_rank",
     "fcp_shard_batch_slice", "fcp_shard_exchange", "fcp_shard_exchange_columns",
     "fcp_shard_step_create", "fcp_shard_step_run", "fcp_shard_step_destroy",
-    "fcp_stager_create", "fcp_stager_create_ex", "fcp_stager_stage", "fcp_stager_stage_ex", "fcp_stager_stage_narrow", "fcp_stager_destroy",
+    "fcp_stager_create", "fcp_stager_create_ex", "fcp_stager_stage", "fcp_stager_stage_ex", "fcp_stager_stage_narrow", "fcp_stager_destroy", "fcp_stager_stats",
     "fcp_concat_inputs_ex_sizes", "fcp_concat_inputs_ex", "fcp_plan_file_stage_info",
     "fcp_pack_pool_create", "fcp_pack_pool_destroy", "fcp_concat_inputs_ex_pool",
     "fcp_graph_build", "fcp_graph_free", "fcp_placement_assign", "fcp_concat_outputs_scatter_strided",
@@ -231,6 +237,8 @@ def load() -> C.CDLL:
                                           C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
                                           C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.POINTER(C.c_int32))]
     L.fcp_stager_destroy.argtypes = [C.c_void_p]
+    if hasattr(L, "fcp_stager_stats"):
+        L.fcp_stager_stats.argtypes = [C.c_void_p, C.POINTER(StagerStats)]
     if hasattr(L, "fcp_pack_pool_create"):
         L.fcp_pack_pool_create.argtypes = [C.c_int32, C.POINTER(C.c_void_p)]
         L.fcp_pack_pool_destroy.argtypes = [C.c_void_p]

@@ -605,12 +605,21 @@ class RequestStager:
     ring itself, mapped into the device's address space (``FCP_STAGER_ZERO_COPY``)."""
 
     def __init__(self, capacity_bytes: int, max_inputs: int, max_rank_sum: int, device: int = 0, depth: int = 4,
-                 n_threads: int = 8, zero_copy: bool = False) -> None:
+                 n_threads: int = 8, zero_copy: bool = False, copy: Optional[str] = None) -> None:
+        """``copy``: "kernel" (``FCP_STAGER_COPY_KERNEL``, the default: a kernel on the stager's stream reads the pinned
+        ring) or "sdma" (``FCP_STAGER_COPY_SDMA``: ``hipMemcpyAsync``)."""
         self._L = _lib.load()
         h = C.c_void_p()
+        flags = (1 if zero_copy else 0) | {None: 0, "kernel": 2, "sdma": 4}[copy]
         _lib.check(self._L.fcp_stager_create_ex(device, capacity_bytes, max_inputs, max_rank_sum, depth, n_threads,
-                                                1 if zero_copy else 0, C.byref(h)), "fcp_stager_create_ex")
+                                                flags, C.byref(h)), "fcp_stager_create_ex")
         self.handle = h
+
+    def stats(self) -> dict:
+        """``fcp_stager_stats``: staging calls, copy calls, copy calls that held their host thread > 1 ms, the slowest."""
+        st = _lib.StagerStats()
+        _lib.check(self._L.fcp_stager_stats(self.handle, C.byref(st)), "fcp_stager_stats")
+        return {k: getattr(st, k) for k, _ in st._fields_}
 
     def stage_ex(self, inputs: Sequence[np.ndarray], modes: Sequence[int], mode_args: Sequence[int],
                  stream: Optional[int] = None):

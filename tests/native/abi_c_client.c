@@ -127,6 +127,13 @@ int main(void) {
     CHECK(fcp_result_wait(NULL, NULL) == FCP_ERR_INVALID_ARGUMENT);
     CHECK(fcp_result_synchronize(blob) == FCP_OK); /* nothing pending for an address no request ever used */
   }
+  { /* round 5: the stager's record; a bad flag combination is refused before anything touches a device */
+    fcp_stager_stats_t ss;
+    fcp_stager_t *st = NULL;
+    CHECK(fcp_stager_stats(NULL, &ss) == FCP_ERR_INVALID_ARGUMENT);
+    CHECK(fcp_stager_create_ex(0, 1 << 20, 4, 4, 2, 2, FCP_STAGER_COPY_KERNEL | FCP_STAGER_COPY_SDMA, &st) == FCP_ERR_INVALID_ARGUMENT && st == NULL);
+    CHECK(fcp_stager_create_ex(0, 1 << 20, 4, 4, 2, 2, 1u << 7, &st) == FCP_ERR_INVALID_ARGUMENT);
+  }
   CHECK(strlen(fcp_status_string(FCP_ERR_NO_DEVICE)) > 0);
   CHECK(fcp_plan_destroy(plan) == FCP_OK);
   puts("abi_c_client ok");

@@ -25,13 +25,24 @@ int main(int argc, char **argv) {
     for (int c = 0; c < n; ++c) hits[c].store(0, std::memory_order_relaxed);
     if (rng & 64) pool.expect();                                       // announced jobs, unannounced jobs ...
     if ((rng & 0x3f00) == 0) { pool.expect(); std::this_thread::sleep_for(std::chrono::microseconds(150)); } // ... and announcements nothing follows in time
-    pool.run(n, [&](int c) {
+    auto chunk = [&](int c) {
       hits[c].fetch_add(1, std::memory_order_relaxed);
       if ((c & 7) == 0) {
         volatile int sink = 0;
         for (int k = 0; k < 200; ++k) sink = sink + k; // uneven chunk cost
       }
-    });
+    };
+    if (rng & 128) { // the two-halves form the stager uses when it ships groups while the workers pack (round 5)
+      if (pool.start(n, chunk)) {
+        while (hits[0].load(std::memory_order_relaxed) == 0 && (rng & 256)) std::this_thread::yield(); // the caller watches ...
+        pool.finish();                                                                                  // ... then helps and waits
+        if (rng & 512) pool.finish(); // (a second call finds nothing to do)
+      } else {
+        for (int c = 0; c < n; ++c) chunk(c);
+      }
+    } else {
+      pool.run(n, chunk);
+    }
     for (int c = 0; c < n; ++c) {
       if (hits[c].load(std::memory_order_relaxed) != 1) {
         std::printf("job %d: chunk %d ran %d times\n", j, c, hits[c].load());

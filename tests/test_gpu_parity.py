@@ -815,6 +815,48 @@ def test_request_stager_matches_concat_inputs_and_feeds_the_kernel(torch_cuda, o
     st.close()
 
 
+@pytest.mark.parametrize("copy", ["kernel", "sdma"])
+@pytest.mark.parametrize("groups", ["1", "4", "16"])
+def test_request_stager_ships_a_request_in_groups_with_either_copy_engine(torch_cuda, oracle, monkeypatch, copy, groups):
+    """Round 5: a request is packed in groups of inputs and every group is shipped as soon as it is packed (FCP_STAGER_GROUPS,
+    here for every request: FCP_STAGER_GROUPS_ALWAYS), by a copy KERNEL on the stager's stream (the default: no SDMA engine in
+    the path) or by hipMemcpyAsync (FCP_STAGER_COPY_SDMA).  A request large enough for several pack chunks (64 KB each), odd
+    tensor sizes (group boundaries at any 4-byte offset): the device blob is byte-identical to ConcatInputs' output, the
+    kernel's result through it equals the oracle, the stager counts one copy call per group."""
+    import ctypes as C
+    from recom_amd import synth
+    from recom_amd.ops import FeatureColumnProcess, RequestStager, concat_inputs
+    torch = torch_cuda
+    monkeypatch.setenv("FCP_STAGER_GROUPS", groups)
+    monkeypatch.setenv("FCP_STAGER_GROUPS_ALWAYS", "1")
+    m = synth.model_mixed(batch=2051, vocab=4999, n_groups=1)          # ~1 MB of host tensors per request
+    tabs_np = m.numpy_tables()
+    tabs = [torch.from_numpy(t).cuda() for t in tabs_np]
+    op = FeatureColumnProcess(m.spec, 0)
+    st = RequestStager(8 << 20, m.spec.n_host_inputs, sum(m.spec.host_input_ranks), depth=3, n_threads=6, copy=copy)
+    hip = C.CDLL("libamdhip64.so")
+    calls = 0
+    for seed in range(7):                                              # more requests than ring slots
+        req = m.make_request(seed, B=2051 - 3 * seed)
+        blob, offsets, shapes = concat_inputs(req.inputs)
+        d_ptr, nbytes, off2, shp2 = st.stage(req.inputs)
+        assert nbytes == blob.nbytes and np.array_equal(off2, offsets) and np.array_equal(shp2, shapes)
+        out = op(_RawBlob(d_ptr, nbytes), off2, shp2, tabs, req.symbols)       # the kernel on the staged blob itself
+        torch.cuda.synchronize()
+        tmp = torch.empty(nbytes, dtype=torch.int8, device="cuda")
+        assert hip.hipMemcpy(C.c_void_p(tmp.data_ptr()), C.c_void_p(d_ptr), C.c_size_t(nbytes), 3) == 0
+        assert np.array_equal(tmp.cpu().numpy(), blob)
+        want, _ = oracle.process_feature_columns(m.spec.to_dict(), blob, offsets, shapes, tabs_np, req.symbols)
+        assert np.array_equal(out.groups[0].cpu().numpy(), want[0])
+        stats = st.stats()
+        assert stats["calls"] == seed + 1 and 1 <= stats["copy_calls"] - calls <= int(groups)
+        if groups != "1" and blob.nbytes > (256 << 10):
+            assert stats["copy_calls"] - calls > 1                     # several chunks -> several groups
+        calls = stats["copy_calls"]
+    assert st.stats()["copy_calls_over_1ms"] == 0 or copy == "sdma"   # (the engine's submission may stall: that is why it is not the default)
+    st.close()
+
+
 @pytest.mark.parametrize("zero_copy", [False, True])
 def test_request_stager_turns_sparse_indices_into_row_offsets(torch_cuda, oracle, zero_copy):
     """fcp_stager_stage_ex / FCP_STAGE_SEG_TO_CSR: the sorted row ids of multi-hot features (SparseTensor indices [nnz, 2],
