@@ -521,13 +521,13 @@ def main():
                 ht.plan.set_private_streams(3)
                 ht.run(1)
                 ht.plan.verify_private_streams(ht.caller_stream(), 400)
-                ht.run_private(max(sc_warm // T, 50), depth, T)
+                ht.run_private(max(1400 // T, 50), depth, T)         # (long enough for three evaluations of the supervisor)
                 w_ms, d_ms = ht.run_private(per, depth, T)
                 st = ht.plan.private_streams_stats()
                 threads_sweep[f"threads_{T}_depth_{depth}"] = {
                     "private_streams_us": w_ms * 1e3 / (per * T), "stream_order_same_consumer_us": b_ms * 1e3 / (per * T),
-                    "verified_overlap": ht.plan.private_streams_verdict(ht.caller_stream()), "supervisor_demoted": st["demoted"],
-                    "supervisor_last_ratio": st["last_ratio"], "requests_per_thread": per}
+                    "verdict_at_the_end": ht.plan.private_streams_verdict(ht.caller_stream()), "supervisor_demoted": st["demoted"],
+                    "supervisor_last_ratio": st["last_ratio"], "supervisor_evaluations": st["evaluations"], "requests_per_thread": per}
                 ht.close()
         # and the cheap variant for callers that own their buffers (this harness does): FCP_ORDER_INPUTS_READY — the same K
         # requests back to back on the one stream, the fused kernel launched without the queue's barrier bit
@@ -555,7 +555,9 @@ def main():
                                                         "Session = one compute stream, recom_examples.patch:193-216), 3 private streams; depth 1 = the "
                                                         "consumer right behind its request (FeatureColumnProcess -> Addons>ConcatOutputs inside one "
                                                         "Session::Run), depth 3 = two more requests of the thread in between; us per request over all "
-                                                        "threads, next to the same threads in stream order (a demoted caller runs in stream order)",
+                                                        "threads, next to the same threads in stream order.  The supervisor A/Bs the two modes while "
+                                                        "serving (48 requests each, at request 1, ~360, ~970, ...): a caller for whom the private streams lose "
+                                                        "(ratio > 0.97 twice) is demoted and finishes in stream order",
                                                 **threads_sweep},
                          "sweep_us_per_request": {str(k): v["us_per_request"] for k, v in sweep.items()},
                          "sweep_verified_overlap": {str(k): v["verified_overlap"] for k, v in sweep.items()},

@@ -449,6 +449,16 @@ int fcp_process_feature_columns(fcp_plan_t *plan,
  * right after plan creation); changing the count synchronises the old streams.
  * The sharded step (fcp_shard_step_run) always runs on args->stream.
  *
+ * When the mode pays (round 5, profiles/r05_caller_threads_grid.txt): only when
+ * the READER of a request is queued on args->stream at least one other request
+ * later — every request waits for everything recorded on args->stream before its
+ * allocation, readers included, so a reader right behind its request (what one
+ * Session::Run of the rewritten graph does: FeatureColumnProcess, then
+ * ConcatOutputs) serialises the requests again and the events are pure cost (S2
+ * 30 -> 36-39 us, with 1 to 4 host threads on the stream); two requests behind:
+ * 30.1 -> 24.7-25.3 us.  The supervisor below demotes callers for whom it does
+ * not pay.
+ *
  * Which requests take a private stream: the cross-stream events cost the host
  * about 8 us per request, so a request only gains when its kernel is long enough
  * to have something to overlap (S2 28 -> 24.5 us, RAGGED 27.8 -> 22 us per
@@ -487,21 +497,24 @@ int fcp_process_feature_columns(fcp_plan_t *plan,
  * docs/build_from_source.md:42) call fcp_plan_verify_private_streams there: no
  * serving request then ever pays for the search.
  *
- * Supervision.  A verdict is learnt once; the mapping can stop overlapping later
- * (another library of the process creates streams).  The plan therefore keeps
- * measuring: the first four lane-eligible requests of a caller stream run on THAT
- * stream between two timing events (the stream-order time per byte of work of the
- * plan's real requests); afterwards every 256th private-stream request opens a
- * window of 48 requests between two timing events on one private stream.  A
- * window counts when at least 3/4 of its requests found their private stream
- * still busy with the previous one (otherwise the host set the pace); when two
- * consecutive counted windows ran slower than 1.10x the stream-order time per
- * byte (private streams that overlap measure 0.64-0.92, those that do not
- * 1.13-1.64: profiles/r05_caller_threads_grid.txt), the caller is DEMOTED: verdict 0, one line on stderr, its requests stay
- * on its own stream (results are unaffected at every point).
- * fcp_plan_verify_private_streams searches a new mapping and re-admits it.
- * FCP_LANE_SUPERVISE=0 turns the supervisor off; FCP_LANE_SUPERVISE_PERIOD,
- * FCP_LANE_DEMOTE_RATIO tune it; fcp_plan_private_streams_stats reads it. */
+ * Supervision.  A verdict is learnt once, from a synthetic probe; what the private
+ * streams buy the caller's REAL traffic — its readers, its host threads, its pace —
+ * and whether the mapping still overlaps later, is measured while serving: an
+ * online A/B.  An evaluation runs 48 consecutive requests of the caller on
+ * args->stream between two timing events there, then 48 on the private streams
+ * between two timing events on one of them, and compares the time per byte of
+ * work (private / stream order: streams that overlap measure 0.64-0.92; readers
+ * right behind their requests 1.13-1.64; sparse traffic ~1.0 — nothing to overlap;
+ * a mapping that stopped overlapping 1.1 and more:
+ * profiles/r05_caller_threads_grid.txt).  Two consecutive evaluations above 0.97
+ * DEMOTE the caller: verdict 0, one line on stderr, its requests stay on
+ * args->stream; two consecutive ones below it re-admit a demoted caller (a trickle
+ * at start-up, load later).  Evaluations run at the caller's first eligible
+ * request, 256 requests later, then at doubling gaps up to 8192 requests: < 1 %
+ * of the traffic runs in the mode that loses.  Results are unaffected at every
+ * point.  FCP_LANE_SUPERVISE=0 turns the supervisor off; FCP_LANE_SUPERVISE_PERIOD
+ * (largest gap), FCP_LANE_KEEP_RATIO tune it; fcp_plan_private_streams_stats reads
+ * it; fcp_plan_verify_private_streams (a new search) starts it over. */
 enum { FCP_PRIVATE_NO_CALLER_WAIT = 1u << 0, FCP_PRIVATE_ALWAYS = 1u << 1, FCP_PRIVATE_NO_VERIFY = 1u << 2 };
 int fcp_plan_set_private_streams(fcp_plan_t *plan, int32_t n_streams, uint32_t flags);
 
@@ -524,23 +537,24 @@ int fcp_plan_private_streams_verdict(fcp_plan_t *plan, void *stream, int32_t *ve
 /* The verification at a time of the caller's choosing (warm-up): probes the private streams behind `stream` now and, while
  * no live plan relies on the present mapping, searches another one for at most about budget_ms of wall time (<= 0: 400 ms;
  * one mapping costs ~8 ms, the whole search space ~22 of them).  A negative verdict of an earlier, cheaper look — or a
- * demotion by the supervisor — is forgotten and the search runs again; a positive one is returned as it is.  Blocks the
+ * demotion by the supervisor — is forgotten and the search runs again (the supervisor then starts over with an evaluation at
+ * the next request); a positive one is returned as it is.  Blocks the
  * host, drains `stream`.  *verdict (optional) as fcp_plan_private_streams_verdict; -1 when the mode is off, or when the
  * plan's requests so far are below the work threshold (they stay on `stream` anyway: nothing is probed).  Call it after
  * the first (warm-up) request of the plan, as the shim does. */
 int fcp_plan_verify_private_streams(fcp_plan_t *plan, void *stream, int32_t budget_ms, int32_t *verdict);
 /* What the run-time supervisor of the plan's private streams has seen (see Supervision above). */
 typedef struct fcp_private_streams_stats {
-  void *supervised_stream;     /* the caller stream under supervision (the first that took the private streams), or NULL */
-  int64_t lane_requests;       /* its requests that ran on a private stream                                              */
-  int64_t windows;             /* timed windows completed                                                                */
-  int64_t windows_counted;     /* ... of which GPU-bound (>= 3/4 of the requests found their stream busy)                */
-  double baseline_us_per_mib;  /* stream-order time per MiB of work (rows gathered + output written), 0: not known yet   */
-  double last_ratio;           /* last counted window: time per byte on the private streams / baseline                   */
-  double worst_ratio;          /* the largest such ratio so far                                                          */
-  double demote_ratio;         /* threshold (1.10)                                                                       */
-  int32_t demoted;             /* 1: the supervisor has moved this caller back to its own stream                         */
-  int32_t baseline_samples;    /* baseline requests read so far (4)                                                      */
+  void *supervised_stream;        /* the caller stream under supervision (the first that took the private streams), or NULL   */
+  int64_t requests;               /* its requests that were eligible for a private stream so far                              */
+  int64_t lane_requests;          /* ... of which ran on one                                                                  */
+  int64_t evaluations;            /* completed A/B evaluations (48 requests in stream order, 48 on the private streams)       */
+  double stream_order_us_per_mib; /* last evaluation: stream-order time per MiB of work (rows gathered + output written)      */
+  double last_ratio;              /* last evaluation: time per byte on the private streams / in stream order                  */
+  double worst_ratio;             /* the largest such ratio so far                                                            */
+  double keep_ratio;              /* private streams are kept while the ratio stays at or below this (0.97)                   */
+  int32_t demoted;                /* 1: the supervisor keeps this caller's requests on its own stream at present              */
+  int32_t evaluation_in_progress; /* 1: an evaluation is running or waiting for its timing events                             */
 } fcp_private_streams_stats_t;
 int fcp_plan_private_streams_stats(fcp_plan_t *plan, fcp_private_streams_stats_t *out);
 

@@ -161,38 +161,43 @@ thread_local const LaneDep *tl_lane_dep = nullptr;
 // gathered + written bytes of the request this thread processed last (DynMeta::work_bytes; the supervisor's unit of work)
 thread_local int64_t tl_work_bytes = 0;
 
-// Supervision of one plan's lane traffic behind ONE caller stream (the first that took the lanes; TensorFlow has one).
-//   baseline: the first kBaseline lane-eligible requests run on the CALLER's stream between two timing events: the
-//             stream-order cost per byte of work of this plan's real requests (minimum of the samples);
-//   window:   every `period`-th lane request opens one: a timing event behind that request on its lane, a second one behind
-//             the first request at least kWindow requests later that lands on the same lane; work bytes summed in between,
-//             and per request whether its lane still had the previous request in flight when it was issued (hipEventQuery);
-//   verdict:  a window counts only when >= 3/4 of its requests found their lane busy (otherwise the host, not the GPU, set
-//             the pace and the window says nothing); its time per byte over the baseline's is the ratio; two consecutive
-//             counted windows above `demote_ratio` (1.10: lanes that overlap measure 0.64-0.92, lanes that do not 1.13-1.64,
-//             profiles/r05_caller_threads_grid.txt) demote the caller: verdict 0, logged once, requests stay on its stream.
-// Cost: two marker packets per window and ~kWindow event queries — nothing between windows but one mutex and a counter.
-constexpr int kSupBaseline = 4, kSupWindow = 48;
+// Supervision of one plan's lane traffic behind ONE caller stream (the first that took the lanes; TensorFlow has one): an
+// online A/B of the two ways a request can run, under the caller's REAL traffic — its consumers, its host threads, its pace.
+//   evaluation: kSupWindow consecutive requests run on the CALLER's stream between two timing events there (time per byte of
+//               work in stream order), the next kSupWindow on the private streams between two timing events on one of them
+//               (the second behind the first request >= kSupWindow later that lands on the same lane); ratio = lanes / stream
+//               order.  No idle / busy heuristics: a caller that issues sparsely measures ~1.0 in both (nothing to overlap:
+//               the lanes buy nothing), readers right behind their requests measure > 1 (the events are pure cost), lanes
+//               that overlap measure 0.64-0.92, a hardware-queue mapping that stopped overlapping 1.1 and more
+//               (profiles/r05_caller_threads_grid.txt).
+//   decision:   two consecutive evaluations with ratio > keep_ratio (0.97): the caller is DEMOTED — verdict 0, one line on
+//               stderr, its requests stay on its stream; two consecutive ones below it re-admit a demoted caller (traffic
+//               changes: a trickle at start-up, load later).  One evaluation alone never switches.
+//   schedule:   the first at the caller's first eligible request, the next after 256 requests, then the gap doubles up to
+//               `period` (8192): one evaluation costs kSupWindow requests in the mode that loses, < 1 % of the traffic.
+// Cost outside evaluations: one mutex and a counter per request.
+constexpr int kSupWindow = 48;
 struct LaneSupervisor {
   std::mutex mu;
   bool on = true;
-  uint32_t period = 256;
-  double demote_ratio = 1.10;
+  uint32_t period = 8192, first_gap = 256;
+  double keep_ratio = 0.97;
   void *caller = nullptr;
-  int base_issued = 0, base_read = 0;
-  hipEvent_t b0[kSupBaseline] = {}, b1[kSupBaseline] = {};
-  int64_t base_bytes[kSupBaseline] = {};
-  double base_ns_per_byte = 0; // 0: not known yet
-  uint64_t seq = 0;
-  int state = 0; // 0 idle, 1 window open, 2 window closed (events pending)
-  hipEvent_t w0 = nullptr, w1 = nullptr;
+  bool use_lanes = true;        // the mode requests run in between evaluations
+  uint64_t seq = 0;             // eligible requests of the supervised caller so far
+  uint64_t next_eval = 1, gap = 256;
+  // phase of the running evaluation: 0 none, 1 stream-order window open, 2 lane window to open, 3 lane window open,
+  // 4 both closed (events pending)
+  int phase = 0;
+  hipEvent_t b0 = nullptr, b1 = nullptr; // on the caller's stream
+  hipEvent_t w0 = nullptr, w1 = nullptr; // on one lane
   PrivateLane *w_lane = nullptr;
-  int w_count = 0, w_busy = 0;
-  int64_t w_bytes = 0;
-  int strikes = 0;
-  uint64_t windows = 0, counted = 0;
-  double last_ratio = 0, worst_ratio = 0;
-  bool demoted = false;
+  int so_count = 0, w_count = 0;
+  int64_t so_bytes = 0, w_bytes = 0;
+  int strikes = 0;              // consecutive evaluations that contradict the present mode
+  uint64_t evaluations = 0, lane_requests = 0;
+  double so_ns_per_byte = 0, last_ratio = 0, worst_ratio = 0;
+  bool demoted = false;         // == !use_lanes after at least one decision
 };
 
 struct LanePool {
@@ -2385,90 +2390,97 @@ int default_verify_budget_ms() {
 // ---- the supervisor (struct LaneSupervisor above) -----------------------------------------------------------------------
 void sup_reset(LaneSupervisor &S) { // (S.mu held, or no request in flight); events are kept
   S.caller = nullptr;
-  S.base_issued = S.base_read = 0;
-  S.base_ns_per_byte = 0;
+  S.use_lanes = true;
   S.seq = 0;
-  S.state = 0;
+  S.next_eval = 1;
+  S.phase = 0;
   S.w_lane = nullptr;
   S.strikes = 0;
-  S.windows = S.counted = 0;
-  S.last_ratio = S.worst_ratio = 0;
+  S.evaluations = S.lane_requests = 0;
+  S.so_ns_per_byte = S.last_ratio = S.worst_ratio = 0;
   S.demoted = false;
+  S.on = true;
+  S.period = 8192;
+  S.first_gap = 256;
+  S.keep_ratio = 0.97;
   if (const char *e = std::getenv("FCP_LANE_SUPERVISE")) S.on = std::atoi(e) != 0;
-  if (const char *e = std::getenv("FCP_LANE_SUPERVISE_PERIOD")) S.period = (uint32_t)std::max(std::atoi(e), kSupWindow + 8);
-  if (const char *e = std::getenv("FCP_LANE_DEMOTE_RATIO")) S.demote_ratio = std::max(std::atof(e), 1.0);
+  if (const char *e = std::getenv("FCP_LANE_SUPERVISE_PERIOD")) S.period = (uint32_t)std::max(std::atoi(e), 4 * kSupWindow);
+  if (const char *e = std::getenv("FCP_LANE_KEEP_RATIO")) S.keep_ratio = std::max(std::atof(e), 0.1);
+  S.first_gap = std::min<uint32_t>(S.first_gap, S.period);
+  S.gap = S.first_gap;
 }
 
 int sup_events(LaneSupervisor &S) { // timing events, created on first use (S.mu held)
   if (S.w0) return FCP_OK;
   HIP_TRY(hipEventCreate(&S.w0));
   HIP_TRY(hipEventCreate(&S.w1));
-  for (int i = 0; i < kSupBaseline; ++i) {
-    HIP_TRY(hipEventCreate(&S.b0[i]));
-    HIP_TRY(hipEventCreate(&S.b1[i]));
-  }
+  HIP_TRY(hipEventCreate(&S.b0));
+  HIP_TRY(hipEventCreate(&S.b1));
   return FCP_OK;
 }
 
-// completed baseline samples -> base_ns_per_byte (S.mu held)
-void sup_read_baseline(LaneSupervisor &S) {
-  while (S.base_read < S.base_issued && hipEventQuery(S.b1[S.base_read]) == hipSuccess) {
-    float ms = 0;
-    if (hipEventElapsedTime(&ms, S.b0[S.base_read], S.b1[S.base_read]) == hipSuccess && ms > 0 && S.base_bytes[S.base_read] > 0) {
-      const double r = (double)ms * 1e6 / (double)S.base_bytes[S.base_read];
-      S.base_ns_per_byte = S.base_ns_per_byte > 0 ? std::min(S.base_ns_per_byte, r) : r;
-    }
-    ++S.base_read;
-  }
-}
-
-// a closed window whose events have completed -> strikes; returns true when the caller is to be demoted (S.mu held)
-bool sup_read_window(LaneSupervisor &S) {
-  if (S.state != 2 || hipEventQuery(S.w1) != hipSuccess) return false;
-  S.state = 0;
-  ++S.windows;
-  sup_read_baseline(S);
-  float ms = 0;
-  if (hipEventElapsedTime(&ms, S.w0, S.w1) != hipSuccess || S.w_bytes <= 0 || S.base_ns_per_byte <= 0) return false;
-  if (4 * S.w_busy < 3 * S.w_count) return false; // the host set the pace: says nothing about the lanes
-  ++S.counted;
-  S.last_ratio = (double)ms * 1e6 / (double)S.w_bytes / S.base_ns_per_byte;
+// An evaluation whose four events have completed -> ratio -> strikes.  Returns +1: demote the caller now, -1: re-admit it
+// now, 0: nothing changes.  (S.mu held)
+int sup_decide(LaneSupervisor &S) {
+  if (S.phase != 4 || hipEventQuery(S.b1) != hipSuccess || hipEventQuery(S.w1) != hipSuccess) return 0;
+  S.phase = 0;
+  S.next_eval = S.seq + S.gap;
+  S.gap = std::min<uint64_t>(S.gap * 2, S.period);
+  float so_ms = 0, w_ms = 0;
+  if (hipEventElapsedTime(&so_ms, S.b0, S.b1) != hipSuccess || hipEventElapsedTime(&w_ms, S.w0, S.w1) != hipSuccess || so_ms <= 0 ||
+      w_ms <= 0 || S.so_bytes <= 0 || S.w_bytes <= 0)
+    return 0;
+  ++S.evaluations;
+  S.so_ns_per_byte = (double)so_ms * 1e6 / (double)S.so_bytes;
+  S.last_ratio = ((double)w_ms * 1e6 / (double)S.w_bytes) / S.so_ns_per_byte;
   S.worst_ratio = std::max(S.worst_ratio, S.last_ratio);
-  S.strikes = S.last_ratio > S.demote_ratio ? S.strikes + 1 : 0;
-  return S.strikes >= 2 && !S.demoted;
+  const bool lanes_win = S.last_ratio <= S.keep_ratio;
+  S.strikes = lanes_win != S.use_lanes ? S.strikes + 1 : 0;
+  if (S.strikes < 2) return 0;
+  S.strikes = 0;
+  S.gap = S.first_gap; // after a switch: look again soon
+  return lanes_win ? -1 : +1;
 }
 
 // (no lane mutex held: cal_mu is taken, and verify_lanes takes the lanes' mutexes under cal_mu)
-void demote_caller(fcp_plan *p, void *caller) {
+// to_lanes false: the supervisor demotes `caller` — verdict 0, its requests stay on its stream; true: it re-admits it.
+void switch_caller(fcp_plan *p, void *caller, bool to_lanes) {
   LanePool *pool = p->pool;
   if (!pool) return;
-  double ratio = 0;
-  uint64_t counted = 0;
+  double ratio = 0, keep = 0;
+  uint64_t evals = 0;
   {
     std::lock_guard<std::mutex> sup_lock(p->sup.mu);
-    if (p->sup.demoted) return;
-    p->sup.demoted = true;
+    if (p->sup.use_lanes == to_lanes) return;
+    p->sup.use_lanes = to_lanes;
+    p->sup.demoted = !to_lanes;
     ratio = p->sup.last_ratio;
-    counted = p->sup.counted;
+    keep = p->sup.keep_ratio;
+    evals = p->sup.evaluations;
   }
   std::lock_guard<std::mutex> cal_lock(pool->cal_mu);
   bool found = false;
   for (auto &v : p->lane_verdicts)
-    if (v.first == caller) v.second = false, found = true;
-  if (!found) p->lane_verdicts.emplace_back(caller, false);
-  void *expect = caller;
-  p->lane_good_caller.compare_exchange_strong(expect, nullptr, std::memory_order_acq_rel);
-  p->lane_demoted.store(true, std::memory_order_release);
-  bool any_good = false;
-  for (auto &v : p->lane_verdicts) any_good = any_good || v.second;
-  // nobody of this plan relies on the mapping any more: a later verification may search another one
-  if (!any_good && p->lane_relies.exchange(false)) pool->n_relying.fetch_sub(1, std::memory_order_acq_rel);
-  std::fprintf(stderr, "fcp private streams: caller stream %p DEMOTED to its own stream: its requests ran at %.2fx the stream-order "
-                       "time per byte on the private streams (threshold %.2f, %llu supervised window(s)); the hardware-queue mapping "
-                       "no longer overlaps — fcp_plan_verify_private_streams searches a new one\n",
-               caller, ratio, p->sup.demote_ratio, (unsigned long long)counted);
+    if (v.first == caller) v.second = to_lanes, found = true;
+  if (!found) p->lane_verdicts.emplace_back(caller, to_lanes);
+  if (to_lanes) {
+    p->lane_good_caller.store(caller, std::memory_order_release);
+    if (!p->lane_relies.exchange(true)) pool->n_relying.fetch_add(1, std::memory_order_acq_rel);
+  } else {
+    void *expect = caller;
+    p->lane_good_caller.compare_exchange_strong(expect, nullptr, std::memory_order_acq_rel);
+    p->lane_demoted.store(true, std::memory_order_release);
+    bool any_good = false;
+    for (auto &v : p->lane_verdicts) any_good = any_good || v.second;
+    // nobody of this plan relies on the mapping any more: a later verification may search another one
+    if (!any_good && p->lane_relies.exchange(false)) pool->n_relying.fetch_sub(1, std::memory_order_acq_rel);
+  }
+  std::fprintf(stderr, "fcp private streams: caller stream %p %s: its requests ran at %.2fx the stream-order time per byte on the private "
+                       "streams in two consecutive evaluations (kept below %.2f; %llu evaluation(s) so far)%s\n",
+               caller, to_lanes ? "RE-ADMITTED to the private streams" : "DEMOTED to its own stream", ratio, keep, (unsigned long long)evals,
+               to_lanes ? "" : " — readers right behind their requests, sparse traffic, or a hardware-queue mapping that no longer overlaps "
+                               "(fcp_plan_verify_private_streams searches a new one)");
 }
-
 } // namespace
 
 // What the verification decided for `stream`: 1 = its requests take the private streams, 0 = they stay on `stream` (nothing
@@ -2503,7 +2515,7 @@ int fcp_plan_verify_private_streams(fcp_plan_t *p, void *stream, int32_t budget_
   bool ok = false;
   rc = verify_lanes(p, caller, budget_ms > 0 ? budget_ms : 400, /*again=*/true, &ok);
   if (rc) return rc;
-  if (ok) { // a new mapping, or a new look at the old one: the supervisor starts over
+  if (ok) { // a new mapping, or a new look at the old one: the supervisor starts over (first evaluation at the next request)
     std::lock_guard<std::mutex> sup_lock(p->sup.mu);
     if (p->sup.demoted || p->sup.caller != stream) sup_reset(p->sup);
     p->lane_demoted.store(false, std::memory_order_release);
@@ -2518,15 +2530,15 @@ int fcp_plan_private_streams_stats(fcp_plan_t *p, fcp_private_streams_stats_t *o
   std::lock_guard<std::mutex> sup_lock(p->sup.mu);
   const LaneSupervisor &S = p->sup;
   out->supervised_stream = S.caller;
-  out->lane_requests = (int64_t)S.seq;
-  out->windows = (int64_t)S.windows;
-  out->windows_counted = (int64_t)S.counted;
-  out->baseline_us_per_mib = S.base_ns_per_byte * 1048576.0 / 1e3;
+  out->requests = (int64_t)S.seq;
+  out->lane_requests = (int64_t)S.lane_requests;
+  out->evaluations = (int64_t)S.evaluations;
+  out->stream_order_us_per_mib = S.so_ns_per_byte * 1048576.0 / 1e3;
   out->last_ratio = S.last_ratio;
   out->worst_ratio = S.worst_ratio;
-  out->demote_ratio = S.demote_ratio;
+  out->keep_ratio = S.keep_ratio;
   out->demoted = S.demoted ? 1 : 0;
-  out->baseline_samples = S.base_read;
+  out->evaluation_in_progress = S.phase != 0 ? 1 : 0;
   return FCP_OK;
 }
 
@@ -2572,16 +2584,22 @@ int fcp_process_feature_columns(fcp_plan_t *p, const fcp_process_args_t *a, fcp_
   DeviceGuard guard;
   int rc = guard.enter(p->desc.device);
   if (rc) return rc;
-  if (!(p->lane_flags & FCP_PRIVATE_NO_VERIFY)) {
-    if (p->lane_good_caller.load(std::memory_order_acquire) != (void *)caller) {
-      bool ok = false;
-      // first request of this caller: probes (and may re-create) the lanes within the budget; later: a lookup
-      rc = verify_lanes(p, caller, default_verify_budget_ms(), /*again=*/false, &ok);
-      if (rc) return rc;
-      if (!ok) return process_on_caller(p, a, r);
-    }
-  } else {
-    if (p->lane_demoted.load(std::memory_order_acquire)) { // the supervisor has demoted a caller of this plan: this one?
+  LaneSupervisor &S = p->sup;
+  bool supervised = false; // the supervisor routes this caller's requests (it may have demoted it: the verdict is then its own)
+  if (S.on) {
+    std::lock_guard<std::mutex> sup_lock(S.mu);
+    supervised = S.caller == (void *)caller;
+  }
+  if (!supervised) {
+    if (!(p->lane_flags & FCP_PRIVATE_NO_VERIFY)) {
+      if (p->lane_good_caller.load(std::memory_order_acquire) != (void *)caller) {
+        bool ok = false;
+        // first request of this caller: probes (and may re-create) the lanes within the budget; later: a lookup
+        rc = verify_lanes(p, caller, default_verify_budget_ms(), /*again=*/false, &ok);
+        if (rc) return rc;
+        if (!ok) return process_on_caller(p, a, r);
+      }
+    } else if (p->lane_demoted.load(std::memory_order_acquire)) { // a caller of this plan has been demoted: this one?
       bool mine = false;
       {
         std::lock_guard<std::mutex> cal_lock(p->pool->cal_mu);
@@ -2589,37 +2607,58 @@ int fcp_process_feature_columns(fcp_plan_t *p, const fcp_process_args_t *a, fcp_
       }
       if (mine) return process_on_caller(p, a, r);
     }
-    if (!p->lane_relies.load(std::memory_order_acquire)) {
-      // first unverified use: counted under the pool's mutex, where verify_lanes of another plan reads the count before it
-      // re-creates the lanes
-      std::lock_guard<std::mutex> cal_lock(p->pool->cal_mu);
-      if (!p->lane_relies.exchange(true)) p->pool->n_relying.fetch_add(1, std::memory_order_acq_rel);
-    }
+  }
+  if ((p->lane_flags & FCP_PRIVATE_NO_VERIFY) && !p->lane_relies.load(std::memory_order_acquire)) {
+    // first unverified use: counted under the pool's mutex, where verify_lanes of another plan reads the count before it
+    // re-creates the lanes
+    std::lock_guard<std::mutex> cal_lock(p->pool->cal_mu);
+    if (!p->lane_relies.exchange(true)) p->pool->n_relying.fetch_add(1, std::memory_order_acq_rel);
   }
   static const bool lane_stats = std::getenv("FCP_LANE_STATS") != nullptr; // diagnostic: host time of a private-stream request by part
   auto now_ns = [] { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-  LaneSupervisor &S = p->sup;
-  // -- supervisor: the stream-order baseline (the first lane-eligible requests of the supervised caller stay on its stream,
-  //    between two timing events) -------------------------------------------------------------------------------------------
+  // -- supervisor: which way does this request go? --------------------------------------------------------------------------
+  bool to_lane = true, so_window = false, lane_window = false;
+  int decision = 0; // +1: demote the caller after this request, -1: re-admit it
   if (S.on) {
-    std::unique_lock<std::mutex> sup_lock(S.mu);
-    if (!S.caller) S.caller = (void *)caller;
-    if (S.caller == (void *)caller && !S.demoted && S.base_issued < kSupBaseline) {
-      rc = sup_events(S);
-      if (rc) return rc;
-      const int i = S.base_issued++;
-      HIP_TRY(hipEventRecord(S.b0[i], caller));
-      const int prc = process_on_caller(p, a, r); // (S.mu held over the call: baseline samples are serial by construction)
-      if (prc) {
-        --S.base_issued;
-        return prc;
+    std::lock_guard<std::mutex> sup_lock(S.mu);
+    if (!S.caller) S.caller = (void *)caller; // the first caller that got this far: verified good, or taken unverified
+    if (S.caller == (void *)caller) {
+      ++S.seq;
+      decision = sup_decide(S);
+      if (S.phase == 0 && S.seq >= S.next_eval) { // an evaluation starts with this request: stream order first
+        if ((rc = sup_events(S))) return rc;
+        S.phase = 1;
+        S.so_count = 0;
+        S.so_bytes = 0;
+        HIP_TRY(hipEventRecord(S.b0, caller));
       }
-      S.base_bytes[i] = tl_work_bytes;
-      HIP_TRY(hipEventRecord(S.b1[i], caller));
-      return FCP_OK;
+      to_lane = S.use_lanes != (decision != 0); // (a decision taken just now counts from this request on)
+      if (S.phase == 1) {
+        to_lane = false;
+        so_window = true;
+      } else if (S.phase == 2 || S.phase == 3) {
+        to_lane = true;
+        lane_window = true;
+      }
+      if (to_lane) ++S.lane_requests;
     }
   }
-  bool demote = false;
+  if (!to_lane) {
+    rc = process_on_caller(p, a, r);
+    if (rc) return rc;
+    if (so_window) {
+      std::lock_guard<std::mutex> sup_lock(S.mu);
+      if (S.phase == 1) {
+        S.so_bytes += tl_work_bytes;
+        if (++S.so_count >= kSupWindow) { // every counted request has been enqueued: the window ends behind this one
+          HIP_TRY(hipEventRecord(S.b1, caller));
+          S.phase = 2;
+        }
+      }
+    }
+    if (decision) switch_caller(p, (void *)caller, decision < 0);
+    return FCP_OK;
+  }
   {
     PrivateLane &L = *p->pool->lanes[p->pool->rr.fetch_add(1, std::memory_order_relaxed) % (uint32_t)p->lane_count];
     const uint64_t s0 = lane_stats ? now_ns() : 0;
@@ -2629,32 +2668,23 @@ int fcp_process_feature_columns(fcp_plan_t *p, const fcp_process_args_t *a, fcp_
       return process_on_caller(p, a, r);
     }
     const uint32_t e = L.next++ % kLaneEvents;
-    // -- supervisor: window bookkeeping in front of the request -----------------------------------------------------------
-    int mark = 0; // 1: this request opens a window (w0 behind it), 2: it closes one (w1 behind it)
+    // -- supervisor: the lane window of an evaluation -----------------------------------------------------------------------
+    int mark = 0; // 1: this request opens the window (w0 behind it), 2: it closes it (w1 behind it)
     bool in_window = false;
-    if (S.on) {
+    if (lane_window) {
       std::lock_guard<std::mutex> sup_lock(S.mu);
-      if (S.caller == (void *)caller && !S.demoted) {
-        ++S.seq;
-        if (S.state == 2) demote = sup_read_window(S);
-        if (S.state == 0 && S.seq % S.period == 1 && S.base_issued >= kSupBaseline) {
-          if ((rc = sup_events(S))) return rc;
-          S.state = 1;
-          S.w_lane = &L;
-          S.w_count = S.w_busy = 0;
-          S.w_bytes = 0;
-          mark = 1;
-        } else if (S.state == 1) {
-          in_window = true;
-          ++S.w_count;
-          // was this lane still working on its previous request when this one was issued?
-          if (L.next >= 2 && hipEventQuery(L.out[(e + kLaneEvents - 1) % kLaneEvents]) == hipErrorNotReady) ++S.w_busy;
-          if (S.w_count >= kSupWindow && S.w_lane == &L) mark = 2;
-        }
+      if (S.phase == 2) {
+        S.phase = 3;
+        S.w_lane = &L;
+        S.w_count = 0;
+        S.w_bytes = 0;
+        mark = 1;
+      } else if (S.phase == 3) {
+        in_window = true;
+        if (++S.w_count >= kSupWindow && S.w_lane == &L) mark = 2;
       }
     }
     LaneDep dep{L.in[e], caller, L.stream};
-    uint64_t s1 = s0, s2 = s0;
     fcp_process_args_t b = *a;
     b.stream = L.stream;
     fcp_process_result_t local{};
@@ -2695,18 +2725,16 @@ int fcp_process_feature_columns(fcp_plan_t *p, const fcp_process_args_t *a, fcp_
     if (fault) p->pool->last_out.store(L.out[e], std::memory_order_release);
     if (mark || in_window) {
       std::lock_guard<std::mutex> sup_lock(S.mu);
-      if (in_window && S.state == 1) S.w_bytes += tl_work_bytes;
-      if (mark == 1 && S.state == 1) HIP_TRY(hipEventRecord(S.w0, L.stream));
-      if (mark == 2 && S.state == 1) {
+      if (in_window && S.phase == 3) S.w_bytes += tl_work_bytes;
+      if (mark == 1 && S.phase == 3) HIP_TRY(hipEventRecord(S.w0, L.stream));
+      if (mark == 2 && S.phase == 3) {
         HIP_TRY(hipEventRecord(S.w1, L.stream));
-        S.state = 2;
+        S.phase = 4;
       }
     }
     if (lane_stats) {
       static std::atomic<uint64_t> n{0}, a_proc{0}, a_reg{0};
       const uint64_t s4 = now_ns();
-      (void)s1;
-      (void)s2;
       a_proc += s3 - s0;
       a_reg += s4 - s3;
       if ((++n & 1023) == 0)
@@ -2714,7 +2742,7 @@ int fcp_process_feature_columns(fcp_plan_t *p, const fcp_process_args_t *a, fcp_
                      a_proc.load() / 1e3 / n.load(), a_reg.load() / 1e3 / n.load());
     }
   }
-  if (demote) demote_caller(p, (void *)caller);
+  if (decision) switch_caller(p, (void *)caller, decision < 0);
   return FCP_OK;
 }
 

@@ -98,9 +98,9 @@ class Placement(C.Structure):
 
 class PrivateStreamsStats(C.Structure):
     """fcp_private_streams_stats_t"""
-    _fields_ = [("supervised_stream", C.c_void_p), ("lane_requests", C.c_int64), ("windows", C.c_int64),
-                ("windows_counted", C.c_int64), ("baseline_us_per_mib", C.c_double), ("last_ratio", C.c_double),
-                ("worst_ratio", C.c_double), ("demote_ratio", C.c_double), ("demoted", C.c_int32), ("baseline_samples", C.c_int32)]
+    _fields_ = [("supervised_stream", C.c_void_p), ("requests", C.c_int64), ("lane_requests", C.c_int64), ("evaluations", C.c_int64),
+                ("stream_order_us_per_mib", C.c_double), ("last_ratio", C.c_double), ("worst_ratio", C.c_double),
+                ("keep_ratio", C.c_double), ("demoted", C.c_int32), ("evaluation_in_progress", C.c_int32)]
 
 
 class StagerStats(C.Structure):

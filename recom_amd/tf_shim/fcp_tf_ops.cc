@@ -168,10 +168,14 @@ public:
     out_cols_.resize(n_out);
     OP_REQUIRES(c, static_cast<size_t>(n_out) == output_types_.size(), errors::InvalidArgument("plan output columns != output_types"));
     OP_REQUIRES(c, static_cast<size_t>(n_tables) == input_types_.size(), errors::InvalidArgument("plan tables != input_types"));
-    // FCP_PRIVATE_STREAMS=<n> (3 measured best): TensorFlow gives this op one compute stream, shared by every Session::Run
-    // thread; with private streams the lookup kernels of consecutive requests overlap and only Addons>ConcatOutputs
-    // (fcp_result_wait below) orders the compute stream behind them.  Blob, tables and arena are inputs of that
-    // ConcatOutputs node (`tensor_buffers`, cuda_emitter.cc:2632-2643), so they outlive the kernels.
+    // FCP_PRIVATE_STREAMS=<n> (3 measured best; OPT-IN): TensorFlow gives this op one compute stream, shared by every
+    // Session::Run thread; with private streams the lookup kernels of consecutive requests can overlap and only
+    // Addons>ConcatOutputs (fcp_result_wait below) orders the compute stream behind them.  Blob, tables and arena are inputs
+    // of that ConcatOutputs node (`tensor_buffers`, cuda_emitter.cc:2632-2643), so they outlive the kernels.  It pays only
+    // where work of OTHER requests is queued between this op and its ConcatOutputs (measured: consumer two requests behind,
+    // S2 30.1 -> 24.7-25.3 us; right behind — the stock rewritten graph inside one Session::Run — 30 -> 36-39 us,
+    // profiles/r05_caller_threads_grid.txt): leave it unset for stock graphs; the library's supervisor demotes a compute
+    // stream on which the mode loses.
     if (const char *e = std::getenv("FCP_PRIVATE_STREAMS")) {
       const int n = std::atoi(e);
       if (n > 0) OP_REQUIRES_OK(c, FcpStatus(fcp_plan_set_private_streams(plan_, n, 0), "fcp_plan_set_private_streams"));

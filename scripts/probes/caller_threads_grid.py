@@ -28,10 +28,10 @@ for T in (1, 2, 3, 4, 6, 8):
         h.plan.set_private_streams(3)
         h.run(1)
         v = h.plan.verify_private_streams(h.caller_stream(), 400)
-        h.run_private(100, depth, T)
+        h.run_private(max(1400 // T, 100), depth, T)   # long enough for three evaluations of the supervisor
         pv = h.run_private(per, depth, T)[0] * 1e3 / (per * T)
         st = h.plan.private_streams_stats()
         out["grid"][f"T{T}_d{depth}"] = {"stream_order_us": round(so, 2), "private3_us": round(pv, 2), "verdict": v,
-                                         "sup_last_ratio": round(st["last_ratio"], 3), "demoted": st["demoted"]}
+                                         "sup_last_ratio": round(st["last_ratio"], 3), "demoted": st["demoted"], "evaluations": st["evaluations"]}
         h.close()
 print(json.dumps(out, indent=1))

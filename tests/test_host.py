@@ -128,7 +128,7 @@ def test_host_only_plan_cannot_run_and_real_plan_needs_a_gpu():
     assert p._L.fcp_plan_verify_private_streams(p.handle, None, 50, C.byref(v)) == lib.FCP_ERR_NO_DEVICE and v.value == -1
     assert p._L.fcp_plan_verify_private_streams(None, None, 50, None) == lib.FCP_ERR_INVALID_ARGUMENT
     st = lib.PrivateStreamsStats()
-    assert p._L.fcp_plan_private_streams_stats(p.handle, C.byref(st)) == lib.FCP_OK and st.lane_requests == 0 and st.demoted == 0
+    assert p._L.fcp_plan_private_streams_stats(p.handle, C.byref(st)) == lib.FCP_OK and st.lane_requests == 0 and st.demoted == 0 and st.requests == 0
     assert p._L.fcp_plan_private_streams_stats(p.handle, None) == lib.FCP_ERR_INVALID_ARGUMENT
     p.close()
     if not torch.cuda.is_available():
