@@ -1917,6 +1917,11 @@ int fcp_plan_destroy(fcp_plan_t *p) {
       (void)hipDeviceSynchronize();
       pending_forget(p); // (the lanes belong to the device's pool and stay)
       if (p->pool && p->lane_relies.exchange(false)) p->pool->n_relying.fetch_sub(1, std::memory_order_acq_rel);
+      for (hipEvent_t *ev : {&p->sup.b0, &p->sup.b1, &p->sup.w0, &p->sup.w1}) // the supervisor's timing events
+        if (*ev) {
+          (void)hipEventDestroy(*ev);
+          *ev = nullptr;
+        }
       destroy_device(p);
     }
   }
