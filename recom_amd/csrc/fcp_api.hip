@@ -3157,9 +3157,10 @@ int fcp_stager_create_ex(int32_t device, int64_t capacity_bytes, int32_t max_inp
   s->stats = std::getenv("FCP_STAGER_STATS") != nullptr;
   s->slots.resize(depth);
   for (auto &sl : s->slots) {
-    if (hipHostMalloc(reinterpret_cast<void **>(&sl.h_blob), capacity_bytes, hipHostMallocMapped) != hipSuccess ||
+    const size_t alloc_bytes = (size_t)capacity_bytes + 64; // (the copy kernel rounds a group's range up to 16 bytes)
+    if (hipHostMalloc(reinterpret_cast<void **>(&sl.h_blob), alloc_bytes, hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer(reinterpret_cast<void **>(&sl.h_blob_dev), sl.h_blob, 0) != hipSuccess ||
-        (s->zero_copy ? ((sl.d_blob = sl.h_blob_dev), hipSuccess) : hipMalloc(reinterpret_cast<void **>(&sl.d_blob), capacity_bytes)) != hipSuccess ||
+        (s->zero_copy ? ((sl.d_blob = sl.h_blob_dev), hipSuccess) : hipMalloc(reinterpret_cast<void **>(&sl.d_blob), alloc_bytes)) != hipSuccess ||
         hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&sl.consumed, hipEventDisableTiming) != hipSuccess) {
       fcp_stager_destroy(s);
@@ -3455,9 +3456,13 @@ int fcp_stager_stage_ex(fcp_stager_t *s, const fcp_host_tensor_t *inputs, int32_
     if (b1 <= b0) return;
     const auto t0 = std::chrono::steady_clock::now();
     hipError_t e;
-    if (x.s->copy_kernel)
-      e = (hipError_t)fcp_launch_h2d_copy(x.sl->h_blob_dev + b0, x.sl->d_blob + b0, (size_t)(b1 - b0), x.s->copy_stream);
-    else
+    if (x.s->copy_kernel) {
+      // the kernel moves 16-byte words: the range is widened to 16-byte boundaries (tensors of 1- or 2-byte elements put group
+      // boundaries anywhere).  The bytes it picks up from a neighbouring group are either final already (the group before: groups
+      // are shipped in order) or rewritten by that group's own copy, which follows on the same stream; the buffers have slack.
+      const int64_t a0 = b0 & ~(int64_t)15, a1 = (b1 + 15) & ~(int64_t)15;
+      e = (hipError_t)fcp_launch_h2d_copy(x.sl->h_blob_dev + a0, x.sl->d_blob + a0, (size_t)(a1 - a0), x.s->copy_stream);
+    } else
       e = hipMemcpyAsync(x.sl->d_blob + b0, x.sl->h_blob + b0, (size_t)(b1 - b0), hipMemcpyHostToDevice, x.s->copy_stream);
     if (e != hipSuccess) x.err.store((int)e, std::memory_order_relaxed);
     const uint64_t ns = (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();

@@ -857,6 +857,36 @@ def test_request_stager_ships_a_request_in_groups_with_either_copy_engine(torch_
     st.close()
 
 
+@pytest.mark.parametrize("copy", ["kernel", "sdma"])
+def test_request_stager_groups_with_one_and_two_byte_tensors(torch_cuda, monkeypatch, copy):
+    """ConcatInputs packs tensors of ANY dtype (concat_inputs_ops.cc:42-77): int8 / uint16 tensors of odd lengths put the
+    boundaries of the stager's groups at arbitrary byte offsets; the copy kernel moves 16-byte words and widens every group's
+    range — the device blob must still be byte-identical to ConcatInputs' output, for every request of a ring that is reused."""
+    import ctypes as C
+    from recom_amd.ops import RequestStager, concat_inputs
+    torch = torch_cuda
+    monkeypatch.setenv("FCP_STAGER_GROUPS", "7")
+    monkeypatch.setenv("FCP_STAGER_GROUPS_ALWAYS", "1")
+    rng = np.random.default_rng(5)
+    st = RequestStager(16 << 20, 64, 128, depth=2, n_threads=5, copy=copy)
+    hip = C.CDLL("libamdhip64.so")
+    for req in range(6):
+        inputs = []
+        for i in range(40 + req):
+            dt = [np.int8, np.uint16, np.float32, np.int64, np.uint8][int(rng.integers(5))]
+            n = int(rng.integers(1, 40_000)) | 1                         # odd element counts
+            inputs.append(rng.integers(0, 100, size=n).astype(dt))
+        blob, offsets, shapes = concat_inputs(inputs)
+        d_ptr, nbytes, off2, shp2 = st.stage(inputs)
+        assert nbytes == blob.nbytes and np.array_equal(off2, offsets) and np.array_equal(shp2, shapes)
+        torch.cuda.synchronize()
+        tmp = torch.empty(nbytes, dtype=torch.int8, device="cuda")
+        assert hip.hipMemcpy(C.c_void_p(tmp.data_ptr()), C.c_void_p(d_ptr), C.c_size_t(nbytes), 3) == 0
+        assert np.array_equal(tmp.cpu().numpy(), blob), req
+    assert st.stats()["copy_calls"] > 6
+    st.close()
+
+
 @pytest.mark.parametrize("zero_copy", [False, True])
 def test_request_stager_turns_sparse_indices_into_row_offsets(torch_cuda, oracle, zero_copy):
     """fcp_stager_stage_ex / FCP_STAGE_SEG_TO_CSR: the sorted row ids of multi-hot features (SparseTensor indices [nnz, 2],
