@@ -561,10 +561,13 @@ int fcp_plan_private_streams_stats(fcp_plan_t *plan, fcp_private_streams_stats_t
 /* The cheap half of the same idea, for callers that OWN their buffers: FCP_ORDER_INPUTS_READY is the caller's promise, for
  * every request of the plan, that when fcp_process_feature_columns is CALLED the blob is complete in device memory and
  * nothing still queued or running on args->stream touches the memory malloc_buff returns.  The fused kernel is then
- * launched without the queue's barrier bit: it may begin while the commands queued in front of it on args->stream still
- * run, so the tail of request k covers the kernel boundary and the dependent front of request k + 1 — on ONE stream,
- * without events or extra streams (S2 back to back: 28.3 -> 26.0-26.5 us per request, 0.60-0.61 of 8 TB/s; Zipf ids
- * 25.4 -> 23.4).  Everything queued BEHIND the kernel on args->stream (the consumer) still waits for it, as any
+ * launched without the queue's barrier bit, so the command processor need not wait for the queue to drain before it takes
+ * the next packet: the BOUNDARY between two requests shrinks — on ONE stream, without events or extra streams (S2 back to
+ * back: 28.3 -> 26.0-26.5 us per request, 0.60-0.61 of 8 TB/s; Zipf ids 25.4 -> 23.4).  What it does NOT do on this runtime
+ * (round 5, scripts/probes/any_order_probe.hip): start the kernel while blocks of its predecessor still run — behind a
+ * kernel whose blocks retire between 10 and 20 us the first block of the next one starts at 21.4 us without the barrier bit,
+ * 22.7 us with it, wave slots free from 10 us on — so there is no overlap of a front with a predecessor's tail, only a
+ * cheaper hand-over.  Everything queued BEHIND the kernel on args->stream (the consumer) still waits for it, as any
  * stream-ordered command waits for all commands before it — which is also why the gain is only there while requests
  * follow each other directly: an ordinary command between two requests (a consumer kernel, an event record) orders
  * the second request behind the first again; private streams (above) are the tool for that pattern.  NOT for

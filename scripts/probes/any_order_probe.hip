@@ -13,6 +13,14 @@ __global__ void spin_kernel(unsigned long long ticks, unsigned long long *t) { /
   while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(4);
   if (threadIdx.x == 0 && blockIdx.x == 0) t[1] = __builtin_amdgcn_s_memrealtime();
 }
+// A with a TAIL: block i spins between ticks / 2 (i = 0) and ticks (the last block): wave slots free up from ticks / 2 on
+__global__ void tail_kernel(unsigned long long ticks, unsigned long long *t) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  if (threadIdx.x == 0 && blockIdx.x == 0) t[0] = t0;
+  const unsigned long long mine = ticks / 2 + ticks / 2 * blockIdx.x / gridDim.x;
+  while (__builtin_amdgcn_s_memrealtime() - t0 < mine) __builtin_amdgcn_s_sleep(4);
+  if (threadIdx.x == 0 && blockIdx.x == gridDim.x - 1) t[1] = __builtin_amdgcn_s_memrealtime();
+}
 __global__ void stamp_kernel(unsigned long long *t) { // B: when did my first block start / my last block end?
   const unsigned long long now = __builtin_amdgcn_s_memrealtime();
   if (threadIdx.x == 0) atomicMin(t + 2, now);
@@ -50,6 +58,20 @@ int main() {
     }
     printf("A %s (20 us spin, %d blocks) -> B %s (2048 blocks): B's first block starts %.2f us after A's start; B's last block ends %.2f us after A's end\n",
            a_any ? "any-order" : "in order", a_small ? 256 : 1024, b_any ? "any-order" : "in order", acc_start / reps, acc_end / reps);
+  }
+  // A with a tail (2048 blocks = every wave slot of the GPU taken; they retire between 10 and 20 us): does B start into the tail?
+  for (int b_any = 0; b_any < 2; ++b_any) {
+    double acc_start = 0, acc_end = 0;
+    const int reps = 50;
+    for (int r = 0; r < reps + 5; ++r) {
+      t[0] = t[1] = 0; t[2] = ~0ull; t[3] = 0;
+      hipExtLaunchKernelGGL(tail_kernel, dim3(2048), dim3(256), 0, s, nullptr, nullptr, 0, ticks, dt);
+      hipExtLaunchKernelGGL(stamp_kernel, dim3(2048), dim3(256), 0, s, nullptr, nullptr, b_any ? (int)hipExtAnyOrderLaunch : 0, dt);
+      CK(hipStreamSynchronize(s));
+      if (r >= 5) { acc_start += ((double)t[2] - (double)t[0]) / 100.0; acc_end += ((double)t[3] - (double)t[1]) / 100.0; }
+    }
+    printf("A in order with a TAIL (2048 blocks retire between 10 and 20 us) -> B %s: B's first block starts %.2f us after A's start; B's last block ends %.2f us after A's last block\n",
+           b_any ? "any-order" : "in order", acc_start / reps, acc_end / reps);
   }
   // same-address atomics: 1024 blocks, one atomic each
   unsigned *ctr, *sink;
