@@ -691,7 +691,7 @@ int finish_geometry(const fcp_plan *p, DynMeta *m) {
       // de-phase the read and write bursts; 8 rows lose to the tail.  Choosing fewer rows per wave for
       // narrow plans so that the grid reaches 8 blocks per CU (round 2: DLRM 896 -> 3584 blocks) made
       // them SLOWER (DLRM 5.0 -> 7.0 us, S2 at batch 128 11.0 -> 11.9 us): a block's fixed staging chain
-      // costs more than the idle CUs, see profiles/HISTORY.md section 4b.
+      // costs more than the idle CUs, see profiles/HISTORY.md, round 2.
       while (rpw < 4 && max_rows >= 32 * rpw) rpw *= 2; // >= 64 rows -> 4, 32..63 -> 2, < 32 -> 1
       static const int forced = [] { // tuning aid: FCP_ROWS_PER_WAVE=1|2|4
         const char *e = std::getenv("FCP_ROWS_PER_WAVE");

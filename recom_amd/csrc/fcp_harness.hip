@@ -10,11 +10,10 @@
 // The arena allocator plays the role of TF's allocator: a ring of pre-allocated
 // arenas, sized so that consecutive requests never write the same bytes while
 // they could still sit in the 256 MiB Infinity Cache.
-// Under FCP_ORDER_INPUTS_READY (kernels launched without the queue's barrier bit) nothing orders request k + ring against
-// request k, which wrote the same arena: the harness relies on the queue processing its packets in order — a kernel's
-// workgroups are dispatched only after every workgroup of the packets in front of it has been dispatched — so request
-// k + 6 cannot begin before requests k .. k + 5 are all at least in their tails; a straggling wave of request k would have
-// to outlive five whole requests.  The harness reads no result of such a run (verify_resident runs in stream order).  A
+// Under FCP_ORDER_INPUTS_READY (kernels launched without the queue's barrier bit) nothing FORMALLY orders request k + ring
+// against request k, which wrote the same arena.  The harness relies on what the queue does in practice: it takes its
+// packets in order and — measured, scripts/probes/any_order_probe.hip — does not start a kernel before the one in front of
+// it has ended, barrier bit or not; request k + 6 follows five whole requests behind request k.  The harness reads no result of such a run (verify_resident runs in stream order).  A
 // caller that consumes results must not copy this: it gives every in-flight request an arena nothing else writes
 // (the promise FCP_ORDER_INPUTS_READY states in fcp_hip.h), e.g. by waiting for request k's completion event before it
 // hands arena k out again.
@@ -325,7 +324,7 @@ int fcp_harness_destroy(fcp_harness *h) {
 // Device-side copy bandwidth probe (float4 copy of `bytes` bytes, `iters` times): the "measured copy
 // peak" the roofline is also quoted against.  One element per thread — the shape that reaches the
 // highest rate on MI355X (6.0-6.25 TB/s read+write; a grid-stride loop over the same buffers only
-// reaches 4.6-4.95 TB/s, scripts/probes/copy_variants.hip, profiles/HISTORY.md section 4).
+// reaches 4.6-4.95 TB/s, scripts/probes/copy_variants.hip, profiles/HISTORY.md, round 1).
 __global__ void __launch_bounds__(256) fcp_copy_probe_kernel(const float4 *__restrict__ src,
                                                              float4 *__restrict__ dst, size_t n) {
   typedef float __attribute__((ext_vector_type(4))) f4;

@@ -766,7 +766,7 @@ __global__ void __launch_bounds__(FCP_BLOCK_THREADS) fcp_dense_kernel(const FcpL
 }
 
 // Table reads a lane of the ragged kernel keeps in flight while it walks a bag (tuning builds:
-// 12 / 16 need 71 / 87 VGPRs and lose more to occupancy than they gain, profiles/HISTORY.md section 4).
+// 12 / 16 need 71 / 87 VGPRs and lose more to occupancy than they gain, profiles/HISTORY.md, round 1).
 #if !defined(FCP_WALK)
 #define FCP_WALK 8
 #endif
@@ -806,7 +806,7 @@ __global__ void __launch_bounds__(FCP_BLOCK_THREADS) fcp_dense_kernel(const FcpL
 // rows behind four barriers, 19.7 KB of LDS); measured against this form on RAGGED,
 // E and F the two are equal within noise (30.3-30.7 us RAGGED): a launch is bounded
 // by its ramp, tail and the ~2.4 us kernel boundary, not by the barriers
-// (profiles/HISTORY.md section 4b).  The wave-scope form stays: 15.1 KB of LDS, one barrier.
+// (profiles/HISTORY.md, round 2).  The wave-scope form stays: 15.1 KB of LDS, one barrier.
 // The kernel is instruction-issue bound rather than HBM bound (rocprofv3: ~490
 // VALU per wave before this layout), hence the pre-scaled 32-bit slot offsets:
 // a table read costs one LDS read, one compare, one 64-bit shift-add, one load.
@@ -1508,9 +1508,11 @@ static thread_local hipEvent_t tl_stop_event = nullptr;
 void fcp_set_stop_event(void *ev) { tl_stop_event = static_cast<hipEvent_t>(ev); }
 bool fcp_stop_event_pending() { return tl_stop_event != nullptr; }
 // FCP_ORDER_INPUTS_READY plans (fcp_plan_set_request_order): the next fused / hybrid launch of this thread goes out WITHOUT
-// the barrier bit (hipExtAnyOrderLaunch): it may start while the commands queued in front of it on the same stream still
-// run — the previous request's kernel above all, whose tail then covers this one's kernel boundary and dependent front
-// (S2: 28.3 -> 26.0-26.5 us per request back to back on one stream, no events, no extra streams).
+// the barrier bit (hipExtAnyOrderLaunch): the command processor need not wait for the queue to drain before it takes the
+// packet, which makes the hand-over between two requests cheaper (S2: 28.3 -> 26.0-26.5 us per request back to back on one
+// stream, no events, no extra streams).  It does NOT start while blocks of the kernel in front of it still run, not even
+// into its tail (round 5, scripts/probes/any_order_probe.hip: 21.4 us after the start of a predecessor whose blocks retire
+// between 10 and 20 us, against 22.7 us with the barrier bit).
 static thread_local int tl_launch_flags = 0;
 void fcp_set_any_order(bool on) { tl_launch_flags = on ? (int)hipExtAnyOrderLaunch : 0; }
 #define FCP_KLAUNCH(KERNEL, GRID, BLOCK, LDS, STREAM, ...)                                      \
@@ -1629,8 +1631,9 @@ int fcp_launch_upload(const void *host_mapped_src, void *dst, size_t bytes, ihip
   return (int)hipGetLastError();
 }
 
-// any_order: FCP_ORDER_INPUTS_READY plans — the pre-pass reads the blob and writes the new arena's scratch only, so it may
-// begin under the tail of the previous request's kernel; the fused kernel behind it keeps the barrier bit and waits for it
+// any_order: FCP_ORDER_INPUTS_READY plans — the pre-pass reads the blob and writes the new arena's scratch only, so it needs
+// no barrier against the previous request's kernel (a cheaper hand-over); the fused kernel behind it keeps the barrier bit
+// and waits for it
 int fcp_launch_segment_offsets(const FcpSegLaunch &L, int n_seg_cols, int max_nnz, ihipStream_t *s, bool any_order) {
   if (n_seg_cols <= 0) return 0;
   const int gx = (max_nnz + 1 + FCP_SEG_IDS_PER_BLOCK - 1) / FCP_SEG_IDS_PER_BLOCK;
