@@ -85,7 +85,7 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])          # 8: the world BASELINE configs[4] names (one node of 8 GPUs)
 def test_row_sharded_exchange_gloo(world, tmp_path):
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     assert all((tmp_path / f"ok{r}").exists() for r in range(world))
