@@ -657,9 +657,9 @@ def test_supervisor_re_admits_a_demoted_caller_when_the_private_streams_win_agai
     from recom_amd import synth
     from recom_amd.harness import ServingHarness
     torch = torch_cuda
-    monkeypatch.setenv("FCP_LANE_FAULT_US", "60")
+    monkeypatch.setenv("FCP_LANE_FAULT_US", "120")
     monkeypatch.setenv("FCP_LANE_SUPERVISE_PERIOD", "192")
-    monkeypatch.setenv("FCP_LANE_KEEP_RATIO", "4.0")
+    monkeypatch.setenv("FCP_LANE_KEEP_RATIO", "3.0")
     model = synth.model_s2(columns=96, vocab=5000, batch=512)
     h = ServingHarness(model, device=0, n_requests=8, arena_ring=6, n_threads=1)
     caller = h.caller_stream()
@@ -668,7 +668,7 @@ def test_supervisor_re_admits_a_demoted_caller_when_the_private_streams_win_agai
     for _ in range(10):
         h.run_private(100, 3)
     st = h.plan.private_streams_stats()
-    assert st["demoted"] == 1 and st["worst_ratio"] > 4.0, st             # 60 us of stall per request against a few us of kernel
+    assert st["demoted"] == 1 and st["worst_ratio"] > 3.0, st             # 120 us of stall per request against ~10 us in stream order
     # the fault is a property of the device's lane pool, read when the mode is set: another plan on the device clears it
     monkeypatch.delenv("FCP_LANE_FAULT_US")
     other = ServingHarness(model, device=0, n_requests=2, arena_ring=2, n_threads=1, tables=h.tables)
