@@ -595,6 +595,7 @@ def test_supervisor_demotes_a_caller_whose_private_streams_stop_overlapping(torc
     from recom_amd.harness import ServingHarness
     from recom_amd.ops import FeatureColumnProcess
     torch = torch_cuda
+    monkeypatch.delenv("FCP_LANE_SUPERVISE", raising=False)              # (the supervisor on, whatever the environment says)
     monkeypatch.setenv("FCP_LANE_FAULT_US", "60")
     monkeypatch.setenv("FCP_LANE_SUPERVISE_PERIOD", "256")               # evaluations at request 1, 1 + 256 (+ their windows), ...
     model = synth.model_s2(columns=96, vocab=5000, batch=512)
@@ -657,6 +658,7 @@ def test_supervisor_re_admits_a_demoted_caller_when_the_private_streams_win_agai
     from recom_amd import synth
     from recom_amd.harness import ServingHarness
     torch = torch_cuda
+    monkeypatch.delenv("FCP_LANE_SUPERVISE", raising=False)
     monkeypatch.setenv("FCP_LANE_FAULT_US", "120")
     monkeypatch.setenv("FCP_LANE_SUPERVISE_PERIOD", "192")
     monkeypatch.setenv("FCP_LANE_KEEP_RATIO", "3.0")
