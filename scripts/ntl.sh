@@ -1,6 +1,7 @@
 #!/bin/bash
 # GPU box: default build (plain table loads) vs build/ntl (-DFCP_NT_LOADS), interleaved.
-cd $GRAFT_REPO_ROOT
+: "${GRAFT_REPO_ROOT:?run on a gpurun box (or export GRAFT_REPO_ROOT)}"
+cd "$GRAFT_REPO_ROOT" || exit 1
 one() { python bench.py --no-cpu-baseline --steps 1000 "$@" 2>/dev/null | python -c "import sys,json; r=json.loads(sys.stdin.read()); print(round(r['ms_per_step']*1e3,2), 'overlapped', round((r.get('overlapped') or {}).get('us_per_request',0),2))"; }
 for round in 1 2; do
   for v in plain ntl; do

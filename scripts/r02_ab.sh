@@ -1,7 +1,8 @@
 #!/bin/bash
 # Round 2: interleaved A/B of builds on S2 (fcp_bench, single stream), then the block timeline of the
 # current build (diagnostic build/stamps).  Usage: r02_ab.sh [build dirs...]   (default: build/r01 recom_amd)
-cd $GRAFT_REPO_ROOT
+: "${GRAFT_REPO_ROOT:?run on a gpurun box (or export GRAFT_REPO_ROOT)}"
+cd "$GRAFT_REPO_ROOT" || exit 1
 BUILDS=${*:-build/r01 recom_amd}
 us() { sed 's/.*"dev_us_per_step": \([0-9.]*\).*/\1/'; }
 for round in 1 2 3; do

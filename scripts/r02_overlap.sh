@@ -1,7 +1,8 @@
 #!/bin/bash
 # Round 2: why does the 3-worker pass of bench.py (25.9 us) trail fcp_bench --threads 3 (23.2 us)?  Hardware
 # queues (GPU_MAX_HW_QUEUES), and the sc1-nt store policy across all workloads.
-cd $GRAFT_REPO_ROOT
+: "${GRAFT_REPO_ROOT:?run on a gpurun box (or export GRAFT_REPO_ROOT)}"
+cd "$GRAFT_REPO_ROOT" || exit 1
 ov() { python3 bench.py --no-cpu-baseline --steps 600 --warmup 100 "$@" 2>/dev/null | python3 -c "
 import json,sys
 r=json.loads(sys.stdin.readline()); o=r.get('overlapped_serving') or {}

@@ -1,6 +1,7 @@
 #!/bin/bash
 # RAGGED with SparseTensor indices: builds of the segment-offset pre-pass, interleaved (single stream / overlapped).
-cd $GRAFT_REPO_ROOT
+: "${GRAFT_REPO_ROOT:?run on a gpurun box (or export GRAFT_REPO_ROOT)}"
+cd "$GRAFT_REPO_ROOT" || exit 1
 one() { local d=$1; shift; if [ "$d" != product ]; then export FCP_LIB_DIR=$GRAFT_REPO_ROOT/$d; else unset FCP_LIB_DIR; fi
   python3 bench.py --workload ragged --no-cpu-baseline --steps 800 --warmup 100 "$@" 2>/dev/null | python3 -c "
 import json,sys

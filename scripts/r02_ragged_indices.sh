@@ -1,6 +1,7 @@
 #!/bin/bash
 # RAGGED (BASELINE configs[3]) with SparseTensor indices: pre-pass launch vs in-block search, single stream and overlapped.
-cd $GRAFT_REPO_ROOT
+: "${GRAFT_REPO_ROOT:?run on a gpurun box (or export GRAFT_REPO_ROOT)}"
+cd "$GRAFT_REPO_ROOT" || exit 1
 one() { python3 bench.py --workload ragged --no-cpu-baseline --steps 800 --warmup 100 "$@" 2>/dev/null | python3 -c "
 import json,sys
 r=json.loads(sys.stdin.readline()); o=r.get('overlapped_serving') or {}

@@ -1,7 +1,8 @@
 #!/bin/bash
 # Round 2, experiment 2: cost of the front of a launch (kernel arguments in host vs device memory,
 # dependent-load hops at launch start), and the sc1-nt store policy re-checked after the hazard fix.
-cd $GRAFT_REPO_ROOT
+: "${GRAFT_REPO_ROOT:?run on a gpurun box (or export GRAFT_REPO_ROOT)}"
+cd "$GRAFT_REPO_ROOT" || exit 1
 us() { sed 's/.*"dev_us_per_step": \([0-9.]*\).*/\1/'; }
 for k in 0 1; do
   echo "== HIP_FORCE_DEV_KERNARG=$k"

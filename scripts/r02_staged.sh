@@ -1,7 +1,8 @@
 #!/bin/bash
 # RAGGED and the reference's models E / F: requests resident as they arrive (SparseTensor indices) vs as the staging step leaves
 # them (--staged: ids int32, row ids -> CSR offsets on the host).  Single stream / overlapped, interleaved.
-cd $GRAFT_REPO_ROOT
+: "${GRAFT_REPO_ROOT:?run on a gpurun box (or export GRAFT_REPO_ROOT)}"
+cd "$GRAFT_REPO_ROOT" || exit 1
 one() { python3 bench.py --no-cpu-baseline --steps 800 --warmup 100 "$@" 2>/dev/null | python3 -c "
 import json,sys
 r=json.loads(sys.stdin.readline()); o=r.get('overlapped_serving') or {}

@@ -4,7 +4,8 @@
 # Interleaved rounds of the product build (nt stores) against plain / sc1 / sc0 sc1 / sc1 nt / sc0 sc1 nt
 # builds, S2 at batch 512 and 2048, single stream; plus FCP_DYN_UPLOAD=kernel (descriptors in ordinary
 # instead of fine-grained device memory).
-cd $GRAFT_REPO_ROOT
+: "${GRAFT_REPO_ROOT:?run on a gpurun box (or export GRAFT_REPO_ROOT)}"
+cd "$GRAFT_REPO_ROOT" || exit 1
 us() { sed 's/.*"dev_us_per_step": \([0-9.]*\).*/\1/'; }
 for round in 1 2; do
   for v in recom_amd build/stplain build/st2 build/st3 build/st4 build/st5; do

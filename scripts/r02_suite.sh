@@ -1,7 +1,8 @@
 #!/bin/bash
 # Round 2: RAGGED, reference models E / F and DLRM through bench.py (single stream + the 3-worker pass, no
 # CPU baseline), interleaved over builds.  Usage: r02_suite.sh [build dirs...] ("product" = recom_amd/)
-cd $GRAFT_REPO_ROOT
+: "${GRAFT_REPO_ROOT:?run on a gpurun box (or export GRAFT_REPO_ROOT)}"
+cd "$GRAFT_REPO_ROOT" || exit 1
 BUILDS=${*:-product}
 one() { # $1 = lib dir or "product", rest = bench args
   local d=$1; shift

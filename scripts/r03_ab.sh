@@ -1,6 +1,7 @@
 #!/bin/bash
 # Round 3: interleaved A/B of builds through bench.py (single stream + overlapped).  Usage: r03_ab.sh "<build dirs>" "<workload args>"...
-cd $GRAFT_REPO_ROOT
+: "${GRAFT_REPO_ROOT:?run on a gpurun box (or export GRAFT_REPO_ROOT)}"
+cd "$GRAFT_REPO_ROOT" || exit 1
 BUILDS=$1; shift
 one() { local d=$1; shift; if [ "$d" != product ]; then export FCP_LIB_DIR=$GRAFT_REPO_ROOT/$d; else unset FCP_LIB_DIR; fi
   python3 bench.py --no-cpu-baseline --no-pcie --steps 800 --warmup 100 $* 2>/dev/null | python3 -c "

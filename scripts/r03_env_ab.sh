@@ -1,6 +1,7 @@
 #!/bin/bash
 # GPU box: one library, an environment switch on / off, interleaved.  Usage: r03_env_ab.sh VAR "<bench args>"...
-cd $GRAFT_REPO_ROOT
+: "${GRAFT_REPO_ROOT:?run on a gpurun box (or export GRAFT_REPO_ROOT)}"
+cd "$GRAFT_REPO_ROOT" || exit 1
 VAR=$1; shift
 one() { python3 bench.py --no-cpu-baseline --no-pcie --no-verify --steps 800 --warmup 100 $* 2>/dev/null | python3 -c "
 import json,sys

@@ -1,6 +1,7 @@
 #!/bin/bash
 # GPU box: one library, an environment variable at several values, interleaved.  Usage: r03_envval_ab.sh VAR "v1 v2 ..." "<bench args>"...
-cd $GRAFT_REPO_ROOT
+: "${GRAFT_REPO_ROOT:?run on a gpurun box (or export GRAFT_REPO_ROOT)}"
+cd "$GRAFT_REPO_ROOT" || exit 1
 VAR=$1; VALS=$2; shift 2
 one() { python3 bench.py --no-cpu-baseline --no-pcie --no-verify --steps 800 --warmup 100 $* 2>/dev/null | python3 -c "
 import json,sys

@@ -1,7 +1,8 @@
 #!/bin/bash
 # Round 3: where the PCIe-inclusive S2 request spends its time (fcp_bench --h2d 1 --narrow 1): stager phase timers
 # (FCP_STAGER_STATS), host time of the two calls, by pack threads, pinned / unpinned workers, copy vs zero copy.
-cd $GRAFT_REPO_ROOT
+: "${GRAFT_REPO_ROOT:?run on a gpurun box (or export GRAFT_REPO_ROOT)}"
+cd "$GRAFT_REPO_ROOT" || exit 1
 export FCP_STAGER_STATS=1
 for round in 1 2; do
   for t in 1 4 8 16 32; do

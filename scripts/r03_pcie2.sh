@@ -1,7 +1,8 @@
 #!/bin/bash
 # Round 3, second look at the PCIe-inclusive S2 request: which runtime call of the enqueue phase takes the time, and does it
 # follow the spinning pack workers (FCP_PACK_SPINS) or the ring depth?
-cd $GRAFT_REPO_ROOT
+: "${GRAFT_REPO_ROOT:?run on a gpurun box (or export GRAFT_REPO_ROOT)}"
+cd "$GRAFT_REPO_ROOT" || exit 1
 export FCP_STAGER_STATS=1
 run() { echo "== $*"; "$@" 2>&1 | grep -E "pcie_inclusive|fcp_stager"; }
 B="./recom_amd/fcp_bench --h2d 1 --narrow 1 --steps 400 --warmup 50 --verify 0"

@@ -1,6 +1,7 @@
 #!/bin/bash
 # GPU box: PCIe-inclusive S2 with 1 / 2 / 3 serve workers (each its own stager + stream), pack threads 8 / 16.
-cd $GRAFT_REPO_ROOT
+: "${GRAFT_REPO_ROOT:?run on a gpurun box (or export GRAFT_REPO_ROOT)}"
+cd "$GRAFT_REPO_ROOT" || exit 1
 for rep in 1 2; do
 for w in 1 2 3; do
   for pt in 8 16; do

@@ -2,7 +2,8 @@
 # Round 3: interleaved A/B of builds on the ragged path (bench.py, single stream + overlapped): RAGGED as staged (the
 # default: CSR offsets + int32 ids made by ConcatInputs on the host), as delivered (SparseTensor indices on the device),
 # with long bags, and the reference's model E.  Usage: r03_ragged_ab.sh [build dirs...]   (default: build/r02 product)
-cd $GRAFT_REPO_ROOT
+: "${GRAFT_REPO_ROOT:?run on a gpurun box (or export GRAFT_REPO_ROOT)}"
+cd "$GRAFT_REPO_ROOT" || exit 1
 BUILDS=${*:-build/r02 product}
 one() { local d=$1; shift; if [ "$d" != product ]; then export FCP_LIB_DIR=$GRAFT_REPO_ROOT/$d; else unset FCP_LIB_DIR; fi
   python3 bench.py --no-cpu-baseline --no-pcie --steps 600 --warmup 100 "$@" 2>/dev/null | python3 -c "

@@ -1,6 +1,7 @@
 #!/bin/bash
 # GPU box: PCIe-inclusive S2 (host int64 ids -> stager (narrow) -> H2D -> kernel), phase timers per pack-thread count
-cd $GRAFT_REPO_ROOT
+: "${GRAFT_REPO_ROOT:?run on a gpurun box (or export GRAFT_REPO_ROOT)}"
+cd "$GRAFT_REPO_ROOT" || exit 1
 B=${FCP_LIB_DIR:-./recom_amd}
 for rep in 1 2; do
 for pt in 1 4 8 16 32; do

@@ -1,6 +1,7 @@
 #!/bin/bash
 # GPU box: wake-up style x spin window of the stager's pack pool (S2, narrow, h2d copy), interleaved in one call
-cd $GRAFT_REPO_ROOT
+: "${GRAFT_REPO_ROOT:?run on a gpurun box (or export GRAFT_REPO_ROOT)}"
+cd "$GRAFT_REPO_ROOT" || exit 1
 for rep in 1 2; do
 for pt in 8 16; do
 for fan in 0 2 4; do

@@ -1,6 +1,7 @@
 #!/bin/bash
 # GPU box: how often does hipMemcpyAsync block inside the stager, and what does it depend on?  (S2, narrow, h2d copy)
-cd $GRAFT_REPO_ROOT
+: "${GRAFT_REPO_ROOT:?run on a gpurun box (or export GRAFT_REPO_ROOT)}"
+cd "$GRAFT_REPO_ROOT" || exit 1
 run() { # label, env..., args
   local label=$1; shift
   for rep in 1 2 3 4 5; do

@@ -1,6 +1,7 @@
 #!/bin/bash
 # GPU box: the stager's zero-copy fallback against the blocking-hipMemcpyAsync anomaly (provoked with unpinned pack workers)
-cd $GRAFT_REPO_ROOT
+: "${GRAFT_REPO_ROOT:?run on a gpurun box (or export GRAFT_REPO_ROOT)}"
+cd "$GRAFT_REPO_ROOT" || exit 1
 for rep in 1 2 3 4 5 6 7 8; do
   for fb in on off; do
     if [ $fb = off ]; then export FCP_STAGER_NO_FALLBACK=1; else unset FCP_STAGER_NO_FALLBACK; fi

@@ -1,6 +1,7 @@
 #!/bin/bash
 # GPU box: regenerate every round-1 record under gpurun_out/refresh/ (copied into profiles/ afterwards).
-cd $GRAFT_REPO_ROOT
+: "${GRAFT_REPO_ROOT:?run on a gpurun box (or export GRAFT_REPO_ROOT)}"
+cd "$GRAFT_REPO_ROOT" || exit 1
 O=$GRAFT_REPO_ROOT/gpurun_out/refresh
 mkdir -p $O
 python bench.py > $O/r01_bench_s2.json 2> $O/bench_s2.err

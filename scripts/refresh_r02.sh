@@ -1,8 +1,9 @@
 #!/bin/bash
 # GPU box: regenerate the round-2 records under gpurun_out/refresh2/ (copied into profiles/ afterwards).
-cd $GRAFT_REPO_ROOT
+: "${GRAFT_REPO_ROOT:?run on a gpurun box (or export GRAFT_REPO_ROOT)}"
+cd "$GRAFT_REPO_ROOT" || exit 1
 O=$GRAFT_REPO_ROOT/gpurun_out/refresh2
-rm -rf $O; mkdir -p $O
+rm -rf "${O:?}"; mkdir -p "$O"
 # PMC passes first (their own runs: --pmc with --kernel-trace only): the bench lines below report
 # roofline.traffic from profiles/traffic.json, which must describe the kernels of this build
 bash scripts/pmc.sh refresh2 > $O/r02_s2_pmc_fcp_bench.txt 2>&1
@@ -33,5 +34,5 @@ python3 scripts/summarize_prof.py $O/r > $O/r02_ragged_kernel_trace_stats.txt 2>
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/e/trace -- python3 $GRAFT_REPO_ROOT/bench.py --workload e --steps 300 --warmup 50 --no-cpu-baseline --no-overlap > $O/trace_e.log 2>&1 )
 python3 scripts/summarize_prof.py $O/e > $O/r02_ae_model_e_kernel_trace_stats.txt 2>&1
 find $O -name "*.csv" -size +2M -delete
-rm -rf $O/r $O/e
+rm -rf "${O:?}"/r $O/e
 ls -la $O

@@ -1,8 +1,9 @@
 #!/bin/bash
 # GPU box: regenerate the round-3 records under gpurun_out/refresh3/ (copied into profiles/ afterwards).
-cd $GRAFT_REPO_ROOT
+: "${GRAFT_REPO_ROOT:?run on a gpurun box (or export GRAFT_REPO_ROOT)}"
+cd "$GRAFT_REPO_ROOT" || exit 1
 O=$GRAFT_REPO_ROOT/gpurun_out/refresh3
-rm -rf $O; mkdir -p $O
+rm -rf "${O:?}"; mkdir -p "$O"
 # PMC passes first (their own runs: --pmc with --kernel-trace only): the bench lines below report
 # roofline.traffic from profiles/traffic.json, which must describe the kernels of this build
 bash scripts/pmc.sh refresh3 > $O/r03_s2_pmc_fcp_bench.txt 2>&1
@@ -27,5 +28,5 @@ for w in s2 ragged "ragged --as-delivered" e; do
   python3 scripts/summarize_prof.py $O/t_$tag > $O/r03_${tag}_kernel_trace_stats.txt  # (ragged --as-delivered is renamed r03_ragged_as_delivered_… when copied) 2>&1
 done
 find $O -name "*.csv" -size +2M -delete
-rm -rf $O/t_*
+rm -rf "${O:?}"/t_*
 ls -la $O

@@ -1,8 +1,9 @@
 #!/bin/bash
 # GPU box: regenerate the round-4 records under gpurun_out/refresh4/ (copied into profiles/ afterwards).
-cd $GRAFT_REPO_ROOT
+: "${GRAFT_REPO_ROOT:?run on a gpurun box (or export GRAFT_REPO_ROOT)}"
+cd "$GRAFT_REPO_ROOT" || exit 1
 O=$GRAFT_REPO_ROOT/gpurun_out/refresh4
-rm -rf $O; mkdir -p $O
+rm -rf "${O:?}"; mkdir -p "$O"
 fail() { echo "refresh_r04: $*" >&2; exit 1; }
 # PMC passes first (their own runs: --pmc with --kernel-trace only): the bench lines below report
 # roofline.traffic from profiles/traffic.json, which must describe the kernels of this build
@@ -39,5 +40,5 @@ python scripts/r04_private_sweep.py --combos 2x2,2x3,3x3,3x4 --nowait 0,1 > $O/r
 python scripts/r04_private_sweep.py --workload ragged --combos 2x3,3x3,3x4 --nowait 0 >> $O/r04_private_streams_sweep.txt 2>&1
 python scripts/r04_private_sweep.py --workload e --combos 2x3,3x3 --nowait 0 >> $O/r04_private_streams_sweep.txt 2>&1
 find $O -name "*.csv" -size +2M -delete
-rm -rf $O/t_*
+rm -rf "${O:?}"/t_*
 ls -la $O

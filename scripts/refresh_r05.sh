@@ -1,8 +1,9 @@
 #!/bin/bash
 # GPU box: regenerate the round-5 records under gpurun_out/refresh5/ (copied into profiles/ afterwards).
-cd $GRAFT_REPO_ROOT
+: "${GRAFT_REPO_ROOT:?run on a gpurun box (or export GRAFT_REPO_ROOT)}"
+cd "$GRAFT_REPO_ROOT" || exit 1
 O=$GRAFT_REPO_ROOT/gpurun_out/refresh5
-rm -rf $O; mkdir -p $O
+rm -rf "${O:?}"; mkdir -p "$O"
 fail() { echo "refresh_r05: $*" >&2; exit 1; }
 # PMC passes first (their own runs: --pmc with --kernel-trace only): the bench lines below report
 # roofline.traffic from profiles/traffic.json, which must describe the kernels of this build
@@ -38,5 +39,5 @@ trace e --workload e
 python scripts/probes/caller_threads_grid.py s2 > $O/grid_s2.json 2>/dev/null
 python scripts/probes/caller_threads_grid.py ragged > $O/grid_ragged.json 2>/dev/null
 find $O -name "*.csv" -size +2M -delete
-rm -rf $O/t_*
+rm -rf "${O:?}"/t_*
 ls -la $O
