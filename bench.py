@@ -47,6 +47,9 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+PREWARM_S = 0.25       # untimed pre-warm in front of the timed region, seconds of the same requests (whatever --warmup is)
+PREWARM_CHUNK = 256    # ... issued in calls of this many requests
+REPEATS = 5            # the K timed steps are repeated this many times; the median repeat is the one reported
 METRIC = "inference QPS + p50 latency, 1000-col synth model, batch 512, 1\u00d7MI355X"  # == BASELINE.json "metric"
 try:
     with open(os.path.join(ROOT, "BASELINE.json")) as _f:
@@ -160,13 +163,15 @@ def host_staging_cost(raw_model, n_requests: int = 8):
             "inputs": n}
 
 
-def cpu_baseline(model, budget_s: float = 20.0, sample_columns: int = 200):
+def cpu_baseline(model, budget_s: float = 20.0, sample_columns: int = 0):
     """The CPU oracle (oracle/: a C port of the TF-CPU semantics of the reference's path; TensorFlow is absent) on this
-    box's host cores over a bounded sample: the first `sample_columns` columns of the workload at full batch, scaled to
-    the whole model.  ONE sweep decides everything that is reported: every worker count serves for the same duration
-    (orc_serve_for: independent single-threaded workers, the reference harness' serve_workers on TF-CPU), `value` is the
-    best entry of that sweep and the 32-core / all-core figures are entries of the same sweep — they cannot disagree.
-    The intra-request mode (one request at a time, OpenMP over its columns) is measured beside it and reported."""
+    box's host cores: the WHOLE workload when its tables fit host memory (S2: 120 GB; `sampled: false`), else the first k
+    columns at full batch, scaled to the whole model (`sampled: true`).  ONE sweep decides everything that is reported:
+    every worker count serves for the same duration (orc_serve_for: independent single-threaded workers, the reference
+    harness' serve_workers on TF-CPU).  `value` is the 32-worker entry — the reference's TF-CPU budget is 32 cores
+    (AE/build_and_run.py:57) — with the best of the sweep and the all-core entry beside it; they are entries of the same
+    sweep and cannot disagree.  The intra-request mode (one request at a time, OpenMP over its columns) is measured beside
+    it and reported."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import fcp_oracle
     from recom_amd.ops import concat_inputs
@@ -174,21 +179,26 @@ def cpu_baseline(model, budget_s: float = 20.0, sample_columns: int = 200):
 
     cores = len(os.sched_getaffinity(0))
     spec = model.spec
-    # host RAM bounds the sample: 200 S2 columns are 24 GB of tables; stay under a quarter of what is free
+    # host RAM bounds the sample: the tables (S2: 120 GB) + 8 GB of requests / outputs within 80 % of what is available
     try:
         import psutil
         avail = psutil.virtual_memory().available
     except Exception:
         avail = 64 << 30
-    k = min(sample_columns, spec.n_columns)
+    if os.environ.get("FCP_BENCH_CPU_RAM_BYTES"):    # testing aid: pretend the host is this small
+        avail = int(os.environ["FCP_BENCH_CPU_RAM_BYTES"])
+    k = min(sample_columns or spec.n_columns, spec.n_columns)
     per_col = [t.vocab * t.dim * 4 for t in model.tables]
-    while k > 8 and sum(per_col[:1 + max(c.table_input for c in spec.columns[:k] if c.table_input >= 0)]) > avail // 4:
+
+    def table_bytes(k_):
+        return sum(per_col[:1 + max([c.table_input for c in spec.columns[:k_] if c.table_input >= 0] or [-1])])
+    while k > 8 and table_bytes(k) + (8 << 30) > 0.8 * avail:
         k //= 2
     cols = spec.columns[:k]
     n_host = 1 + max(max(c.ids_input, c.seg_input) for c in cols)
     n_tab = 1 + max(c.table_input for c in cols)
-    sub = PlanSpec(cols, spec.host_input_ranks[:n_host], spec.host_input_elem_sizes[:n_host], n_tab,
-                   n_groups=1, n_symbols=spec.n_symbols)
+    sub = spec if k == spec.n_columns else PlanSpec(cols, spec.host_input_ranks[:n_host], spec.host_input_elem_sizes[:n_host], n_tab,
+                                                    n_groups=1, n_symbols=spec.n_symbols)
     # 64 distinct requests, rotated, so that the touched rows are not cache-resident
     reqs = [model.make_request(12345 + i) for i in range(64)]
     packed = [concat_inputs(r.inputs[:n_host]) for r in reqs]
@@ -196,13 +206,15 @@ def cpu_baseline(model, budget_s: float = 20.0, sample_columns: int = 200):
     blob, offsets, shapes = packed[0]
     # table VALUES do not affect CPU time; every page is written (an untouched page would read from the shared zero page)
     # and it is written from all cores at once, so that on a two-socket host a table's pages are spread over both sockets'
-    # memory instead of landing next to this thread (a NUMA-blind baseline collapsed from 0.56 M at 16 workers to 0.12 M at 256)
+    # memory instead of landing next to this thread
     orc = fcp_oracle.COracle()
+    t_fill = time.perf_counter()
     tables = []
     for t in model.tables[:n_tab]:
         a = np.empty((t.vocab, t.dim), np.float32)
         orc.fill_parallel(a, 0.5)
         tables.append(a)
+    t_fill = time.perf_counter() - t_fill
     plan = sub.to_dict()
     rows = sub.group_rows(0, shapes, req.symbols)
     scale = spec.n_columns / k
@@ -215,8 +227,9 @@ def cpu_baseline(model, budget_s: float = 20.0, sample_columns: int = 200):
         sweep[t] = rows * done / sec / scale
         detail[t] = {"requests": done, "seconds": sec}
     best_t = max(sweep, key=sweep.get)
+    head_t = 32 if 32 in sweep else best_t           # the reference's TF-CPU budget (AE/build_and_run.py:57)
     # intra-request mode, the same duration in total
-    out = [np.zeros((rows, sub.group_width(0)), np.float32)]
+    out = [np.zeros((sub.group_rows(g, shapes, req.symbols), sub.group_width(g)), np.float32) for g in range(sub.n_groups)]
     intra = {}
     intra_cands = sorted({t for t in (8, 32, cores) if t <= max(cores, 1)})
     for t in intra_cands:
@@ -230,15 +243,18 @@ def cpu_baseline(model, budget_s: float = 20.0, sample_columns: int = 200):
                 break
         intra[t] = rows * n / el / scale
     return {
-        "value": sweep[best_t], "unit": "inferences/s", "cores": best_t, "kind": "port",
-        # the reference's TF-CPU budget is 32 cores (AE/build_and_run.py:57); same sweep
+        "value": sweep[head_t], "unit": "inferences/s", "cores": head_t, "kind": "port", "sampled": k != spec.n_columns,
+        "best_of_sweep": {"cores": best_t, "inferences_per_s": sweep[best_t]},
         "cores_32_inferences_per_s": sweep.get(32), "all_cores": cores, "all_cores_inferences_per_s": sweep.get(cores),
         "serve_workers_sweep": {str(t): v for t, v in sorted(sweep.items())},
         "intra_request_openmp_inferences_per_s": {str(t): v for t, v in sorted(intra.items())},
-        "sample": f"first {k} of {spec.n_columns} columns at batch {rows} ({sum(a.nbytes for a in tables) / 1e9:.1f} GB of host tables), "
-                  f"{len(packed)} distinct requests rotated, scaled x{scale:.1f} to the whole model; one sweep of independent "
+        "host_table_fill_s": t_fill,
+        "sample": (f"all {spec.n_columns} columns" if k == spec.n_columns else f"first {k} of {spec.n_columns} columns, scaled x{scale:.1f} to the whole model,")
+                  + f" at batch {rows} ({sum(a.nbytes for a in tables) / 1e9:.1f} GB of host tables), "
+                  f"{len(packed)} distinct requests rotated; one sweep of independent "
                   f"single-threaded workers ({serve_cands}), {per:.1f} s each (requests completed: "
-                  f"{ {t: d['requests'] for t, d in detail.items()} }); value = the best of that sweep ({best_t} workers); "
+                  f"{ {t: d['requests'] for t, d in detail.items()} }); value = the {head_t}-worker entry of that sweep (the reference's "
+                  f"TF-CPU budget, AE/build_and_run.py:57), best_of_sweep beside it; "
                   f"{cores} cores visible; tables first-touched from all cores (pages spread over the sockets); C port of TF-CPU semantics (TensorFlow absent)",
     }
 
@@ -333,6 +349,12 @@ def main():
                     help="distinct resident requests cycled through (default: 16; 64 for the dynamic-shape workloads ragged / e / f, "
                          "more than the plan's 32 descriptor slots: every request brings shapes that are NOT resident, as real "
                          "dynamic-shape traffic does)")
+    ap.add_argument("--arena-ring", type=int, default=1,
+                    help="output arenas the timed loop rotates through.  1 (default) = the reference's allocation pattern: the op takes "
+                         "its arena from allocate_output(2) once per Compute (feature_column_process_op_gpu.cu.cc:107-111) and a one-thread "
+                         "serving loop (benchmark_multi_thread, recom_examples.patch:193-216) gets back the block the previous request "
+                         "freed; 6 = what rounds 1-5 timed (every output line evicted between two writes).  `arena_reuse` reports 1 / 2 / 6 "
+                         "side by side whatever this is")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) normally; gloo only to exercise the N>1 control flow on a 1-GPU box")
     args = ap.parse_args()
 
@@ -425,7 +447,7 @@ def main():
             dist.destroy_process_group()
         return
 
-    h = ServingHarness(model, device=local_rank, n_requests=args.requests, arena_ring=6, n_threads=args.threads,
+    h = ServingHarness(model, device=local_rank, n_requests=args.requests, arena_ring=args.arena_ring, n_threads=args.threads,
                        seed0=1000 * rank)
     bytes_alg = h.algorithmic_bytes()
     # a wrong kernel is not timed: every resident request is served once and compared with the closed-form tables (no
@@ -433,23 +455,55 @@ def main():
     verified = h.verify_resident() if not args.no_verify else {"checked": 0, "note": "--no-verify"}
 
     h.run(max(args.warmup, 1))                       # W untimed warm-up steps
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    wall_ms, dev_ms, _ = h.run(args.steps)           # exactly K timed steps (native loop, ends with a stream sync)
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    # ... and, whatever --warmup says, an untimed pre-warm of >= PREWARM_S of the same requests: the reference's protocol
+    # discards >= 10 iterations (recom_examples.patch:110, 186-207) so that clocks, queues and TLBs are those of a serving
+    # process; a 5-request warm-up in front of a 0.6-ms region measured the clock ramp (r05: 31.2 us by the driver's
+    # --steps 20 against 28.6 over 2000 steps)
+    extra_warmup, t_end = 0, time.perf_counter() + PREWARM_S
+    while time.perf_counter() < t_end:
+        h.run(PREWARM_CHUNK)
+        extra_warmup += PREWARM_CHUNK
+    # exactly K timed steps, REPEATS times, each repeat bracketed by barrier + synchronize on both sides and reduced to the
+    # MAX over ranks; `ms_per_step` / `value` = the MEDIAN repeat, min / max beside it
+    repeats = []
+    for _ in range(REPEATS):
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        wall_ms, dev_ms, _ = h.run(args.steps)       # exactly K timed steps (native loop, ends with a stream sync)
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        if dist:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        repeats.append((elapsed, dev_ms, wall_ms))
+    repeats.sort()
+    elapsed, dev_ms, wall_ms = repeats[len(repeats) // 2]
 
     # latency percentiles: separate pass with one HIP event pair per request, at least 200 samples
     # whatever --steps is
     _, _, it = h.run(min(max(args.steps, 200), 500), per_request=True)
+    # What the output costs by reuse distance of the arena: the same loop over rings of 1 / 2 / 6 arenas,
+    # the library choosing its store policy per request (plain stores into an arena one of the plan's last two requests wrote,
+    # nt / sc1 nt otherwise: store_policy_for, fcp_api.hip).  Extra field only; `value` is the ring --arena-ring names.
+    arena_reuse = None
+    if args.threads == 1 and not dist and not args.no_overlap:
+        arena_reuse = {"what": "stream order, one serve worker, HIP-event us per request by the number of output arenas the loop rotates "
+                               "through; 1 = TF's allocate_output handing a one-thread serving loop the block it just freed; the library "
+                               "picks the store policy from the arena's reuse (profiles/r06_arena_reuse_store_policy.txt)",
+                       "value_used_ring": args.arena_ring}
+        ar_steps = max(args.steps, 800)
+        for ring in (1, 2, 6):
+            ha = ServingHarness(model, device=local_rank, n_requests=args.requests, arena_ring=ring, n_threads=1, tables=h.tables,
+                                seed0=1000 * rank)
+            ha.run(max(args.warmup, 200))
+            _, a_dev, _ = ha.run(ar_steps)
+            arena_reuse[f"ring_{ring}_us"] = a_dev * 1e3 / ar_steps
+            ha.close()
     # overlapped serving (the reference harness' serve_workers): independent requests on
     # 3 streams hide each launch's ramp / tail behind its neighbours.  Extra field only.
     overlap = None
@@ -573,12 +627,19 @@ def main():
                   f"inference QPS + p50 latency, {model.name} config{' (staged request form: as Addons>ConcatInputs leaves it in HBM)' if args.staged and raw_model is not model else ''}, batch {batch}, 1xMI355X",
         "value": value, "unit": "inferences/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+        "extra_warmup_requests": extra_warmup, "timed_region_s": elapsed,
+        "repeats": {"n": len(repeats), "reported": "median", "ms_per_step_min": repeats[0][0] * 1e3 / steps_total,
+                    "ms_per_step_max": repeats[-1][0] * 1e3 / steps_total,
+                    "ms_per_step_all": [r[0] * 1e3 / steps_total for r in repeats],
+                    "kernel_avg_us_all": [r[1] * 1e3 / args.steps for r in repeats],
+                    "what": f"exactly --steps requests timed {len(repeats)} times (barrier + synchronize on both sides of each, max over "
+                            f"ranks) behind >= {PREWARM_S} s of untimed requests; ms_per_step / value / roofline are the median repeat"},
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{model.name}: {model.description}", "batch": batch,
                    "columns": model.spec.n_columns, "table_bytes": model.table_bytes(),
                    "parallelism": f"{world} replica(s), requests sharded across ranks, no collective (placement gate: "
                                   f"{model.table_bytes() / 1e9:.0f} GB of tables fit one GPU)",
-                   "serve_workers": args.threads},
+                   "serve_workers": args.threads, "arena_ring": args.arena_ring},
         "requests_per_s": value / batch,
         "verified": verified,
         "p50_latency_ms": float(np.percentile(it, 50)), "p95_latency_ms": float(np.percentile(it, 95)),
@@ -602,6 +663,8 @@ def main():
             "measured_copy_peak_GBs": copy_probe() / 1e9,
         }
         rec["roofline"]["access_mix"] = access_mix_floor(model, h, bytes_alg, dev_ms_per_req * 1e3)
+        if arena_reuse:
+            rec["arena_reuse"] = arena_reuse
         if overlap:
             overlap["inferences_per_s"] = batch / (overlap["us_per_request"] * 1e-6)
             overlap["aggregate_frac_of_peak"] = bytes_alg["total"] / (overlap["us_per_request"] * 1e-6) / 1e9 / HBM_PEAK_GBS

@@ -756,30 +756,30 @@ static int64_t process_column(const orc_plan_t *p, int32_t k, const int8_t *blob
   return bad;
 }
 
-/* (group, slot)-ordered prefix sums of dims: O(n log n) once per call. */
-static const orc_plan_t *g_sort_plan; /* qsort has no context argument */
+/* (group, slot)-ordered prefix sums of dims: O(n log n) once per call.  The sort keys are copied next to the column
+ * index so that the comparator needs no context: until round 6 it read the plan through a global under
+ * `omp critical`, i.e. every request of every serving worker queued for one lock — bench.py's cpu_baseline fell from
+ * 516 k inferences/s at 16 workers to 151 k at 256. */
+typedef struct { int32_t group, slot, k; } orc_slot_key_t;
 static int cmp_group_slot(const void *a, const void *b) {
-  const orc_column_t *x = &g_sort_plan->columns[*(const int32_t *)a];
-  const orc_column_t *y = &g_sort_plan->columns[*(const int32_t *)b];
-  if (x->concat_group != y->concat_group) return x->concat_group < y->concat_group ? -1 : 1;
-  if (x->concat_slot != y->concat_slot) return x->concat_slot < y->concat_slot ? -1 : 1;
-  return 0;
+  const orc_slot_key_t *x = (const orc_slot_key_t *)a, *y = (const orc_slot_key_t *)b;
+  if (x->group != y->group) return x->group < y->group ? -1 : 1;
+  if (x->slot != y->slot) return x->slot < y->slot ? -1 : 1;
+  return x->k < y->k ? -1 : x->k > y->k;
 }
 
 static void layout_columns(const orc_plan_t *p, int32_t *widths, int32_t *col_offs) {
-  int32_t *order = (int32_t *)malloc(sizeof(int32_t) * (size_t)(p->n_columns + 1));
-  for (int32_t k = 0; k < p->n_columns; ++k) order[k] = k;
-#ifdef _OPENMP
-#pragma omp critical(orc_sort)
-#endif
-  {
-    g_sort_plan = p;
-    qsort(order, (size_t)p->n_columns, sizeof(int32_t), cmp_group_slot);
+  orc_slot_key_t *order = (orc_slot_key_t *)malloc(sizeof(orc_slot_key_t) * (size_t)(p->n_columns + 1));
+  for (int32_t k = 0; k < p->n_columns; ++k) {
+    order[k].group = p->columns[k].concat_group;
+    order[k].slot = p->columns[k].concat_slot;
+    order[k].k = k;
   }
+  qsort(order, (size_t)p->n_columns, sizeof(orc_slot_key_t), cmp_group_slot);
   for (int32_t g = 0; g < p->n_groups; ++g) widths[g] = 0;
   for (int32_t j = 0; j < p->n_columns; ++j) {
-    const orc_column_t *c = &p->columns[order[j]];
-    col_offs[order[j]] = widths[c->concat_group];
+    const orc_column_t *c = &p->columns[order[j].k];
+    col_offs[order[j].k] = widths[c->concat_group];
     widths[c->concat_group] += c->dim;
   }
   free(order);

@@ -385,6 +385,7 @@ struct fcp_plan {
   std::atomic<int64_t> last_work_bytes{0};
   int64_t lane_min_work = 0;
   int32_t request_order = FCP_ORDER_STREAM; // fcp_plan_set_request_order
+  std::atomic<uintptr_t> recent_arena[2] = {}; // the arenas of the last two requests (store_policy_for)
   // Run-time supervision of the lanes (LaneSupervisor below): a verdict is learnt once, a mapping can go bad later (another
   // library of the process creates streams; the runtime re-maps queues): sampled windows of lane requests are timed
   // against the stream-order rate of the same requests and the caller is demoted to its own stream when they lose.
@@ -1277,7 +1278,35 @@ struct SlotUnpin { // every exit path of a request: publish what `done` covers a
   }
 };
 
-void fill_launch(const fcp_plan *p, const DynSlot &s, int kind, const void *blob, void *arena, FcpLaunch *L) {
+// Which cache policy the output stores of a request take (FcpLaunch::store_through bits 0 and 2; st_out in fcp_kernels.hip):
+//   * the arena is the one this plan's previous request wrote, or the one before it (TF's allocate_output hands a serving
+//     loop the block it just freed, feature_column_process_op_gpu.cu.cc:107-111): PLAIN stores — the lines are still in the
+//     Infinity Cache / L2 and rewriting a resident line beats streaming it (S2, one arena: 27.2 us against 27.9 nt / 28.0
+//     sc1 nt; two arenas 28.0 / 28.2 / 28.2; RAGGED 27.25 / 27.4 / 27.55);
+//   * any other arena (a ring of three or more, fresh memory): plain stores LOSE there (S2 31.1 us against 28.1) —
+//     write-through `sc1 nt` once the outputs exceed what the eight 4-MiB L2s hold, `nt` below
+//   (profiles/r06_arena_reuse_store_policy.txt).  A performance hint only: read and updated without the plan's mutex.
+int store_policy_for(fcp_plan *p, const void *arena, int64_t out_bytes) {
+  static const int64_t through_bytes = [] {
+    const char *e = std::getenv("FCP_STORE_THROUGH_BYTES"); // tuning aid
+    return e ? std::atoll(e) : (int64_t)32 << 20;
+  }();
+  static const int reuse_mode = [] { // tuning aid: 0 = never plain stores, 2 = always, default 1 = for a reused arena
+    const char *e = std::getenv("FCP_STORE_PLAIN_REUSE");
+    return e ? std::atoi(e) : 1;
+  }();
+  const uintptr_t ar = reinterpret_cast<uintptr_t>(arena);
+  const uintptr_t a0 = p->recent_arena[0].load(std::memory_order_relaxed), a1 = p->recent_arena[1].load(std::memory_order_relaxed);
+  const bool reused = ar == a0 || ar == a1;
+  if (ar != a0) {
+    p->recent_arena[1].store(a0, std::memory_order_relaxed);
+    p->recent_arena[0].store(ar, std::memory_order_relaxed);
+  }
+  if (reuse_mode == 2 || (reuse_mode == 1 && reused)) return 4;
+  return out_bytes >= through_bytes ? 1 : 0;
+}
+
+void fill_launch(const fcp_plan *p, const DynSlot &s, int kind, const void *blob, void *arena, int store_policy, FcpLaunch *L) {
   L->slot_map = p->d_slot_map;
   L->span_list = p->d_span_list;
   L->cols = p->d_cols;
@@ -1294,12 +1323,7 @@ void fill_launch(const fcp_plan *p, const DynSlot &s, int kind, const void *blob
   L->n_groups = p->desc.n_groups;
   L->rows_per_wave = s.meta.geo[kind].rows_per_wave;
   L->seg_search = s.meta.seg_search ? 1 : 0;
-  // write-through output stores once the outputs exceed what the eight 4-MiB L2s can hold (see st_through)
-  static const int64_t through_bytes = [] {
-    const char *e = std::getenv("FCP_STORE_THROUGH_BYTES"); // tuning aid
-    return e ? std::atoll(e) : (int64_t)32 << 20;
-  }();
-  L->store_through = (s.meta.csr_arena_off >= through_bytes ? 1 : 0) | (p->wide_rows ? 2 : 0);
+  L->store_through = store_policy | (p->wide_rows ? 2 : 0); // (store_policy_for: bit 0 write-through, bit 2 plain stores)
   for (int g = 0; g < p->desc.n_groups; ++g) L->groups[g] = s.meta.geo[kind].groups[g];
 }
 
@@ -2054,7 +2078,8 @@ int fcp_internal_process(fcp_plan_t *p, const fcp_process_args_t *a, fcp_process
   }
 
   FcpLaunch L;
-  fill_launch(p, *slot, 1, a->concated_inputs, arena, &L);
+  const int store_policy = store_policy_for(p, arena, m.csr_arena_off);
+  fill_launch(p, *slot, 1, a->concated_inputs, arena, store_policy, &L);
   if (!p->seg_cols.empty() && !m.seg_search) {
     FcpSegLaunch S;
     S.seg_cols = p->d_seg_cols;
@@ -2105,14 +2130,14 @@ int fcp_internal_process(fcp_plan_t *p, const fcp_process_args_t *a, fcp_process
   // hybrid dispatch: spans with pooled columns -> ragged body, all other spans -> dense body
   if (m.geo[1].grid_blocks > 0 && m.geo[0].grid_blocks > 0) {
     FcpLaunch Ld;
-    fill_launch(p, *slot, 0, a->concated_inputs, arena, &Ld);
+    fill_launch(p, *slot, 0, a->concated_inputs, arena, store_policy, &Ld);
     const int e = fcp_launch_hybrid(Ld, m.geo[0].grid_blocks, L, m.geo[1].grid_blocks, p->vec, stream);
     if (e) return hip_fail("hybrid kernel launch", (hipError_t)e);
   } else if (m.geo[1].grid_blocks > 0) {
     const int e = fcp_launch_fused(L, p->vec, false, m.geo[1].grid_blocks, stream);
     if (e) return hip_fail("ragged kernel launch", (hipError_t)e);
   } else if (m.geo[0].grid_blocks > 0) {
-    fill_launch(p, *slot, 0, a->concated_inputs, arena, &L);
+    fill_launch(p, *slot, 0, a->concated_inputs, arena, store_policy, &L);
     const int e = fcp_launch_fused(L, p->vec, true, m.geo[0].grid_blocks, stream);
     if (e) return hip_fail("dense kernel launch", (hipError_t)e);
   }
@@ -3030,7 +3055,7 @@ int fcp_shard_finalize(fcp_plan_t *p, const fcp_process_args_t *a, int32_t group
     scratch = a->malloc_temp(a->malloc_temp_ctx, (size_t)std::max<int64_t>(bytes, 1));
     if (!scratch) return fail(FCP_ERR_ALLOC, "malloc_temp returned NULL");
   }
-  fill_launch(p, *slot, 1, a->concated_inputs, scratch, &L);
+  fill_launch(p, *slot, 1, a->concated_inputs, scratch, 0, &L);
   L.csr_arena_off = 0;
   if (need_csr) {
     FcpSegLaunch S;

@@ -94,19 +94,30 @@ __device__ __forceinline__ void st_through(FCP_GLOBAL VecType<1>::T *p, VecType<
   asm volatile("global_store_dword %0, %1, off sc1 nt" ::"v"(p), "v"(t) : "memory");
 }
 
-template <int V> __device__ __forceinline__ void st_out(float *p, const VF<V> &v, bool through = false) {
+// (r6) Third policy, PLAIN stores (default cache policy), for an arena that is the one the plan's previous request (or the
+// one before it) wrote: TF's allocate_output(2) hands a serving loop the block it just freed
+// (feature_column_process_op_gpu.cu.cc:107-111), so an output line is rewritten one request later — 61 MB of output + 86 MB
+// of table lines in between stay within the 256-MiB Infinity Cache, and rewriting a resident line is cheaper than streaming
+// it past the caches: S2 27.2 us against 27.9 (nt) / 28.0 (sc1 nt) with one arena, 28.0 / 28.2 / 28.2 with two; with three
+// or more arenas plain stores LOSE (31.1 against 28.1): profiles/r06_arena_reuse_store_policy.txt.  The host decides per
+// request (FcpLaunch::store_through bit 2, fill_launch).
+#define FCP_ST_THROUGH 1
+#define FCP_ST_PLAIN 4
+template <int V> __device__ __forceinline__ void st_out(float *p, const VF<V> &v, int policy = 0) {
   typedef typename VecType<V>::T T;
   T t;
   __builtin_memcpy(&t, &v, sizeof(T));
-  if (through) {
+  if (policy & FCP_ST_THROUGH) {
     st_through(as_global(reinterpret_cast<T *>(p)), t);
     return;
   }
 #if !defined(FCP_NO_NT)
-  __builtin_nontemporal_store(t, as_global(reinterpret_cast<T *>(p)));
-#else
-  *as_global(reinterpret_cast<T *>(p)) = t;
+  if (!(policy & FCP_ST_PLAIN)) {
+    __builtin_nontemporal_store(t, as_global(reinterpret_cast<T *>(p)));
+    return;
+  }
 #endif
+  *as_global(reinterpret_cast<T *>(p)) = t;
 }
 
 // Row `off` of a table of `spr` slots (of V floats) per row whose lane-specific base is `tb`: one v_mad_u64_u32
@@ -741,7 +752,7 @@ __device__ __forceinline__ void dense_body(const FcpLaunch &L, int bid, char *sm
     asm volatile("" ::"v"(v[r].v[0]), "v"(v[r].v[V - 1]));
     if (b < B.rows && v[r].v[0] == 1234.5f) st_out<V>(outp + (int64_t)b * ostride, v[r]);
 #else
-    if (b < B.rows) st_out<V>(outp + (int64_t)b * ostride, v[r], (H.store_through & 1) != 0);
+    if (b < B.rows) st_out<V>(outp + (int64_t)b * ostride, v[r], H.store_through);
 #endif
   }
 #if defined(FCP_STAMPS)
@@ -1182,7 +1193,7 @@ __device__ __forceinline__ void ragged_body(const FcpLaunch &L, int bid, char *s
 #pragma unroll
     for (int t = 0; t < V; ++t) acc.v[t] = acc.v[t] / fc;
   }
-  st_out<V>(reinterpret_cast<float *>(H.arena + C.out_base) + e + (int64_t)b * C.out_stride, acc, (H.store_through & 1) != 0);
+  st_out<V>(reinterpret_cast<float *>(H.arena + C.out_base) + e + (int64_t)b * C.out_stride, acc, H.store_through);
 #if defined(FCP_STAMPS)
   if (L.stamps && tid == 0) { // wave 0 = first row of the block
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
