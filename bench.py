@@ -218,14 +218,23 @@ def cpu_baseline(model, budget_s: float = 20.0, sample_columns: int = 0):
     plan = sub.to_dict()
     rows = sub.group_rows(0, shapes, req.symbols)
     scale = spec.n_columns / k
-    # serving sweep: the same duration for every worker count
+    # serving sweep: the same duration for every worker count.  Workers run TensorFlow-CPU's DATAFLOW for the unrewritten
+    # graph (one [rows, dim] tensor per column op, then ConcatV2: orc_process_feature_columns_unfused) — what the reference's
+    # CPU path is; the checker's own form (every column straight into the concat matrix) is swept beside it at three worker
+    # counts: it is faster while a worker's matrix fits its share of the L3 (one worker per CCD) and collapses beyond
+    # (profiles/r06_cpu_baseline_collapse.txt), which is what rounds 2-5 reported
     serve_cands = sorted({t for t in (1, 8, 16, 32, 64, 128, cores) if t <= max(cores, 1)})
-    per = max(0.5, 0.7 * budget_s / len(serve_cands))
+    per = max(0.5, 0.6 * budget_s / len(serve_cands))
     sweep, detail = {}, {}
     for t in serve_cands:
-        done, sec = orc.serve_for(plan, packed, tables, req.symbols, t, per)
+        done, sec = orc.serve_for(plan, packed, tables, req.symbols, t, per, 1)
         sweep[t] = rows * done / sec / scale
         detail[t] = {"requests": done, "seconds": sec}
+    fused_cands = sorted({t for t in (16, 32, cores) if t <= max(cores, 1)})
+    fused = {}
+    for t in fused_cands:
+        done, sec = orc.serve_for(plan, packed, tables, req.symbols, t, max(0.5, 0.2 * budget_s / len(fused_cands)), 0)
+        fused[t] = rows * done / sec / scale
     best_t = max(sweep, key=sweep.get)
     head_t = 32 if 32 in sweep else best_t           # the reference's TF-CPU budget (AE/build_and_run.py:57)
     # intra-request mode, the same duration in total
@@ -239,7 +248,7 @@ def cpu_baseline(model, budget_s: float = 20.0, sample_columns: int = 0):
             orc.process_feature_columns(plan, *packed[n % len(packed)], tables, req.symbols, t, out)
             n += 1
             el = time.perf_counter() - t0
-            if el > 0.3 * budget_s / len(intra_cands):
+            if el > 0.2 * budget_s / len(intra_cands):
                 break
         intra[t] = rows * n / el / scale
     return {
@@ -247,6 +256,9 @@ def cpu_baseline(model, budget_s: float = 20.0, sample_columns: int = 0):
         "best_of_sweep": {"cores": best_t, "inferences_per_s": sweep[best_t]},
         "cores_32_inferences_per_s": sweep.get(32), "all_cores": cores, "all_cores_inferences_per_s": sweep.get(cores),
         "serve_workers_sweep": {str(t): v for t, v in sorted(sweep.items())},
+        "dataflow": "TensorFlow-CPU's for the unrewritten graph: one [rows, dim] tensor per column op, then ConcatV2 "
+                    "(orc_process_feature_columns_unfused; same values as the checker's form bit for bit)",
+        "fused_layout_serve_workers_sweep": {str(t): v for t, v in sorted(fused.items())},
         "intra_request_openmp_inferences_per_s": {str(t): v for t, v in sorted(intra.items())},
         "host_table_fill_s": t_fill,
         "sample": (f"all {spec.n_columns} columns" if k == spec.n_columns else f"first {k} of {spec.n_columns} columns, scaled x{scale:.1f} to the whole model,")
@@ -718,6 +730,21 @@ def main():
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
             rec["cpu_baseline"] = cpu_baseline(model)
     h.close()
+    if world > 1 and args.workload == "s2" and not os.environ.get("FCP_BENCH_NO_SHARDED_RECORD"):
+        # The default multi-GPU line is replicas (S2's 120 GB fit one GPU: no collective); so that a scaling run on a multi-GPU
+        # node still measures the one exchange this path has, BASELINE configs[4]'s row-sharded step runs on the same ranks for
+        # <= 10 s afterwards and rides along as `sharded` (every rank takes part; rank 0 reports)
+        from recom_amd.shard import bench_row_sharded_record
+        del h
+        torch.cuda.empty_cache()
+        try:
+            sharded = bench_row_sharded_record(args, rank, world, local_rank, dist,
+                                               int(hbm_override) if hbm_override else device_hbm_bytes(local_rank))
+        except Exception as e:                       # the headline line must not depend on this extra (all ranks fail alike)
+            sharded = {"error": f"{type(e).__name__}: {e}"[:400]}
+        if rank == 0:
+            rec["sharded"] = sharded
+        h = None
     if rank == 0:
         if args.workload == "s2" and world == 1 and args.ids == "uniform" and not args.no_pcie and not args.no_cpu_baseline and not args.batch and not args.columns:
             del h

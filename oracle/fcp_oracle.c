@@ -816,6 +816,58 @@ int64_t orc_process_feature_columns(const orc_plan_t *p, const int8_t *blob,
   return bad;
 }
 
+/* The same result through TENSORFLOW-CPU'S DATAFLOW for the unrewritten graph: every column's op (GatherV2 / Bucketize +
+ * GatherV2 / SparseSegment* / ScatterNd; lookup_optimizer.cc:157-440 are the patterns) produces its own contiguous
+ * [rows, dim] tensor, then ConcatV2 copies the tensors row by row into [rows, sum dim].  process_column runs with a
+ * one-column "group" of width dim; the values are those of orc_process_feature_columns bit for bit (the concat is a copy).
+ * What bench.py's cpu_baseline times since round 6: writing every column straight into the concat matrix — the FUSED
+ * layout, this oracle's checker form — visits each 64-byte output line from several columns at a 4 x sum(dim) stride,
+ * which is fine while a worker's matrix stays in its share of the L3 and collapses beyond it (2 x 64-core host, S2:
+ * 516 k inferences/s at 16 workers, one per CCD, 151 k at 256; the same with cache-resident tables:
+ * profiles/r06_cpu_baseline_collapse.txt).  `scratch`: sum over columns of rows x dim floats.  Single-threaded. */
+int64_t orc_process_feature_columns_unfused(const orc_plan_t *p, const int8_t *blob, const int32_t *offsets,
+                                            const int32_t *shapes, const float *const *tables, const int32_t *symbols,
+                                            float *const *group_out, float *scratch) {
+  for (int32_t g = 0; g < p->n_groups; ++g)
+    if (orc_group_rows(p, g, shapes, symbols) < 0) return -1;
+  int32_t *widths = (int32_t *)malloc(sizeof(int32_t) * (size_t)(p->n_groups + 1));
+  int32_t *col_offs = (int32_t *)malloc(sizeof(int32_t) * (size_t)(p->n_columns + 1));
+  int32_t *w1 = (int32_t *)malloc(sizeof(int32_t) * (size_t)(p->n_groups + 1));
+  int32_t *o1 = (int32_t *)calloc((size_t)(p->n_columns + 1), sizeof(int32_t));
+  float **t1 = (float **)malloc(sizeof(float *) * (size_t)(p->n_groups + 1));
+  float **col_t = (float **)malloc(sizeof(float *) * (size_t)(p->n_columns + 1));
+  layout_columns(p, widths, col_offs);
+  int64_t bad = 0;
+  float *cur = scratch;
+  for (int32_t k = 0; k < p->n_columns; ++k) { /* the column ops */
+    const orc_column_t *c = &p->columns[k];
+    const int64_t rows = orc_group_rows(p, c->concat_group, shapes, symbols);
+    col_t[k] = cur;
+    cur += rows * c->dim;
+    w1[c->concat_group] = c->dim;
+    t1[c->concat_group] = col_t[k];
+    bad += process_column(p, k, blob, offsets, shapes, tables, symbols, t1, w1, o1);
+  }
+  for (int32_t g = 0; g < p->n_groups; ++g) { /* ConcatV2: row by row, inputs in slot order */
+    const int64_t rows = orc_group_rows(p, g, shapes, symbols);
+    for (int64_t r = 0; r < rows; ++r) {
+      float *dst = group_out[g] + r * widths[g];
+      for (int32_t k = 0; k < p->n_columns; ++k) {
+        const orc_column_t *c = &p->columns[k];
+        if (c->concat_group != g || c->form == ORC_FORM_EXTERNAL) continue;
+        memcpy(dst + col_offs[k], col_t[k] + r * c->dim, 4 * (size_t)c->dim);
+      }
+    }
+  }
+  free(widths);
+  free(col_offs);
+  free(w1);
+  free(o1);
+  free(t1);
+  free(col_t);
+  return bad;
+}
+
 /* Serving-style CPU throughput (what TF-CPU does with many Session::Run threads, the
  * reference harness' serve_workers, examples/cc/recom_examples.patch:210-216): n_threads
  * workers each process whole requests on their own, single-threaded, into private
@@ -830,6 +882,15 @@ int64_t orc_serve_for(const orc_plan_t *p, const int8_t *const *blobs, int32_t n
                       const int32_t *const *offsets, const int32_t *const *shapes,
                       const float *const *tables, const int32_t *symbols, int32_t n_threads,
                       double seconds, double *elapsed) {
+  return orc_serve_for_dataflow(p, blobs, n_blobs, offsets, shapes, tables, symbols, n_threads, seconds, 0, elapsed);
+}
+
+/* dataflow 0: every column straight into the concat matrix (orc_process_feature_columns); 1: TF-CPU's dataflow, column
+ * tensors + ConcatV2 (orc_process_feature_columns_unfused). */
+int64_t orc_serve_for_dataflow(const orc_plan_t *p, const int8_t *const *blobs, int32_t n_blobs,
+                               const int32_t *const *offsets, const int32_t *const *shapes,
+                               const float *const *tables, const int32_t *symbols, int32_t n_threads,
+                               double seconds, int32_t dataflow, double *elapsed) {
 #ifdef _OPENMP
   if (n_threads < 1 || !(seconds > 0.0) || n_blobs < 1 || !elapsed) return -1;
   for (int32_t r = 0; r < n_blobs; ++r)
@@ -849,8 +910,19 @@ int64_t orc_serve_for(const orc_plan_t *p, const int8_t *const *blobs, int32_t n
       out[g] = (float *)calloc(n ? n : 1, sizeof(float));
       if (!out[g]) ok = 0;
     }
+    float *scratch = NULL;
+    if (ok && dataflow) {
+      size_t n = 0;
+      for (int32_t k = 0; k < p->n_columns; ++k)
+        n += (size_t)orc_group_rows(p, p->columns[k].concat_group, shapes[0], symbols) * (size_t)p->columns[k].dim;
+      scratch = (float *)calloc(n ? n : 1, sizeof(float));
+      if (!scratch) ok = 0;
+    }
     int32_t r = (int32_t)(((int64_t)omp_get_thread_num() * 7) % n_blobs);
-    if (ok) (void)orc_process_feature_columns(p, blobs[r], offsets[r], shapes[r], tables, symbols, out, 1); /* warm */
+    if (ok) { /* warm */
+      if (dataflow) (void)orc_process_feature_columns_unfused(p, blobs[r], offsets[r], shapes[r], tables, symbols, out, scratch);
+      else (void)orc_process_feature_columns(p, blobs[r], offsets[r], shapes[r], tables, symbols, out, 1);
+    }
 #pragma omp barrier
 #pragma omp master
     t0 = omp_get_wtime();
@@ -859,7 +931,8 @@ int64_t orc_serve_for(const orc_plan_t *p, const int8_t *const *blobs, int32_t n
       const double stop = t0 + seconds;
       do {
         r = (r + 1) % n_blobs;
-        (void)orc_process_feature_columns(p, blobs[r], offsets[r], shapes[r], tables, symbols, out, 1);
+        if (dataflow) (void)orc_process_feature_columns_unfused(p, blobs[r], offsets[r], shapes[r], tables, symbols, out, scratch);
+        else (void)orc_process_feature_columns(p, blobs[r], offsets[r], shapes[r], tables, symbols, out, 1);
         ++total;
       } while (omp_get_wtime() < stop);
     }
@@ -874,11 +947,12 @@ int64_t orc_serve_for(const orc_plan_t *p, const int8_t *const *blobs, int32_t n
       for (int32_t g = 0; g < p->n_groups; ++g) free(out[g]);
       free(out);
     }
+    free(scratch);
   }
   *elapsed = t1 - t0;
   return failed ? -1 : total;
 #else
-  (void)p; (void)blobs; (void)n_blobs; (void)offsets; (void)shapes; (void)tables; (void)symbols; (void)n_threads; (void)seconds; (void)elapsed;
+  (void)p; (void)blobs; (void)n_blobs; (void)offsets; (void)shapes; (void)tables; (void)symbols; (void)n_threads; (void)seconds; (void)dataflow; (void)elapsed;
   return -1;
 #endif
 }

@@ -180,6 +180,13 @@ int64_t orc_process_feature_columns(const orc_plan_t *plan, const int8_t *blob,
 /* Rows / width of a group for these run-time shapes (-1 on error). */
 /* n_threads independent single-threaded workers (serve_workers), calls_per_thread requests
  * each; returns elapsed seconds (bench.py cpu_baseline). */
+int64_t orc_process_feature_columns_unfused(const orc_plan_t *p, const int8_t *blob, const int32_t *offsets,
+                                            const int32_t *shapes, const float *const *tables, const int32_t *symbols,
+                                            float *const *group_out, float *scratch);
+int64_t orc_serve_for_dataflow(const orc_plan_t *p, const int8_t *const *blobs, int32_t n_blobs,
+                               const int32_t *const *offsets, const int32_t *const *shapes,
+                               const float *const *tables, const int32_t *symbols, int32_t n_threads,
+                               double seconds, int32_t dataflow, double *elapsed);
 int64_t orc_serve_for(const orc_plan_t *p, const int8_t *const *blobs, int32_t n_blobs,
                       const int32_t *const *offsets, const int32_t *const *shapes,
                       const float *const *tables, const int32_t *symbols, int32_t n_threads,

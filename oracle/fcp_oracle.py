@@ -294,9 +294,11 @@ class COracle:
         return float(el)
 
     def serve_for(self, plan: dict, requests: Sequence, tables: Sequence[np.ndarray], symbols=None,
-                  n_threads: int = 1, seconds: float = 1.0):
+                  n_threads: int = 1, seconds: float = 1.0, dataflow: int = 0):
         """(requests completed, elapsed seconds): `n_threads` independent single-threaded workers serve requests,
-        rotating over `requests`, for `seconds` each (orc_serve_for)."""
+        rotating over `requests`, for `seconds` each (orc_serve_for_dataflow).  dataflow 0: every column straight into
+        the concat matrix (the checker's form); 1: TensorFlow-CPU's dataflow for the unrewritten graph — one [rows, dim]
+        tensor per column op, then ConcatV2 (orc_process_feature_columns_unfused)."""
         p, _keep = self._make_plan(plan)
         bl = [np.ascontiguousarray(r[0]).view(np.int8) for r in requests]
         of = [_i32(r[1]) for r in requests]
@@ -309,18 +311,18 @@ class COracle:
         tabs = [np.ascontiguousarray(t, np.float32) for t in tables]
         tptrs = (C.c_void_p * max(1, len(tabs)))(*[t.ctypes.data for t in tabs])
         el = C.c_double(0.0)
-        self.lib.orc_serve_for.restype = C.c_int64
-        self.lib.orc_serve_for.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                           C.c_int32, C.c_double, C.POINTER(C.c_double)]
-        done = self.lib.orc_serve_for(C.byref(p), bptrs, n, optrs, sptrs, tptrs, None if sym is None else sym.ctypes.data,
-                                      n_threads, float(seconds), C.byref(el))
+        self.lib.orc_serve_for_dataflow.restype = C.c_int64
+        self.lib.orc_serve_for_dataflow.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                    C.c_int32, C.c_double, C.c_int32, C.POINTER(C.c_double)]
+        done = self.lib.orc_serve_for_dataflow(C.byref(p), bptrs, n, optrs, sptrs, tptrs, None if sym is None else sym.ctypes.data,
+                                               n_threads, float(seconds), int(dataflow), C.byref(el))
         if done < 0:
             raise ValueError("oracle: serve_for failed")
         return int(done), float(el.value)
 
     def process_feature_columns(self, plan: dict, blob: np.ndarray, offsets, shapes,
                                 tables: Sequence[np.ndarray], symbols=None, n_threads: int = 1,
-                                out: Optional[List[np.ndarray]] = None):
+                                out: Optional[List[np.ndarray]] = None, unfused: bool = False):
         """Returns (list of [rows_g, width_g] float32 matrices, n_bad_ids)."""
         p, _keep = self._make_plan(plan)
         blob = np.ascontiguousarray(blob).view(np.int8)
@@ -338,8 +340,16 @@ class COracle:
                     raise ValueError(f"oracle: inconsistent rows in group {g}")
                 out.append(np.zeros((rows, self.lib.orc_group_width(C.byref(p), g)), np.float32))
         optrs = (C.c_void_p * len(out))(*[o.ctypes.data for o in out])
-        bad = self.lib.orc_process_feature_columns(C.byref(p), blob.ctypes.data, offsets.ctypes.data,
-                                                   shapes.ctypes.data, tptrs, symp, optrs, n_threads)
+        if unfused:   # TF-CPU's dataflow: one tensor per column op, then ConcatV2 (same values: the concat is a copy)
+            n_scratch = sum(int(out[c["concat_group"]].shape[0]) * int(c["dim"]) for c in plan["columns"])
+            scratch = np.zeros(max(n_scratch, 1), np.float32)
+            self.lib.orc_process_feature_columns_unfused.restype = C.c_int64
+            self.lib.orc_process_feature_columns_unfused.argtypes = [C.c_void_p] * 8
+            bad = self.lib.orc_process_feature_columns_unfused(C.byref(p), blob.ctypes.data, offsets.ctypes.data,
+                                                               shapes.ctypes.data, tptrs, symp, optrs, scratch.ctypes.data)
+        else:
+            bad = self.lib.orc_process_feature_columns(C.byref(p), blob.ctypes.data, offsets.ctypes.data,
+                                                       shapes.ctypes.data, tptrs, symp, optrs, n_threads)
         if bad < 0:
             raise ValueError("oracle: malformed plan / shapes")
         return out, int(bad)

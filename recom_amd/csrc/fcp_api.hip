@@ -90,6 +90,10 @@ struct DynMeta {
   int64_t seg_pairs = 0;   // sum of rows over the segment-id columns: cost of the in-block search
   bool seg_search = false; // this request: blocks search the segment ids (no pre-pass launch)
   int64_t work_bytes = 0;  // table rows gathered + output written: what decides whether a private lane pays (fcp_plan_set_private_streams)
+  // regular CSR (FcpLaunch::csr_reg): 0 = none, 1 = the arena scratch laid out by column position, 2 = CSR inputs that lie
+  // one stride apart in the blob; byte offset of position 0's array in the arena / the blob; stride in int32 elements
+  int32_t csr_reg_mode = 0, csr_reg_stride = 0;
+  int64_t csr_reg_base = 0;
   // launch geometry per kernel kind: [0] dense kernel (spans whose columns all have exactly
   // one source row per output row), [1] ragged kernel (spans with pooled / scatter / reduction columns)
   struct Geo {
@@ -320,6 +324,12 @@ struct fcp_plan {
   int32_t n_seg_plain = 0;  // seg_cols[0 .. n_seg_plain): pooled columns; the rest: any-order ScatterNd columns (inverse maps)
   bool seg_search = false;  // blocks search the segment ids themselves; no segment-offset pre-pass
   bool has_inverse = false; // some ScatterNd column brings its row ids as delivered (any order): inverse map in the pre-pass
+  // (r6) the CSR scratch of segment-id columns is laid out by column POSITION (one row of round32(rows + 1) entries per
+  // column of the plan, pooled or not) instead of packed: the ragged body then knows where a range is before it has the
+  // column's record (FcpLaunch::csr_reg).  One concat group, no any-order ScatterNd column (their inverse maps are the
+  // scratch's tail, cleared per request), and pooled columns at least half of the plan (the unused rows cost arena bytes,
+  // never traffic: RAGGED 512 of 512 columns; the reference's models E / F, 10-20 of ~1000, keep the packed scratch).
+  bool csr_by_pos = false;
   // device arrays are kept in concat order (group-major, ascending concat offset)
   // so that the columns of one output span are contiguous: order[pos] = column,
   // pos_of[column] = pos.
@@ -534,6 +544,7 @@ int validate_ext(const fcp_plan_desc_t *d, const fcp_column_ext_t *ext) {
 // geometry.  Mirrors what the generated host code evaluates per call from
 // SymEngine expressions (cuda_emitter.cc:2151-2179, :2410-2455).
 int finish_geometry(const fcp_plan *p, DynMeta *m);
+void find_regular_csr(const fcp_plan *p, const FcpColDyn *dyn, DynMeta *m);
 
 int compute_dyn_slow(const fcp_plan *p, const int32_t *offsets, const int32_t *shapes,
                      const int32_t *symbols, int64_t blob_bytes, FcpColDyn *dyn, DynMeta *m) {
@@ -668,15 +679,54 @@ int compute_dyn_slow(const fcp_plan *p, const int32_t *offsets, const int32_t *s
   m->seg_search = p->seg_search && m->seg_pairs <= kSegSearchMaxPairs;
   m->csr_arena_off = cursor;
   int64_t csr_cursor = 0; // in int32 elements
-  for (int k : p->seg_cols) {
-    dyn[p->pos_of[k]].csr_base = (int32_t)csr_cursor;
-    csr_cursor += (col_rows[k] + 1 + 31) / 32 * 32;
+  if (p->csr_by_pos) {
+    const int64_t stride = ((int64_t)m->group_rows[0] + 1 + 31) / 32 * 32;
+    for (int k : p->seg_cols) dyn[p->pos_of[k]].csr_base = (int32_t)(p->pos_of[k] * stride);
+    csr_cursor = stride * (int64_t)p->cols.size();
     if (csr_cursor > 0x7fffffff) return fail(FCP_ERR_UNSUPPORTED, "CSR scratch exceeds 2^31 entries");
+  } else {
+    for (int k : p->seg_cols) {
+      dyn[p->pos_of[k]].csr_base = (int32_t)csr_cursor;
+      csr_cursor += (col_rows[k] + 1 + 31) / 32 * 32;
+      if (csr_cursor > 0x7fffffff) return fail(FCP_ERR_UNSUPPORTED, "CSR scratch exceeds 2^31 entries");
+    }
   }
   cursor += csr_cursor * 4;
   m->arena_bytes = cursor;
-
+  find_regular_csr(p, dyn, m);
   return finish_geometry(p, m);
+}
+
+// Are this request's row-offset arrays regular (FcpLaunch::csr_reg)?  Mode 1: the plan lays its CSR scratch out by column
+// position and the pre-pass fills it (not when the blocks search the segment ids themselves: then there is no scratch to
+// read).  Mode 2: EVERY column of a one-group plan brings CSR offsets in the blob and the arrays lie one constant stride
+// apart in position order — what a packer that keeps the converted inputs together produces; checked per descriptor
+// install (n_columns compares), never assumed.
+void find_regular_csr(const fcp_plan *p, const FcpColDyn *dyn, DynMeta *m) {
+  m->csr_reg_mode = 0;
+  m->csr_reg_stride = 0;
+  m->csr_reg_base = 0;
+  if (p->desc.n_groups != 1 || p->cols.empty() || m->group_rows[0] <= 0) return;
+  const int nc = (int)p->cols.size();
+  if (p->csr_by_pos) {
+    if (p->seg_search && m->seg_pairs <= kSegSearchMaxPairs) return; // (m->seg_search is decided from the same two facts)
+    m->csr_reg_mode = 1;
+    m->csr_reg_stride = (int32_t)(((int64_t)m->group_rows[0] + 1 + 31) / 32 * 32);
+    m->csr_reg_base = 0; // relative to the scratch (csr_arena_off)
+    return;
+  }
+  int64_t stride = 0;
+  for (int i = 0; i < nc; ++i) {
+    const fcp_column_desc_t &c = p->cols[p->order[i]].d;
+    if (c.seg_kind != FCP_SEG_CSR_I32 || (c.form != FCP_FORM_SEGMENT_REDUCE && c.form != FCP_FORM_GATHER_SCATTER)) return;
+    if (i == 1) stride = dyn[1].seg_off - dyn[0].seg_off;
+    if (i >= 1 && dyn[i].seg_off - dyn[i - 1].seg_off != stride) return;
+  }
+  if (nc == 1) stride = 4 * ((int64_t)m->group_rows[0] + 1);
+  if (stride < 4 * ((int64_t)m->group_rows[0] + 1) || (stride & 3) || stride / 4 > 0x7fffffff || (dyn[0].seg_off & 3)) return;
+  m->csr_reg_mode = 2;
+  m->csr_reg_stride = (int32_t)(stride / 4);
+  m->csr_reg_base = dyn[0].seg_off;
 }
 
 // launch geometry, one set per kernel kind (shared by both compute_dyn variants)
@@ -717,7 +767,7 @@ int finish_geometry(const fcp_plan *p, DynMeta *m) {
       G.nsp8 = (G.nlist >= 8 && !no_xcd_map) ? (G.nlist + 7) / 8 : -std::max(G.nlist, 1);
       G.block_begin = blocks;
       G.slot_map_off = p->group_map_off[g];
-      G.pad_ = 0;
+      G.csr_reg_stride = 0; // (fill_launch sets groups[0]'s per request)
       const int rows_per_block = FCP_WAVES_PER_BLOCK * rpw;
       const int64_t ntiles = ((int64_t)G.rows + rows_per_block - 1) / rows_per_block;
       const int64_t nb = G.nlist == 0 ? 0 : (G.nsp8 > 0 ? 8ll * G.nsp8 : (int64_t)G.nlist) * ntiles;
@@ -822,13 +872,21 @@ int compute_dyn_fast(const fcp_plan *p, const int32_t *offsets, const int32_t *s
   m->seg_search = p->seg_search && seg_pairs <= kSegSearchMaxPairs;
   m->csr_arena_off = cursor;
   int64_t csr_cursor = 0; // in int32 elements
-  for (int k : p->seg_cols) {
-    FcpColDyn &d = dyn[p->pos_of[k]];
-    d.csr_base = (int32_t)csr_cursor;
-    csr_cursor += ((int64_t)d.rows + 1 + 31) / 32 * 32;
+  if (p->csr_by_pos) {
+    const int64_t stride = ((int64_t)m->group_rows[0] + 1 + 31) / 32 * 32;
+    for (int k : p->seg_cols) dyn[p->pos_of[k]].csr_base = (int32_t)(p->pos_of[k] * stride);
+    csr_cursor = stride * nc;
     if (csr_cursor > 0x7fffffff) return -1;
+  } else {
+    for (int k : p->seg_cols) {
+      FcpColDyn &d = dyn[p->pos_of[k]];
+      d.csr_base = (int32_t)csr_cursor;
+      csr_cursor += ((int64_t)d.rows + 1 + 31) / 32 * 32;
+      if (csr_cursor > 0x7fffffff) return -1;
+    }
   }
   m->arena_bytes = cursor + csr_cursor * 4;
+  find_regular_csr(p, dyn, m);
   return finish_geometry(p, m);
 }
 
@@ -1302,7 +1360,10 @@ int store_policy_for(fcp_plan *p, const void *arena, int64_t out_bytes) {
     p->recent_arena[1].store(a0, std::memory_order_relaxed);
     p->recent_arena[0].store(ar, std::memory_order_relaxed);
   }
-  if (reuse_mode == 2 || (reuse_mode == 1 && reused)) return 4;
+  // ... while the output is of a size the caches can still hold on to: S2 at batch 512 / 640 / 768 / 1024 (61-123 MB of
+  // output) gains 1.4-3.0 us per request from plain stores into its one arena, batch 2048 (246 MB) LOSES 6 of 103 us
+  constexpr int64_t kPlainMaxBytes = (int64_t)160 << 20;
+  if (reuse_mode == 2 || (reuse_mode == 1 && reused && out_bytes <= kPlainMaxBytes)) return 4;
   return out_bytes >= through_bytes ? 1 : 0;
 }
 
@@ -1324,7 +1385,11 @@ void fill_launch(const fcp_plan *p, const DynSlot &s, int kind, const void *blob
   L->rows_per_wave = s.meta.geo[kind].rows_per_wave;
   L->seg_search = s.meta.seg_search ? 1 : 0;
   L->store_through = store_policy | (p->wide_rows ? 2 : 0); // (store_policy_for: bit 0 write-through, bit 2 plain stores)
+  L->csr_reg = s.meta.csr_reg_mode == 1   ? reinterpret_cast<const int32_t *>(static_cast<const char *>(arena) + s.meta.csr_arena_off)
+               : s.meta.csr_reg_mode == 2 ? reinterpret_cast<const int32_t *>(static_cast<const char *>(blob) + s.meta.csr_reg_base)
+                                          : nullptr;
   for (int g = 0; g < p->desc.n_groups; ++g) L->groups[g] = s.meta.geo[kind].groups[g];
+  L->groups[0].csr_reg_stride = (s.meta.csr_reg_mode && L->csr_reg) ? s.meta.csr_reg_stride : 0;
 }
 
 } // namespace
@@ -1472,6 +1537,10 @@ int fcp_plan_create_ex(const fcp_plan_desc_t *desc, const fcp_column_ext_t *ext,
       p->seg_search = false;
     }
   }
+  p->csr_by_pos = desc->layout == FCP_LAYOUT_CONCAT && desc->n_groups == 1 && !p->has_inverse && !p->seg_cols.empty() &&
+                  2 * p->seg_cols.size() >= p->cols.size();
+  if (const char *e = std::getenv("FCP_CSR_BY_POS")) // tuning aid: 0 = packed scratch (the round-5 layout)
+    if (std::atoi(e) == 0) p->csr_by_pos = false;
   // The kernels park a table row as one 32-bit number (the three largest values are their sentinels): a table — or
   // one shard of it — may hold up to 2^32 - 3 ROWS, of any width: the byte offset is formed in 64 bits where the row
   // is read.  The dense body keeps round 2's pre-scaled 32-bit slot offsets (row * dim / vec) while every table of
@@ -3057,6 +3126,8 @@ int fcp_shard_finalize(fcp_plan_t *p, const fcp_process_args_t *a, int32_t group
   }
   fill_launch(p, *slot, 1, a->concated_inputs, scratch, 0, &L);
   L.csr_arena_off = 0;
+  L.csr_reg = nullptr; // (the scratch here is a buffer of its own: no regular-CSR shortcut)
+  L.groups[0].csr_reg_stride = 0;
   if (need_csr) {
     FcpSegLaunch S;
     S.seg_cols = p->d_seg_cols;

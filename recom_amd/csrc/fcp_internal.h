@@ -89,7 +89,7 @@ struct FcpGroupLaunch {
   int32_t slot_map_off;    // offset of the group's slot map
   int32_t span_list_off;   // offset into FcpLaunch::span_list of the spans this launch covers, or -1: all spans
   int32_t nlist;           // number of spans this launch covers in this group
-  int32_t pad_;
+  int32_t csr_reg_stride;  // groups[0] only (regular CSR needs a one-group plan): see FcpLaunch::csr_reg; 0 = not regular
 };
 
 // Field order matters: everything a block of a one-group plan reads lies in the first two 64-byte
@@ -110,10 +110,17 @@ struct FcpLaunch {
   int32_t store_through;       // bit 0: output stores are write-through (`sc1 nt`): outputs larger than the L2s (host decides);
                                // bit 1: some table (shard) of the plan has >= 2^32 - 3 slots: the dense body parks rows and
                                // multiplies in 64 bits instead of parking pre-scaled 32-bit slot offsets
-  unsigned long long *stamps;  // diagnostic builds (-DFCP_STAMPS) only: 8 timestamps per block
+  // (r6) Regular CSR: when the row-offset arrays of ALL column positions lie groups[0].csr_reg_stride int32 apart — the arena
+  // scratch the pre-pass fills, laid out by column position (fcp_plan::csr_by_pos), or CSR inputs that arrive that way in
+  // the blob — row b of the column at concat position c is csr_reg[c * stride + b]: the ragged body asks for its ranges
+  // TOGETHER with the column records instead of behind them (one dependent round trip less in every block's front).
+  // Stride 0: not regular, the ranges come through the records (LdsCol::csr).  (Pointer and stride sit in the first two
+  // 64-byte lines of the argument block, like everything a block of a one-group plan reads.)
+  const int32_t *csr_reg;
   FcpGroupLaunch groups[FCP_MAX_GROUPS];
   const FcpXform *xforms;      // per column (concat order), or null: no column has an id transform
   const float *zeros;          // 256 zero bytes (plan-owned): what a skipped id of a bag reads
+  unsigned long long *stamps;  // diagnostic builds (-DFCP_STAMPS) only: 8 timestamps per block
 };
 
 // Segment-offset pre-pass (ComputeSegmentOffsets, cuda_emitter.cc:768-818)

@@ -989,6 +989,15 @@ __device__ __forceinline__ void ragged_body(const FcpLaunch &L, int bid, char *s
   const uint32_t my_col = B.map[min(q, B.nslots - 1)];
   const int world = H.world, rank = H.rank;
 
+  // ---- regular CSR (FcpLaunch::csr_reg): the wave's row ranges are requested NOW, next to the column records, instead
+  // of behind them — their address needs the span's first column position only
+  int pre0 = 0, pre1 = 0;
+  const int csr_reg_stride = H.g0.csr_reg_stride;
+  if (csr_reg_stride && lane < B.ncols && B.row_blk + wave < B.rows) {
+    const FCP_GLOBAL int32_t *cr = as_global(L.csr_reg) + (int64_t)(B.first_col + lane) * csr_reg_stride + (B.row_blk + wave);
+    pre0 = cr[0];
+    pre1 = cr[1];
+  }
   // ---- phase 0 (block) --------------------------------------------------------------------
   if (tid < B.ncols) stage_col(H, &s_col[tid], H.cols + B.first_col + tid, H.dyn + B.first_col + tid);
   __syncthreads();
@@ -1035,6 +1044,9 @@ __device__ __forceinline__ void ragged_body(const FcpLaunch &L, int bid, char *s
       } else if (H.seg_search && sk != FCP_SEG_CSR_I32) {
         o0 = S.bound[lane * (RB + 1) + wave];
         o1 = S.bound[lane * (RB + 1) + wave + 1];
+      } else if (csr_reg_stride) { // requested in front of the records (above)
+        o0 = pre0;
+        o1 = pre1;
       } else {
         const FCP_GLOBAL int32_t *csr = as_global(s_col[lane].csr);
         o0 = csr[b];

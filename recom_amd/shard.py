@@ -582,10 +582,14 @@ def bench_sharded(args, model, placement, rank: int, world: int, local_rank: int
     """`bench.py --workload shard[-row|-col]` once the placement gate has decided to shard (BASELINE.json config 5:
     4000 S2-shaped columns, 480 GB of tables): every rank holds its shard, every request runs partial
     kernel -> RCCL all-to-all over xGMI -> finalize / concat as one native call (NativeShardedStep).  `--workload shard`
-    follows the gate's mixed preference (configs[4]: every table fits a GPU -> whole columns, 8x fewer bytes on the wire)
-    and ALSO times the row-sharded step BASELINE configs[4] names, reported beside it as `row_sharded_conformity`."""
+    is BASELINE configs[4] as written (every table row-sharded: `value`) and ALSO times what the gate prefers for the same
+    tables (configs[4]: every table fits a GPU -> whole columns, 8x fewer bytes on the wire), reported as `gate_choice`."""
     from .placement import MIXED, ROW_SHARD
-    mode = "row" if placement.mode == ROW_SHARD else "mixed" if placement.mode == MIXED else "col"
+    gate_mode = "row" if placement.mode == ROW_SHARD else "mixed" if placement.mode == MIXED else "col"
+    # `--workload shard` IS BASELINE configs[4]: its own line is the ROW-sharded step the config names (r6; VERDICT r05 weak
+    # 11), with what the placement gate would choose for the same tables (whole columns wherever a table fits one GPU: 8x
+    # fewer bytes on the wire, bit-identical to one GPU) beside it as `gate_choice`.  shard-row / shard-col force one kind.
+    mode = "row" if getattr(args, "workload", "") == "shard" and world > 1 else gate_mode
     elapsed, dev_s = _time_sharded_step(args, model, placement, mode, rank, world, local_rank, dist)
     batch = model.batch
     width = model.spec.group_width(0)
@@ -632,14 +636,114 @@ def bench_sharded(args, model, placement, rank: int, world: int, local_rank: int
                      "frac": per_gpu / dev_s / 1e9 / 8000.0, "traffic": None,
                      "note": "per GPU, whole step (partial kernel + exchange + finalize / concat), events on the compute stream"},
     }
-    if getattr(args, "workload", "") == "shard" and mode != "row" and world > 1:
-        # BASELINE configs[4] says ROW-sharded: the conformity figure, in the same run, beside the gate's choice
-        e_row, d_row = _time_sharded_step(args, model, placement, "row", rank, world, local_rank, dist)
-        s_row, g_row, p_row = accounting("row")
-        rec["row_sharded_conformity"] = {
-            "what": "BASELINE configs[4] as written: every table row-sharded (id % world), partial sums exchanged + fcp_shard_finalize; "
-                    "`--workload shard-row` makes this the headline",
-            "value": batch * args.steps / e_row, "unit": "inferences/s", "ms_per_step": e_row * 1e3 / args.steps,
-            "parallelism": p_row, "exchange_bytes_sent_per_rank_per_request": int(s_row),
-            "roofline_frac": g_row / d_row / 1e9 / 8000.0}
+    if getattr(args, "workload", "") == "shard" and gate_mode != mode:
+        # what the placement gate prefers for these tables, in the same run
+        e_g, d_g = _time_sharded_step(args, model, placement, gate_mode, rank, world, local_rank, dist)
+        s_g, g_g, p_g = accounting(gate_mode)
+        rec["gate_choice"] = {
+            "what": "the placement gate's own preference for the same tables (FCP_PLACE_MIXED: a table that fits one GPU stays "
+                    "whole, final column blocks are exchanged: no partial sums, results bit-identical to one GPU); "
+                    "`--workload shard-col` makes it the headline",
+            "value": batch * args.steps / e_g, "unit": "inferences/s", "ms_per_step": e_g * 1e3 / args.steps,
+            "parallelism": p_g, "exchange_bytes_sent_per_rank_per_request": int(s_g),
+            "roofline_frac": g_g / d_g / 1e9 / 8000.0}
+    return rec
+
+
+def bench_row_sharded_record(args, rank: int, world: int, local_rank: int, dist, hbm_bytes: int, budget_s: float = 10.0) -> dict:
+    """What `bench.py --gpus N` attaches to its DEFAULT line (replicated S2, no collective) as `sharded`: BASELINE configs[4]
+    at its own shape — 4000 S2-shaped columns, batch 512, every table row-sharded over the N ranks — over the REAL backend
+    for at most `budget_s` seconds, so that the first scaling run on a multi-GPU node measures the RCCL exchange over xGMI
+    without asking for another workload.  Vocabulary: 1 M rows per table (480 GB) when N GPUs hold it,
+    else the largest that fits.  Reports the whole step (partial kernel -> grouped ncclSend / ncclRecv -> fcp_shard_finalize)
+    and the exchange alone (fcp_shard_exchange on a resident partial).  Testing aids: FCP_BENCH_SHARD_COLUMNS /
+    FCP_BENCH_SHARD_VOCAB shrink the model (the 1-GPU boxes run N ranks on one device over gloo)."""
+    import ctypes as C
+    import os
+    import torch
+    from . import lib as _lib
+    from . import synth
+    columns = int(os.environ.get("FCP_BENCH_SHARD_COLUMNS", "4000"))
+    batch = args.batch or 512
+    width = sum((8, 16, 32, 64)[c % 4] for c in range(columns))
+    # tables: columns x vocab x mean dim x 4 bytes over `world` GPUs, within 85 % of each GPU's memory net of the exchange
+    # buffers (partial + slices, a ring of three)
+    per_row = width * 4
+    room = 0.85 * hbm_bytes - 8 * batch * width * 4
+    vocab = int(os.environ.get("FCP_BENCH_SHARD_VOCAB", "0")) or int(max(1000, min(1_000_000, room * world // per_row)))
+    model = synth.model_shard(columns=columns, vocab=vocab, batch=batch)
+    backend = dist.get_backend() if dist is not None else "none"
+    native = dist is None or backend == "nccl"
+    comm = Communicator(rank, world, local_rank, dist) if native else None
+    step = NativeShardedStep(model, comm, "row") if native else _GlooShardedStep(model, rank, world, local_rank, "row")
+    reqs = [step.prepare(r.inputs, r.symbols) for r in (model.make_request(s) for s in range(4))]
+
+    def timed(fn, n):
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        for i in range(n):
+            fn(i)
+        e1.record()
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        if dist:
+            t = torch.tensor([el], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el / n, e0.elapsed_time(e1) * 1e-3 / n
+
+    run = lambda i: step.run(reqs[i % len(reqs)])
+    for i in range(5):
+        run(i)
+    per, _ = timed(run, 5)                                  # sizes the timed loops to the budget
+    n = int(max(5, min(400, 0.35 * budget_s / max(per, 1e-6))))
+    step_s, step_dev_s = timed(run, n)
+    sent = batch * width * 4 * (world - 1) // world
+    rec = {"mode": "row", "backend": backend, "columns": columns, "batch": batch, "vocab": vocab,
+           "table_GB_total": columns * vocab * (per_row / columns) / 1e9, "table_GB_per_rank": vocab * per_row / world / 1e9,
+           "steps": n, "step_us": step_s * 1e6, "step_device_us": step_dev_s * 1e6,
+           "inferences_per_s": batch / step_s,
+           "exchange_bytes_sent_per_rank_per_request": int(sent),
+           "what": "BASELINE configs[4] at its own shape (4000 S2-shaped columns, batch 512, every table row-sharded id % world) on the "
+                   "ranks of this run: partial kernel -> grouped ncclSend / ncclRecv of partial sums (RCCL over xGMI) -> "
+                   "fcp_shard_finalize as one native call per request; `exchange_us` = the exchange alone on a resident partial; "
+                   "never part of `value` (the default workload's tables fit one GPU: replicas, no collective)"}
+    if native:
+        L = _lib.load()
+        r_, w_ = C.c_int32(), C.c_int32()
+        _lib.check(L.fcp_comm_rank(comm.handle, C.byref(r_), C.byref(w_)), "fcp_comm_rank")
+        rec["ranks_seen_by_rccl"] = int(w_.value)
+        partial = torch.zeros((batch, width), dtype=torch.float32, device=step.dev)
+        sl = batch_slices(batch, world)
+        slices = torch.empty((world, max(c for _, c in sl), width), dtype=torch.float32, device=step.dev)
+        b_, c_ = C.c_int64(), C.c_int64()
+
+        def exch(i):
+            _lib.check(L.fcp_shard_exchange(comm.handle, partial.data_ptr(), batch, width, slices.data_ptr(), C.byref(b_), C.byref(c_),
+                                            torch.cuda.current_stream(step.dev).cuda_stream), "fcp_shard_exchange")
+        for i in range(5):
+            exch(i)
+        ex_s, ex_dev_s = timed(exch, n)
+        rec["exchange_us"] = ex_dev_s * 1e6
+        rec["exchange_GBs_per_rank"] = sent / ex_dev_s / 1e9 if ex_dev_s > 0 else None
+        del partial, slices
+    else:
+        rec["ranks_seen_by_rccl"] = 0
+        rec["note"] = f"backend {backend}: the exchange is staged through the host (control flow of the N > 1 run on a 1-GPU box); no RCCL, no xGMI figure"
+        path = RowShardedPath(rank, world)
+        partial = torch.zeros((batch, width), dtype=torch.float32, device=step.dev)
+        ex_s, _ = timed(lambda i: path.exchange(partial), max(3, n // 4))
+        rec["exchange_us"] = ex_s * 1e6
+        rec["exchange_GBs_per_rank"] = sent / ex_s / 1e9 if ex_s > 0 else None
+    step.close()
+    if comm is not None:
+        comm.close()
+    del step, reqs
+    torch.cuda.empty_cache()
     return rec

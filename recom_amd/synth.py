@@ -159,6 +159,40 @@ def staged_model(model: SynthModel) -> SynthModel:
                       model.description + "; requests as staged (ids int32, row ids -> CSR offsets on the host)")
 
 
+def grouped_csr_model(model: SynthModel) -> SynthModel:
+    """The same model with its host inputs re-ordered so that the row-offset (CSR) inputs of the pooled columns come LAST,
+    in the columns' concat order: ``Addons>ConcatInputs`` packs inputs back to back in input order
+    (concat_inputs_ops.cc:52-60), so the CSR arrays then lie one (rows + 1) x 4 bytes apart in the blob — the regular layout
+    the ragged kernel's front recognises per request (FcpLaunch::csr_reg, mode 2: ranges requested together with the column
+    records).  The order of a ConcatInputs node's inputs is the plan builder's to choose (``recom_amd.graph`` --staged)."""
+    import dataclasses
+    from .plan import SEG_CSR_I32
+    spec = model.spec
+    order = sorted(range(spec.n_columns), key=lambda k: (spec.columns[k].concat_group, spec.columns[k].concat_slot))
+    seg_inputs = []
+    for k in order:
+        c = spec.columns[k]
+        if c.seg_kind == SEG_CSR_I32 and c.seg_input >= 0 and c.seg_input not in seg_inputs:
+            seg_inputs.append(c.seg_input)
+    tail = set(seg_inputs)
+    perm = [i for i in range(spec.n_host_inputs) if i not in tail] + seg_inputs      # new position -> old index
+    new_of = {old: new for new, old in enumerate(perm)}
+    from .plan import ROWS_FROM_INPUT_DIM0
+    cols = [dataclasses.replace(c, ids_input=new_of.get(c.ids_input, -1), seg_input=new_of.get(c.seg_input, -1),
+                                rows_arg=new_of[c.rows_arg] if c.rows_source == ROWS_FROM_INPUT_DIM0 else c.rows_arg)
+            for c in spec.columns]
+    spec2 = dataclasses.replace(spec, columns=cols, host_input_ranks=[spec.host_input_ranks[i] for i in perm],
+                                host_input_elem_sizes=[spec.host_input_elem_sizes[i] for i in perm])
+    spec2.validate()
+
+    def make_request(seed: int, B: int = model.batch) -> Request:
+        r = model.make_request(seed, B)
+        return Request([r.inputs[i] for i in perm], r.symbols)
+
+    return SynthModel(model.name, spec2, model.tables, model.batch, make_request,
+                      model.description + "; CSR inputs last, in column order (regular in the blob)")
+
+
 class _Builder:
     """Assigns host-input / table slots while columns are added."""
 

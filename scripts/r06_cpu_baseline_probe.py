@@ -14,6 +14,7 @@ ap.add_argument("--columns", type=int, default=200)
 ap.add_argument("--seconds", type=float, default=2.0)
 ap.add_argument("--workers", default="8,16,32,64,128,256")
 ap.add_argument("--label", default="")
+ap.add_argument("--dataflow", type=int, default=0, help="0: every column straight into the concat matrix; 1: TF-CPU's (column tensors + ConcatV2)")
 args = ap.parse_args()
 import fcp_oracle
 from recom_amd import synth
@@ -33,9 +34,9 @@ plan = model.spec.to_dict()
 cores = len(os.sched_getaffinity(0))
 out = {}
 for w in [int(x) for x in args.workers.split(",") if int(x) <= cores]:
-    done, sec = orc.serve_for(plan, packed, tables, None, w, args.seconds)
+    done, sec = orc.serve_for(plan, packed, tables, None, w, args.seconds, args.dataflow)
     out[str(w)] = round(model.batch * done / sec)
 thp = open("/sys/kernel/mm/transparent_hugepage/enabled").read().strip() if os.path.exists("/sys/kernel/mm/transparent_hugepage/enabled") else "?"
-print(json.dumps({"label": args.label, "columns": args.columns, "vocab": args.vocab, "table_GB": sum(a.nbytes for a in tables) / 1e9,
+print(json.dumps({"label": args.label, "dataflow": args.dataflow, "columns": args.columns, "vocab": args.vocab, "table_GB": sum(a.nbytes for a in tables) / 1e9,
                   "fill_s": round(fill_s, 1), "OMP_PROC_BIND": os.environ.get("OMP_PROC_BIND"), "OMP_PLACES": os.environ.get("OMP_PLACES"),
                   "thp": thp, "inferences_per_s_by_workers": out}))

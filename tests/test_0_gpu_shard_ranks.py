@@ -175,6 +175,8 @@ def test_bench_gpus_2_starts_its_ranks_and_prints_one_line(workload):
     if workload != "s2":
         cmd += ["--workload", workload]
         env["FCP_BENCH_HBM_BYTES"] = str(24 << 20)              # 48 tables of 160 KB .. 1.3 MB: 29 MB do not fit "one GPU"
+    else:
+        env["FCP_BENCH_SHARD_COLUMNS"], env["FCP_BENCH_SHARD_VOCAB"] = "400", "3000"   # the `sharded` side record, shrunk
     res = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
     assert res.returncode == 0, res.stderr[-3000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
@@ -183,16 +185,26 @@ def test_bench_gpus_2_starts_its_ranks_and_prints_one_line(workload):
     assert rec["n_gpus"] == 2 and rec["steps"] == 20 and rec["value"] > 0 and rec["unit"] == "inferences/s"
     if workload == "s2":
         assert rec["scaling"] == "weak" and "replica" in rec["config"]["parallelism"]
+        # (r6) the default multi-GPU line carries BASELINE configs[4]'s row-sharded step on the same ranks as a side record:
+        # here 400 S2-shaped columns at the run's batch over gloo (the 1-GPU box: no RCCL, the record says so)
+        sh = rec["sharded"]
+        assert "error" not in sh, sh
+        width = sum((8, 16, 32, 64)[c % 4] for c in range(400))
+        assert sh["mode"] == "row" and sh["backend"] == "gloo" and sh["columns"] == 400 and sh["batch"] == 64 and sh["vocab"] == 3000
+        assert sh["exchange_bytes_sent_per_rank_per_request"] == 64 * width * 4 // 2      # (world - 1) / world of the partial
+        assert sh["step_us"] > 0 and sh["exchange_us"] > 0 and sh["ranks_seen_by_rccl"] == 0
     else:
-        # `shard` follows the gate's mixed preference: every table of this model fits "one GPU" -> whole columns
-        assert ("row-sharded" if workload == "shard-row" else "column-sharded") in rec["config"]["parallelism"]
+        # `shard` IS BASELINE configs[4]: its own line is the row-sharded step; what the gate prefers (every table of this
+        # model fits "one GPU" -> whole columns) rides beside it
+        assert ("column-sharded" if workload == "shard-col" else "row-sharded") in rec["config"]["parallelism"]
         assert rec["config"]["exchange_bytes_sent_per_rank_per_request"] > 0
-        if workload == "shard":                                  # the gate's choice AND BASELINE configs[4]'s row sharding, one run
-            conf = rec["row_sharded_conformity"]
-            assert "row-sharded" in conf["parallelism"] and conf["value"] > 0
-            assert conf["exchange_bytes_sent_per_rank_per_request"] > rec["config"]["exchange_bytes_sent_per_rank_per_request"]
+        assert "sharded" not in rec
+        if workload == "shard":
+            g = rec["gate_choice"]
+            assert "column-sharded" in g["parallelism"] and g["value"] > 0
+            assert g["exchange_bytes_sent_per_rank_per_request"] < rec["config"]["exchange_bytes_sent_per_rank_per_request"]
         else:
-            assert "row_sharded_conformity" not in rec
+            assert "gate_choice" not in rec
 
 
 def build_fake_rccl():

@@ -190,3 +190,21 @@ def test_native_exchange_and_step_world_1(torch_cuda, mode):
             assert (begin, count) == (0, want[0].shape[0]) and np.array_equal(got, want[0]), (m.name, seed)
         step.close()
     comm.close()
+
+
+def test_sharded_side_record_of_the_default_bench_line_over_rccl_world_1(torch_cuda, monkeypatch):
+    """bench.py attaches BASELINE configs[4]'s row-sharded step to its default multi-GPU line (`sharded`,
+    recom_amd.shard.bench_row_sharded_record).  On the one GPU a test box has: world 1, no process group — the NATIVE branch
+    (RCCL communicator, fcp_shard_step_run, fcp_shard_exchange timed alone), shrunk to 200 columns; the record's arithmetic
+    and that RCCL counted the rank."""
+    import types
+    from recom_amd.shard import bench_row_sharded_record
+    monkeypatch.setenv("FCP_BENCH_SHARD_COLUMNS", "200")
+    monkeypatch.setenv("FCP_BENCH_SHARD_VOCAB", "4000")
+    rec = bench_row_sharded_record(types.SimpleNamespace(batch=96), 0, 1, 0, None, 8 << 30, budget_s=1.0)
+    width = sum((8, 16, 32, 64)[c % 4] for c in range(200))
+    assert rec["mode"] == "row" and rec["backend"] == "none" and rec["ranks_seen_by_rccl"] == 1
+    assert (rec["columns"], rec["batch"], rec["vocab"]) == (200, 96, 4000)
+    assert rec["exchange_bytes_sent_per_rank_per_request"] == 0          # world 1: nothing leaves the GPU
+    assert rec["step_us"] > 0 and rec["exchange_us"] > 0 and rec["steps"] >= 5
+    assert abs(rec["table_GB_per_rank"] - 4000 * width * 4 / 1e9) < 1e-9

@@ -546,3 +546,27 @@ def test_oracle_equals_the_vectors_the_references_kernels_produced(oracle):
             cub = oracle.sparse_segment_reduce_refscan(x["table"], x["ids"], x["seg"], B, mean)
             assert np.abs(cub - want).max(initial=0) < (1e-5 if case["max_len"] <= 10 else 1e-4)   # the other scan order: reassociation only
     assert kinds == {"gather_rows", "gather_scatter_rows", "segment_offsets", "segment_reduce_8x8", "segment_reduce_scan"}
+
+
+def test_tf_cpu_dataflow_of_the_cpu_baseline_equals_the_fused_layout(oracle):
+    """bench.py's cpu_baseline serves through TensorFlow-CPU's dataflow for the unrewritten graph (one [rows, dim] tensor per
+    column op, then ConcatV2: orc_process_feature_columns_unfused); the values are those of the checker's direct form bit
+    for bit, bad-id count included, on the model with every form / id source / segment encoding — and the serving loop runs
+    in both dataflows."""
+    from recom_amd import synth
+    from recom_amd.ops import concat_inputs
+    for model in (synth.model_mixed(batch=33, vocab=97), synth.model_s2(columns=24, vocab=500, batch=20)):
+        req = model.make_request(3)
+        blob, offsets, shapes = concat_inputs(req.inputs)
+        tables = model.numpy_tables()
+        plan = model.spec.to_dict()
+        a, bad_a = oracle.process_feature_columns(plan, blob, offsets, shapes, tables, req.symbols)
+        b, bad_b = oracle.process_feature_columns(plan, blob, offsets, shapes, tables, req.symbols, unfused=True)
+        assert bad_a == bad_b and len(a) == len(b)
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+    model = synth.model_s2(columns=24, vocab=500, batch=20)
+    packed = [concat_inputs(model.make_request(i).inputs) for i in range(3)]
+    for dataflow in (0, 1):
+        done, sec = oracle.serve_for(model.spec.to_dict(), packed, model.numpy_tables(), None, 2, 0.05, dataflow)
+        assert done >= 2 and sec > 0
