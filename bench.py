@@ -501,7 +501,7 @@ def main():
     _, _, it = h.run(min(max(args.steps, 200), 500), per_request=True)
     # What the output costs by reuse distance of the arena: the same loop over rings of 1 / 2 / 6 arenas,
     # the library choosing its store policy per request (plain stores into an arena one of the plan's last two requests wrote,
-    # nt / sc1 nt otherwise: store_policy_for, fcp_api.hip).  Extra field only; `value` is the ring --arena-ring names.
+    # nt / sc1 nt otherwise: store_policy_for, fcp_process.hip).  Extra field only; `value` is the ring --arena-ring names.
     arena_reuse = None
     if args.threads == 1 and not dist and not args.no_overlap:
         arena_reuse = {"what": "stream order, one serve worker, HIP-event us per request by the number of output arenas the loop rotates "

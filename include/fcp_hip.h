@@ -411,7 +411,8 @@ int fcp_process_feature_columns(fcp_plan_t *plan,
                                 const fcp_process_args_t *args,
                                 fcp_process_result_t *result);
 
-/* ---- plan-owned private streams: overlap behind ONE caller stream ---------- */
+/* ---- plan-owned private streams: overlap behind ONE caller stream (EXPERIMENTAL: opt-in, frozen since round 5; the default
+ * request path never enters it; recom_amd/csrc/fcp_lanes.hip) ---------- */
 /* TensorFlow hands a GPU op exactly one compute stream
  * (feature_column_process_op_gpu.cu.cc:65-131 takes it from the op context; the
  * serve workers of the reference harness share one Session and therefore that one
@@ -516,7 +517,7 @@ int fcp_process_feature_columns(fcp_plan_t *plan,
  * (largest gap), FCP_LANE_KEEP_RATIO tune it; fcp_plan_private_streams_stats reads
  * it; fcp_plan_verify_private_streams (a new search) starts it over. */
 enum { FCP_PRIVATE_NO_CALLER_WAIT = 1u << 0, FCP_PRIVATE_ALWAYS = 1u << 1, FCP_PRIVATE_NO_VERIFY = 1u << 2 };
-int fcp_plan_set_private_streams(fcp_plan_t *plan, int32_t n_streams, uint32_t flags);
+/* experimental */ int fcp_plan_set_private_streams(fcp_plan_t *plan, int32_t n_streams, uint32_t flags);
 
 /* Diagnostic: do the plan's private streams overlap behind THIS caller stream, in THIS process?  Whether event-linked
  * streams overlap depends on which hardware queues the HIP runtime mapped them to — the creation order of every stream of
@@ -529,11 +530,11 @@ int fcp_plan_set_private_streams(fcp_plan_t *plan, int32_t n_streams, uint32_t f
  * ending with a synchronisation of `stream`.  *lanes_us well below *serial_us: they overlap.  (The library runs this
  * probe itself on the first request of every caller stream, see Verification above; the entry point is for harnesses
  * and for processes that pass FCP_PRIVATE_NO_VERIFY.) */
-int fcp_plan_probe_private_streams(fcp_plan_t *plan, void *stream, int32_t requests, int32_t spin_us, int32_t grid_blocks,
+/* experimental */ int fcp_plan_probe_private_streams(fcp_plan_t *plan, void *stream, int32_t requests, int32_t spin_us, int32_t grid_blocks,
                                    double *serial_us, double *lanes_us);
 /* What the verification decided for `stream`: *verdict = 1 (its requests take the private streams), 0 (they stay on
  * `stream`: nothing overlapped behind it) or -1 (no request of that stream verified yet, or the mode is off). */
-int fcp_plan_private_streams_verdict(fcp_plan_t *plan, void *stream, int32_t *verdict);
+/* experimental */ int fcp_plan_private_streams_verdict(fcp_plan_t *plan, void *stream, int32_t *verdict);
 /* The verification at a time of the caller's choosing (warm-up): probes the private streams behind `stream` now and, while
  * no live plan relies on the present mapping, searches another one for at most about budget_ms of wall time (<= 0: 400 ms;
  * one mapping costs ~8 ms, the whole search space ~22 of them).  A negative verdict of an earlier, cheaper look — or a
@@ -542,7 +543,7 @@ int fcp_plan_private_streams_verdict(fcp_plan_t *plan, void *stream, int32_t *ve
  * host, drains `stream`.  *verdict (optional) as fcp_plan_private_streams_verdict; -1 when the mode is off, or when the
  * plan's requests so far are below the work threshold (they stay on `stream` anyway: nothing is probed).  Call it after
  * the first (warm-up) request of the plan, as the shim does. */
-int fcp_plan_verify_private_streams(fcp_plan_t *plan, void *stream, int32_t budget_ms, int32_t *verdict);
+/* experimental */ int fcp_plan_verify_private_streams(fcp_plan_t *plan, void *stream, int32_t budget_ms, int32_t *verdict);
 /* What the run-time supervisor of the plan's private streams has seen (see Supervision above). */
 typedef struct fcp_private_streams_stats {
   void *supervised_stream;        /* the caller stream under supervision (the first that took the private streams), or NULL   */
@@ -556,7 +557,7 @@ typedef struct fcp_private_streams_stats {
   int32_t demoted;                /* 1: the supervisor keeps this caller's requests on its own stream at present              */
   int32_t evaluation_in_progress; /* 1: an evaluation is running or waiting for its timing events                             */
 } fcp_private_streams_stats_t;
-int fcp_plan_private_streams_stats(fcp_plan_t *plan, fcp_private_streams_stats_t *out);
+/* experimental */ int fcp_plan_private_streams_stats(fcp_plan_t *plan, fcp_private_streams_stats_t *out);
 
 /* The cheap half of the same idea, for callers that OWN their buffers: FCP_ORDER_INPUTS_READY is the caller's promise, for
  * every request of the plan, that when fcp_process_feature_columns is CALLED the blob is complete in device memory and
@@ -577,13 +578,13 @@ int fcp_plan_private_streams_stats(fcp_plan_t *plan, fcp_private_streams_stats_t
  * RAGGED as delivered 34.4 -> 33.5 us), the inverse-map memset and the descriptor upload kernel are not.
  * Default: FCP_ORDER_STREAM. */
 enum { FCP_ORDER_STREAM = 0, FCP_ORDER_INPUTS_READY = 1 };
-int fcp_plan_set_request_order(fcp_plan_t *plan, int32_t order);
-int fcp_result_wait(const void *buffer, void *stream);
+/* experimental */ int fcp_plan_set_request_order(fcp_plan_t *plan, int32_t order);
+/* experimental */ int fcp_result_wait(const void *buffer, void *stream);
 /* A host reader: returns once the request has completed on the device.  What that guarantees is device-scope: copies and
  * kernels issued afterwards (hipMemcpy*, any stream) see the result.  A host that reads the arena DIRECTLY — host-mapped or
  * fine-grained memory — gets no system-scope visibility from it (the completion events carry no system fence, which is what
  * keeps them off the GPU's critical path): such a reader copies through the device or synchronises a stream of its own. */
-int fcp_result_synchronize(const void *buffer);
+/* experimental */ int fcp_result_synchronize(const void *buffer);
 
 /* ---- ConcatOutputs (concat_outputs_op_gpu.cu.cc:85-140) ------------------ */
 /* out[p, off_k : off_k + dims[k]] = inputs[k][p*dims[k] ...] for k < n.

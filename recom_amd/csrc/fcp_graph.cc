@@ -17,6 +17,7 @@
 // The same walk exists in Python (recom_amd/graph/: the offline tool `python -m recom_amd.graph`);
 // tests/test_graph_plan.py requires both builders to write identical plan files and equal rewritten graphs.
 // Host-only plain C++ (compiled with g++ into libfcp_hip.so).
+#include "fcp_env.h"
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -36,7 +37,13 @@
 
 #include "../../include/fcp_hip.h"
 
-int fcp_internal_fail(int code, const std::string &msg); // fcp_api.hip: sets fcp_last_error
+// diagnostic: FCP_DIAG=graph_debug prints the plan builder's decisions on stderr
+static bool graph_debug() {
+  static const bool on = fcp::diag_on("graph_debug");
+  return on;
+}
+
+int fcp_internal_fail(int code, const std::string &msg); // fcp_plan.hip: sets fcp_last_error
 
 namespace {
 
@@ -1015,7 +1022,7 @@ struct PlanBuilder {
         if (dt != DT_FLOAT) continue;
         shape = g.static_shape({&n, 0});
       }
-      if (getenv("FCP_GRAPH_DEBUG")) fprintf(stderr, "fcp_graph: table candidate %s (%s): rank %d\n", n.name.c_str(), n.op.c_str(), shape ? (int)shape->size() : -1);
+      if (graph_debug()) fprintf(stderr, "fcp_graph: table candidate %s (%s): rank %d\n", n.name.c_str(), n.op.c_str(), shape ? (int)shape->size() : -1);
       if (!shape || shape->size() != 2 || !GraphView::all_known(*shape) || std::min(*(*shape)[0], *(*shape)[1]) <= 0) continue;
       std::vector<std::string> stack{n.name};
       int lookups = 0;
@@ -1033,7 +1040,7 @@ struct PlanBuilder {
           }
         }
       }
-      if (getenv("FCP_GRAPH_DEBUG")) fprintf(stderr, "fcp_graph:   -> ok %d lookups %d\n", (int)ok, lookups);
+      if (graph_debug()) fprintf(stderr, "fcp_graph:   -> ok %d lookups %d\n", (int)ok, lookups);
       if (ok && lookups) tables[n.name] = {*(*shape)[0], *(*shape)[1]};
     }
   }
@@ -1548,7 +1555,7 @@ struct PlanBuilder {
         continue;
       }
       if (!axis || axis->v.empty() || ((int64_t)axis->v[0] != 1 && (int64_t)axis->v[0] != -1) || dtype != DT_FLOAT) {
-        if (getenv("FCP_GRAPH_DEBUG")) fprintf(stderr, "fcp_graph: concat %s skipped (axis const %d, dtype %d)\n", concat.name.c_str(), axis ? 1 : 0, dtype);
+        if (graph_debug()) fprintf(stderr, "fcp_graph: concat %s skipped (axis const %d, dtype %d)\n", concat.name.c_str(), axis ? 1 : 0, dtype);
         continue;
       }
       // snapshot: a group that turns out unusable must not leave operands behind
@@ -1568,7 +1575,7 @@ struct PlanBuilder {
             ++lookups;
             value = tensor_name(r.first->name, r.second);
           } catch (const Unsupported &why) {
-            if (getenv("FCP_GRAPH_DEBUG")) fprintf(stderr, "fcp_graph: %s input %d (%s, %s): %s\n", concat.name.c_str(), i, r.first->name.c_str(), r.first->op.c_str(), why.what());
+            if (graph_debug()) fprintf(stderr, "fcp_graph: %s input %d (%s, %s): %s\n", concat.name.c_str(), i, r.first->name.c_str(), r.first->op.c_str(), why.what());
             col = host_column(ins[i], group, i);
             value = ins[i];
             if (tables.count(r.first->name) || !upstream_tables(*r.first).empty()) out.skipped.push_back({r.first->name, why.what()});
@@ -1578,7 +1585,7 @@ struct PlanBuilder {
         }
         if (lookups == 0) throw Unsupported("no lookup column converges here");
       } catch (const Unsupported &why) {
-        if (getenv("FCP_GRAPH_DEBUG")) fprintf(stderr, "fcp_graph: concat %s given up: %s\n", concat.name.c_str(), why.what());
+        if (graph_debug()) fprintf(stderr, "fcp_graph: concat %s given up: %s\n", concat.name.c_str(), why.what());
         std::tie(host_ix, host_list, dev_ix, dev_list, sym_ix, sym_list) = snap;
         if (lookups) out.skipped.push_back({concat.name, why.what()});
         continue;

@@ -1,5 +1,5 @@
 // fcp_internal.h — device-visible plan records shared by the host side
-// (fcp_api.hip) and the kernels (fcp_kernels.hip).  gfx950 only.
+// (fcp_plan.hip, fcp_process.hip, ...: fcp_host.h) and the kernels (fcp_kernels.hip).  gfx950 only.
 //
 // What the reference passes to its generated kernel as one flat `KnlArgs`
 // struct of per-model pointers and ints (graph_optimizers/cuda_emitter.cc

@@ -41,6 +41,7 @@
 #include "../../include/fcp_hip.h"
 #include <hip/hip_ext.h>
 #include "fcp_internal.h"
+#include "fcp_env.h"
 
 namespace {
 
@@ -77,6 +78,10 @@ template <int V> __device__ __forceinline__ VF<V> vzero() {
 // cache policy: streaming them (-DFCP_NT_LOADS) changes nothing on S2 (1M-row tables,
 // uniform ids) but costs the reference's models E / F 4.5 us per request — their ~1000
 // bucketize / hash tables of ~100 rows are re-read by every row and belong in L2.
+// (r6) A per-column choice — non-temporal reads for tables far beyond an XCD's L2, default policy for the small hot ones —
+// was built and measured too, because a bare gather probe reads 11 % faster with `nt` at every row size (53.7 against 48.5
+// G rows/s): inside the fused kernels it moved nothing (S2 27.39 against 27.35 us, model F 12.9 / 12.9, RAGGED -0.5 us in
+// one encoding, +0 in the other: profiles/r06_streamed_table_reads_negative.txt) and was taken out again.
 // -DFCP_NO_NT restores the default policy for stores as well (tuning builds).
 // Write-through form (`sc1 nt`: the line leaves the XCD's L2 at once instead of at the kernel boundary) for
 // outputs larger than the L2s can hold — S2's 61 MB: 28.4 vs 29.0 us per request; outputs that FIT the
@@ -1524,7 +1529,7 @@ __global__ void __launch_bounds__(FCP_BLOCK_THREADS) fcp_h2d_copy_kernel(const c
 
 // ------------------------------- launchers ---------------------------------
 
-// Private-stream requests (fcp_api.hip): the completion event of a request is attached to the dispatch packet of its
+// Private-stream requests (fcp_lanes.hip): the completion event of a request is attached to the dispatch packet of its
 // LAST kernel (hipExtLaunchKernelGGL's stop event) instead of being recorded as a marker packet of its own behind it.
 // Thread-local: set by the request path just before it enqueues, taken (and cleared) by the fused / hybrid launcher.
 static thread_local hipEvent_t tl_stop_event = nullptr;
@@ -1568,11 +1573,8 @@ void fcp_set_any_order(bool on) { tl_launch_flags = on ? (int)hipExtAnyOrderLaun
 // rows_per_wave: dense 1 | 2 | 4 (rows per block = 4 x that); ragged always 1.
 int fcp_launch_fused(const FcpLaunch &L, int vec, bool dense_kernel, int grid_blocks, ihipStream_t *s) {
   if (grid_blocks <= 0) return 0;
-  // tuning aid: FCP_LDS_PAD=<bytes> of unused dynamic LDS caps the blocks per CU
-  static const int lds_pad = [] {
-    const char *e = getenv("FCP_LDS_PAD");
-    return e ? atoi(e) : 0;
-  }();
+  // tuning aid: FCP_DIAG=lds_pad=<bytes> of unused dynamic LDS caps the blocks per CU
+  static const int lds_pad = (int)fcp::diag_ll("lds_pad", 0);
   if (dense_kernel) {
     const int R = L.rows_per_wave;
 #define FCP_DENSE_R(VV)                         \

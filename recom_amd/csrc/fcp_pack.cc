@@ -2,6 +2,7 @@
 // fcp_stager_stage_ex): int64 -> int32 narrowing and sorted row ids -> row offsets.  Plain C++ (no HIP), in a file of
 // its own so that the two loops can be built once per instruction set and picked at run time (function
 // multi-versioning): they read 16 bytes per id of a request and are what the CPU op spends its time in.
+#include "fcp_env.h"
 #include <stddef.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -166,7 +167,7 @@ __attribute__((target("avx512f"))) static int seg_to_csr_avx512(int kind, const 
 // returns 1 if the ids were not sorted (the offsets are then meaningless), else 0
 extern "C" int fcp_pack_seg_to_csr(const void *seg, int elem_size, int64_t stride, int64_t nnz, int64_t rows, int32_t *out) {
 #if defined(__x86_64__)
-  static const bool avx512 = __builtin_cpu_supports("avx512f") && !getenv("FCP_PACK_NO_AVX512"); // (tuning / test aid)
+  static const bool avx512 = __builtin_cpu_supports("avx512f") && !fcp::diag_on("pack_no_avx512"); // (tuning / test aid: FCP_DIAG=pack_no_avx512)
   if (avx512 && rows >= 0 && nnz < 0x7fffffff) {
     if (elem_size == 8 && stride == 2) return seg_to_csr_avx512(kSegI64x2, seg, nnz, rows, out);
     if (elem_size == 8 && stride == 1) return seg_to_csr_avx512(kSegI64, seg, nnz, rows, out);

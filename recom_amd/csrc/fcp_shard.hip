@@ -27,10 +27,11 @@
 #include <vector>
 
 #include "../../include/fcp_hip.h"
+#include "fcp_env.h"
 
-// failure reporting shared with fcp_api.hip
+// failure reporting shared with fcp_plan.hip
 int fcp_internal_fail(int code, const std::string &msg);
-extern "C" int fcp_internal_process(fcp_plan_t *p, const fcp_process_args_t *a, fcp_process_result_t *r); // fcp_api.hip
+extern "C" int fcp_internal_process(fcp_plan_t *p, const fcp_process_args_t *a, fcp_process_result_t *r); // fcp_process.hip
 
 namespace {
 
@@ -59,8 +60,8 @@ Rccl *rccl() {
   static Rccl r;
   static std::once_flag once;
   std::call_once(once, [] {
-    const char *env = std::getenv("FCP_RCCL_PATH");
-    const char *names[] = {env, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    static const std::string path = fcp::read_env().rccl_path; // FCP_RCCL_PATH, read once: here
+    const char *names[] = {path.empty() ? nullptr : path.c_str(), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char *n : names) {
       if (!n) continue;
       r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);

@@ -2,6 +2,7 @@
 // Plain C++ (no HIP) so that tests/native/pack_pool_stress.cc can run it under
 // ThreadSanitizer on the CPU.
 #pragma once
+#include "fcp_env.h"
 #include <atomic>
 #include <condition_variable>
 #include <cstdint>
@@ -116,8 +117,7 @@ private:
   // FCP_PACK_FANOUT (tuning aid): 0 = the caller wakes every sleeper itself (notify_all); k > 0 = the caller wakes k, every
   // woken worker k more
   const int kFanout = [] {
-    const char *e = std::getenv("FCP_PACK_FANOUT");
-    return e ? std::atoi(e) : 2;
+    return (int)fcp::diag_ll("pack_fanout", 2); // tuning aid
   }();
   static constexpr int kIdxBits = 20, kMaxChunks = (1 << kIdxBits) - 1;
   static uint64_t pack(uint64_t e, int n, int idx) {
@@ -164,10 +164,9 @@ private:
     }
   }
   // how long a woken worker spins for the announced job: ~20-40 us of pause instructions, a few times the layout phase
-  // that separates expect() from run() (FCP_PACK_SPINS: tuning aid)
+  // that separates expect() from run() (FCP_DIAG=pack_spins=N: tuning aid)
   const int kSpins = [] {
-    const char *e = std::getenv("FCP_PACK_SPINS");
-    return e ? std::atoi(e) : 1 << 10;
+    return (int)fcp::diag_ll("pack_spins", 1 << 10);
   }();
   cpu_set_t affinity_;
   bool pinned_ = false;

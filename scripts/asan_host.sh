@@ -10,10 +10,10 @@ mkdir -p $OUT
 CLANG=/opt/rocm/lib/llvm/bin/clang++
 SAN="-std=c++17 -fPIC -O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer"
 ( cd recom_amd/csrc && $CLANG $SAN -c fcp_graph.cc -o $OUT/fcp_graph.o && $CLANG $SAN -c fcp_pack.cc -o $OUT/fcp_pack.o &&
-  for f in fcp_kernels fcp_api fcp_shard; do
+  for f in fcp_kernels fcp_plan fcp_process fcp_lanes fcp_concat fcp_stager fcp_shard; do
     /opt/rocm/bin/hipcc --offload-arch=gfx950 $SAN -Xarch_device -fno-sanitize=address,undefined -c $f.hip -o $OUT/$f.o || exit 1
   done &&
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -fsanitize=address,undefined -shared $OUT/fcp_kernels.o $OUT/fcp_api.o $OUT/fcp_shard.o \
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -fsanitize=address,undefined -shared $OUT/fcp_kernels.o $OUT/fcp_plan.o $OUT/fcp_process.o $OUT/fcp_lanes.o $OUT/fcp_concat.o $OUT/fcp_stager.o $OUT/fcp_shard.o \
     $OUT/fcp_graph.o $OUT/fcp_pack.o -o $OUT/libfcp_hip.so -ldl )
 RT=$(find /opt/rocm/lib/llvm/lib/clang -name "libclang_rt.asan-x86_64.so" | head -1)
 LD_PRELOAD=$RT ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0 FCP_LIB_DIR=$OUT python -m pytest tests/test_host.py tests/test_graph_plan.py \

@@ -819,7 +819,7 @@ def test_request_stager_matches_concat_inputs_and_feeds_the_kernel(torch_cuda, o
 @pytest.mark.parametrize("groups", ["1", "4", "16"])
 def test_request_stager_ships_a_request_in_groups_with_either_copy_engine(torch_cuda, oracle, monkeypatch, copy, groups):
     """Round 5: a request is packed in groups of inputs and every group is shipped as soon as it is packed (FCP_STAGER_GROUPS,
-    here for every request: FCP_STAGER_GROUPS_ALWAYS), by a copy KERNEL on the stager's stream (the default: no SDMA engine in
+    here for every request: FCP_DIAG=stager_groups_always), by a copy KERNEL on the stager's stream (the default: no SDMA engine in
     the path) or by hipMemcpyAsync (FCP_STAGER_COPY_SDMA).  A request large enough for several pack chunks (64 KB each), odd
     tensor sizes (group boundaries at any 4-byte offset): the device blob is byte-identical to ConcatInputs' output, the
     kernel's result through it equals the oracle, the stager counts one copy call per group."""
@@ -828,7 +828,7 @@ def test_request_stager_ships_a_request_in_groups_with_either_copy_engine(torch_
     from recom_amd.ops import FeatureColumnProcess, RequestStager, concat_inputs
     torch = torch_cuda
     monkeypatch.setenv("FCP_STAGER_GROUPS", groups)
-    monkeypatch.setenv("FCP_STAGER_GROUPS_ALWAYS", "1")
+    monkeypatch.setenv("FCP_DIAG", "stager_groups_always")
     m = synth.model_mixed(batch=2051, vocab=4999, n_groups=1)          # ~1 MB of host tensors per request
     tabs_np = m.numpy_tables()
     tabs = [torch.from_numpy(t).cuda() for t in tabs_np]
@@ -866,7 +866,7 @@ def test_request_stager_groups_with_one_and_two_byte_tensors(torch_cuda, monkeyp
     from recom_amd.ops import RequestStager, concat_inputs
     torch = torch_cuda
     monkeypatch.setenv("FCP_STAGER_GROUPS", "7")
-    monkeypatch.setenv("FCP_STAGER_GROUPS_ALWAYS", "1")
+    monkeypatch.setenv("FCP_DIAG", "stager_groups_always")
     rng = np.random.default_rng(5)
     st = RequestStager(16 << 20, 64, 128, depth=2, n_threads=5, copy=copy)
     hip = C.CDLL("libamdhip64.so")
@@ -1622,9 +1622,9 @@ def test_a_table_beyond_64_gb(torch_cuda, oracle):
 @pytest.mark.gpu
 def test_wide_row_path_of_the_dense_kernel_on_ordinary_plans(torch_cuda, oracle, golden, monkeypatch):
     """The dense body's 64-bit row path (taken when some table has 2^32 - 3 slots or more) forced onto ordinary plans
-    (FCP_WIDE_ROWS, read at plan creation): golden cases and the mixed model stay bit-exact."""
+    (FCP_DIAG=wide_rows, read at plan creation): golden cases and the mixed model stay bit-exact."""
     from recom_amd import synth
-    monkeypatch.setenv("FCP_WIDE_ROWS", "1")
+    monkeypatch.setenv("FCP_DIAG", "wide_rows")
     for name in ("mixed_s0", "bucketize_kat", "scatter"):
         case = golden[0][name]
         out, _, _ = run_gpu(torch_cuda, case.spec(), case.inputs, case.tables, case.symbols)

@@ -419,11 +419,11 @@ def test_fast_and_general_shape_evaluation_agree(monkeypatch):
         for seed in range(3):
             req = m.make_request(seed)
             _, _, shapes = concat_inputs(req.inputs)
-            monkeypatch.delenv("FCP_DYN_GENERAL", raising=False)
+            monkeypatch.delenv("FCP_DIAG", raising=False)
             fast = p.arena_bytes(shapes, req.symbols)
-            monkeypatch.setenv("FCP_DYN_GENERAL", "1")
+            monkeypatch.setenv("FCP_DIAG", "dyn_general")
             assert p.arena_bytes(shapes, req.symbols) == fast > 0
-        monkeypatch.delenv("FCP_DYN_GENERAL", raising=False)
+        monkeypatch.delenv("FCP_DIAG", raising=False)
         gather = [c for c in m.spec.columns if c.form == 1]
         if gather:                                    # a one-hot column one element longer: row counts disagree
             bad = np.array(shapes, np.int32)
@@ -456,11 +456,11 @@ def test_external_slots_host_side(monkeypatch):
     req = m.make_request(0)
     _, _, shapes = concat_inputs(req.inputs)
     base = Plan(m.spec, host_only=True).arena_bytes(shapes, req.symbols)
-    monkeypatch.delenv("FCP_DYN_GENERAL", raising=False)
+    monkeypatch.delenv("FCP_DIAG", raising=False)
     fast = p.arena_bytes(shapes, req.symbols)
-    monkeypatch.setenv("FCP_DYN_GENERAL", "1")
+    monkeypatch.setenv("FCP_DIAG", "dyn_general")
     assert p.arena_bytes(shapes, req.symbols) == fast > base
-    monkeypatch.delenv("FCP_DYN_GENERAL", raising=False)
+    monkeypatch.delenv("FCP_DIAG", raising=False)
     for bad in (dataclasses.replace(ext, rows_source=ROWS_FROM_IDS),):
         with pytest.raises(ValueError):
             dataclasses.replace(m.spec, columns=m.spec.columns + [bad]).validate()
@@ -530,7 +530,7 @@ def test_row_ids_to_row_offsets_loop_both_code_paths():
     """fcp_pack_seg_to_csr (the host loop behind FCP_STAGE_SEG_TO_CSR): sorted row ids -> offsets[rows + 1], offsets[r] = the
     number of ids below row r — ComputeSegmentOffsets (cuda_emitter.cc:768-818) on the host.  The AVX-512 boundary form
     (int64 stride 2 = SparseTensor indices, int64 / int32 stride 1) and the portable run-length form (any stride; forced
-    with FCP_PACK_NO_AVX512 in a child process) against NumPy on adversarial inputs: empty, one id, nnz around multiples of
+    with FCP_DIAG=pack_no_avx512 in a child process) against NumPy on adversarial inputs: empty, one id, nnz around multiples of
     16, empty rows at both ends, ids of rows < 0 and >= rows (dropped), values beyond int32, unsorted ids (refused)."""
     import ctypes as C
     import subprocess
@@ -579,7 +579,7 @@ for dtype, strides in ((np.int64, (1, 2, 3)), (np.int32, (1, 2))):
                     cases += 1
 print("ok", cases)
 """ % ROOT
-    for env_extra in ({}, {"FCP_PACK_NO_AVX512": "1"}):
+    for env_extra in ({}, {"FCP_DIAG": "pack_no_avx512"}):
         res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env={**os.environ, **env_extra}, timeout=600)
         assert res.returncode == 0 and res.stdout.startswith("ok"), res.stderr[-3000:] + res.stdout[-500:]
 

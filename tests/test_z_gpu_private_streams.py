@@ -207,13 +207,13 @@ def test_private_streams_are_verified_per_caller_stream_and_results_do_not_depen
     """Whether event-linked streams overlap depends on the hardware queues the runtime mapped them to (N streams created
     before the lanes change it, profiles/r04_private_streams_queue_mapping.txt), so the first request of a caller stream
     probes it and the library may re-create its lanes or leave that caller's requests on its own stream.  Here: dummy
-    streams shift the mapping; every caller stream gets its verdict exactly once (FCP_PRIVATE_VERIFY_VERBOSE names it);
+    streams shift the mapping; every caller stream gets its verdict exactly once (FCP_DIAG=private_verify_verbose names it);
     results are bit-exact with the oracle whatever the verdict; FCP_PRIVATE_NO_VERIFY probes nothing; the diagnostic entry
     point reports both times of the synthetic pattern."""
     from recom_amd import synth
     from recom_amd.ops import FeatureColumnProcess, concat_inputs
     torch = torch_cuda
-    monkeypatch.setenv("FCP_PRIVATE_VERIFY_VERBOSE", "1")
+    monkeypatch.setenv("FCP_DIAG", "private_verify_verbose")
     m = synth.model_mixed(batch=96, vocab=997, n_groups=1)
     tabs_np = m.numpy_tables()
     tabs = [torch.from_numpy(t).cuda() for t in tabs_np]
@@ -585,7 +585,7 @@ def test_supervisor_demotes_a_caller_whose_private_streams_stop_overlapping(torc
     """a verdict is learnt once, the hardware-queue mapping can go bad later — and a caller's traffic may
     never gain from the private streams at all.  The supervisor A/Bs the two while serving: 48 requests on the caller's
     stream, 48 on the private streams, time per byte of work compared; two consecutive evaluations that the streams lose
-    demote the caller.  FCP_LANE_FAULT_US makes the lanes behave like a mapping that does not overlap (every lane request
+    demote the caller.  FCP_DIAG=lane_fault_us=N makes the lanes behave like a mapping that does not overlap (every lane request
     waits for the device's previous lane request and stalls 60 us: requests serialise at several times their stream-order
     cost); the lanes are used unverified (FCP_PRIVATE_NO_VERIFY) and driven by the native loop.  Demotion must come within
     1000 requests, be logged once, and every result before, at and after it stays bit-exact.  Then the fault goes away:
@@ -596,7 +596,7 @@ def test_supervisor_demotes_a_caller_whose_private_streams_stop_overlapping(torc
     from recom_amd.ops import FeatureColumnProcess
     torch = torch_cuda
     monkeypatch.delenv("FCP_LANE_SUPERVISE", raising=False)              # (the supervisor on, whatever the environment says)
-    monkeypatch.setenv("FCP_LANE_FAULT_US", "60")
+    monkeypatch.setenv("FCP_DIAG", "lane_fault_us=60,lane_log")
     monkeypatch.setenv("FCP_LANE_SUPERVISE_PERIOD", "256")               # evaluations at request 1, 1 + 256 (+ their windows), ...
     model = synth.model_s2(columns=96, vocab=5000, batch=512)
     h = ServingHarness(model, device=0, n_requests=8, arena_ring=6, n_threads=1)
@@ -634,7 +634,7 @@ def test_supervisor_demotes_a_caller_whose_private_streams_stop_overlapping(torc
     err = capfd.readouterr().err
     assert err.count("DEMOTED") == 1 and "RE-ADMITTED" not in err, err
     # the fault goes away; evaluations go on (gap back to 256 after the switch): the caller ends where its measurements say
-    monkeypatch.delenv("FCP_LANE_FAULT_US")
+    monkeypatch.setenv("FCP_DIAG", "lane_log")
     h.plan.set_private_streams(3, always=True, verify=False)            # (re-reads the fault; the supervisor starts over)
     st0 = h.plan.private_streams_stats()
     assert (st0["demoted"], st0["requests"], st0["lane_requests"], st0["evaluations"]) == (0, 0, 0, 0), st0
@@ -659,7 +659,7 @@ def test_supervisor_re_admits_a_demoted_caller_when_the_private_streams_win_agai
     from recom_amd.harness import ServingHarness
     torch = torch_cuda
     monkeypatch.delenv("FCP_LANE_SUPERVISE", raising=False)
-    monkeypatch.setenv("FCP_LANE_FAULT_US", "120")
+    monkeypatch.setenv("FCP_DIAG", "lane_fault_us=120,lane_log")
     monkeypatch.setenv("FCP_LANE_SUPERVISE_PERIOD", "192")
     monkeypatch.setenv("FCP_LANE_KEEP_RATIO", "3.0")
     model = synth.model_s2(columns=96, vocab=5000, batch=512)
@@ -672,7 +672,7 @@ def test_supervisor_re_admits_a_demoted_caller_when_the_private_streams_win_agai
     st = h.plan.private_streams_stats()
     assert st["demoted"] == 1 and st["worst_ratio"] > 3.0, st             # 120 us of stall per request against ~10 us in stream order
     # the fault is a property of the device's lane pool, read when the mode is set: another plan on the device clears it
-    monkeypatch.delenv("FCP_LANE_FAULT_US")
+    monkeypatch.setenv("FCP_DIAG", "lane_log")
     other = ServingHarness(model, device=0, n_requests=2, arena_ring=2, n_threads=1, tables=h.tables)
     other.plan.set_private_streams(3, always=True, verify=False)
     for _ in range(12):
