@@ -178,6 +178,12 @@ def cpu_baseline(model, budget_s: float = 20.0, sample_columns: int = 0):
     from recom_amd.plan import PlanSpec
 
     cores = len(os.sched_getaffinity(0))
+    # The CPUs this process can actually USE: the affinity mask says 256 on the boxes of this pool, the cgroup's CPU quota
+    # (cpu.max: "1600000 100000") says 16 — beyond the quota every runnable thread is throttled, which is why every sweep of
+    # rounds 2-5 peaked at 16 workers and fell to a third at 256 (so does a plain OpenMP triad: 290 GB/s at 32 threads, 42 at
+    # 256; profiles/r06_cpu_baseline_collapse.txt).  Worker counts beyond the quota are reported, never headlined.
+    quota = host_cpu_quota()
+    usable = max(1, min(cores, int(quota + 0.999))) if quota else cores
     spec = model.spec
     # host RAM bounds the sample: the tables (S2: 120 GB) + 8 GB of requests / outputs within 80 % of what is available
     try:
@@ -218,25 +224,28 @@ def cpu_baseline(model, budget_s: float = 20.0, sample_columns: int = 0):
     plan = sub.to_dict()
     rows = sub.group_rows(0, shapes, req.symbols)
     scale = spec.n_columns / k
-    # serving sweep: the same duration for every worker count.  Workers run TensorFlow-CPU's DATAFLOW for the unrewritten
-    # graph (one [rows, dim] tensor per column op, then ConcatV2: orc_process_feature_columns_unfused) — what the reference's
-    # CPU path is; the checker's own form (every column straight into the concat matrix) is swept beside it at three worker
-    # counts: it is faster while a worker's matrix fits its share of the L3 (one worker per CCD) and collapses beyond
-    # (profiles/r06_cpu_baseline_collapse.txt), which is what rounds 2-5 reported
+    # serving sweep: the same duration for every worker count.  `value` stays what rounds 2-5 reported: every column written
+    # straight into the concat matrix (the checker's own, FUSED form: the CPU's best foot forward, ~8x faster per request at
+    # 1000 columns than TensorFlow-CPU's dataflow for the unrewritten graph — one [rows, dim] tensor per column op, then
+    # ConcatV2 copying 512 x 1000 row pieces — which is swept beside it at three worker counts:
+    # orc_process_feature_columns_unfused).  Both get SLOWER beyond 16-32 workers on the boxes of this pool, and so does a plain
+    # OpenMP triad (290 GB/s at 32 threads, 42 GB/s at 256: profiles/r06_cpu_baseline_collapse.txt): the host, not the port.
     serve_cands = sorted({t for t in (1, 8, 16, 32, 64, 128, cores) if t <= max(cores, 1)})
     per = max(0.5, 0.6 * budget_s / len(serve_cands))
     sweep, detail = {}, {}
     for t in serve_cands:
-        done, sec = orc.serve_for(plan, packed, tables, req.symbols, t, per, 1)
+        done, sec = orc.serve_for(plan, packed, tables, req.symbols, t, per, 0)
         sweep[t] = rows * done / sec / scale
         detail[t] = {"requests": done, "seconds": sec}
-    fused_cands = sorted({t for t in (16, 32, cores) if t <= max(cores, 1)})
-    fused = {}
-    for t in fused_cands:
-        done, sec = orc.serve_for(plan, packed, tables, req.symbols, t, max(0.5, 0.2 * budget_s / len(fused_cands)), 0)
-        fused[t] = rows * done / sec / scale
+    tf_cands = sorted({t for t in (16, 32, cores) if t <= max(cores, 1)})
+    tf_flow = {}
+    for t in tf_cands:
+        done, sec = orc.serve_for(plan, packed, tables, req.symbols, t, max(0.5, 0.2 * budget_s / len(tf_cands)), 1)
+        tf_flow[t] = rows * done / sec / scale
     best_t = max(sweep, key=sweep.get)
-    head_t = 32 if 32 in sweep else best_t           # the reference's TF-CPU budget (AE/build_and_run.py:57)
+    # the reference's TF-CPU budget is 32 cores (AE/build_and_run.py:57): that entry where the box grants 32 CPUs, else the
+    # entry at the CPUs it does grant
+    head_t = max([t for t in sweep if t <= min(32, usable)] or [min(sweep)])
     # intra-request mode, the same duration in total
     out = [np.zeros((sub.group_rows(g, shapes, req.symbols), sub.group_width(g)), np.float32) for g in range(sub.n_groups)]
     intra = {}
@@ -255,10 +264,12 @@ def cpu_baseline(model, budget_s: float = 20.0, sample_columns: int = 0):
         "value": sweep[head_t], "unit": "inferences/s", "cores": head_t, "kind": "port", "sampled": k != spec.n_columns,
         "best_of_sweep": {"cores": best_t, "inferences_per_s": sweep[best_t]},
         "cores_32_inferences_per_s": sweep.get(32), "all_cores": cores, "all_cores_inferences_per_s": sweep.get(cores),
+        "cpu_quota_cores": quota, "usable_cores": usable,
         "serve_workers_sweep": {str(t): v for t, v in sorted(sweep.items())},
-        "dataflow": "TensorFlow-CPU's for the unrewritten graph: one [rows, dim] tensor per column op, then ConcatV2 "
-                    "(orc_process_feature_columns_unfused; same values as the checker's form bit for bit)",
-        "fused_layout_serve_workers_sweep": {str(t): v for t, v in sorted(fused.items())},
+        "dataflow": "fused: every column written straight into the concat matrix (orc_process_feature_columns, the checker's form)",
+        "tf_cpu_dataflow_serve_workers_sweep": {str(t): v for t, v in sorted(tf_flow.items())},
+        "tf_cpu_dataflow": "the same values through TensorFlow-CPU's dataflow for the unrewritten graph: one [rows, dim] tensor per "
+                           "column op, then ConcatV2 row by row (orc_process_feature_columns_unfused)",
         "intra_request_openmp_inferences_per_s": {str(t): v for t, v in sorted(intra.items())},
         "host_table_fill_s": t_fill,
         "sample": (f"all {spec.n_columns} columns" if k == spec.n_columns else f"first {k} of {spec.n_columns} columns, scaled x{scale:.1f} to the whole model,")
@@ -266,9 +277,29 @@ def cpu_baseline(model, budget_s: float = 20.0, sample_columns: int = 0):
                   f"{len(packed)} distinct requests rotated; one sweep of independent "
                   f"single-threaded workers ({serve_cands}), {per:.1f} s each (requests completed: "
                   f"{ {t: d['requests'] for t, d in detail.items()} }); value = the {head_t}-worker entry of that sweep (the reference's "
-                  f"TF-CPU budget, AE/build_and_run.py:57), best_of_sweep beside it; "
-                  f"{cores} cores visible; tables first-touched from all cores (pages spread over the sockets); C port of TF-CPU semantics (TensorFlow absent)",
+                  f"TF-CPU budget is 32 cores, AE/build_and_run.py:57; this box grants {usable}: {cores} CPUs in the affinity mask, "
+                  f"cgroup CPU quota {quota if quota else 'none'}), best_of_sweep beside it; entries beyond the quota are throttled; "
+                  f"tables first-touched from all cores (pages spread over the sockets); C port of TF-CPU semantics (TensorFlow absent)",
     }
+
+
+def host_cpu_quota():
+    """CPUs the container may use at once according to its cgroup (v2 `cpu.max`, v1 `cpu.cfs_quota_us / cpu.cfs_period_us`),
+    or None when there is no quota (or no cgroup file system to ask)."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, p = f.read().split()[:2]
+        return None if q == "max" else float(q) / float(p)
+    except (OSError, ValueError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+            q = float(f.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            p = float(f.read())
+        return None if q <= 0 else q / p
+    except (OSError, ValueError):
+        return None
 
 
 def access_mix_floor(model, h, bytes_alg, measured_us):
@@ -527,7 +558,7 @@ def main():
         # and all three reported.
         sweep = {}
         for workers in (2, 3, 4):
-            hw = ServingHarness(model, device=local_rank, n_requests=args.requests, arena_ring=6, n_threads=workers,
+            hw = ServingHarness(model, device=local_rank, n_requests=args.requests, arena_ring=args.arena_ring, n_threads=workers,
                                 tables=h.tables, seed0=1000 * rank)
             ov_warm, ov_steps = max(args.warmup // workers, 50), max(args.steps // workers, 400)
             hw.run(ov_warm)
@@ -548,14 +579,14 @@ def main():
         sc_warm, sc_steps = max(args.warmup, 100), max(args.steps, 1200)
         # the figure every private-stream number has to beat: the SAME loop — same consumer kernel behind every request —
         # with the requests in stream order on the caller's stream (private streams off)
-        hs = ServingHarness(model, device=local_rank, n_requests=args.requests, arena_ring=6, n_threads=1, tables=h.tables,
+        hs = ServingHarness(model, device=local_rank, n_requests=args.requests, arena_ring=max(args.arena_ring, 3), n_threads=1, tables=h.tables,
                             seed0=1000 * rank)
         hs.run_private(sc_warm, 3)
         so_ms, so_dev = hs.run_private(sc_steps, 3)
         stream_order_consumer = {"us_per_request": so_ms * 1e3 / sc_steps, "device_us_per_request": so_dev * 1e3 / sc_steps}
         hs.close()
         for lanes in (2, 3):                         # the library creates at most three (more were slower than one)
-            hp = ServingHarness(model, device=local_rank, n_requests=args.requests, arena_ring=6, n_threads=1,
+            hp = ServingHarness(model, device=local_rank, n_requests=args.requests, arena_ring=max(args.arena_ring, 3), n_threads=1,
                                 tables=h.tables, seed0=1000 * rank)
             hp.plan.set_private_streams(lanes)
             hp.run(1)
@@ -579,7 +610,7 @@ def main():
         threads_sweep = {}
         for T in (1, 2, 4):
             for depth in (1, 3):
-                ht = ServingHarness(model, device=local_rank, n_requests=args.requests, arena_ring=6, n_threads=T, tables=h.tables,
+                ht = ServingHarness(model, device=local_rank, n_requests=args.requests, arena_ring=max(args.arena_ring, 3), n_threads=T, tables=h.tables,
                                     seed0=1000 * rank)
                 per = max(sc_steps // T, 300)
                 ht.run_private(max(sc_warm // T, 50), depth, T)      # private streams off: stream order + the same consumers
@@ -597,7 +628,7 @@ def main():
                 ht.close()
         # and the cheap variant for callers that own their buffers (this harness does): FCP_ORDER_INPUTS_READY — the same K
         # requests back to back on the one stream, the fused kernel launched without the queue's barrier bit
-        hr = ServingHarness(model, device=local_rank, n_requests=args.requests, arena_ring=6, n_threads=1, tables=h.tables,
+        hr = ServingHarness(model, device=local_rank, n_requests=args.requests, arena_ring=args.arena_ring, n_threads=1, tables=h.tables,
                             seed0=1000 * rank)
         hr.plan.set_inputs_ready(True)
         hr.run(max(args.warmup, 100))
@@ -640,6 +671,10 @@ def main():
         "value": value, "unit": "inferences/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
         "extra_warmup_requests": extra_warmup, "timed_region_s": elapsed,
+        # what the bracket itself costs per region (first launch out of an idle queue, the closing torch.cuda.synchronize() =
+        # hipDeviceSynchronize): host wall time of the region minus the HIP-event time of its K requests; ~30 us, i.e. 5 % of
+        # a 20-request region (0.55 ms) and 0.05 % of the default 2000-request one
+        "bracket_overhead_us": (elapsed - dev_ms * 1e-3) * 1e6,
         "repeats": {"n": len(repeats), "reported": "median", "ms_per_step_min": repeats[0][0] * 1e3 / steps_total,
                     "ms_per_step_max": repeats[-1][0] * 1e3 / steps_total,
                     "ms_per_step_all": [r[0] * 1e3 / steps_total for r in repeats],
@@ -696,7 +731,7 @@ def main():
         if args.staged and raw_model is not model:
             # the same requests resident AS DELIVERED (int64 ids, SparseTensor indices; the segment-offset pre-pass runs on the
             # device): the like-for-like figure of rounds 1-2, in the same record
-            hd = ServingHarness(raw_model, device=local_rank, n_requests=args.requests, arena_ring=6, n_threads=1, tables=h.tables,
+            hd = ServingHarness(raw_model, device=local_rank, n_requests=args.requests, arena_ring=args.arena_ring, n_threads=1, tables=h.tables,
                                 seed0=1000 * rank)
             hd.run(max(args.warmup, 1))
             _, d_ms, _ = hd.run(args.steps)
@@ -711,7 +746,7 @@ def main():
             # int32, SparseTensor indices -> row offsets while packing): no pre-pass, no search — and what that conversion costs
             # the HOST per request, stated right beside it (one thread, like the TF op; pack pool of 4 / 8 / 16 threads)
             smodel = synth.staged_model(raw_model)
-            hs2 = ServingHarness(smodel, device=local_rank, n_requests=args.requests, arena_ring=6, n_threads=1, tables=h.tables,
+            hs2 = ServingHarness(smodel, device=local_rank, n_requests=args.requests, arena_ring=args.arena_ring, n_threads=1, tables=h.tables,
                                  seed0=1000 * rank)
             hs2.run(max(args.warmup, 1))
             _, s_ms, _ = hs2.run(args.steps)

@@ -492,8 +492,8 @@ int fcp_process_feature_columns(fcp_plan_t *plan,
  * multiple.  (A verdict is kept per stream HANDLE for the life of the plan: a
  * process that destroys and re-creates its streams calls this function again.)
  * FCP_PRIVATE_NO_VERIFY skips all of it (the streams are used as
- * created); FCP_LANE_PRIORITY=normal|low|high chooses the priority the search
- * starts with; FCP_PRIVATE_VERIFY_VERBOSE=1 prints the search.
+ * created); FCP_DIAG=lane_priority=normal|low|high chooses the priority the search
+ * starts with; FCP_DIAG=private_verify_verbose prints the search.
  * Callers with a warm-up request (every deployment of the reference has one,
  * docs/build_from_source.md:42) call fcp_plan_verify_private_streams there: no
  * serving request then ever pays for the search.
@@ -508,7 +508,7 @@ int fcp_process_feature_columns(fcp_plan_t *plan,
  * right behind their requests 1.13-1.64; sparse traffic ~1.0 — nothing to overlap;
  * a mapping that stopped overlapping 1.1 and more:
  * profiles/r05_caller_threads_grid.txt).  Two consecutive evaluations above 0.97
- * DEMOTE the caller: verdict 0, one line on stderr, its requests stay on
+ * DEMOTE the caller: verdict 0 (a line on stderr only under FCP_DIAG=lane_log), its requests stay on
  * args->stream; two consecutive ones below it re-admit a demoted caller (a trickle
  * at start-up, load later).  Evaluations run at the caller's first eligible
  * request, 256 requests later, then at doubling gaps up to 8192 requests: < 1 %

@@ -108,6 +108,20 @@ __device__ __forceinline__ void st_through(FCP_GLOBAL VecType<1>::T *p, VecType<
 // request (FcpLaunch::store_through bit 2, fill_launch).
 #define FCP_ST_THROUGH 1
 #define FCP_ST_PLAIN 4
+// The non-temporal form in inline asm as well: written as `if (plain) *p = t; else __builtin_nontemporal_store(t, p);` the
+// compiler MERGED the two stores into one and dropped the nontemporal hint with it (the first build of the three-policy
+// st_out had exactly two store instructions per row: `sc1 nt` and plain — every "nt" request wrote with plain stores,
+// RAGGED with six arenas 27.5 -> 29.3 us, profiles/r06_arena_reuse_kernel_traces.txt).
+__device__ __forceinline__ void st_nt(FCP_GLOBAL VecType<4>::T *p, VecType<4>::T t) {
+  asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(p), "v"(t) : "memory");
+}
+__device__ __forceinline__ void st_nt(FCP_GLOBAL VecType<2>::T *p, VecType<2>::T t) {
+  asm volatile("global_store_dwordx2 %0, %1, off nt" ::"v"(p), "v"(t) : "memory");
+}
+__device__ __forceinline__ void st_nt(FCP_GLOBAL VecType<1>::T *p, VecType<1>::T t) {
+  asm volatile("global_store_dword %0, %1, off nt" ::"v"(p), "v"(t) : "memory");
+}
+
 template <int V> __device__ __forceinline__ void st_out(float *p, const VF<V> &v, int policy = 0) {
   typedef typename VecType<V>::T T;
   T t;
@@ -118,7 +132,7 @@ template <int V> __device__ __forceinline__ void st_out(float *p, const VF<V> &v
   }
 #if !defined(FCP_NO_NT)
   if (!(policy & FCP_ST_PLAIN)) {
-    __builtin_nontemporal_store(t, as_global(reinterpret_cast<T *>(p)));
+    st_nt(as_global(reinterpret_cast<T *>(p)), t);
     return;
   }
 #endif

@@ -184,16 +184,20 @@ void publish_slot(fcp_plan *p, DynSlot &s, const std::vector<int32_t> &key, void
 
 
 // Which cache policy the output stores of a request take (FcpLaunch::store_through bits 0 and 2; st_out in fcp_kernels.hip):
-//   * the arena is the one this plan's previous request wrote, or the one before it (TF's allocate_output hands a serving
-//     loop the block it just freed, feature_column_process_op_gpu.cu.cc:107-111): PLAIN stores — the lines are still in the
-//     Infinity Cache / L2 and rewriting a resident line beats streaming it (S2, one arena: 27.2 us against 27.9 nt / 28.0
-//     sc1 nt; two arenas 28.0 / 28.2 / 28.2; RAGGED 27.25 / 27.4 / 27.55);
-//   * any other arena (a ring of three or more, fresh memory): plain stores LOSE there (S2 31.1 us against 28.1) —
-//     write-through `sc1 nt` once the outputs exceed what the eight 4-MiB L2s hold, `nt` below
+//   * outputs that FIT the L2s (below FCP_STORE_THROUGH_BYTES, 32 MiB: DLRM 3.5 MB, RAGGED 15.7 MB, models E / F 16-20 MB):
+//     `nt`, whatever the arena — plain stores leave the whole output dirty in L2 for the kernel boundary to write back
+//     (model F 10.5-10.9 us with nt against 12.4-13.4 with plain stores, one arena or six; RAGGED / DLRM within 0.2 us);
+//   * larger outputs into the arena this plan's previous request wrote, or the one before it (TF's allocate_output hands a
+//     serving loop the block it just freed, feature_column_process_op_gpu.cu.cc:107-111), up to 160 MiB: PLAIN stores — the
+//     lines are still in the Infinity Cache / L2 and rewriting a resident line beats streaming it (S2, one arena: 27.2 us
+//     against 27.9 nt / 28.0 sc1 nt; two arenas 28.0 / 28.2 / 28.2; batch 1024, 123 MB: 50.2 against 53.2; batch 2048,
+//     246 MB: plain LOSES, 109 against 103);
+//   * larger outputs into any other arena (a ring of three or more, fresh memory): plain stores lose 3 us of 28 there —
+//     write-through `sc1 nt`
 //   (profiles/r06_arena_reuse_store_policy.txt).  A performance hint only: read and updated without the plan's mutex.
 int store_policy_for(fcp_plan *p, const void *arena, int64_t out_bytes) {
   const int64_t through_bytes = p->env.store_through_bytes;
-  // tuning aid: FCP_DIAG=store_plain_reuse=0 never plain stores, 2 always, default 1 = for a reused arena
+  // tuning aid: FCP_DIAG=store_plain_reuse=0 never plain stores, 2 always, default 1 = the rule above
   static const int reuse_mode = (int)fcp::diag_ll("store_plain_reuse", 1);
   const uintptr_t ar = reinterpret_cast<uintptr_t>(arena);
   const uintptr_t a0 = p->recent_arena[0].load(std::memory_order_relaxed), a1 = p->recent_arena[1].load(std::memory_order_relaxed);
@@ -202,11 +206,10 @@ int store_policy_for(fcp_plan *p, const void *arena, int64_t out_bytes) {
     p->recent_arena[1].store(a0, std::memory_order_relaxed);
     p->recent_arena[0].store(ar, std::memory_order_relaxed);
   }
-  // ... while the output is of a size the caches can still hold on to: S2 at batch 512 / 640 / 768 / 1024 (61-123 MB of
-  // output) gains 1.4-3.0 us per request from plain stores into its one arena, batch 2048 (246 MB) LOSES 6 of 103 us
   constexpr int64_t kPlainMaxBytes = (int64_t)160 << 20;
-  if (reuse_mode == 2 || (reuse_mode == 1 && reused && out_bytes <= kPlainMaxBytes)) return 4;
-  return out_bytes >= through_bytes ? 1 : 0;
+  if (reuse_mode == 2) return 4;
+  if (out_bytes < through_bytes) return 0;
+  return (reuse_mode == 1 && reused && out_bytes <= kPlainMaxBytes) ? 4 : 1;
 }
 
 void fill_launch(const fcp_plan *p, const DynSlot &s, int kind, const void *blob, void *arena, int store_policy, FcpLaunch *L) {

@@ -162,6 +162,39 @@ def test_ragged_dynamic_shapes(torch_cuda, oracle, monkeypatch, seg, prepass):
         assert_equal_oracle(oracle, m.spec, packed, tabs, req.symbols, out)
 
 
+@pytest.mark.parametrize("layout", ["by_position", "packed", "blob_grouped", "blob_grouped_staged", "mixed_plan"])
+def test_regular_csr_front_of_the_ragged_kernel(torch_cuda, oracle, monkeypatch, layout):
+    """(r6) The ragged body asks for its row ranges TOGETHER with the column records when the CSR arrays are regular
+    (FcpLaunch::csr_reg): the arena scratch laid out by column position and filled by the pre-pass (`by_position`; `packed` =
+    the round-5 layout through FCP_DIAG=csr_by_pos=0: the ranges come through the records), or CSR inputs that lie one
+    stride apart in the blob because the caller grouped them (`blob_grouped[_staged]`, recognised per request).  `mixed_plan`:
+    pooled columns are fewer than half of the plan, so the scratch stays packed and a passthrough column sits between them.
+    Empty rows, rows at the batch's end, more shapes than descriptor slots, a row count that is not a multiple of the block's
+    four rows; all bit-exact against the oracle."""
+    from recom_amd import synth
+    monkeypatch.setenv("FCP_SEG_PREPASS", "1")                           # (64 columns x 255 rows would be searched in the blocks)
+    if layout == "packed":
+        monkeypatch.setenv("FCP_DIAG", "csr_by_pos=0")
+    if layout == "mixed_plan":
+        m = synth.model_mixed(batch=255, vocab=997, n_groups=1)
+    elif layout.startswith("blob_grouped"):
+        base = synth.model_ragged(columns=64, vocab=5000, batch=255, seg="indices" if layout.endswith("staged") else "csr")
+        m = synth.grouped_csr_model(synth.staged_model(base) if layout.endswith("staged") else base)
+    else:
+        m = synth.model_ragged(columns=64, vocab=5000, batch=255, seg="indices")
+    tabs = m.numpy_tables()
+    dev_tabs = [torch_cuda.from_numpy(t).cuda() for t in tabs]
+    op = None
+    for seed in list(range(6)) + [2, 2]:
+        req = m.make_request(seed)
+        out, packed, op = run_gpu(torch_cuda, m.spec, req.inputs, tabs, req.symbols, op, dev_tabs)
+        assert_equal_oracle(oracle, m.spec, packed, tabs, req.symbols, out)
+    if layout.startswith("blob_grouped"):                                # the CSR arrays really are one stride apart in the blob
+        offs = packed[1]
+        seg = [c.seg_input for c in sorted(m.spec.columns, key=lambda c: c.concat_slot)]
+        assert len(set(np.diff([int(offs[i]) for i in seg]))) == 1
+
+
 @pytest.mark.parametrize("columns", [16, 900])
 def test_zipf_and_long_bags(torch_cuda, oracle, columns):
     """Bags of up to 300 ids: what the wave's 384-entry tile cannot take in is staged bag by bag in further

@@ -616,6 +616,18 @@ def test_hot_kernels_keep_full_occupancy(tmp_path):
         assert scratch == 0, f"{name}: uses scratch"
         assert 8 * lds <= 160 * 1024, f"{name}: {lds} bytes of LDS leave fewer than 8 blocks per CU"
     assert seen >= 12
+    # (r6) the three output-store policies are three INSTRUCTIONS: written as C++ (`if (plain) *p = t; else
+    # __builtin_nontemporal_store(t, p)`) the compiler merged the two stores and dropped the hint — every "nt" request stored
+    # with the default policy; both hinted forms are inline asm since
+    label = re.search(r"^_ZN\S*fcp_dense_kernelILi4ELi4ELb0E\S*:", text, re.M)
+    assert label, "dense kernel not found in the assembly"
+    end = text.find(".end_amdhsa_kernel", label.end())            # (the kernel's descriptor follows its code)
+    stores = re.findall(r"global_store_dwordx4 [^\n]*", text[label.end():end])
+    kinds = {"sc1 nt": 0, "nt": 0, "plain": 0}
+    for st in stores:
+        tail = st.split("off", 1)[1].strip()
+        kinds["sc1 nt" if tail.startswith("sc1 nt") else "nt" if tail.startswith("nt") else "plain"] += 1
+    assert kinds["sc1 nt"] >= 4 and kinds["nt"] >= 4 and kinds["plain"] >= 4, kinds
 
 
 def test_shard_exchange_entry_points_without_a_gpu():
