@@ -55,7 +55,7 @@ for pol in plain_always nt sc1nt product; do
     [ -n "$f" ] && grep "fcp_dense" "$f" | head -1
     rm -rf "$d" "$d.log"
   done
-done > "$O/r06_arena_reuse_kernel_traces.txt" 2>&1
+done > "$O/r06_arena_reuse_kernel_traces_fixed.txt" 2>&1
 unset FCP_DIAG; unset FCP_STORE_THROUGH_BYTES
 # the host's memory system and the CPU baseline by dataflow / worker count
 {
