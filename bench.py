@@ -49,7 +49,7 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PREWARM_S = 0.25       # untimed pre-warm in front of the timed region, seconds of the same requests (whatever --warmup is)
 PREWARM_CHUNK = 256    # ... issued in calls of this many requests
-REPEATS = 5            # the K timed steps are repeated this many times; the median repeat is the one reported
+REPEATS = 5            # the K timed steps are repeated this many times (9 times when K < 200); the median repeat is the one reported
 METRIC = "inference QPS + p50 latency, 1000-col synth model, batch 512, 1\u00d7MI355X"  # == BASELINE.json "metric"
 try:
     with open(os.path.join(ROOT, "BASELINE.json")) as _f:
@@ -509,7 +509,8 @@ def main():
     # exactly K timed steps, REPEATS times, each repeat bracketed by barrier + synchronize on both sides and reduced to the
     # MAX over ranks; `ms_per_step` / `value` = the MEDIAN repeat, min / max beside it
     repeats = []
-    for _ in range(REPEATS):
+    # (short regions are noisy — one 20-request region in five came out at 32 us on a fresh box: more of them)
+    for _ in range(REPEATS if args.steps >= 200 else 2 * REPEATS - 1):
         if dist:
             dist.barrier()
         torch.cuda.synchronize()
@@ -524,6 +525,7 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         repeats.append((elapsed, dev_ms, wall_ms))
+    repeats_in_order = list(repeats)
     repeats.sort()
     elapsed, dev_ms, wall_ms = repeats[len(repeats) // 2]
 
@@ -679,6 +681,7 @@ def main():
                     "ms_per_step_max": repeats[-1][0] * 1e3 / steps_total,
                     "ms_per_step_all": [r[0] * 1e3 / steps_total for r in repeats],
                     "kernel_avg_us_all": [r[1] * 1e3 / args.steps for r in repeats],
+                    "kernel_avg_us_in_time_order": [r[1] * 1e3 / args.steps for r in repeats_in_order],
                     "what": f"exactly --steps requests timed {len(repeats)} times (barrier + synchronize on both sides of each, max over "
                             f"ranks) behind >= {PREWARM_S} s of untimed requests; ms_per_step / value / roofline are the median repeat"},
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",

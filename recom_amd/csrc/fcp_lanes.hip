@@ -100,10 +100,6 @@ int stager_input_synchronize(const void *base, int64_t bytes) {
   return FCP_OK;
 }
 
-} // namespace fcph
-
-
-namespace fcph {
 // (callers hold pool->cal_mu)
 // Only the STREAMS go: the PrivateLane objects and their events live as long as the process, so a request that raced
 // with a re-creation (a plan using the lanes unverified, a descriptor slot querying a lane's completion event it
@@ -147,7 +143,6 @@ int create_lanes(LanePool *pool, int n, int prio) {
 } // namespace fcph
 
 extern "C" {
-
 
 // Plan-owned private streams.  TensorFlow gives a GPU op ONE compute stream (feature_column_process_op_gpu.cu.cc:65-131
 // takes it from the op context; the reference harness' serve workers share one Session, recom_examples.patch:193-216), so
@@ -226,13 +221,7 @@ __global__ void fcp_spin_kernel(unsigned long long ticks) { // s_memrealtime: 10
   while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(4);
 }
 __global__ void fcp_probe_consumer_kernel() {}
-} // namespace fcph
 
-extern "C" {
-
-} // extern "C"
-
-namespace fcph {
 // (the plan's device is current; pool->cal_mu is held: the lanes are not re-created meanwhile)
 int run_lane_probe(fcp_plan *p, hipStream_t caller, int requests, int spin_us, int grid_blocks, double *serial_us, double *lanes_us) {
   const unsigned long long ticks = 100ull * (unsigned long long)spin_us;
@@ -573,7 +562,6 @@ int fcp_plan_set_request_order(fcp_plan_t *p, int32_t order) {
   return FCP_OK;
 }
 
-
 } // extern "C"
 
 namespace fcph {
@@ -585,13 +573,6 @@ int process_on_caller(fcp_plan_t *p, const fcp_process_args_t *a, fcp_process_re
   if (rc == FCP_OK && r->buffer) pending_clear_range(r->buffer, r->buffer_bytes);
   return rc;
 }
-} // namespace fcph
-
-extern "C" {
-
-} // extern "C"
-
-namespace fcph {
 
 // An evaluation whose window saw something it does not account for — a request that failed inside it, or one that went
 // around the supervisor (below the work threshold, a stream capture) and so ran between the timing events with its time
@@ -782,10 +763,6 @@ int process_on_private_streams(fcp_plan_t *p, const fcp_process_args_t *a, fcp_p
   return FCP_OK;
 }
 
-} // namespace fcph
-
-
-namespace fcph {
 // the pending result whose address range contains x, or nullptr (g_pending_mu held)
 const PendingResult *pending_find(uintptr_t x, uintptr_t *base) {
   auto it = g_pending.upper_bound(x);
@@ -827,7 +804,6 @@ int fcp_result_synchronize(const void *buffer) {
 }
 
 } // extern "C"
-
 
 namespace fcph {
 // ConcatOutputs reads columns of FeatureColumnProcess arenas — normally ONE arena (output_ptrs of one op), possibly several

@@ -182,7 +182,6 @@ void publish_slot(fcp_plan *p, DynSlot &s, const std::vector<int32_t> &key, void
   s.valid = true;
 }
 
-
 // Which cache policy the output stores of a request take (FcpLaunch::store_through bits 0 and 2; st_out in fcp_kernels.hip):
 //   * outputs that FIT the L2s (below FCP_STORE_THROUGH_BYTES, 32 MiB: DLRM 3.5 MB, RAGGED 15.7 MB, models E / F 16-20 MB):
 //     `nt`, whatever the arena — plain stores leave the whole output dirty in L2 for the kernel boundary to write back

@@ -669,7 +669,17 @@ def bench_row_sharded_record(args, rank: int, world: int, local_rank: int, dist,
     # tables: columns x vocab x mean dim x 4 bytes over `world` GPUs, within 85 % of each GPU's memory net of the exchange
     # buffers (partial + slices, a ring of three)
     per_row = width * 4
-    room = 0.85 * hbm_bytes - 8 * batch * width * 4
+    # what is FREE on the device now (the replicated run's tables have just been released), the smallest over the ranks so
+    # that every rank builds the same model — a rank that ran out of memory alone would leave the others waiting in the exchange
+    free_b = hbm_bytes
+    if not os.environ.get("FCP_BENCH_HBM_BYTES"):
+        torch.cuda.empty_cache()
+        free_b = min(hbm_bytes, torch.cuda.mem_get_info(local_rank)[0])
+        if dist is not None and world > 1:
+            t = torch.tensor([free_b], dtype=torch.int64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            free_b = int(t.item())
+    room = 0.85 * free_b - 8 * batch * width * 4
     vocab = int(os.environ.get("FCP_BENCH_SHARD_VOCAB", "0")) or int(max(1000, min(1_000_000, room * world // per_row)))
     model = synth.model_shard(columns=columns, vocab=vocab, batch=batch)
     backend = dist.get_backend() if dist is not None else "none"

@@ -866,3 +866,28 @@ def test_per_column_arena_steps_by_the_references_own_alignmem(ref_alignmem):
         want = sum(ref_alignmem(batch * c.dim * 4) for c in spec.columns) + \
             sum(ref_alignmem((batch + 1) * 4) for c in spec.columns if c.seg_kind in (1, 2))
         assert got.value == want
+
+
+def test_cpu_baseline_record_full_size_sampled_and_quota(monkeypatch):
+    """bench.py's cpu_baseline (r6): the whole workload when its tables fit host memory (`sampled: false`), the first k columns
+    scaled up when they do not; `value` is the entry at min(32, CPUs the box grants) — the cgroup CPU quota counts, not the
+    affinity mask — with the whole sweep and TensorFlow-CPU's dataflow beside it."""
+    import importlib
+    import sys
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    from recom_amd import synth
+    m = synth.model_s2(columns=32, vocab=4000, batch=64)
+    monkeypatch.delenv("FCP_BENCH_CPU_RAM_BYTES", raising=False)
+    full = bench.cpu_baseline(m, budget_s=1.5)
+    assert full["sampled"] is False and full["kind"] == "port" and full["value"] > 0
+    assert full["cores"] <= min(32, full["usable_cores"]) and str(full["cores"]) in full["serve_workers_sweep"]
+    assert full["value"] == full["serve_workers_sweep"][str(full["cores"])]
+    assert full["tf_cpu_dataflow_serve_workers_sweep"] and "all 32 columns" in full["sample"]
+    # a host that holds only a quarter of the tables (+ the fixed 8 GB margin the sizing keeps): a sample, scaled
+    tables = sum(t.vocab * t.dim * 4 for t in m.tables)
+    monkeypatch.setenv("FCP_BENCH_CPU_RAM_BYTES", str(int(((8 << 30) + tables / 3) / 0.8)))
+    part = bench.cpu_baseline(m, budget_s=1.5)
+    assert part["sampled"] is True and "first 8 of 32 columns" in part["sample"] or "first 16 of 32 columns" in part["sample"]
+    # the quota parser
+    assert bench.host_cpu_quota() is None or bench.host_cpu_quota() > 0
