@@ -398,6 +398,10 @@ def main():
                          "serving loop (benchmark_multi_thread, recom_examples.patch:193-216) gets back the block the previous request "
                          "freed; 6 = what rounds 1-5 timed (every output line evicted between two writes).  `arena_reuse` reports 1 / 2 / 6 "
                          "side by side whatever this is")
+    ap.add_argument("--sla-ms", type=float, default=0.0,
+                    help="instead of the latency protocol: the reference's THROUGHPUT benchmark (benchmark_throughput, "
+                         "recom_examples.patch:264-465) for this path - grow the batch until the average request latency reaches this "
+                         "many milliseconds (--threads = its serve_workers, --steps = its num_iterations); s2 / dlrm / ragged; one JSON line")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) normally; gloo only to exercise the N>1 control flow on a 1-GPU box")
     args = ap.parse_args()
 
@@ -430,6 +434,26 @@ def main():
         else:
             dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
 
+    if args.sla_ms > 0:
+        # the reference's other harness: the pressure test (recom_amd.harness.sla_throughput_search); N = 1 only
+        from recom_amd.harness import sla_throughput_search
+        if world != 1 or args.workload not in ("s2", "dlrm", "ragged"):
+            print("bench.py --sla-ms: one GPU; --workload s2 | dlrm | ragged", file=sys.stderr)
+            sys.exit(2)
+        make = {"s2": lambda b: synth.model_s2(columns=args.columns or 1000, batch=b, **({'vocab': args.vocab} if args.vocab else {})),
+                "dlrm": lambda b: synth.model_dlrm(batch=b),
+                "ragged": lambda b: synth.model_ragged(columns=args.columns or 512, seg=args.seg, batch=b,
+                                                       **({'vocab': args.vocab} if args.vocab else {}))}[args.workload]
+        free_b, _ = torch.cuda.mem_get_info(local_rank)
+        probe = make(16)
+        res = sla_throughput_search(make, args.sla_ms, serve_workers=args.threads, num_iterations=min(args.steps, 100), device=local_rank,
+                                    arena_budget_bytes=int(0.8 * max(free_b - probe.table_bytes(), 1 << 30)),
+                                    log=lambda m: print(m, file=sys.stderr))
+        print(json.dumps({"metric": f"max throughput under a {args.sla_ms} ms SLA of the embedding stage (reference protocol: benchmark_throughput, "
+                                    f"recom_examples.patch:264-465), {probe.name}", "value": res["max_throughput"], "unit": "inferences/s",
+                          "n_gpus": 1, "higher_is_better": True, "dtype": "f32", "data": "synthetic", "vs_baseline": None,
+                          "config": {"workload": f"{probe.name}: {probe.description} (batch grown by the search)", "serve_workers": args.threads}, **res}))
+        return
     if args.workload in ("shard", "shard-row", "shard-col"):
         # BASELINE.json config 5: 4000 S2-shaped columns (480 GB); the flag names the model and the preferred sharding
         model = synth.model_shard(columns=args.columns or 4000, **({'vocab': args.vocab} if args.vocab else {}),

@@ -232,3 +232,54 @@ def read_probe(nbytes: int = 4 << 30, iters: int = 5) -> float:
     _lib.check(load().fcp_harness_bw_probe(0, nbytes, iters, C.byref(ms)), "read probe")
     return nbytes / (ms.value * 1e-3)
 
+
+
+def sla_throughput_search(make_model, sla_ms: float, serve_workers: int = 1, num_iterations: int = 100, device: int = 0,
+                          start_batch: int = 16, max_batch: int = 0, arena_budget_bytes: int = 0, log=None) -> dict:
+    """The reference's throughput benchmark for THIS path (``benchmark_throughput``, examples/cc/recom_examples.patch:264-465):
+    a pressure test that grows the batch until the average latency of a request reaches the service-level agreement and
+    reports the largest batch that stayed under it with its throughput.  Same protocol — one warm-up request, then
+    ``serve_workers`` threads x ``num_iterations`` requests of the SAME inputs (``:396-420``), latency = wall time /
+    ``num_iterations``, throughput = workers x iterations x batch / wall time — and the same search (``:422-463``): start at 16;
+    under the SLA the batch grows by itself below 50 % of the SLA, by a 5th / 10th / 30th / 100th of itself below 70 / 80 / 90 /
+    100 % (at least 5); at or over the SLA it grows by 50 while it is <= 512 and the search ends beyond that.  The reference's
+    thresholds are milliseconds against its 100-ms default for a whole model; here they are fractions of ``sla_ms`` (the
+    embedding stage alone is 27 us at batch 512).  ``make_model(batch)`` builds the workload at one batch size (tables are
+    shared between the harnesses: same vocabulary); the search also ends when the next arena would not fit
+    ``arena_budget_bytes`` (reported as ``ended_by``)."""
+    import torch
+    batch, tables, steps = start_batch, None, []
+    best = {"max_batch_size": 0, "max_throughput": 0.0}
+    ended_by = "sla"
+    while True:
+        model = make_model(batch)
+        width = sum(model.spec.group_width(g) for g in range(model.spec.n_groups))
+        if arena_budget_bytes and 4 * batch * width * serve_workers > arena_budget_bytes:
+            ended_by = "arena memory"
+            break
+        h = ServingHarness(model, device=device, n_requests=1, arena_ring=1, n_threads=serve_workers, tables=tables)
+        tables = h.tables
+        h.run(1)                                                  # "Start warmup predict"
+        wall_ms, _, _ = h.run(num_iterations)
+        h.close()
+        latency = wall_ms / num_iterations
+        throughput = serve_workers * num_iterations * batch / (wall_ms * 1e-3)
+        steps.append({"batch": batch, "avg_latency_ms": latency, "throughput": throughput})
+        if log:
+            log(f"batch size: {batch}, avg latency: {latency:.4f} ms, throughput: {throughput:.0f}")
+        if latency >= sla_ms:
+            if batch > 512:
+                break
+            batch += 50
+        else:
+            best = {"max_batch_size": batch, "max_throughput": throughput}
+            frac = latency / sla_ms
+            inc = batch if frac < 0.5 else batch // 5 if frac < 0.7 else batch // 10 if frac < 0.8 else batch // 30 if frac < 0.9 else batch // 100
+            batch += max(5, inc)
+        if max_batch and batch > max_batch:
+            ended_by = "max_batch"
+            break
+    del tables
+    torch.cuda.empty_cache()
+    return {**best, "sla_ms": sla_ms, "serve_workers": serve_workers, "num_iterations": num_iterations, "ended_by": ended_by,
+            "search": steps}

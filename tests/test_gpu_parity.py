@@ -1760,3 +1760,21 @@ def test_bench_refuses_to_time_wrong_results(torch_cuda):
         with pytest.raises(RuntimeError, match="closed-form"):
             h.verify_resident()
         h.close()
+
+
+def test_sla_bounded_throughput_search_follows_the_reference_protocol(torch_cuda):
+    """The reference's throughput benchmark for this path (benchmark_throughput, recom_examples.patch:264-465): the batch grows
+    from 16 — doubling below half of the SLA, by ever smaller fractions towards it — until the average latency of a request
+    reaches the SLA; the result is the largest batch that stayed under it and its throughput."""
+    from recom_amd import synth
+    from recom_amd.harness import sla_throughput_search
+    res = sla_throughput_search(lambda b: synth.model_s2(columns=48, vocab=5000, batch=b), sla_ms=0.05, serve_workers=1,
+                                num_iterations=40, arena_budget_bytes=2 << 30)
+    s = res["search"]
+    assert s[0]["batch"] == 16 and s[1]["batch"] == 32                     # far below the SLA: the batch doubles
+    assert all(a["batch"] < b["batch"] for a, b in zip(s, s[1:]))
+    assert res["ended_by"] in ("sla", "arena memory") and res["max_batch_size"] >= 32 and res["max_throughput"] > 0
+    under = [x for x in s if x["avg_latency_ms"] < 0.05]
+    assert res["max_batch_size"] == under[-1]["batch"] and res["max_throughput"] == under[-1]["throughput"]
+    if res["ended_by"] == "sla":
+        assert s[-1]["avg_latency_ms"] >= 0.05 and s[-1]["batch"] > 512
