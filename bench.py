@@ -82,6 +82,46 @@ def measured_traffic(workload):
     return entry["traffic_bytes"], "profiles/traffic.json: separate rocprofv3 --pmc passes (scripts/pmc.sh), per launch"
 
 
+def live_traffic(arena_ring: int):
+    """HBM bytes per launch of the S2 kernel measured NOW, on this box: two separate `rocprofv3 --pmc` passes (FETCH_SIZE,
+    WRITE_SIZE; counters restricted to fcp_* kernels, `--kernel-trace` the only trace domain) over the torch-free native
+    binary of the same workload (`recom_amd/fcp_bench`, the program itself right after `--`), as MI355X_MICROARCH.md's HBM /
+    rocprofv3 section prescribes: (2 x FETCH_SIZE + WRITE_SIZE) x 1024 — FETCH_SIZE tallies gfx950's 128-byte requests at 64.
+    Returns (bytes, source) or (None, why): the caller then falls back to the committed record (profiles/traffic.json)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = os.path.join(os.environ.get("FCP_LIB_DIR", os.path.join(ROOT, "recom_amd")), "fcp_bench")
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe) or not os.path.exists(prof):
+        return None, "rocprofv3 or fcp_bench not found"
+    vals = {}
+    tmp = tempfile.mkdtemp(prefix="fcp_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = [prof, "--pmc", counter, "--kernel-trace", "--kernel-include-regex", "fcp_", "--output-format", "csv", "-d", out, "--",
+                   exe, "--steps", "40", "--warmup", "10", "--verify", "0", "--ring", str(arena_ring)]
+            res = subprocess.run(cmd, capture_output=True, text=True, timeout=240, cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp"})
+            got = []
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if "fcp_dense_kernel" in row.get("Kernel_Name", "") and row.get("Counter_Name") == counter:
+                        got.append(float(row["Counter_Value"]))
+            if not got:
+                return None, f"rocprofv3 --pmc {counter}: no fcp_dense_kernel rows (rc {res.returncode}): {res.stderr[-200:]}"
+            vals[counter] = sum(got) / len(got)
+    except Exception as e:
+        return None, f"{type(e).__name__}: {e}"[:300]
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return int(round((2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024)), (
+        f"measured in this run: two rocprofv3 --pmc passes (FETCH_SIZE {vals['FETCH_SIZE']:.1f} KiB, WRITE_SIZE {vals['WRITE_SIZE']:.1f} KiB per "
+        f"launch) over recom_amd/fcp_bench --ring {arena_ring}, (2 x FETCH_SIZE + WRITE_SIZE) x 1024")
+
+
 def pcie_inclusive():
     """The same workload with the request on the HOST when the clock starts: host id tensors -> fcp_stager (pinned ring,
     pack threads, int64 ids shipped as int32) -> one H2D -> kernel, from the torch-free native binary in its own process
@@ -812,6 +852,14 @@ def main():
             del h
             torch.cuda.empty_cache()
             rec["pcie_inclusive"] = pcie_inclusive()
+            # HBM traffic of the dominant kernel measured on THIS box in THIS run (the committed PMC record is the fallback
+            # and stays in the line as `traffic_record` for comparison)
+            live, why = live_traffic(args.arena_ring)
+            rec["roofline"]["traffic_record"] = {"bytes": rec["roofline"]["traffic"], "source": rec["roofline"]["traffic_source"]}
+            if live is not None:
+                rec["roofline"]["traffic"], rec["roofline"]["traffic_source"] = live, why
+            else:
+                rec["roofline"]["traffic_live_error"] = why
         print(json.dumps(rec))
     if dist:
         dist.destroy_process_group()

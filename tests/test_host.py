@@ -891,3 +891,14 @@ def test_cpu_baseline_record_full_size_sampled_and_quota(monkeypatch):
     assert part["sampled"] is True and "first 8 of 32 columns" in part["sample"] or "first 16 of 32 columns" in part["sample"]
     # the quota parser
     assert bench.host_cpu_quota() is None or bench.host_cpu_quota() > 0
+
+
+def test_live_traffic_falls_back_cleanly_without_a_gpu():
+    """bench.py measures `roofline.traffic` in the run itself (two rocprofv3 --pmc passes over fcp_bench); where that cannot
+    work — no GPU here — it says why and the caller keeps the committed record."""
+    import importlib
+    import sys
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    got, why = bench.live_traffic(1)
+    assert got is None and isinstance(why, str) and why
