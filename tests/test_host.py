@@ -901,4 +901,5 @@ def test_live_traffic_falls_back_cleanly_without_a_gpu():
     sys.path.insert(0, ROOT)
     bench = importlib.import_module("bench")
     got, why = bench.live_traffic(1)
-    assert got is None and isinstance(why, str) and why
+    assert isinstance(why, str) and why
+    assert got is None or got > 100_000_000          # (on a GPU box the passes really run: S2 moves ~148 MB per launch)
