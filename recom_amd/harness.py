@@ -15,7 +15,7 @@ from typing import List, Optional, Sequence
 import numpy as np
 
 from . import lib as _lib
-from .ops import Plan, concat_inputs
+from .ops import Plan, concat_inputs, pack_as_staged
 from .synth import Request, SynthModel
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -75,8 +75,9 @@ class ServingHarness:
         args = (_lib.ProcessArgs * n_requests)()
         tptrs = (C.c_void_p * max(1, len(self.tables)))(*[t.data_ptr() for t in self.tables])
         self._keep.append(tptrs)
+        stage_modes = getattr(model, "stage_modes", None)   # a staged model: the blob as the staged ConcatInputs lays it out
         for i, r in enumerate(self.requests):
-            blob, offsets, shapes = concat_inputs(r.inputs)
+            blob, offsets, shapes = pack_as_staged(r.inputs, stage_modes) if stage_modes else concat_inputs(r.inputs)
             d_blob = torch.from_numpy(blob).to(self.dev)
             sym = None if r.symbols is None else np.ascontiguousarray(r.symbols, np.int32)
             self._keep += [d_blob, offsets, shapes, sym]

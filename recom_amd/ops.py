@@ -94,6 +94,30 @@ def concat_inputs(inputs: Sequence[np.ndarray], stage=None, pool: Optional[PackP
     return blob, offsets, shapes
 
 
+def pack_as_staged(inputs: Sequence[np.ndarray], modes: Sequence[int]):
+    """ALREADY CONVERTED tensors (``synth.staged_model``: int32 ids, int32 row offsets) laid out as the staged
+    ``Addons>ConcatInputs`` lays out its blob (``stage_layout``, ``csrc/fcp_stager.hip``): copied / narrowed inputs back to back
+    in input order from offset 0, the inputs that were converted to row offsets (mode 2) behind all of them, in input order, from
+    a 4-byte boundary — one [columns, rows + 1] matrix.  For harnesses that keep staged requests resident (the op itself
+    converts while it packs: ``concat_inputs(raw, stage)``; tests hold the two to each other, ``conftest.assert_staged_blob``).
+    Returns ``(blob, offsets, shapes)``."""
+    _, _, shapes = concat_inputs(inputs)
+    raws = [np.ascontiguousarray(a).view(np.int8).reshape(-1) if np.asarray(a).size else np.zeros(0, np.int8) for a in inputs]
+    order = [i for i, m in enumerate(modes) if m != 2] + [i for i, m in enumerate(modes) if m == 2]
+    n_first = sum(1 for m in modes if m != 2)
+    offsets = np.zeros(len(inputs), np.int32)
+    size = 0
+    for pos, i in enumerate(order):
+        if pos == n_first:
+            size = (size + 3) & ~3
+        offsets[i] = size
+        size += raws[i].size
+    blob = np.zeros(size, np.int8)
+    for i in order:
+        blob[offsets[i]:offsets[i] + raws[i].size] = raws[i]
+    return blob, offsets, shapes
+
+
 class ConcatInputs:
     """``Addons>ConcatInputs`` as the shim builds it from a node of the rewritten graph: attrs ``T`` / ``ranks``
     (``concat_inputs_ops.cc:33-40``) and, when the graph was rewritten for a staged plan, the node's ``_fcp_plan``

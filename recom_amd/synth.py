@@ -155,8 +155,10 @@ def staged_model(model: SynthModel) -> SynthModel:
                 out.append(a)
         return Request(out, r.symbols)
 
-    return SynthModel(model.name, spec, model.tables, model.batch, make_request,
-                      model.description + "; requests as staged (ids int32, row ids -> CSR offsets on the host)")
+    out = SynthModel(model.name, spec, model.tables, model.batch, make_request,
+                     model.description + "; requests as staged (ids int32, row ids -> CSR offsets on the host)")
+    out.stage_modes = list(modes)   # how the staged op lays these requests out in its blob (ops.pack_as_staged)
+    return out
 
 
 def grouped_csr_model(model: SynthModel) -> SynthModel:

@@ -107,3 +107,27 @@ def check_against_expected(case, outs, pooled_atol=1e-5):
         got = np.asarray(outs[g])[:, off:off + dim]
         want = case.expected[g][:, off:off + dim].astype(np.float32)
         assert np.array_equal(got, want), (case.name, "copy column not bit-exact", g, off)
+
+
+def assert_staged_blob(blob, offsets, shapes, conv, modes):
+    """The staged blob of Addons>ConcatInputs (fcp_concat_inputs_ex / fcp_stager_stage_ex; layout: stage_layout in
+    recom_amd/csrc/fcp_stager.hip) against the converted tensors `conv` (NumPy): copied and narrowed inputs back to back in
+    input order from offset 0 — the reference op's layout, concat_inputs_ops.cc:52-66 — and the inputs converted to row
+    offsets (mode 2) behind ALL of them, in input order, from a 4-byte boundary: one [columns, rows + 1] matrix.  Shapes
+    stay in input order.  Returns the blob size."""
+    from recom_amd.ops import concat_inputs
+    blob = np.asarray(blob).view(np.int8).reshape(-1)
+    _, _, want_shapes = concat_inputs(conv)
+    assert np.array_equal(np.asarray(shapes), want_shapes)
+    size = 0
+    order = [i for i, m in enumerate(modes) if m != 2] + [i for i, m in enumerate(modes) if m == 2]
+    n_first = sum(1 for m in modes if m != 2)
+    for pos, i in enumerate(order):
+        if pos == n_first:
+            size = (size + 3) & ~3
+        raw = np.ascontiguousarray(conv[i]).view(np.int8).reshape(-1)
+        assert int(offsets[i]) == size, (i, int(offsets[i]), size)
+        assert np.array_equal(blob[size:size + raw.size], raw), f"input {i} differs in the staged blob"
+        size += raw.size
+    assert blob.size >= size
+    return size

@@ -925,7 +925,7 @@ def test_request_stager_turns_sparse_indices_into_row_offsets(torch_cuda, oracle
     """fcp_stager_stage_ex / FCP_STAGE_SEG_TO_CSR: the sorted row ids of multi-hot features (SparseTensor indices [nnz, 2],
     int32 / int64 row ids) become int32 CSR offsets while the host packs them, ids are narrowed; the staged plan
     (PlanSpec.staged(): those columns read CSR, no pre-pass, no in-block search) gives the same bits as the original
-    request through the oracle.  The staged blob is exactly ConcatInputs of the converted tensors."""
+    request through the oracle.  The staged blob is the converted tensors in the staged layout (conftest.assert_staged_blob)."""
     import fcp_oracle as O
     from recom_amd import synth
     from recom_amd.ops import FeatureColumnProcess, RequestStager, concat_inputs
@@ -951,15 +951,14 @@ def test_request_stager_turns_sparse_indices_into_row_offsets(torch_cuda, oracle
                     conv.append(np.where((a >= 0) & (a <= 0x7fffffff), a, -1).astype(np.int32))
                 else:
                     conv.append(a)
-            blob2, offs2, shps2 = concat_inputs(conv)
-            assert nbytes == blob2.nbytes and np.array_equal(offs, offs2) and np.array_equal(shps, shps2)
             out = op(_RawBlob(d_ptr, nbytes), offs, shps, tabs, req.symbols)
             torch.cuda.synchronize()
             staged = np.empty(nbytes, np.int8)
             import ctypes as C
             hip = C.CDLL("libamdhip64.so")
             assert hip.hipMemcpy(C.c_void_p(staged.ctypes.data), C.c_void_p(d_ptr), C.c_size_t(nbytes), 2) == 0
-            assert np.array_equal(staged, blob2)
+            from conftest import assert_staged_blob
+            assert assert_staged_blob(staged, offs, shps, conv, modes) == nbytes   # (row offsets: one matrix behind the other inputs)
             want, _ = oracle.process_feature_columns(m.spec.to_dict(), *concat_inputs(req.inputs), tabs_np, req.symbols)
             for g, w in enumerate(want):
                 assert np.array_equal(out.groups[g].cpu().numpy(), w), (m.name, seed, g)

@@ -652,8 +652,8 @@ def test_shard_exchange_entry_points_without_a_gpu():
 
 def test_staged_concat_inputs_and_the_stage_section(L, tmp_path):
     """Addons>ConcatInputs in its staged form (fcp_concat_inputs_ex, host only): with the modes of the plan file's stage
-    section the blob carries int32 ids and int32 row offsets — exactly ConcatInputs of the converted tensors (NumPy
-    conversion) — and the stage section survives the file (fcp_plan_file_stage_info, what the shim's ConcatInputsOp reads
+    section the blob carries int32 ids and int32 row offsets — the converted tensors (NumPy conversion) in the staged layout:
+    copied / narrowed inputs in the reference op's order, the row offsets behind them as one matrix — and the stage section survives the file (fcp_plan_file_stage_info, what the shim's ConcatInputsOp reads
     through the node's `_fcp_plan` attr)."""
     import fcp_oracle as O  # noqa: F401  (np_segment_offsets: the checker)
     from recom_amd import synth
@@ -689,8 +689,23 @@ def test_staged_concat_inputs_and_the_stage_section(L, tmp_path):
                     conv.append(np.where((a >= 0) & (a <= 0x7fffffff), a, -1).astype(np.int32))
                 else:
                     conv.append(a)
-            b2, o2, s2 = concat_inputs(conv)
-            assert np.array_equal(blob, b2) and np.array_equal(offsets, o2) and np.array_equal(shapes, s2)
+            from conftest import assert_staged_blob
+            from recom_amd.ops import pack_as_staged
+            assert assert_staged_blob(blob, offsets, shapes, conv, stage.modes) == blob.size
+            b3, o3, s3 = pack_as_staged(conv, stage.modes)          # the harnesses' NumPy statement of the same layout
+            assert np.array_equal(o3, offsets) and np.array_equal(s3, shapes) and b3.size == blob.size
+            if not converted:                                      # nothing converted: the reference op's layout, byte for byte
+                b2, o2, s2 = concat_inputs(conv)
+                assert np.array_equal(blob, b2) and np.array_equal(offsets, o2) and np.array_equal(shapes, s2)
+            else:                                                  # the row offsets form ONE matrix behind everything else
+                csr = [i for i, md in enumerate(stage.modes) if md == PL.STAGE_SEG_TO_CSR]
+                by_rows = {}
+                for i in csr:
+                    by_rows.setdefault(conv[i].size, []).append(int(offsets[i]))
+                for size_, offs_ in by_rows.items():
+                    if len(by_rows) == 1:
+                        assert np.array_equal(np.diff(offs_), np.full(len(offs_) - 1, 4 * size_)), "CSR arrays are not one stride apart"
+                assert min(int(offsets[i]) for i in csr) >= max(int(offsets[i]) for i in range(len(conv)) if i not in csr)
             assert spec.host_input_ranks == [np.asarray(a).ndim for a in conv]
             assert spec.host_input_elem_sizes == [np.asarray(a).dtype.itemsize for a in conv]
     # a plain plan file has no stage section; a wrong one is refused
