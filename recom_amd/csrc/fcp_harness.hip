@@ -154,14 +154,10 @@ int fcp_harness_run(fcp_harness *h, int steps, double *wall_ms, float *dev_ms, f
   for (auto &w : workers) w.join();
   H_TRY(worker0);
   H_TRY(hipEventRecord(h->e1, h->streams[0]));
-  // the end of the region is POLLED (hipStreamQuery): a serving loop that wants its result spins on it, and
-  // hipStreamSynchronize's own wake-up costs 10-20 us — 3-4 % of the driver's 20-request region (0.55 ms)
-  for (int t = 0; t < n_threads; ++t) {
-    hipError_t q;
-    while ((q = hipStreamQuery(h->streams[t])) == hipErrorNotReady) {
-    }
-    H_TRY(q);
-  }
+  // (round 6 polled the end of the region with hipStreamQuery for a few runs: it bought nothing against hipStreamSynchronize's
+  // wake-up — the bracket is the first launch out of an idle queue and the caller's device synchronisation — and is suspected
+  // of leaving the stream of a host-bound loop in a slower mode: profiles/HISTORY.md, round 6, models E / F)
+  for (int t = 0; t < n_threads; ++t) H_TRY(hipStreamSynchronize(h->streams[t]));
   const auto t1 = std::chrono::steady_clock::now();
   h->issued += steps;
   for (int t = 0; t < n_threads; ++t)
