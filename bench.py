@@ -591,7 +591,8 @@ def main():
         repeats.append((elapsed, dev_ms, wall_ms))
     repeats_in_order = list(repeats)
     repeats.sort()
-    elapsed, dev_ms, wall_ms = repeats[len(repeats) // 2]
+    elapsed, _, wall_ms = repeats[len(repeats) // 2]           # ms_per_step / value: the repeat with the median wall time
+    dev_ms = sorted(r[1] for r in repeats)[len(repeats) // 2]   # roofline: the median HIP-event time of the repeats
 
     # latency percentiles: separate pass with one HIP event pair per request, at least 200 samples
     # whatever --steps is

@@ -860,6 +860,10 @@ int fcp_plan_create_ex(const fcp_plan_desc_t *desc, const fcp_column_ext_t *ext,
   }
   p->csr_by_pos = desc->layout == FCP_LAYOUT_CONCAT && desc->n_groups == 1 && !p->has_inverse && !p->seg_cols.empty() &&
                   2 * p->seg_cols.size() >= p->cols.size();
+  // (a column that brings its row offsets in the blob reads them there: the kernel's regular-CSR shortcut serves every pooled /
+  // scatter column of the launch from ONE matrix, so a plan that mixes the two encodings keeps the packed scratch)
+  for (const HostColumn &hc : p->cols)
+    if ((hc.d.form == FCP_FORM_SEGMENT_REDUCE || hc.d.form == FCP_FORM_GATHER_SCATTER) && hc.d.seg_kind == FCP_SEG_CSR_I32) p->csr_by_pos = false;
   if (fcp::diag_ll("csr_by_pos", 1) == 0) p->csr_by_pos = false; // tuning aid: FCP_DIAG=csr_by_pos=0 = packed scratch (the round-5 layout)
   // The kernels park a table row as one 32-bit number (the three largest values are their sentinels): a table — or
   // one shard of it — may hold up to 2^32 - 3 ROWS, of any width: the byte offset is formed in 64 bits where the row

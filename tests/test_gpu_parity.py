@@ -162,7 +162,7 @@ def test_ragged_dynamic_shapes(torch_cuda, oracle, monkeypatch, seg, prepass):
         assert_equal_oracle(oracle, m.spec, packed, tabs, req.symbols, out)
 
 
-@pytest.mark.parametrize("layout", ["by_position", "packed", "blob_grouped", "blob_grouped_staged", "mixed_plan"])
+@pytest.mark.parametrize("layout", ["by_position", "packed", "blob_grouped", "blob_grouped_staged", "mixed_plan", "mixed_encodings"])
 def test_regular_csr_front_of_the_ragged_kernel(torch_cuda, oracle, monkeypatch, layout):
     """(r6) The ragged body asks for its row ranges TOGETHER with the column records when the CSR arrays are regular
     (FcpLaunch::csr_reg): the arena scratch laid out by column position and filled by the pre-pass (`by_position`; `packed` =
@@ -175,7 +175,16 @@ def test_regular_csr_front_of_the_ragged_kernel(torch_cuda, oracle, monkeypatch,
     monkeypatch.setenv("FCP_SEG_PREPASS", "1")                           # (64 columns x 255 rows would be searched in the blocks)
     if layout == "packed":
         monkeypatch.setenv("FCP_DIAG", "csr_by_pos=0")
-    if layout == "mixed_plan":
+    if layout == "mixed_encodings":
+        # two thirds of the pooled columns bring SparseTensor indices (pre-pass, scratch), one third CSR offsets in the blob:
+        # the shortcut serves a launch from ONE matrix, so such a plan keeps the packed scratch and every column reads its own
+        from recom_amd.plan import COMBINER_MEAN, COMBINER_SUM
+        b = synth._Builder()
+        for c in range(33):
+            synth._add_ragged(b, 3000, (8, 16, 32, 64)[c % 4], slot=c, combiner=COMBINER_SUM if c % 2 else COMBINER_MEAN,
+                              seg="indices" if c % 3 else "csr")
+        m = synth._finish("MIXENC", b, 255, n_symbols=1)
+    elif layout == "mixed_plan":
         m = synth.model_mixed(batch=255, vocab=997, n_groups=1)
     elif layout.startswith("blob_grouped"):
         base = synth.model_ragged(columns=64, vocab=5000, batch=255, seg="indices" if layout.endswith("staged") else "csr")
