@@ -840,11 +840,33 @@ def main():
         from recom_amd.shard import bench_row_sharded_record
         del h
         torch.cuda.empty_cache()
+        # The headline line must not depend on this extra.  An exception is caught (all ranks fail alike); a rank that never
+        # comes back from the exchange (RCCL with N > 1 ranks has not run on this pool: every box has one GPU) would take the
+        # whole line with it, so every rank arms a watchdog first: when it fires, rank 0 prints the finished headline with the
+        # reason under `sharded` and every rank leaves with status 0 (ctypes and torch release the GIL inside their calls)
+        import threading
+        limit_s = float(os.environ.get("FCP_BENCH_SHARDED_WATCHDOG_S", "240"))
+        line_lock, leg_done = threading.Lock(), []
+
+        def abandon():
+            with line_lock:
+                if leg_done:
+                    return
+                if rank == 0:
+                    rec["sharded"] = {"error": f"abandoned: no result within {limit_s:g} s (the replicated headline above is complete)"}
+                    print(json.dumps(rec), flush=True)
+                os._exit(0)
+        watchdog = threading.Timer(limit_s, abandon)
+        watchdog.daemon = True
+        watchdog.start()
         try:
             sharded = bench_row_sharded_record(args, rank, world, local_rank, dist,
                                                int(hbm_override) if hbm_override else device_hbm_bytes(local_rank))
-        except Exception as e:                       # the headline line must not depend on this extra (all ranks fail alike)
+        except Exception as e:
             sharded = {"error": f"{type(e).__name__}: {e}"[:400]}
+        with line_lock:                              # from here the line is this thread's to print
+            leg_done.append(True)
+            watchdog.cancel()
         if rank == 0:
             rec["sharded"] = sharded
         h = None

@@ -207,6 +207,27 @@ def test_bench_gpus_2_starts_its_ranks_and_prints_one_line(workload):
             assert "gate_choice" not in rec
 
 
+def test_bench_gpus_2_headline_survives_a_sharded_leg_that_never_returns():
+    """The `sharded` side record runs AFTER the replicated headline is measured; if its exchange never comes back (RCCL with
+    N > 1 ranks is unmeasured on this pool) the watchdog prints the finished headline with the reason and every rank exits 0.
+    Here the limit is 50 ms, far less than the leg needs, so the watchdog always fires."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["FCP_BENCH_DEVICE"] = "0"
+    env["FCP_BENCH_SHARD_COLUMNS"], env["FCP_BENCH_SHARD_VOCAB"] = "400", "3000"
+    env["FCP_BENCH_SHARDED_WATCHDOG_S"] = "0.05"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--steps", "20", "--warmup", "5",
+           "--no-cpu-baseline", "--no-pcie", "--no-overlap", "--columns", "48", "--vocab", "5000", "--batch", "64"]
+    res = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 20 and rec["value"] > 0 and rec["roofline"]["frac"] > 0
+    assert rec["sharded"]["error"].startswith("abandoned"), rec["sharded"]
+
+
 def build_fake_rccl():
     """tests/native/libfake_rccl.so: the test double for the RCCL entry points (tests/native/fake_rccl.cc)."""
     import subprocess
