@@ -856,19 +856,27 @@ def main():
                     rec["sharded"] = {"error": f"abandoned: no result within {limit_s:g} s (the replicated headline above is complete)"}
                     print(json.dumps(rec), flush=True)
                 os._exit(0)
-        watchdog = threading.Timer(limit_s, abandon)
+        # (rank 0 gives up first: a peer that left earlier would only turn its wait into a "connection closed" error)
+        watchdog = threading.Timer(limit_s + (0.0 if rank == 0 else 3.0), abandon)
         watchdog.daemon = True
         watchdog.start()
+        leg_failed = False
         try:
             sharded = bench_row_sharded_record(args, rank, world, local_rank, dist,
                                                int(hbm_override) if hbm_override else device_hbm_bytes(local_rank))
         except Exception as e:
-            sharded = {"error": f"{type(e).__name__}: {e}"[:400]}
+            sharded, leg_failed = {"error": f"{type(e).__name__}: {e}"[:400]}, True
         with line_lock:                              # from here the line is this thread's to print
             leg_done.append(True)
             watchdog.cancel()
         if rank == 0:
             rec["sharded"] = sharded
+        if leg_failed:
+            # the process group is suspect (a peer may be gone or stuck in the exchange): no further collective, no
+            # destroy_process_group — the line (rank 0) and out
+            if rank == 0:
+                print(json.dumps(rec), flush=True)
+            os._exit(0)
         h = None
     if rank == 0:
         if args.workload == "s2" and world == 1 and args.ids == "uniform" and not args.no_pcie and not args.no_cpu_baseline and not args.batch and not args.columns:

