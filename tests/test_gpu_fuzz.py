@@ -46,10 +46,13 @@ def random_values(rng, n, bnd):
     return v
 
 
-def random_model(rng, dense_only=False, extended=True):
-    """Returns (spec, tables, make_inputs(batch per group) -> (inputs, symbols))."""
+def random_model(rng, dense_only=False, extended=True, n_groups_fixed=None, forms_fixed=None, segs_fixed=None):
+    """Returns (spec, tables, make_inputs(batch per group) -> (inputs, symbols)).  The `_fixed` arguments narrow the draw
+    (the regular-row-offsets fuzz below); the default draw is unchanged by them."""
     vec = int(rng.choice([4, 4, 4, 2, 1]))
     n_groups = int(rng.integers(1, 4))
+    if n_groups_fixed:
+        n_groups = n_groups_fixed
     n_cols = int(rng.integers(1, 40)) if rng.random() > 0.12 else int(rng.integers(100, 400))   # some plans span dozens of 64-slot spans
     cols, ranks, esz, tables, gens = [], [], [], [], []
     extra_syms = []                      # symbols beyond the groups' row counts: per-request factors of segment-id maps
@@ -67,6 +70,8 @@ def random_model(rng, dense_only=False, extended=True):
         forms = [FORM_GATHER, FORM_PASSTHROUGH] if dense_only else \
             [FORM_GATHER, FORM_SEGMENT_REDUCE, FORM_SEGMENT_REDUCE, FORM_GATHER_SCATTER, FORM_PASSTHROUGH,
              FORM_BATCH_COL_REDUCTION]
+        if forms_fixed:
+            forms = list(forms_fixed)
         form = int(rng.choice(forms))
         slot = slots[g]
         slots[g] += 1
@@ -121,7 +126,7 @@ def random_model(rng, dense_only=False, extended=True):
             gens.append((g, lambda r, B, d=draw_ids: [d(r, B)]))
             cols.append(ColumnSpec(form, dim, vocab, COMBINER_NONE, src, t, i, -1, SEG_NONE, 1, ROWS_FROM_IDS, 0, bnd, g, slot, **xf))
             continue
-        seg = str(rng.choice(["csr", "indices", "rowids32"]))
+        seg = str(rng.choice(list(segs_fixed) if segs_fixed else ["csr", "indices", "rowids32"]))
         # ScatterNd columns: mostly at most one id per row, sometimes rows hit several times (the last write wins); with
         # row ids (not offsets) the pairs arrive in any order and some rows lie outside the output
         max_len = int(rng.choice([1, 1, 3])) if form == FORM_GATHER_SCATTER else int(rng.choice([0, 1, 3, 10, 10, 70, 200, 500]))
@@ -376,6 +381,64 @@ def test_sixteen_concat_groups_with_their_own_batches(oracle):
         for g, w in enumerate(want):
             got = out.groups[g].cpu().numpy()
             assert got.shape == w.shape and np.array_equal(got, w), (trial, g)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FCP_FUZZ_SEED0", "0")),
+                                        int(os.environ.get("FCP_FUZZ_SEED0", "0")) + int(os.environ.get("FCP_FUZZ_REGULAR_SEEDS", "9"))))
+def test_random_one_group_pooled_plans_with_regular_row_offsets(oracle, monkeypatch, seed):
+    """(r6) The shapes of plan the ragged kernel's regular-row-offsets front serves (FcpLaunch::csr_reg, `find_regular_csr`),
+    drawn at random — the general fuzz above seldom draws them (one concat group AND no pooled column with CSR offsets of its
+    own).  seed % 3 == 0: mostly pooled columns over SparseTensor indices / sorted row ids with the pre-pass forced: the arena
+    scratch is laid out by column position (mode 1), gathers and table-free columns in between.  == 1: every column pooled or
+    scattered over CSR offsets packed the plain way: the arrays lie at irregular distances, which the per-request check must
+    refuse.  == 2: every column pooled over indices / row ids and STAGED (fcp_stager_stage_ex: ids narrowed, row ids -> one
+    [columns, rows + 1] matrix of offsets behind the copied inputs): mode 2.  Bit-exact against the oracle on the original
+    request; batches that are not multiples of the block's rows, empty bags, 1-row batches, new shapes every request."""
+    import torch
+    from recom_amd.ops import FeatureColumnProcess, RequestStager, concat_inputs
+    kind = seed % 3
+    rng = np.random.default_rng(11000 + seed)
+    monkeypatch.setenv("FCP_SEG_PREPASS", "1")
+    if kind == 0:
+        spec, tables, make = random_model(rng, n_groups_fixed=1, segs_fixed=("indices", "rowids32"),
+                                          forms_fixed=(FORM_SEGMENT_REDUCE, FORM_SEGMENT_REDUCE, FORM_SEGMENT_REDUCE, FORM_GATHER,
+                                                       FORM_GATHER_SCATTER, FORM_PASSTHROUGH))
+    elif kind == 1:
+        spec, tables, make = random_model(rng, n_groups_fixed=1, segs_fixed=("csr",),
+                                          forms_fixed=(FORM_SEGMENT_REDUCE, FORM_SEGMENT_REDUCE, FORM_GATHER_SCATTER))
+    else:
+        spec, tables, make = random_model(rng, extended=False, n_groups_fixed=1, segs_fixed=("indices", "rowids32"),
+                                          forms_fixed=(FORM_SEGMENT_REDUCE,))
+    dev = torch.device("cuda", 0)
+    d_tabs = [torch.from_numpy(t).to(dev) for t in tables]
+    st = None
+    if kind == 2:
+        sspec, modes, rows_col = spec.staged()
+        assert all(m == 2 for i, m in enumerate(modes) if any(c.seg_input == i for c in spec.columns))   # every row-id input is converted
+        op = FeatureColumnProcess(sspec, 0)
+        st = RequestStager(64 << 20, max(spec.n_host_inputs, 1), max(sum(spec.host_input_ranks), 1), depth=3, n_threads=4)
+    else:
+        op = FeatureColumnProcess(spec, 0)
+    for trial in range(5):
+        batches = [int(rng.choice([1, 2, 3, 5, 33, 64, 130, 255, 257]))]
+        inputs, symbols = make(rng, batches)
+        packed = concat_inputs(inputs)
+        if kind == 2:
+            rows = [int(symbols[spec.columns[k].rows_arg]) if k >= 0 else 0 for k in rows_col]
+            d_ptr, nbytes, offs, shps = st.stage_ex(inputs, modes, rows)
+            seg_in = [c.seg_input for c in sorted(sspec.columns, key=lambda c: c.concat_slot)]
+            assert len({int(offs[b]) - int(offs[a]) for a, b in zip(seg_in, seg_in[1:])}) <= 1      # one stride apart, in column order?
+            out = op(_RawBlob(d_ptr, nbytes), offs, shps, d_tabs, symbols)
+        else:
+            blob, offsets, shapes = packed
+            d_blob = torch.from_numpy(blob).to(dev) if blob.size else torch.empty(0, dtype=torch.int8, device=dev)
+            out = op(d_blob, offsets, shapes, d_tabs, symbols)
+        torch.cuda.synchronize()
+        want, _ = oracle.process_feature_columns(spec.to_dict(), *packed, tables, symbols)
+        got = out.groups[0].cpu().numpy()
+        assert got.shape == want[0].shape and np.array_equal(got, want[0]), (seed, kind, trial)
+    if st is not None:
+        st.close()
 
 
 class _RawBlob:
