@@ -54,6 +54,18 @@ void *ring_alloc(void *ctx, size_t bytes) {
     }                                                                                  \
   } while (0)
 
+// the calling thread on the harness' device for the length of a call (kernels launched here, events, hipMalloc)
+struct OnDevice {
+  int prev = -1;
+  explicit OnDevice(int dev) {
+    int cur = -1;
+    if (hipGetDevice(&cur) == hipSuccess && cur != dev && hipSetDevice(dev) == hipSuccess) prev = cur;
+  }
+  ~OnDevice() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
 } // namespace
 
 struct fcp_harness {
@@ -64,6 +76,8 @@ struct fcp_harness {
   std::vector<int> status;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   long issued = 0; // requests issued so far per worker (variant rotation)
+  int device = 0;  // the device the streams and arenas were created on: a new host thread starts on device 0, so every
+                   // worker thread selects it first (rank r of a multi-GPU node serves device r)
 
   void issue(int t, long begin, int count) {
     const int nv = (int)variants.size();
@@ -102,6 +116,7 @@ int fcp_harness_create(fcp_plan_t *plan, const fcp_process_args_t *variants, int
   }
   fcp_harness *h = new fcp_harness();
   h->plan = plan;
+  H_TRY(hipGetDevice(&h->device));
   h->variants.assign(variants, variants + n_variants);
   h->rings.resize(n_threads);
   h->streams.resize(n_threads);
@@ -130,6 +145,7 @@ int fcp_harness_create(fcp_plan_t *plan, const fcp_process_args_t *variants, int
 //             a separate call for latency percentiles).
 int fcp_harness_run(fcp_harness *h, int steps, double *wall_ms, float *dev_ms, float *iter_ms) {
   if (!h || steps < 1) return FCP_ERR_INVALID_ARGUMENT;
+  OnDevice on(h->device);
   const int n_threads = (int)h->streams.size();
   const long begin = h->issued;
   std::vector<hipEvent_t> ev;
@@ -140,7 +156,10 @@ int fcp_harness_run(fcp_harness *h, int steps, double *wall_ms, float *dev_ms, f
   const auto t0 = std::chrono::steady_clock::now();
   H_TRY(hipEventRecord(h->e0, h->streams[0]));
   std::vector<std::thread> workers;
-  for (int t = 1; t < n_threads; ++t) workers.emplace_back([h, t, begin, steps] { h->issue(t, begin, steps); });
+  for (int t = 1; t < n_threads; ++t) workers.emplace_back([h, t, begin, steps] {
+      (void)hipSetDevice(h->device);
+      h->issue(t, begin, steps);
+    });
   hipError_t worker0 = hipSuccess; // no early return while the other workers run: a joinable std::thread must be joined
   if (iter_ms) {
     for (int k = 0; k < steps && worker0 == hipSuccess; ++k) {
@@ -177,6 +196,7 @@ int fcp_harness_run(fcp_harness *h, int steps, double *wall_ms, float *dev_ms, f
 // models (one-hot columns: S2, DLRM); a request with new shapes needs a new capture.
 int fcp_harness_run_graph(fcp_harness *h, int steps, int group, double *wall_ms, float *dev_ms) {
   if (!h || group < 1 || steps < group || steps % group) return FCP_ERR_INVALID_ARGUMENT;
+  OnDevice on(h->device);
   hipStream_t s = h->streams[0];
   h->issue(0, 0, group); // descriptors of the captured variants are now resident
   H_TRY(hipStreamSynchronize(s));
@@ -227,6 +247,7 @@ __global__ void fcp_consume_probe_kernel(const float *arena, size_t n_floats, fl
 int fcp_harness_run_private_threads(fcp_harness *h, int steps, int depth, int threads, double *wall_ms, float *dev_ms) {
   if (!h || steps < 1 || depth < 1 || threads < 1 || threads > (int)h->rings.size() || depth > (int)h->rings[0].bufs.size())
     return FCP_ERR_INVALID_ARGUMENT;
+  OnDevice on(h->device);
   hipStream_t caller = h->streams[0];
   static float *sink = nullptr;
   if (!sink) H_TRY(hipMalloc(&sink, sizeof(float)));
@@ -289,7 +310,10 @@ int fcp_harness_run_private_threads(fcp_harness *h, int steps, int depth, int th
   H_TRY(hipEventRecord(h->e0, caller));
   std::vector<int> rcs((size_t)threads, FCP_OK);
   std::vector<std::thread> workers;
-  for (int t = 1; t < threads; ++t) workers.emplace_back([&, t] { rcs[(size_t)t] = serve(t); });
+  for (int t = 1; t < threads; ++t) workers.emplace_back([&, t] {
+      (void)hipSetDevice(h->device);
+      rcs[(size_t)t] = serve(t);
+    });
   rcs[0] = serve(0);
   for (auto &w : workers) w.join();
   for (int rc : rcs)
@@ -313,6 +337,7 @@ void *fcp_harness_stream(fcp_harness *h, int t) { return (h && t >= 0 && t < (in
 
 int fcp_harness_destroy(fcp_harness *h) {
   if (!h) return FCP_OK;
+  OnDevice on(h->device);
   for (size_t t = 0; t < h->streams.size(); ++t) {
     (void)hipStreamSynchronize(h->streams[t]);
     for (void *p : h->rings[t].bufs) (void)hipFree(p);

@@ -90,8 +90,9 @@ class ServingHarness:
         self._args = args
         handle = C.c_void_p()
         torch.cuda.synchronize()
-        _lib.check(self.H.fcp_harness_create(self.plan.handle, args, n_requests, arena_ring, n_threads,
-                                             C.byref(handle)), "fcp_harness_create")
+        with torch.cuda.device(self.dev):        # the native harness creates its streams and arenas on the CURRENT device
+            _lib.check(self.H.fcp_harness_create(self.plan.handle, args, n_requests, arena_ring, n_threads,
+                                                 C.byref(handle)), "fcp_harness_create")
         self.handle = handle
         self.n_threads = n_threads
 
