@@ -845,6 +845,7 @@ def main():
         # whole line with it, so every rank arms a watchdog first: when it fires, rank 0 prints the finished headline with the
         # reason under `sharded` and every rank leaves with status 0 (ctypes and torch release the GIL inside their calls)
         import threading
+        dist.barrier()                               # rank 0 arrives later (its side records): every rank's clock starts here
         limit_s = float(os.environ.get("FCP_BENCH_SHARDED_WATCHDOG_S", "240"))
         line_lock, leg_done = threading.Lock(), []
 
