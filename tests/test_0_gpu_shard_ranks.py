@@ -491,23 +491,3 @@ def test_bench_gpus_8_row_sharded_at_configs4_shape():
     assert rec["config"]["columns"] == 4000 and rec["config"]["batch"] == 512
     assert "row-sharded x8" in rec["config"]["parallelism"]
     assert rec["config"]["exchange_bytes_sent_per_rank_per_request"] == 7 * (512 // 8) * 120_000 * 4
-
-
-def test_native_sharded_step_over_rccl_two_gpus():
-    """the native RCCL step (grouped send / recv layout, batch-slice order against fcp_shard_finalize, ring
-    reuse) with world = 2 on two GPUs, both modes, against the unsharded oracle.  Needs 2 GPUs (skipped on the 1-GPU
-    boxes of this pool; `torch.cuda.device_count()` does not initialise the GPU in the parent)."""
-    import torch
-    if torch.cuda.device_count() < 2:
-        pytest.skip("needs 2 GPUs")
-    ctx = multiprocessing.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_rccl_rank_main, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    results = [q.get(timeout=600) for _ in procs]
-    for p in procs:
-        p.join(timeout=60)
-    for rank, status in results:
-        assert status == "ok", f"rank {rank}:\n{status}"
