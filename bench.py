@@ -451,6 +451,8 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
+    # dmabuf IPC: RCCL across processes needs it on this driver (the pool exports it; a launcher's environment may not)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     from recom_amd import synth
     from recom_amd.harness import ServingHarness, copy_probe
