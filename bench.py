@@ -203,6 +203,11 @@ def host_staging_cost(raw_model, n_requests: int = 8):
             "inputs": n}
 
 
+def side_error(e: BaseException) -> str:
+    """What a failed SIDE record says in its place (the line's contract fields never depend on a side record)."""
+    return f"{type(e).__name__}: {e}"[:400]
+
+
 def cpu_baseline(model, budget_s: float = 20.0, sample_columns: int = 0):
     """The CPU oracle (oracle/: a C port of the TF-CPU semantics of the reference's path; TensorFlow is absent) on this
     box's host cores: the WHOLE workload when its tables fit host memory (S2: 120 GB; `sampled: false`), else the first k
@@ -609,13 +614,16 @@ def main():
                                "picks the store policy from the arena's reuse (profiles/r06_arena_reuse_store_policy.txt)",
                        "value_used_ring": args.arena_ring}
         ar_steps = max(args.steps, 800)
-        for ring in (1, 2, 6):
-            ha = ServingHarness(model, device=local_rank, n_requests=args.requests, arena_ring=ring, n_threads=1, tables=h.tables,
-                                seed0=1000 * rank)
-            ha.run(max(args.warmup, 200))
-            _, a_dev, _ = ha.run(ar_steps)
-            arena_reuse[f"ring_{ring}_us"] = a_dev * 1e3 / ar_steps
-            ha.close()
+        try:                                         # (side records never cost the line: a failure is reported in their place)
+            for ring in (1, 2, 6):
+                ha = ServingHarness(model, device=local_rank, n_requests=args.requests, arena_ring=ring, n_threads=1, tables=h.tables,
+                                    seed0=1000 * rank)
+                ha.run(max(args.warmup, 200))
+                _, a_dev, _ = ha.run(ar_steps)
+                arena_reuse[f"ring_{ring}_us"] = a_dev * 1e3 / ar_steps
+                ha.close()
+        except Exception as e:
+            arena_reuse["error"] = side_error(e)
     # overlapped serving (the reference harness' serve_workers): independent requests on
     # 3 streams hide each launch's ramp / tail behind its neighbours.  Extra field only.
     overlap = None
@@ -626,108 +634,114 @@ def main():
         # best depends on how the process' streams fall on the GPU's hardware queues, so 2, 3 and 4 are measured
         # and all three reported.
         sweep = {}
-        for workers in (2, 3, 4):
-            hw = ServingHarness(model, device=local_rank, n_requests=args.requests, arena_ring=args.arena_ring, n_threads=workers,
-                                tables=h.tables, seed0=1000 * rank)
-            ov_warm, ov_steps = max(args.warmup // workers, 50), max(args.steps // workers, 400)
-            hw.run(ov_warm)
-            w_ms, _, _ = hw.run(ov_steps)
-            sweep[workers] = {"requests_per_worker": ov_steps, "warmup_per_worker": ov_warm,
-                              "us_per_request": w_ms * 1e3 / (workers * ov_steps)}
-            hw.close()
-        best = min(sweep, key=lambda k: sweep[k]["us_per_request"])
-        overlap = {"serve_workers": best, **sweep[best],
-                   "sweep_us_per_request": {str(k): v["us_per_request"] for k, v in sweep.items()},
-                   "env": {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")}}
+        try:
+            for workers in (2, 3, 4):
+                hw = ServingHarness(model, device=local_rank, n_requests=args.requests, arena_ring=args.arena_ring, n_threads=workers,
+                                    tables=h.tables, seed0=1000 * rank)
+                ov_warm, ov_steps = max(args.warmup // workers, 50), max(args.steps // workers, 400)
+                hw.run(ov_warm)
+                w_ms, _, _ = hw.run(ov_steps)
+                sweep[workers] = {"requests_per_worker": ov_steps, "warmup_per_worker": ov_warm,
+                                  "us_per_request": w_ms * 1e3 / (workers * ov_steps)}
+                hw.close()
+            best = min(sweep, key=lambda k: sweep[k]["us_per_request"])
+            overlap = {"serve_workers": best, **sweep[best],
+                       "sweep_us_per_request": {str(k): v["us_per_request"] for k, v in sweep.items()},
+                       "env": {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")}}
+        except Exception as e:
+            overlap = {"error": side_error(e)}
     # The same overlap behind ONE caller stream and ONE host thread — what the TensorFlow op has: the plan's private
     # streams (fcp_plan_set_private_streams), the consumer of each request (fcp_result_wait + a reader kernel on the
     # caller's stream, standing for Addons>ConcatOutputs) enqueued `lanes - 1` requests behind it.  Extra field only.
     single_caller = None
     if args.threads == 1 and not dist and not args.no_overlap:
-        sweep = {}
-        sc_warm, sc_steps = max(args.warmup, 100), max(args.steps, 1200)
-        # the figure every private-stream number has to beat: the SAME loop — same consumer kernel behind every request —
-        # with the requests in stream order on the caller's stream (private streams off)
-        hs = ServingHarness(model, device=local_rank, n_requests=args.requests, arena_ring=max(args.arena_ring, 3), n_threads=1, tables=h.tables,
-                            seed0=1000 * rank)
-        hs.run_private(sc_warm, 3)
-        so_ms, so_dev = hs.run_private(sc_steps, 3)
-        stream_order_consumer = {"us_per_request": so_ms * 1e3 / sc_steps, "device_us_per_request": so_dev * 1e3 / sc_steps}
-        hs.close()
-        for lanes in (2, 3):                         # the library creates at most three (more were slower than one)
-            hp = ServingHarness(model, device=local_rank, n_requests=args.requests, arena_ring=max(args.arena_ring, 3), n_threads=1,
-                                tables=h.tables, seed0=1000 * rank)
-            hp.plan.set_private_streams(lanes)
-            hp.run(1)
-            t_v = time.perf_counter()
-            hp.plan.verify_private_streams(hp.caller_stream(), 400)   # ... and the verification, as the shim's first Compute runs it
-            verify_ms = (time.perf_counter() - t_v) * 1e3
-            hp.run_private(sc_warm, lanes)
-            w_ms, d_ms = hp.run_private(sc_steps, lanes)
-            sweep[lanes] = {"requests": sc_steps, "warmup": sc_warm, "us_per_request": w_ms * 1e3 / sc_steps,
-                            "device_us_per_request": d_ms * 1e3 / sc_steps, "verify_at_warmup_ms": verify_ms,
-                            # 1: the library found its streams to overlap behind this caller stream and used them; 0: it did not
-                            # and kept the requests on the caller's stream; -1: never asked (requests below the work threshold)
-                            "verified_overlap": hp.plan.private_streams_verdict(hp.caller_stream()),
-                            "supervisor": {k: v for k, v in hp.plan.private_streams_stats().items() if k != "supervised_stream"}}
-            hp.close()
-        # The reference's real protocol: `serve_workers` host threads share ONE Session, hence one compute stream
-        # (recom_examples.patch:193-216): T threads issue on the one caller stream over the 3 private streams, every thread
-        # enqueues the consumer of its request `depth - 1` of its own requests later.  depth 1 = FeatureColumnProcess and
-        # Addons>ConcatOutputs back to back inside one Session::Run (what the rewritten graph does); depth 3 = a graph that
-        # runs other work of the same thread between the two.  Every figure next to the same threads in stream order.
-        threads_sweep = {}
-        for T in (1, 2, 4):
-            for depth in (1, 3):
-                ht = ServingHarness(model, device=local_rank, n_requests=args.requests, arena_ring=max(args.arena_ring, 3), n_threads=T, tables=h.tables,
-                                    seed0=1000 * rank)
-                per = max(sc_steps // T, 300)
-                ht.run_private(max(sc_warm // T, 50), depth, T)      # private streams off: stream order + the same consumers
-                b_ms, _ = ht.run_private(per, depth, T)
-                ht.plan.set_private_streams(3)
-                ht.run(1)
-                ht.plan.verify_private_streams(ht.caller_stream(), 400)
-                ht.run_private(max(1400 // T, 50), depth, T)         # (long enough for three evaluations of the supervisor)
-                w_ms, d_ms = ht.run_private(per, depth, T)
-                st = ht.plan.private_streams_stats()
-                threads_sweep[f"threads_{T}_depth_{depth}"] = {
-                    "private_streams_us": w_ms * 1e3 / (per * T), "stream_order_same_consumer_us": b_ms * 1e3 / (per * T),
-                    "verdict_at_the_end": ht.plan.private_streams_verdict(ht.caller_stream()), "supervisor_demoted": st["demoted"],
-                    "supervisor_last_ratio": st["last_ratio"], "supervisor_evaluations": st["evaluations"], "requests_per_thread": per}
-                ht.close()
-        # and the cheap variant for callers that own their buffers (this harness does): FCP_ORDER_INPUTS_READY — the same K
-        # requests back to back on the one stream, the fused kernel launched without the queue's barrier bit
-        hr = ServingHarness(model, device=local_rank, n_requests=args.requests, arena_ring=args.arena_ring, n_threads=1, tables=h.tables,
-                            seed0=1000 * rank)
-        hr.plan.set_inputs_ready(True)
-        hr.run(max(args.warmup, 100))
-        r_ms, r_dev, _ = hr.run(max(args.steps, 1200))
-        inputs_ready = {"us_per_request": r_ms * 1e3 / max(args.steps, 1200), "device_us_per_request": r_dev * 1e3 / max(args.steps, 1200),
-                        "what": "fcp_plan_set_request_order(FCP_ORDER_INPUTS_READY): requests back to back on ONE stream, no events, no "
-                                "extra streams; the fused kernel may begin under the previous request's tail (any-order launch)"}
-        hr.close()
-        best = min(sweep, key=lambda k: sweep[k]["us_per_request"])
-        single_caller = {"what": "one host thread, one caller stream (the TF op's situation): requests run on the plan's private "
-                                 "streams, the consumer of request k (fcp_result_wait + a reader kernel on the caller's stream) is "
-                                 "enqueued `private_streams - 1` requests later; host wall clock over the loop incl. the final sync.  The "
-                                 "library verified on the first request that its private streams overlap behind this caller stream (or searched a "
-                                 "hardware-queue mapping that does; profiles/r04_private_streams_queue_mapping.txt)",
-                         "private_streams": best, **sweep[best],
-                         "stream_order_same_consumer": {**stream_order_consumer,
-                                                        "what": "the same loop with private streams OFF: requests in stream order on the caller's "
-                                                                "stream, the same consumer kernel behind each — the figure the private-stream number "
-                                                                "has to beat (the plain `value` loop has no consumer)"},
-                         "host_threads_sweep": {"what": "T host threads issuing on the ONE caller stream (the reference's serve_workers share one "
-                                                        "Session = one compute stream, recom_examples.patch:193-216), 3 private streams; depth 1 = the "
-                                                        "consumer right behind its request (FeatureColumnProcess -> Addons>ConcatOutputs inside one "
-                                                        "Session::Run), depth 3 = two more requests of the thread in between; us per request over all "
-                                                        "threads, next to the same threads in stream order.  The supervisor A/Bs the two modes while "
-                                                        "serving (48 requests each, at request 1, ~360, ~970, ...): a caller for whom the private streams lose "
-                                                        "(ratio > 0.97 twice) is demoted and finishes in stream order",
-                                                **threads_sweep},
-                         "sweep_us_per_request": {str(k): v["us_per_request"] for k, v in sweep.items()},
-                         "sweep_verified_overlap": {str(k): v["verified_overlap"] for k, v in sweep.items()},
-                         "inputs_ready_back_to_back": inputs_ready}
+        try:
+            sweep = {}
+            sc_warm, sc_steps = max(args.warmup, 100), max(args.steps, 1200)
+            # the figure every private-stream number has to beat: the SAME loop — same consumer kernel behind every request —
+            # with the requests in stream order on the caller's stream (private streams off)
+            hs = ServingHarness(model, device=local_rank, n_requests=args.requests, arena_ring=max(args.arena_ring, 3), n_threads=1, tables=h.tables,
+                                seed0=1000 * rank)
+            hs.run_private(sc_warm, 3)
+            so_ms, so_dev = hs.run_private(sc_steps, 3)
+            stream_order_consumer = {"us_per_request": so_ms * 1e3 / sc_steps, "device_us_per_request": so_dev * 1e3 / sc_steps}
+            hs.close()
+            for lanes in (2, 3):                         # the library creates at most three (more were slower than one)
+                hp = ServingHarness(model, device=local_rank, n_requests=args.requests, arena_ring=max(args.arena_ring, 3), n_threads=1,
+                                    tables=h.tables, seed0=1000 * rank)
+                hp.plan.set_private_streams(lanes)
+                hp.run(1)
+                t_v = time.perf_counter()
+                hp.plan.verify_private_streams(hp.caller_stream(), 400)   # ... and the verification, as the shim's first Compute runs it
+                verify_ms = (time.perf_counter() - t_v) * 1e3
+                hp.run_private(sc_warm, lanes)
+                w_ms, d_ms = hp.run_private(sc_steps, lanes)
+                sweep[lanes] = {"requests": sc_steps, "warmup": sc_warm, "us_per_request": w_ms * 1e3 / sc_steps,
+                                "device_us_per_request": d_ms * 1e3 / sc_steps, "verify_at_warmup_ms": verify_ms,
+                                # 1: the library found its streams to overlap behind this caller stream and used them; 0: it did not
+                                # and kept the requests on the caller's stream; -1: never asked (requests below the work threshold)
+                                "verified_overlap": hp.plan.private_streams_verdict(hp.caller_stream()),
+                                "supervisor": {k: v for k, v in hp.plan.private_streams_stats().items() if k != "supervised_stream"}}
+                hp.close()
+            # The reference's real protocol: `serve_workers` host threads share ONE Session, hence one compute stream
+            # (recom_examples.patch:193-216): T threads issue on the one caller stream over the 3 private streams, every thread
+            # enqueues the consumer of its request `depth - 1` of its own requests later.  depth 1 = FeatureColumnProcess and
+            # Addons>ConcatOutputs back to back inside one Session::Run (what the rewritten graph does); depth 3 = a graph that
+            # runs other work of the same thread between the two.  Every figure next to the same threads in stream order.
+            threads_sweep = {}
+            for T in (1, 2, 4):
+                for depth in (1, 3):
+                    ht = ServingHarness(model, device=local_rank, n_requests=args.requests, arena_ring=max(args.arena_ring, 3), n_threads=T, tables=h.tables,
+                                        seed0=1000 * rank)
+                    per = max(sc_steps // T, 300)
+                    ht.run_private(max(sc_warm // T, 50), depth, T)      # private streams off: stream order + the same consumers
+                    b_ms, _ = ht.run_private(per, depth, T)
+                    ht.plan.set_private_streams(3)
+                    ht.run(1)
+                    ht.plan.verify_private_streams(ht.caller_stream(), 400)
+                    ht.run_private(max(1400 // T, 50), depth, T)         # (long enough for three evaluations of the supervisor)
+                    w_ms, d_ms = ht.run_private(per, depth, T)
+                    st = ht.plan.private_streams_stats()
+                    threads_sweep[f"threads_{T}_depth_{depth}"] = {
+                        "private_streams_us": w_ms * 1e3 / (per * T), "stream_order_same_consumer_us": b_ms * 1e3 / (per * T),
+                        "verdict_at_the_end": ht.plan.private_streams_verdict(ht.caller_stream()), "supervisor_demoted": st["demoted"],
+                        "supervisor_last_ratio": st["last_ratio"], "supervisor_evaluations": st["evaluations"], "requests_per_thread": per}
+                    ht.close()
+            # and the cheap variant for callers that own their buffers (this harness does): FCP_ORDER_INPUTS_READY — the same K
+            # requests back to back on the one stream, the fused kernel launched without the queue's barrier bit
+            hr = ServingHarness(model, device=local_rank, n_requests=args.requests, arena_ring=args.arena_ring, n_threads=1, tables=h.tables,
+                                seed0=1000 * rank)
+            hr.plan.set_inputs_ready(True)
+            hr.run(max(args.warmup, 100))
+            r_ms, r_dev, _ = hr.run(max(args.steps, 1200))
+            inputs_ready = {"us_per_request": r_ms * 1e3 / max(args.steps, 1200), "device_us_per_request": r_dev * 1e3 / max(args.steps, 1200),
+                            "what": "fcp_plan_set_request_order(FCP_ORDER_INPUTS_READY): requests back to back on ONE stream, no events, no "
+                                    "extra streams; the fused kernel may begin under the previous request's tail (any-order launch)"}
+            hr.close()
+            best = min(sweep, key=lambda k: sweep[k]["us_per_request"])
+            single_caller = {"what": "one host thread, one caller stream (the TF op's situation): requests run on the plan's private "
+                                     "streams, the consumer of request k (fcp_result_wait + a reader kernel on the caller's stream) is "
+                                     "enqueued `private_streams - 1` requests later; host wall clock over the loop incl. the final sync.  The "
+                                     "library verified on the first request that its private streams overlap behind this caller stream (or searched a "
+                                     "hardware-queue mapping that does; profiles/r04_private_streams_queue_mapping.txt)",
+                             "private_streams": best, **sweep[best],
+                             "stream_order_same_consumer": {**stream_order_consumer,
+                                                            "what": "the same loop with private streams OFF: requests in stream order on the caller's "
+                                                                    "stream, the same consumer kernel behind each — the figure the private-stream number "
+                                                                    "has to beat (the plain `value` loop has no consumer)"},
+                             "host_threads_sweep": {"what": "T host threads issuing on the ONE caller stream (the reference's serve_workers share one "
+                                                            "Session = one compute stream, recom_examples.patch:193-216), 3 private streams; depth 1 = the "
+                                                            "consumer right behind its request (FeatureColumnProcess -> Addons>ConcatOutputs inside one "
+                                                            "Session::Run), depth 3 = two more requests of the thread in between; us per request over all "
+                                                            "threads, next to the same threads in stream order.  The supervisor A/Bs the two modes while "
+                                                            "serving (48 requests each, at request 1, ~360, ~970, ...): a caller for whom the private streams lose "
+                                                            "(ratio > 0.97 twice) is demoted and finishes in stream order",
+                                                    **threads_sweep},
+                             "sweep_us_per_request": {str(k): v["us_per_request"] for k, v in sweep.items()},
+                             "sweep_verified_overlap": {str(k): v["verified_overlap"] for k, v in sweep.items()},
+                             "inputs_ready_back_to_back": inputs_ready}
+        except Exception as e:
+            single_caller = {"error": side_error(e)}
     batch = model.batch
     steps_total = args.steps * args.threads
     ms_per_step = elapsed * 1e3 / steps_total
@@ -777,12 +791,17 @@ def main():
             "kernel_avg_us": dev_ms_per_req * 1e3,
             "algorithmic_bytes_per_request": bytes_alg,
             "read_only_frac": bytes_alg["read"] / (dev_ms_per_req * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "measured_copy_peak_GBs": copy_probe() / 1e9,
         }
-        rec["roofline"]["access_mix"] = access_mix_floor(model, h, bytes_alg, dev_ms_per_req * 1e3)
+        try:
+            rec["roofline"]["measured_copy_peak_GBs"] = copy_probe() / 1e9
+            rec["roofline"]["access_mix"] = access_mix_floor(model, h, bytes_alg, dev_ms_per_req * 1e3)
+        except Exception as e:
+            rec["roofline"]["access_mix"] = {"error": side_error(e)}
         if arena_reuse:
             rec["arena_reuse"] = arena_reuse
-        if overlap:
+        if overlap and "error" in overlap:
+            rec["overlapped_serving"] = overlap
+        elif overlap:
             overlap["inferences_per_s"] = batch / (overlap["us_per_request"] * 1e-6)
             overlap["aggregate_frac_of_peak"] = bytes_alg["total"] / (overlap["us_per_request"] * 1e-6) / 1e9 / HBM_PEAK_GBS
             rec["overlapped_serving"] = overlap
@@ -792,7 +811,9 @@ def main():
                                      "examples/cc/recom_examples.patch:193-225 - is overlapped_serving.inferences_per_s "
                                      f"({overlap['inferences_per_s'] / 1e6:.1f} M with {overlap['serve_workers']} workers), next to the single-request "
                                      "p50 above")
-        if single_caller:
+        if single_caller and "error" in single_caller:
+            rec["single_caller_stream"] = single_caller
+        elif single_caller:
             single_caller["inferences_per_s"] = batch / (single_caller["us_per_request"] * 1e-6)
             single_caller["frac_of_peak"] = bytes_alg["total"] / (single_caller["us_per_request"] * 1e-6) / 1e9 / HBM_PEAK_GBS
             single_caller["inputs_ready_back_to_back"]["frac_of_peak"] = (
@@ -833,7 +854,11 @@ def main():
         if args.staged and "FCP_LIB_DIR" not in os.environ:
             rec["staging"] = host_staging_cost(raw_model)
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
-            rec["cpu_baseline"] = cpu_baseline(model)
+            try:
+                rec["cpu_baseline"] = cpu_baseline(model)
+            except Exception as e:                   # (e.g. a host that cannot hold the tables and cannot even sample them)
+                rec["cpu_baseline"] = {"value": None, "unit": "inferences/s", "cores": 0, "kind": "port", "sample": "failed",
+                                       "error": side_error(e)}
     h.close()
     if world > 1 and args.workload == "s2" and not os.environ.get("FCP_BENCH_NO_SHARDED_RECORD"):
         # The default multi-GPU line is replicas (S2's 120 GB fit one GPU: no collective); so that a scaling run on a multi-GPU
